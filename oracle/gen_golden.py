@@ -1,0 +1,171 @@
+"""Generate golden vectors from the *imported reference* (build container only).
+
+TEST INFRASTRUCTURE.  Run here (``python oracle/gen_golden.py``) where
+``/root/reference`` exists; it writes ``tests/golden/*.npz``.  The fixtures are
+data only (inputs, parameters, expected outputs); the reference sources never
+travel.  Import recipe: SURVEY.md Appendix A (two ``sys.modules`` stubs for
+``dolfinx.common.timed`` and the compiled ``_bindings``).
+
+Each fixture file holds a list of independent *calls*
+``(params, del_t, grad, stress_in, hist_in) -> (stress_out, tangent_out, hist_out)``;
+multi-step sequences follow the protocol of ``LawOnSubMesh.evaluate`` /
+``IncrSmallStrainProblem.update`` (solver/_lawonsubmesh.py:72-95,
+solver/_solver.py:149-159): every call starts from a fresh copy of the committed
+state; a step may be evaluated several times (Newton iterations) before the last
+result is committed.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference/src"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def import_reference():
+    df = types.ModuleType("dolfinx")
+    common = types.ModuleType("dolfinx.common")
+    common.timed = lambda name: (lambda f: f)
+    df.common = common
+    sys.modules["dolfinx"] = df
+    sys.modules["dolfinx.common"] = common
+    b = types.ModuleType("fenics_constitutive._bindings")
+    for n in ("PyDruckerPrager3D", "PyDruckerPragerHyperbolic3D", "PyLinearElasticity3D", "PyMisesPlasticity3D"):
+        setattr(b, n, type(n, (), {}))
+    sys.modules["fenics_constitutive._bindings"] = b
+    sys.path.insert(0, REF)
+    import fenics_constitutive.models as m
+
+    return m
+
+
+class Recorder:
+    def __init__(self):
+        self.d = {}
+        self.calls = []
+
+    def call(self, name, law, params, del_t, grad, stress_in, hist_in):
+        s = stress_in.copy()
+        h = None if hist_in is None else {k: v.copy() for k, v in hist_in.items()}
+        n = grad.size // 9
+        tan = np.full(36 * n, np.nan)
+        law.evaluate(0.0, del_t, grad.copy(), s, tan, h)
+        i = len(self.calls)
+        self.calls.append(name)
+        p = f"c{i}."
+        self.d[p + "del_t"] = np.float64(del_t)
+        self.d[p + "param_keys"] = np.array(list(params.keys()))
+        self.d[p + "param_vals"] = np.array([float(v) for v in params.values()])
+        self.d[p + "grad"] = grad.copy()
+        self.d[p + "stress_in"] = stress_in.copy()
+        self.d[p + "stress_out"] = s
+        self.d[p + "tangent_out"] = tan
+        if hist_in is not None:
+            self.d[p + "hist_keys"] = np.array(list(hist_in.keys()))
+            for k in hist_in:
+                self.d[p + "hist_in." + k] = hist_in[k].copy()
+                self.d[p + "hist_out." + k] = h[k]
+        return s, h
+
+    def save(self, fname):
+        self.d["calls"] = np.array(self.calls)
+        os.makedirs(OUT, exist_ok=True)
+        np.savez_compressed(os.path.join(OUT, fname), **self.d)
+        print(fname, len(self.calls), "calls")
+
+
+def main():
+    m = import_reference()
+    FULL = m.StressStrainConstraint.FULL
+    rng = np.random.default_rng(20251114)
+
+    # ---- a1: strain_from_grad_u (FULL) -----------------------------------
+    g = rng.normal(size=9 * 131)
+    np.savez_compressed(
+        os.path.join(OUT, "strain_from_grad_u.npz"),
+        grad=g,
+        strain=m.strain_from_grad_u(g, FULL),
+        grad_ka=np.arange(1.0, 10.0),
+        strain_ka=m.strain_from_grad_u(np.arange(1.0, 10.0), FULL),
+    )
+
+    # ---- a3: LinearElasticityModel ---------------------------------------
+    r = Recorder()
+    for params, n, gs, ss in [
+        ({"E": 42.0, "nu": 0.3}, 257, 1e-3, 0.0),  # cfg1 distribution, sigma_in = 0
+        ({"E": 42.0, "nu": 0.3}, 257, 1e-3, 1.0),  # cfg2 distribution
+        ({"E": 210e9, "nu": 0.25}, 64, 1e-4, 1e6),
+        ({"E": 42.0, "nu": 0.3}, 1, 1e-3, 1.0),
+        ({"E": 42.0, "nu": 0.0}, 63, 1.0, 1.0),
+    ]:
+        law = m.LinearElasticityModel(params, FULL)
+        r.call("rand", law, params, 1.0, rng.normal(scale=gs, size=9 * n), rng.normal(scale=ss, size=6 * n) if ss else np.zeros(6 * n), None)
+    params = {"E": 42.0, "nu": 0.3}
+    law = m.LinearElasticityModel(params, FULL)
+    r.call("zero_strain", law, params, 1.0, np.zeros(9 * 65), rng.normal(size=6 * 65), None)
+    r.save("linear_elasticity.npz")
+
+    # ---- a4: VonMises3D ---------------------------------------------------
+    r = Recorder()
+    params = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}
+    law = m.VonMises3D(params)
+    n = 193
+
+    def zero_hist(n):
+        return {"eps_n": np.zeros(6 * n), "alpha": np.zeros(n)}
+
+    r.call("all_elastic", law, params, 1.0, rng.normal(scale=1e-4, size=9 * n), np.zeros(6 * n), zero_hist(n))
+    r.call("all_plastic", law, params, 1.0, rng.normal(scale=1e-2, size=9 * n), np.zeros(6 * n), zero_hist(n))
+    r.call("zero_strain", law, params, 1.0, np.zeros(9 * 67), np.zeros(6 * 67), zero_hist(67))
+    # mixed multi-step with carried history; each step: a discarded Newton iterate, then the committed one
+    scale = np.repeat(10 ** rng.uniform(-4, -2, size=n), 9)
+    s, h = np.zeros(6 * n), zero_hist(n)
+    h["alpha"] = rng.uniform(0, 0.02, size=n)
+    for k in range(4):
+        gk = rng.normal(size=9 * n) * scale
+        r.call(f"mixed_step{k}_iter0", law, params, 1.0, 0.9 * gk, s, h)
+        s, h = r.call(f"mixed_step{k}_iter1", law, params, 1.0, gk, s, h)
+    # near-yield: uniaxial-like strain ramp through the yield point
+    n2 = 129
+    gk = np.zeros((n2, 9))
+    gk[:, 0] = np.linspace(0.8, 1.2, n2) * (1200.0 * np.sqrt(2.0 / 3.0) / (2 * 80769.0)) * 1.5
+    gk[:, 4] = -0.5 * gk[:, 0]
+    gk[:, 8] = -0.5 * gk[:, 0]
+    r.call("near_yield", law, params, 1.0, gk.reshape(-1), np.zeros(6 * n2), zero_hist(n2))
+    # perfect plasticity (y00 = y0) and a softer hardening set
+    for pp in (
+        {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 1200.0, "p_w": 200.0},
+        {"p_ka": 1.6e9, "p_mu": 1.2e9, "p_y0": 3.0e6, "p_y00": 9.0e6, "p_w": 35.0},
+    ):
+        lw = m.VonMises3D(pp)
+        sc = 1e-2 if pp["p_mu"] < 1e6 else 3e-3
+        r.call("other_params", lw, pp, 1.0, rng.normal(scale=sc, size=9 * 97), np.zeros(6 * 97), zero_hist(97))
+    r.save("von_mises_3d.npz")
+
+    # ---- a5/a6: SLS Maxwell / Kelvin -------------------------------------
+    for cls, fname in ((m.SpringMaxwellModel, "spring_maxwell.npz"), (m.SpringKelvinModel, "spring_kelvin.npz")):
+        r = Recorder()
+        params = {"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}
+        law = cls(params, FULL)
+        n = 201
+        s = np.zeros(6 * n)
+        h = {"strain_visco": np.zeros(6 * n), "strain": np.zeros(6 * n)}
+        for k, dt in enumerate([1e-8, 2.0, 2.0, 5.0, 0.1]):
+            gk = rng.normal(scale=1e-3, size=9 * n)
+            r.call(f"step{k}_iter0", law, params, dt, 1.1 * gk, s, h)
+            s, h = r.call(f"step{k}_iter1", law, params, dt, gk, s, h)
+        p2 = {"E0": 3.0e10, "E1": 1.2e10, "tau": 0.7, "nu": 0.35}
+        law2 = cls(p2, FULL)
+        hh = {"strain_visco": rng.normal(scale=1e-4, size=6 * 70), "strain": rng.normal(scale=1e-3, size=6 * 70)}
+        r.call("other_params", law2, p2, 0.05, rng.normal(scale=1e-4, size=9 * 70), rng.normal(scale=1e6, size=6 * 70), hh)
+        r.call("zero_strain", law, params, 2.0, np.zeros(9 * 66), s[: 6 * 66], {k: v[: 6 * 66] for k, v in h.items()})
+        r.save(fname)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,219 @@
+"""Pin the CPU oracle (oracle/numpy_oracle.py) against
+
+* golden vectors captured from the imported reference (oracle/gen_golden.py),
+* the reference's own known-answer tests for this path
+  (tests/models/test_conversions.py:14-44; comfe-rs/src/mandel.rs:181-243,
+  comfe-rs/src/consts.rs:121-131),
+* closed-form identities for the comfe-rs Mises law whose plastic values the
+  reference does not pin.
+
+CPU only (no GPU, no reference import).
+"""
+
+import numpy as np
+import pytest
+from golden_util import load_calls, rel_err
+
+from oracle import numpy_oracle as O
+
+TOL_LE = 1e-13  # oracle vs reference on the same machine: rounding-level only
+TOL_PL = 1e-11
+
+
+def _run(fn, c):
+    s, t, h = c.fresh()
+    fn(c.params, 0.0, c.del_t, c.grad.copy(), s, t, h)
+    return s, t, h
+
+
+def _check(c, s, t, h, tol):
+    assert rel_err(s, c.stress_out) <= tol, c.name
+    assert rel_err(t, c.tangent_out) <= tol, c.name
+    if c.hist_out is not None:
+        for k in c.hist_out:
+            assert rel_err(h[k], c.hist_out[k]) <= tol, (c.name, k)
+
+
+# ---- known-answer tests taken from the reference's own tests ---------------
+
+
+def test_strain_from_grad_u_known_answer():
+    # tests/models/test_conversions.py:29-44
+    g = np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0], [7.0, 8.0, 9.0]])
+    e = O.strain_from_grad_u_full(g.reshape(-1))
+    ref = np.array([1.0, 5.0, 9.0, 0.5 * (2.0 + 4.0) * 2**0.5, 0.5 * (3.0 + 7.0) * 2**0.5, 0.5 * (6.0 + 8.0) * 2**0.5])
+    assert np.allclose(e, ref)
+    # comfe-rs/src/mandel.rs:196-205,223-229 (Rust twin, FRAC_1_SQRT_2)
+    e_rs = O.strain_from_grad_u_full(g.reshape(-1), O.F_RS)
+    ref_rs = np.array([1.0, 5.0, 9.0, 6.0 * O.F_RS, 10.0 * O.F_RS, 14.0 * O.F_RS])
+    assert np.linalg.norm(e_rs - ref_rs) < 1e-14
+
+
+def test_strain_factor_bit_patterns():
+    # the two references differ by one ULP
+    assert O.F_PY.hex() == "0x1.6a09e667f3bccp-1"
+    assert O.F_RS.hex() == "0x1.6a09e667f3bcdp-1"
+
+
+def test_strain_from_grad_u_golden():
+    z = np.load(__import__("os").path.join(__import__("golden_util").GOLDEN, "strain_from_grad_u.npz"))
+    assert np.array_equal(O.strain_from_grad_u_full(z["grad"]), z["strain"])
+    assert np.array_equal(O.strain_from_grad_u_full(z["grad_ka"]), z["strain_ka"])
+
+
+def test_comfe_projector_identities():
+    # comfe-rs/src/consts.rs:121-131
+    _, soo, pvol, pdev = O.comfe_projections()
+    assert np.linalg.norm(soo @ pdev) < 1e-14
+    assert np.linalg.norm(pvol @ pdev) < 1e-14
+    assert np.linalg.norm(pvol @ pvol - pvol) < 1e-14
+    assert np.linalg.norm(pdev @ pdev - pdev) < 1e-14
+
+
+def test_comfe_tangent_known_answer():
+    # comfe-rs/src/mandel.rs:181-221
+    MU, KAPPA = 1.2e9, 1.6e9
+    LAM = KAPPA - 2.0 * MU / 3.0
+    T = np.zeros((6, 6))
+    T[:3, :3] = LAM
+    for i in range(3):
+        T[i, i] = 2.0 * MU + LAM
+        T[3 + i, 3 + i] = 2.0 * MU
+    C = O.comfe_isotropic_elastic_tangent(MU, KAPPA)
+    assert np.linalg.norm(C - T) < 1e-14 + 1e-14 * np.linalg.norm(T)
+    Ci = O.comfe_isotropic_elastic_tangent_inv(MU, KAPPA)
+    assert np.linalg.norm(C @ Ci - np.eye(6)) < 1e-14
+
+
+# ---- golden vectors from the imported reference ----------------------------
+
+
+@pytest.mark.parametrize("c", load_calls("linear_elasticity.npz"), ids=lambda c: c.name)
+def test_linear_elasticity_golden(c):
+    _check(c, *_run(O.linear_elasticity, c), TOL_LE)
+
+
+@pytest.mark.parametrize("c", load_calls("spring_maxwell.npz"), ids=lambda c: c.name)
+def test_spring_maxwell_golden(c):
+    _check(c, *_run(O.spring_maxwell, c), TOL_LE)
+
+
+@pytest.mark.parametrize("c", load_calls("spring_kelvin.npz"), ids=lambda c: c.name)
+def test_spring_kelvin_golden(c):
+    _check(c, *_run(O.spring_kelvin, c), TOL_LE)
+
+
+@pytest.mark.parametrize("c", load_calls("von_mises_3d.npz"), ids=lambda c: c.name)
+def test_von_mises_golden_vectorised(c):
+    _check(c, *_run(O.von_mises_3d, c), TOL_PL)
+
+
+@pytest.mark.parametrize("c", load_calls("von_mises_3d.npz")[:4], ids=lambda c: c.name)
+def test_von_mises_golden_loop(c):
+    _check(c, *_run(O.von_mises_3d_loop, c), TOL_PL)
+
+
+def test_von_mises_multistep_protocol():
+    """The mixed sequence chains: committed output of step k is the input of k+1."""
+    calls = {c.name: c for c in load_calls("von_mises_3d.npz")}
+    for k in range(3):
+        a, b = calls[f"mixed_step{k}_iter1"], calls[f"mixed_step{k + 1}_iter0"]
+        assert np.array_equal(a.stress_out, b.stress_in)
+        assert np.array_equal(a.hist_out["alpha"], b.hist_in["alpha"])
+    # plastic fraction of the mixed case is neither 0 nor 1
+    c = calls["mixed_step0_iter1"]
+    s, t, h = c.fresh()
+    npl, nit = O.von_mises_3d(c.params, 0.0, c.del_t, c.grad, s, t, h)
+    assert 0 < npl < c.n and 3 * npl <= nit <= 6 * npl
+
+
+def test_von_mises_newton_nonconvergence_raises():
+    p = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}
+    g = np.zeros(9)
+    g[0] = np.nan
+    h = {"eps_n": np.zeros(6), "alpha": np.zeros(1)}
+    # NaN trial state: phitr > 0 is False -> elastic branch, no exception (reference behaviour)
+    O.von_mises_3d_loop(p, 0, 1, g, np.zeros(6), np.zeros(36), h)
+
+
+# ---- comfe-rs laws: identities that follow from the reference code ---------
+
+P_RS = {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0}
+
+
+def _dev(s):
+    d = s.reshape(-1, 6).copy()
+    d[:, :3] -= d[:, :3].sum(axis=1, keepdims=True) / 3
+    return d
+
+
+def test_comfe_mises_identities():
+    rng = np.random.default_rng(3)
+    n = 500
+    scale = np.repeat(10 ** rng.uniform(-4, -2, size=n), 9)
+    g = rng.normal(size=9 * n) * scale
+    s0 = rng.normal(scale=50.0, size=6 * n)
+    hist = {"history": np.zeros(7 * n)}
+    hist["history"].reshape(-1, 7)[:, 0] = rng.uniform(0, 0.02, size=n)
+    a0 = hist["history"].reshape(-1, 7)[:, 0].copy()
+    s = s0.copy()
+    t = np.zeros(36 * n)
+    npl = O.comfe_mises_plasticity(P_RS, 0, 1, g, s, t, hist)
+    assert 0 < npl < n
+    a1 = hist["history"].reshape(-1, 7)[:, 0]
+    pl = a1 > a0
+    assert pl.sum() == npl
+    de = O.strain_from_grad_u_full(g, O.F_RS).reshape(-1, 6)
+    # pressure update: tr(sigma_new)/3 = p0 + kappa tr(d_eps)   (mises_plasticity.rs:85-87)
+    p0 = s0.reshape(-1, 6)[:, :3].sum(axis=1) / 3
+    p1 = s.reshape(-1, 6)[:, :3].sum(axis=1) / 3
+    assert np.allclose(p1, p0 + P_RS["kappa"] * de[:, :3].sum(axis=1), rtol=1e-12, atol=1e-9)
+    # consistency: after a plastic step sqrt(3/2)|dev sigma| = y0 + h alpha_new
+    q1 = np.sqrt(1.5 * (_dev(s) ** 2).sum(axis=1))
+    assert np.allclose(q1[pl], P_RS["y_0"] + P_RS["h"] * a1[pl], rtol=1e-11)
+    # elastic points stay inside the yield surface and keep their history
+    assert np.all(q1[~pl] < P_RS["y_0"] + P_RS["h"] * a1[~pl])
+    assert np.array_equal(a1[~pl], a0[~pl])
+    # alpha increment (mises_plasticity.rs:105)
+    s_tr = _dev(s0) + 2 * P_RS["mu"] * _dev(de)
+    q = np.sqrt(1.5 * (s_tr**2).sum(axis=1))
+    assert np.allclose((a1 - a0)[pl], ((q - (P_RS["y_0"] + P_RS["h"] * a0)) / (3 * P_RS["mu"] + P_RS["h"]))[pl], rtol=1e-9)
+    # elastic tangent = kappa 1x1 + 2 mu P_dev = isotropic tangent
+    C = O.comfe_isotropic_elastic_tangent(P_RS["mu"], P_RS["kappa"])
+    assert np.allclose(t.reshape(-1, 36)[~pl], C.reshape(36), rtol=1e-14)
+
+
+def test_comfe_le_agrees_with_python_le():
+    """Elastic steps of comfe LE == Python LE up to the 1-ULP strain factor."""
+    rng = np.random.default_rng(4)
+    n = 300
+    E, nu = 42.0, 0.3
+    mu, kappa = E / (2 * (1 + nu)), E / (3 * (1 - 2 * nu))  # tests/models/test_elasticity.py:347-352
+    g = rng.normal(scale=1e-3, size=9 * n)
+    s_py, s_rs = rng.normal(size=6 * n), None
+    s_rs = s_py.copy()
+    t_py, t_rs = np.zeros(36 * n), np.zeros(36 * n)
+    O.linear_elasticity({"E": E, "nu": nu}, 0, 1, g, s_py, t_py)
+    O.comfe_linear_elasticity({"mu": mu, "kappa": kappa}, 0, 1, g, s_rs, t_rs)
+    assert rel_err(s_rs, s_py) < 1e-13
+    assert rel_err(t_rs, t_py) < 1e-13
+    # tangent=None is accepted by the Rust entry (interfaces.rs:383-394)
+    s2 = s_py.copy()
+    O.comfe_linear_elasticity({"mu": mu, "kappa": kappa}, 0, 1, g, s2, None)
+
+
+def test_perfect_plasticity_cross_check():
+    """with y00 = y0 and h = 0 both Mises laws give the same stress
+    and the same alpha."""
+    rng = np.random.default_rng(5)
+    n = 400
+    g = rng.normal(scale=5e-3, size=9 * n)
+    p_py = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 1200.0, "p_w": 200.0}
+    p_rs = {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 0.0}
+    s_py, s_rs = np.zeros(6 * n), np.zeros(6 * n)
+    h_py = {"eps_n": np.zeros(6 * n), "alpha": np.zeros(n)}
+    h_rs = {"history": np.zeros(7 * n)}
+    O.von_mises_3d(p_py, 0, 1, g, s_py, np.zeros(36 * n), h_py)
+    O.comfe_mises_plasticity(p_rs, 0, 1, g, s_rs, np.zeros(36 * n), h_rs)
+    assert rel_err(s_rs, s_py) < 1e-10
+    assert rel_err(h_rs["history"].reshape(-1, 7)[:, 0], h_py["alpha"]) < 1e-9
