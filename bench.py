@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: quadrature-point stress updates per second.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--n POINTS]
+
+One "step" = one ``evaluate`` pass of one constitutive law over n synthetic quadrature points
+per GPU, device-resident (inputs already in HBM when the timed region starts).  Default
+workload at N = 1: BASELINE.json's target configuration, VonMises3D return mapping, 1e8
+points, mixed elastic/plastic (SURVEY.md 8d cfg3 "mixed").  For N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank evaluates its own contiguous shard of
+n points (weak scaling, no data-path collective: SURVEY.md 8e); the optional stress/tangent
+all-gather of the single-assembler mode is timed separately and reported under "allgather".
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+VM_P = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}
+RS_P = {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0}
+SLS_P = {"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}
+LE_P = {"E": 42.0, "nu": 0.3}
+
+# workload -> (law kind, strain scale spec, bytes/pt elastic, bytes/pt plastic, history dims)
+WORKLOADS = {
+    "von_mises_mixed": ("von_mises_3d", "loguniform", 464, 568),
+    "von_mises_plastic": ("von_mises_3d", 1e-2, 464, 568),
+    "von_mises_elastic": ("von_mises_3d", 1e-4, 464, 568),
+    "linear_elasticity": ("linear_elasticity", 1e-3, 456, 456),
+    "spring_maxwell": ("spring_maxwell", 1e-3, 648, 648),
+    "spring_kelvin": ("spring_kelvin", 1e-3, 648, 648),
+    "comfe_mises_mixed": ("comfe_mises_plasticity", "loguniform", 464, 568),
+}
+
+
+def make_law(kind):
+    import numpy as np
+
+    import fenics_constitutive_amd as fc
+
+    FULL = fc.StressStrainConstraint.FULL
+    if kind == "von_mises_3d":
+        return fc.VonMises3D(VM_P), VM_P
+    if kind == "linear_elasticity":
+        return fc.LinearElasticityModel(LE_P, FULL), LE_P
+    if kind == "spring_maxwell":
+        return fc.SpringMaxwellModel(SLS_P, FULL), SLS_P
+    if kind == "spring_kelvin":
+        return fc.SpringKelvinModel(SLS_P, FULL), SLS_P
+    if kind == "comfe_mises_plasticity":
+        return fc.MisesPlasticityLinearHardening3D({k: np.array([v]) for k, v in RS_P.items()}), RS_P
+    raise ValueError(kind)
+
+
+def synth_inputs(kind, scale_spec, n, seed, device):
+    """Synthetic state, generated on the device: returns
+    (grad, committed stress, committed history dict, warm-up grad)."""
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+
+    def grad_array():
+        g = torch.randn(9 * n, dtype=torch.float64, device=device, generator=gen)
+        if scale_spec == "loguniform":
+            sc = torch.pow(10.0, torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 2.0 - 4.0)
+            g.view(n, 9).mul_(sc[:, None])
+        else:
+            g.mul_(float(scale_spec))
+        return g
+
+    stress = torch.zeros(6 * n, dtype=torch.float64, device=device)
+    if kind == "von_mises_3d":
+        hist = {"eps_n": torch.zeros(6 * n, dtype=torch.float64, device=device),
+                "alpha": torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 0.02}
+    elif kind in ("spring_maxwell", "spring_kelvin"):
+        hist = {"strain_visco": torch.zeros(6 * n, dtype=torch.float64, device=device),
+                "strain": torch.zeros(6 * n, dtype=torch.float64, device=device)}
+    elif kind == "comfe_mises_plasticity":
+        h = torch.zeros(7 * n, dtype=torch.float64, device=device)
+        h.view(n, 7)[:, 0] = torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 0.02
+        hist = {"history": h}
+    else:
+        hist = None
+        stress.normal_(generator=gen)  # cfg2: sigma_in ~ N(0,1) exercises the "+="
+    return grad_array, stress, hist
+
+
+def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
+    """Time the C oracle ("port": serial per-point loop, 1 thread -- what the reference does per
+    MPI rank) on a bounded sample of the same workload."""
+    import numpy as np
+
+    from oracle import c_oracle as CO
+
+    ns = min(grad.numel() // 9, 2_000_000)
+    g = grad[: 9 * ns].cpu().numpy()
+    s0 = stress[: 6 * ns].cpu().numpy()
+    dims = {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}
+    h0 = None if hist is None else {k: v[: dims[k] * ns].cpu().numpy() for k, v in hist.items()}
+    tan = np.zeros(36 * ns)
+    fn = CO.MODELS[kind]
+
+    def one_pass():
+        s = s0.copy()
+        h = None if h0 is None else {k: v.copy() for k, v in h0.items()}
+        t0 = time.perf_counter()
+        fn(params, 0.0, del_t, g, s, tan, h)
+        return time.perf_counter() - t0
+
+    one_pass()  # untimed: faults in the pages of the output arrays
+    reps, t_total = 0, 0.0
+    while t_total < budget_s and reps < 500:
+        t_total += one_pass()
+        reps += 1
+    return {
+        "value": round(ns * reps / t_total / 1e6, 3),
+        "unit": "Mpts/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle/oracle.c serial loop, first {ns} points of the same workload x {reps} passes ({t_total:.1f} s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="von_mises_mixed", choices=sorted(WORKLOADS))
+    ap.add_argument("--n", type=int, default=100_000_000, help="quadrature points per GPU")
+    ap.add_argument("--grid", type=int, default=0, help="override the launch grid (workgroups)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-points", type=int, default=20_000_000,
+                    help="points per rank of the separately timed stress/tangent all-gather (N>1)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    kind, scale_spec, b_el, b_pl = WORKLOADS[args.workload]
+    n = args.n
+    del_t = 2.0
+    law, params = make_law(kind)
+    grad_array, stress_c, hist_c = synth_inputs(kind, scale_spec, n, seed=1234 + rank, device=device)
+
+    # one in-place warm step from the initial state gives a committed state "from a previous step"
+    tangent = torch.empty(36 * n, dtype=torch.float64, device=device)
+    g_warm = grad_array()
+    law.evaluate(0.0, del_t, g_warm, stress_c, tangent, hist_c)
+    del g_warm
+    grad = grad_array()
+    # trial-state arrays: every timed step reads the committed state and writes the trial state
+    # (same traffic as in place, stationary workload)
+    stress_t = torch.empty_like(stress_c)
+    hist_t = None if hist_c is None else {k: torch.empty_like(v) for k, v in hist_c.items()}
+    if args.grid:
+        law._handle(local_rank).ctx.set_grid(args.grid)
+
+    def step():
+        law.evaluate_from(0.0, del_t, grad, stress_c, stress_t, tangent, hist_c, hist_t)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    st = law.device_stats(local_rank)
+    n_pl = int(st.n_plastic) if kind in ("von_mises_3d", "comfe_mises_plasticity") else 0
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()
+        step()
+        ev1[i].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = sorted(ev0[i].elapsed_time(ev1[i]) for i in range(args.steps))
+    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+
+    # optional exchange step, timed separately (never part of `value`)
+    gather = None
+    if world > 1:
+        from fenics_constitutive_amd.sharded import ShardPlan
+
+        ng = min(args.gather_points, n)
+        plan = ShardPlan.create(ng * world, world)
+        per = plan.per_rank
+        out_s = torch.empty(6 * per * world, dtype=torch.float64, device=device)
+        out_t = torch.empty(36 * per * world, dtype=torch.float64, device=device)
+        out_s[6 * per * rank : 6 * per * (rank + 1)].copy_(stress_t[: 6 * per])
+        out_t[36 * per * rank : 36 * per * (rank + 1)].copy_(tangent[: 36 * per])
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            dist.all_gather_into_tensor(out_s, out_s[6 * per * rank : 6 * per * (rank + 1)])
+            dist.all_gather_into_tensor(out_t, out_t[36 * per * rank : 36 * per * (rank + 1)])
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - tg)
+        tg = torch.tensor([min(times)], dtype=torch.float64, device=device)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        shard_bytes = 42 * 8 * per
+        gather = {"points_per_rank": per, "shard_GB": round(shard_bytes / 1e9, 3), "ms": round(float(tg.item()) * 1e3, 3),
+                  "algbw_GBs": round(shard_bytes * (world - 1) / float(tg.item()) / 1e9, 1),
+                  "note": "in-place all_gather_into_tensor of stress+tangent, outside the timed steps"}
+        del out_s, out_t
+
+    if rank == 0:
+        total_pts = n * world * args.steps
+        value = total_pts / elapsed / 1e6
+        alg_bytes = (n - n_pl) * b_el + n_pl * b_pl
+        achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                with open(tf) as f:
+                    tj = json.load(f)
+                e = tj.get(args.workload)
+                if e and int(e.get("n", 0)) == n:
+                    traffic = e.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "quadrature-point stress updates/sec (Mpts/s) + % HBM roofline",
+            "value": round(value, 1),
+            "unit": "Mpts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {kind} FULL-3D, {n} quadrature points per GPU, device-resident AoS, "
+                                   f"committed->trial evaluate", "points_per_gpu": n, "plastic_fraction": round(n_pl / n, 4),
+                       "mean_newton_iters": round(st.n_newton_iters / max(n_pl, 1), 3) if kind == "von_mises_3d" else None,
+                       "parallelism": f"shard{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms_avg": round(kernel_avg_ms, 4), "kernel_ms_min": round(kernel_ms[0], 4),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "bytes_per_point": {"elastic": b_el, "plastic": b_pl}},
+        }
+        if gather:
+            out["allgather"] = gather
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(kind, params, grad, stress_c, hist_c, del_t)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Build libfcamd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+``python -m fenics_constitutive_amd._build`` or ``build_library()``.  hipcc cross-compiles
+without a GPU; the resulting ``lib/libfcamd.so`` travels to the GPU box with the snapshot.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libfcamd.so")
+SOURCES = ["fcamd_kernels.hip", "fcamd_capi.cpp"]
+HEADERS = ["fcamd_internal.h", os.path.join("..", "..", "include", "fcamd.h")]
+ARCH = "gfx950"
+# -ffp-contract=off: arithmetic order is part of the parity contract (see fcamd_kernels.hip)
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False, keep_temps: bool = False) -> str:
+    """Compile the library if missing or older than its sources; return its path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found; cannot build libfcamd.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    tmp = LIB + ".tmp"
+    cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS]
+    if keep_temps:
+        bdir = os.path.join(CSRC, "build")
+        os.makedirs(bdir, exist_ok=True)
+        cmd += [f"-save-temps={'obj'}", "-Rpass-analysis=kernel-resource-usage"]
+        tmp = os.path.join(bdir, "libfcamd.so")
+    cmd += ["-o", tmp, *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+    if keep_temps:
+        shutil.copyfile(tmp, LIB)
+        sys.stderr.write(r.stderr)
+    else:
+        os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True, keep_temps="--temps" in sys.argv))

@@ -1,0 +1,231 @@
+"""ctypes binding of ``libfcamd.so`` (C ABI in ``include/fcamd.h``).
+
+This is the only place that touches the shared library.  There is no CPU fallback: when
+the library cannot be loaded, or no HIP device is present, every entry raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _build
+
+# status codes (include/fcamd.h)
+OK, ERR_SIZE, ERR_NULL_HISTORY, ERR_DEL_T, ERR_NONCONVERGED, ERR_HIP, ERR_BAD_ARG, ERR_ALIGN, ERR_UNSUPPORTED = range(9)
+
+# model ids (include/fcamd.h)
+LINEAR_ELASTICITY, VON_MISES_3D, SPRING_MAXWELL, SPRING_KELVIN, COMFE_LINEAR_ELASTICITY, COMFE_MISES_PLASTICITY = range(1, 7)
+
+MAX_HISTORY = 2
+
+#: every symbol include/fcamd.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "fcamd_context_create", "fcamd_context_destroy", "fcamd_context_set_stream",
+    "fcamd_context_synchronize", "fcamd_model_create", "fcamd_model_destroy",
+    "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_evaluate_device",
+    "fcamd_evaluate_device_from", "fcamd_evaluate_host", "fcamd_strain_from_grad_u_device",
+    "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
+    "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
+    "fcamd_last_error", "fcamd_status_string", "fcamd_version",
+]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_nonconverged", C.c_uint64),
+        ("n_plastic", C.c_uint64),
+        ("n_newton_iters", C.c_uint64),
+        ("reserved", C.c_uint64),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load (building first if needed) libfcamd.so.  Raises if that is impossible."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB
+        if not os.path.exists(path):
+            if not build_if_missing:
+                raise RuntimeError(f"{path} is missing; run __graft_entry__.build()")
+            _build.build_library()
+        lib = C.CDLL(path)
+        dp = C.POINTER(C.c_double)
+        vp = C.c_void_p
+        lib.fcamd_context_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+        lib.fcamd_context_destroy.argtypes = [vp]
+        lib.fcamd_context_set_stream.argtypes = [vp, vp]
+        lib.fcamd_context_synchronize.argtypes = [vp]
+        lib.fcamd_context_set_grid.argtypes = [vp, C.c_int]
+        lib.fcamd_context_set_timing.argtypes = [vp, C.c_int]
+        lib.fcamd_model_create.argtypes = [vp, C.c_int, C.c_int, dp, C.c_int, C.POINTER(vp)]
+        lib.fcamd_model_destroy.argtypes = [vp]
+        lib.fcamd_model_history_count.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.fcamd_model_history_field.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+        lib.fcamd_evaluate_device.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int]
+        lib.fcamd_evaluate_device_from.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int]
+        lib.fcamd_evaluate_host.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int, C.POINTER(Stats)]
+        lib.fcamd_strain_from_grad_u_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int]
+        lib.fcamd_model_last_stats.argtypes = [vp, C.POINTER(Stats)]
+        lib.fcamd_model_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        lib.fcamd_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
+        lib.fcamd_unregister_host_buffer.argtypes = [vp, vp]
+        lib.fcamd_last_error.restype = C.c_char_p
+        lib.fcamd_status_string.restype = C.c_char_p
+        lib.fcamd_status_string.argtypes = [C.c_int]
+        for name in SYMBOLS:
+            f = getattr(lib, name)
+            if name not in ("fcamd_last_error", "fcamd_status_string"):
+                f.restype = C.c_int
+        _lib = lib
+        return lib
+
+
+def check(status: int) -> None:
+    """Map a status code to the exception type the reference raises in the same situation
+    (SURVEY.md 8b "Error conventions")."""
+    if status == OK:
+        return
+    lib = load()
+    detail = (lib.fcamd_last_error() or b"").decode() or lib.fcamd_status_string(status).decode()
+    if status in (ERR_SIZE, ERR_DEL_T):
+        raise AssertionError(detail)
+    if status == ERR_NULL_HISTORY:
+        raise ValueError(detail)
+    if status == ERR_NONCONVERGED:
+        raise RuntimeError(detail)
+    if status == ERR_UNSUPPORTED:
+        raise NotImplementedError(detail)
+    if status in (ERR_BAD_ARG, ERR_ALIGN):
+        raise ValueError(detail)
+    raise RuntimeError(f"libfcamd: {detail}")
+
+
+# ---------------------------------------------------------------------------------------
+# contexts: one per (device, thread); the launch stream is re-bound per call
+# ---------------------------------------------------------------------------------------
+_contexts: dict[tuple[int, int], "Context"] = {}
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.fcamd_context_create(int(device), None, C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        self._lib = lib
+
+    def set_stream(self, stream_ptr: int | None) -> None:
+        check(self._lib.fcamd_context_set_stream(self.handle, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self) -> None:
+        check(self._lib.fcamd_context_synchronize(self.handle))
+
+    def set_grid(self, n_workgroups: int) -> None:
+        check(self._lib.fcamd_context_set_grid(self.handle, int(n_workgroups)))
+
+    def set_timing(self, enabled: bool) -> None:
+        check(self._lib.fcamd_context_set_timing(self.handle, int(bool(enabled))))
+
+    def register_host_buffer(self, arr: np.ndarray) -> None:
+        check(self._lib.fcamd_register_host_buffer(self.handle, C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def unregister_host_buffer(self, arr: np.ndarray) -> None:
+        check(self._lib.fcamd_unregister_host_buffer(self.handle, C.c_void_p(arr.ctypes.data)))
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.fcamd_context_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def get_context(device: int = 0) -> Context:
+    key = (int(device), threading.get_ident())
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = _contexts[key] = Context(device)
+    return ctx
+
+
+class Model:
+    """Handle of one constitutive law on one context."""
+
+    def __init__(self, ctx: Context, model_id: int, constraint: int, params):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        h = C.c_void_p()
+        check(self._lib.fcamd_model_create(ctx.handle, int(model_id), int(constraint),
+                                           p.ctypes.data_as(C.POINTER(C.c_double)), p.size, C.byref(h)))
+        self.handle = h
+        n = C.c_int()
+        check(self._lib.fcamd_model_history_count(h, C.byref(n)))
+        self.history_fields: list[tuple[str, int]] = []
+        for k in range(n.value):
+            name, dim = C.c_char_p(), C.c_int()
+            check(self._lib.fcamd_model_history_field(h, k, C.byref(name), C.byref(dim)))
+            self.history_fields.append((name.value.decode(), dim.value))
+
+    def _ptr_array(self, ptrs):
+        if not ptrs:
+            return None, 0
+        arr = (C.c_void_p * len(ptrs))(*[C.c_void_p(int(p)) for p in ptrs])
+        return arr, len(ptrs)
+
+    def evaluate_host(self, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, hist_ptrs) -> Stats:
+        arr, nh = self._ptr_array(hist_ptrs)
+        st = Stats()
+        status = self._lib.fcamd_evaluate_host(self.handle, float(t), float(del_t), int(n),
+                                               C.c_void_p(grad_ptr), C.c_void_p(stress_ptr),
+                                               C.c_void_p(tangent_ptr or 0), arr, nh, C.byref(st))
+        check(status)
+        return st
+
+    def evaluate_device(self, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, hist_ptrs,
+                        stress_prev_ptr=None, hist_prev_ptrs=None) -> None:
+        arr, nh = self._ptr_array(hist_ptrs)
+        if stress_prev_ptr is None and hist_prev_ptrs is None:
+            check(self._lib.fcamd_evaluate_device(self.handle, float(t), float(del_t), int(n),
+                                                  C.c_void_p(grad_ptr), C.c_void_p(stress_ptr),
+                                                  C.c_void_p(tangent_ptr or 0), arr, nh))
+            return
+        parr, _ = self._ptr_array(hist_prev_ptrs if hist_prev_ptrs is not None else hist_ptrs)
+        check(self._lib.fcamd_evaluate_device_from(
+            self.handle, float(t), float(del_t), int(n), C.c_void_p(grad_ptr),
+            C.c_void_p(stress_prev_ptr if stress_prev_ptr is not None else stress_ptr),
+            C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), parr, arr, nh))
+
+    def last_stats(self) -> Stats:
+        st = Stats()
+        check(self._lib.fcamd_model_last_stats(self.handle, C.byref(st)))
+        return st
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        check(self._lib.fcamd_model_last_kernel_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.fcamd_model_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,630 @@
+// C-ABI layer of libfcamd: contexts, model handles, host staging and launches.
+// Public contract: include/fcamd.h.  Device code: fcamd_kernels.hip.
+//
+// Everything that depends on material parameters is computed here, on the host, in plain
+// IEEE double arithmetic and in the reference's own expression order (this file is built
+// with -ffp-contract=off), so that the device kernels can reproduce NumPy bit for bit:
+//   lame_parameters / get_elastic_tangent  src/fenics_constitutive/models/utils.py:18-51
+//   VonMises3D.__init__                     models/mises_plasticity_isotropic_hardening.py:32-55
+//   SpringMaxwellModel / SpringKelvinModel  models/spring_maxwell_model.py:24-38,72-86,
+//                                           models/spring_kelvin_model.py:24-41,73-86
+//   comfe-rs projections / tangents         comfe-rs/src/consts.rs:6-115, mandel.rs:126-128
+#include "../../include/fcamd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fcamd_internal.h"
+
+using namespace fcamd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(FCAMD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+// Python "1 / 2**0.5" and Rust FRAC_1_SQRT_2 differ by one ULP.
+constexpr double kFactorPy = 0x1.6a09e667f3bccp-1;
+constexpr double kFactorRs = 0x1.6a09e667f3bcdp-1;
+
+struct HistField {
+    const char* name;
+    int dim;
+};
+
+struct LawInfo {
+    int n_params;
+    int n_hist;
+    HistField hist[FCAMD_MAX_HISTORY];
+    bool needs_del_t;
+};
+
+bool law_info(int id, LawInfo* li) {
+    switch (id) {
+        case FCAMD_LINEAR_ELASTICITY: *li = {2, 0, {}, false}; return true;
+        case FCAMD_VON_MISES_3D: *li = {5, 2, {{"eps_n", 6}, {"alpha", 1}}, false}; return true;
+        case FCAMD_SPRING_MAXWELL: *li = {4, 2, {{"strain_visco", 6}, {"strain", 6}}, true}; return true;
+        case FCAMD_SPRING_KELVIN: *li = {4, 2, {{"strain_visco", 6}, {"strain", 6}}, true}; return true;
+        case FCAMD_COMFE_LINEAR_ELASTICITY: *li = {2, 0, {}, false}; return true;
+        case FCAMD_COMFE_MISES_PLASTICITY: *li = {4, 1, {{"history", 7}}, false}; return true;
+        default: return false;
+    }
+}
+
+// ---- reference constants ------------------------------------------------------------------
+
+void lame(double E, double nu, double* mu, double* lam) {
+    *mu = E / (2.0 * (1.0 + nu));
+    *lam = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+}
+
+void elastic_tangent_full(double E, double nu, double D[36]) {
+    double mu, lam;
+    lame(E, nu, &mu, &lam);
+    for (int i = 0; i < 36; ++i) D[i] = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) D[6 * i + j] = (i == j) ? 2.0 * mu + lam : lam;
+    for (int i = 3; i < 6; ++i) D[6 * i + i] = 2.0 * mu;
+}
+
+void comfe_projections(double soo[36], double pvol[36], double pdev[36]) {
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            const double s = (i < 3 && j < 3) ? 1.0 : 0.0;
+            soo[6 * i + j] = s;
+            pvol[6 * i + j] = s * (1.0 / 3.0);
+            pdev[6 * i + j] = ((i == j) ? 1.0 : 0.0) + pvol[6 * i + j] * -1.0;
+        }
+}
+
+}  // namespace
+
+struct fcamd_context {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int grid_override = 0;
+    bool timing = false;
+    // host path: two chunk slots, each with its own stream and device buffers
+    hipStream_t hstream[2] = {nullptr, nullptr};
+    double* dchunk[2] = {nullptr, nullptr};
+    size_t dchunk_points = 0;
+    std::map<void*, size_t> registered;
+};
+
+struct fcamd_model {
+    fcamd_context* ctx = nullptr;
+    int law = 0;
+    LawInfo info{};
+    double params[8] = {0};
+    unsigned long long* d_counters = nullptr;  // [4] device
+    unsigned long long* h_counters = nullptr;  // [4] pinned host
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int grid_auto = 0;
+};
+
+namespace {
+
+// Fill scalars and tables of `args` for one call (del_t enters the SLS constants).
+void fill_constants(const fcamd_model* m, double del_t, EvalArgs* a) {
+    Scalars& sc = a->sc;
+    Tables& tb = a->tb;
+    std::memset(&sc, 0, sizeof(sc));
+    std::memset(&tb, 0, sizeof(tb));
+    const double* p = m->params;
+    switch (m->law) {
+        case FCAMD_LINEAR_ELASTICITY: {
+            sc.s[0] = kFactorPy;
+            elastic_tangent_full(p[0], p[1], tb.a);
+            std::memcpy(tb.c, tb.a, sizeof(tb.a));
+            break;
+        }
+        case FCAMD_VON_MISES_3D: {
+            const double ka = p[0], mu = p[1], y0 = p[2], y00 = p[3], w = p[4];
+            sc.s[0] = kFactorPy;
+            sc.s[1] = ka;
+            sc.s[2] = 2 * mu;
+            sc.s[3] = std::sqrt(2.0 / 3.0);
+            sc.s[4] = y0;
+            sc.s[5] = y00 - y0;
+            sc.s[6] = -w;
+            sc.s[7] = -2 * mu;
+            sc.s[8] = (2.0 / 3.0) * (y00 - y0) * w;
+            sc.s[9] = 4 * mu * mu;
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    const double xioi = (i < 3 && j < 3) ? 1.0 : 0.0;
+                    tb.a[6 * i + j] = ka * xioi;
+                    tb.b[6 * i + j] = ((i == j) ? 1.0 : 0.0) - (1.0 / 3.0) * xioi;
+                }
+            break;
+        }
+        case FCAMD_SPRING_MAXWELL: {
+            const double E0 = p[0], E1 = p[1], tau = p[2], nu = p[3];
+            double D0[36], D1[36], mu1, lam1;
+            elastic_tangent_full(E0, nu, D0);
+            elastic_tangent_full(E1, nu, D1);
+            lame(E1, nu, &mu1, &lam1);
+            const double factor = 1 / del_t + 1 / tau;
+            sc.s[0] = kFactorPy;
+            sc.s[1] = 1 / factor;
+            sc.s[2] = 1 / (tau * 2 * mu1);
+            sc.s[3] = 1 / tau;
+            sc.s[4] = 2 * mu1;
+            const double w1 = 1 - 1 / (tau * factor);
+            for (int i = 0; i < 36; ++i) {
+                tb.a[i] = D1[i];
+                tb.b[i] = D0[i] + D1[i];
+                tb.c[i] = D0[i] + w1 * D1[i];
+            }
+            break;
+        }
+        case FCAMD_SPRING_KELVIN: {
+            const double E0 = p[0], E1 = p[1], tau = p[2], nu = p[3];
+            double D0[36], mu0, lam0, mu1, lam1;
+            elastic_tangent_full(E0, nu, D0);
+            lame(E0, nu, &mu0, &lam0);
+            lame(E1, nu, &mu1, &lam1);
+            const double factor = 1 / del_t + 1 / tau + mu0 / (tau * mu1);
+            sc.s[0] = kFactorPy;
+            sc.s[1] = 1 / factor;
+            sc.s[2] = 1 / (tau * 2 * mu1);
+            sc.s[3] = 1 / tau;
+            sc.s[4] = 2 * mu0;
+            sc.s[5] = mu0 / (tau * mu1);
+            sc.s[6] = lam0 / (tau * 2 * mu1);
+            const double w0 = 1 - mu0 / (tau * mu1 * factor);
+            for (int i = 0; i < 36; ++i) {
+                tb.a[i] = D0[i];
+                tb.c[i] = w0 * D0[i];
+            }
+            break;
+        }
+        case FCAMD_COMFE_LINEAR_ELASTICITY: {
+            const double mu = p[0], kappa = p[1];
+            double soo[36], pvol[36], pdev[36];
+            comfe_projections(soo, pvol, pdev);
+            sc.s[0] = kFactorRs;
+            for (int i = 0; i < 36; ++i) tb.a[i] = (2.0 * mu) * pdev[i] + (3.0 * kappa) * pvol[i];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) tb.c[6 * j + i] = tb.a[6 * i + j];  // column-major .data.0
+            break;
+        }
+        case FCAMD_COMFE_MISES_PLASTICITY: {
+            const double mu = p[0], kappa = p[1], y_0 = p[2], h = p[3];
+            double soo[36], pvol[36], pdev[36];
+            comfe_projections(soo, pvol, pdev);
+            sc.s[0] = kFactorRs;
+            sc.s[1] = mu;
+            sc.s[2] = kappa;
+            sc.s[3] = y_0;
+            sc.s[4] = h;
+            sc.s[5] = 2. * mu;
+            sc.s[6] = 3. * mu + h;
+            sc.s[7] = std::sqrt(3. / 2.);
+            sc.s[8] = 3. * mu;
+            sc.s[9] = 1.0 / (1.0 + (h / (3.0 * mu)));
+            for (int i = 0; i < 36; ++i) {
+                tb.a[i] = kappa * soo[i];
+                tb.b[i] = pdev[i];
+            }
+            break;
+        }
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* grad,
+                  const void* stress_prev, const void* stress, const void* const* hist_prev,
+                  const void* const* hist, int n_hist) {
+    if (!m) return fail(FCAMD_ERR_BAD_ARG, "model handle is NULL");
+    if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
+    if (m->info.n_hist > 0) {
+        if (!hist || !hist_prev || n_hist == 0)
+            return fail(FCAMD_ERR_NULL_HISTORY, "history must not be None");
+        if (n_hist != m->info.n_hist)
+            return fail(FCAMD_ERR_SIZE, "law expects %d history fields, got %d", m->info.n_hist,
+                        n_hist);
+        for (int k = 0; k < n_hist; ++k)
+            if (n > 0 && (!hist[k] || !hist_prev[k]))
+                return fail(FCAMD_ERR_NULL_HISTORY, "history must not be None");
+    }
+    if (m->info.needs_del_t && !(del_t > 0.0))
+        return fail(FCAMD_ERR_DEL_T, "Time step must be defined and positive.");
+    if (n > 0 && (!grad || !stress || !stress_prev))
+        return fail(FCAMD_ERR_BAD_ARG, "grad_del_u / stress pointer is NULL");
+    return FCAMD_OK;
+}
+
+int grid_for(fcamd_model* m, int64_t n) {
+    fcamd_context* c = m->ctx;
+    int grid = c->grid_override;
+    if (grid <= 0) {
+        if (m->grid_auto <= 0) m->grid_auto = default_grid(m->law, c->num_cu);
+        grid = m->grid_auto;
+    }
+    const int64_t tiles = (n + 63) / 64;
+    const int64_t need = (tiles + 3) / 4;
+    if (need < grid) grid = (int)std::max<int64_t>(need, 1);
+    return grid;
+}
+
+// enqueue one launch on `stream`; device pointers already validated
+int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
+            double* stress, double* tangent, const double* const* hprev, double* const* hcur,
+            hipStream_t stream, bool reset_counters) {
+    EvalArgs a;
+    a.grad = grad;
+    a.stress_in = stress_prev;
+    a.stress_out = stress;
+    a.tangent = tangent;
+    a.h0_in = m->info.n_hist > 0 ? hprev[0] : nullptr;
+    a.h0_out = m->info.n_hist > 0 ? hcur[0] : nullptr;
+    a.h1_in = m->info.n_hist > 1 ? hprev[1] : nullptr;
+    a.h1_out = m->info.n_hist > 1 ? hcur[1] : nullptr;
+    a.n = n;
+    a.counters = m->d_counters;
+    fill_constants(m, del_t, &a);
+    if (reset_counters) HIP_TRY(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    if (n == 0) return FCAMD_OK;
+    const int grid = grid_for(m, n);
+    HIP_TRY(launch_evaluate(m->law, a, grid, stream));
+    return FCAMD_OK;
+}
+
+int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
+    HIP_TRY(hipMemcpyAsync(m->h_counters, m->d_counters, 4 * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (out) {
+        out->n_nonconverged = m->h_counters[0];
+        out->n_plastic = m->h_counters[1];
+        out->n_newton_iters = m->h_counters[2];
+        out->reserved = 0;
+    }
+    return FCAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fcamd_version(void) { return FCAMD_VERSION_MAJOR * 1000 + FCAMD_VERSION_MINOR; }
+
+const char* fcamd_last_error(void) { return g_last_error.c_str(); }
+
+const char* fcamd_status_string(int status) {
+    switch (status) {
+        case FCAMD_OK: return "ok";
+        case FCAMD_ERR_SIZE: return "inconsistent array sizes";
+        case FCAMD_ERR_NULL_HISTORY: return "history must not be None";
+        case FCAMD_ERR_DEL_T: return "Time step must be defined and positive.";
+        case FCAMD_ERR_NONCONVERGED: return "Newton-Raphson method did not converge for plastic multiplier.";
+        case FCAMD_ERR_HIP: return "HIP runtime error";
+        case FCAMD_ERR_BAD_ARG: return "bad argument";
+        case FCAMD_ERR_ALIGN: return "device pointer not 16-byte aligned";
+        case FCAMD_ERR_UNSUPPORTED: return "not implemented";
+        default: return "unknown status";
+    }
+}
+
+int fcamd_context_create(int device, void* stream, fcamd_context** out) {
+    if (!out) return fail(FCAMD_ERR_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count)
+        return fail(FCAMD_ERR_BAD_ARG, "device %d out of range (%d devices)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    fcamd_context* c = new (std::nothrow) fcamd_context();
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "out of host memory");
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->owns_stream = true;
+    }
+    *out = c;
+    return FCAMD_OK;
+}
+
+int fcamd_context_destroy(fcamd_context* c) {
+    if (!c) return FCAMD_OK;
+    (void)hipSetDevice(c->device);
+    for (auto& kv : c->registered) (void)hipHostUnregister(kv.first);
+    for (int i = 0; i < 2; ++i) {
+        if (c->dchunk[i]) (void)hipFree(c->dchunk[i]);
+        if (c->hstream[i]) (void)hipStreamDestroy(c->hstream[i]);
+    }
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FCAMD_OK;
+}
+
+int fcamd_context_set_stream(fcamd_context* c, void* stream) {
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    if (c->owns_stream && c->stream) {
+        (void)hipStreamDestroy(c->stream);
+        c->owns_stream = false;
+    }
+    c->stream = static_cast<hipStream_t>(stream);
+    return FCAMD_OK;
+}
+
+int fcamd_context_synchronize(fcamd_context* c) {
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FCAMD_OK;
+}
+
+int fcamd_context_set_grid(fcamd_context* c, int n_workgroups) {
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    c->grid_override = n_workgroups > 0 ? n_workgroups : 0;
+    return FCAMD_OK;
+}
+
+int fcamd_context_set_timing(fcamd_context* c, int enabled) {
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    c->timing = enabled != 0;
+    return FCAMD_OK;
+}
+
+int fcamd_model_create(fcamd_context* c, int model_id, int constraint, const double* params,
+                       int n_params, fcamd_model** out) {
+    if (!out) return fail(FCAMD_ERR_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    LawInfo li;
+    if (!law_info(model_id, &li)) return fail(FCAMD_ERR_BAD_ARG, "unknown model id %d", model_id);
+    if (constraint != FCAMD_FULL)
+        return fail(FCAMD_ERR_UNSUPPORTED,
+                    "only StressStrainConstraint.FULL has device kernels (got %d)", constraint);
+    if (!params || n_params != li.n_params)
+        return fail(FCAMD_ERR_BAD_ARG, "model %d expects %d parameters, got %d", model_id,
+                    li.n_params, n_params);
+    HIP_TRY(hipSetDevice(c->device));
+    fcamd_model* m = new (std::nothrow) fcamd_model();
+    if (!m) return fail(FCAMD_ERR_BAD_ARG, "out of host memory");
+    m->ctx = c;
+    m->law = model_id;
+    m->info = li;
+    for (int i = 0; i < n_params; ++i) m->params[i] = params[i];
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_counters), 4 * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), 4 * sizeof(unsigned long long),
+                          hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemset(m->d_counters, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&m->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&m->ev1);
+    if (e != hipSuccess) {
+        fcamd_model_destroy(m);
+        return fail(FCAMD_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
+    }
+    std::memset(m->h_counters, 0, 4 * sizeof(unsigned long long));
+    *out = m;
+    return FCAMD_OK;
+}
+
+int fcamd_model_destroy(fcamd_model* m) {
+    if (!m) return FCAMD_OK;
+    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    if (m->d_counters) (void)hipFree(m->d_counters);
+    if (m->h_counters) (void)hipHostFree(m->h_counters);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    delete m;
+    return FCAMD_OK;
+}
+
+int fcamd_model_history_count(const fcamd_model* m, int* n_fields) {
+    if (!m || !n_fields) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    *n_fields = m->info.n_hist;
+    return FCAMD_OK;
+}
+
+int fcamd_model_history_field(const fcamd_model* m, int k, const char** name, int* dim) {
+    if (!m || !name || !dim) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    if (k < 0 || k >= m->info.n_hist) return fail(FCAMD_ERR_BAD_ARG, "history field %d out of range", k);
+    *name = m->info.hist[k].name;
+    *dim = m->info.hist[k].dim;
+    return FCAMD_OK;
+}
+
+int fcamd_evaluate_device_from(fcamd_model* m, double t, double del_t, int64_t n,
+                               const double* grad, const double* stress_prev, double* stress,
+                               double* tangent, const double* const* hist_prev,
+                               double* const* hist, int n_hist) {
+    (void)t;
+    int st = validate_call(m, del_t, n, grad, stress_prev, stress,
+                           reinterpret_cast<const void* const*>(hist_prev),
+                           reinterpret_cast<const void* const*>(hist), n_hist);
+    if (st != FCAMD_OK) return st;
+    if (!aligned16(grad) || !aligned16(stress) || !aligned16(stress_prev) || !aligned16(tangent))
+        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
+    for (int k = 0; k < m->info.n_hist; ++k)
+        if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
+            return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
+    fcamd_context* c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    m->timed = c->timing;
+    if (m->timed) {
+        // counters are reset before the timed window so that the events bracket the kernel only
+        HIP_TRY(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipEventRecord(m->ev0, c->stream));
+    }
+    st = enqueue(m, del_t, n, grad, stress_prev, stress, tangent, hist_prev, hist, c->stream,
+                 !m->timed);
+    if (st != FCAMD_OK) return st;
+    if (m->timed) HIP_TRY(hipEventRecord(m->ev1, c->stream));
+    return FCAMD_OK;
+}
+
+int fcamd_evaluate_device(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
+                          double* stress, double* tangent, double* const* hist, int n_hist) {
+    return fcamd_evaluate_device_from(m, t, del_t, n, grad, stress, stress, tangent,
+                                      const_cast<const double* const*>(hist), hist, n_hist);
+}
+
+int fcamd_model_last_stats(fcamd_model* m, fcamd_stats* stats) {
+    if (!m || !stats) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    return read_stats(m, m->ctx->stream, stats);
+}
+
+int fcamd_model_last_kernel_ms(fcamd_model* m, float* ms) {
+    if (!m || !ms) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    if (!m->timed) return fail(FCAMD_ERR_BAD_ARG, "timing was not enabled for the last launch");
+    HIP_TRY(hipEventSynchronize(m->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, m->ev0, m->ev1));
+    return FCAMD_OK;
+}
+
+int fcamd_strain_from_grad_u_device(fcamd_context* c, int64_t n, const double* grad_u,
+                                    double* strain, int rust_factor) {
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
+    if (n == 0) return FCAMD_OK;
+    if (!grad_u || !strain) return fail(FCAMD_ERR_BAD_ARG, "NULL array");
+    if (!aligned16(grad_u) || !aligned16(strain))
+        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    int grid = c->grid_override > 0 ? c->grid_override : c->num_cu * 8;
+    const int64_t need = ((n + 63) / 64 + 3) / 4;
+    if (need < grid) grid = (int)std::max<int64_t>(need, 1);
+    HIP_TRY(launch_strain(grad_u, strain, n, rust_factor ? kFactorRs : kFactorPy, grid, c->stream));
+    return FCAMD_OK;
+}
+
+int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
+    if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->registered.count(ptr)) return FCAMD_OK;
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    c->registered[ptr] = bytes;
+    return FCAMD_OK;
+}
+
+int fcamd_unregister_host_buffer(fcamd_context* c, void* ptr) {
+    if (!c || !ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    auto it = c->registered.find(ptr);
+    if (it == c->registered.end()) return FCAMD_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostUnregister(ptr));
+    c->registered.erase(it);
+    return FCAMD_OK;
+}
+
+// Host (ndarray) entry: chunked H2D -> kernel -> D2H, two chunk slots on two streams so that
+// the copies of one chunk overlap the kernel of the other when the caller's arrays are
+// page-locked (fcamd_register_host_buffer); pageable arrays are staged by the HIP runtime.
+int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
+                        double* stress, double* tangent, double* const* hist, int n_hist,
+                        fcamd_stats* stats) {
+    (void)t;
+    int st = validate_call(m, del_t, n, grad, stress, stress,
+                           reinterpret_cast<const void* const*>(hist),
+                           reinterpret_cast<const void* const*>(hist), n_hist);
+    if (st != FCAMD_OK) return st;
+    fcamd_context* c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+
+    // per-point doubles on the device: grad 9, stress 6, tangent 36, history
+    int hdim_total = 0;
+    for (int k = 0; k < m->info.n_hist; ++k) hdim_total += m->info.hist[k].dim;
+    const size_t per_point = 9 + 6 + 36 + (size_t)hdim_total;
+    constexpr int64_t kChunk = 1 << 18;  // points per chunk (multiple of 64)
+    const int64_t chunk = std::min<int64_t>(kChunk, ((n + 63) / 64) * 64);
+    if (chunk > 0 && (size_t)chunk > c->dchunk_points) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->dchunk[i]) HIP_TRY(hipFree(c->dchunk[i]));
+            c->dchunk[i] = nullptr;
+        }
+        c->dchunk_points = 0;
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dchunk[i]), (size_t)chunk * 64 * sizeof(double)));
+        c->dchunk_points = (size_t)chunk;
+    }
+    (void)per_point;
+    for (int i = 0; i < 2; ++i)
+        if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
+
+    HIP_TRY(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), c->hstream[0]));
+    HIP_TRY(hipStreamSynchronize(c->hstream[0]));
+
+    int slot = 0;
+    for (int64_t p0 = 0; p0 < n; p0 += chunk, slot ^= 1) {
+        const int64_t np = std::min<int64_t>(chunk, n - p0);
+        hipStream_t s = c->hstream[slot];
+        // device layout of a slot (each sub-array starts 16-byte aligned: chunk is a multiple of 64)
+        double* d_grad = c->dchunk[slot];
+        double* d_stress = d_grad + 9 * c->dchunk_points;
+        double* d_tan = d_stress + 6 * c->dchunk_points;
+        double* d_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+        double* cur = d_tan + 36 * c->dchunk_points;
+        for (int k = 0; k < m->info.n_hist; ++k) {
+            d_hist[k] = cur;
+            cur += (size_t)m->info.hist[k].dim * c->dchunk_points;
+            // keep 16-byte alignment for odd per-point dimensions (alpha: 1, comfe history: 7)
+            if ((reinterpret_cast<uintptr_t>(cur) & 15u) != 0) cur += 1;
+        }
+        HIP_TRY(hipMemcpyAsync(d_grad, grad + 9 * p0, (size_t)np * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_stress, stress + 6 * p0, (size_t)np * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+        for (int k = 0; k < m->info.n_hist; ++k) {
+            const size_t d = (size_t)m->info.hist[k].dim;
+            HIP_TRY(hipMemcpyAsync(d_hist[k], hist[k] + d * p0, (size_t)np * d * sizeof(double), hipMemcpyHostToDevice, s));
+        }
+        st = enqueue(m, del_t, np, d_grad, d_stress, d_stress, tangent ? d_tan : nullptr, d_hist, d_hist, s, false);
+        if (st != FCAMD_OK) return st;
+        HIP_TRY(hipMemcpyAsync(stress + 6 * p0, d_stress, (size_t)np * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (tangent)
+            HIP_TRY(hipMemcpyAsync(tangent + 36 * p0, d_tan, (size_t)np * 36 * sizeof(double), hipMemcpyDeviceToHost, s));
+        for (int k = 0; k < m->info.n_hist; ++k) {
+            const size_t d = (size_t)m->info.hist[k].dim;
+            HIP_TRY(hipMemcpyAsync(hist[k] + d * p0, d_hist[k], (size_t)np * d * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->hstream[0]));
+    HIP_TRY(hipStreamSynchronize(c->hstream[1]));
+    fcamd_stats local;
+    st = read_stats(m, c->hstream[0], &local);
+    if (st != FCAMD_OK) return st;
+    if (stats) *stats = local;
+    if (local.n_nonconverged > 0)
+        return fail(FCAMD_ERR_NONCONVERGED,
+                    "Newton-Raphson method did not converge for plastic multiplier.");
+    return FCAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Internal interface between the C-ABI layer (fcamd_capi.cpp) and the HIP kernels
+// (fcamd_kernels.hip).  Not installed; the public boundary is include/fcamd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fcamd {
+
+// Law ids double as template arguments of the kernel (values = fcamd_model_id).
+enum Law : int {
+    LAW_LE = 1,
+    LAW_VM3D = 2,
+    LAW_MAXWELL = 3,
+    LAW_KELVIN = 4,
+    LAW_COMFE_LE = 5,
+    LAW_COMFE_MISES = 6,
+};
+
+// Three 6x6 tables staged into LDS by every workgroup; meaning depends on the law
+// (see fill_constants in fcamd_capi.cpp).
+struct Tables {
+    double a[36];
+    double b[36];
+    double c[36];
+};
+
+// Scalar constants, pre-computed on the host with the reference's own expression
+// order so that device results can match NumPy bit for bit.
+struct Scalars {
+    double s[16];
+};
+
+struct EvalArgs {
+    const double* grad;        // [9n]
+    const double* stress_in;   // [6n] committed stress (may alias stress_out)
+    double* stress_out;        // [6n]
+    double* tangent;           // [36n] or nullptr
+    const double* h0_in;       // first history field (may alias h0_out) or nullptr
+    double* h0_out;
+    const double* h1_in;       // second history field or nullptr
+    double* h1_out;
+    long long n;               // quadrature points
+    unsigned long long* counters;  // [4]: nonconverged, plastic, newton iterations, reserved
+    Scalars sc;
+    Tables tb;
+};
+
+// Launch the evaluate kernel of `law` on `stream` with `grid` workgroups of 256 threads.
+hipError_t launch_evaluate(int law, const EvalArgs& args, int grid, hipStream_t stream);
+// Occupancy-derived default grid (workgroups) for `law` on the current device.
+int default_grid(int law, int num_cu);
+// strain_from_grad_u, FULL.
+hipError_t launch_strain(const double* grad, double* strain, long long n, double factor, int grid,
+                         hipStream_t stream);
+
+}  // namespace fcamd

@@ -1,0 +1,770 @@
+// HIP kernels (gfx950 / CDNA4) for the quadrature-point constitutive update.
+//
+// Execution model
+//   * one quadrature point per lane, one 64-point tile per wavefront iteration,
+//     persistent grid (tiles are dealt round-robin to all resident wavefronts);
+//   * the caller's arrays stay in the reference's point-major AoS layout in HBM.  Every
+//     global access is a wave-contiguous 16-byte-per-lane stream (1 KiB per instruction);
+//     the AoS<->lane transposition happens in a small wave-private LDS region, so no
+//     workgroup barrier is needed inside the tile loop;
+//   * the 36-double tangent (288 of the 456-648 bytes per point) is never staged as a
+//     matrix: laws with a constant tangent stream it from an LDS-resident table; the
+//     plasticity laws publish 8 doubles per point (two scalars + the flow direction) to LDS
+//     and every lane rebuilds the two tangent entries of the 16-byte chunk it stores;
+//   * material constants are pre-computed on the host in the reference's expression order
+//     and reach the kernel as kernel arguments; the 6x6 tables are staged into LDS once per
+//     workgroup;
+//   * the elastic/plastic branch is taken per wavefront from a 64-bit ballot: fully elastic
+//     tiles skip the Newton iteration and (in place) the plastic-strain traffic.
+//
+// Arithmetic follows the reference operation by operation (compiled with
+// -ffp-contract=off; fma() only where NumPy/OpenBLAS use one: the n x 6 . 6 x 6 products and
+// the 6-term dot product, both verified to be ascending-k FMA chains).
+//
+// Reference algorithms restated here (never copied):
+//   strain:   src/fenics_constitutive/models/utils.py:187-208, comfe-rs/src/mandel.rs:143-171
+//   LE:       models/linear_elasticity_model.py:26-45
+//   VonMises: models/mises_plasticity_isotropic_hardening.py:57-175
+//   Maxwell:  models/spring_maxwell_model.py:40-88      Kelvin: models/spring_kelvin_model.py:43-88
+//   comfe LE: comfe-rs/src/linear_elasticity.rs:49-74   comfe Mises: comfe-rs/src/mises_plasticity.rs:58-126
+#include "fcamd_internal.h"
+
+namespace fcamd {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+// wave-private LDS region: 64 points x 10 doubles (largest user: tangent parameters)
+constexpr int kRegionDoubles = 64 * 10;
+
+// ---------------------------------------------------------------------------------------
+// wave-level helpers
+// ---------------------------------------------------------------------------------------
+
+// Order LDS traffic between the lanes of one wavefront.  The hardware executes a wave's DS
+// instructions in order; this only pins the compiler.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool NT>
+__device__ __forceinline__ d2 load16(const double* p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(reinterpret_cast<const d2*>(p));
+    else
+        return *reinterpret_cast<const d2*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void store16(double* p, d2 v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, reinterpret_cast<d2*>(p));
+    else
+        *reinterpret_cast<d2*>(p) = v;
+}
+
+// A 64-point tile of an AoS array with NC doubles per point is 32*NC contiguous 16-byte
+// chunks; lane l owns chunks l, l+64, ...  (K = ceil(NC/2) per lane, the last one only on
+// lanes < 32 when NC is odd).
+template <int NC>
+struct Chunks {
+    static constexpr int K = (NC + 1) / 2;
+    d2 v[K];
+};
+
+template <int NC, int K>
+__device__ __forceinline__ bool chunk_live(int k, int lane) {
+    return (2 * (k + 1) <= NC) || lane < 32;
+}
+
+// global -> registers.  FULL: whole tile, 16-byte loads.  Otherwise (last, ragged tile):
+// guarded 8-byte loads of the `nelem` valid doubles.
+template <int NC, bool FULL, bool NT>
+__device__ __forceinline__ void tile_load(Chunks<NC>& c, const double* src, int nelem, int lane) {
+#pragma unroll
+    for (int k = 0; k < Chunks<NC>::K; ++k) {
+        const int q = k * kWave + lane;
+        if constexpr (FULL) {
+            if (chunk_live<NC, Chunks<NC>::K>(k, lane)) c.v[k] = load16<NT>(src + 2 * q);
+        } else {
+            const int e = 2 * q;
+            c.v[k].x = e < nelem ? src[e] : 0.0;
+            c.v[k].y = e + 1 < nelem ? src[e + 1] : 0.0;
+        }
+    }
+}
+
+// registers -> LDS (linear image of the tile)
+template <int NC>
+__device__ __forceinline__ void tile_to_lds(const Chunks<NC>& c, double* lds, int lane) {
+#pragma unroll
+    for (int k = 0; k < Chunks<NC>::K; ++k) {
+        const int q = k * kWave + lane;
+        if (chunk_live<NC, Chunks<NC>::K>(k, lane)) reinterpret_cast<d2*>(lds)[q] = c.v[k];
+    }
+}
+
+// registers -> global
+template <int NC, bool FULL, bool NT>
+__device__ __forceinline__ void tile_store(const Chunks<NC>& c, double* dst, int nelem, int lane) {
+#pragma unroll
+    for (int k = 0; k < Chunks<NC>::K; ++k) {
+        const int q = k * kWave + lane;
+        if constexpr (FULL) {
+            if (chunk_live<NC, Chunks<NC>::K>(k, lane)) store16<NT>(dst + 2 * q, c.v[k]);
+        } else {
+            const int e = 2 * q;
+            if (e < nelem) dst[e] = c.v[k].x;
+            if (e + 1 < nelem) dst[e + 1] = c.v[k].y;
+        }
+    }
+}
+
+// LDS (linear image) -> global
+template <int NC, bool FULL, bool NT>
+__device__ __forceinline__ void lds_to_global(const double* lds, double* dst, int nelem, int lane) {
+    Chunks<NC> c;
+#pragma unroll
+    for (int k = 0; k < Chunks<NC>::K; ++k) {
+        const int q = k * kWave + lane;
+        if (chunk_live<NC, Chunks<NC>::K>(k, lane)) c.v[k] = reinterpret_cast<const d2*>(lds)[q];
+    }
+    tile_store<NC, FULL, NT>(c, dst, nelem, lane);
+}
+
+// per-lane view of the LDS image: the NC doubles of this lane's point
+template <int NC>
+__device__ __forceinline__ void lds_get_point(const double* lds, int lane, double (&x)[NC]) {
+    const double* p = lds + lane * NC;
+    if constexpr (NC % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < NC / 2; ++i) {
+            d2 v = reinterpret_cast<const d2*>(p)[i];
+            x[2 * i] = v.x;
+            x[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) x[i] = p[i];
+    }
+}
+template <int NC>
+__device__ __forceinline__ void lds_put_point(double* lds, int lane, const double (&x)[NC]) {
+    double* p = lds + lane * NC;
+    if constexpr (NC % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < NC / 2; ++i) {
+            d2 v;
+            v.x = x[2 * i];
+            v.y = x[2 * i + 1];
+            reinterpret_cast<d2*>(p)[i] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) p[i] = x[i];
+    }
+}
+
+// AoS tile -> per-lane point values, through the wave's LDS region.
+template <int NC>
+__device__ __forceinline__ void transpose_in(const Chunks<NC>& c, double* region, int lane,
+                                             double (&x)[NC]) {
+    tile_to_lds<NC>(c, region, lane);
+    wave_sync();
+    lds_get_point<NC>(region, lane, x);
+    wave_sync();
+}
+// per-lane point values -> AoS tile in global memory, through the wave's LDS region.
+template <int NC, bool FULL, bool NT>
+__device__ __forceinline__ void transpose_out(const double (&x)[NC], double* region, int lane,
+                                              double* dst, int nelem) {
+    lds_put_point<NC>(region, lane, x);
+    wave_sync();
+    lds_to_global<NC, FULL, NT>(region, dst, nelem, lane);
+    wave_sync();
+}
+
+// Mandel strain increment from the row-major 3x3 displacement-gradient increment.
+__device__ __forceinline__ void mandel_strain(const double (&g)[9], double f, double (&e)[6]) {
+    e[0] = g[0];
+    e[1] = g[4];
+    e[2] = g[8];
+    e[3] = f * (g[1] + g[3]);
+    e[4] = f * (g[2] + g[6]);
+    e[5] = f * (g[5] + g[7]);
+}
+
+// y_i = sum_k x_k * M[k][i] as an ascending-k FMA chain (what OpenBLAS dgemm does for the
+// reference's "strain.reshape(-1, 6) @ D"); M is an LDS-resident row-major 6x6 table.
+__device__ __forceinline__ void row_times_matrix_fma(const double (&x)[6], const double* M,
+                                                     double (&y)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double acc = x[0] * M[i];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc = __builtin_fma(x[k], M[6 * k + i], acc);
+        y[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// tangent writers
+// ---------------------------------------------------------------------------------------
+
+// Constant tangent (LE, SLS, comfe LE): every point gets the same 36 doubles = 18 chunks,
+// read from the LDS table `tab` (np.tile(D.flatten(), n) in the reference).
+template <bool FULL, bool NT>
+__device__ __forceinline__ void tangent_const(const double* tab, double* dst, int npts, int lane,
+                                              int r0 /* lane % 18 */) {
+    const int nchunks = npts * 18;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        int r = r0 + (10 * k) % 18;
+        r = r >= 18 ? r - 18 : r;
+        const int q = k * kWave + lane;
+        d2 v = reinterpret_cast<const d2*>(tab)[r];
+        if (FULL || q < nchunks) store16<NT>(dst + 2 * q, v);
+    }
+}
+
+// Point-dependent tangent of the two Mises laws.  Lane p has published
+//   tp[10p + 0] = B, tp[10p + 1] = C, tp[10p + 2 .. 7] = N   (stride 10: conflict-free b128)
+// and the tile's tangent is   T[p][i][j] = (ta[i][j] + B * tb[i][j]) + third(i, j)  with
+//   VonMises3D:   third = C * (N_i * N_j)      (aah, mises_plasticity_isotropic_hardening.py:170-175)
+//   comfe Mises:  third = (C * N_j) * N_i      (column-major .data.0 of ((2 mu theta_bar) n) n^T,
+//                                               mises_plasticity.rs:118-123)
+template <bool COMFE, bool FULL, bool NT>
+__device__ __forceinline__ void tangent_mises(const double* tp, const double* ta, const double* tb,
+                                              double* dst, int npts, int lane) {
+    const int nchunks = npts * 18;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const int q = k * kWave + lane;
+        const int p = q / 18;
+        const int r = q - 18 * p;
+        const int i = r / 3;
+        const int j = 2 * (r - 3 * i);
+        const double* t = tp + 10 * p;
+        const d2 bc = reinterpret_cast<const d2*>(t)[0];
+        const double ni = t[2 + i];
+        const d2 nj = *reinterpret_cast<const d2*>(t + 2 + j);
+        const d2 a = *reinterpret_cast<const d2*>(ta + 6 * i + j);
+        const d2 b = *reinterpret_cast<const d2*>(tb + 6 * i + j);
+        d2 v;
+        if constexpr (COMFE) {
+            v.x = (a.x + bc.x * b.x) + (bc.y * nj.x) * ni;
+            v.y = (a.y + bc.x * b.y) + (bc.y * nj.y) * ni;
+        } else {
+            v.x = (a.x + bc.x * b.x) + bc.y * (ni * nj.x);
+            v.y = (a.y + bc.x * b.y) + bc.y * (ni * nj.y);
+        }
+        if (FULL || q < nchunks) store16<NT>(dst + 2 * q, v);
+        // bound the register pressure: let the scheduler interleave at most 3 chunks
+        if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void publish_tangent_params(double* region, int lane, double B, double C,
+                                                       const double (&N)[6]) {
+    double* t = region + 10 * lane;
+    d2 v;
+    v.x = B;
+    v.y = C;
+    reinterpret_cast<d2*>(t)[0] = v;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v.x = N[2 * i];
+        v.y = N[2 * i + 1];
+        reinterpret_cast<d2*>(t)[1 + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// per-wave statistics
+// ---------------------------------------------------------------------------------------
+struct WaveStats {
+    unsigned long long nonconv = 0, plastic = 0, iters = 0;
+};
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// tile bodies, one per law.  `region` is the wave's LDS scratch, `T` the staged tables.
+// ---------------------------------------------------------------------------------------
+
+// --- LinearElasticityModel: sigma += d_eps @ D ; tangent = tile(D) ----------------------
+template <bool FULL, bool NT>
+__device__ __forceinline__ void tile_linear_elasticity(const EvalArgs& a, const Tables* T,
+                                                       double* region, long long p0, int npts,
+                                                       int lane, int r0) {
+    Chunks<9> cg;
+    Chunks<6> cs;
+    tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
+    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
+    // the constant tangent does not depend on the loads: stream it while they are in flight
+    if (a.tangent) tangent_const<FULL, NT>(T->c, a.tangent + p0 * 36, npts, lane, r0);
+    double g[9], s[6], e[6], ds[6];
+    transpose_in<9>(cg, region, lane, g);
+    transpose_in<6>(cs, region, lane, s);
+    mandel_strain(g, a.sc.s[0], e);
+    row_times_matrix_fma(e, T->a, ds);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s[i] = s[i] + ds[i];
+    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+}
+
+// --- comfe-rs LinearElasticity3D: sigma += C . d_eps (column axpy, no FMA) ---------------
+template <bool FULL, bool NT>
+__device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const Tables* T, double* region,
+                                              long long p0, int npts, int lane, int r0) {
+    Chunks<9> cg;
+    Chunks<6> cs;
+    tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
+    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
+    if (a.tangent) tangent_const<FULL, NT>(T->c, a.tangent + p0 * 36, npts, lane, r0);
+    double g[9], s[6], e[6];
+    transpose_in<9>(cg, region, lane, g);
+    transpose_in<6>(cs, region, lane, s);
+    mandel_strain(g, a.sc.s[0], e);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double acc = T->a[6 * i] * e[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) acc = T->a[6 * i + j] * e[j] + acc;
+        s[i] = s[i] + acc;
+    }
+    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+}
+
+// --- SLS Maxwell / Kelvin -----------------------------------------------------------------
+// scalars: s[0]=strain factor, s[1]=1/factor, s[2]=1/(tau*2*mu1), s[3]=1/tau,
+//          Maxwell: s[4]=2*mu1 ; Kelvin: s[4]=2*mu0, s[5]=mu0/(tau*mu1), s[6]=lam0/(tau*2*mu1)
+// tables:  Maxwell a=D1, b=D0+D1, c=tangent ; Kelvin a=D0, c=tangent
+template <bool KELVIN, bool FULL, bool NT>
+__device__ __forceinline__ void tile_sls(const EvalArgs& a, const Tables* T, double* region,
+                                         long long p0, int npts, int lane, int r0) {
+    Chunks<9> cg;
+    Chunks<6> cs, cv, cn;
+    tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
+    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
+    tile_load<6, FULL, NT>(cv, a.h0_in + p0 * 6, npts * 6, lane);  // strain_visco
+    tile_load<6, FULL, NT>(cn, a.h1_in + p0 * 6, npts * 6, lane);  // strain
+    if (a.tangent) tangent_const<FULL, NT>(T->c, a.tangent + p0 * 36, npts, lane, r0);
+    double g[9], s[6], ev[6], en[6], e[6], dv[6], y[6];
+    transpose_in<9>(cg, region, lane, g);
+    transpose_in<6>(cs, region, lane, s);
+    transpose_in<6>(cv, region, lane, ev);
+    transpose_in<6>(cn, region, lane, en);
+    mandel_strain(g, a.sc.s[0], e);
+    const double inv_factor = a.sc.s[1], cA = a.sc.s[2], cB = a.sc.s[3], c2mu = a.sc.s[4];
+    if constexpr (!KELVIN) {
+        // deps_v = 1/factor * ((cA * (eps_n + d_eps)) @ D1 - 1/tau * eps_v)
+        double x[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = cA * (en[i] + e[i]);
+        row_times_matrix_fma(x, T->a, y);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dv[i] = inv_factor * (y[i] - cB * ev[i]);
+        // sigma += d_eps @ (D0 + D1) - 2 mu1 deps_v
+        row_times_matrix_fma(e, T->b, y);
+    } else {
+        const double cC = a.sc.s[5], cD = a.sc.s[6];
+        const double tr = (e[0] + e[1]) + e[2];
+        const double ctr = cD * tr;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double id = i < 3 ? ctr : ctr * 0.0;
+            dv[i] = inv_factor * (((cA * s[i] - cB * ev[i]) + cC * e[i]) + id);
+        }
+        // sigma += d_eps @ D0 - 2 mu0 deps_v
+        row_times_matrix_fma(e, T->a, y);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        s[i] = s[i] + (y[i] - c2mu * dv[i]);
+        ev[i] = ev[i] + dv[i];
+        en[i] = en[i] + e[i];
+    }
+    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+    transpose_out<6, FULL, NT>(ev, region, lane, a.h0_out + p0 * 6, npts * 6);
+    transpose_out<6, FULL, NT>(en, region, lane, a.h1_out + p0 * 6, npts * 6);
+}
+
+// --- VonMises3D: J2 plasticity, saturation hardening, scalar Newton per point -----------------
+// scalars: s[0]=strain factor, s[1]=ka, s[2]=2*mu, s[3]=sqrt(2/3), s[4]=y0, s[5]=y00-y0,
+//          s[6]=-w, s[7]=(-2)*mu, s[8]=((2/3)*(y00-y0))*w, s[9]=(4*mu)*mu
+// tables:  a = ka*xioi, b = xpp
+template <bool FULL, bool NT>
+__device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* T, double* region,
+                                               long long p0, int npts, int lane, WaveStats& st) {
+    Chunks<9> cg;
+    Chunks<6> cs;
+    tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
+    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
+    const bool live = FULL || lane < npts;
+    const double alpha_n = live ? a.h1_in[p0 + lane] : 0.0;
+    const bool hist_in_place = (a.h0_in == a.h0_out) && (a.h1_in == a.h1_out);
+
+    double g[9], s[6], e[6];
+    transpose_in<9>(cg, region, lane, g);
+    transpose_in<6>(cs, region, lane, s);
+    mandel_strain(g, a.sc.s[0], e);
+
+    const double ka = a.sc.s[1], two_mu = a.sc.s[2], s23 = a.sc.s[3], y0 = a.sc.s[4], dy = a.sc.s[5],
+                 mw = a.sc.s[6], m2mu = a.sc.s[7], c23dyw = a.sc.s[8], four_mu2 = a.sc.s[9];
+
+    const double tr_eps = (e[0] + e[1]) + e[2];
+    const double tr_sig = (s[0] + s[1]) + s[2];
+    const double tr_eps3 = tr_eps / 3.0, tr_sig3 = tr_sig / 3.0;
+    double dsig[6], sigtr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double ed = i < 3 ? e[i] - tr_eps3 : e[i];
+        const double sd = i < 3 ? s[i] - tr_sig3 : s[i];
+        dsig[i] = two_mu * ed;
+        sigtr[i] = sd + dsig[i];
+    }
+    double nn = sigtr[0] * sigtr[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) nn = __builtin_fma(sigtr[i], sigtr[i], nn);  // np.dot == fma chain
+    const double sigtrn = sqrt(nn);
+    const double phitr = sigtrn - s23 * (y0 + dy * (1.0 - exp(mw * alpha_n)));
+
+    const bool plastic = live && (phitr > 0.0);
+    const unsigned long long mask = __ballot(plastic);
+
+    // plastic-strain history: needed only by tiles with a plastic point (in place), or always
+    // when the trial history lives in a different array (out of place).
+    Chunks<6> ce;
+    const bool touch_eps = (mask != 0ull) || !hist_in_place;
+    if (touch_eps) tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
+
+    double gamma = 0.0, xc1 = 0.0, xc2 = 0.0;
+    double N[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (mask != 0ull) {
+        if (plastic) {
+            double g0 = 1.0, g1 = 0.0, xr = 1.0, xg;
+            int it = 0;
+            bool failed = false;
+            while (__builtin_fabs(xr) > 1e-12 &&
+                   __builtin_fabs(g1 - g0) > 1e-8 * __builtin_fabs(g1)) {
+                g0 = g1;
+                ++it;
+                const double ex = exp(mw * (alpha_n + s23 * g0));
+                xr = (sigtrn - two_mu * g0) - s23 * (y0 + dy * (1.0 - ex));
+                xg = m2mu - c23dyw * ex;
+                g1 = g0 - xr / xg;
+                if (it > 100) {
+                    failed = true;
+                    break;
+                }
+            }
+            const double ex = exp(mw * (alpha_n + s23 * g1));
+            xg = m2mu - c23dyw * ex;
+            xc1 = -1.0 / xg;
+            xc2 = g1 / sigtrn;
+            gamma = g1;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) N[i] = sigtr[i] / sigtrn;
+            st.iters += (unsigned long long)it;
+            st.nonconv += failed ? 1ull : 0ull;
+        }
+        st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
+    }
+
+    // stress: sigma += (ka tr_eps) I2 + del_sigtr - (2 mu gamma) N
+    const double kt = ka * tr_eps, tmg = two_mu * gamma;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double vol = i < 3 ? kt : kt * 0.0;
+        s[i] = s[i] + ((vol + dsig[i]) - tmg * N[i]);
+    }
+    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+
+    // history: eps_n += gamma N ; alpha += sqrt(2/3) gamma
+    if (touch_eps) {
+        if (mask != 0ull) {
+            double ep[6];
+            transpose_in<6>(ce, region, lane, ep);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ep[i] = ep[i] + gamma * N[i];
+            transpose_out<6, FULL, NT>(ep, region, lane, a.h0_out + p0 * 6, npts * 6);
+        } else {
+            tile_store<6, FULL, NT>(ce, a.h0_out + p0 * 6, npts * 6, lane);
+        }
+        if (live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
+    }
+
+    // tangent: ka xioi + 2 mu (1 - 2 mu xc2) xpp + 4 mu^2 (xc2 - xc1) N (x) N
+    if (a.tangent) {
+        const double B = two_mu * (1.0 - two_mu * xc2);
+        const double C = four_mu2 * (xc2 - xc1);
+        publish_tangent_params(region, lane, B, C, N);
+        wave_sync();
+        tangent_mises<false, FULL, NT>(region, T->a, T->b, a.tangent + p0 * 36, npts, lane);
+        wave_sync();
+    }
+}
+
+// --- comfe-rs MisesPlasticity3D: linear hardening, closed-form radial return ---------------
+// scalars: s[0]=strain factor (FRAC_1_SQRT_2), s[1]=mu, s[2]=kappa, s[3]=y_0, s[4]=h,
+//          s[5]=2*mu, s[6]=3*mu+h, s[7]=sqrt(3/2), s[8]=3*mu, s[9]=1/(1+h/(3 mu))
+// tables:  a = kappa*sym_id(x)sym_id, b = P_dev.   history field 0: [alpha, eps_p(6)] per point.
+template <bool FULL, bool NT>
+__device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Tables* T, double* region,
+                                                 long long p0, int npts, int lane, WaveStats& st) {
+    Chunks<9> cg;
+    Chunks<6> cs;
+    Chunks<7> ch;
+    tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
+    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
+    tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
+    const bool live = FULL || lane < npts;
+    const bool hist_in_place = (a.h0_in == a.h0_out);
+
+    double g[9], s[6], h[7], e[6];
+    transpose_in<9>(cg, region, lane, g);
+    transpose_in<6>(cs, region, lane, s);
+    transpose_in<7>(ch, region, lane, h);
+    mandel_strain(g, a.sc.s[0], e);
+
+    const double kappa = a.sc.s[2], y_0 = a.sc.s[3], hh = a.sc.s[4], two_mu = a.sc.s[5],
+                 den = a.sc.s[6], s32 = a.sc.s[7], three_mu = a.sc.s[8], hfac = a.sc.s[9];
+    const double alpha = h[0];
+
+    // (p_0, s_0) = vol_dev(sigma) ; (tr, dev) = trace_dev(d_eps)
+    const double p_0 = ((s[0] + s[1]) + s[2]) / 3.0;
+    const double eps_trace = (e[0] + e[1]) + e[2];
+    const double eps_vol = eps_trace / 3.0;
+    const double p_1 = p_0 + kappa * eps_trace;
+    double s_tr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double s0 = i < 3 ? s[i] + (-p_0) : s[i];
+        const double ed = i < 3 ? e[i] + (-eps_vol) : e[i];
+        s_tr[i] = s0 + two_mu * ed;
+    }
+    // mises_norm(): deviator once more, sqrt(3 * (0.5 * |dev|^2)), sequential sum
+    const double v3 = ((s_tr[0] + s_tr[1]) + s_tr[2]) / 3.0;
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double d = i < 3 ? s_tr[i] + (-v3) : s_tr[i];
+        n2 = i == 0 ? d * d : n2 + d * d;
+    }
+    const double q = sqrt(3.0 * (0.5 * n2));
+    const double sigma_y = y_0 + hh * alpha;
+    const bool plastic = live && !(q < sigma_y);
+    const unsigned long long mask = __ballot(plastic);
+
+    double theta = 1.0, sc = 0.0;  // sc = 2 mu theta_bar
+    double nv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (plastic) {
+        const double del_alpha = (q - sigma_y) / den;
+        const double del_gamma = s32 * del_alpha;
+        theta = 1.0 - (three_mu * del_alpha) / q;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            nv[i] = s_tr[i] / q;
+            h[1 + i] = h[1 + i] + del_gamma * nv[i];
+        }
+        h[0] = alpha + del_alpha;
+        const double theta_bar = hfac - (1.0 - theta);
+        sc = two_mu * theta_bar;
+    }
+    st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
+
+    // total (not incremental) stress:  p_1 1 + theta s_tr   (elastic: theta == 1 exactly)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double ts = theta * s_tr[i];
+        s[i] = i < 3 ? p_1 + ts : ts;
+    }
+    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+    if (mask != 0ull || !hist_in_place)
+        transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+
+    if (a.tangent) {
+        const double B = plastic ? two_mu * theta : two_mu;
+        publish_tangent_params(region, lane, B, sc, nv);
+        wave_sync();
+        tangent_mises<true, FULL, NT>(region, T->a, T->b, a.tangent + p0 * 36, npts, lane);
+        wave_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------
+template <int LAW, bool FULL, bool NT>
+__device__ __forceinline__ void run_tile(const EvalArgs& a, const Tables* T, double* region,
+                                         long long p0, int npts, int lane, int r0, WaveStats& st) {
+    // Everything derived from the lane id (chunk -> point/row/column maps, LDS and global
+    // offsets) is tile-invariant; left alone, LICM hoists ~100 such values out of the
+    // persistent loop and spills them.  Laundering the lane id per tile keeps them as
+    // cheap per-tile integer VALU work instead.
+    asm volatile("" : "+v"(lane));
+    asm volatile("" : "+v"(r0));
+    if constexpr (LAW == LAW_LE)
+        tile_linear_elasticity<FULL, NT>(a, T, region, p0, npts, lane, r0);
+    else if constexpr (LAW == LAW_COMFE_LE)
+        tile_comfe_le<FULL, NT>(a, T, region, p0, npts, lane, r0);
+    else if constexpr (LAW == LAW_MAXWELL)
+        tile_sls<false, FULL, NT>(a, T, region, p0, npts, lane, r0);
+    else if constexpr (LAW == LAW_KELVIN)
+        tile_sls<true, FULL, NT>(a, T, region, p0, npts, lane, r0);
+    else if constexpr (LAW == LAW_VM3D)
+        tile_von_mises<FULL, NT>(a, T, region, p0, npts, lane, st);
+    else
+        tile_comfe_mises<FULL, NT>(a, T, region, p0, npts, lane, st);
+}
+
+__device__ __forceinline__ void stage_tables(const EvalArgs& a, Tables* T) {
+    const double* src = reinterpret_cast<const double*>(&a.tb);
+    double* dst = reinterpret_cast<double*>(T);
+    for (int i = threadIdx.x; i < 108; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+template <int LAW>
+__device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& st, int lane) {
+    if constexpr (LAW == LAW_VM3D || LAW == LAW_COMFE_MISES) {
+        const unsigned long long nc = wave_sum(st.nonconv);
+        const unsigned long long np = wave_sum(st.plastic);
+        const unsigned long long ni = wave_sum(st.iters);
+        if (lane == 0) {
+            if (nc) atomicAdd(a.counters + 0, nc);
+            if (np) atomicAdd(a.counters + 1, np);
+            if (ni) atomicAdd(a.counters + 2, ni);
+        }
+    }
+}
+
+// Main kernel: all full 64-point tiles.  Persistent: wave w of the grid takes tiles
+// w, w + W, w + 2W, ...
+template <int LAW, bool NT>
+__global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
+    __shared__ __attribute__((aligned(16))) Tables T;
+    __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
+    stage_tables(a, &T);
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    double* region = scratch[wave];
+    const int r0 = lane % 18;
+    const long long nfull = a.n / kWave;
+    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
+    WaveStats st;
+    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
+        run_tile<LAW, true, NT>(a, &T, region, tile * kWave, kWave, lane, r0, st);
+    flush_stats<LAW>(a, st, lane);
+}
+
+// Tail kernel: the last, ragged tile (n % 64 points), one wavefront, guarded 8-byte accesses.
+template <int LAW>
+__global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) {
+    __shared__ __attribute__((aligned(16))) Tables T;
+    __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
+    stage_tables(a, &T);
+    const int lane = threadIdx.x;
+    const long long p0 = (a.n / kWave) * kWave;
+    WaveStats st;
+    run_tile<LAW, false, false>(a, &T, region, p0, (int)(a.n - p0), lane, lane % 18, st);
+    flush_stats<LAW>(a, st, lane);
+}
+
+// strain_from_grad_u (FULL): [9n] -> [6n]
+template <bool NT>
+__global__ void __launch_bounds__(kBlock)
+    strain_kernel(const double* grad, double* strain, long long n, double factor) {
+    __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    double* region = scratch[wave];
+    const long long ntiles = (n + kWave - 1) / kWave;
+    const long long nfull = n / kWave;
+    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
+    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
+         tile += wstride) {
+        const long long p0 = tile * kWave;
+        Chunks<9> cg;
+        double g[9], e[6];
+        if (tile < nfull) {
+            tile_load<9, true, NT>(cg, grad + p0 * 9, kWave * 9, lane);
+            transpose_in<9>(cg, region, lane, g);
+            mandel_strain(g, factor, e);
+            transpose_out<6, true, NT>(e, region, lane, strain + p0 * 6, kWave * 6);
+        } else {
+            const int npts = (int)(n - p0);
+            tile_load<9, false, NT>(cg, grad + p0 * 9, npts * 9, lane);
+            transpose_in<9>(cg, region, lane, g);
+            mandel_strain(g, factor, e);
+            transpose_out<6, false, NT>(e, region, lane, strain + p0 * 6, npts * 6);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------
+constexpr bool kNT = true;
+
+template <int LAW>
+static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream) {
+    if (args.n >= kWave)
+        hipLaunchKernelGGL((evaluate_kernel<LAW, kNT>), dim3(grid), dim3(kBlock), 0, stream, args);
+    if (args.n % kWave != 0)
+        hipLaunchKernelGGL((evaluate_tail_kernel<LAW>), dim3(1), dim3(kWave), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_evaluate(int law, const EvalArgs& args, int grid, hipStream_t stream) {
+    switch (law) {
+        case LAW_LE: return launch_law<LAW_LE>(args, grid, stream);
+        case LAW_VM3D: return launch_law<LAW_VM3D>(args, grid, stream);
+        case LAW_MAXWELL: return launch_law<LAW_MAXWELL>(args, grid, stream);
+        case LAW_KELVIN: return launch_law<LAW_KELVIN>(args, grid, stream);
+        case LAW_COMFE_LE: return launch_law<LAW_COMFE_LE>(args, grid, stream);
+        case LAW_COMFE_MISES: return launch_law<LAW_COMFE_MISES>(args, grid, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int LAW>
+static int occupancy_of() {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, evaluate_kernel<LAW, kNT>, kBlock, 0) !=
+            hipSuccess ||
+        blocks <= 0)
+        blocks = 2;
+    return blocks;
+}
+
+int default_grid(int law, int num_cu) {
+    int per_cu = 2;
+    switch (law) {
+        case LAW_LE: per_cu = occupancy_of<LAW_LE>(); break;
+        case LAW_VM3D: per_cu = occupancy_of<LAW_VM3D>(); break;
+        case LAW_MAXWELL: per_cu = occupancy_of<LAW_MAXWELL>(); break;
+        case LAW_KELVIN: per_cu = occupancy_of<LAW_KELVIN>(); break;
+        case LAW_COMFE_LE: per_cu = occupancy_of<LAW_COMFE_LE>(); break;
+        case LAW_COMFE_MISES: per_cu = occupancy_of<LAW_COMFE_MISES>(); break;
+    }
+    return per_cu * num_cu;
+}
+
+hipError_t launch_strain(const double* grad, double* strain, long long n, double factor, int grid,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL((strain_kernel<kNT>), dim3(grid), dim3(kBlock), 0, stream, grad, strain, n,
+                       factor);
+    return hipGetLastError();
+}
+
+}  // namespace fcamd

@@ -1,0 +1,203 @@
+"""Array plumbing between the ndarray interface and the C ABI.
+
+Two kinds of arrays are accepted everywhere the reference takes ``np.ndarray``:
+
+* ``numpy.ndarray`` (float64, C-contiguous)  -> host path, ``fcamd_evaluate_host``:
+  the library stages the arrays to the GPU, runs the kernel and writes the results back in
+  place.  This is the drop-in path for dolfinx ``Function.x.array`` views.
+* ``torch.Tensor`` on a ROCm device (float64, contiguous) -> device path,
+  ``fcamd_evaluate_device`` on torch's current stream, zero copies.
+
+PyTorch is used for device memory and streams only.  No CPU fallback exists: without the
+built library and a GPU, evaluation raises.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi
+from .interfaces import IncrSmallStrainModel, StressStrainConstraint
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def _check_numpy(name: str, a: np.ndarray) -> np.ndarray:
+    if not isinstance(a, np.ndarray):
+        raise TypeError(f"{name} must be a numpy.ndarray or a torch CUDA tensor, got {type(a).__name__}")
+    if a.dtype != np.float64:
+        raise TypeError(f"{name} must be float64, got {a.dtype}")
+    if not a.flags.c_contiguous:
+        raise TypeError(f"{name} must be C-contiguous")
+    return a
+
+
+def _check_torch(name: str, a):
+    import torch
+
+    if a.dtype != torch.float64:
+        raise TypeError(f"{name} must be float64, got {a.dtype}")
+    if not a.is_cuda:
+        raise TypeError(f"{name} must live on the GPU (or be a numpy array)")
+    if not a.is_contiguous():
+        raise TypeError(f"{name} must be contiguous")
+    return a
+
+
+def _current_stream_ptr(device_index: int) -> int:
+    import torch
+
+    return int(torch.cuda.current_stream(device_index).cuda_stream)
+
+
+class DeviceLaw(IncrSmallStrainModel):
+    """Base of all GPU-backed laws: owns the C model handle (created lazily, per device)
+    and implements ``evaluate`` on top of the C ABI with the reference's validation."""
+
+    #: set by subclasses
+    _model_id: int = 0
+
+    def __init__(self, parameter_vector, constraint: StressStrainConstraint = None):
+        self._constraint = constraint if constraint is not None else StressStrainConstraint.FULL
+        self._parameter_vector = [float(p) for p in parameter_vector]
+        self._handles: dict[int, _capi.Model] = {}
+        self.last_stats = None
+
+    # -- interface properties --------------------------------------------------------------
+    @property
+    def constraint(self) -> StressStrainConstraint:
+        return self._constraint
+
+    # -- C handle ---------------------------------------------------------------------------
+    def _handle(self, device: int = 0) -> _capi.Model:
+        h = self._handles.get(device)
+        if h is None:
+            if self._constraint.name != "FULL":
+                raise NotImplementedError(
+                    f"{type(self).__name__}: only StressStrainConstraint.FULL has device kernels; "
+                    "wrap the 3-D model in PlaneStrainFrom3D / UniaxialStrainFrom3D"
+                )
+            ctx = _capi.get_context(device)
+            h = self._handles[device] = _capi.Model(ctx, self._model_id, self._constraint.value,
+                                                    self._parameter_vector)
+        return h
+
+    def _history_arrays(self, history):
+        """Order the caller's history dict by the law's field order."""
+        fields = self._history_fields()
+        if not fields:
+            return []
+        if history is None:
+            raise ValueError("history must not be None")
+        return [history[name] for name, _ in fields]
+
+    def _history_fields(self) -> list[tuple[str, int]]:
+        hd = self.history_dim
+        return [] if hd is None else list(hd.items())
+
+    # -- the hot call --------------------------------------------------------------------------
+    def evaluate(self, t, del_t, grad_del_u, stress, tangent, history) -> None:
+        """``IncrSmallStrainModel.evaluate`` (interfaces.py:82-101): overwrite ``stress``,
+        ``tangent`` and every history array in place."""
+        hist = self._history_arrays(history)
+        gd2 = self.geometric_dim**2
+        sd = self.stress_strain_dim
+        n = _size(grad_del_u) // gd2
+        # size assertion of the reference (linear_elasticity_model.py:36-40, interfaces.rs:402-415)
+        assert n == _size(stress) // sd and (tangent is None or n == _size(tangent) // (sd * sd)), (
+            "Stress, strain, and tangent lengths do not match"
+        )
+        assert _size(grad_del_u) == n * gd2 and _size(stress) == n * sd, "Input arrays are not of the correct length"
+        for (name, dim), h in zip(self._history_fields(), hist):
+            assert _size(h) == n * dim, f"history '{name}' has the wrong length"
+        if _is_torch(grad_del_u):
+            self._evaluate_device(t, del_t, n, grad_del_u, stress, tangent, hist)
+        else:
+            self._evaluate_host(t, del_t, n, grad_del_u, stress, tangent, hist)
+
+    def _evaluate_host(self, t, del_t, n, grad, stress, tangent, hist) -> None:
+        _check_numpy("grad_del_u", grad)
+        _check_numpy("stress", stress)
+        if tangent is not None:
+            _check_numpy("tangent", tangent)
+        for (name, _), h in zip(self._history_fields(), hist):
+            _check_numpy(f"history['{name}']", h)
+        m = self._handle(0)
+        self.last_stats = m.evaluate_host(
+            t, del_t, n, grad.ctypes.data, stress.ctypes.data,
+            None if tangent is None else tangent.ctypes.data, [h.ctypes.data for h in hist],
+        )
+
+    def _evaluate_device(self, t, del_t, n, grad, stress, tangent, hist,
+                         stress_prev=None, hist_prev=None) -> None:
+        _check_torch("grad_del_u", grad)
+        _check_torch("stress", stress)
+        if tangent is not None:
+            _check_torch("tangent", tangent)
+        for (name, _), h in zip(self._history_fields(), hist):
+            _check_torch(f"history['{name}']", h)
+        dev = grad.device.index or 0
+        m = self._handle(dev)
+        m.ctx.set_stream(_current_stream_ptr(dev))
+        m.evaluate_device(
+            t, del_t, n, grad.data_ptr(), stress.data_ptr(),
+            None if tangent is None else tangent.data_ptr(), [h.data_ptr() for h in hist],
+            None if stress_prev is None else _check_torch("stress_prev", stress_prev).data_ptr(),
+            None if hist_prev is None else [_check_torch("history_prev", h).data_ptr() for h in hist_prev],
+        )
+
+    def evaluate_from(self, t, del_t, grad_del_u, stress_prev, stress, tangent, history_prev, history) -> None:
+        """Out-of-place device evaluate: read the committed state (``stress_prev``,
+        ``history_prev``), write the trial state (``stress``, ``history``).  Fuses the two
+        copies the reference makes before every call (solver/_lawonsubmesh.py:58-61,
+        solver/_history.py:64-79).  Device tensors only."""
+        hist = self._history_arrays(history)
+        hprev = self._history_arrays(history_prev)
+        n = _size(grad_del_u) // 9
+        assert n == _size(stress) // 6 == _size(stress_prev) // 6 and (tangent is None or n == _size(tangent) // 36)
+        self._evaluate_device(t, del_t, n, grad_del_u, stress, tangent, hist, stress_prev, hprev)
+
+    def device_stats(self, device: int = 0):
+        """Synchronise and return the counters of the last device-path launch; raises
+        RuntimeError like the reference if a Newton iteration did not converge."""
+        st = self._handle(device).last_stats()
+        self.last_stats = st
+        if st.n_nonconverged:
+            raise RuntimeError("Newton-Raphson method did not converge for plastic multiplier.")
+        return st
+
+
+def _size(a) -> int:
+    if isinstance(a, np.ndarray):
+        return int(a.size)
+    if _is_torch(a):
+        return int(a.numel())
+    return int(np.asarray(a).size)
+
+
+def strain_from_grad_u_full(grad_u):
+    """FULL-constraint ``strain_from_grad_u`` on the GPU (utils.py:187-208)."""
+    import ctypes as C
+
+    lib = _capi.load()
+    if _is_torch(grad_u):
+        import torch
+
+        _check_torch("grad_u", grad_u)
+        n = grad_u.numel() // 9
+        out = torch.empty(6 * n, dtype=torch.float64, device=grad_u.device)
+        dev = grad_u.device.index or 0
+        ctx = _capi.get_context(dev)
+        ctx.set_stream(_current_stream_ptr(dev))
+        _capi.check(lib.fcamd_strain_from_grad_u_device(ctx.handle, n, C.c_void_p(grad_u.data_ptr()),
+                                                        C.c_void_p(out.data_ptr()), 0))
+        return out
+    import torch
+
+    g = np.ascontiguousarray(np.asarray(grad_u, dtype=np.float64)).reshape(-1)
+    if not torch.cuda.is_available():
+        raise RuntimeError("strain_from_grad_u(FULL) runs on the GPU and no HIP device is available")
+    d = torch.from_numpy(g).cuda()
+    return strain_from_grad_u_full(d).cpu().numpy()

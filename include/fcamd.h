@@ -1,0 +1,179 @@
+/*
+ * fcamd.h -- C ABI of the MI355X (gfx950) quadrature-point constitutive-update engine.
+ *
+ * Drop-in boundary for the hot path of BAMresearch/fenics-constitutive:
+ *     IncrSmallStrainModel.evaluate(t, del_t, grad_del_u, stress, tangent, history)
+ *         reference: src/fenics_constitutive/models/interfaces.py:82-101
+ * The entry points below are what a native backend for that interface binds, in the
+ * same position as the reference's PyO3 layer (bindings/src/lib.rs:45-152, class
+ * new()/evaluate()/history_dim/constraint) and its raw-pointer precedent
+ * (comfe-rs/src/linear_elasticity.rs:77-96, examples/elasticity_cpp/src/main.cpp:35-50).
+ *
+ * Conventions (all taken from the reference):
+ *   - every array is flat, C-contiguous IEEE float64, point-major AoS:
+ *       grad_del_u[9*i + 3*r + c]   (row-major 3x3 of nabla_grad(u - u_prev))
+ *       stress[6*i + k]             Mandel order xx,yy,zz,xy,xz,yz
+ *       tangent[36*i + 6*r + c]
+ *       history[k][dim_k*i + j]     one array per history field
+ *   - stress / tangent / history are overwritten (in-place semantics of evaluate()).
+ *   - no C++ types, no exceptions: every function returns an fcamd_status.
+ *   - a context is bound to one device and one stream; use one context per thread.
+ *
+ * Plain pointers and sizes only; nothing from torch or numpy appears here.
+ */
+#ifndef FCAMD_H
+#define FCAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCAMD_VERSION_MAJOR 0
+#define FCAMD_VERSION_MINOR 1
+
+/* ---- status codes (mapped to Python exceptions by the ctypes shim) -------- */
+typedef enum fcamd_status {
+    FCAMD_OK = 0,
+    FCAMD_ERR_SIZE = 1,          /* inconsistent array sizes -> AssertionError
+                                    (linear_elasticity_model.py:36-40; interfaces.rs:402-415) */
+    FCAMD_ERR_NULL_HISTORY = 2,  /* history missing -> ValueError (spring_maxwell_model.py:63-65) */
+    FCAMD_ERR_DEL_T = 3,         /* del_t <= 0 -> AssertionError (spring_kelvin_model.py:72) */
+    FCAMD_ERR_NONCONVERGED = 4,  /* Newton > 100 iterations -> RuntimeError
+                                    (mises_plasticity_isotropic_hardening.py:141-143) */
+    FCAMD_ERR_HIP = 5,           /* HIP runtime error (see fcamd_last_error) */
+    FCAMD_ERR_BAD_ARG = 6,       /* null pointer, unknown model id, bad parameter count -> ValueError */
+    FCAMD_ERR_ALIGN = 7,         /* device pointer not 16-byte aligned */
+    FCAMD_ERR_UNSUPPORTED = 8    /* constraint / layout not implemented -> NotImplementedError */
+} fcamd_status;
+
+/* ---- constitutive laws on the hot path ---------------------- */
+typedef enum fcamd_model_id {
+    /* LinearElasticityModel, FULL -- models/linear_elasticity_model.py:26-45.
+       params[36]: tangent D row-major (host: get_elastic_tangent, utils.py:25-51). */
+    FCAMD_LINEAR_ELASTICITY = 1,
+    /* VonMises3D -- models/mises_plasticity_isotropic_hardening.py:57-175.
+       params[5]: p_ka, p_mu, p_y0, p_y00, p_w.  history: eps_n(6), alpha(1). */
+    FCAMD_VON_MISES_3D = 2,
+    /* SpringMaxwellModel, FULL -- models/spring_maxwell_model.py:40-88.
+       params[4]: E0, E1, tau, nu.  history: strain_visco(6), strain(6). */
+    FCAMD_SPRING_MAXWELL = 3,
+    /* SpringKelvinModel, FULL -- models/spring_kelvin_model.py:43-88. params/history as Maxwell. */
+    FCAMD_SPRING_KELVIN = 4,
+    /* comfe-rs LinearElasticity3D -- comfe-rs/src/linear_elasticity.rs:42-75. params[2]: mu, kappa. */
+    FCAMD_COMFE_LINEAR_ELASTICITY = 5,
+    /* comfe-rs MisesPlasticity3D (linear hardening) -- comfe-rs/src/mises_plasticity.rs:58-126.
+       params[4]: mu, kappa, y_0, h.  history: "history"(7) = [alpha, plastic_strain(6)]. */
+    FCAMD_COMFE_MISES_PLASTICITY = 6
+} fcamd_model_id;
+
+/* StressStrainConstraint values -- models/interfaces.py:14-28. Only FULL has kernels. */
+typedef enum fcamd_constraint {
+    FCAMD_UNIAXIAL_STRAIN = 1,
+    FCAMD_UNIAXIAL_STRESS = 2,
+    FCAMD_PLANE_STRAIN = 3,
+    FCAMD_PLANE_STRESS = 4,
+    FCAMD_FULL = 5
+} fcamd_constraint;
+
+#define FCAMD_MAX_HISTORY 2
+
+typedef struct fcamd_context fcamd_context;
+typedef struct fcamd_model fcamd_model;
+
+/* Per-call statistics (device counters, read back after the launch has completed). */
+typedef struct fcamd_stats {
+    uint64_t n_nonconverged; /* points whose Newton iteration exceeded 100 steps */
+    uint64_t n_plastic;      /* points that took the plastic branch */
+    uint64_t n_newton_iters; /* total Newton iterations over all plastic points */
+    uint64_t reserved;
+} fcamd_stats;
+
+/* ---- lifecycle --------------------------------------------------------------- */
+
+/* Create a context on HIP device `device`.  `stream` is a hipStream_t to launch on
+   (e.g. torch's current stream), or NULL to let the context own a private stream. */
+int fcamd_context_create(int device, void* stream, fcamd_context** out);
+int fcamd_context_destroy(fcamd_context* ctx);
+/* Re-bind the launch stream (borrowed; not destroyed with the context). */
+int fcamd_context_set_stream(fcamd_context* ctx, void* stream);
+int fcamd_context_synchronize(fcamd_context* ctx);
+
+/* Model handle = law id + constraint + host-precomputed constants.
+   Replaces the PyO3 constructor `Py*::new(parameters)` (bindings/src/lib.rs:60-75).
+   `params` holds the law's parameters in the order documented at fcamd_model_id. */
+int fcamd_model_create(fcamd_context* ctx, int model_id, int constraint,
+                       const double* params, int n_params, fcamd_model** out);
+int fcamd_model_destroy(fcamd_model* model);
+
+/* history_dim of the law (models/interfaces.py:133-143; bindings/src/lib.rs:131-136):
+   number of fields, and per field its name and per-point dimension. */
+int fcamd_model_history_count(const fcamd_model* model, int* n_fields);
+int fcamd_model_history_field(const fcamd_model* model, int k, const char** name, int* dim);
+
+/* ---- the hot path ------------------------------------------------------------- */
+
+/* Device-resident evaluate (roofline path): all pointers are device pointers, 16-byte
+   aligned.  Asynchronous on the context's stream.  `tangent` may be NULL (the Rust
+   entry allows it, comfe-rs/src/interfaces.rs:383-394).  `history` has n_hist device
+   pointers in history-field order, or NULL/0 for laws without history.
+   In place: stress and history are read and overwritten. */
+int fcamd_evaluate_device(fcamd_model* model, double t, double del_t, int64_t n,
+                          const double* grad_del_u, double* stress, double* tangent,
+                          double* const* history, int n_hist);
+
+/* Out-of-place form: reads the committed state (stress_prev, history_prev) and writes
+   the trial state (stress, history).  Fuses the copies the reference performs before
+   every call (solver/_lawonsubmesh.py:58-61 stress_local <- stress.previous;
+   solver/_history.py:64-79 history_1 <- history_0).  prev pointers may alias the
+   outputs, which is then exactly fcamd_evaluate_device. */
+int fcamd_evaluate_device_from(fcamd_model* model, double t, double del_t, int64_t n,
+                               const double* grad_del_u, const double* stress_prev,
+                               double* stress, double* tangent,
+                               const double* const* history_prev, double* const* history,
+                               int n_hist);
+
+/* Host evaluate: the ndarray entry.  Pointers are host arrays laid out as above; the
+   library stages them through pinned buffers (chunked, H2D / kernel / D2H overlapped
+   on three streams), runs the device path and writes stress / tangent / history back
+   in place.  Synchronous.  Validates like the reference and returns the matching
+   status; on FCAMD_ERR_NONCONVERGED the outputs hold the values the kernel produced
+   (the reference raises mid-loop). `stats` may be NULL. */
+int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
+                        const double* grad_del_u, double* stress, double* tangent,
+                        double* const* history, int n_hist, fcamd_stats* stats);
+
+/* Mandel strain from displacement gradient, FULL (utils.py:132-151,187-208).
+   rust_factor = 0: factor 1/2**0.5 (Python); 1: FRAC_1_SQRT_2 (mandel.rs:147). */
+int fcamd_strain_from_grad_u_device(fcamd_context* ctx, int64_t n, const double* grad_u,
+                                    double* strain, int rust_factor);
+
+/* Synchronise the stream and read the counters accumulated by the last
+   evaluate_device* launch of this model. */
+int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
+
+/* Caller arrays are stable across Newton iterations (views of Function.x.array,
+   solver/_lawonsubmesh.py:87-94): page-lock them once so evaluate_host can DMA
+   directly instead of copying through the pinned staging ring. */
+int fcamd_register_host_buffer(fcamd_context* ctx, void* ptr, size_t bytes);
+int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
+
+/* ---- tuning / introspection -------------------------------------------------- */
+/* Override the launch grid (number of 256-thread workgroups; 0 = automatic). */
+int fcamd_context_set_grid(fcamd_context* ctx, int n_workgroups);
+/* Time of the last evaluate_device* kernel in milliseconds, measured with HIP events
+   on the context's stream (synchronises). */
+int fcamd_model_last_kernel_ms(fcamd_model* model, float* ms);
+/* Enable/disable HIP-event timing around each launch (default off). */
+int fcamd_context_set_timing(fcamd_context* ctx, int enabled);
+
+const char* fcamd_last_error(void);
+const char* fcamd_status_string(int status);
+int fcamd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCAMD_H */

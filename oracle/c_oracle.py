@@ -1,0 +1,93 @@
+"""ctypes wrapper of the C oracle (oracle/oracle.c).  TEST INFRASTRUCTURE / CPU baseline only:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", HERE, "-B" if force else "-s"], check=True, capture_output=True)
+    return LIB
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+        _lib.oracle_von_mises_3d.restype = C.c_longlong
+        _lib.oracle_comfe_mises.restype = C.c_longlong
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return C.c_void_p(0)
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return C.c_void_p(a.ctypes.data)
+
+
+def _d(x):
+    return C.c_double(float(x))
+
+
+def strain_from_grad_u(grad, rust=False):
+    n = grad.size // 9
+    out = np.empty(6 * n)
+    lib().oracle_strain_from_grad_u(C.c_longlong(n), _p(grad), _p(out), C.c_int(int(rust)))
+    return out
+
+
+def linear_elasticity(p, t, del_t, grad, stress, tangent, history=None):
+    lib().oracle_linear_elasticity(_d(p["E"]), _d(p["nu"]), C.c_longlong(grad.size // 9), _p(grad), _p(stress), _p(tangent))
+
+
+def von_mises_3d(p, t, del_t, grad, stress, tangent, history):
+    npl, nit = C.c_longlong(0), C.c_longlong(0)
+    bad = lib().oracle_von_mises_3d(_d(p["p_ka"]), _d(p["p_mu"]), _d(p["p_y0"]), _d(p["p_y00"]), _d(p["p_w"]),
+                                    C.c_longlong(grad.size // 9), _p(grad), _p(stress), _p(tangent),
+                                    _p(history["eps_n"]), _p(history["alpha"]), C.byref(npl), C.byref(nit))
+    if bad:
+        raise RuntimeError("Newton-Raphson method did not converge for plastic multiplier.")
+    return npl.value, nit.value
+
+
+def spring_maxwell(p, t, del_t, grad, stress, tangent, history):
+    lib().oracle_spring_maxwell(_d(p["E0"]), _d(p["E1"]), _d(p["tau"]), _d(p["nu"]), _d(del_t), C.c_longlong(grad.size // 9),
+                                _p(grad), _p(stress), _p(tangent), _p(history["strain_visco"]), _p(history["strain"]))
+
+
+def spring_kelvin(p, t, del_t, grad, stress, tangent, history):
+    lib().oracle_spring_kelvin(_d(p["E0"]), _d(p["E1"]), _d(p["tau"]), _d(p["nu"]), _d(del_t), C.c_longlong(grad.size // 9),
+                               _p(grad), _p(stress), _p(tangent), _p(history["strain_visco"]), _p(history["strain"]))
+
+
+def comfe_linear_elasticity(p, t, del_t, grad, stress, tangent, history=None):
+    lib().oracle_comfe_linear_elasticity(_d(p["mu"]), _d(p["kappa"]), C.c_longlong(grad.size // 9), _p(grad), _p(stress), _p(tangent))
+
+
+def comfe_mises_plasticity(p, t, del_t, grad, stress, tangent, history):
+    return lib().oracle_comfe_mises(_d(p["mu"]), _d(p["kappa"]), _d(p["y_0"]), _d(p["h"]), C.c_longlong(grad.size // 9),
+                                    _p(grad), _p(stress), _p(tangent), _p(history["history"]))
+
+
+MODELS = {
+    "linear_elasticity": linear_elasticity,
+    "von_mises_3d": von_mises_3d,
+    "spring_maxwell": spring_maxwell,
+    "spring_kelvin": spring_kelvin,
+    "comfe_linear_elasticity": comfe_linear_elasticity,
+    "comfe_mises_plasticity": comfe_mises_plasticity,
+}

@@ -1,0 +1,289 @@
+/*
+ * oracle.c -- plain-C CPU restatement of the reference's quadrature-point updates.
+ *
+ * TEST INFRASTRUCTURE ONLY: this is the checker and the CPU baseline ("port"), never the
+ * product.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * it.  Built by oracle/Makefile into oracle/_build/liboracle.so (gcc, -O2,
+ * -ffp-contract=off so that the rounding is the one written here).
+ *
+ * Parity pin: tests/test_oracle_c.py checks every function against the golden vectors
+ * captured from the imported reference (tests/golden/, oracle/gen_golden.py) and against
+ * oracle/numpy_oracle.py.  The plastic values of the comfe-rs Mises law are not pinned by
+ * any reference test ("parity unpinned" for those values; see numpy_oracle.py).
+ *
+ * Serial loops over points mirror the reference's own structure:
+ *   Python per-point loop   models/mises_plasticity_isotropic_hardening.py:74-175
+ *   Rust evaluate_model     comfe-rs/src/interfaces.rs:441-455
+ * NumPy's n x 6 . 6 x 6 product and 6-term np.dot are ascending-k FMA chains (verified
+ * against OpenBLAS 0.3.29 Haswell in the build container) -> fma() below.
+ *
+ * Third-party arithmetic restated: nalgebra 0.32.6 (Cargo.lock:117-119) static 6x6 *
+ * 6x1 product = column-wise axpy (y = A[:,0]*x0; y += A[:,j]*x_j, no FMA), norm_squared of
+ * a 6-vector = sequential sum of squares.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+
+#define F_PY 0x1.6a09e667f3bccp-1 /* 1 / 2**0.5      (models/utils.py:202-204) */
+#define F_RS 0x1.6a09e667f3bcdp-1 /* FRAC_1_SQRT_2   (comfe-rs/src/mandel.rs:147) */
+
+static void strain6(const double* g, double f, double* e) {
+    e[0] = g[0];
+    e[1] = g[4];
+    e[2] = g[8];
+    e[3] = f * (g[1] + g[3]);
+    e[4] = f * (g[2] + g[6]);
+    e[5] = f * (g[5] + g[7]);
+}
+
+static void lame(double E, double nu, double* mu, double* lam) {
+    *mu = E / (2.0 * (1.0 + nu));
+    *lam = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+}
+
+static void tangent_full(double E, double nu, double* D) {
+    double mu, lam;
+    lame(E, nu, &mu, &lam);
+    memset(D, 0, 36 * sizeof(double));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) D[6 * i + j] = (i == j) ? 2.0 * mu + lam : lam;
+    for (int i = 3; i < 6; ++i) D[6 * i + i] = 2.0 * mu;
+}
+
+/* y = x @ M as OpenBLAS does it: ascending-k FMA chain */
+static void row_mat(const double* x, const double* M, double* y) {
+    for (int i = 0; i < 6; ++i) {
+        double acc = x[0] * M[i];
+        for (int k = 1; k < 6; ++k) acc = fma(x[k], M[6 * k + i], acc);
+        y[i] = acc;
+    }
+}
+
+/* utils.py:132-208 (FULL); rust = 1 selects mandel.rs:143-171 */
+void oracle_strain_from_grad_u(long long n, const double* grad, double* strain, int rust) {
+    for (long long p = 0; p < n; ++p) strain6(grad + 9 * p, rust ? F_RS : F_PY, strain + 6 * p);
+}
+
+/* models/linear_elasticity_model.py:26-45 */
+void oracle_linear_elasticity(double E, double nu, long long n, const double* grad, double* stress,
+                              double* tangent) {
+    double D[36], e[6], y[6];
+    tangent_full(E, nu, D);
+    for (long long p = 0; p < n; ++p) {
+        strain6(grad + 9 * p, F_PY, e);
+        row_mat(e, D, y);
+        for (int i = 0; i < 6; ++i) stress[6 * p + i] += y[i];
+        if (tangent) memcpy(tangent + 36 * p, D, sizeof(D));
+    }
+}
+
+/* models/mises_plasticity_isotropic_hardening.py:57-175.  Returns the number of points whose
+   Newton iteration exceeded 100 steps (the reference raises RuntimeError at the first). */
+long long oracle_von_mises_3d(double ka, double mu, double y0, double y00, double w, long long n,
+                              const double* grad, double* stress, double* tangent, double* eps_n,
+                              double* alpha, long long* n_plastic, long long* n_iter) {
+    const double s23 = sqrt(2.0 / 3.0), two_mu = 2 * mu, dy = y00 - y0, mw = -w;
+    const double m2mu = -2 * mu, c23 = (2.0 / 3.0) * dy * w, four_mu2 = 4 * mu * mu;
+    long long bad = 0, npl = 0, nit = 0;
+    for (long long p = 0; p < n; ++p) {
+        double e[6], dsig[6], sigtr[6], N[6] = {0, 0, 0, 0, 0, 0};
+        double* s = stress + 6 * p;
+        strain6(grad + 9 * p, F_PY, e);
+        const double tr_eps = (e[0] + e[1]) + e[2], tr_sig = (s[0] + s[1]) + s[2];
+        for (int i = 0; i < 6; ++i) {
+            const double ed = i < 3 ? e[i] - tr_eps / 3 : e[i];
+            const double sd = i < 3 ? s[i] - tr_sig / 3 : s[i];
+            dsig[i] = two_mu * ed;
+            sigtr[i] = sd + dsig[i];
+        }
+        double nn = sigtr[0] * sigtr[0];
+        for (int i = 1; i < 6; ++i) nn = fma(sigtr[i], sigtr[i], nn);
+        const double sigtrn = sqrt(nn), a_n = alpha[p];
+        const double phitr = sigtrn - s23 * (y0 + dy * (1 - exp(mw * a_n)));
+        double gamma = 0, xc1 = 0, xc2 = 0;
+        if (phitr > 0) {
+            double g0 = 1, g1 = 0, xr = 1, xg;
+            int it = 0;
+            while (fabs(xr) > 1e-12 && fabs(g1 - g0) > 1e-8 * fabs(g1)) {
+                g0 = g1;
+                ++it;
+                const double ex = exp(mw * (a_n + s23 * g0));
+                xr = (sigtrn - two_mu * g0) - s23 * (y0 + dy * (1 - ex));
+                xg = m2mu - c23 * ex;
+                g1 = g0 - xr / xg;
+                if (it > 100) {
+                    ++bad;
+                    break;
+                }
+            }
+            xg = m2mu - c23 * exp(mw * (a_n + s23 * g1));
+            xc1 = -1 / xg;
+            xc2 = g1 / sigtrn;
+            gamma = g1;
+            for (int i = 0; i < 6; ++i) N[i] = sigtr[i] / sigtrn;
+            ++npl;
+            nit += it;
+        }
+        const double kt = ka * tr_eps, tmg = two_mu * gamma;
+        for (int i = 0; i < 6; ++i) {
+            eps_n[6 * p + i] += gamma * N[i];
+            s[i] += ((i < 3 ? kt : kt * 0.0) + dsig[i]) - tmg * N[i];
+        }
+        alpha[p] += s23 * gamma;
+        if (tangent) {
+            const double B = two_mu * (1 - two_mu * xc2), C = four_mu2 * (xc2 - xc1);
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    const double xioi = (i < 3 && j < 3) ? 1.0 : 0.0;
+                    const double xpp = ((i == j) ? 1.0 : 0.0) - (1.0 / 3.0) * xioi;
+                    tangent[36 * p + 6 * i + j] = (ka * xioi + B * xpp) + C * (N[i] * N[j]);
+                }
+        }
+    }
+    if (n_plastic) *n_plastic = npl;
+    if (n_iter) *n_iter = nit;
+    return bad;
+}
+
+/* models/spring_maxwell_model.py:40-88 */
+void oracle_spring_maxwell(double E0, double E1, double tau, double nu, double del_t, long long n,
+                           const double* grad, double* stress, double* tangent, double* ev,
+                           double* en) {
+    double D0[36], D1[36], D01[36], Dt[36], mu1, lam1;
+    tangent_full(E0, nu, D0);
+    tangent_full(E1, nu, D1);
+    lame(E1, nu, &mu1, &lam1);
+    const double factor = 1 / del_t + 1 / tau, inv_factor = 1 / factor;
+    const double cA = 1 / (tau * 2 * mu1), cB = 1 / tau, c2mu = 2 * mu1, w1 = 1 - 1 / (tau * factor);
+    for (int i = 0; i < 36; ++i) {
+        D01[i] = D0[i] + D1[i];
+        Dt[i] = D0[i] + w1 * D1[i];
+    }
+    for (long long p = 0; p < n; ++p) {
+        double e[6], x[6], y[6], dv[6];
+        strain6(grad + 9 * p, F_PY, e);
+        for (int i = 0; i < 6; ++i) x[i] = cA * (en[6 * p + i] + e[i]);
+        row_mat(x, D1, y);
+        for (int i = 0; i < 6; ++i) dv[i] = inv_factor * (y[i] - cB * ev[6 * p + i]);
+        row_mat(e, D01, y);
+        for (int i = 0; i < 6; ++i) {
+            stress[6 * p + i] += y[i] - c2mu * dv[i];
+            ev[6 * p + i] += dv[i];
+            en[6 * p + i] += e[i];
+        }
+        if (tangent) memcpy(tangent + 36 * p, Dt, sizeof(Dt));
+    }
+}
+
+/* models/spring_kelvin_model.py:43-88 */
+void oracle_spring_kelvin(double E0, double E1, double tau, double nu, double del_t, long long n,
+                          const double* grad, double* stress, double* tangent, double* ev,
+                          double* en) {
+    double D0[36], Dt[36], mu0, lam0, mu1, lam1;
+    tangent_full(E0, nu, D0);
+    lame(E0, nu, &mu0, &lam0);
+    lame(E1, nu, &mu1, &lam1);
+    const double factor = 1 / del_t + 1 / tau + mu0 / (tau * mu1), inv_factor = 1 / factor;
+    const double cA = 1 / (tau * 2 * mu1), cB = 1 / tau, cC = mu0 / (tau * mu1);
+    const double cD = lam0 / (tau * 2 * mu1), c2mu = 2 * mu0, w0 = 1 - mu0 / (tau * mu1 * factor);
+    for (int i = 0; i < 36; ++i) Dt[i] = w0 * D0[i];
+    for (long long p = 0; p < n; ++p) {
+        double e[6], y[6], dv[6];
+        double* s = stress + 6 * p;
+        strain6(grad + 9 * p, F_PY, e);
+        const double ctr = cD * ((e[0] + e[1]) + e[2]);
+        for (int i = 0; i < 6; ++i)
+            dv[i] = inv_factor * (((cA * s[i] - cB * ev[6 * p + i]) + cC * e[i]) + (i < 3 ? ctr : ctr * 0.0));
+        row_mat(e, D0, y);
+        for (int i = 0; i < 6; ++i) {
+            s[i] += y[i] - c2mu * dv[i];
+            ev[6 * p + i] += dv[i];
+            en[6 * p + i] += e[i];
+        }
+        if (tangent) memcpy(tangent + 36 * p, Dt, sizeof(Dt));
+    }
+}
+
+/* comfe-rs/src/consts.rs:6-115 */
+static void comfe_proj(double* soo, double* pvol, double* pdev) {
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            const double s = (i < 3 && j < 3) ? 1.0 : 0.0;
+            soo[6 * i + j] = s;
+            pvol[6 * i + j] = s * (1.0 / 3.0);
+            pdev[6 * i + j] = ((i == j) ? 1.0 : 0.0) + pvol[6 * i + j] * -1.0;
+        }
+}
+
+/* comfe-rs/src/linear_elasticity.rs:49-74 driven by interfaces.rs:441-455 */
+void oracle_comfe_linear_elasticity(double mu, double kappa, long long n, const double* grad,
+                                    double* stress, double* tangent) {
+    double soo[36], pvol[36], pdev[36], Cm[36], Ct[36], e[6];
+    comfe_proj(soo, pvol, pdev);
+    for (int i = 0; i < 36; ++i) Cm[i] = (2.0 * mu) * pdev[i] + (3.0 * kappa) * pvol[i];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) Ct[6 * j + i] = Cm[6 * i + j];
+    for (long long p = 0; p < n; ++p) {
+        strain6(grad + 9 * p, F_RS, e);
+        for (int i = 0; i < 6; ++i) {
+            double acc = Cm[6 * i] * e[0];
+            for (int j = 1; j < 6; ++j) acc = Cm[6 * i + j] * e[j] + acc;
+            stress[6 * p + i] += acc;
+        }
+        if (tangent) memcpy(tangent + 36 * p, Ct, sizeof(Ct));
+    }
+}
+
+/* comfe-rs/src/mises_plasticity.rs:58-126 driven by interfaces.rs:441-455.
+   hist: 7 doubles per point [alpha, plastic_strain(6)].  Returns the number of plastic points. */
+long long oracle_comfe_mises(double mu, double kappa, double y_0, double h, long long n,
+                             const double* grad, double* stress, double* tangent, double* hist) {
+    double soo[36], pvol[36], pdev[36];
+    comfe_proj(soo, pvol, pdev);
+    const double two_mu = 2. * mu, den = 3. * mu + h, s32 = sqrt(3. / 2.), three_mu = 3. * mu;
+    const double hfac = 1.0 / (1.0 + (h / (3.0 * mu)));
+    long long npl = 0;
+    for (long long p = 0; p < n; ++p) {
+        double e[6], s_tr[6], nv[6] = {0, 0, 0, 0, 0, 0};
+        double* s = stress + 6 * p;
+        double* hp = hist + 7 * p;
+        strain6(grad + 9 * p, F_RS, e);
+        const double alpha = hp[0];
+        const double p_0 = ((s[0] + s[1]) + s[2]) / 3.0;
+        const double eps_trace = (e[0] + e[1]) + e[2], eps_vol = eps_trace / 3.0;
+        const double p_1 = p_0 + kappa * eps_trace;
+        for (int i = 0; i < 6; ++i) {
+            const double s0 = i < 3 ? s[i] + (-p_0) : s[i];
+            const double ed = i < 3 ? e[i] + (-eps_vol) : e[i];
+            s_tr[i] = s0 + two_mu * ed;
+        }
+        const double v3 = ((s_tr[0] + s_tr[1]) + s_tr[2]) / 3.0;
+        double n2 = 0.0;
+        for (int i = 0; i < 6; ++i) {
+            const double d = i < 3 ? s_tr[i] + (-v3) : s_tr[i];
+            n2 = i == 0 ? d * d : n2 + d * d;
+        }
+        const double q = sqrt(3.0 * (0.5 * n2)), sigma_y = y_0 + h * alpha;
+        double theta = 1.0, B = two_mu, sc = 0.0;
+        if (!(q < sigma_y)) {
+            const double del_alpha = (q - sigma_y) / den, del_gamma = s32 * del_alpha;
+            theta = 1.0 - (three_mu * del_alpha) / q;
+            for (int i = 0; i < 6; ++i) {
+                nv[i] = s_tr[i] / q;
+                hp[1 + i] += del_gamma * nv[i];
+            }
+            hp[0] = alpha + del_alpha;
+            B = two_mu * theta;
+            sc = two_mu * (hfac - (1.0 - theta));
+            ++npl;
+        }
+        for (int i = 0; i < 6; ++i) s[i] = i < 3 ? p_1 + theta * s_tr[i] : theta * s_tr[i];
+        if (tangent)
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) /* flat[6i+j] = element (row j, col i): column-major .data.0 */
+                    tangent[36 * p + 6 * i + j] =
+                        (kappa * soo[6 * j + i] + B * pdev[6 * j + i]) + (sc * nv[j]) * nv[i];
+    }
+    return npl;
+}
