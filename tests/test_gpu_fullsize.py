@@ -1,0 +1,113 @@
+"""Full-size (BASELINE.json: 1e8 quadrature points on one GPU) checks through
+size-independent properties, plus a strided sample against the oracle."""
+
+import numpy as np
+import pytest
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import fenics_constitutive_amd as fc  # noqa: E402
+from oracle import c_oracle as CO  # noqa: E402
+
+N = 100_000_000
+FULL = fc.StressStrainConstraint.FULL
+VM_P = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}
+LE_P = {"E": 42.0, "nu": 0.3}
+
+
+def need_memory(gb):
+    free, _ = torch.cuda.mem_get_info()
+    if free < gb * 1e9:
+        pytest.skip(f"needs {gb} GB of free HBM")
+
+
+def sample_points(n, m=100_000):
+    idx = np.unique(np.concatenate([np.arange(0, n, n // m), [0, 63, 64, n - 65, n - 64, n - 1]]))
+    return torch.from_numpy(idx).cuda()
+
+
+def gather(a, idx, dim):
+    return a.view(-1, dim)[idx].reshape(-1).cpu().numpy()
+
+
+def test_linear_elasticity_1e8():
+    need_memory(60)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    g = torch.randn(9 * N, dtype=torch.float64, device="cuda", generator=gen) * 1e-3
+    s0 = torch.randn(6 * N, dtype=torch.float64, device="cuda", generator=gen)
+    s = s0.clone()
+    t = torch.full((36 * N,), float("nan"), dtype=torch.float64, device="cuda")
+    law = fc.LinearElasticityModel(LE_P, FULL)
+    law.evaluate(0.0, 1.0, g, s, t, None)
+    torch.cuda.synchronize()
+    # property 1: tangent == tile(D): every point carries exactly D
+    tv = t.view(N, 36)
+    D = torch.from_numpy(law.D.reshape(-1)).cuda()
+    assert torch.equal(tv.min(dim=0).values, D) and torch.equal(tv.max(dim=0).values, D)
+    del tv
+    # property 2: strided sample against the oracle (1e-10 relative; bit pattern reported)
+    idx = sample_points(N)
+    gs, ss = gather(g, idx, 9), gather(s0, idx, 6)
+    ts = np.zeros(36 * idx.numel())
+    CO.linear_elasticity(LE_P, 0, 1, gs, ss, ts)
+    got = gather(s, idx, 6)
+    assert rel_err(got, ss) <= 1e-10
+    print(f"LE 1e8: {np.mean(got == ss) * 100:.4f} % of sampled stresses bit-identical to the oracle")
+    # property 3: linearity -- with sigma_in = 0 the update of 2*grad is exactly twice the update of grad
+    s1 = torch.zeros(6 * N, dtype=torch.float64, device="cuda")
+    law.evaluate(0.0, 1.0, g, s1, None, None)
+    g.mul_(2.0)
+    s2 = torch.zeros(6 * N, dtype=torch.float64, device="cuda")
+    law.evaluate(0.0, 1.0, g, s2, None, None)
+    assert torch.equal(s2, 2.0 * s1)
+    # property 4: additivity of the in-place "+=": evaluate(g) from s0 == s0 + evaluate(g) from 0 up to one rounding
+    g.mul_(0.5)
+    assert torch.allclose(s, s0 + s1, rtol=1e-14, atol=1e-14)
+
+
+def test_von_mises_1e8():
+    need_memory(70)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    g = torch.randn(9 * N, dtype=torch.float64, device="cuda", generator=gen)
+    g.view(N, 9).mul_(torch.pow(10.0, torch.rand(N, dtype=torch.float64, device="cuda", generator=gen) * 2 - 4)[:, None])
+    s0 = torch.randn(6 * N, dtype=torch.float64, device="cuda", generator=gen) * 100.0
+    a0 = torch.rand(N, dtype=torch.float64, device="cuda", generator=gen) * 0.02
+    e0 = torch.zeros(6 * N, dtype=torch.float64, device="cuda")
+    s, a, e = s0.clone(), a0.clone(), e0.clone()
+    t = torch.full((36 * N,), float("nan"), dtype=torch.float64, device="cuda")
+    law = fc.VonMises3D(VM_P)
+    law.evaluate(0.0, 1.0, g, s, t, {"eps_n": e, "alpha": a})
+    st = law.device_stats()
+    assert st.n_nonconverged == 0
+    # property 1: the plastic counter equals the number of points whose alpha grew
+    grew = a > a0
+    assert int(grew.sum().item()) == st.n_plastic and 0 < st.n_plastic < N
+    # property 2: yield consistency.  plastic: |dev sigma| = sqrt(2/3) y(alpha); elastic: <=
+    sv = s.view(N, 6)
+    tr3 = (sv[:, 0] + sv[:, 1] + sv[:, 2]) / 3.0
+    nrm2 = ((sv[:, :3] - tr3[:, None]) ** 2).sum(dim=1) + (sv[:, 3:] ** 2).sum(dim=1)
+    nrm = nrm2.sqrt()
+    del nrm2, tr3
+    y = np.sqrt(2.0 / 3.0) * (VM_P["p_y0"] + (VM_P["p_y00"] - VM_P["p_y0"]) * (1.0 - torch.exp(-VM_P["p_w"] * a)))
+    assert float(((nrm - y).abs() / y)[grew].max().item()) < 1e-9
+    assert bool((nrm[~grew] <= y[~grew] * (1 + 1e-12)).all().item())
+    del nrm, y
+    # property 3: elastic points keep eps_n bit for bit; the tangent has no unwritten entry
+    assert torch.equal(e.view(N, 6)[~grew], e0.view(N, 6)[~grew])
+    assert not bool(torch.isnan(t).any().item())
+    # property 4: the tangent of every point is symmetric (C = ka 1x1 + b P_dev + c N x N)
+    tv = t.view(N, 6, 6)
+    assert float((tv - tv.transpose(1, 2)).abs().max().item()) == 0.0
+    del tv
+    # strided sample against the oracle at the plasticity tolerance
+    idx = sample_points(N)
+    gs, ss = gather(g, idx, 9), gather(s0, idx, 6)
+    hs = {"eps_n": gather(e0, idx, 6), "alpha": gather(a0, idx, 1)}
+    ts = np.zeros(36 * idx.numel())
+    CO.von_mises_3d(VM_P, 0, 1, gs, ss, ts, hs)
+    for name, got, ref in [("stress", gather(s, idx, 6), ss), ("tangent", gather(t, idx, 36), ts),
+                           ("eps_n", gather(e, idx, 6), hs["eps_n"]), ("alpha", gather(a, idx, 1), hs["alpha"])]:
+        assert rel_err(got, ref) <= 1e-6, name
+        assert rel_err(got, ref) <= 1e-11, "strict " + name

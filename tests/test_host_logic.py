@@ -1,0 +1,124 @@
+"""CPU tests of the host side: interface mirror, helpers, the C-ABI library's exports, the
+loud failure without a GPU.  No compute calls (no GPU here)."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fenics_constitutive_amd as fc
+from fenics_constitutive_amd import _capi
+from fenics_constitutive_amd.sharded import ShardPlan
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+C = fc.StressStrainConstraint
+
+
+def test_constraint_enum_matches_reference_values():
+    # models/interfaces.py:14-73
+    assert [c.value for c in (C.UNIAXIAL_STRAIN, C.UNIAXIAL_STRESS, C.PLANE_STRAIN, C.PLANE_STRESS, C.FULL)] == [1, 2, 3, 4, 5]
+    assert [c.stress_strain_dim for c in C] == [1, 1, 4, 4, 6]
+    assert [c.geometric_dim for c in C] == [1, 1, 2, 2, 3]
+
+
+def test_interface_is_abstract():
+    with pytest.raises(TypeError):
+        fc.IncrSmallStrainModel()
+
+
+def test_model_properties_without_gpu():
+    vm = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
+    assert vm.constraint == C.FULL and vm.history_dim == {"eps_n": 6, "alpha": 1}
+    assert vm.stress_strain_dim == 6 and vm.geometric_dim == 3
+    assert np.allclose(vm.xpp, np.eye(6) - np.pad(np.ones((3, 3)), (0, 3)) / 3)
+    le = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, C.FULL)
+    assert le.history_dim is None and le.D.shape == (6, 6)
+    for cls in (fc.SpringMaxwellModel, fc.SpringKelvinModel):
+        m = cls({"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}, C.FULL)
+        assert m.history_dim == {"strain_visco": 6, "strain": 6}
+        m1 = cls({"E0": 42.0, "E1": 10.0, "tau": 10.0}, C.UNIAXIAL_STRESS)  # nu forced to 0 (:31-34)
+        assert m1.nu == 0.0 and m1.history_dim == {"strain_visco": 1, "strain": 1}
+    rs = fc.MisesPlasticityLinearHardening3D({k: np.array([v]) for k, v in
+                                              {"mu": 1.0, "kappa": 2.0, "y_0": 3.0, "h": 4.0}.items()})
+    assert rs.history_dim == {"history": 7} and rs.constraint == C.FULL
+    assert fc.LinearElasticity3D({"mu": np.array([1.0]), "kappa": np.array([2.0])}).history_dim is None
+    with pytest.raises(KeyError):  # Python-style dict handed to the Rust-style class (test_plasticity.py:33-37)
+        fc.MisesPlasticityLinearHardening3D({"p_ka": 1.0})
+
+
+def test_elastic_tangent_all_constraints():
+    E, nu = 42.0, 0.3
+    mu, lam = fc.lame_parameters(E, nu)
+    assert mu == E / (2.0 * (1.0 + nu)) and lam == E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    D = fc.get_elastic_tangent(E, nu, C.FULL)
+    assert D.shape == (6, 6) and D[0, 0] == 2.0 * mu + lam and D[0, 1] == lam and D[3, 3] == 2.0 * mu and D[0, 3] == 0
+    assert np.array_equal(fc.get_elastic_tangent(E, nu, C.PLANE_STRAIN), D[:4, :4])
+    Dps = fc.get_elastic_tangent(E, nu, C.PLANE_STRESS)
+    assert np.isclose(Dps[0, 0], E / (1 - nu**2)) and Dps[2, 2] == 0 and np.isclose(Dps[3, 3], E / (1 + nu))
+    assert fc.get_elastic_tangent(E, nu, C.UNIAXIAL_STRESS)[0, 0] == E
+    assert np.isclose(fc.get_elastic_tangent(E, nu, C.UNIAXIAL_STRAIN)[0, 0], lam + 2 * mu)
+    assert list(fc.get_identity(6, C.FULL)) == [1, 1, 1, 0, 0, 0]
+    assert list(fc.get_identity(4, C.PLANE_STRESS)) == [1, 1, 0, 0]
+    assert list(fc.get_identity(1, C.UNIAXIAL_STRAIN)) == [1]
+
+
+def test_strain_from_grad_u_low_dimensional():
+    # tests/models/test_conversions.py:14-28 (host-side constraints)
+    assert np.allclose(fc.strain_from_grad_u(np.array([[1.0]]), C.UNIAXIAL_STRAIN), [1.0])
+    assert np.allclose(fc.strain_from_grad_u(np.array([[1.0]]), C.UNIAXIAL_STRESS), [1.0])
+    g = np.array([[1.0, 2.0], [3.0, 4.0]])
+    for c in (C.PLANE_STRAIN, C.PLANE_STRESS):
+        assert np.allclose(fc.strain_from_grad_u(g, c), [1.0, 4.0, 0.0, 0.5 * 5.0 * 2**0.5])
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "fcamd.h")).read()
+    declared = sorted(set(re.findall(r"\b(fcamd_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(_capi.SYMBOLS)
+    lib = ctypes.CDLL(_capi.library_path()) if os.path.exists(_capi.library_path()) else _capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _capi.load().fcamd_version() == 1
+    assert _capi.load().fcamd_status_string(4).decode().startswith("Newton-Raphson")
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product path raises; it never computes on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    le = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, C.FULL)
+    s = np.ones(6)
+    with pytest.raises(RuntimeError, match="no ROCm-capable device|hipGetDeviceCount"):
+        le.evaluate(0.0, 1.0, np.ones(9), s, np.zeros(36), None)
+    assert np.array_equal(s, np.ones(6))
+    with pytest.raises(RuntimeError):
+        fc.strain_from_grad_u(np.ones(9), C.FULL)
+
+
+def test_validation_happens_before_any_device_work():
+    le = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, C.FULL)
+    with pytest.raises(AssertionError):
+        le.evaluate(0.0, 1.0, np.zeros(18), np.zeros(6), np.zeros(72), None)
+    sls = fc.SpringMaxwellModel({"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}, C.FULL)
+    with pytest.raises(ValueError, match="history must not be None"):
+        sls.evaluate(0.0, 1.0, np.zeros(9), np.zeros(6), np.zeros(36), None)
+    with pytest.raises(AssertionError, match="Time step"):
+        sls.evaluate(0.0, 0.0, np.zeros(9), np.zeros(6), np.zeros(36),
+                     {"strain_visco": np.zeros(6), "strain": np.zeros(6)})
+
+
+@pytest.mark.parametrize("n,world", [(0, 2), (1, 2), (64, 2), (65, 2), (1000, 3), (10**8, 8), (8 * 10**8, 8), (129, 8)])
+def test_shard_plan(n, world):
+    plan = ShardPlan.create(n, world)
+    assert plan.per_rank % 64 == 0 and plan.per_rank * world >= n
+    covered = 0
+    for r in range(world):
+        lo, hi = plan.bounds(r)
+        assert lo == min(r * plan.per_rank, n) and lo <= hi <= n
+        assert lo % 64 == 0 or lo == n
+        covered += hi - lo
+    assert covered == n
