@@ -160,8 +160,11 @@ def main():
         sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): one rank per GPU over RCCL, also for world 1
+    distributed = "RANK" in os.environ
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=device)
 
     kind, scale_spec, b_el, b_pl = WORKLOADS[args.workload]
@@ -194,7 +197,7 @@ def main():
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -203,10 +206,10 @@ def main():
         step()
         ev1[i].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -215,7 +218,7 @@ def main():
 
     # optional exchange step, timed separately (never part of `value`)
     gather = None
-    if world > 1:
+    if distributed:
         from fenics_constitutive_amd.sharded import ShardPlan
 
         ng = min(args.gather_points, n)
@@ -238,7 +241,7 @@ def main():
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         shard_bytes = 42 * 8 * per
         gather = {"points_per_rank": per, "shard_GB": round(shard_bytes / 1e9, 3), "ms": round(float(tg.item()) * 1e3, 3),
-                  "algbw_GBs": round(shard_bytes * (world - 1) / float(tg.item()) / 1e9, 1),
+                  "recv_GBs_per_gpu": round(shard_bytes * (world - 1) / float(tg.item()) / 1e9, 1),
                   "note": "in-place all_gather_into_tensor of stress+tangent, outside the timed steps"}
         del out_s, out_t
 
@@ -288,7 +291,7 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

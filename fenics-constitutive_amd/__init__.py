@@ -15,6 +15,7 @@ from .models import (  # noqa: F401
     SpringMaxwellModel,
     VonMises3D,
 )
+from .wrappers import PlaneStrainFrom3D, UniaxialStrainFrom3D  # noqa: F401
 from .utils import get_elastic_tangent, get_identity, lame_parameters, strain_from_grad_u  # noqa: F401
 
 __version__ = "0.1.0"
@@ -28,6 +29,8 @@ __all__ = [
     "SpringKelvinModel",
     "LinearElasticity3D",
     "MisesPlasticityLinearHardening3D",
+    "UniaxialStrainFrom3D",
+    "PlaneStrainFrom3D",
     "lame_parameters",
     "get_elastic_tangent",
     "get_identity",

@@ -22,13 +22,17 @@ LINEAR_ELASTICITY, VON_MISES_3D, SPRING_MAXWELL, SPRING_KELVIN, COMFE_LINEAR_ELA
 
 MAX_HISTORY = 2
 
+# conversion kinds (include/fcamd.h)
+(GRAD_1D_TO_3D, STRESS_1D_TO_3D, STRESS_3D_TO_1D, TANGENT_3D_TO_1D,
+ GRAD_2D_TO_3D, STRESS_2D_TO_3D, STRESS_3D_TO_2D, TANGENT_3D_TO_2D) = range(1, 9)
+
 #: every symbol include/fcamd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "fcamd_context_create", "fcamd_context_destroy", "fcamd_context_set_stream",
     "fcamd_context_synchronize", "fcamd_model_create", "fcamd_model_destroy",
     "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_evaluate_device",
     "fcamd_evaluate_device_from", "fcamd_evaluate_host", "fcamd_strain_from_grad_u_device",
-    "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
+    "fcamd_convert_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
     "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
     "fcamd_last_error", "fcamd_status_string", "fcamd_version",
 ]
@@ -97,6 +101,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_evaluate_device_from.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_host.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int, C.POINTER(Stats)]
         lib.fcamd_strain_from_grad_u_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int]
+        lib.fcamd_convert_device.argtypes = [vp, C.c_int, C.c_int64, vp, vp]
         lib.fcamd_model_last_stats.argtypes = [vp, C.POINTER(Stats)]
         lib.fcamd_model_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         lib.fcamd_register_host_buffer.argtypes = [vp, vp, C.c_size_t]

@@ -526,6 +526,37 @@ int fcamd_strain_from_grad_u_device(fcamd_context* c, int64_t n, const double* g
     return FCAMD_OK;
 }
 
+int fcamd_convert_device(fcamd_context* c, int kind, int64_t n, const double* src, double* dst) {
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
+    if (n == 0) return FCAMD_OK;
+    if (!src || !dst) return fail(FCAMD_ERR_BAD_ARG, "NULL array");
+    CopyMap m{};
+    switch (kind) {
+        case FCAMD_GRAD_1D_TO_3D: m = {1, 1, 9, {0}, {0}}; break;
+        case FCAMD_STRESS_1D_TO_3D: m = {1, 1, 6, {0}, {0}}; break;
+        case FCAMD_STRESS_3D_TO_1D: m = {1, 6, 1, {0}, {0}}; break;
+        case FCAMD_TANGENT_3D_TO_1D: m = {1, 36, 1, {0}, {0}}; break;
+        case FCAMD_GRAD_2D_TO_3D: m = {4, 4, 9, {0, 1, 2, 3}, {0, 1, 3, 4}}; break;
+        case FCAMD_STRESS_2D_TO_3D: m = {4, 4, 6, {0, 1, 2, 3}, {0, 1, 2, 3}}; break;
+        case FCAMD_STRESS_3D_TO_2D: m = {4, 6, 4, {0, 1, 2, 3}, {0, 1, 2, 3}}; break;
+        case FCAMD_TANGENT_3D_TO_2D:
+            m.K = 16;
+            m.in_stride = 36;
+            m.out_stride = 16;
+            for (int r = 0; r < 4; ++r)
+                for (int cc = 0; cc < 4; ++cc) {
+                    m.imap[4 * r + cc] = 6 * r + cc;
+                    m.omap[4 * r + cc] = 4 * r + cc;
+                }
+            break;
+        default: return fail(FCAMD_ERR_BAD_ARG, "unknown conversion kind %d", kind);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_strided_copy(src, dst, n, m, c->stream));
+    return FCAMD_OK;
+}
+
 int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
     if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));

@@ -53,4 +53,12 @@ int default_grid(int law, int num_cu);
 hipError_t launch_strain(const double* grad, double* strain, long long n, double factor, int grid,
                          hipStream_t stream);
 
+// out[out_stride*i + omap[k]] = in[in_stride*i + imap[k]], k < K, i < n
+struct CopyMap {
+    int K, in_stride, out_stride;
+    int imap[16], omap[16];
+};
+hipError_t launch_strided_copy(const double* in, double* out, long long n, const CopyMap& m,
+                               hipStream_t stream);
+
 }  // namespace fcamd

@@ -761,6 +761,28 @@ int default_grid(int law, int num_cu) {
     return 16 * num_cu;
 }
 
+// Component maps of the 3D<->1D/2D wrappers: a pure strided copy, one thread per moved double.
+__global__ void __launch_bounds__(kBlock)
+    strided_copy_kernel(const double* in, double* out, long long n, const CopyMap m) {
+    const long long total = n * m.K;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+         e += (long long)gridDim.x * kBlock) {
+        const long long i = e / m.K;
+        const int k = (int)(e - i * m.K);
+        out[i * m.out_stride + m.omap[k]] = in[i * m.in_stride + m.imap[k]];
+    }
+}
+
+hipError_t launch_strided_copy(const double* in, double* out, long long n, const CopyMap& m,
+                               hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const long long total = n * m.K;
+    long long blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(strided_copy_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, in, out, n, m);
+    return hipGetLastError();
+}
+
 hipError_t launch_strain(const double* grad, double* strain, long long n, double factor, int grid,
                          hipStream_t stream) {
     hipLaunchKernelGGL((strain_kernel<kNT>), dim3(grid), dim3(kBlock), 0, stream, grad, strain, n,

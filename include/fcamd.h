@@ -52,7 +52,8 @@ typedef enum fcamd_status {
 /* ---- constitutive laws on the hot path ---------------------- */
 typedef enum fcamd_model_id {
     /* LinearElasticityModel, FULL -- models/linear_elasticity_model.py:26-45.
-       params[36]: tangent D row-major (host: get_elastic_tangent, utils.py:25-51). */
+       params[2]: E, nu (the tangent D is built on the host as get_elastic_tangent does,
+       utils.py:25-51). */
     FCAMD_LINEAR_ELASTICITY = 1,
     /* VonMises3D -- models/mises_plasticity_isotropic_hardening.py:57-175.
        params[5]: p_ka, p_mu, p_y0, p_y00, p_w.  history: eps_n(6), alpha(1). */
@@ -136,9 +137,10 @@ int fcamd_evaluate_device_from(fcamd_model* model, double t, double del_t, int64
                                int n_hist);
 
 /* Host evaluate: the ndarray entry.  Pointers are host arrays laid out as above; the
-   library stages them through pinned buffers (chunked, H2D / kernel / D2H overlapped
-   on three streams), runs the device path and writes stress / tangent / history back
-   in place.  Synchronous.  Validates like the reference and returns the matching
+   library stages them chunk by chunk (two chunk slots on two streams: H2D / kernel / D2H of
+   one chunk overlap the other's when the arrays are page-locked, see
+   fcamd_register_host_buffer), runs the device path and writes stress / tangent / history
+   back in place.  Synchronous.  Validates like the reference and returns the matching
    status; on FCAMD_ERR_NONCONVERGED the outputs hold the values the kernel produced
    (the reference raises mid-loop). `stats` may be NULL. */
 int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
@@ -149,6 +151,22 @@ int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
    rust_factor = 0: factor 1/2**0.5 (Python); 1: FRAC_1_SQRT_2 (mandel.rs:147). */
 int fcamd_strain_from_grad_u_device(fcamd_context* ctx, int64_t n, const double* grad_u,
                                     double* strain, int rust_factor);
+
+/* Component maps of the reference's 3D->1D/2D wrappers (models/utils.py:276-297, 362-412):
+   strided copies between a low-dimensional AoS array and its 3-D counterpart.  "TO_3D" kinds
+   write only the mapped components of dst (the others keep their values, as the reference's
+   cached 3-D arrays do). */
+typedef enum fcamd_convert_kind {
+    FCAMD_GRAD_1D_TO_3D = 1,     /* grad3d[9i+0]        <- grad1d[i]            utils.py:276-279 */
+    FCAMD_STRESS_1D_TO_3D = 2,   /* stress3d[6i+0]      <- stress1d[i]          utils.py:281-284 */
+    FCAMD_STRESS_3D_TO_1D = 3,   /* stress1d[i]         <- stress3d[6i+0]       utils.py:286-289 */
+    FCAMD_TANGENT_3D_TO_1D = 4,  /* tangent1d[i]        <- tangent3d[36i+0]     utils.py:291-294 */
+    FCAMD_GRAD_2D_TO_3D = 5,     /* grad3d[9i+{0,1,3,4}] <- grad2d[4i+{0,1,2,3}] utils.py:362-375 */
+    FCAMD_STRESS_2D_TO_3D = 6,   /* stress3d[6i+0..3]   <- stress2d[4i+0..3]    utils.py:377-383 */
+    FCAMD_STRESS_3D_TO_2D = 7,   /* stress2d[4i+0..3]   <- stress3d[6i+0..3]    utils.py:385-388 */
+    FCAMD_TANGENT_3D_TO_2D = 8   /* tangent2d[16i+4r+c] <- tangent3d[36i+6r+c], r,c<4  utils.py:390-412 */
+} fcamd_convert_kind;
+int fcamd_convert_device(fcamd_context* ctx, int kind, int64_t n, const double* src, double* dst);
 
 /* Synchronise the stream and read the counters accumulated by the last
    evaluate_device* launch of this model. */

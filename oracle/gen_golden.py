@@ -167,5 +167,53 @@ def main():
         r.save(fname)
 
 
+def main_wrappers():
+    """Golden vectors of the 3D->1D/2D wrappers (models/utils.py:211-412) around LE, VonMises3D and
+    Maxwell; multi-call sequences on ONE wrapper instance so the cached 3-D arrays persist as in
+    the reference."""
+    m = import_reference()
+    FULL = m.StressStrainConstraint.FULL
+    rng = np.random.default_rng(7)
+    d = {}
+    idx = 0
+    vm_p = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}
+    sls_p = {"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}
+    le_p = {"E": 42.0, "nu": 0.3}
+    cases = [
+        ("plane_strain", "le", m.PlaneStrainFrom3D, lambda: m.LinearElasticityModel(le_p, FULL), None, 1e-3),
+        ("uniaxial_strain", "le", m.UniaxialStrainFrom3D, lambda: m.LinearElasticityModel(le_p, FULL), None, 1e-3),
+        ("plane_strain", "vm", m.PlaneStrainFrom3D, lambda: m.VonMises3D(vm_p), {"eps_n": 6, "alpha": 1}, 4e-3),
+        ("uniaxial_strain", "vm", m.UniaxialStrainFrom3D, lambda: m.VonMises3D(vm_p), {"eps_n": 6, "alpha": 1}, 6e-3),
+        ("plane_strain", "maxwell", m.PlaneStrainFrom3D, lambda: m.SpringMaxwellModel(sls_p, FULL), {"strain_visco": 6, "strain": 6}, 1e-3),
+    ]
+    for cname, lname, wcls, mk, hd, gscale in cases:
+        w = wcls(mk())
+        gd2, sd = w.geometric_dim**2, w.stress_strain_dim
+        n = 150
+        s = np.zeros(sd * n)
+        h = None if hd is None else {k: np.zeros(dim * n) for k, dim in hd.items()}
+        for step in range(3):
+            g = rng.normal(scale=gscale, size=gd2 * n)
+            s_in = s.copy()
+            h_in = None if h is None else {k: v.copy() for k, v in h.items()}
+            tan = np.full(sd * sd * n, np.nan)
+            w.evaluate(0.0, 2.0, g, s, tan, h)
+            p = f"c{idx}."
+            d[p + "wrapper"], d[p + "law"], d[p + "step"] = np.array(cname), np.array(lname), np.int64(step)
+            d[p + "grad"], d[p + "stress_in"], d[p + "stress_out"], d[p + "tangent_out"] = g, s_in, s.copy(), tan
+            if h is not None:
+                d[p + "hist_keys"] = np.array(list(h.keys()))
+                for k in h:
+                    d[p + "hist_in." + k], d[p + "hist_out." + k] = h_in[k], h[k].copy()
+            idx += 1
+    d["n_calls"] = np.int64(idx)
+    np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **d)
+    print("wrappers.npz", idx, "calls")
+
+
 if __name__ == "__main__":
-    main()
+    if "--wrappers" in sys.argv:
+        main_wrappers()
+    else:
+        main()
+        main_wrappers()

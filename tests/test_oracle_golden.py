@@ -217,3 +217,23 @@ def test_perfect_plasticity_cross_check():
     O.comfe_mises_plasticity(p_rs, 0, 1, g, s_rs, np.zeros(36 * n), h_rs)
     assert rel_err(s_rs, s_py) < 1e-10
     assert rel_err(h_rs["history"].reshape(-1, 7)[:, 0], h_py["alpha"]) < 1e-9
+
+
+# ---- 3D -> 1D/2D wrappers (models/utils.py:211-412) --------------------------
+
+
+def test_wrappers_golden():
+    from wrappers_util import PARAMS, load_sequences
+
+    fns = {"le": O.linear_elasticity, "vm": O.von_mises_3d_loop, "maxwell": O.spring_maxwell}
+    for kind, lname, calls in load_sequences():
+        w = O.From3D(kind, fns[lname], PARAMS[lname])
+        for c in calls:  # one wrapper instance per sequence: the cached 3-D arrays persist
+            s = c["stress_in"].copy()
+            t = np.full_like(c["tangent_out"], np.nan)
+            h = None if c["hist_in"] is None else {k: v.copy() for k, v in c["hist_in"].items()}
+            w.evaluate(0.0, 2.0, c["grad"], s, t, h)
+            assert rel_err(s, c["stress_out"]) <= 1e-13 and rel_err(t, c["tangent_out"]) <= 1e-13, (kind, lname)
+            if h is not None:
+                for k in h:
+                    assert rel_err(h[k], c["hist_out"][k]) <= 1e-13
