@@ -32,7 +32,7 @@ SYMBOLS = [
     "fcamd_context_synchronize", "fcamd_model_create", "fcamd_model_destroy",
     "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_evaluate_device",
     "fcamd_evaluate_device_from", "fcamd_evaluate_host", "fcamd_strain_from_grad_u_device",
-    "fcamd_convert_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
+    "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
     "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
     "fcamd_last_error", "fcamd_status_string", "fcamd_version",
 ]
@@ -102,6 +102,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_evaluate_host.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int, C.POINTER(Stats)]
         lib.fcamd_strain_from_grad_u_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int]
         lib.fcamd_convert_device.argtypes = [vp, C.c_int, C.c_int64, vp, vp]
+        lib.fcamd_map_rows_device.argtypes = [vp, C.c_int64, C.c_int, vp, vp, vp, vp]
         lib.fcamd_model_last_stats.argtypes = [vp, C.POINTER(Stats)]
         lib.fcamd_model_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         lib.fcamd_register_host_buffer.argtypes = [vp, vp, C.c_size_t]

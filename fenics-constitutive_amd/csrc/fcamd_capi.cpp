@@ -91,6 +91,53 @@ void elastic_tangent_full(double E, double nu, double D[36]) {
     for (int i = 3; i < 6; ++i) D[6 * i + i] = 2.0 * mu;
 }
 
+struct Dims {
+    int gd2, sd, gdim;
+};
+
+// stress_strain_dim / geometric_dim of a constraint (models/interfaces.py:30-73)
+Dims dims_of(int constraint) {
+    switch (constraint) {
+        case FCAMD_UNIAXIAL_STRAIN:
+        case FCAMD_UNIAXIAL_STRESS: return {1, 1, 1};
+        case FCAMD_PLANE_STRAIN:
+        case FCAMD_PLANE_STRESS: return {4, 4, 2};
+        default: return {9, 6, 3};
+    }
+}
+
+// get_elastic_tangent for every constraint (utils.py:25-93), compact row-major sd x sd
+void elastic_tangent(double E, double nu, int constraint, double D[36]) {
+    for (int i = 0; i < 36; ++i) D[i] = 0.0;
+    double mu, lam;
+    lame(E, nu, &mu, &lam);
+    switch (constraint) {
+        case FCAMD_FULL: elastic_tangent_full(E, nu, D); break;
+        case FCAMD_PLANE_STRAIN:
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) D[4 * i + j] = (i == j) ? 2.0 * mu + lam : lam;
+            D[15] = 2.0 * mu;
+            break;
+        case FCAMD_PLANE_STRESS: {
+            const double c = E / (1 - std::pow(nu, 2.0));
+            const double M[16] = {1.0, nu, 0.0, 0.0, nu, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, (1.0 - nu)};
+            for (int i = 0; i < 16; ++i) D[i] = c * M[i];
+            break;
+        }
+        case FCAMD_UNIAXIAL_STRAIN: D[0] = E * (1.0 - nu) / ((1.0 + nu) * (1.0 - 2.0 * nu)); break;
+        case FCAMD_UNIAXIAL_STRESS: D[0] = E; break;
+    }
+}
+
+// get_identity (utils.py:96-129)
+void identity_of(int constraint, double I2[6]) {
+    for (int i = 0; i < 6; ++i) I2[i] = 0.0;
+    const int ones = (constraint == FCAMD_FULL || constraint == FCAMD_PLANE_STRAIN) ? 3
+                     : (constraint == FCAMD_PLANE_STRESS)                           ? 2
+                                                                                    : 1;
+    for (int i = 0; i < ones; ++i) I2[i] = 1.0;
+}
+
 void comfe_projections(double soo[36], double pvol[36], double pdev[36]) {
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) {
@@ -120,6 +167,8 @@ struct fcamd_context {
 struct fcamd_model {
     fcamd_context* ctx = nullptr;
     int law = 0;
+    int constraint = FCAMD_FULL;
+    Dims dims{9, 6, 3};
     LawInfo info{};
     double params[8] = {0};
     unsigned long long* d_counters = nullptr;  // [4] device
@@ -141,7 +190,7 @@ void fill_constants(const fcamd_model* m, double del_t, EvalArgs* a) {
     switch (m->law) {
         case FCAMD_LINEAR_ELASTICITY: {
             sc.s[0] = kFactorPy;
-            elastic_tangent_full(p[0], p[1], tb.a);
+            elastic_tangent(p[0], p[1], m->constraint, tb.a);
             std::memcpy(tb.c, tb.a, sizeof(tb.a));
             break;
         }
@@ -166,10 +215,11 @@ void fill_constants(const fcamd_model* m, double del_t, EvalArgs* a) {
             break;
         }
         case FCAMD_SPRING_MAXWELL: {
-            const double E0 = p[0], E1 = p[1], tau = p[2], nu = p[3];
+            const double E0 = p[0], E1 = p[1], tau = p[2];
+            const double nu = (m->constraint == FCAMD_UNIAXIAL_STRESS) ? 0.0 : p[3];  // spring_*_model.py:31-34
             double D0[36], D1[36], mu1, lam1;
-            elastic_tangent_full(E0, nu, D0);
-            elastic_tangent_full(E1, nu, D1);
+            elastic_tangent(E0, nu, m->constraint, D0);
+            elastic_tangent(E1, nu, m->constraint, D1);
             lame(E1, nu, &mu1, &lam1);
             const double factor = 1 / del_t + 1 / tau;
             sc.s[0] = kFactorPy;
@@ -186,9 +236,12 @@ void fill_constants(const fcamd_model* m, double del_t, EvalArgs* a) {
             break;
         }
         case FCAMD_SPRING_KELVIN: {
-            const double E0 = p[0], E1 = p[1], tau = p[2], nu = p[3];
-            double D0[36], mu0, lam0, mu1, lam1;
-            elastic_tangent_full(E0, nu, D0);
+            const double E0 = p[0], E1 = p[1], tau = p[2];
+            const double nu = (m->constraint == FCAMD_UNIAXIAL_STRESS) ? 0.0 : p[3];  // spring_*_model.py:31-34
+            double D0[36], mu0, lam0, mu1, lam1, I2[6];
+            elastic_tangent(E0, nu, m->constraint, D0);
+            identity_of(m->constraint, I2);
+            for (int i = 0; i < 6; ++i) sc.s[8 + i] = I2[i];
             lame(E0, nu, &mu0, &lam0);
             lame(E1, nu, &mu1, &lam1);
             const double factor = 1 / del_t + 1 / tau + mu0 / (tau * mu1);
@@ -295,7 +348,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     if (reset_counters) HIP_TRY(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), stream));
     if (n == 0) return FCAMD_OK;
     const int grid = grid_for(m, n);
-    HIP_TRY(launch_evaluate(m->law, a, grid, stream));
+    HIP_TRY(launch_evaluate(m->law, m->dims.gdim, a, grid, stream));
     return FCAMD_OK;
 }
 
@@ -407,9 +460,13 @@ int fcamd_model_create(fcamd_context* c, int model_id, int constraint, const dou
     if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
     LawInfo li;
     if (!law_info(model_id, &li)) return fail(FCAMD_ERR_BAD_ARG, "unknown model id %d", model_id);
-    if (constraint != FCAMD_FULL)
-        return fail(FCAMD_ERR_UNSUPPORTED,
-                    "only StressStrainConstraint.FULL has device kernels (got %d)", constraint);
+    if (constraint < FCAMD_UNIAXIAL_STRAIN || constraint > FCAMD_FULL)
+        return fail(FCAMD_ERR_BAD_ARG, "unknown constraint %d", constraint);
+    const bool all_constraints = model_id == FCAMD_LINEAR_ELASTICITY || model_id == FCAMD_SPRING_MAXWELL ||
+                                 model_id == FCAMD_SPRING_KELVIN;
+    if (constraint != FCAMD_FULL && !all_constraints)
+        return fail(FCAMD_ERR_UNSUPPORTED, "model %d is implemented for StressStrainConstraint.FULL only (got %d)",
+                    model_id, constraint);
     if (!params || n_params != li.n_params)
         return fail(FCAMD_ERR_BAD_ARG, "model %d expects %d parameters, got %d", model_id,
                     li.n_params, n_params);
@@ -418,6 +475,10 @@ int fcamd_model_create(fcamd_context* c, int model_id, int constraint, const dou
     if (!m) return fail(FCAMD_ERR_BAD_ARG, "out of host memory");
     m->ctx = c;
     m->law = model_id;
+    m->constraint = constraint;
+    m->dims = dims_of(constraint);
+    if (all_constraints)
+        for (int k = 0; k < li.n_hist; ++k) li.hist[k].dim = m->dims.sd;  // history_dim = stress_strain_dim
     m->info = li;
     for (int i = 0; i < n_params; ++i) m->params[i] = params[i];
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_counters), 4 * sizeof(unsigned long long));
@@ -557,6 +618,17 @@ int fcamd_convert_device(fcamd_context* c, int kind, int64_t n, const double* sr
     return FCAMD_OK;
 }
 
+int fcamd_map_rows_device(fcamd_context* c, int64_t n_rows, int row_size, const double* src,
+                          const int32_t* src_idx, double* dst, const int32_t* dst_idx) {
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    if (n_rows < 0 || row_size <= 0) return fail(FCAMD_ERR_SIZE, "bad row count / row size");
+    if (n_rows == 0) return FCAMD_OK;
+    if (!src || !dst) return fail(FCAMD_ERR_BAD_ARG, "NULL array");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_map_rows(src, src_idx, dst, dst_idx, n_rows, row_size, c->stream));
+    return FCAMD_OK;
+}
+
 int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
     if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -604,7 +676,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
         }
         c->dchunk_points = 0;
         for (int i = 0; i < 2; ++i)
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dchunk[i]), (size_t)chunk * 64 * sizeof(double)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dchunk[i]), (size_t)chunk * 66 * sizeof(double)));
         c->dchunk_points = (size_t)chunk;
     }
     (void)per_point;
@@ -620,7 +692,8 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
         hipStream_t s = c->hstream[slot];
         // device layout of a slot (each sub-array starts 16-byte aligned: chunk is a multiple of 64)
         double* d_grad = c->dchunk[slot];
-        double* d_stress = d_grad + 9 * c->dchunk_points;
+        const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
+        double* d_stress = d_grad + 10 * c->dchunk_points;  // slots sized for FULL (9 -> 10: keeps 16-B alignment)
         double* d_tan = d_stress + 6 * c->dchunk_points;
         double* d_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
         double* cur = d_tan + 36 * c->dchunk_points;
@@ -630,17 +703,17 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
             // keep 16-byte alignment for odd per-point dimensions (alpha: 1, comfe history: 7)
             if ((reinterpret_cast<uintptr_t>(cur) & 15u) != 0) cur += 1;
         }
-        HIP_TRY(hipMemcpyAsync(d_grad, grad + 9 * p0, (size_t)np * 9 * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_stress, stress + 6 * p0, (size_t)np * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_stress, stress + SD * p0, (size_t)np * SD * sizeof(double), hipMemcpyHostToDevice, s));
         for (int k = 0; k < m->info.n_hist; ++k) {
             const size_t d = (size_t)m->info.hist[k].dim;
             HIP_TRY(hipMemcpyAsync(d_hist[k], hist[k] + d * p0, (size_t)np * d * sizeof(double), hipMemcpyHostToDevice, s));
         }
         st = enqueue(m, del_t, np, d_grad, d_stress, d_stress, tangent ? d_tan : nullptr, d_hist, d_hist, s, false);
         if (st != FCAMD_OK) return st;
-        HIP_TRY(hipMemcpyAsync(stress + 6 * p0, d_stress, (size_t)np * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(stress + SD * p0, d_stress, (size_t)np * SD * sizeof(double), hipMemcpyDeviceToHost, s));
         if (tangent)
-            HIP_TRY(hipMemcpyAsync(tangent + 36 * p0, d_tan, (size_t)np * 36 * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(tangent + TD * p0, d_tan, (size_t)np * TD * sizeof(double), hipMemcpyDeviceToHost, s));
         for (int k = 0; k < m->info.n_hist; ++k) {
             const size_t d = (size_t)m->info.hist[k].dim;
             HIP_TRY(hipMemcpyAsync(hist[k] + d * p0, d_hist[k], (size_t)np * d * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -46,7 +46,8 @@ struct EvalArgs {
 };
 
 // Launch the evaluate kernel of `law` on `stream` with `grid` workgroups of 256 threads.
-hipError_t launch_evaluate(int law, const EvalArgs& args, int grid, hipStream_t stream);
+// dims = geometric dimension of the constraint (3: FULL; 2: plane strain/stress; 1: uniaxial)
+hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hipStream_t stream);
 // Occupancy-derived default grid (workgroups) for `law` on the current device.
 int default_grid(int law, int num_cu);
 // strain_from_grad_u, FULL.
@@ -60,5 +61,8 @@ struct CopyMap {
 };
 hipError_t launch_strided_copy(const double* in, double* out, long long n, const CopyMap& m,
                                hipStream_t stream);
+
+hipError_t launch_map_rows(const double* src, const int* src_idx, double* dst, const int* dst_idx,
+                           long long n_rows, int row_size, hipStream_t stream);
 
 }  // namespace fcamd

@@ -602,6 +602,131 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Tables
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Low-dimensional constraints (uniaxial strain/stress: DIMS = 1; plane strain/stress:
+// DIMS = 2) of the three laws the reference implements "for all constraints": LE
+// (linear_elasticity_model.py:26-45), Maxwell (spring_maxwell_model.py:40-88), Kelvin
+// (spring_kelvin_model.py:43-88).  Same skeleton as the 3-D tiles; gradient GD2 = DIMS^2 and
+// Mandel vectors SD = 1 / 4 doubles per point, tangent SD^2.  The strain/stress variants of
+// one dimension differ only in host constants (tangent tables, identity vector).
+// Tables are compact (row stride SD).  scalars as in tile_sls; s[8 + i] = I2[i].
+// ---------------------------------------------------------------------------------------
+template <int DIMS>
+struct LowDim {
+    static constexpr int GD2 = DIMS * DIMS;
+    static constexpr int SD = DIMS == 2 ? 4 : 1;
+};
+
+// strain_from_grad_u, utils.py:153-186
+template <int DIMS>
+__device__ __forceinline__ void strain_lowdim(const double (&g)[LowDim<DIMS>::GD2], double f,
+                                              double (&e)[LowDim<DIMS>::SD]) {
+    if constexpr (DIMS == 1) {
+        e[0] = g[0];
+    } else {
+        e[0] = g[0];
+        e[1] = g[3];
+        e[2] = 0.0;
+        e[3] = f * (g[1] + g[2]);
+    }
+}
+
+template <int SD>
+__device__ __forceinline__ void row_times_matrix_fma_n(const double (&x)[SD], const double* M,
+                                                       double (&y)[SD]) {
+#pragma unroll
+    for (int i = 0; i < SD; ++i) {
+        double acc = x[0] * M[i];
+#pragma unroll
+        for (int k = 1; k < SD; ++k) acc = __builtin_fma(x[k], M[SD * k + i], acc);
+        y[i] = acc;
+    }
+}
+
+// tangent = tile(D.flatten()): SD = 4 -> 8 chunks per point (the chunk a lane stores never
+// changes: 64 = 0 mod 8); SD = 1 -> half a chunk per point, lanes < 32 store (D, D).
+template <int SD, bool FULL, bool NT>
+__device__ __forceinline__ void tangent_const_n(const double* tab, double* dst, int npts, int lane) {
+    if constexpr (SD == 4) {
+        const d2 v = reinterpret_cast<const d2*>(tab)[lane & 7];
+        const int nchunks = npts * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = k * kWave + lane;
+            if (FULL || q < nchunks) store16<NT>(dst + 2 * q, v);
+        }
+    } else {
+        const double D = tab[0];
+        if constexpr (FULL) {
+            d2 v;
+            v.x = D;
+            v.y = D;
+            if (lane < 32) store16<NT>(dst + 2 * lane, v);
+        } else {
+            if (lane < npts) dst[lane] = D;
+        }
+    }
+}
+
+template <int LAW, int DIMS, bool FULL, bool NT>
+__device__ __forceinline__ void tile_lowdim(const EvalArgs& a, const Tables* T, double* region,
+                                            long long p0, int npts, int lane) {
+    constexpr int GD2 = LowDim<DIMS>::GD2, SD = LowDim<DIMS>::SD;
+    constexpr bool HIST = (LAW != LAW_LE);
+    Chunks<GD2> cg;
+    Chunks<SD> cs, cv, cn;
+    tile_load<GD2, FULL, NT>(cg, a.grad + p0 * GD2, npts * GD2, lane);
+    tile_load<SD, FULL, NT>(cs, a.stress_in + p0 * SD, npts * SD, lane);
+    if constexpr (HIST) {
+        tile_load<SD, FULL, NT>(cv, a.h0_in + p0 * SD, npts * SD, lane);
+        tile_load<SD, FULL, NT>(cn, a.h1_in + p0 * SD, npts * SD, lane);
+    }
+    if (a.tangent) tangent_const_n<SD, FULL, NT>(T->c, a.tangent + p0 * SD * SD, npts, lane);
+    double g[GD2], s[SD], e[SD], y[SD];
+    transpose_in<GD2>(cg, region, lane, g);
+    transpose_in<SD>(cs, region, lane, s);
+    strain_lowdim<DIMS>(g, a.sc.s[0], e);
+    if constexpr (LAW == LAW_LE) {
+        row_times_matrix_fma_n<SD>(e, T->a, y);
+#pragma unroll
+        for (int i = 0; i < SD; ++i) s[i] = s[i] + y[i];
+        transpose_out<SD, FULL, NT>(s, region, lane, a.stress_out + p0 * SD, npts * SD);
+    } else {
+        double ev[SD], en[SD], dv[SD];
+        transpose_in<SD>(cv, region, lane, ev);
+        transpose_in<SD>(cn, region, lane, en);
+        const double inv_factor = a.sc.s[1], cA = a.sc.s[2], cB = a.sc.s[3], c2mu = a.sc.s[4];
+        if constexpr (LAW == LAW_MAXWELL) {
+            double x[SD];
+#pragma unroll
+            for (int i = 0; i < SD; ++i) x[i] = cA * (en[i] + e[i]);
+            row_times_matrix_fma_n<SD>(x, T->a, y);
+#pragma unroll
+            for (int i = 0; i < SD; ++i) dv[i] = inv_factor * (y[i] - cB * ev[i]);
+            row_times_matrix_fma_n<SD>(e, T->b, y);
+        } else {
+            const double cC = a.sc.s[5], cD = a.sc.s[6];
+            double tr = e[0];  // np.sum(strain_increment[:, :gdim], axis=1), gdim = DIMS
+            if constexpr (DIMS == 2) tr = e[0] + e[1];
+            const double ctr = cD * tr;
+#pragma unroll
+            for (int i = 0; i < SD; ++i)
+                dv[i] = inv_factor * (((cA * s[i] - cB * ev[i]) + cC * e[i]) + ctr * a.sc.s[8 + i]);
+            row_times_matrix_fma_n<SD>(e, T->a, y);
+        }
+#pragma unroll
+        for (int i = 0; i < SD; ++i) {
+            s[i] = s[i] + (y[i] - c2mu * dv[i]);
+            ev[i] = ev[i] + dv[i];
+            en[i] = en[i] + e[i];
+        }
+        transpose_out<SD, FULL, NT>(s, region, lane, a.stress_out + p0 * SD, npts * SD);
+        transpose_out<SD, FULL, NT>(ev, region, lane, a.h0_out + p0 * SD, npts * SD);
+        transpose_out<SD, FULL, NT>(en, region, lane, a.h1_out + p0 * SD, npts * SD);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------
@@ -667,6 +792,31 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
     for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
         run_tile<LAW, true, NT>(a, &T, region, tile * kWave, kWave, lane, r0, st);
     flush_stats<LAW>(a, st, lane);
+}
+
+// Low-dimensional constraints: same persistent structure, DIMS = 1 or 2.
+template <int LAW, int DIMS, bool NT>
+__global__ void __launch_bounds__(kBlock, 4) evaluate_lowdim_kernel(const EvalArgs a) {
+    __shared__ __attribute__((aligned(16))) Tables T;
+    __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
+    stage_tables(a, &T);
+    int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const long long nfull = a.n / kWave;
+    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
+    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride) {
+        asm volatile("" : "+v"(lane));
+        tile_lowdim<LAW, DIMS, true, NT>(a, &T, scratch[wave], tile * kWave, kWave, lane);
+    }
+}
+
+template <int LAW, int DIMS>
+__global__ void __launch_bounds__(kWave) evaluate_lowdim_tail_kernel(const EvalArgs a) {
+    __shared__ __attribute__((aligned(16))) Tables T;
+    __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
+    stage_tables(a, &T);
+    const long long p0 = (a.n / kWave) * kWave;
+    tile_lowdim<LAW, DIMS, false, false>(a, &T, region, p0, (int)(a.n - p0), (int)threadIdx.x);
 }
 
 // Tail kernel: the last, ragged tile (n % 64 points), one wavefront, guarded 8-byte accesses.
@@ -740,7 +890,27 @@ static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_evaluate(int law, const EvalArgs& args, int grid, hipStream_t stream) {
+template <int LAW, int DIMS>
+static hipError_t launch_lowdim(const EvalArgs& args, int grid, hipStream_t stream) {
+    if (args.n >= kWave)
+        hipLaunchKernelGGL((evaluate_lowdim_kernel<LAW, DIMS, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+    if (args.n % kWave != 0)
+        hipLaunchKernelGGL((evaluate_lowdim_tail_kernel<LAW, DIMS>), dim3(1), dim3(kWave), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hipStream_t stream) {
+    if (dims == 1 || dims == 2) {
+        switch (law * 10 + dims) {
+            case LAW_LE * 10 + 1: return launch_lowdim<LAW_LE, 1>(args, grid, stream);
+            case LAW_LE * 10 + 2: return launch_lowdim<LAW_LE, 2>(args, grid, stream);
+            case LAW_MAXWELL * 10 + 1: return launch_lowdim<LAW_MAXWELL, 1>(args, grid, stream);
+            case LAW_MAXWELL * 10 + 2: return launch_lowdim<LAW_MAXWELL, 2>(args, grid, stream);
+            case LAW_KELVIN * 10 + 1: return launch_lowdim<LAW_KELVIN, 1>(args, grid, stream);
+            case LAW_KELVIN * 10 + 2: return launch_lowdim<LAW_KELVIN, 2>(args, grid, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (law) {
         case LAW_LE: return launch_law<LAW_LE>(args, grid, stream);
         case LAW_VM3D: return launch_law<LAW_VM3D>(args, grid, stream);
@@ -780,6 +950,45 @@ hipError_t launch_strided_copy(const double* in, double* out, long long n, const
     long long blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(strided_copy_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, in, out, n, m);
+    return hipGetLastError();
+}
+
+// Row gather/scatter (submesh <-> parent maps).  One thread per 16-byte chunk when rows are an
+// even number of doubles (6, 36, 16, 4: consecutive lanes walk along a row, so each row is moved
+// by full-width contiguous accesses), one per double otherwise.
+template <int W>  // doubles per thread: 2 or 1
+__global__ void __launch_bounds__(kBlock)
+    map_rows_kernel(const double* src, const int* src_idx, double* dst, const int* dst_idx,
+                    long long n_rows, int row_size) {
+    const int per_row = row_size / W;
+    const long long total = n_rows * per_row;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+         e += (long long)gridDim.x * kBlock) {
+        const long long r = e / per_row;
+        const int c = (int)(e - r * per_row);
+        const long long sr = src_idx ? (long long)src_idx[r] : r;
+        const long long dr = dst_idx ? (long long)dst_idx[r] : r;
+        if constexpr (W == 2) {
+            *reinterpret_cast<d2*>(dst + dr * row_size + 2 * c) =
+                *reinterpret_cast<const d2*>(src + sr * row_size + 2 * c);
+        } else {
+            dst[dr * row_size + c] = src[sr * row_size + c];
+        }
+    }
+}
+
+hipError_t launch_map_rows(const double* src, const int* src_idx, double* dst, const int* dst_idx,
+                           long long n_rows, int row_size, hipStream_t stream) {
+    if (n_rows <= 0 || row_size <= 0) return hipSuccess;
+    const bool wide = (row_size % 2 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+    const long long total = n_rows * (wide ? row_size / 2 : row_size);
+    long long blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (wide)
+        hipLaunchKernelGGL(map_rows_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, src, src_idx, dst, dst_idx, n_rows, row_size);
+    else
+        hipLaunchKernelGGL(map_rows_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, src, src_idx, dst, dst_idx, n_rows, row_size);
     return hipGetLastError();
 }
 

@@ -74,11 +74,6 @@ class DeviceLaw(IncrSmallStrainModel):
     def _handle(self, device: int = 0) -> _capi.Model:
         h = self._handles.get(device)
         if h is None:
-            if self._constraint.name != "FULL":
-                raise NotImplementedError(
-                    f"{type(self).__name__}: only StressStrainConstraint.FULL has device kernels; "
-                    "wrap the 3-D model in PlaneStrainFrom3D / UniaxialStrainFrom3D"
-                )
             ctx = _capi.get_context(device)
             h = self._handles[device] = _capi.Model(ctx, self._model_id, self._constraint.value,
                                                     self._parameter_vector)
@@ -155,8 +150,9 @@ class DeviceLaw(IncrSmallStrainModel):
         solver/_history.py:64-79).  Device tensors only."""
         hist = self._history_arrays(history)
         hprev = self._history_arrays(history_prev)
-        n = _size(grad_del_u) // 9
-        assert n == _size(stress) // 6 == _size(stress_prev) // 6 and (tangent is None or n == _size(tangent) // 36)
+        gd2, sd = self.geometric_dim**2, self.stress_strain_dim
+        n = _size(grad_del_u) // gd2
+        assert n == _size(stress) // sd == _size(stress_prev) // sd and (tangent is None or n == _size(tangent) // (sd * sd))
         self._evaluate_device(t, del_t, n, grad_del_u, stress, tangent, hist, stress_prev, hprev)
 
     def device_stats(self, device: int = 0):

@@ -168,6 +168,15 @@ typedef enum fcamd_convert_kind {
 } fcamd_convert_kind;
 int fcamd_convert_device(fcamd_context* ctx, int kind, int64_t n, const double* src, double* dst);
 
+/* Row gather/scatter between a parent quadrature array and a per-material submesh array:
+       dst[row_size*dst_idx[r] + k] = src[row_size*src_idx[r] + k],  r < n_rows, k < row_size
+   = SubSpaceMap.map_to_parent / map_to_sub (solver/maps.py:82-123:
+   "parent_array[self.parent] = sub_array[self.sub]" with rows of 6 (stress) or 36 (tangent)
+   doubles).  Index arrays are int32 device arrays (dolfinx dof indices are int32); NULL means
+   the identity (IdentityMap, solver/maps.py:29-59). */
+int fcamd_map_rows_device(fcamd_context* ctx, int64_t n_rows, int row_size, const double* src,
+                          const int32_t* src_idx, double* dst, const int32_t* dst_idx);
+
 /* Synchronise the stream and read the counters accumulated by the last
    evaluate_device* launch of this model. */
 int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);

@@ -211,9 +211,46 @@ def main_wrappers():
     print("wrappers.npz", idx, "calls")
 
 
+def main_constraints():
+    """LE / Maxwell / Kelvin under the four non-FULL constraints (multi-step, carried history)."""
+    m = import_reference()
+    C = m.StressStrainConstraint
+    rng = np.random.default_rng(99)
+    d, idx = {}, 0
+    sls_p = {"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}
+    le_p = {"E": 42.0, "nu": 0.3}
+    for c in (C.UNIAXIAL_STRAIN, C.UNIAXIAL_STRESS, C.PLANE_STRAIN, C.PLANE_STRESS):
+        for lname, mk, hist in (("le", lambda: m.LinearElasticityModel(le_p, c), False),
+                                ("maxwell", lambda: m.SpringMaxwellModel(sls_p, c), True),
+                                ("kelvin", lambda: m.SpringKelvinModel(sls_p, c), True)):
+            law = mk()
+            gd2, sd = law.geometric_dim**2, law.stress_strain_dim
+            n = 203
+            s = rng.normal(size=sd * n)
+            h = {"strain_visco": np.zeros(sd * n), "strain": np.zeros(sd * n)} if hist else None
+            for step, dt in enumerate([1e-8, 2.0, 0.1]):
+                g = rng.normal(scale=1e-3, size=gd2 * n)
+                s_in, h_in = s.copy(), None if h is None else {k: v.copy() for k, v in h.items()}
+                tan = np.full(sd * sd * n, np.nan)
+                law.evaluate(0.0, dt, g, s, tan, h)
+                p = f"c{idx}."
+                d[p + "constraint"], d[p + "law"], d[p + "del_t"] = np.array(c.name), np.array(lname), np.float64(dt)
+                d[p + "grad"], d[p + "stress_in"], d[p + "stress_out"], d[p + "tangent_out"] = g, s_in, s.copy(), tan
+                if h is not None:
+                    for k in h:
+                        d[p + "hist_in." + k], d[p + "hist_out." + k] = h_in[k], h[k].copy()
+                idx += 1
+    d["n_calls"] = np.int64(idx)
+    np.savez_compressed(os.path.join(OUT, "constraints.npz"), **d)
+    print("constraints.npz", idx, "calls")
+
+
 if __name__ == "__main__":
-    if "--wrappers" in sys.argv:
+    if "--constraints" in sys.argv:
+        main_constraints()
+    elif "--wrappers" in sys.argv:
         main_wrappers()
     else:
         main()
         main_wrappers()
+        main_constraints()

@@ -1,0 +1,98 @@
+"""GPU parity of LinearElasticityModel / SpringMaxwellModel / SpringKelvinModel under the four
+non-FULL constraints (native low-dimensional kernels) against golden vectors captured from the
+reference, plus ragged sizes against the oracle and the reference's own cross-checks in array
+form (tests/models/test_elasticity.py:239-333: plane strain == 3-D wrapper)."""
+
+import numpy as np
+import pytest
+from golden_util import rel_err
+from wrappers_util import CPARAMS, load_constraint_calls
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import fenics_constitutive_amd as fc  # noqa: E402
+from oracle import numpy_oracle as O  # noqa: E402
+
+C = fc.StressStrainConstraint
+
+
+def make(law, cname):
+    c = C[cname]
+    return {"le": lambda: fc.LinearElasticityModel(CPARAMS["le"], c), "maxwell": lambda: fc.SpringMaxwellModel(CPARAMS["maxwell"], c),
+            "kelvin": lambda: fc.SpringKelvinModel(CPARAMS["kelvin"], c)}[law]()
+
+
+CALLS = load_constraint_calls()
+
+
+@pytest.mark.parametrize("path", ["host", "device"])
+@pytest.mark.parametrize("c", CALLS, ids=[f"{c['law']}-{c['constraint']}-{i}" for i, c in enumerate(CALLS)])
+def test_constraint_golden(c, path):
+    law = make(c["law"], c["constraint"])
+    s, t = c["stress_in"].copy(), np.full_like(c["tangent_out"], np.nan)
+    h = None if c["hist_in"] is None else {k: v.copy() for k, v in c["hist_in"].items()}
+    if path == "host":
+        law.evaluate(0.0, c["del_t"], c["grad"], s, t, h)
+    else:
+        sd, td = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+        hd = None if h is None else {k: torch.from_numpy(v).cuda() for k, v in h.items()}
+        law.evaluate(0.0, c["del_t"], torch.from_numpy(c["grad"]).cuda(), sd, td, hd)
+        s, t = sd.cpu().numpy(), td.cpu().numpy()
+        h = None if hd is None else {k: v.cpu().numpy() for k, v in hd.items()}
+    assert rel_err(s, c["stress_out"]) <= 1e-10 and rel_err(t, c["tangent_out"]) <= 1e-10
+    assert rel_err(s, c["stress_out"]) <= 1e-14 and rel_err(t, c["tangent_out"]) <= 1e-14  # regression bound
+    if h is not None:
+        for k in h:
+            assert rel_err(h[k], c["hist_out"][k]) <= 1e-10, k
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 32, 33, 63, 64, 65, 1000, 100_003])
+@pytest.mark.parametrize("cname", ["UNIAXIAL_STRAIN", "UNIAXIAL_STRESS", "PLANE_STRAIN", "PLANE_STRESS"])
+@pytest.mark.parametrize("law", ["le", "maxwell", "kelvin"])
+def test_constraint_sizes(law, cname, n):
+    rng = np.random.default_rng(n)
+    gdim, sd = O.DIMS[cname]
+    g = rng.normal(scale=1e-3, size=gdim * gdim * n)
+    s0 = rng.normal(size=sd * n)
+    h0 = None if law == "le" else {"strain_visco": rng.normal(scale=1e-4, size=sd * n), "strain": rng.normal(scale=1e-3, size=sd * n)}
+    s_ref, t_ref = s0.copy(), np.zeros(sd * sd * n)
+    h_ref = None if h0 is None else {k: v.copy() for k, v in h0.items()}
+    O.MODELS_C[law](CPARAMS[law], cname, 0.0, 0.7, g, s_ref, t_ref, h_ref)
+    m = make(law, cname)
+    for path in ("host", "device"):
+        if path == "host":
+            s, t = s0.copy(), np.full(sd * sd * n, np.nan)
+            h = None if h0 is None else {k: v.copy() for k, v in h0.items()}
+            m.evaluate(0.0, 0.7, g, s, t, h)
+        else:
+            sdv, tdv = torch.from_numpy(s0).cuda(), torch.full((sd * sd * n,), float("nan"), dtype=torch.float64, device="cuda")
+            hd = None if h0 is None else {k: torch.from_numpy(v).cuda() for k, v in h0.items()}
+            m.evaluate(0.0, 0.7, torch.from_numpy(g).cuda(), sdv, tdv, hd)
+            s, t = sdv.cpu().numpy(), tdv.cpu().numpy()
+            h = None if hd is None else {k: v.cpu().numpy() for k, v in hd.items()}
+        assert not np.isnan(t).any()
+        assert rel_err(s, s_ref) <= 1e-10 and rel_err(t, t_ref) <= 1e-10, (law, cname, n, path)
+        if h is not None:
+            for k in h:
+                assert rel_err(h[k], h_ref[k]) <= 1e-10
+
+
+def test_plane_strain_native_equals_wrapper():
+    """tests/models/test_elasticity.py:239-333: the native PLANE_STRAIN law and PlaneStrainFrom3D
+    around the FULL law agree."""
+    rng = np.random.default_rng(5)
+    n = 777
+    g = rng.normal(scale=1e-3, size=4 * n)
+    s1, t1 = np.zeros(4 * n), np.zeros(16 * n)
+    s2, t2 = np.zeros(4 * n), np.zeros(16 * n)
+    fc.LinearElasticityModel(CPARAMS["le"], C.PLANE_STRAIN).evaluate(0, 1, g, s1, t1, None)
+    fc.PlaneStrainFrom3D(fc.LinearElasticityModel(CPARAMS["le"], C.FULL)).evaluate(0, 1, g, s2, t2, None)
+    assert rel_err(s1, s2) <= 1e-14 and np.array_equal(t1, t2)
+
+
+def test_unsupported_constraint_raises():
+    with pytest.raises(NotImplementedError):
+        law = fc.VonMises3D({"p_ka": 1.0, "p_mu": 1.0, "p_y0": 1.0, "p_y00": 2.0, "p_w": 1.0})
+        law._constraint = C.PLANE_STRAIN
+        law._handle(0)

@@ -286,9 +286,6 @@ def test_error_conventions():
         le.evaluate(0, 1.0, np.zeros(18 * n)[::2], s, t, None)
     with pytest.raises(ValueError):
         fc.VonMises3D(VM_P).evaluate(0, 1.0, g, s, t, None)
-    with pytest.raises(NotImplementedError):
-        fc.LinearElasticityModel(LE_P, fc.StressStrainConstraint.PLANE_STRAIN).evaluate(
-            0, 1.0, np.zeros(4 * n), np.zeros(4 * n), np.zeros(16 * n), None)
 
 
 def test_newton_nonconvergence_raises_runtime_error():

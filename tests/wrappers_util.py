@@ -25,3 +25,22 @@ def load_sequences():
             c["hist_out"] = {k: z[p + "hist_out." + k] for k in keys}
         seqs.setdefault(key, []).append(c)
     return [(k[0], k[1], v) for k, v in seqs.items()]
+
+
+def load_constraint_calls():
+    """tests/golden/constraints.npz -> list of call dicts (sequences are in file order)."""
+    z = np.load(os.path.join(GOLDEN, "constraints.npz"))
+    out = []
+    for i in range(int(z["n_calls"])):
+        p = f"c{i}."
+        c = {"constraint": str(z[p + "constraint"]), "law": str(z[p + "law"]), "del_t": float(z[p + "del_t"]),
+             "grad": z[p + "grad"], "stress_in": z[p + "stress_in"], "stress_out": z[p + "stress_out"],
+             "tangent_out": z[p + "tangent_out"], "hist_in": None, "hist_out": None}
+        if p + "hist_in.strain" in z:
+            c["hist_in"] = {k: z[p + "hist_in." + k] for k in ("strain_visco", "strain")}
+            c["hist_out"] = {k: z[p + "hist_out." + k] for k in ("strain_visco", "strain")}
+        out.append(c)
+    return out
+
+
+CPARAMS = {"le": LE_P, "maxwell": SLS_P, "kelvin": SLS_P}
