@@ -125,13 +125,31 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
     while t_total < budget_s and reps < 500:
         t_total += one_pass()
         reps += 1
-    return {
+    out = {
         "value": round(ns * reps / t_total / 1e6, 3),
         "unit": "Mpts/s",
         "cores": 1,
         "kind": "port",
         "sample": f"oracle/oracle.c serial loop, first {ns} points of the same workload x {reps} passes ({t_total:.1f} s)",
     }
+    # the reference's own NumPy code path, restated (oracle/numpy_oracle.py): a few seconds, for scale
+    try:
+        from oracle import numpy_oracle as NO
+
+        def time_np(fn, m):
+            s = s0[: 6 * m].copy()
+            h = None if h0 is None else {k: v[: dims[k] * m].copy() for k, v in h0.items()}
+            t0 = time.perf_counter()
+            fn(params, 0.0, del_t, g[: 9 * m], s, tan[: 36 * m], h)
+            return round(m / (time.perf_counter() - t0) / 1e6, 4)
+
+        extra = {"numpy_port_Mpts_s": time_np(NO.MODELS[kind], min(ns, 500_000)), "threads": "NumPy/OpenBLAS default"}
+        if kind == "von_mises_3d":
+            extra["python_per_point_loop_port_Mpts_s"] = time_np(NO.von_mises_3d_loop, min(ns, 30_000))
+        out["extra"] = extra
+    except Exception as e:  # the extra figures are informational only
+        out["extra"] = {"error": str(e)}
+    return out
 
 
 def main():

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -157,10 +158,13 @@ struct fcamd_context {
     bool owns_stream = false;
     int grid_override = 0;
     bool timing = false;
-    // host path: two chunk slots, each with its own stream and device buffers
-    hipStream_t hstream[2] = {nullptr, nullptr};
-    double* dchunk[2] = {nullptr, nullptr};
+    // host path: kSlots chunk slots, each with its own stream and device buffers
+    static constexpr int kSlots = 4;
+    hipStream_t hstream[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    double* dchunk[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     size_t dchunk_points = 0;
+    int slots = 4;             // slots in use (FCAMD_HOST_SLOTS, 1..kSlots)
+    int64_t chunk_points = 0;  // points per chunk (FCAMD_HOST_CHUNK), 0 = default
     std::map<void*, size_t> registered;
 };
 
@@ -416,7 +420,7 @@ int fcamd_context_destroy(fcamd_context* c) {
     if (!c) return FCAMD_OK;
     (void)hipSetDevice(c->device);
     for (auto& kv : c->registered) (void)hipHostUnregister(kv.first);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < fcamd_context::kSlots; ++i) {
         if (c->dchunk[i]) (void)hipFree(c->dchunk[i]);
         if (c->hstream[i]) (void)hipStreamDestroy(c->hstream[i]);
     }
@@ -667,27 +671,38 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     int hdim_total = 0;
     for (int k = 0; k < m->info.n_hist; ++k) hdim_total += m->info.hist[k].dim;
     const size_t per_point = 9 + 6 + 36 + (size_t)hdim_total;
-    constexpr int64_t kChunk = 1 << 18;  // points per chunk (multiple of 64)
-    const int64_t chunk = std::min<int64_t>(kChunk, ((n + 63) / 64) * 64);
+    // chunking: enough chunks in flight to keep both DMA directions busy (tunable for experiments)
+    if (c->chunk_points == 0) {
+        const char* e = getenv("FCAMD_HOST_CHUNK");
+        // measured on MI355X / PCIe gen5 (tools/host_path_bench.py): page-locked caller arrays like
+        // many small chunks in flight (4 x 128 Ki points: 116 Mpts/s); pageable arrays are staged by
+        // the runtime and prefer large chunks (512 Ki points: 93 Mpts/s)
+        const bool pinned = c->registered.count(const_cast<double*>(grad)) != 0;
+        c->chunk_points = e ? std::max<int64_t>(64, (atoll(e) / 64) * 64) : (pinned ? (1 << 17) : (1 << 19));
+        const char* sl = getenv("FCAMD_HOST_SLOTS");
+        if (sl) c->slots = std::min(fcamd_context::kSlots, std::max(1, atoi(sl)));
+    }
+    const int nslots = c->slots;
+    const int64_t chunk = std::min<int64_t>(c->chunk_points, ((n + 63) / 64) * 64);
     if (chunk > 0 && (size_t)chunk > c->dchunk_points) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < fcamd_context::kSlots; ++i) {
             if (c->dchunk[i]) HIP_TRY(hipFree(c->dchunk[i]));
             c->dchunk[i] = nullptr;
         }
         c->dchunk_points = 0;
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < nslots; ++i)
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dchunk[i]), (size_t)chunk * 66 * sizeof(double)));
         c->dchunk_points = (size_t)chunk;
     }
     (void)per_point;
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < nslots; ++i)
         if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
 
     HIP_TRY(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), c->hstream[0]));
     HIP_TRY(hipStreamSynchronize(c->hstream[0]));
 
     int slot = 0;
-    for (int64_t p0 = 0; p0 < n; p0 += chunk, slot ^= 1) {
+    for (int64_t p0 = 0; p0 < n; p0 += chunk, slot = (slot + 1) % nslots) {
         const int64_t np = std::min<int64_t>(chunk, n - p0);
         hipStream_t s = c->hstream[slot];
         // device layout of a slot (each sub-array starts 16-byte aligned: chunk is a multiple of 64)
@@ -719,8 +734,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
             HIP_TRY(hipMemcpyAsync(hist[k] + d * p0, d_hist[k], (size_t)np * d * sizeof(double), hipMemcpyDeviceToHost, s));
         }
     }
-    HIP_TRY(hipStreamSynchronize(c->hstream[0]));
-    HIP_TRY(hipStreamSynchronize(c->hstream[1]));
+    for (int i = 0; i < nslots; ++i) HIP_TRY(hipStreamSynchronize(c->hstream[i]));
     fcamd_stats local;
     st = read_stats(m, c->hstream[0], &local);
     if (st != FCAMD_OK) return st;

@@ -923,12 +923,11 @@ hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hi
 }
 
 int default_grid(int law, int num_cu) {
-    // Measured on MI355X (VonMises3D, 1e8 points): 4096 workgroups (16 per CU, i.e. ~4x the
-    // resident set the occupancy API reports) beat the exactly-resident grid by 2-3 %: short
-    // queues of workgroups rebalance the CUs at the end of the launch.  Grids that are a small
-    // non-integer multiple of the resident set (1.5x, 2x) are the worst.
+    // Measured on MI355X (VonMises3D, 1e8 points, tools/variance_probe2.py): the more workgroups
+    // the better, monotonically -- 512: 9.5-10.3 ms, 1024 (= resident set): 9.3-10.0, 4096:
+    // 9.0-9.6, 16384: 9.0-9.4 -- short queues of workgroups rebalance CUs and HBM channels.
     (void)law;
-    return 16 * num_cu;
+    return 64 * num_cu;
 }
 
 // Component maps of the 3D<->1D/2D wrappers: a pure strided copy, one thread per moved double.

@@ -1,0 +1,109 @@
+"""Device-resident increment state.
+
+The reference keeps two copies of stress and history (previous = committed, current = trial)
+and, around every ``evaluate`` of every Newton iteration, copies committed -> trial on the host
+(``solver/_lawonsubmesh.py:58-61``, ``solver/_history.py:64-79``) and, on ``update()``, trial ->
+committed (``solver/_history.py:68-88``, ``solver/_incrementalunknowns.py:70-72``).  Between the
+iterations of one increment only ``grad_del_u`` changes.
+
+``ResidentState`` holds both copies on the GPU:
+
+* ``evaluate(t, del_t, grad)``: one out-of-place launch (committed -> trial,
+  ``fcamd_evaluate_device_from``); only ``grad`` crosses PCIe when it is a NumPy array;
+* ``update()``: the commit is a pointer swap -- no copy at all;
+* ``stress`` / ``tangent`` / ``history`` expose the trial state as device tensors (for a device
+  assembler) and ``download_*`` copy them into the caller's NumPy arrays (for dolfinx).
+
+Per Newton iteration this moves 72 B/pt up and (if the host assembles) 336 B/pt down instead of
+176 + 392 B/pt, and removes every host-side state copy.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .device import DeviceLaw, _is_torch
+
+__all__ = ["ResidentState"]
+
+
+class ResidentState:
+    def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None):
+        import torch
+
+        self.law, self.n = law, int(n)
+        self.device = torch.device("cuda", 0) if device is None else torch.device(device)
+        gd2, sd = law.geometric_dim**2, law.stress_strain_dim
+        self._gd2, self._sd = gd2, sd
+        f = dict(dtype=torch.float64, device=self.device)
+        self.grad = torch.zeros(gd2 * n, **f)
+        self.tangent = torch.zeros(sd * sd * n, **f)
+        self._stress = [torch.zeros(sd * n, **f), torch.zeros(sd * n, **f)]
+        hd = law.history_dim
+        self._hist = None if hd is None else [{k: torch.zeros(d * n, **f) for k, d in hd.items()} for _ in range(2)]
+        self._c = 0  # index of the committed copy
+        if stress0 is not None:
+            self._stress[0].copy_(self._as_dev(stress0))
+        if history0 is not None and self._hist is not None:
+            for k in self._hist[0]:
+                self._hist[0][k].copy_(self._as_dev(history0[k]))
+        self._evaluated = False
+
+    def _as_dev(self, a):
+        import torch
+
+        return a if _is_torch(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    # committed (previous) and trial (current) views -------------------------------------------
+    @property
+    def stress_committed(self):
+        return self._stress[self._c]
+
+    @property
+    def stress(self):
+        return self._stress[1 - self._c]
+
+    @property
+    def history_committed(self):
+        return None if self._hist is None else self._hist[self._c]
+
+    @property
+    def history(self):
+        return None if self._hist is None else self._hist[1 - self._c]
+
+    # the Newton-iteration call --------------------------------------------------------------------
+    def evaluate(self, t: float, del_t: float, grad_del_u) -> None:
+        """Trial state <- law(committed state, grad_del_u).  May be called any number of times per
+        increment; the committed state is never modified."""
+        g = grad_del_u
+        if not _is_torch(g):
+            self.grad.copy_(self._as_dev(g), non_blocking=True)
+            g = self.grad
+        assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
+        self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, self.tangent,
+                               self.history_committed, self.history)
+        self._evaluated = True
+
+    def update(self) -> None:
+        """Commit the trial state (``IncrSmallStrainProblem.update``, solver/_solver.py:149-159):
+        a pointer swap."""
+        if not self._evaluated:
+            raise RuntimeError("update() before any evaluate() of this increment")
+        self._c = 1 - self._c
+        self._evaluated = False
+
+    # host access ------------------------------------------------------------------------------------
+    def download(self, stress: np.ndarray | None = None, tangent: np.ndarray | None = None,
+                 history: dict | None = None) -> None:
+        """Copy the trial stress / tangent / history into the caller's NumPy arrays in place."""
+        if stress is not None:
+            stress[:] = self.stress.cpu().numpy()
+        if tangent is not None:
+            tangent[:] = self.tangent.cpu().numpy()
+        if history is not None and self._hist is not None:
+            for k in history:
+                history[k][:] = self.history[k].cpu().numpy()
+
+    def check(self):
+        """Synchronise; raises the reference's RuntimeError on Newton non-convergence."""
+        return self.law.device_stats(self.device.index or 0)

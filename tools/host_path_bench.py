@@ -45,6 +45,7 @@ def run(n, register):
 
 
 if __name__ == "__main__":
-    for n in (1_000_000, 10_000_000):
+    ns = (10_000_000,) if "--big" in sys.argv else (1_000_000, 10_000_000)
+    for n in ns:
         for reg in (False, True):
             print(json.dumps(run(n, reg)), flush=True)
