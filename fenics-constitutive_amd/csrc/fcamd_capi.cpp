@@ -348,6 +348,11 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.h1_out = m->info.n_hist > 1 ? hcur[1] : nullptr;
     a.n = n;
     a.counters = m->d_counters;
+    {
+        const char* e = getenv("FCAMD_TILE_MAP");
+        const int tm = e ? atoi(e) : 0;
+        a.tile_map = tm;
+    }
     fill_constants(m, del_t, &a);
     if (reset_counters) HIP_TRY(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), stream));
     if (n == 0) return FCAMD_OK;

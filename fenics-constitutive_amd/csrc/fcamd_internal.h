@@ -41,6 +41,7 @@ struct EvalArgs {
     double* h1_out;
     long long n;               // quadrature points
     unsigned long long* counters;  // [4]: nonconverged, plastic, newton iterations, reserved
+    int tile_map;              // 0: tiles dealt round-robin to all waves; 1: one contiguous region per XCD
     Scalars sc;
     Tables tb;
 };

@@ -787,10 +787,22 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
     double* region = scratch[wave];
     const int r0 = lane % 18;
     const long long nfull = a.n / kWave;
-    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
     WaveStats st;
-    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
-        run_tile<LAW, true, NT>(a, &T, region, tile * kWave, kWave, lane, r0, st);
+    if (a.tile_map == 0) {
+        const long long wstride = (long long)gridDim.x * kWavesPerBlock;
+        for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
+            run_tile<LAW, true, NT>(a, &T, region, tile * kWave, kWave, lane, r0, st);
+    } else {
+        // XCD-aware variant (experiment): workgroups b and b+8 share an XCD (round-robin dispatch);
+        // give every XCD one contiguous eighth of the tiles.  There is no data reuse to keep in an
+        // L2, so this only changes DRAM/TLB locality.
+        const int xcd = blockIdx.x & 7;
+        const long long per = (nfull + 7) / 8;
+        const long long lo = xcd * per, hi = (lo + per < nfull) ? lo + per : nfull;
+        const long long wstride = (long long)((gridDim.x + 7 - xcd) / 8) * kWavesPerBlock;
+        for (long long tile = lo + (long long)(blockIdx.x >> 3) * kWavesPerBlock + wave; tile < hi; tile += wstride)
+            run_tile<LAW, true, NT>(a, &T, region, tile * kWave, kWave, lane, r0, st);
+    }
     flush_stats<LAW>(a, st, lane);
 }
 
