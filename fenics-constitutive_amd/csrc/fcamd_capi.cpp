@@ -336,7 +336,7 @@ int grid_for(fcamd_model* m, int64_t n) {
 // enqueue one launch on `stream`; device pointers already validated
 int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
             double* stress, double* tangent, const double* const* hprev, double* const* hcur,
-            hipStream_t stream, bool reset_counters) {
+            hipStream_t stream, bool reset_counters, const int* rows = nullptr) {
     EvalArgs a;
     a.grad = grad;
     a.stress_in = stress_prev;
@@ -346,6 +346,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.h0_out = m->info.n_hist > 0 ? hcur[0] : nullptr;
     a.h1_in = m->info.n_hist > 1 ? hprev[1] : nullptr;
     a.h1_out = m->info.n_hist > 1 ? hcur[1] : nullptr;
+    a.rows = rows;
     a.n = n;
     a.counters = m->d_counters;
     {
@@ -558,6 +559,31 @@ int fcamd_evaluate_device_from(fcamd_model* m, double t, double del_t, int64_t n
     if (st != FCAMD_OK) return st;
     if (m->timed) HIP_TRY(hipEventRecord(m->ev1, c->stream));
     return FCAMD_OK;
+}
+
+int fcamd_evaluate_device_indexed(fcamd_model* m, double t, double del_t, int64_t n,
+                                  const double* grad, const double* stress_prev_parent,
+                                  double* stress_parent, double* tangent_parent,
+                                  const int32_t* parent_rows, const double* const* hist_prev,
+                                  double* const* hist, int n_hist) {
+    (void)t;
+    int st = validate_call(m, del_t, n, grad, stress_prev_parent, stress_parent,
+                           reinterpret_cast<const void* const*>(hist_prev),
+                           reinterpret_cast<const void* const*>(hist), n_hist);
+    if (st != FCAMD_OK) return st;
+    if (m->constraint != FCAMD_FULL)
+        return fail(FCAMD_ERR_UNSUPPORTED, "the indexed form exists for StressStrainConstraint.FULL only");
+    if (n > 0 && !parent_rows) return fail(FCAMD_ERR_BAD_ARG, "parent_rows is NULL");
+    if (!aligned16(grad) || !aligned16(stress_parent) || !aligned16(stress_prev_parent) || !aligned16(tangent_parent))
+        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
+    for (int k = 0; k < m->info.n_hist; ++k)
+        if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
+            return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
+    fcamd_context* c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    m->timed = false;
+    return enqueue(m, del_t, n, grad, stress_prev_parent, stress_parent, tangent_parent, hist_prev, hist,
+                   c->stream, true, parent_rows);
 }
 
 int fcamd_evaluate_device(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,

@@ -189,6 +189,76 @@ __device__ __forceinline__ void transpose_out(const double (&x)[NC], double* reg
     wave_sync();
 }
 
+// ---------------------------------------------------------------------------------------
+// Where the stress / tangent rows of a tile live.
+//   IDX = false: the law's own arrays, point p0 + lane at row p0 + lane (contiguous tile).
+//   IDX = true : rows of PARENT arrays, point p0 + lane at row a.rows[p0 + lane] -- the submesh
+//                gather/scatter of the reference (solver/maps.py:82-123, "parent_array[parent] =
+//                sub_array[sub]") folded into the kernel's addressing: every lane loads and stores
+//                its own 48-byte stress row, and the tangent writers look the row of each chunk's
+//                point up in a per-wave LDS table.
+// ---------------------------------------------------------------------------------------
+template <bool IDX, bool FULL, bool NT>
+struct StressRows {
+    Chunks<6> c;
+    long long row = 0;
+
+    __device__ __forceinline__ void load(const EvalArgs& a, long long p0, int npts, int lane, int* rows_lds) {
+        if constexpr (IDX) {
+            const bool live = FULL || lane < npts;
+            row = live ? (long long)a.rows[p0 + lane] : 0ll;
+            rows_lds[lane] = (int)row;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d2 z;
+                z.x = 0.0;
+                z.y = 0.0;
+                c.v[k] = live ? load16<NT>(a.stress_in + row * 6 + 2 * k) : z;
+            }
+        } else {
+            tile_load<6, FULL, NT>(c, a.stress_in + p0 * 6, npts * 6, lane);
+        }
+    }
+    __device__ __forceinline__ void get(double* region, int lane, double (&s)[6]) {
+        if constexpr (IDX) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s[2 * k] = c.v[k].x;
+                s[2 * k + 1] = c.v[k].y;
+            }
+        } else {
+            transpose_in<6>(c, region, lane, s);
+        }
+    }
+    __device__ __forceinline__ void put(const EvalArgs& a, double* region, int lane, const double (&s)[6],
+                                        long long p0, int npts) {
+        if constexpr (IDX) {
+            if (FULL || lane < npts) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    d2 v;
+                    v.x = s[2 * k];
+                    v.y = s[2 * k + 1];
+                    store16<NT>(a.stress_out + row * 6 + 2 * k, v);
+                }
+            }
+        } else {
+            transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+        }
+    }
+};
+
+// destination of tangent chunk q (= 16 bytes) of the tile
+template <bool IDX>
+__device__ __forceinline__ double* tangent_chunk(double* tangent, long long p0, int q, const int* rows_lds) {
+    if constexpr (IDX) {
+        const int p = q / 18;
+        return tangent + (long long)rows_lds[p] * 36 + 2 * (q - 18 * p);
+    } else {
+        return tangent + p0 * 36 + 2 * q;
+    }
+}
+
 // Mandel strain increment from the row-major 3x3 displacement-gradient increment.
 __device__ __forceinline__ void mandel_strain(const double (&g)[9], double f, double (&e)[6]) {
     e[0] = g[0];
@@ -218,8 +288,9 @@ __device__ __forceinline__ void row_times_matrix_fma(const double (&x)[6], const
 
 // Constant tangent (LE, SLS, comfe LE): every point gets the same 36 doubles = 18 chunks,
 // read from the LDS table `tab` (np.tile(D.flatten(), n) in the reference).
-template <bool FULL, bool NT>
-__device__ __forceinline__ void tangent_const(const double* tab, double* dst, int npts, int lane,
+template <bool IDX, bool FULL, bool NT>
+__device__ __forceinline__ void tangent_const(const double* tab, double* tangent, long long p0,
+                                              const int* rows_lds, int npts, int lane,
                                               int r0 /* lane % 18 */) {
     const int nchunks = npts * 18;
 #pragma unroll
@@ -228,7 +299,7 @@ __device__ __forceinline__ void tangent_const(const double* tab, double* dst, in
         r = r >= 18 ? r - 18 : r;
         const int q = k * kWave + lane;
         d2 v = reinterpret_cast<const d2*>(tab)[r];
-        if (FULL || q < nchunks) store16<NT>(dst + 2 * q, v);
+        if (FULL || q < nchunks) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
     }
 }
 
@@ -238,9 +309,10 @@ __device__ __forceinline__ void tangent_const(const double* tab, double* dst, in
 //   VonMises3D:   third = C * (N_i * N_j)      (aah, mises_plasticity_isotropic_hardening.py:170-175)
 //   comfe Mises:  third = (C * N_j) * N_i      (column-major .data.0 of ((2 mu theta_bar) n) n^T,
 //                                               mises_plasticity.rs:118-123)
-template <bool COMFE, bool FULL, bool NT>
+template <bool COMFE, bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta, const double* tb,
-                                              double* dst, int npts, int lane) {
+                                              double* tangent, long long p0, const int* rows_lds,
+                                              int npts, int lane) {
     const int nchunks = npts * 18;
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
@@ -263,7 +335,7 @@ __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta
             v.x = (a.x + bc.x * b.x) + bc.y * (ni * nj.x);
             v.y = (a.y + bc.x * b.y) + bc.y * (ni * nj.y);
         }
-        if (FULL || q < nchunks) store16<NT>(dst + 2 * q, v);
+        if (FULL || q < nchunks) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         // bound the register pressure: let the scheduler interleave at most 3 chunks
         if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);
     }
@@ -302,38 +374,44 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 // ---------------------------------------------------------------------------------------
 
 // --- LinearElasticityModel: sigma += d_eps @ D ; tangent = tile(D) ----------------------
-template <bool FULL, bool NT>
+template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tile_linear_elasticity(const EvalArgs& a, const Tables* T,
-                                                       double* region, long long p0, int npts,
-                                                       int lane, int r0) {
+                                                       double* region, int* rows_lds, long long p0,
+                                                       int npts, int lane, int r0) {
     Chunks<9> cg;
-    Chunks<6> cs;
+    StressRows<IDX, FULL, NT> sr;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
+    sr.load(a, p0, npts, lane, rows_lds);
     // the constant tangent does not depend on the loads: stream it while they are in flight
-    if (a.tangent) tangent_const<FULL, NT>(T->c, a.tangent + p0 * 36, npts, lane, r0);
+    if (a.tangent) {
+        if constexpr (IDX) wave_sync();  // rows_lds visible to all lanes
+        tangent_const<IDX, FULL, NT>(T->c, a.tangent, p0, rows_lds, npts, lane, r0);
+    }
     double g[9], s[6], e[6], ds[6];
     transpose_in<9>(cg, region, lane, g);
-    transpose_in<6>(cs, region, lane, s);
+    sr.get(region, lane, s);
     mandel_strain(g, a.sc.s[0], e);
     row_times_matrix_fma(e, T->a, ds);
 #pragma unroll
     for (int i = 0; i < 6; ++i) s[i] = s[i] + ds[i];
-    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+    sr.put(a, region, lane, s, p0, npts);
 }
 
 // --- comfe-rs LinearElasticity3D: sigma += C . d_eps (column axpy, no FMA) ---------------
-template <bool FULL, bool NT>
+template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const Tables* T, double* region,
-                                              long long p0, int npts, int lane, int r0) {
+                                              int* rows_lds, long long p0, int npts, int lane, int r0) {
     Chunks<9> cg;
-    Chunks<6> cs;
+    StressRows<IDX, FULL, NT> sr;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
-    if (a.tangent) tangent_const<FULL, NT>(T->c, a.tangent + p0 * 36, npts, lane, r0);
+    sr.load(a, p0, npts, lane, rows_lds);
+    if (a.tangent) {
+        if constexpr (IDX) wave_sync();  // rows_lds visible to all lanes
+        tangent_const<IDX, FULL, NT>(T->c, a.tangent, p0, rows_lds, npts, lane, r0);
+    }
     double g[9], s[6], e[6];
     transpose_in<9>(cg, region, lane, g);
-    transpose_in<6>(cs, region, lane, s);
+    sr.get(region, lane, s);
     mandel_strain(g, a.sc.s[0], e);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -342,26 +420,30 @@ __device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const Tables* T
         for (int j = 1; j < 6; ++j) acc = T->a[6 * i + j] * e[j] + acc;
         s[i] = s[i] + acc;
     }
-    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+    sr.put(a, region, lane, s, p0, npts);
 }
 
 // --- SLS Maxwell / Kelvin -----------------------------------------------------------------
 // scalars: s[0]=strain factor, s[1]=1/factor, s[2]=1/(tau*2*mu1), s[3]=1/tau,
 //          Maxwell: s[4]=2*mu1 ; Kelvin: s[4]=2*mu0, s[5]=mu0/(tau*mu1), s[6]=lam0/(tau*2*mu1)
 // tables:  Maxwell a=D1, b=D0+D1, c=tangent ; Kelvin a=D0, c=tangent
-template <bool KELVIN, bool FULL, bool NT>
+template <bool KELVIN, bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tile_sls(const EvalArgs& a, const Tables* T, double* region,
-                                         long long p0, int npts, int lane, int r0) {
+                                         int* rows_lds, long long p0, int npts, int lane, int r0) {
     Chunks<9> cg;
-    Chunks<6> cs, cv, cn;
+    StressRows<IDX, FULL, NT> sr;
+    Chunks<6> cv, cn;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
+    sr.load(a, p0, npts, lane, rows_lds);
     tile_load<6, FULL, NT>(cv, a.h0_in + p0 * 6, npts * 6, lane);  // strain_visco
     tile_load<6, FULL, NT>(cn, a.h1_in + p0 * 6, npts * 6, lane);  // strain
-    if (a.tangent) tangent_const<FULL, NT>(T->c, a.tangent + p0 * 36, npts, lane, r0);
+    if (a.tangent) {
+        if constexpr (IDX) wave_sync();  // rows_lds visible to all lanes
+        tangent_const<IDX, FULL, NT>(T->c, a.tangent, p0, rows_lds, npts, lane, r0);
+    }
     double g[9], s[6], ev[6], en[6], e[6], dv[6], y[6];
     transpose_in<9>(cg, region, lane, g);
-    transpose_in<6>(cs, region, lane, s);
+    sr.get(region, lane, s);
     transpose_in<6>(cv, region, lane, ev);
     transpose_in<6>(cn, region, lane, en);
     mandel_strain(g, a.sc.s[0], e);
@@ -394,7 +476,7 @@ __device__ __forceinline__ void tile_sls(const EvalArgs& a, const Tables* T, dou
         ev[i] = ev[i] + dv[i];
         en[i] = en[i] + e[i];
     }
-    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+    sr.put(a, region, lane, s, p0, npts);
     transpose_out<6, FULL, NT>(ev, region, lane, a.h0_out + p0 * 6, npts * 6);
     transpose_out<6, FULL, NT>(en, region, lane, a.h1_out + p0 * 6, npts * 6);
 }
@@ -403,20 +485,21 @@ __device__ __forceinline__ void tile_sls(const EvalArgs& a, const Tables* T, dou
 // scalars: s[0]=strain factor, s[1]=ka, s[2]=2*mu, s[3]=sqrt(2/3), s[4]=y0, s[5]=y00-y0,
 //          s[6]=-w, s[7]=(-2)*mu, s[8]=((2/3)*(y00-y0))*w, s[9]=(4*mu)*mu
 // tables:  a = ka*xioi, b = xpp
-template <bool FULL, bool NT>
+template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* T, double* region,
-                                               long long p0, int npts, int lane, WaveStats& st) {
+                                               int* rows_lds, long long p0, int npts, int lane,
+                                               WaveStats& st) {
     Chunks<9> cg;
-    Chunks<6> cs;
+    StressRows<IDX, FULL, NT> sr;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
+    sr.load(a, p0, npts, lane, rows_lds);
     const bool live = FULL || lane < npts;
     const double alpha_n = live ? a.h1_in[p0 + lane] : 0.0;
     const bool hist_in_place = (a.h0_in == a.h0_out) && (a.h1_in == a.h1_out);
 
     double g[9], s[6], e[6];
     transpose_in<9>(cg, region, lane, g);
-    transpose_in<6>(cs, region, lane, s);
+    sr.get(region, lane, s);
     mandel_strain(g, a.sc.s[0], e);
 
     const double ka = a.sc.s[1], two_mu = a.sc.s[2], s23 = a.sc.s[3], y0 = a.sc.s[4], dy = a.sc.s[5],
@@ -488,7 +571,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
         const double vol = i < 3 ? kt : kt * 0.0;
         s[i] = s[i] + ((vol + dsig[i]) - tmg * N[i]);
     }
-    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+    sr.put(a, region, lane, s, p0, npts);
 
     // history: eps_n += gamma N ; alpha += sqrt(2/3) gamma
     if (touch_eps) {
@@ -510,7 +593,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
         const double C = four_mu2 * (xc2 - xc1);
         publish_tangent_params(region, lane, B, C, N);
         wave_sync();
-        tangent_mises<false, FULL, NT>(region, T->a, T->b, a.tangent + p0 * 36, npts, lane);
+        tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, a.tangent, p0, rows_lds, npts, lane);
         wave_sync();
     }
 }
@@ -519,21 +602,22 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
 // scalars: s[0]=strain factor (FRAC_1_SQRT_2), s[1]=mu, s[2]=kappa, s[3]=y_0, s[4]=h,
 //          s[5]=2*mu, s[6]=3*mu+h, s[7]=sqrt(3/2), s[8]=3*mu, s[9]=1/(1+h/(3 mu))
 // tables:  a = kappa*sym_id(x)sym_id, b = P_dev.   history field 0: [alpha, eps_p(6)] per point.
-template <bool FULL, bool NT>
+template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Tables* T, double* region,
-                                                 long long p0, int npts, int lane, WaveStats& st) {
+                                                 int* rows_lds, long long p0, int npts, int lane,
+                                                 WaveStats& st) {
     Chunks<9> cg;
-    Chunks<6> cs;
+    StressRows<IDX, FULL, NT> sr;
     Chunks<7> ch;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    tile_load<6, FULL, NT>(cs, a.stress_in + p0 * 6, npts * 6, lane);
+    sr.load(a, p0, npts, lane, rows_lds);
     tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
     const bool live = FULL || lane < npts;
     const bool hist_in_place = (a.h0_in == a.h0_out);
 
     double g[9], s[6], h[7], e[6];
     transpose_in<9>(cg, region, lane, g);
-    transpose_in<6>(cs, region, lane, s);
+    sr.get(region, lane, s);
     transpose_in<7>(ch, region, lane, h);
     mandel_strain(g, a.sc.s[0], e);
 
@@ -589,7 +673,7 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Tables
         const double ts = theta * s_tr[i];
         s[i] = i < 3 ? p_1 + ts : ts;
     }
-    transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+    sr.put(a, region, lane, s, p0, npts);
     if (mask != 0ull || !hist_in_place)
         transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
 
@@ -597,7 +681,7 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Tables
         const double B = plastic ? two_mu * theta : two_mu;
         publish_tangent_params(region, lane, B, sc, nv);
         wave_sync();
-        tangent_mises<true, FULL, NT>(region, T->a, T->b, a.tangent + p0 * 36, npts, lane);
+        tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, a.tangent, p0, rows_lds, npts, lane);
         wave_sync();
     }
 }
@@ -730,9 +814,10 @@ __device__ __forceinline__ void tile_lowdim(const EvalArgs& a, const Tables* T, 
 // ---------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------
-template <int LAW, bool FULL, bool NT>
+template <int LAW, bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void run_tile(const EvalArgs& a, const Tables* T, double* region,
-                                         long long p0, int npts, int lane, int r0, WaveStats& st) {
+                                         int* rows_lds, long long p0, int npts, int lane, int r0,
+                                         WaveStats& st) {
     // Everything derived from the lane id (chunk -> point/row/column maps, LDS and global
     // offsets) is tile-invariant; left alone, LICM hoists ~100 such values out of the
     // persistent loop and spills them.  Laundering the lane id per tile keeps them as
@@ -740,17 +825,17 @@ __device__ __forceinline__ void run_tile(const EvalArgs& a, const Tables* T, dou
     asm volatile("" : "+v"(lane));
     asm volatile("" : "+v"(r0));
     if constexpr (LAW == LAW_LE)
-        tile_linear_elasticity<FULL, NT>(a, T, region, p0, npts, lane, r0);
+        tile_linear_elasticity<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_COMFE_LE)
-        tile_comfe_le<FULL, NT>(a, T, region, p0, npts, lane, r0);
+        tile_comfe_le<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_MAXWELL)
-        tile_sls<false, FULL, NT>(a, T, region, p0, npts, lane, r0);
+        tile_sls<false, IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_KELVIN)
-        tile_sls<true, FULL, NT>(a, T, region, p0, npts, lane, r0);
+        tile_sls<true, IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_VM3D)
-        tile_von_mises<FULL, NT>(a, T, region, p0, npts, lane, st);
+        tile_von_mises<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, st);
     else
-        tile_comfe_mises<FULL, NT>(a, T, region, p0, npts, lane, st);
+        tile_comfe_mises<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, st);
 }
 
 __device__ __forceinline__ void stage_tables(const EvalArgs& a, Tables* T) {
@@ -776,22 +861,24 @@ __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& 
 
 // Main kernel: all full 64-point tiles.  Persistent: wave w of the grid takes tiles
 // w, w + W, w + 2W, ...
-template <int LAW, bool NT>
+template <int LAW, bool NT, bool IDX>
 __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
+    __shared__ int rows_all[IDX ? kWavesPerBlock : 1][kWave];
     stage_tables(a, &T);
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     double* region = scratch[wave];
+    int* rows_lds = rows_all[IDX ? wave : 0];
     const int r0 = lane % 18;
     const long long nfull = a.n / kWave;
     WaveStats st;
     if (a.tile_map == 0) {
         const long long wstride = (long long)gridDim.x * kWavesPerBlock;
         for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
-            run_tile<LAW, true, NT>(a, &T, region, tile * kWave, kWave, lane, r0, st);
+            run_tile<LAW, IDX, true, NT>(a, &T, region, rows_lds, tile * kWave, kWave, lane, r0, st);
     } else {
         // XCD-aware variant (experiment): workgroups b and b+8 share an XCD (round-robin dispatch);
         // give every XCD one contiguous eighth of the tiles.  There is no data reuse to keep in an
@@ -801,7 +888,7 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
         const long long lo = xcd * per, hi = (lo + per < nfull) ? lo + per : nfull;
         const long long wstride = (long long)((gridDim.x + 7 - xcd) / 8) * kWavesPerBlock;
         for (long long tile = lo + (long long)(blockIdx.x >> 3) * kWavesPerBlock + wave; tile < hi; tile += wstride)
-            run_tile<LAW, true, NT>(a, &T, region, tile * kWave, kWave, lane, r0, st);
+            run_tile<LAW, IDX, true, NT>(a, &T, region, rows_lds, tile * kWave, kWave, lane, r0, st);
     }
     flush_stats<LAW>(a, st, lane);
 }
@@ -832,15 +919,16 @@ __global__ void __launch_bounds__(kWave) evaluate_lowdim_tail_kernel(const EvalA
 }
 
 // Tail kernel: the last, ragged tile (n % 64 points), one wavefront, guarded 8-byte accesses.
-template <int LAW>
+template <int LAW, bool IDX>
 __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
+    __shared__ int rows_lds[kWave];
     stage_tables(a, &T);
     const int lane = threadIdx.x;
     const long long p0 = (a.n / kWave) * kWave;
     WaveStats st;
-    run_tile<LAW, false, false>(a, &T, region, p0, (int)(a.n - p0), lane, lane % 18, st);
+    run_tile<LAW, IDX, false, false>(a, &T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
     flush_stats<LAW>(a, st, lane);
 }
 
@@ -891,14 +979,21 @@ static bool use_nontemporal() {
 
 template <int LAW>
 static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream) {
+    if (args.rows) {  // stress / tangent rows addressed through a parent-row index
+        if (args.n >= kWave)
+            hipLaunchKernelGGL((evaluate_kernel<LAW, true, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+        if (args.n % kWave != 0)
+            hipLaunchKernelGGL((evaluate_tail_kernel<LAW, true>), dim3(1), dim3(kWave), 0, stream, args);
+        return hipGetLastError();
+    }
     if (args.n >= kWave) {
         if (use_nontemporal())
-            hipLaunchKernelGGL((evaluate_kernel<LAW, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+            hipLaunchKernelGGL((evaluate_kernel<LAW, true, false>), dim3(grid), dim3(kBlock), 0, stream, args);
         else
-            hipLaunchKernelGGL((evaluate_kernel<LAW, false>), dim3(grid), dim3(kBlock), 0, stream, args);
+            hipLaunchKernelGGL((evaluate_kernel<LAW, false, false>), dim3(grid), dim3(kBlock), 0, stream, args);
     }
     if (args.n % kWave != 0)
-        hipLaunchKernelGGL((evaluate_tail_kernel<LAW>), dim3(1), dim3(kWave), 0, stream, args);
+        hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false>), dim3(1), dim3(kWave), 0, stream, args);
     return hipGetLastError();
 }
 

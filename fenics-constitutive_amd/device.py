@@ -155,6 +155,34 @@ class DeviceLaw(IncrSmallStrainModel):
         assert n == _size(stress) // sd == _size(stress_prev) // sd and (tangent is None or n == _size(tangent) // (sd * sd))
         self._evaluate_device(t, del_t, n, grad_del_u, stress, tangent, hist, stress_prev, hprev)
 
+    def evaluate_indexed(self, t, del_t, grad_del_u, stress_prev_parent, stress_parent, tangent_parent,
+                         parent_rows, history_prev, history) -> None:
+        """Multi-material form: this law owns ``n = len(parent_rows)`` points whose stress/tangent
+        rows live in PARENT arrays at ``parent_rows`` (int32 device tensor).  Reads the committed
+        stress from ``stress_prev_parent`` rows, writes stress and tangent into the parent rows;
+        ``grad_del_u`` and the history are local to the law.  Replaces map_to_sub + evaluate +
+        map_to_parent of ``LawOnSubMesh`` (solver/_lawonsubmesh.py:58-95) by one launch."""
+        import torch
+
+        hist = self._history_arrays(history)
+        hprev = hist if history_prev is None else self._history_arrays(history_prev)
+        n = parent_rows.numel()
+        assert _size(grad_del_u) == 9 * n, "grad_del_u has the wrong length"
+        assert parent_rows.dtype == torch.int32 and parent_rows.is_cuda and parent_rows.is_contiguous()
+        for x in (grad_del_u, stress_prev_parent, stress_parent):
+            _check_torch("array", x)
+        assert _size(stress_prev_parent) == _size(stress_parent)
+        assert tangent_parent is None or _size(tangent_parent) == 6 * _size(stress_parent)
+        for (name, dim), h in zip(self._history_fields(), hist):
+            assert _size(h) == n * dim, f"history '{name}' has the wrong length"
+        dev = grad_del_u.device.index or 0
+        m = self._handle(dev)
+        m.ctx.set_stream(_current_stream_ptr(dev))
+        m.evaluate_device_indexed(
+            t, del_t, n, grad_del_u.data_ptr(), stress_prev_parent.data_ptr(), stress_parent.data_ptr(),
+            None if tangent_parent is None else _check_torch("tangent", tangent_parent).data_ptr(),
+            parent_rows.data_ptr(), [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist])
+
     def device_stats(self, device: int = 0):
         """Synchronise and return the counters of the last device-path launch; raises
         RuntimeError like the reference if a Newton iteration did not converge."""

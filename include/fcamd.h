@@ -136,6 +136,20 @@ int fcamd_evaluate_device_from(fcamd_model* model, double t, double del_t, int64
                                const double* const* history_prev, double* const* history,
                                int n_hist);
 
+/* Submesh-indexed form (multi-material problems, FULL laws): the gather of the committed
+   stress and the scatter of stress and tangent that the reference performs around evaluate
+   (solver/_lawonsubmesh.py:58-70 with SubSpaceMap, solver/maps.py:82-123) are folded into the
+   kernel's addressing.  `grad_del_u` and the history arrays are local to the n points of this
+   law (as in the reference); `stress_prev_parent`, `stress_parent` and `tangent_parent` are
+   the PARENT arrays and point i of this law uses their row `parent_rows[i]` (int32 device
+   array, every row at most once).  Rows of other laws are not touched. */
+int fcamd_evaluate_device_indexed(fcamd_model* model, double t, double del_t, int64_t n,
+                                  const double* grad_del_u, const double* stress_prev_parent,
+                                  double* stress_parent, double* tangent_parent,
+                                  const int32_t* parent_rows,
+                                  const double* const* history_prev, double* const* history,
+                                  int n_hist);
+
 /* Host evaluate: the ndarray entry.  Pointers are host arrays laid out as above; the
    library stages them chunk by chunk (two chunk slots on two streams: H2D / kernel / D2H of
    one chunk overlap the other's when the arrays are page-locked, see
