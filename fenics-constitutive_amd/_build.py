@@ -22,12 +22,26 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
+HASHFILE = os.path.join(LIBDIR, "libfcamd.srchash")
+
+
+def _source_hash() -> str:
+    """Content hash of everything the library is built from (sources, headers, flags).  mtimes are
+    not used: a snapshot copy to the GPU box does not preserve their order."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join([ARCH, *FLAGS]).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(HASHFILE)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(HASHFILE) as fh:
+        return fh.read().strip() != _source_hash()
 
 
 def build_library(force: bool = False, verbose: bool = False, keep_temps: bool = False) -> str:
@@ -38,7 +52,7 @@ def build_library(force: bool = False, verbose: bool = False, keep_temps: bool =
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build libfcamd.so")
     os.makedirs(LIBDIR, exist_ok=True)
-    tmp = LIB + ".tmp"
+    tmp = f"{LIB}.{os.getpid()}.tmp"  # several ranks may build at once; the rename below is atomic
     cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS]
     if keep_temps:
         bdir = os.path.join(CSRC, "build")
@@ -52,10 +66,14 @@ def build_library(force: bool = False, verbose: bool = False, keep_temps: bool =
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
     if keep_temps:
-        shutil.copyfile(tmp, LIB)
+        shutil.copyfile(tmp, LIB + ".cp")
+        os.replace(LIB + ".cp", LIB)
         sys.stderr.write(r.stderr)
     else:
         os.replace(tmp, LIB)
+    with open(HASHFILE + f".{os.getpid()}", "w") as fh:
+        fh.write(_source_hash())
+    os.replace(HASHFILE + f".{os.getpid()}", HASHFILE)
     return LIB
 
 

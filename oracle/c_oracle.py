@@ -15,10 +15,25 @@ LIB = os.path.join(HERE, "_build", "liboracle.so")
 _lib = None
 
 
+def _src_hash() -> str:
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("oracle.c", "Makefile"):
+        with open(os.path.join(HERE, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False) -> str:
-    src = os.path.join(HERE, "oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", HERE, "-B" if force else "-s"], check=True, capture_output=True)
+    """(Re)build liboracle.so when its sources changed (content hash, not mtimes: snapshot copies
+    do not keep mtime order)."""
+    stamp = LIB + ".srchash"
+    fresh = os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == _src_hash()
+    if force or not fresh:
+        subprocess.run(["make", "-C", HERE, "-B", "-s"], check=True, capture_output=True)
+        with open(stamp, "w") as fh:
+            fh.write(_src_hash())
     return LIB
 
 
