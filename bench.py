@@ -146,6 +146,17 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
         extra = {"numpy_port_Mpts_s": time_np(NO.MODELS[kind], min(ns, 500_000)), "threads": "NumPy/OpenBLAS default"}
         if kind == "von_mises_3d":
             extra["python_per_point_loop_port_Mpts_s"] = time_np(NO.von_mises_3d_loop, min(ns, 30_000))
+        # the same C loop on all host cores (OpenMP over points), for scale only
+        nthr = min(CO.max_threads(), os.cpu_count() or 1)
+        CO.set_num_threads(nthr)
+        one_pass()
+        tt, rr = 0.0, 0
+        while tt < 2.0 and rr < 200:
+            tt += one_pass()
+            rr += 1
+        CO.set_num_threads(1)
+        extra["c_port_all_cores_Mpts_s"] = round(ns * rr / tt / 1e6, 1)
+        extra["c_port_all_cores_threads"] = nthr
         out["extra"] = extra
     except Exception as e:  # the extra figures are informational only
         out["extra"] = {"error": str(e)}

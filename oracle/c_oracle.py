@@ -47,6 +47,15 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def set_num_threads(n: int) -> None:
+    """Threads of the point loops (default 1 = the reference's serial loop)."""
+    lib().oracle_set_num_threads(C.c_int(int(n)))
+
+
+def max_threads() -> int:
+    return int(lib().oracle_max_threads())
+
+
 def _p(a):
     if a is None:
         return C.c_void_p(0)

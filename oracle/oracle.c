@@ -24,6 +24,23 @@
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads used by the point loops.  Default 1 = the reference's serial loop (one MPI rank);
+   bench.py also reports an all-cores figure.  Results do not depend on the thread count. */
+static int g_threads = 1;
+void oracle_set_num_threads(int n) { g_threads = n > 0 ? n : 1; }
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+#define POINT_LOOP _Pragma("omp parallel for schedule(static) num_threads(g_threads)")
+#define POINT_LOOP_COUNT(...) _Pragma("omp parallel for schedule(static) num_threads(g_threads) reduction(+ : bad, npl, nit)")
 
 #define F_PY 0x1.6a09e667f3bccp-1 /* 1 / 2**0.5      (models/utils.py:202-204) */
 #define F_RS 0x1.6a09e667f3bcdp-1 /* FRAC_1_SQRT_2   (comfe-rs/src/mandel.rs:147) */
@@ -68,9 +85,11 @@ void oracle_strain_from_grad_u(long long n, const double* grad, double* strain, 
 /* models/linear_elasticity_model.py:26-45 */
 void oracle_linear_elasticity(double E, double nu, long long n, const double* grad, double* stress,
                               double* tangent) {
-    double D[36], e[6], y[6];
+    double D[36];
     tangent_full(E, nu, D);
+    POINT_LOOP
     for (long long p = 0; p < n; ++p) {
+        double e[6], y[6];
         strain6(grad + 9 * p, F_PY, e);
         row_mat(e, D, y);
         for (int i = 0; i < 6; ++i) stress[6 * p + i] += y[i];
@@ -86,6 +105,7 @@ long long oracle_von_mises_3d(double ka, double mu, double y0, double y00, doubl
     const double s23 = sqrt(2.0 / 3.0), two_mu = 2 * mu, dy = y00 - y0, mw = -w;
     const double m2mu = -2 * mu, c23 = (2.0 / 3.0) * dy * w, four_mu2 = 4 * mu * mu;
     long long bad = 0, npl = 0, nit = 0;
+    POINT_LOOP_COUNT()
     for (long long p = 0; p < n; ++p) {
         double e[6], dsig[6], sigtr[6], N[6] = {0, 0, 0, 0, 0, 0};
         double* s = stress + 6 * p;
@@ -160,6 +180,7 @@ void oracle_spring_maxwell(double E0, double E1, double tau, double nu, double d
         D01[i] = D0[i] + D1[i];
         Dt[i] = D0[i] + w1 * D1[i];
     }
+    POINT_LOOP
     for (long long p = 0; p < n; ++p) {
         double e[6], x[6], y[6], dv[6];
         strain6(grad + 9 * p, F_PY, e);
@@ -188,6 +209,7 @@ void oracle_spring_kelvin(double E0, double E1, double tau, double nu, double de
     const double cA = 1 / (tau * 2 * mu1), cB = 1 / tau, cC = mu0 / (tau * mu1);
     const double cD = lam0 / (tau * 2 * mu1), c2mu = 2 * mu0, w0 = 1 - mu0 / (tau * mu1 * factor);
     for (int i = 0; i < 36; ++i) Dt[i] = w0 * D0[i];
+    POINT_LOOP
     for (long long p = 0; p < n; ++p) {
         double e[6], y[6], dv[6];
         double* s = stress + 6 * p;
@@ -219,12 +241,14 @@ static void comfe_proj(double* soo, double* pvol, double* pdev) {
 /* comfe-rs/src/linear_elasticity.rs:49-74 driven by interfaces.rs:441-455 */
 void oracle_comfe_linear_elasticity(double mu, double kappa, long long n, const double* grad,
                                     double* stress, double* tangent) {
-    double soo[36], pvol[36], pdev[36], Cm[36], Ct[36], e[6];
+    double soo[36], pvol[36], pdev[36], Cm[36], Ct[36];
     comfe_proj(soo, pvol, pdev);
     for (int i = 0; i < 36; ++i) Cm[i] = (2.0 * mu) * pdev[i] + (3.0 * kappa) * pvol[i];
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 6; ++j) Ct[6 * j + i] = Cm[6 * i + j];
+    POINT_LOOP
     for (long long p = 0; p < n; ++p) {
+        double e[6];
         strain6(grad + 9 * p, F_RS, e);
         for (int i = 0; i < 6; ++i) {
             double acc = Cm[6 * i] * e[0];
@@ -244,6 +268,7 @@ long long oracle_comfe_mises(double mu, double kappa, double y_0, double h, long
     const double two_mu = 2. * mu, den = 3. * mu + h, s32 = sqrt(3. / 2.), three_mu = 3. * mu;
     const double hfac = 1.0 / (1.0 + (h / (3.0 * mu)));
     long long npl = 0;
+    _Pragma("omp parallel for schedule(static) num_threads(g_threads) reduction(+ : npl)")
     for (long long p = 0; p < n; ++p) {
         double e[6], s_tr[6], nv[6] = {0, 0, 0, 0, 0, 0};
         double* s = stress + 6 * p;

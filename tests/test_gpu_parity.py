@@ -303,3 +303,23 @@ def test_newton_nonconvergence_raises_runtime_error():
     law.evaluate(0, 1.0, gd, sd, td, hd)
     with pytest.raises(RuntimeError, match="did not converge"):
         law.device_stats()
+
+
+def test_auto_pin_host_arrays():
+    """auto_pin page-locks the caller's arrays once; results are unchanged and repeat calls work."""
+    n = 400_000
+    p, g, s, h = random_case("von_mises_3d", n, seed=21)
+    ref = oracle_run("von_mises_3d", p, 1.0, g, s, h, mod=CO)
+    law = make_law("von_mises_3d", p)
+    law.auto_pin = True
+    t = np.full(36 * n, np.nan)
+    for _ in range(3):
+        sc, hc = s.copy(), {k: v.copy() for k, v in h.items()}
+        law.evaluate(0.0, 1.0, g, sc, t, hc)
+        compare((sc, t, hc), ref, TOL["pl"], "auto_pin")
+    assert any(v is not None for v in law._pinned.values())
+    law.unpin_arrays()
+    sc, hc = s.copy(), {k: v.copy() for k, v in h.items()}
+    law.evaluate(0.0, 1.0, g, sc, t, hc)
+    compare((sc, t, hc), ref, TOL["pl"], "after unpin")
+    law.unpin_arrays()
