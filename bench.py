@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--n", type=int, default=100_000_000, help="quadrature points per GPU")
     ap.add_argument("--grid", type=int, default=0, help="override the launch grid (workgroups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sparse-history", action="store_true",
+                    help="VonMises3D: sparse trial-history protocol of device-resident Newton loops "
+                         "(fcamd_evaluate_device_from_sparse); same results, elastic points cost no history traffic")
     ap.add_argument("--gather-points", type=int, default=20_000_000,
                     help="points per rank of the separately timed stress/tangent all-gather (N>1)")
     args = ap.parse_args()
@@ -215,8 +218,15 @@ def main():
     if args.grid:
         law._handle(local_rank).ctx.set_grid(args.grid)
 
+    hmask = None
+    if args.sparse_history:
+        assert kind == "von_mises_3d", "--sparse-history is a VonMises3D protocol"
+        for k in hist_c:
+            hist_t[k].copy_(hist_c[k])  # contract: trial == committed where the mask is clear
+        hmask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
+
     def step():
-        law.evaluate_from(0.0, del_t, grad, stress_c, stress_t, tangent, hist_c, hist_t)
+        law.evaluate_from(0.0, del_t, grad, stress_c, stress_t, tangent, hist_c, hist_t, history_mask=hmask)
 
     for _ in range(args.warmup):
         step()
@@ -285,7 +295,7 @@ def main():
             try:
                 with open(tf) as f:
                     tj = json.load(f)
-                e = tj.get(args.workload)
+                e = tj.get(args.workload + ("_sparse" if args.sparse_history else ""))
                 if e and int(e.get("n", 0)) == n:
                     traffic = e.get("hbm_bytes_per_launch")
             except Exception:
@@ -304,7 +314,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {kind} FULL-3D, {n} quadrature points per GPU, device-resident AoS, "
-                                   f"committed->trial evaluate", "points_per_gpu": n, "plastic_fraction": round(n_pl / n, 4),
+                                   f"committed->trial evaluate{' (sparse trial history)' if args.sparse_history else ''}", "points_per_gpu": n, "plastic_fraction": round(n_pl / n, 4),
                        "mean_newton_iters": round(st.n_newton_iters / max(n_pl, 1), 3) if kind == "von_mises_3d" else None,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

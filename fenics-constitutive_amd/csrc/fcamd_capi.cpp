@@ -336,7 +336,8 @@ int grid_for(fcamd_model* m, int64_t n) {
 // enqueue one launch on `stream`; device pointers already validated
 int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
             double* stress, double* tangent, const double* const* hprev, double* const* hcur,
-            hipStream_t stream, bool reset_counters, const int* rows = nullptr) {
+            hipStream_t stream, bool reset_counters, const int* rows = nullptr,
+            unsigned long long* hmask = nullptr) {
     EvalArgs a;
     a.grad = grad;
     a.stress_in = stress_prev;
@@ -347,6 +348,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.h1_in = m->info.n_hist > 1 ? hprev[1] : nullptr;
     a.h1_out = m->info.n_hist > 1 ? hcur[1] : nullptr;
     a.rows = rows;
+    a.hmask = hmask;
     a.n = n;
     a.counters = m->d_counters;
     {
@@ -584,6 +586,30 @@ int fcamd_evaluate_device_indexed(fcamd_model* m, double t, double del_t, int64_
     m->timed = false;
     return enqueue(m, del_t, n, grad, stress_prev_parent, stress_parent, tangent_parent, hist_prev, hist,
                    c->stream, true, parent_rows);
+}
+
+int fcamd_evaluate_device_from_sparse(fcamd_model* m, double t, double del_t, int64_t n,
+                                      const double* grad, const double* stress_prev, double* stress,
+                                      double* tangent, const double* const* hist_prev,
+                                      double* const* hist, int n_hist, uint64_t* history_mask) {
+    (void)t;
+    int st = validate_call(m, del_t, n, grad, stress_prev, stress,
+                           reinterpret_cast<const void* const*>(hist_prev),
+                           reinterpret_cast<const void* const*>(hist), n_hist);
+    if (st != FCAMD_OK) return st;
+    if (m->law != FCAMD_VON_MISES_3D)
+        return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for VonMises3D only");
+    if (n > 0 && !history_mask) return fail(FCAMD_ERR_BAD_ARG, "history_mask is NULL");
+    if (!aligned16(grad) || !aligned16(stress) || !aligned16(stress_prev) || !aligned16(tangent))
+        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
+    for (int k = 0; k < m->info.n_hist; ++k)
+        if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
+            return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
+    fcamd_context* c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    m->timed = false;
+    return enqueue(m, del_t, n, grad, stress_prev, stress, tangent, hist_prev, hist, c->stream, true, nullptr,
+                   reinterpret_cast<unsigned long long*>(history_mask));
 }
 
 int fcamd_evaluate_device(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,

@@ -39,6 +39,7 @@ struct EvalArgs {
     double* h0_out;
     const double* h1_in;       // second history field or nullptr
     double* h1_out;
+    unsigned long long* hmask; // nullptr, or sparse-trial-history mask, one word per 64-point tile (VonMises3D)
     const int* rows;           // nullptr, or parent row of every point: stress/tangent are parent arrays
     long long n;               // quadrature points
     unsigned long long* counters;  // [4]: nonconverged, plastic, newton iterations, reserved

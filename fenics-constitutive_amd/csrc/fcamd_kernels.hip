@@ -485,7 +485,7 @@ __device__ __forceinline__ void tile_sls(const EvalArgs& a, const Tables* T, dou
 // scalars: s[0]=strain factor, s[1]=ka, s[2]=2*mu, s[3]=sqrt(2/3), s[4]=y0, s[5]=y00-y0,
 //          s[6]=-w, s[7]=(-2)*mu, s[8]=((2/3)*(y00-y0))*w, s[9]=(4*mu)*mu
 // tables:  a = ka*xioi, b = xpp
-template <bool IDX, bool FULL, bool NT>
+template <bool IDX, bool SPARSE, bool FULL, bool NT>
 __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* T, double* region,
                                                int* rows_lds, long long p0, int npts, int lane,
                                                WaveStats& st) {
@@ -527,9 +527,26 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
 
     // plastic-strain history: needed only by tiles with a plastic point (in place), or always
     // when the trial history lives in a different array (out of place).
+    //
+    // Sparse trial history (a.hmask != nullptr; device-resident Newton loops): the trial arrays
+    // are kept equal to the committed ones except at the points recorded in hmask (one 64-bit
+    // word per tile = the plastic ballot of the previous evaluate).  Then only plastic lanes
+    // (new trial value) and stale lanes (plastic last time, elastic now: restore the committed
+    // value) touch their own 48-byte eps_n row; elastic points cost no history traffic at all,
+    // which is exactly the algorithmic byte count (464 B/pt elastic, 568 B/pt plastic).
     Chunks<6> ce;
-    const bool touch_eps = (mask != 0ull) || !hist_in_place;
+    constexpr bool sparse = SPARSE;
+    unsigned long long m_old = 0ull;
+    if constexpr (sparse) m_old = a.hmask[p0 >> 6];
+    const bool need_row = sparse && (plastic || (((m_old >> lane) & 1ull) != 0ull));
+    const bool touch_eps = !sparse && ((mask != 0ull) || !hist_in_place);
     if (touch_eps) tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
+    if constexpr (sparse) {
+        if (need_row) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ce.v[k] = load16<NT>(a.h0_in + (p0 + lane) * 6 + 2 * k);
+        }
+    }
 
     double gamma = 0.0, xc1 = 0.0, xc2 = 0.0;
     double N[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -585,6 +602,20 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
             tile_store<6, FULL, NT>(ce, a.h0_out + p0 * 6, npts * 6, lane);
         }
         if (live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
+    }
+    if constexpr (sparse) {
+        if (need_row) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d2 v;
+                v.x = ce.v[k].x + gamma * N[2 * k];
+                v.y = ce.v[k].y + gamma * N[2 * k + 1];
+                store16<NT>(a.h0_out + (p0 + lane) * 6 + 2 * k, v);
+            }
+        }
+        // alpha: one coalesced 512-byte store per tile that has (or had) a plastic point
+        if (((mask | m_old) != 0ull) && live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
+        if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
     }
 
     // tangent: ka xioi + 2 mu (1 - 2 mu xc2) xpp + 4 mu^2 (xc2 - xc1) N (x) N
@@ -814,7 +845,7 @@ __device__ __forceinline__ void tile_lowdim(const EvalArgs& a, const Tables* T, 
 // ---------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------
-template <int LAW, bool IDX, bool FULL, bool NT>
+template <int LAW, bool IDX, bool FULL, bool NT, bool SPARSE = false>
 __device__ __forceinline__ void run_tile(const EvalArgs& a, const Tables* T, double* region,
                                          int* rows_lds, long long p0, int npts, int lane, int r0,
                                          WaveStats& st) {
@@ -833,7 +864,7 @@ __device__ __forceinline__ void run_tile(const EvalArgs& a, const Tables* T, dou
     else if constexpr (LAW == LAW_KELVIN)
         tile_sls<true, IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_VM3D)
-        tile_von_mises<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, st);
+        tile_von_mises<IDX, SPARSE, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, st);
     else
         tile_comfe_mises<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, st);
 }
@@ -861,7 +892,7 @@ __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& 
 
 // Main kernel: all full 64-point tiles.  Persistent: wave w of the grid takes tiles
 // w, w + W, w + 2W, ...
-template <int LAW, bool NT, bool IDX>
+template <int LAW, bool NT, bool IDX, bool SPARSE = false>
 __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
@@ -878,7 +909,7 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
     if (a.tile_map == 0) {
         const long long wstride = (long long)gridDim.x * kWavesPerBlock;
         for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
-            run_tile<LAW, IDX, true, NT>(a, &T, region, rows_lds, tile * kWave, kWave, lane, r0, st);
+            run_tile<LAW, IDX, true, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, kWave, lane, r0, st);
     } else {
         // XCD-aware variant (experiment): workgroups b and b+8 share an XCD (round-robin dispatch);
         // give every XCD one contiguous eighth of the tiles.  There is no data reuse to keep in an
@@ -888,7 +919,7 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
         const long long lo = xcd * per, hi = (lo + per < nfull) ? lo + per : nfull;
         const long long wstride = (long long)((gridDim.x + 7 - xcd) / 8) * kWavesPerBlock;
         for (long long tile = lo + (long long)(blockIdx.x >> 3) * kWavesPerBlock + wave; tile < hi; tile += wstride)
-            run_tile<LAW, IDX, true, NT>(a, &T, region, rows_lds, tile * kWave, kWave, lane, r0, st);
+            run_tile<LAW, IDX, true, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, kWave, lane, r0, st);
     }
     flush_stats<LAW>(a, st, lane);
 }
@@ -919,7 +950,7 @@ __global__ void __launch_bounds__(kWave) evaluate_lowdim_tail_kernel(const EvalA
 }
 
 // Tail kernel: the last, ragged tile (n % 64 points), one wavefront, guarded 8-byte accesses.
-template <int LAW, bool IDX>
+template <int LAW, bool IDX, bool SPARSE = false>
 __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
@@ -928,7 +959,7 @@ __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) 
     const int lane = threadIdx.x;
     const long long p0 = (a.n / kWave) * kWave;
     WaveStats st;
-    run_tile<LAW, IDX, false, false>(a, &T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
+    run_tile<LAW, IDX, false, false, SPARSE>(a, &T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
     flush_stats<LAW>(a, st, lane);
 }
 
@@ -979,6 +1010,15 @@ static bool use_nontemporal() {
 
 template <int LAW>
 static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream) {
+    if constexpr (LAW == LAW_VM3D) {
+        if (args.hmask) {  // sparse trial history
+            if (args.n >= kWave)
+                hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+            if (args.n % kWave != 0)
+                hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false, true>), dim3(1), dim3(kWave), 0, stream, args);
+            return hipGetLastError();
+        }
+    }
     if (args.rows) {  // stress / tangent rows addressed through a parent-row index
         if (args.n >= kWave)
             hipLaunchKernelGGL((evaluate_kernel<LAW, true, true>), dim3(grid), dim3(kBlock), 0, stream, args);

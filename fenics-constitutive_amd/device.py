@@ -168,7 +168,8 @@ class DeviceLaw(IncrSmallStrainModel):
             None if hist_prev is None else [_check_torch("history_prev", h).data_ptr() for h in hist_prev],
         )
 
-    def evaluate_from(self, t, del_t, grad_del_u, stress_prev, stress, tangent, history_prev, history) -> None:
+    def evaluate_from(self, t, del_t, grad_del_u, stress_prev, stress, tangent, history_prev, history,
+                      history_mask=None) -> None:
         """Out-of-place device evaluate: read the committed state (``stress_prev``,
         ``history_prev``), write the trial state (``stress``, ``history``).  Fuses the two
         copies the reference makes before every call (solver/_lawonsubmesh.py:58-61,
@@ -178,7 +179,22 @@ class DeviceLaw(IncrSmallStrainModel):
         gd2, sd = self.geometric_dim**2, self.stress_strain_dim
         n = _size(grad_del_u) // gd2
         assert n == _size(stress) // sd == _size(stress_prev) // sd and (tangent is None or n == _size(tangent) // (sd * sd))
-        self._evaluate_device(t, del_t, n, grad_del_u, stress, tangent, hist, stress_prev, hprev)
+        if history_mask is None:
+            self._evaluate_device(t, del_t, n, grad_del_u, stress, tangent, hist, stress_prev, hprev)
+            return
+        # sparse trial history (fcamd_evaluate_device_from_sparse): see ResidentState
+        import torch
+
+        assert history_mask.dtype == torch.int64 and history_mask.is_cuda and history_mask.numel() >= (n + 63) // 64
+        for x in (grad_del_u, stress, stress_prev):
+            _check_torch("array", x)
+        dev = grad_del_u.device.index or 0
+        m = self._handle(dev)
+        m.ctx.set_stream(_current_stream_ptr(dev))
+        m.evaluate_device_from_sparse(
+            t, del_t, n, grad_del_u.data_ptr(), stress_prev.data_ptr(), stress.data_ptr(),
+            None if tangent is None else tangent.data_ptr(), [h.data_ptr() for h in hprev],
+            [h.data_ptr() for h in hist], history_mask.data_ptr())
 
     def evaluate_indexed(self, t, del_t, grad_del_u, stress_prev_parent, stress_parent, tangent_parent,
                          parent_rows, history_prev, history) -> None:

@@ -28,7 +28,7 @@ __all__ = ["ResidentState"]
 
 
 class ResidentState:
-    def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None):
+    def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True):
         import torch
 
         self.law, self.n = law, int(n)
@@ -47,6 +47,13 @@ class ResidentState:
         if history0 is not None and self._hist is not None:
             for k in self._hist[0]:
                 self._hist[0][k].copy_(self._as_dev(history0[k]))
+                self._hist[1][k].copy_(self._hist[0][k])  # trial == committed (sparse-history contract)
+        # VonMises3D: sparse trial history (fcamd_evaluate_device_from_sparse).  Elastic points keep
+        # their history, so only plastic / formerly plastic points are written; the mask (one word
+        # per 64-point tile) survives the pointer swap of update().
+        self._mask = None
+        if sparse_history and type(law).__name__ == "VonMises3D":
+            self._mask = torch.zeros((self.n + 63) // 64, dtype=torch.int64, device=self.device)
         self._evaluated = False
 
     def _as_dev(self, a):
@@ -81,7 +88,7 @@ class ResidentState:
             g = self.grad
         assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
         self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, self.tangent,
-                               self.history_committed, self.history)
+                               self.history_committed, self.history, history_mask=self._mask)
         self._evaluated = True
 
     def update(self) -> None:

@@ -136,6 +136,22 @@ int fcamd_evaluate_device_from(fcamd_model* model, double t, double del_t, int64
                                const double* const* history_prev, double* const* history,
                                int n_hist);
 
+/* Sparse-trial-history form of fcamd_evaluate_device_from for device-resident Newton loops
+   (VonMises3D).  Contract: on entry the trial history arrays equal the committed ones except at
+   the points whose bit is set in `history_mask` (one uint64 per 64-point tile, bit l = point
+   64*tile + l; all zero initially).  On return the trial history is exactly what
+   fcamd_evaluate_device_from would have written -- but only plastic points (new value) and
+   points that were plastic at the previous call and are elastic now (restored to the committed
+   value) are touched, and `history_mask` holds the new plastic set.  Elastic points cost no
+   history traffic: HBM traffic equals the algorithmic 464 / 568 bytes per point.  A commit by
+   swapping the committed and trial pointers keeps the contract (the mask then marks the points
+   where the new trial array is stale). */
+int fcamd_evaluate_device_from_sparse(fcamd_model* model, double t, double del_t, int64_t n,
+                                      const double* grad_del_u, const double* stress_prev,
+                                      double* stress, double* tangent,
+                                      const double* const* history_prev, double* const* history,
+                                      int n_hist, uint64_t* history_mask);
+
 /* Submesh-indexed form (multi-material problems, FULL laws): the gather of the committed
    stress and the scatter of stress and tangent that the reference performs around evaluate
    (solver/_lawonsubmesh.py:58-70 with SubSpaceMap, solver/maps.py:82-123) are folded into the

@@ -61,3 +61,31 @@ def test_update_without_evaluate_raises():
         st.update()
     st.evaluate(0, 1, np.zeros(90))
     st.update()
+
+
+@pytest.mark.parametrize("n", [64 * 40 + 17, 5000])
+def test_sparse_history_equals_full_history(n):
+    """The sparse trial-history protocol (only plastic / formerly plastic points touch eps_n) must give
+    the same trial state as the full out-of-place evaluate at every Newton iteration of every
+    increment, with plastic sets that grow, shrink and move, across pointer-swap commits."""
+    rng = np.random.default_rng(n)
+    law = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
+    s0 = rng.normal(scale=30.0, size=6 * n)
+    h0 = {"eps_n": rng.normal(scale=1e-3, size=6 * n), "alpha": rng.uniform(0, 0.02, size=n)}
+    sp = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=True)
+    fu = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False)
+    assert sp._mask is not None and fu._mask is None
+    for inc in range(5):
+        for it in range(3):
+            # very different plastic sets from call to call: random per-point scale, some calls all elastic
+            scale = 10 ** rng.uniform(-5, -2, size=n) * (0.0 if (inc == 2 and it == 1) else 1.0)
+            g = torch.from_numpy(rng.normal(size=9 * n) * np.repeat(scale, 9)).cuda()
+            sp.evaluate(0.0, 1.0, g)
+            fu.evaluate(0.0, 1.0, g)
+            assert torch.equal(sp.stress, fu.stress) and torch.equal(sp.tangent, fu.tangent)
+            for k in ("eps_n", "alpha"):
+                assert torch.equal(sp.history[k], fu.history[k]), (inc, it, k)
+                assert torch.equal(sp.history_committed[k], fu.history_committed[k]), (inc, it, k)
+        sp.check()
+        sp.update()
+        fu.update()
