@@ -693,7 +693,12 @@ int fcamd_map_rows_device(fcamd_context* c, int64_t n_rows, int row_size, const 
 int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
     if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->registered.count(ptr)) return FCAMD_OK;
+    if (c->registered.count(ptr)) {
+        // Same address again: either a repeated call or a NEW buffer that landed where a freed,
+        // still-registered one was.  Re-pin: a stale registration would DMA through old pages.
+        (void)hipHostUnregister(ptr);
+        c->registered.erase(ptr);
+    }
     HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     c->registered[ptr] = bytes;
     return FCAMD_OK;

@@ -58,11 +58,12 @@ class DeviceLaw(IncrSmallStrainModel):
 
     #: set by subclasses
     _model_id: int = 0
-    #: page-lock the caller's NumPy arrays the first time they are seen (they are stable views of
-    #: ``Function.x.array`` in the dolfinx loop, solver/_lawonsubmesh.py:87-94) so that later calls
-    #: DMA directly: 93 -> 116 Mpts/s on the host path.  Off by default: pinning is a one-off cost
-    #: of ~1 s per 5 GB and the arrays stay pinned until ``unpin_arrays()``.
-    auto_pin: bool = False
+    #: Opt-in: page-lock the caller's NumPy arrays the first time they are passed so that the host
+    #: path DMAs directly (93 -> 116 Mpts/s).  Meant for the dolfinx loop, which hands over the same
+    #: ``Function.x.array`` views every Newton iteration (solver/_lawonsubmesh.py:87-94).  The law
+    #: keeps a reference to every pinned array until ``unpin_arrays()``: page-locked memory must not
+    #: be freed while registered (a later array at the same address would DMA through stale pages).
+    auto_pin = False
 
     def __init__(self, parameter_vector, constraint: StressStrainConstraint = None):
         self._constraint = constraint if constraint is not None else StressStrainConstraint.FULL
@@ -133,20 +134,24 @@ class DeviceLaw(IncrSmallStrainModel):
         )
 
     def _pin(self, ctx, arrays) -> None:
-        pinned = self.__dict__.setdefault("_pinned", {})
+        pinned = self.__dict__.setdefault("_pinned", {})  # (ptr, nbytes) -> array (kept alive) | None
         for a in arrays:
             key = (a.ctypes.data, a.nbytes)
-            if key not in pinned and a.nbytes >= (1 << 20):
-                try:
-                    ctx.register_host_buffer(a)
-                    pinned[key] = a  # keeps the array alive while it is page-locked
-                except RuntimeError:
-                    pinned[key] = None  # e.g. overlaps an existing registration: use the staged path
+            if key in pinned or a.nbytes < (1 << 20):
+                continue
+            try:
+                ctx.register_host_buffer(a)
+                pinned[key] = a
+            except RuntimeError:
+                pinned[key] = None  # e.g. overlaps another registration: keep the staged path
 
     def unpin_arrays(self) -> None:
-        """Undo ``auto_pin`` registrations."""
+        """Undo ``auto_pin`` registrations and drop the references that kept the arrays alive."""
+        pinned = self.__dict__.pop("_pinned", {})
+        if not any(a is not None for a in pinned.values()):
+            return
         ctx = self._handle(0).ctx
-        for a in self.__dict__.pop("_pinned", {}).values():
+        for a in pinned.values():
             if a is not None:
                 ctx.unregister_host_buffer(a)
 

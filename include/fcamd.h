@@ -213,7 +213,9 @@ int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
 
 /* Caller arrays are stable across Newton iterations (views of Function.x.array,
    solver/_lawonsubmesh.py:87-94): page-lock them once so evaluate_host can DMA
-   directly instead of copying through the pinned staging ring. */
+   directly instead of being staged by the runtime.  The caller must unregister a buffer BEFORE
+   freeing it: a registration that outlives its memory makes later DMA at the same address go
+   through stale pages. */
 int fcamd_register_host_buffer(fcamd_context* ctx, void* ptr, size_t bytes);
 int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
 
