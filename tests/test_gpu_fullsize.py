@@ -111,3 +111,37 @@ def test_von_mises_1e8():
                            ("eps_n", gather(e, idx, 6), hs["eps_n"]), ("alpha", gather(a, idx, 1), hs["alpha"])]:
         assert rel_err(got, ref) <= 1e-6, name
         assert rel_err(got, ref) <= 1e-11, "strict " + name
+
+
+def test_spring_maxwell_1e8():
+    """BASELINE.json config 4: Maxwell-SLS update with history arrays, 1e8 points."""
+    need_memory(80)
+    SLS_P = {"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    g = torch.randn(9 * N, dtype=torch.float64, device="cuda", generator=gen) * 1e-3
+    s0 = torch.randn(6 * N, dtype=torch.float64, device="cuda", generator=gen)
+    ev0 = torch.randn(6 * N, dtype=torch.float64, device="cuda", generator=gen) * 1e-4
+    en0 = torch.randn(6 * N, dtype=torch.float64, device="cuda", generator=gen) * 1e-3
+    s, ev, en = s0.clone(), ev0.clone(), en0.clone()
+    t = torch.full((36 * N,), float("nan"), dtype=torch.float64, device="cuda")
+    law = fc.SpringMaxwellModel(SLS_P, FULL)
+    law.evaluate(0.0, 2.0, g, s, t, {"strain_visco": ev, "strain": en})
+    torch.cuda.synchronize()
+    # property 1: one tangent for all points
+    tv = t.view(N, 36)
+    assert torch.equal(tv.min(dim=0).values, tv.max(dim=0).values)
+    del tv
+    # property 2: strain history is the running sum of Mandel strain increments, exactly
+    de = fc.strain_from_grad_u(g, FULL)
+    assert torch.equal(en, en0 + de)
+    del de
+    # property 3: strided sample against the oracle
+    idx = sample_points(N)
+    gs, ss = gather(g, idx, 9), gather(s0, idx, 6)
+    hs = {"strain_visco": gather(ev0, idx, 6), "strain": gather(en0, idx, 6)}
+    ts = np.zeros(36 * idx.numel())
+    CO.spring_maxwell(SLS_P, 0, 2.0, gs, ss, ts, hs)
+    for name, got, ref in [("stress", gather(s, idx, 6), ss), ("tangent", gather(t, idx, 36), ts),
+                           ("strain_visco", gather(ev, idx, 6), hs["strain_visco"]), ("strain", gather(en, idx, 6), hs["strain"])]:
+        assert rel_err(got, ref) <= 1e-10, name
+        assert rel_err(got, ref) <= 1e-14, "strict " + name
