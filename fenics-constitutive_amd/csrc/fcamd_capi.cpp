@@ -28,6 +28,8 @@ using namespace fcamd;
 
 namespace {
 
+constexpr size_t kCounterBytes = (size_t)fcamd::kCounterSlots * 4 * sizeof(unsigned long long);
+
 thread_local std::string g_last_error;
 
 int fail(int status, const char* fmt, ...) {
@@ -357,7 +359,9 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
         a.tile_map = tm;
     }
     fill_constants(m, del_t, &a);
-    if (reset_counters) HIP_TRY(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    // only the plasticity laws count anything: skip the extra launch for the others
+    const bool counts = (m->law == FCAMD_VON_MISES_3D || m->law == FCAMD_COMFE_MISES_PLASTICITY);
+    if (reset_counters && counts) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, stream));
     if (n == 0) return FCAMD_OK;
     const int grid = grid_for(m, n);
     HIP_TRY(launch_evaluate(m->law, m->dims.gdim, a, grid, stream));
@@ -365,14 +369,16 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
 }
 
 int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
-    HIP_TRY(hipMemcpyAsync(m->h_counters, m->d_counters, 4 * sizeof(unsigned long long),
+    HIP_TRY(hipMemcpyAsync(m->h_counters, m->d_counters, kCounterBytes,
                            hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (out) {
-        out->n_nonconverged = m->h_counters[0];
-        out->n_plastic = m->h_counters[1];
-        out->n_newton_iters = m->h_counters[2];
-        out->reserved = 0;
+        out->n_nonconverged = out->n_plastic = out->n_newton_iters = out->reserved = 0;
+        for (int s = 0; s < fcamd::kCounterSlots; ++s) {
+            out->n_nonconverged += m->h_counters[4 * s + 0];
+            out->n_plastic += m->h_counters[4 * s + 1];
+            out->n_newton_iters += m->h_counters[4 * s + 2];
+        }
     }
     return FCAMD_OK;
 }
@@ -493,18 +499,18 @@ int fcamd_model_create(fcamd_context* c, int model_id, int constraint, const dou
         for (int k = 0; k < li.n_hist; ++k) li.hist[k].dim = m->dims.sd;  // history_dim = stress_strain_dim
     m->info = li;
     for (int i = 0; i < n_params; ++i) m->params[i] = params[i];
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_counters), 4 * sizeof(unsigned long long));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_counters), kCounterBytes);
     if (e == hipSuccess)
-        e = hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), 4 * sizeof(unsigned long long),
+        e = hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), kCounterBytes,
                           hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMemset(m->d_counters, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(m->d_counters, 0, kCounterBytes);
     if (e == hipSuccess) e = hipEventCreate(&m->ev0);
     if (e == hipSuccess) e = hipEventCreate(&m->ev1);
     if (e != hipSuccess) {
         fcamd_model_destroy(m);
         return fail(FCAMD_ERR_HIP, "model allocation failed: %s", hipGetErrorString(e));
     }
-    std::memset(m->h_counters, 0, 4 * sizeof(unsigned long long));
+    std::memset(m->h_counters, 0, kCounterBytes);
     *out = m;
     return FCAMD_OK;
 }
@@ -553,7 +559,7 @@ int fcamd_evaluate_device_from(fcamd_model* m, double t, double del_t, int64_t n
     m->timed = c->timing;
     if (m->timed) {
         // counters are reset before the timed window so that the events bracket the kernel only
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->stream));
         HIP_TRY(hipEventRecord(m->ev0, c->stream));
     }
     st = enqueue(m, del_t, n, grad, stress_prev, stress, tangent, hist_prev, hist, c->stream,
@@ -760,7 +766,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     for (int i = 0; i < nslots; ++i)
         if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
 
-    HIP_TRY(hipMemsetAsync(m->d_counters, 0, 4 * sizeof(unsigned long long), c->hstream[0]));
+    HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
     HIP_TRY(hipStreamSynchronize(c->hstream[0]));
 
     int slot = 0;

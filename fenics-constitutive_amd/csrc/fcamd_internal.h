@@ -30,6 +30,9 @@ struct Scalars {
     double s[16];
 };
 
+// the device counters exist in kCounterSlots copies of 4 words each (see flush_stats)
+constexpr int kCounterSlots = 64;
+
 struct EvalArgs {
     const double* grad;        // [9n]
     const double* stress_in;   // [6n] committed stress (may alias stress_out)
@@ -42,7 +45,7 @@ struct EvalArgs {
     unsigned long long* hmask; // nullptr, or sparse-trial-history mask, one word per 64-point tile (VonMises3D)
     const int* rows;           // nullptr, or parent row of every point: stress/tangent are parent arrays
     long long n;               // quadrature points
-    unsigned long long* counters;  // [4]: nonconverged, plastic, newton iterations, reserved
+    unsigned long long* counters;  // [kCounterSlots][4]: nonconverged, plastic, newton iterations, reserved
     int tile_map;              // 0: tiles dealt round-robin to all waves; 1: one contiguous region per XCD
     Scalars sc;
     Tables tb;

@@ -855,6 +855,7 @@ __device__ __forceinline__ void run_tile(const EvalArgs& a, const Tables* T, dou
     // cheap per-tile integer VALU work instead.
     asm volatile("" : "+v"(lane));
     asm volatile("" : "+v"(r0));
+    lane &= kWave - 1;  // range known again: per-lane offsets are provably small and non-negative
     if constexpr (LAW == LAW_LE)
         tile_linear_elasticity<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_COMFE_LE)
@@ -876,6 +877,9 @@ __device__ __forceinline__ void stage_tables(const EvalArgs& a, Tables* T) {
     __syncthreads();
 }
 
+// Per-wave statistics go to one of kCounterSlots copies of the counters (slot = workgroup % slots):
+// with tens of thousands of waves, atomics on ONE address serialise at ~10 ns each (measured:
+// +0.8 ms at 65k waves); spread over 64 addresses they vanish.  The host sums the slots.
 template <int LAW>
 __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& st, int lane) {
     if constexpr (LAW == LAW_VM3D || LAW == LAW_COMFE_MISES) {
@@ -883,9 +887,10 @@ __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& 
         const unsigned long long np = wave_sum(st.plastic);
         const unsigned long long ni = wave_sum(st.iters);
         if (lane == 0) {
-            if (nc) atomicAdd(a.counters + 0, nc);
-            if (np) atomicAdd(a.counters + 1, np);
-            if (ni) atomicAdd(a.counters + 2, ni);
+            unsigned long long* c = a.counters + 4 * (blockIdx.x & (kCounterSlots - 1));
+            if (nc) atomicAdd(c + 0, nc);
+            if (np) atomicAdd(c + 1, np);
+            if (ni) atomicAdd(c + 2, ni);
         }
     }
 }
@@ -900,7 +905,9 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
     stage_tables(a, &T);
 
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
+    // wave index as a scalar: tile index, p0 and every array's tile base pointer then live in SGPRs and
+    // the per-lane part of an address is a small 32-bit offset (saddr addressing)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     double* region = scratch[wave];
     int* rows_lds = rows_all[IDX ? wave : 0];
     const int r0 = lane % 18;
@@ -931,7 +938,9 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_lowdim_kernel(const EvalAr
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     stage_tables(a, &T);
     int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
+    // wave index as a scalar: tile index, p0 and every array's tile base pointer then live in SGPRs and
+    // the per-lane part of an address is a small 32-bit offset (saddr addressing)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const long long nfull = a.n / kWave;
     const long long wstride = (long long)gridDim.x * kWavesPerBlock;
     for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride) {
@@ -969,7 +978,9 @@ __global__ void __launch_bounds__(kBlock)
     strain_kernel(const double* grad, double* strain, long long n, double factor) {
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
+    // wave index as a scalar: tile index, p0 and every array's tile base pointer then live in SGPRs and
+    // the per-lane part of an address is a small 32-bit offset (saddr addressing)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     double* region = scratch[wave];
     const long long ntiles = (n + kWave - 1) / kWave;
     const long long nfull = n / kWave;

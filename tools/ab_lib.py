@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""A/B two builds of libfcamd.so in ONE process on identical buffers (interleaved rounds):
+    python tools/ab_lib.py libA.so libB.so [n ...]
+VonMises3D mixed workload, committed->trial evaluate."""
+import ctypes as C
+import sys
+
+import torch
+
+libs = sys.argv[1:3]
+sizes = [int(float(x)) for x in sys.argv[3:]] or [1_000_000, 10_000_000, 100_000_000]
+dev = torch.device("cuda", 0)
+torch.zeros(1, device=dev)
+stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = (C.c_double * 5)(175000.0, 80769.0, 1200.0, 2500.0, 200.0)
+
+
+class Lib:
+    def __init__(self, path):
+        self.l = C.CDLL(path)
+        self.ctx, self.m = C.c_void_p(), C.c_void_p()
+        assert self.l.fcamd_context_create(0, stream, C.byref(self.ctx)) == 0
+        # torch's default stream has handle 0 = "own a private stream" for create(); bind it explicitly
+        assert self.l.fcamd_context_set_stream(self.ctx, stream) == 0
+        assert self.l.fcamd_model_create(self.ctx, 2, 5, P, 5, C.byref(self.m)) == 0
+        self.l.fcamd_evaluate_device_from.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64] + [C.c_void_p] * 4 + [C.POINTER(C.c_void_p)] * 2 + [C.c_int]
+
+    def run(self, n, g, s0, s1, t, h0, h1):
+        a0 = (C.c_void_p * 2)(h0[0].data_ptr(), h0[1].data_ptr())
+        a1 = (C.c_void_p * 2)(h1[0].data_ptr(), h1[1].data_ptr())
+        rc = self.l.fcamd_evaluate_device_from(self.m, 0.0, 1.0, n, g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, 2)
+        assert rc == 0, rc
+
+
+L = [Lib(p) for p in libs]
+f = dict(dtype=torch.float64, device=dev)
+for n in sizes:
+    gen = torch.Generator(device=dev).manual_seed(1)
+    g = torch.randn(9 * n, generator=gen, **f)
+    g.view(n, 9).mul_(torch.pow(10.0, torch.rand(n, generator=gen, **f) * 2 - 4)[:, None])
+    s0, s1 = torch.zeros(6 * n, **f), torch.empty(6 * n, **f)
+    h0 = [torch.zeros(6 * n, **f), torch.rand(n, generator=gen, **f) * 0.02]
+    h1 = [torch.empty(6 * n, **f), torch.empty(n, **f)]
+    t = torch.empty(36 * n, **f)
+    outs = []
+    res = [[] for _ in L]
+    reps = 5 if n >= 10**8 else 20
+    for rnd in range(5):
+        for i, lib in enumerate(L):
+            for _ in range(2):
+                lib.run(n, g, s0, s1, t, h0, h1)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b in ev:
+                a.record()
+                lib.run(n, g, s0, s1, t, h0, h1)
+                b.record()
+            torch.cuda.synchronize()
+            res[i].append(sum(a.elapsed_time(b) for a, b in ev) / reps)
+            if rnd == 0:
+                outs.append((s1.clone(), t.clone() if n <= 10**7 else None, h1[0].clone()))
+    same = all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][2], o[2]) and (o[1] is None or torch.equal(outs[0][1], o[1])) for o in outs[1:])
+    maxdiff = max(float((outs[0][0] - o[0]).abs().max()) for o in outs[1:]) if len(outs) > 1 else 0.0
+    print(f"n={n:>10}: " + "  ".join(f"{libs[i].split('/')[-1]} {sorted(r)[len(r)//2]*1e3:9.1f} us" for i, r in enumerate(res)) + f"   identical={same} max|dstress|={maxdiff:.3e}", flush=True)
+    del g, s0, s1, h0, h1, t
+    torch.cuda.empty_cache()
