@@ -353,3 +353,17 @@ def test_special_values_propagate_like_the_reference(kind):
         assert np.array_equal(np.isinf(a), np.isinf(b)), f"{kind} {name}: Inf pattern differs"
         ok = np.isfinite(b)
         assert rel_err(a[ok], b[ok]) <= TOL[CLASS[kind]], f"{kind} {name}"
+
+
+@pytest.mark.parametrize("kind", ["von_mises_3d", "spring_kelvin"])
+def test_host_path_many_chunks_ragged(kind):
+    """ndarray path over several staging chunks (4 slots in flight) with a ragged tail."""
+    n = 3 * (1 << 19) + 4 * 64 + 37
+    p, g, s, h = random_case(kind, n, seed=31)
+    ref = oracle_run(kind, p, 0.9, g, s, h, mod=CO)
+    law = make_law(kind, p)
+    got = run_host(law, 0.9, g, s.copy(), np.full(36 * n, np.nan), {k: v.copy() for k, v in h.items()})
+    compare(got, ref, TOL[CLASS[kind]], kind)
+    compare(got, ref, STRICT[CLASS[kind]], "strict " + kind)
+    if kind == "von_mises_3d":
+        assert law.last_stats.n_plastic == int(np.sum(ref[2]["alpha"] > h["alpha"]))
