@@ -1012,11 +1012,8 @@ constexpr bool kNT = true;
 
 // Tuning knob for experiments: FCAMD_NT=0 selects plain (temporal) global loads/stores.
 static bool use_nontemporal() {
-    static const bool v = [] {
-        const char* e = getenv("FCAMD_NT");
-        return !(e && e[0] == '0');
-    }();
-    return v;
+    const char* e = getenv("FCAMD_NT");  // re-read per launch: lets tools/ab_probe*.py A/B in one process
+    return !(e && e[0] == '0');
 }
 
 template <int LAW>
