@@ -1,0 +1,90 @@
+"""The C ABI used directly through ctypes, exactly as INTEGRATION.md section 2 shows a maintainer
+binding it (no fenics_constitutive_amd Python classes on the call path): context / model
+lifecycle, history introspection, host evaluate, status codes and error strings."""
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+from golden_util import load_calls, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")  # one HIP runtime per process: torch first
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fenics-constitutive_amd", "lib", "libfcamd.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from fenics_constitutive_amd import _build
+
+    _build.build_library()
+    l = C.CDLL(LIB)
+    l.fcamd_last_error.restype = C.c_char_p
+    l.fcamd_status_string.restype = C.c_char_p
+    return l
+
+
+def test_integration_stub_von_mises(lib):
+    ctx, mdl = C.c_void_p(), C.c_void_p()
+    assert lib.fcamd_context_create(0, None, C.byref(ctx)) == 0
+    p = (C.c_double * 5)(175000.0, 80769.0, 1200.0, 2500.0, 200.0)
+    assert lib.fcamd_model_create(ctx, 2, 5, p, 5, C.byref(mdl)) == 0  # FCAMD_VON_MISES_3D, FCAMD_FULL
+    nh = C.c_int()
+    assert lib.fcamd_model_history_count(mdl, C.byref(nh)) == 0 and nh.value == 2
+    names = []
+    for k in range(2):
+        name, dim = C.c_char_p(), C.c_int()
+        assert lib.fcamd_model_history_field(mdl, k, C.byref(name), C.byref(dim)) == 0
+        names.append((name.value.decode(), dim.value))
+    assert names == [("eps_n", 6), ("alpha", 1)]  # history_dim of the reference (:184-186)
+
+    class Stats(C.Structure):
+        _fields_ = [("nonconv", C.c_uint64), ("plastic", C.c_uint64), ("iters", C.c_uint64), ("reserved", C.c_uint64)]
+
+    for c in load_calls("von_mises_3d.npz")[:6]:
+        s, t, h = c.fresh()
+        g = c.grad.copy()
+        hp = (C.c_void_p * 2)(h["eps_n"].ctypes.data, h["alpha"].ctypes.data)
+        st = Stats()
+        rc = lib.fcamd_evaluate_host(mdl, C.c_double(0.0), C.c_double(c.del_t), C.c_int64(c.n), C.c_void_p(g.ctypes.data),
+                                     C.c_void_p(s.ctypes.data), C.c_void_p(t.ctypes.data), hp, 2, C.byref(st))
+        assert rc == 0, lib.fcamd_last_error()
+        assert rel_err(s, c.stress_out) <= 1e-6 and rel_err(t, c.tangent_out) <= 1e-6
+        assert rel_err(h["alpha"], c.hist_out["alpha"]) <= 1e-6
+        assert st.plastic == int(np.sum(c.hist_out["alpha"] > c.hist_in["alpha"]))
+    assert lib.fcamd_model_destroy(mdl) == 0 and lib.fcamd_context_destroy(ctx) == 0
+
+
+def test_status_codes(lib):
+    ctx, mdl = C.c_void_p(), C.c_void_p()
+    assert lib.fcamd_context_create(0, None, C.byref(ctx)) == 0
+    assert lib.fcamd_context_create(99, None, C.byref(C.c_void_p())) == 6  # FCAMD_ERR_BAD_ARG
+    p4 = (C.c_double * 4)(42.0, 10.0, 10.0, 0.2)
+    assert lib.fcamd_model_create(ctx, 77, 5, p4, 4, C.byref(mdl)) == 6  # unknown law
+    assert lib.fcamd_model_create(ctx, 2, 3, p4, 4, C.byref(mdl)) == 8  # VonMises3D is FULL-only -> UNSUPPORTED
+    assert lib.fcamd_model_create(ctx, 3, 5, p4, 3, C.byref(mdl)) == 6  # wrong parameter count
+    assert lib.fcamd_model_create(ctx, 3, 5, p4, 4, C.byref(mdl)) == 0  # SpringMaxwellModel FULL
+    n = 10
+    g, s, t = np.zeros(9 * n), np.zeros(6 * n), np.zeros(36 * n)
+    h = [np.zeros(6 * n), np.zeros(6 * n)]
+    hp = (C.c_void_p * 2)(h[0].ctypes.data, h[1].ctypes.data)
+    args = (C.c_int64(n), C.c_void_p(g.ctypes.data), C.c_void_p(s.ctypes.data), C.c_void_p(t.ctypes.data))
+    assert lib.fcamd_evaluate_host(mdl, C.c_double(0), C.c_double(1.0), *args, None, 0, None) == 2  # NULL_HISTORY
+    assert b"history must not be None" in lib.fcamd_last_error()
+    assert lib.fcamd_evaluate_host(mdl, C.c_double(0), C.c_double(0.0), *args, hp, 2, None) == 3  # DEL_T
+    assert lib.fcamd_evaluate_host(mdl, C.c_double(0), C.c_double(1.0), *args, hp, 1, None) == 1  # SIZE
+    assert lib.fcamd_evaluate_host(mdl, C.c_double(0), C.c_double(1.0), *args, hp, 2, None) == 0
+    assert lib.fcamd_evaluate_host(mdl, C.c_double(0), C.c_double(1.0), C.c_int64(0), None, None, None, hp, 2, None) == 0  # n = 0
+    assert lib.fcamd_status_string(4).startswith(b"Newton-Raphson")
+    # device entry rejects misaligned pointers
+    d = torch.zeros(64 * 60, dtype=torch.float64, device="cuda")
+    base = d.data_ptr()
+    lib.fcamd_evaluate_device.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int]
+    hd = (C.c_void_p * 2)(base + 8 * 1024, base + 8 * 2048)
+    assert lib.fcamd_evaluate_device(mdl, 0.0, 1.0, 8, base + 8, base + 8 * 512, None, hd, 2) == 7  # ALIGN
+    assert lib.fcamd_evaluate_device(mdl, 0.0, 1.0, 8, base, base + 8 * 512, None, hd, 2) == 0
+    assert lib.fcamd_context_synchronize(ctx) == 0
+    lib.fcamd_model_destroy(mdl)
+    lib.fcamd_context_destroy(ctx)
