@@ -2,7 +2,7 @@
 //
 // Execution model
 //   * one quadrature point per lane, one 64-point tile per wavefront iteration,
-//     persistent grid (tiles are dealt round-robin to all resident wavefronts);
+//     grid-stride (tiles are dealt round-robin to all wavefronts of the grid);
 //   * the caller's arrays stay in the reference's point-major AoS layout in HBM.  Every
 //     global access is a wave-contiguous 16-byte-per-lane stream (1 KiB per instruction);
 //     the AoS<->lane transposition happens in a small wave-private LDS region, so no
@@ -77,7 +77,8 @@ struct Chunks {
     d2 v[K];
 };
 
-template <int NC, int K>
+// chunk k of lane `lane` exists: always, except the odd last half-instruction of odd NC
+template <int NC>
 __device__ __forceinline__ bool chunk_live(int k, int lane) {
     return (2 * (k + 1) <= NC) || lane < 32;
 }
@@ -90,7 +91,7 @@ __device__ __forceinline__ void tile_load(Chunks<NC>& c, const double* src, int 
     for (int k = 0; k < Chunks<NC>::K; ++k) {
         const int q = k * kWave + lane;
         if constexpr (FULL) {
-            if (chunk_live<NC, Chunks<NC>::K>(k, lane)) c.v[k] = load16<NT>(src + 2 * q);
+            if (chunk_live<NC>(k, lane)) c.v[k] = load16<NT>(src + 2 * q);
         } else {
             const int e = 2 * q;
             c.v[k].x = e < nelem ? src[e] : 0.0;
@@ -105,7 +106,7 @@ __device__ __forceinline__ void tile_to_lds(const Chunks<NC>& c, double* lds, in
 #pragma unroll
     for (int k = 0; k < Chunks<NC>::K; ++k) {
         const int q = k * kWave + lane;
-        if (chunk_live<NC, Chunks<NC>::K>(k, lane)) reinterpret_cast<d2*>(lds)[q] = c.v[k];
+        if (chunk_live<NC>(k, lane)) reinterpret_cast<d2*>(lds)[q] = c.v[k];
     }
 }
 
@@ -116,7 +117,7 @@ __device__ __forceinline__ void tile_store(const Chunks<NC>& c, double* dst, int
     for (int k = 0; k < Chunks<NC>::K; ++k) {
         const int q = k * kWave + lane;
         if constexpr (FULL) {
-            if (chunk_live<NC, Chunks<NC>::K>(k, lane)) store16<NT>(dst + 2 * q, c.v[k]);
+            if (chunk_live<NC>(k, lane)) store16<NT>(dst + 2 * q, c.v[k]);
         } else {
             const int e = 2 * q;
             if (e < nelem) dst[e] = c.v[k].x;
@@ -132,7 +133,7 @@ __device__ __forceinline__ void lds_to_global(const double* lds, double* dst, in
 #pragma unroll
     for (int k = 0; k < Chunks<NC>::K; ++k) {
         const int q = k * kWave + lane;
-        if (chunk_live<NC, Chunks<NC>::K>(k, lane)) c.v[k] = reinterpret_cast<const d2*>(lds)[q];
+        if (chunk_live<NC>(k, lane)) c.v[k] = reinterpret_cast<const d2*>(lds)[q];
     }
     tile_store<NC, FULL, NT>(c, dst, nelem, lane);
 }
