@@ -735,16 +735,12 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     HIP_TRY(hipSetDevice(c->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
 
-    // per-point doubles on the device: grad 9, stress 6, tangent 36, history
-    int hdim_total = 0;
-    for (int k = 0; k < m->info.n_hist; ++k) hdim_total += m->info.hist[k].dim;
-    const size_t per_point = 9 + 6 + 36 + (size_t)hdim_total;
-    // chunking: enough chunks in flight to keep both DMA directions busy (tunable for experiments)
-    if (c->chunk_points == 0) {
+    // chunking: enough chunks in flight to keep both DMA directions busy.  Measured on MI355X / PCIe
+    // gen5 (tools/host_path_bench.py): page-locked caller arrays like many small chunks in flight
+    // (4 x 128 Ki points: 116 Mpts/s); pageable arrays are staged by the runtime and prefer large
+    // chunks (512 Ki points: 93 Mpts/s).  FCAMD_HOST_CHUNK / FCAMD_HOST_SLOTS override (experiments).
+    {
         const char* e = getenv("FCAMD_HOST_CHUNK");
-        // measured on MI355X / PCIe gen5 (tools/host_path_bench.py): page-locked caller arrays like
-        // many small chunks in flight (4 x 128 Ki points: 116 Mpts/s); pageable arrays are staged by
-        // the runtime and prefer large chunks (512 Ki points: 93 Mpts/s)
         const bool pinned = c->registered.count(const_cast<double*>(grad)) != 0;
         c->chunk_points = e ? std::max<int64_t>(64, (atoll(e) / 64) * 64) : (pinned ? (1 << 17) : (1 << 19));
         const char* sl = getenv("FCAMD_HOST_SLOTS");
@@ -762,7 +758,6 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dchunk[i]), (size_t)chunk * 66 * sizeof(double)));
         c->dchunk_points = (size_t)chunk;
     }
-    (void)per_point;
     for (int i = 0; i < nslots; ++i)
         if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
 
