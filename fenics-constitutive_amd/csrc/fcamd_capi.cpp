@@ -748,7 +748,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     }
     const int nslots = c->slots;
     const int64_t chunk = std::min<int64_t>(c->chunk_points, ((n + 63) / 64) * 64);
-    if (chunk > 0 && (size_t)chunk > c->dchunk_points) {
+    if (chunk > 0 && ((size_t)chunk > c->dchunk_points || !c->dchunk[nslots - 1])) {
         for (int i = 0; i < fcamd_context::kSlots; ++i) {
             if (c->dchunk[i]) HIP_TRY(hipFree(c->dchunk[i]));
             c->dchunk[i] = nullptr;
