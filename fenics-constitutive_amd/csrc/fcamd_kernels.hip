@@ -545,15 +545,16 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
     // take the dense path -- which also restores stale lanes, since it writes the whole tile.
     constexpr int kSparseRowMax = 12;
     const unsigned long long need_mask = mask | m_old;
-    const bool use_rows = sparse && (__popcll(need_mask) <= kSparseRowMax);
+    // The same row path serves the plain in-place call (the reference contract): there only the
+    // plastic lanes of a tile change their history, no mask is needed.
+    const bool use_rows = (sparse || hist_in_place) && (need_mask != 0ull) &&
+                          (__popcll(need_mask) <= kSparseRowMax);
     const bool need_row = use_rows && (plastic || (((m_old >> lane) & 1ull) != 0ull));
     const bool touch_eps = !use_rows && (sparse ? (need_mask != 0ull) : ((mask != 0ull) || !hist_in_place));
     if (touch_eps) tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
-    if constexpr (sparse) {
-        if (need_row) {
+    if (need_row) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) ce.v[k] = load16<NT>(a.h0_in + (p0 + lane) * 6 + 2 * k);
-        }
+        for (int k = 0; k < 3; ++k) ce.v[k] = load16<NT>(a.h0_in + (p0 + lane) * 6 + 2 * k);
     }
 
     double gamma = 0.0, xc1 = 0.0, xc2 = 0.0;
@@ -611,20 +612,20 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
         }
         if (live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
     }
-    if constexpr (sparse) {
-        if (use_rows) {
-            if (need_row) {
+    if (use_rows) {
+        if (need_row) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    d2 v;
-                    v.x = ce.v[k].x + gamma * N[2 * k];
-                    v.y = ce.v[k].y + gamma * N[2 * k + 1];
-                    store16<NT>(a.h0_out + (p0 + lane) * 6 + 2 * k, v);
-                }
+            for (int k = 0; k < 3; ++k) {
+                d2 v;
+                v.x = ce.v[k].x + gamma * N[2 * k];
+                v.y = ce.v[k].y + gamma * N[2 * k + 1];
+                store16<NT>(a.h0_out + (p0 + lane) * 6 + 2 * k, v);
             }
-            // alpha: one coalesced 512-byte store per tile that has (or had) a plastic point
-            if ((need_mask != 0ull) && live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
         }
+        // alpha: one coalesced 512-byte store per tile that has (or had) a plastic point
+        if (live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
+    }
+    if constexpr (sparse) {
         if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
     }
 
