@@ -88,3 +88,20 @@ def test_status_codes(lib):
     assert lib.fcamd_context_synchronize(ctx) == 0
     lib.fcamd_model_destroy(mdl)
     lib.fcamd_context_destroy(ctx)
+
+
+def test_c_program_runs(tmp_path, lib):
+    """examples/c_caller.c: a plain-C host, compiled with gcc, evaluates through the C ABI."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(LIB)
+    exe = tmp_path / "c_caller"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_caller.c"),
+                    "-o", str(exe), "-L", libdir, "-lfcamd", "-lm", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "max error" in r.stdout

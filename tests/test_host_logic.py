@@ -122,3 +122,21 @@ def test_shard_plan(n, world):
         assert lo % 64 == 0 or lo == n
         covered += hi - lo
     assert covered == n
+
+
+def test_header_is_plain_c_and_c_caller_links(tmp_path):
+    """include/fcamd.h must compile as C99 and a C program must link against libfcamd.so (running it
+    needs a GPU: tests/test_gpu_capi_raw.py)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    _capi.load()
+    exe = tmp_path / "c_caller"
+    libdir = os.path.dirname(_capi.library_path())
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c_caller.c"), "-o", str(exe), "-L", libdir, "-lfcamd", "-lm",
+                        f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert exe.exists()
