@@ -199,12 +199,22 @@ __device__ __forceinline__ void transpose_out(const double (&x)[NC], double* reg
 //                its own 48-byte stress row, and the tangent writers look the row of each chunk's
 //                point up in a per-wave LDS table.
 // ---------------------------------------------------------------------------------------
+// Base pointers of the stress / tangent arrays as seen by one tile.  Normally the kernel arguments;
+// for a tile of the indexed kernel whose 64 parent rows are consecutive they are shifted by
+// (row0 - p0) rows, so that the coalesced (non-indexed) tile body addresses the parent rows directly.
+struct StressBases {
+    const double* sin;
+    double* sout;
+    double* tan;
+};
+
 template <bool IDX, bool FULL, bool NT>
 struct StressRows {
     Chunks<6> c;
     long long row = 0;
 
-    __device__ __forceinline__ void load(const EvalArgs& a, long long p0, int npts, int lane, int* rows_lds) {
+    __device__ __forceinline__ void load(const EvalArgs& a, const StressBases& sb, long long p0, int npts, int lane,
+                                         int* rows_lds) {
         if constexpr (IDX) {
             const bool live = FULL || lane < npts;
             row = live ? (long long)a.rows[p0 + lane] : 0ll;
@@ -214,10 +224,10 @@ struct StressRows {
                 d2 z;
                 z.x = 0.0;
                 z.y = 0.0;
-                c.v[k] = live ? load16<NT>(a.stress_in + row * 6 + 2 * k) : z;
+                c.v[k] = live ? load16<NT>(sb.sin + row * 6 + 2 * k) : z;
             }
         } else {
-            tile_load<6, FULL, NT>(c, a.stress_in + p0 * 6, npts * 6, lane);
+            tile_load<6, FULL, NT>(c, sb.sin + p0 * 6, npts * 6, lane);
         }
     }
     __device__ __forceinline__ void get(double* region, int lane, double (&s)[6]) {
@@ -231,7 +241,7 @@ struct StressRows {
             transpose_in<6>(c, region, lane, s);
         }
     }
-    __device__ __forceinline__ void put(const EvalArgs& a, double* region, int lane, const double (&s)[6],
+    __device__ __forceinline__ void put(const StressBases& sb, double* region, int lane, const double (&s)[6],
                                         long long p0, int npts) {
         if constexpr (IDX) {
             if (FULL || lane < npts) {
@@ -240,11 +250,11 @@ struct StressRows {
                     d2 v;
                     v.x = s[2 * k];
                     v.y = s[2 * k + 1];
-                    store16<NT>(a.stress_out + row * 6 + 2 * k, v);
+                    store16<NT>(sb.sout + row * 6 + 2 * k, v);
                 }
             }
         } else {
-            transpose_out<6, FULL, NT>(s, region, lane, a.stress_out + p0 * 6, npts * 6);
+            transpose_out<6, FULL, NT>(s, region, lane, sb.sout + p0 * 6, npts * 6);
         }
     }
 };
@@ -376,17 +386,17 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 // --- LinearElasticityModel: sigma += d_eps @ D ; tangent = tile(D) ----------------------
 template <bool IDX, bool FULL, bool NT>
-__device__ __forceinline__ void tile_linear_elasticity(const EvalArgs& a, const Tables* T,
+__device__ __forceinline__ void tile_linear_elasticity(const EvalArgs& a, const StressBases& sb, const Tables* T,
                                                        double* region, int* rows_lds, long long p0,
                                                        int npts, int lane, int r0) {
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    sr.load(a, p0, npts, lane, rows_lds);
+    sr.load(a, sb, p0, npts, lane, rows_lds);
     // the constant tangent does not depend on the loads: stream it while they are in flight
-    if (a.tangent) {
+    if (sb.tan) {
         if constexpr (IDX) wave_sync();  // rows_lds visible to all lanes
-        tangent_const<IDX, FULL, NT>(T->c, a.tangent, p0, rows_lds, npts, lane, r0);
+        tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
     }
     double g[9], s[6], e[6], ds[6];
     transpose_in<9>(cg, region, lane, g);
@@ -395,20 +405,20 @@ __device__ __forceinline__ void tile_linear_elasticity(const EvalArgs& a, const 
     row_times_matrix_fma(e, T->a, ds);
 #pragma unroll
     for (int i = 0; i < 6; ++i) s[i] = s[i] + ds[i];
-    sr.put(a, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts);
 }
 
 // --- comfe-rs LinearElasticity3D: sigma += C . d_eps (column axpy, no FMA) ---------------
 template <bool IDX, bool FULL, bool NT>
-__device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                               int* rows_lds, long long p0, int npts, int lane, int r0) {
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    sr.load(a, p0, npts, lane, rows_lds);
-    if (a.tangent) {
+    sr.load(a, sb, p0, npts, lane, rows_lds);
+    if (sb.tan) {
         if constexpr (IDX) wave_sync();  // rows_lds visible to all lanes
-        tangent_const<IDX, FULL, NT>(T->c, a.tangent, p0, rows_lds, npts, lane, r0);
+        tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
     }
     double g[9], s[6], e[6];
     transpose_in<9>(cg, region, lane, g);
@@ -421,7 +431,7 @@ __device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const Tables* T
         for (int j = 1; j < 6; ++j) acc = T->a[6 * i + j] * e[j] + acc;
         s[i] = s[i] + acc;
     }
-    sr.put(a, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts);
 }
 
 // --- SLS Maxwell / Kelvin -----------------------------------------------------------------
@@ -429,18 +439,18 @@ __device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const Tables* T
 //          Maxwell: s[4]=2*mu1 ; Kelvin: s[4]=2*mu0, s[5]=mu0/(tau*mu1), s[6]=lam0/(tau*2*mu1)
 // tables:  Maxwell a=D1, b=D0+D1, c=tangent ; Kelvin a=D0, c=tangent
 template <bool KELVIN, bool IDX, bool FULL, bool NT>
-__device__ __forceinline__ void tile_sls(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void tile_sls(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                          int* rows_lds, long long p0, int npts, int lane, int r0) {
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     Chunks<6> cv, cn;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    sr.load(a, p0, npts, lane, rows_lds);
+    sr.load(a, sb, p0, npts, lane, rows_lds);
     tile_load<6, FULL, NT>(cv, a.h0_in + p0 * 6, npts * 6, lane);  // strain_visco
     tile_load<6, FULL, NT>(cn, a.h1_in + p0 * 6, npts * 6, lane);  // strain
-    if (a.tangent) {
+    if (sb.tan) {
         if constexpr (IDX) wave_sync();  // rows_lds visible to all lanes
-        tangent_const<IDX, FULL, NT>(T->c, a.tangent, p0, rows_lds, npts, lane, r0);
+        tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
     }
     double g[9], s[6], ev[6], en[6], e[6], dv[6], y[6];
     transpose_in<9>(cg, region, lane, g);
@@ -477,7 +487,7 @@ __device__ __forceinline__ void tile_sls(const EvalArgs& a, const Tables* T, dou
         ev[i] = ev[i] + dv[i];
         en[i] = en[i] + e[i];
     }
-    sr.put(a, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts);
     transpose_out<6, FULL, NT>(ev, region, lane, a.h0_out + p0 * 6, npts * 6);
     transpose_out<6, FULL, NT>(en, region, lane, a.h1_out + p0 * 6, npts * 6);
 }
@@ -487,13 +497,13 @@ __device__ __forceinline__ void tile_sls(const EvalArgs& a, const Tables* T, dou
 //          s[6]=-w, s[7]=(-2)*mu, s[8]=((2/3)*(y00-y0))*w, s[9]=(4*mu)*mu
 // tables:  a = ka*xioi, b = xpp
 template <bool IDX, bool SPARSE, bool FULL, bool NT>
-__device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                                int* rows_lds, long long p0, int npts, int lane,
                                                WaveStats& st) {
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    sr.load(a, p0, npts, lane, rows_lds);
+    sr.load(a, sb, p0, npts, lane, rows_lds);
     const bool live = FULL || lane < npts;
     const double alpha_n = live ? a.h1_in[p0 + lane] : 0.0;
     const bool hist_in_place = (a.h0_in == a.h0_out) && (a.h1_in == a.h1_out);
@@ -597,7 +607,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
         const double vol = i < 3 ? kt : kt * 0.0;
         s[i] = s[i] + ((vol + dsig[i]) - tmg * N[i]);
     }
-    sr.put(a, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts);
 
     // history: eps_n += gamma N ; alpha += sqrt(2/3) gamma
     if (touch_eps) {
@@ -630,12 +640,12 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
     }
 
     // tangent: ka xioi + 2 mu (1 - 2 mu xc2) xpp + 4 mu^2 (xc2 - xc1) N (x) N
-    if (a.tangent) {
+    if (sb.tan) {
         const double B = two_mu * (1.0 - two_mu * xc2);
         const double C = four_mu2 * (xc2 - xc1);
         publish_tangent_params(region, lane, B, C, N);
         wave_sync();
-        tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, a.tangent, p0, rows_lds, npts, lane);
+        tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane);
         wave_sync();
     }
 }
@@ -645,14 +655,14 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const Tables* 
 //          s[5]=2*mu, s[6]=3*mu+h, s[7]=sqrt(3/2), s[8]=3*mu, s[9]=1/(1+h/(3 mu))
 // tables:  a = kappa*sym_id(x)sym_id, b = P_dev.   history field 0: [alpha, eps_p(6)] per point.
 template <bool IDX, bool FULL, bool NT>
-__device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                                  int* rows_lds, long long p0, int npts, int lane,
                                                  WaveStats& st) {
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     Chunks<7> ch;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
-    sr.load(a, p0, npts, lane, rows_lds);
+    sr.load(a, sb, p0, npts, lane, rows_lds);
     tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
     const bool live = FULL || lane < npts;
     const bool hist_in_place = (a.h0_in == a.h0_out);
@@ -715,15 +725,15 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Tables
         const double ts = theta * s_tr[i];
         s[i] = i < 3 ? p_1 + ts : ts;
     }
-    sr.put(a, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts);
     if (mask != 0ull || !hist_in_place)
         transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
 
-    if (a.tangent) {
+    if (sb.tan) {
         const double B = plastic ? two_mu * theta : two_mu;
         publish_tangent_params(region, lane, B, sc, nv);
         wave_sync();
-        tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, a.tangent, p0, rows_lds, npts, lane);
+        tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane);
         wave_sync();
     }
 }
@@ -857,7 +867,7 @@ __device__ __forceinline__ void tile_lowdim(const EvalArgs& a, const Tables* T, 
 // the kernel
 // ---------------------------------------------------------------------------------------
 template <int LAW, bool IDX, bool FULL, bool NT, bool SPARSE = false>
-__device__ __forceinline__ void run_tile(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void run_tile(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                          int* rows_lds, long long p0, int npts, int lane, int r0,
                                          WaveStats& st) {
     // Everything derived from the lane id (chunk -> point/row/column maps, LDS and global
@@ -868,17 +878,38 @@ __device__ __forceinline__ void run_tile(const EvalArgs& a, const Tables* T, dou
     asm volatile("" : "+v"(r0));
     lane &= kWave - 1;  // range known again: per-lane offsets are provably small and non-negative
     if constexpr (LAW == LAW_LE)
-        tile_linear_elasticity<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
+        tile_linear_elasticity<IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_COMFE_LE)
-        tile_comfe_le<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
+        tile_comfe_le<IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_MAXWELL)
-        tile_sls<false, IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
+        tile_sls<false, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_KELVIN)
-        tile_sls<true, IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, r0);
+        tile_sls<true, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_VM3D)
-        tile_von_mises<IDX, SPARSE, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, st);
+        tile_von_mises<IDX, SPARSE, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, st);
     else
-        tile_comfe_mises<IDX, FULL, NT>(a, T, region, rows_lds, p0, npts, lane, st);
+        tile_comfe_mises<IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, st);
+}
+
+// One full tile of the main kernel.  Indexed kernel: when the 64 parent rows of the tile are
+// consecutive (cells of a material are mostly numbered in runs) the coalesced tile body runs on
+// shifted base pointers; only tiles with scattered rows pay the per-lane row accesses.
+template <int LAW, bool IDX, bool NT, bool SPARSE>
+__device__ __forceinline__ void run_full_tile(const EvalArgs& a, const Tables* T, double* region,
+                                              int* rows_lds, long long p0, int lane, int r0, WaveStats& st) {
+    const StressBases sb{a.stress_in, a.stress_out, a.tangent};
+    if constexpr (IDX) {
+        const int row = a.rows[p0 + lane];
+        const int row0 = __builtin_amdgcn_readfirstlane(row);
+        if (__all(row == row0 + lane)) {
+            const long long shift = (long long)row0 - p0;
+            const StressBases sc{a.stress_in + shift * 6, a.stress_out + shift * 6,
+                                 a.tangent ? a.tangent + shift * 36 : nullptr};
+            run_tile<LAW, false, true, NT, SPARSE>(a, sc, T, region, rows_lds, p0, kWave, lane, r0, st);
+            return;
+        }
+    }
+    run_tile<LAW, IDX, true, NT, SPARSE>(a, sb, T, region, rows_lds, p0, kWave, lane, r0, st);
 }
 
 __device__ __forceinline__ void stage_tables(const EvalArgs& a, Tables* T) {
@@ -927,7 +958,7 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
     if (a.tile_map == 0) {
         const long long wstride = (long long)gridDim.x * kWavesPerBlock;
         for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
-            run_tile<LAW, IDX, true, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, kWave, lane, r0, st);
+            run_full_tile<LAW, IDX, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, lane, r0, st);
     } else {
         // XCD-aware variant (experiment): workgroups b and b+8 share an XCD (round-robin dispatch);
         // give every XCD one contiguous eighth of the tiles.  There is no data reuse to keep in an
@@ -937,7 +968,7 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
         const long long lo = xcd * per, hi = (lo + per < nfull) ? lo + per : nfull;
         const long long wstride = (long long)((gridDim.x + 7 - xcd) / 8) * kWavesPerBlock;
         for (long long tile = lo + (long long)(blockIdx.x >> 3) * kWavesPerBlock + wave; tile < hi; tile += wstride)
-            run_tile<LAW, IDX, true, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, kWave, lane, r0, st);
+            run_full_tile<LAW, IDX, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, lane, r0, st);
     }
     flush_stats<LAW>(a, st, lane);
 }
@@ -979,7 +1010,8 @@ __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) 
     const int lane = threadIdx.x;
     const long long p0 = (a.n / kWave) * kWave;
     WaveStats st;
-    run_tile<LAW, IDX, false, false, SPARSE>(a, &T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
+    const StressBases sb{a.stress_in, a.stress_out, a.tangent};
+    run_tile<LAW, IDX, false, false, SPARSE>(a, sb, &T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
     flush_stats<LAW>(a, st, lane);
 }
 

@@ -7,12 +7,15 @@ import sys
 
 import torch
 
+import os
 libs = sys.argv[1:3]
 sizes = [int(float(x)) for x in sys.argv[3:]] or [1_000_000, 10_000_000, 100_000_000]
+LAW = os.environ.get("AB_LAW", "vm")  # vm | le | maxwell
+MODEL = {"vm": (2, [175000.0, 80769.0, 1200.0, 2500.0, 200.0], 2), "le": (1, [42.0, 0.3], 0), "maxwell": (3, [42.0, 10.0, 10.0, 0.2], 2)}[LAW]
 dev = torch.device("cuda", 0)
 torch.zeros(1, device=dev)
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-P = (C.c_double * 5)(175000.0, 80769.0, 1200.0, 2500.0, 200.0)
+P = (C.c_double * len(MODEL[1]))(*MODEL[1])
 
 
 class Lib:
@@ -22,13 +25,13 @@ class Lib:
         assert self.l.fcamd_context_create(0, stream, C.byref(self.ctx)) == 0
         # torch's default stream has handle 0 = "own a private stream" for create(); bind it explicitly
         assert self.l.fcamd_context_set_stream(self.ctx, stream) == 0
-        assert self.l.fcamd_model_create(self.ctx, 2, 5, P, 5, C.byref(self.m)) == 0
+        assert self.l.fcamd_model_create(self.ctx, MODEL[0], 5, P, len(MODEL[1]), C.byref(self.m)) == 0
         self.l.fcamd_evaluate_device_from.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64] + [C.c_void_p] * 4 + [C.POINTER(C.c_void_p)] * 2 + [C.c_int]
 
     def run(self, n, g, s0, s1, t, h0, h1):
         a0 = (C.c_void_p * 2)(h0[0].data_ptr(), h0[1].data_ptr())
         a1 = (C.c_void_p * 2)(h1[0].data_ptr(), h1[1].data_ptr())
-        rc = self.l.fcamd_evaluate_device_from(self.m, 0.0, 1.0, n, g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, 2)
+        rc = self.l.fcamd_evaluate_device_from(self.m, 0.0, 1.0, n, g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, MODEL[2])
         assert rc == 0, rc
 
 
@@ -39,8 +42,12 @@ for n in sizes:
     g = torch.randn(9 * n, generator=gen, **f)
     g.view(n, 9).mul_(torch.pow(10.0, torch.rand(n, generator=gen, **f) * 2 - 4)[:, None])
     s0, s1 = torch.zeros(6 * n, **f), torch.empty(6 * n, **f)
-    h0 = [torch.zeros(6 * n, **f), torch.rand(n, generator=gen, **f) * 0.02]
-    h1 = [torch.empty(6 * n, **f), torch.empty(n, **f)]
+    if LAW == "maxwell":
+        h0 = [torch.zeros(6 * n, **f), torch.zeros(6 * n, **f)]
+        h1 = [torch.empty(6 * n, **f), torch.empty(6 * n, **f)]
+    else:
+        h0 = [torch.zeros(6 * n, **f), torch.rand(n, generator=gen, **f) * 0.02]
+        h1 = [torch.empty(6 * n, **f), torch.empty(n, **f)]
     t = torch.empty(36 * n, **f)
     outs = []
     res = [[] for _ in L]
