@@ -179,6 +179,23 @@ class Context:
             self.handle = C.c_void_p()
 
 
+def default_device() -> int:
+    """GPU used by the NumPy (host) path of this process: ``FCAMD_DEVICE`` if set, else torch's
+    current device when torch has been imported, else the node-local rank of the usual launchers
+    (one MPI rank / one torchrun worker per GPU, as dolfinx runs), else 0."""
+    import sys
+
+    if "FCAMD_DEVICE" in os.environ:
+        return int(os.environ["FCAMD_DEVICE"])
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        return int(torch.cuda.current_device())
+    for var in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"):
+        if var in os.environ:
+            return int(os.environ[var])
+    return 0
+
+
 def get_context(device: int = 0) -> Context:
     key = (int(device), threading.get_ident())
     ctx = _contexts.get(key)

@@ -125,7 +125,7 @@ class DeviceLaw(IncrSmallStrainModel):
             _check_numpy("tangent", tangent)
         for (name, _), h in zip(self._history_fields(), hist):
             _check_numpy(f"history['{name}']", h)
-        m = self._handle(0)
+        m = self._handle(_capi.default_device())
         if self.auto_pin:
             self._pin(m.ctx, [grad, stress] + ([] if tangent is None else [tangent]) + list(hist))
         self.last_stats = m.evaluate_host(
@@ -150,7 +150,7 @@ class DeviceLaw(IncrSmallStrainModel):
         pinned = self.__dict__.pop("_pinned", {})
         if not any(a is not None for a in pinned.values()):
             return
-        ctx = self._handle(0).ctx
+        ctx = self._handle(_capi.default_device()).ctx
         for a in pinned.values():
             if a is not None:
                 ctx.unregister_host_buffer(a)
@@ -269,5 +269,5 @@ def strain_from_grad_u_full(grad_u):
     g = np.ascontiguousarray(np.asarray(grad_u, dtype=np.float64)).reshape(-1)
     if not torch.cuda.is_available():
         raise RuntimeError("strain_from_grad_u(FULL) runs on the GPU and no HIP device is available")
-    d = torch.from_numpy(g).cuda()
+    d = torch.from_numpy(g).to(torch.device("cuda", _capi.default_device()))
     return strain_from_grad_u_full(d).cpu().numpy()

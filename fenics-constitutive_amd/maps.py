@@ -32,7 +32,7 @@ class DeviceSubSpaceMap:
     def __init__(self, parent, sub, device=None):
         import torch
 
-        dev = torch.device("cuda", 0) if device is None else torch.device(device)
+        dev = torch.device("cuda", _capi.default_device()) if device is None else torch.device(device)
         self.parent = torch.as_tensor(parent, dtype=torch.int32).to(dev).contiguous()
         self.sub = torch.as_tensor(sub, dtype=torch.int32).to(dev).contiguous()
         assert self.parent.numel() == self.sub.numel(), "index arrays must have equal length"

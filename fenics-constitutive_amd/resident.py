@@ -32,7 +32,9 @@ class ResidentState:
         import torch
 
         self.law, self.n = law, int(n)
-        self.device = torch.device("cuda", 0) if device is None else torch.device(device)
+        from . import _capi
+
+        self.device = torch.device("cuda", _capi.default_device()) if device is None else torch.device(device)
         gd2, sd = law.geometric_dim**2, law.stress_strain_dim
         self._gd2, self._sd = gd2, sd
         f = dict(dtype=torch.float64, device=self.device)

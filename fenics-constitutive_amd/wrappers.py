@@ -60,7 +60,7 @@ class _From3D(IncrSmallStrainModel):
         if host:
             if not torch.cuda.is_available():
                 raise RuntimeError("the 3D wrappers evaluate on the GPU and no HIP device is available")
-            dev = torch.device("cuda", 0)
+            dev = torch.device("cuda", _capi.default_device())
             g_lo = torch.from_numpy(np.ascontiguousarray(grad_del_u, dtype=np.float64)).to(dev)
             s_lo = torch.from_numpy(np.ascontiguousarray(stress, dtype=np.float64)).to(dev)
             t_lo = torch.empty(tangent.size, dtype=torch.float64, device=dev)

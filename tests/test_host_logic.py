@@ -140,3 +140,22 @@ def test_header_is_plain_c_and_c_caller_links(tmp_path):
                         f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert exe.exists()
+
+
+def test_default_device_selection(monkeypatch):
+    import sys
+
+    for v in ("FCAMD_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"):
+        monkeypatch.delenv(v, raising=False)
+    import torch
+
+    if torch.cuda.is_available():
+        assert _capi.default_device() == torch.cuda.current_device()
+    else:
+        assert _capi.default_device() == 0
+        monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "3")
+        assert _capi.default_device() == 3
+        monkeypatch.setenv("LOCAL_RANK", "5")
+        assert _capi.default_device() == 5
+    monkeypatch.setenv("FCAMD_DEVICE", "2")
+    assert _capi.default_device() == 2
