@@ -42,7 +42,10 @@ WORKLOADS = {
     "spring_maxwell": ("spring_maxwell", 1e-3, 648, 648),
     "spring_kelvin": ("spring_kelvin", 1e-3, 648, 648),
     "comfe_mises_mixed": ("comfe_mises_plasticity", "loguniform", 464, 568),
+    # general return mapping (7x7 Newton per plastic point), bound by FP64 issue rather than HBM
+    "drucker_prager_mixed": ("comfe_drucker_prager", "isochoric", 464, 568),
 }
+DP_P = {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02}
 
 
 def make_law(kind):
@@ -61,6 +64,8 @@ def make_law(kind):
         return fc.SpringKelvinModel(SLS_P, FULL), SLS_P
     if kind == "comfe_mises_plasticity":
         return fc.MisesPlasticityLinearHardening3D({k: np.array([v]) for k, v in RS_P.items()}), RS_P
+    if kind == "comfe_drucker_prager":
+        return fc.DruckerPrager3D({k: np.array([v]) for k, v in DP_P.items()}), DP_P
     raise ValueError(kind)
 
 
@@ -77,6 +82,15 @@ def synth_inputs(kind, scale_spec, n, seed, device):
         if scale_spec == "loguniform":
             sc = torch.pow(10.0, torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 2.0 - 4.0)
             g.view(n, 9).mul_(sc[:, None])
+        elif scale_spec == "isochoric":
+            # Drucker-Prager: mostly isochoric increments, scale log-uniform in [1e-4, 5e-3] (keeps the
+            # trial states away from the tip of the classic surface)
+            sc = torch.pow(10.0, torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 1.7 - 4.0)
+            gv = g.view(n, 9)
+            gv.mul_(sc[:, None])
+            tr = (gv[:, 0] + gv[:, 4] + gv[:, 8]) * (0.95 / 3.0)
+            for c in (0, 4, 8):
+                gv[:, c] -= tr
         else:
             g.mul_(float(scale_spec))
         return g
@@ -88,6 +102,9 @@ def synth_inputs(kind, scale_spec, n, seed, device):
     elif kind in ("spring_maxwell", "spring_kelvin"):
         hist = {"strain_visco": torch.zeros(6 * n, dtype=torch.float64, device=device),
                 "strain": torch.zeros(6 * n, dtype=torch.float64, device=device)}
+    elif kind == "comfe_drucker_prager":
+        hist = {"history": torch.zeros(7 * n, dtype=torch.float64, device=device)}
+        stress.view(n, 6)[:, :3] = -1000.0  # compressive prestress
     elif kind == "comfe_mises_plasticity":
         h = torch.zeros(7 * n, dtype=torch.float64, device=device)
         h.view(n, 7)[:, 0] = torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 0.02
@@ -163,6 +180,27 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
     return out
 
 
+def cpu_baseline_numpy_dp(params, grad, stress, hist, budget_s=10.0):
+    """Drucker-Prager has no C restatement: time the NumPy port of comfe-rs general.rs (batched LAPACK
+    solves, oracle/numpy_oracle.py) on a bounded sample."""
+    import numpy as np
+
+    from oracle import numpy_oracle as NO
+
+    ns = min(grad.numel() // 9, 200_000)
+    g, s0, h0 = grad[: 9 * ns].cpu().numpy(), stress[: 6 * ns].cpu().numpy(), hist["history"][: 7 * ns].cpu().numpy()
+    tan = np.zeros(36 * ns)
+    reps, t_total = 0, 0.0
+    while t_total < budget_s and reps < 50:
+        s, h = s0.copy(), {"history": h0.copy()}
+        t0 = time.perf_counter()
+        NO.comfe_drucker_prager(params, 0.0, 1.0, g, s, tan, h)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    return {"value": round(ns * reps / t_total / 1e6, 4), "unit": "Mpts/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle/numpy_oracle.py comfe_drucker_prager (NumPy/LAPACK default threads), first {ns} points x {reps} passes ({t_total:.1f} s)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,7 +270,7 @@ def main():
         step()
     torch.cuda.synchronize()
     st = law.device_stats(local_rank)
-    n_pl = int(st.n_plastic) if kind in ("von_mises_3d", "comfe_mises_plasticity") else 0
+    n_pl = int(st.n_plastic) if kind in ("von_mises_3d", "comfe_mises_plasticity", "comfe_drucker_prager") else 0
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -315,7 +353,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {kind} FULL-3D, {n} quadrature points per GPU, device-resident AoS, "
                                    f"committed->trial evaluate{' (sparse trial history)' if args.sparse_history else ''}", "points_per_gpu": n, "plastic_fraction": round(n_pl / n, 4),
-                       "mean_newton_iters": round(st.n_newton_iters / max(n_pl, 1), 3) if kind == "von_mises_3d" else None,
+                       "mean_newton_iters": round(st.n_newton_iters / max(n_pl, 1), 3) if kind in ("von_mises_3d", "comfe_drucker_prager") else None,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -325,7 +363,9 @@ def main():
         }
         if gather:
             out["allgather"] = gather
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and kind == "comfe_drucker_prager":
+            out["cpu_baseline"] = cpu_baseline_numpy_dp(params, grad, stress_c, hist_c)
+        elif not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kind, params, grad, stress_c, hist_c, del_t)
         elif world == 1:
             out["cpu_baseline"] = None

@@ -8,6 +8,8 @@ reference's own model interface.  Import as ``fenics_constitutive_amd``.
 
 from .interfaces import IncrSmallStrainModel, StressStrainConstraint  # noqa: F401
 from .models import (  # noqa: F401
+    DruckerPrager3D,
+    DruckerPragerHyperbolic3D,
     LinearElasticity3D,
     LinearElasticityModel,
     MisesPlasticityLinearHardening3D,
@@ -29,6 +31,8 @@ __all__ = [
     "SpringKelvinModel",
     "LinearElasticity3D",
     "MisesPlasticityLinearHardening3D",
+    "DruckerPrager3D",
+    "DruckerPragerHyperbolic3D",
     "UniaxialStrainFrom3D",
     "PlaneStrainFrom3D",
     "lame_parameters",

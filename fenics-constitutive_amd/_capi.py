@@ -15,10 +15,11 @@ import numpy as np
 from . import _build
 
 # status codes (include/fcamd.h)
-OK, ERR_SIZE, ERR_NULL_HISTORY, ERR_DEL_T, ERR_NONCONVERGED, ERR_HIP, ERR_BAD_ARG, ERR_ALIGN, ERR_UNSUPPORTED = range(9)
+OK, ERR_SIZE, ERR_NULL_HISTORY, ERR_DEL_T, ERR_NONCONVERGED, ERR_HIP, ERR_BAD_ARG, ERR_ALIGN, ERR_UNSUPPORTED, ERR_DOMAIN = range(10)
 
 # model ids (include/fcamd.h)
-LINEAR_ELASTICITY, VON_MISES_3D, SPRING_MAXWELL, SPRING_KELVIN, COMFE_LINEAR_ELASTICITY, COMFE_MISES_PLASTICITY = range(1, 7)
+(LINEAR_ELASTICITY, VON_MISES_3D, SPRING_MAXWELL, SPRING_KELVIN, COMFE_LINEAR_ELASTICITY, COMFE_MISES_PLASTICITY,
+ COMFE_DRUCKER_PRAGER, COMFE_DRUCKER_PRAGER_HYPERBOLIC) = range(1, 9)
 
 MAX_HISTORY = 2
 
@@ -43,7 +44,7 @@ class Stats(C.Structure):
         ("n_nonconverged", C.c_uint64),
         ("n_plastic", C.c_uint64),
         ("n_newton_iters", C.c_uint64),
-        ("reserved", C.c_uint64),
+        ("n_domain", C.c_uint64),
     ]
 
 
@@ -131,7 +132,7 @@ def check(status: int) -> None:
         raise AssertionError(detail)
     if status == ERR_NULL_HISTORY:
         raise ValueError(detail)
-    if status == ERR_NONCONVERGED:
+    if status in (ERR_NONCONVERGED, ERR_DOMAIN):
         raise RuntimeError(detail)
     if status == ERR_UNSUPPORTED:
         raise NotImplementedError(detail)

@@ -74,6 +74,8 @@ bool law_info(int id, LawInfo* li) {
         case FCAMD_SPRING_KELVIN: *li = {4, 2, {{"strain_visco", 6}, {"strain", 6}}, true}; return true;
         case FCAMD_COMFE_LINEAR_ELASTICITY: *li = {2, 0, {}, false}; return true;
         case FCAMD_COMFE_MISES_PLASTICITY: *li = {4, 1, {{"history", 7}}, false}; return true;
+        case FCAMD_COMFE_DRUCKER_PRAGER: *li = {5, 1, {{"history", 7}}, false}; return true;
+        case FCAMD_COMFE_DRUCKER_PRAGER_HYPERBOLIC: *li = {6, 1, {{"history", 7}}, false}; return true;
         default: return false;
     }
 }
@@ -295,6 +297,27 @@ void fill_constants(const fcamd_model* m, double del_t, EvalArgs* a) {
             }
             break;
         }
+        case FCAMD_COMFE_DRUCKER_PRAGER:
+        case FCAMD_COMFE_DRUCKER_PRAGER_HYPERBOLIC: {
+            const bool hyper = m->law == FCAMD_COMFE_DRUCKER_PRAGER_HYPERBOLIC;
+            const double mu = p[0], kappa = p[1], a_ = p[2], b = p[3];
+            const double d = hyper ? p[4] : 0.0, b_flow = hyper ? p[5] : p[4];
+            double soo[36], pvol[36], pdev[36];
+            comfe_projections(soo, pvol, pdev);
+            sc.s[0] = kFactorRs;
+            sc.s[1] = mu;
+            sc.s[2] = kappa;
+            sc.s[3] = a_;
+            sc.s[4] = b;
+            sc.s[5] = b_flow;
+            sc.s[6] = d * d;  // d.powi(2)
+            sc.s[7] = 2.0 * mu;
+            sc.s[8] = std::sqrt(2.0 / 3.0);
+            sc.s[9] = 1.0 / (4.0 * mu);    // isotropic_elastic_tangent_inv, mandel.rs:130-141
+            sc.s[10] = 1.0 / (9.0 * kappa);
+            for (int i = 0; i < 36; ++i) tb.c[i] = (2.0 * mu) * pdev[i] + (3.0 * kappa) * pvol[i];  // E (symmetric)
+            break;
+        }
     }
 }
 
@@ -360,7 +383,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     }
     fill_constants(m, del_t, &a);
     // only the plasticity laws count anything: skip the extra launch for the others
-    const bool counts = (m->law == FCAMD_VON_MISES_3D || m->law == FCAMD_COMFE_MISES_PLASTICITY);
+    const bool counts = (m->law == FCAMD_VON_MISES_3D || m->law >= FCAMD_COMFE_MISES_PLASTICITY);
     if (reset_counters && counts) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, stream));
     if (n == 0) return FCAMD_OK;
     const int grid = grid_for(m, n);
@@ -373,11 +396,12 @@ int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
                            hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (out) {
-        out->n_nonconverged = out->n_plastic = out->n_newton_iters = out->reserved = 0;
+        out->n_nonconverged = out->n_plastic = out->n_newton_iters = out->n_domain = 0;
         for (int s = 0; s < fcamd::kCounterSlots; ++s) {
             out->n_nonconverged += m->h_counters[4 * s + 0];
             out->n_plastic += m->h_counters[4 * s + 1];
             out->n_newton_iters += m->h_counters[4 * s + 2];
+            out->n_domain += m->h_counters[4 * s + 3];
         }
     }
     return FCAMD_OK;
@@ -402,6 +426,7 @@ const char* fcamd_status_string(int status) {
         case FCAMD_ERR_BAD_ARG: return "bad argument";
         case FCAMD_ERR_ALIGN: return "device pointer not 16-byte aligned";
         case FCAMD_ERR_UNSUPPORTED: return "not implemented";
+        case FCAMD_ERR_DOMAIN: return "non-differentiable tip of Drucker-Prager surface reached";
         default: return "unknown status";
     }
 }
@@ -802,9 +827,12 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     st = read_stats(m, c->hstream[0], &local);
     if (st != FCAMD_OK) return st;
     if (stats) *stats = local;
+    if (local.n_domain > 0)
+        return fail(FCAMD_ERR_DOMAIN, "non-differentiable tip of Drucker-Prager surface reached");
     if (local.n_nonconverged > 0)
         return fail(FCAMD_ERR_NONCONVERGED,
-                    "Newton-Raphson method did not converge for plastic multiplier.");
+                    m->law >= FCAMD_COMFE_DRUCKER_PRAGER ? "Plasticity3D: Newton-Raphson did not converge."
+                                                         : "Newton-Raphson method did not converge for plastic multiplier.");
     return FCAMD_OK;
 }
 

@@ -14,6 +14,8 @@ enum Law : int {
     LAW_KELVIN = 4,
     LAW_COMFE_LE = 5,
     LAW_COMFE_MISES = 6,
+    LAW_COMFE_DP = 7,        // Drucker-Prager, classic yield surface
+    LAW_COMFE_DP_HYPER = 8,  // Drucker-Prager, hyperbolic approximation of the tip
 };
 
 // Three 6x6 tables staged into LDS by every workgroup; meaning depends on the law

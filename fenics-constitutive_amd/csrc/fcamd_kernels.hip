@@ -371,7 +371,7 @@ __device__ __forceinline__ void publish_tangent_params(double* region, int lane,
 // per-wave statistics
 // ---------------------------------------------------------------------------------------
 struct WaveStats {
-    unsigned long long nonconv = 0, plastic = 0, iters = 0;
+    unsigned long long nonconv = 0, plastic = 0, iters = 0, domain = 0;
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -739,6 +739,279 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
 }
 
 
+
+// --- comfe-rs general return mapping with the Drucker-Prager yield surfaces -------------------
+// Reference: comfe-rs/src/plasticity/general.rs:105-266 (Newton on sigma(6), lambda, kappa; maxit
+// 25, atol = rtol = 1e-8; consistent tangent from the inverse of the last Jacobian),
+// drucker_prager_classic.rs:62-116, drucker_prager_hyperbolic.rs:64-114.
+// The 8x8 Newton system of the reference has a zero kappa column in its first seven rows
+// (df/dkappa = dg/dkappa = 0 for both surfaces), so it is solved here as a 7x7 system for
+// (sigma, lambda) plus one back-substitution for kappa; the leading block is I + (SPD) and needs
+// no pivoting.  E.(dg/dsigma) = 2 mu (dg/dsigma) and E.g = 2 mu c1 s + 3 kappa b_flow 1 are used
+// as identities (dg/dsigma maps into the deviatoric space).  Quirks kept as read: the kappa
+// residual carries no del_lambda (alpha converges to alpha_0 + sqrt(2/3)|g|).
+// scalars: s[0]=strain factor, s[1]=mu, s[2]=kappa, s[3]=a, s[4]=b, s[5]=b_flow, s[6]=d*d,
+//          s[7]=2*mu, s[8]=sqrt(2/3), s[9]=1/(4 mu) , s[10]=1/(9 kappa)   tables: c = E (tangent)
+struct DPModel {
+    double f, k, c1, c2;
+    double s[6];  // deviator of sigma
+};
+
+template <bool HYPER>
+__device__ __forceinline__ void dp_state(const double (&sig)[6], double a_, double b, double dsq, DPModel& m,
+                                         bool& tip) {
+    const double i_1 = (sig[0] + sig[1]) + sig[2];
+    const double vol = i_1 / 3.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m.s[i] = i < 3 ? sig[i] + (-vol) : sig[i];
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) n2 = i == 0 ? m.s[0] * m.s[0] : n2 + m.s[i] * m.s[i];
+    const double j_2 = 0.5 * n2;
+    if constexpr (HYPER) {
+        const double root = sqrt(j_2 + dsq);
+        m.f = root + b * i_1 - a_;
+        m.c1 = 0.5 * (1.0 / root);
+        m.c2 = -0.25 / ((j_2 + dsq) * root);
+    } else {
+        tip = tip || !(i_1 < a_ / b);
+        const double root = sqrt(j_2);
+        m.f = root + b * i_1 - a_;
+        m.c1 = 0.5 / root;
+        m.c2 = -0.25 / (j_2 * root);
+    }
+}
+
+// dg/dsigma (symmetric): (s_i c2) s_j + c1 P_dev[i][j]
+__device__ __forceinline__ double dp_dgs(const DPModel& m, int i, int j) {
+    const double pd = (i == j ? 1.0 : 0.0) - ((i < 3 && j < 3) ? (1.0 / 3.0) : 0.0);
+    return (m.s[i] * m.c2) * m.s[j] + m.c1 * pd;
+}
+
+// Fill the 7x7 Newton block M, the kappa row r[0..6] and k for the state m and multiplier dl.
+__device__ __forceinline__ void dp_newton_matrix(const DPModel& m, double dl, double b, double bflow, double two_mu,
+                                                 double kappa, double s23, double (&M)[7][7], double (&r)[7],
+                                                 double& k) {
+    double g[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = (i < 3 ? bflow : 0.0) + m.c1 * m.s[i];
+    double gn2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gn2 = i == 0 ? g[0] * g[0] : gn2 + g[i] * g[i];
+    const double gnorm = sqrt(gn2);
+    k = s23 * gnorm;
+    const double w = two_mu * dl;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) M[i][j] = (i == j ? 1.0 : 0.0) + w * dp_dgs(m, i, j);
+        M[i][6] = two_mu * (m.c1 * m.s[i]) + (i < 3 ? 3.0 * kappa * bflow : 0.0);  // E g
+        M[6][i] = (i < 3 ? b : 0.0) + m.c1 * m.s[i];                             // df/dsigma
+    }
+    M[6][6] = 0.0;
+    const double cg = s23 / gnorm;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc = i == 0 ? (cg * g[0]) * dp_dgs(m, 0, j) : acc + (cg * g[i]) * dp_dgs(m, i, j);
+        r[j] = (-dl) * acc;  // -del_lambda dk/dsigma
+    }
+    r[6] = -k;
+}
+
+// In-place LU of the 7x7 block without pivoting (L unit lower, U upper; see header comment).
+__device__ __forceinline__ void dp_lu7(double (&M)[7][7]) {
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        const double inv = 1.0 / M[c][c];
+#pragma unroll
+        for (int i = c + 1; i < 7; ++i) {
+            const double l = M[i][c] * inv;
+            M[i][c] = l;
+#pragma unroll
+            for (int j = c + 1; j < 7; ++j) M[i][j] = M[i][j] - l * M[c][j];
+        }
+    }
+}
+__device__ __forceinline__ void dp_solve7(const double (&M)[7][7], double (&x)[7]) {
+#pragma unroll
+    for (int i = 1; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) x[i] = x[i] - M[i][j] * x[j];
+#pragma unroll
+    for (int i = 6; i >= 0; --i) {
+#pragma unroll
+        for (int j = i + 1; j < 7; ++j) x[i] = x[i] - M[i][j] * x[j];
+        x[i] = x[i] / M[i][i];
+    }
+}
+
+template <bool HYPER, bool IDX, bool FULL, bool NT>
+__device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBases& sb, const Tables* T,
+                                              double* region, int* rows_lds, long long p0, int npts, int lane,
+                                              int r0, WaveStats& st) {
+    Chunks<9> cg;
+    StressRows<IDX, FULL, NT> sr;
+    Chunks<7> ch;
+    tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
+    sr.load(a, sb, p0, npts, lane, rows_lds);
+    tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
+    const bool live = FULL || lane < npts;
+    const bool hist_in_place = (a.h0_in == a.h0_out);
+
+    double g9[9], sig0[6], h[7], e[6];
+    transpose_in<9>(cg, region, lane, g9);
+    sr.get(region, lane, sig0);
+    transpose_in<7>(ch, region, lane, h);
+    mandel_strain(g9, a.sc.s[0], e);
+    const double kappa = a.sc.s[2], a_ = a.sc.s[3], b = a.sc.s[4], bflow = a.sc.s[5], dsq = a.sc.s[6],
+                 two_mu = a.sc.s[7], s23 = a.sc.s[8], inv4mu = a.sc.s[9], inv9k = a.sc.s[10];
+
+    // sigma_tr = E d_eps + sigma_0  (E v = 2 mu dev v + kappa tr(v) 1)
+    double sig_tr[6], sig1[6];
+    {
+        const double tr = (e[0] + e[1]) + e[2], vol = tr / 3.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            sig_tr[i] = (i < 3 ? two_mu * (e[i] + (-vol)) + kappa * tr : two_mu * e[i]) + sig0[i];
+    }
+    DPModel m;
+    bool tip = false;
+    dp_state<HYPER>(sig_tr, a_, b, dsq, m, tip);
+    const bool plastic = live && (m.f > 0.0);
+    const unsigned long long mask = __ballot(plastic);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sig1[i] = sig_tr[i];
+
+    if (mask == 0ull) {
+        // fully elastic tile: stress = sigma_tr, tangent = E, history untouched
+        sr.put(sb, region, lane, sig1, p0, npts);
+        if (!hist_in_place) transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+        if (sb.tan) {
+            if constexpr (IDX) wave_sync();
+            tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
+        }
+        st.domain += (live && tip) ? 1ull : 0ull;
+        return;
+    }
+
+    double M[7][7], r[7], kk = 0.0;
+    if (plastic) {
+        const double alpha_0 = h[0];
+        double alpha_1 = alpha_0, dl = 0.0;
+        double res[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, m.f};
+        double res_kappa = 0.0;
+        dp_newton_matrix(m, 0.0, b, bflow, two_mu, kappa, s23, M, r, kk);
+        int it = 0;
+        bool failed = false;
+        for (;;) {
+            double x[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[i] = res[i];
+            dp_lu7(M);
+            dp_solve7(M, x);
+            double dk = res_kappa;  // kappa row: r . x + 1 * dk = res_kappa
+#pragma unroll
+            for (int j = 0; j < 7; ++j) dk = dk - r[j] * x[j];
+            double dsig2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                sig1[i] = sig1[i] - x[i];
+                dsig2 = i == 0 ? x[0] * x[0] : dsig2 + x[i] * x[i];
+            }
+            const double dl_prev = dl, al_prev = alpha_1;
+            dl = dl - x[6];
+            alpha_1 = alpha_1 - dk;
+            dp_state<HYPER>(sig1, a_, b, dsq, m, tip);
+            dp_newton_matrix(m, dl, b, bflow, two_mu, kappa, s23, M, r, kk);
+            // residuals: sigma_1 - sigma_tr + dl E g ;  alpha_1 - alpha_0 - k ;  f
+            double rs2 = 0.0, s1n2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                res[i] = (sig1[i] - sig_tr[i]) + dl * M[i][6];
+                rs2 = i == 0 ? res[0] * res[0] : rs2 + res[i] * res[i];
+                s1n2 = i == 0 ? sig1[0] * sig1[0] : s1n2 + sig1[i] * sig1[i];
+            }
+            res[6] = m.f;
+            res_kappa = (alpha_1 - alpha_0) - kk;
+            const double atol = 1e-8, rtol = 1e-8;
+            const bool conv_res = sqrt(rs2) < atol && fabs(res_kappa) < atol && fabs(m.f) < atol;
+            const bool conv_inc = sqrt(dsig2) < atol + rtol * sqrt(s1n2) &&
+                                  fabs(alpha_1 - al_prev) < atol + rtol * fabs(alpha_1) &&
+                                  fabs(dl - dl_prev) < atol + rtol * fabs(dl);
+            if (conv_res || conv_inc) break;
+            if (it > 25) {
+                failed = true;
+                break;
+            }
+            ++it;
+        }
+        st.iters += (unsigned long long)(it + 1);
+        st.nonconv += failed ? 1ull : 0ull;
+        // history: alpha ; plastic_strain += d_eps - E^-1 (sigma_1 - sigma_0)
+        h[0] = alpha_1;
+        {
+            double ds[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ds[i] = sig1[i] - sig0[i];
+            const double tr = (ds[0] + ds[1]) + ds[2], vol = tr / 3.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                // E^-1 v = (1/(4 mu)) * 2 dev v + (1/(9 kappa)) * ... : isotropic_elastic_tangent(1/(4mu), 1/(9kappa))
+                const double einv = i < 3 ? (2.0 * inv4mu) * (ds[i] + (-vol)) + (3.0 * inv9k) * vol : (2.0 * inv4mu) * ds[i];
+                h[1 + i] = h[1 + i] + (e[i] - einv);
+            }
+        }
+        // tangent = (dres^-1)[0:6,0:6] . E with dres = last Jacobian.  Column c of the inverse block X
+        // comes from one 7x7 solve; (X E)_ic = 2 mu X_ic + [c < 3] lam (X_i0 + X_i1 + X_i2).  Entries are
+        // stored as they are produced (8-byte stores into this point's own 288-byte row: this law is
+        // bound by FP64 issue, not by HBM), which keeps the register footprint at M plus three columns.
+        if (sb.tan) {
+            long long row = p0 + lane;
+            if constexpr (IDX) row = sr.row;
+            double* tp = sb.tan + row * 36;
+            dp_lu7(M);
+            double X3[3][6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double x[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) x[i] = i == c ? 1.0 : 0.0;
+                dp_solve7(M, x);
+                if (c < 3) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) X3[c][i] = x[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) tp[6 * i + c] = two_mu * x[i];
+                }
+            }
+            const double lam = kappa - two_mu / 3.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double rs = lam * ((X3[0][i] + X3[1][i]) + X3[2][i]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tp[6 * i + c] = two_mu * X3[c][i] + rs;
+            }
+        }
+    }
+    st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
+    st.domain += (live && tip) ? 1ull : 0ull;  // tip of the classic surface reached (reference: assert!)
+
+    sr.put(sb, region, lane, sig1, p0, npts);
+    transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+
+    // elastic lanes of a tile that has plastic points: tangent = E, written to their own row
+    if (sb.tan && live && !plastic) {
+        long long row = p0 + lane;
+        if constexpr (IDX) row = sr.row;
+        double* tp = sb.tan + row * 36;
+#pragma unroll
+        for (int q = 0; q < 18; ++q) store16<NT>(tp + 2 * q, reinterpret_cast<const d2*>(T->c)[q]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Low-dimensional constraints (uniaxial strain/stress: DIMS = 1; plane strain/stress:
 // DIMS = 2) of the three laws the reference implements "for all constraints": LE
@@ -887,6 +1160,10 @@ __device__ __forceinline__ void run_tile(const EvalArgs& a, const StressBases& s
         tile_sls<true, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_VM3D)
         tile_von_mises<IDX, SPARSE, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, st);
+    else if constexpr (LAW == LAW_COMFE_DP)
+        tile_comfe_dp<false, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0, st);
+    else if constexpr (LAW == LAW_COMFE_DP_HYPER)
+        tile_comfe_dp<true, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0, st);
     else
         tile_comfe_mises<IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, st);
 }
@@ -924,15 +1201,17 @@ __device__ __forceinline__ void stage_tables(const EvalArgs& a, Tables* T) {
 // +0.8 ms at 65k waves); spread over 64 addresses they vanish.  The host sums the slots.
 template <int LAW>
 __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& st, int lane) {
-    if constexpr (LAW == LAW_VM3D || LAW == LAW_COMFE_MISES) {
+    if constexpr (LAW == LAW_VM3D || LAW == LAW_COMFE_MISES || LAW == LAW_COMFE_DP || LAW == LAW_COMFE_DP_HYPER) {
         const unsigned long long nc = wave_sum(st.nonconv);
         const unsigned long long np = wave_sum(st.plastic);
         const unsigned long long ni = wave_sum(st.iters);
+        const unsigned long long nd = wave_sum(st.domain);
         if (lane == 0) {
             unsigned long long* c = a.counters + 4 * (blockIdx.x & (kCounterSlots - 1));
             if (nc) atomicAdd(c + 0, nc);
             if (np) atomicAdd(c + 1, np);
             if (ni) atomicAdd(c + 2, ni);
+            if (nd) atomicAdd(c + 3, nd);
         }
     }
 }
@@ -940,7 +1219,7 @@ __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& 
 // Main kernel: all full 64-point tiles.  Persistent: wave w of the grid takes tiles
 // w, w + W, w + 2W, ...
 template <int LAW, bool NT, bool IDX, bool SPARSE = false>
-__global__ void __launch_bounds__(kBlock, 4) evaluate_kernel(const EvalArgs a) {
+__global__ void __launch_bounds__(kBlock, (LAW >= LAW_COMFE_DP ? 1 : 4)) evaluate_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     __shared__ int rows_all[IDX ? kWavesPerBlock : 1][kWave];
@@ -1116,6 +1395,8 @@ hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hi
         case LAW_KELVIN: return launch_law<LAW_KELVIN>(args, grid, stream);
         case LAW_COMFE_LE: return launch_law<LAW_COMFE_LE>(args, grid, stream);
         case LAW_COMFE_MISES: return launch_law<LAW_COMFE_MISES>(args, grid, stream);
+        case LAW_COMFE_DP: return launch_law<LAW_COMFE_DP>(args, grid, stream);
+        case LAW_COMFE_DP_HYPER: return launch_law<LAW_COMFE_DP_HYPER>(args, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }

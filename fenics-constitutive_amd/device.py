@@ -234,6 +234,8 @@ class DeviceLaw(IncrSmallStrainModel):
         RuntimeError like the reference if a Newton iteration did not converge."""
         st = self._handle(device).last_stats()
         self.last_stats = st
+        if getattr(st, "n_domain", 0):
+            raise RuntimeError("non-differentiable tip of Drucker-Prager surface reached")
         if st.n_nonconverged:
             raise RuntimeError("Newton-Raphson method did not converge for plastic multiplier.")
         return st

@@ -24,6 +24,8 @@ from .interfaces import StressStrainConstraint
 from .utils import get_elastic_tangent, get_identity, lame_parameters
 
 __all__ = [
+    "DruckerPrager3D",
+    "DruckerPragerHyperbolic3D",
     "LinearElasticityModel",
     "VonMises3D",
     "SpringMaxwellModel",
@@ -175,6 +177,43 @@ class MisesPlasticityLinearHardening3D(DeviceLaw):
         super().__init__(
             [_scalar(parameters, k) for k in ("mu", "kappa", "y_0", "h")], StressStrainConstraint.FULL
         )
+
+    @property
+    def history_dim(self) -> dict[str, int]:
+        return {"history": 7}
+
+
+class DruckerPrager3D(DeviceLaw):
+    """comfe-rs classic Drucker-Prager plasticity (``f = sqrt(J2) + b I1 - a``) solved by the general
+    return mapping (reference: models/rust_models.py:97-118, comfe-rs/src/plasticity/general.rs,
+    drucker_prager_classic.rs).  History ``{"history": 7}`` = ``[alpha, plastic_strain(6)]``.
+
+    Args:
+        parameters: ``{"mu", "kappa", "a", "b", "b_flow"}`` as one-element arrays.
+    """
+
+    _model_id = _capi.COMFE_DRUCKER_PRAGER
+
+    def __init__(self, parameters: dict[str, np.ndarray]):
+        super().__init__([_scalar(parameters, k) for k in ("mu", "kappa", "a", "b", "b_flow")], StressStrainConstraint.FULL)
+
+    @property
+    def history_dim(self) -> dict[str, int]:
+        return {"history": 7}
+
+
+class DruckerPragerHyperbolic3D(DeviceLaw):
+    """comfe-rs hyperbolically smoothed Drucker-Prager plasticity (``f = sqrt(J2 + d^2) + b I1 - a``),
+    reference: models/rust_models.py:121-142, drucker_prager_hyperbolic.rs.
+
+    Args:
+        parameters: ``{"mu", "kappa", "a", "b", "d", "b_flow"}`` as one-element arrays.
+    """
+
+    _model_id = _capi.COMFE_DRUCKER_PRAGER_HYPERBOLIC
+
+    def __init__(self, parameters: dict[str, np.ndarray]):
+        super().__init__([_scalar(parameters, k) for k in ("mu", "kappa", "a", "b", "d", "b_flow")], StressStrainConstraint.FULL)
 
     @property
     def history_dim(self) -> dict[str, int]:

@@ -46,7 +46,9 @@ typedef enum fcamd_status {
     FCAMD_ERR_HIP = 5,           /* HIP runtime error (see fcamd_last_error) */
     FCAMD_ERR_BAD_ARG = 6,       /* null pointer, unknown model id, bad parameter count -> ValueError */
     FCAMD_ERR_ALIGN = 7,         /* device pointer not 16-byte aligned */
-    FCAMD_ERR_UNSUPPORTED = 8    /* constraint / layout not implemented -> NotImplementedError */
+    FCAMD_ERR_UNSUPPORTED = 8,   /* constraint / layout not implemented -> NotImplementedError */
+    FCAMD_ERR_DOMAIN = 9         /* a point left the law's domain: "non-differentiable tip of Drucker-Prager
+                                    surface reached" (assert!, drucker_prager_classic.rs:82) -> RuntimeError */
 } fcamd_status;
 
 /* ---- constitutive laws on the hot path ---------------------- */
@@ -67,7 +69,14 @@ typedef enum fcamd_model_id {
     FCAMD_COMFE_LINEAR_ELASTICITY = 5,
     /* comfe-rs MisesPlasticity3D (linear hardening) -- comfe-rs/src/mises_plasticity.rs:58-126.
        params[4]: mu, kappa, y_0, h.  history: "history"(7) = [alpha, plastic_strain(6)]. */
-    FCAMD_COMFE_MISES_PLASTICITY = 6
+    FCAMD_COMFE_MISES_PLASTICITY = 6,
+    /* comfe-rs IsotropicPlasticityModel3D<DruckerPrager3D> -- general return mapping
+       comfe-rs/src/plasticity/general.rs:105-266 with drucker_prager_classic.rs:62-116.
+       params[5]: mu, kappa, a, b, b_flow.  history: "history"(7) = [alpha, plastic_strain(6)]. */
+    FCAMD_COMFE_DRUCKER_PRAGER = 7,
+    /* ... <DruckerPragerHyperbolic3D> -- drucker_prager_hyperbolic.rs:64-114.
+       params[6]: mu, kappa, a, b, d, b_flow.  history as above. */
+    FCAMD_COMFE_DRUCKER_PRAGER_HYPERBOLIC = 8
 } fcamd_model_id;
 
 /* StressStrainConstraint values -- models/interfaces.py:14-28. Only FULL has kernels. */
@@ -89,7 +98,7 @@ typedef struct fcamd_stats {
     uint64_t n_nonconverged; /* points whose Newton iteration exceeded 100 steps */
     uint64_t n_plastic;      /* points that took the plastic branch */
     uint64_t n_newton_iters; /* total Newton iterations over all plastic points */
-    uint64_t reserved;
+    uint64_t n_domain;       /* points that left the law's domain (Drucker-Prager tip) */
 } fcamd_stats;
 
 /* ---- lifecycle --------------------------------------------------------------- */

@@ -1,0 +1,70 @@
+"""the comfe-rs general return mapping with the two Drucker-Prager surfaces on the GPU,
+against the NumPy restatement of comfe-rs/src/plasticity/general.rs (oracle/numpy_oracle.py).
+PARITY UNPINNED by the reference (no test exercises these laws, no Rust toolchain): the oracle itself
+is pinned by identities only (tests/test_oracle_golden.py::test_drucker_prager_identities)."""
+
+import numpy as np
+import pytest
+from golden_util import rel_err
+from test_oracle_golden import DP_H, DP_P, dp_inputs
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import fenics_constitutive_amd as fc  # noqa: E402
+from oracle import numpy_oracle as O  # noqa: E402
+
+
+def make(hyper):
+    p = DP_H if hyper else DP_P
+    cls = fc.DruckerPragerHyperbolic3D if hyper else fc.DruckerPrager3D
+    return cls({k: np.array([v]) for k, v in p.items()}), p
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 50_017])
+@pytest.mark.parametrize("hyper", [False, True])
+def test_drucker_prager_vs_oracle(hyper, n):
+    law, p = make(hyper)
+    assert law.history_dim == {"history": 7}
+    g, s0, h0 = dp_inputs(n, n + 7)
+    s_ref, t_ref, h_ref = s0.copy(), np.zeros(36 * n), {"history": h0["history"].copy()}
+    npl, _ = O.comfe_drucker_prager(p, 0, 1, g, s_ref, t_ref, h_ref, hyperbolic=hyper)
+    for path in ("host", "device"):
+        if path == "host":
+            s, t, h = s0.copy(), np.full(36 * n, np.nan), {"history": h0["history"].copy()}
+            law.evaluate(0.0, 1.0, g, s, t, h)
+            assert law.last_stats.n_plastic == npl
+            hh = h["history"]
+        else:
+            sd, td = torch.from_numpy(s0).cuda(), torch.full((36 * n,), float("nan"), dtype=torch.float64, device="cuda")
+            hd = {"history": torch.from_numpy(h0["history"]).cuda()}
+            law.evaluate(0.0, 1.0, torch.from_numpy(g).cuda(), sd, td, hd)
+            assert law.device_stats().n_plastic == npl
+            s, t, hh = sd.cpu().numpy(), td.cpu().numpy(), hd["history"].cpu().numpy()
+        assert not np.isnan(t).any()
+        assert rel_err(s, s_ref) <= 1e-6 and rel_err(t, t_ref) <= 1e-6 and rel_err(hh, h_ref["history"]) <= 1e-6, (path, n)
+        assert rel_err(s, s_ref) <= 1e-9 and rel_err(t, t_ref) <= 1e-7, ("strict", path, n)
+
+
+def test_all_elastic_and_out_of_place():
+    law, p = make(False)
+    n = 64 * 20 + 5
+    g, s0, h0 = dp_inputs(n, 5, smax=-4.0)
+    g *= 0.01
+    s_ref, t_ref, h_ref = s0.copy(), np.zeros(36 * n), {"history": h0["history"].copy()}
+    assert O.comfe_drucker_prager(p, 0, 1, g, s_ref, t_ref, h_ref)[0] == 0
+    sp, sc = torch.from_numpy(s0).cuda(), torch.zeros(6 * n, dtype=torch.float64, device="cuda")
+    td = torch.zeros(36 * n, dtype=torch.float64, device="cuda")
+    hp, hc = {"history": torch.from_numpy(h0["history"]).cuda()}, {"history": torch.zeros(7 * n, dtype=torch.float64, device="cuda")}
+    law.evaluate_from(0.0, 1.0, torch.from_numpy(g).cuda(), sp, sc, td, hp, hc)
+    assert law.device_stats().n_plastic == 0
+    assert rel_err(sc.cpu().numpy(), s_ref) <= 1e-12 and np.array_equal(td.cpu().numpy(), t_ref)
+    assert np.array_equal(hc["history"].cpu().numpy(), h0["history"])
+
+
+def test_tip_is_reported():
+    law, p = make(False)
+    g, s, h = dp_inputs(100, 1)
+    s.reshape(-1, 6)[37, :3] = 700.0  # i_1 = 2100 > a / b = 2000
+    with pytest.raises(RuntimeError, match="non-differentiable tip"):
+        law.evaluate(0.0, 1.0, g, s, np.zeros(3600), h)

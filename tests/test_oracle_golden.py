@@ -251,3 +251,78 @@ def test_constraints_golden():
         if h is not None:
             for k in h:
                 assert rel_err(h[k], c["hist_out"][k]) <= 1e-13
+
+
+# ---- f4: Drucker-Prager general return mapping (parity unpinned: identities only) -------------
+
+DP_P = {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02}
+DP_H = dict(DP_P, d=40.0)
+
+
+def dp_inputs(n, seed, smax=-2.3):
+    """Mostly isochoric strain increments on a compressive prestress: the trial states stay away from
+    the tip of the classic surface (i_1 < a / b) while 10-90 % of the points yield."""
+    rng = np.random.default_rng(seed)
+    g = (rng.normal(size=9 * n) * np.repeat(10 ** rng.uniform(-4, smax, size=n), 9)).reshape(-1, 9)
+    tr = g[:, [0, 4, 8]].sum(axis=1)
+    g[:, [0, 4, 8]] -= (0.95 * tr / 3.0)[:, None]
+    s = rng.normal(scale=50.0, size=6 * n)
+    s.reshape(-1, 6)[:, :3] -= 1000.0
+    h = rng.normal(scale=1e-4, size=7 * n)
+    h.reshape(-1, 7)[:, 0] = rng.uniform(0, 0.1, size=n)
+    return g.reshape(-1).copy(), s, {"history": h}
+
+
+@pytest.mark.parametrize("hyper", [False, True])
+def test_drucker_prager_identities(hyper):
+    p = DP_H if hyper else DP_P
+    n = 1500
+    g, s0, h0 = dp_inputs(n, 3)
+    s, t, h = s0.copy(), np.zeros(36 * n), {"history": h0["history"].copy()}
+    npl, nit = O.comfe_drucker_prager(p, 0, 1, g, s, t, h, hyperbolic=hyper)
+    assert 0.1 * n < npl < 0.9 * n and npl <= nit <= 8 * npl
+    f1, *_ = O._dp_state(p, hyper, s.reshape(-1, 6))
+    a1, a0 = h["history"].reshape(-1, 7)[:, 0], h0["history"].reshape(-1, 7)[:, 0]
+    pl = a1 != a0
+    assert pl.sum() == npl
+    # return mapping: plastic points end on the yield surface, elastic points inside
+    assert np.abs(f1[pl]).max() < 1e-7 and f1[~pl].max() <= 0.0
+    # elastic points: sigma = sigma_0 + E d_eps, tangent = E, history untouched
+    E = O.comfe_isotropic_elastic_tangent(p["mu"], p["kappa"])
+    de = O.strain_from_grad_u_full(g, O.F_RS).reshape(-1, 6)
+    assert np.allclose(s.reshape(-1, 6)[~pl], s0.reshape(-1, 6)[~pl] + de[~pl] @ E.T, rtol=1e-13, atol=1e-10)
+    assert np.array_equal(t.reshape(-1, 36)[~pl], np.tile(E.T.reshape(36), ((~pl).sum(), 1)))
+    assert np.array_equal(h["history"].reshape(-1, 7)[~pl], h0["history"].reshape(-1, 7)[~pl])
+    # plastic strain increment = d_eps - E^-1 (sigma_1 - sigma_0) points along the flow direction g
+    _, _, gdir, *_ = O._dp_state(p, hyper, s.reshape(-1, 6)[pl])
+    dep = (h["history"].reshape(-1, 7)[pl, 1:] - h0["history"].reshape(-1, 7)[pl, 1:])
+    cos = np.einsum("ij,ij->i", dep, gdir) / (np.linalg.norm(dep, axis=1) * np.linalg.norm(gdir, axis=1))
+    assert cos.min() > 1 - 1e-8
+    # kappa quirk kept as read: alpha_1 = alpha_0 + sqrt(2/3) |g|
+    assert np.allclose(a1[pl] - a0[pl], np.sqrt(2 / 3) * np.linalg.norm(gdir, axis=1), rtol=1e-7)
+    # consistent tangent = d sigma / d eps (central differences on three plastic points)
+    for i in np.nonzero(pl)[0][:3]:
+        T = t.reshape(-1, 36)[i].reshape(6, 6)
+        Tfd = np.zeros((6, 6))
+        for j in range(6):
+            for sgn in (1, -1):
+                gp = g[9 * i : 9 * i + 9].copy()
+                if j < 3:
+                    gp[[0, 4, 8][j]] += sgn * 1e-7
+                else:
+                    u, v = [(1, 3), (2, 6), (5, 7)][j - 3]
+                    gp[u] += sgn * 1e-7 / (2 * O.F_RS)
+                    gp[v] += sgn * 1e-7 / (2 * O.F_RS)
+                ss = s0[6 * i : 6 * i + 6].copy()
+                O.comfe_drucker_prager(p, 0, 1, gp, ss, np.zeros(36), {"history": h0["history"][7 * i : 7 * i + 7].copy()}, hyperbolic=hyper)
+                Tfd[:, j] += sgn * ss / 2e-7
+        assert np.abs(T - Tfd).max() / np.abs(T).max() < 1e-6
+
+
+def test_drucker_prager_tip_assertion():
+    g, s, h = dp_inputs(10, 1)
+    s.reshape(-1, 6)[3, :3] = 700.0  # i_1 = 2100 > a / b = 2000
+    with pytest.raises(O.DruckerPragerTip):
+        O.comfe_drucker_prager(DP_P, 0, 1, g, s, np.zeros(360), h)
+    # the hyperbolic surface has no tip assertion
+    O.comfe_drucker_prager(DP_H, 0, 1, g, s, np.zeros(360), h, hyperbolic=True)
