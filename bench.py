@@ -213,6 +213,8 @@ def main():
     ap.add_argument("--sparse-history", action="store_true",
                     help="VonMises3D: sparse trial-history protocol of device-resident Newton loops "
                          "(fcamd_evaluate_device_from_sparse); same results, elastic points cost no history traffic")
+    ap.add_argument("--gather-direct", action="store_true",
+                    help="N>1: also time the one-hop point-to-point gather (batched isend/irecv to all peers)")
     ap.add_argument("--gather-points", type=int, default=20_000_000,
                     help="points per rank of the separately timed stress/tangent all-gather (N>1)")
     args = ap.parse_args()
@@ -305,21 +307,46 @@ def main():
         out_t = torch.empty(36 * per * world, dtype=torch.float64, device=device)
         out_s[6 * per * rank : 6 * per * (rank + 1)].copy_(stress_t[: 6 * per])
         out_t[36 * per * rank : 36 * per * (rank + 1)].copy_(tangent[: 36 * per])
-        times = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            dist.barrier()
-            tg = time.perf_counter()
+        def time_gather(fn):
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                dist.barrier()
+                t_ = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                dt_ = time.perf_counter() - t_
+                best = dt_ if best is None else min(best, dt_)
+            tt_ = torch.tensor([best], dtype=torch.float64, device=device)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            return float(tt_.item())
+
+        def ring():
             dist.all_gather_into_tensor(out_s, out_s[6 * per * rank : 6 * per * (rank + 1)])
             dist.all_gather_into_tensor(out_t, out_t[36 * per * rank : 36 * per * (rank + 1)])
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - tg)
-        tg = torch.tensor([min(times)], dtype=torch.float64, device=device)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+
+        def direct():  # one-hop point-to-point transfers, all peers at once (sharded.allgather_direct)
+            for buf, dim in ((out_s, 6), (out_t, 36)):
+                mine = buf[dim * per * rank : dim * per * (rank + 1)]
+                ops = []
+                for shift in range(1, world):
+                    dst, src = (rank + shift) % world, (rank - shift) % world
+                    ops.append(dist.P2POp(dist.isend, mine, dst))
+                    ops.append(dist.P2POp(dist.irecv, buf[dim * per * src : dim * per * (src + 1)], src))
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+
         shard_bytes = 42 * 8 * per
-        gather = {"points_per_rank": per, "shard_GB": round(shard_bytes / 1e9, 3), "ms": round(float(tg.item()) * 1e3, 3),
-                  "recv_GBs_per_gpu": round(shard_bytes * (world - 1) / float(tg.item()) / 1e9, 1),
-                  "note": "in-place all_gather_into_tensor of stress+tangent, outside the timed steps"}
+        t_ring = time_gather(ring)
+        gather = {"points_per_rank": per, "shard_GB": round(shard_bytes / 1e9, 3),
+                  "rccl_all_gather_ms": round(t_ring * 1e3, 3),
+                  "rccl_all_gather_recv_GBs_per_gpu": round(shard_bytes * (world - 1) / t_ring / 1e9, 1),
+                  "note": "in-place all_gather_into_tensor of stress+tangent slices, outside the timed steps"}
+        if args.gather_direct:
+            t_direct = time_gather(direct)
+            gather["direct_p2p_ms"] = round(t_direct * 1e3, 3)
+            gather["direct_p2p_recv_GBs_per_gpu"] = round(shard_bytes * (world - 1) / t_direct / 1e9, 1)
         del out_s, out_t
 
     if rank == 0:

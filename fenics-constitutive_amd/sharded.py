@@ -83,20 +83,48 @@ class ShardedEvaluator:
         self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
         return gathered
 
+    def allgather_direct(self, local, gathered, dim: int):
+        """Same result as :meth:`allgather`, as one-hop point-to-point transfers: this rank's slice
+        is sent to every peer and every peer's slice is received straight into its slot, all in one
+        batched group (``batch_isend_irecv`` = one RCCL group call).  On a fully connected xGMI node
+        the 7 transfers of a rank use 7 different links at once, where a ring all-gather forwards
+        every slice 7 times over one link per step."""
+        per = dim * self.plan.per_rank
+        mine = gathered[per * self.rank : per * (self.rank + 1)]
+        if local.data_ptr() != mine.data_ptr():
+            mine[: local.numel()].copy_(local)
+        if self.world == 1:
+            return gathered
+        dist = self.dist
+        ops = []
+        for shift in range(1, self.world):  # staggered peers: rank r talks to r+shift / r-shift in step `shift`
+            dst = (self.rank + shift) % self.world
+            src = (self.rank - shift) % self.world
+            gdst = dst if self.group is None else dist.get_global_rank(self.group, dst)
+            gsrc = src if self.group is None else dist.get_global_rank(self.group, src)
+            ops.append(dist.P2POp(dist.isend, mine, gdst, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, gathered[per * src : per * (src + 1)], gsrc, group=self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return gathered
+
     def compact(self, gathered, dim: int):
         """View of the n valid points.  Every rank before the last non-empty one is full, so
         rank r's slot offset ``r * per_rank`` equals its global offset: the valid points are
         contiguous at the front of the gathered buffer."""
         return gathered[: dim * self.plan.n]
 
-    def evaluate_and_gather(self, t, del_t, grad_local, stress_gathered, tangent_gathered, history_local):
+    def evaluate_and_gather(self, t, del_t, grad_local, stress_gathered, tangent_gathered, history_local,
+                            direct: bool = False):
         """Evaluate directly into this rank's slice of the gathered buffers, then all-gather
-        both in place (no staging copy: sendbuf = recvbuf + rank*count)."""
+        both in place (no staging copy: sendbuf = recvbuf + rank*count).  ``direct`` selects the
+        one-hop point-to-point variant."""
         sd, td = 6, 36
         per = self.plan.per_rank
         s_mine = stress_gathered[sd * per * self.rank : sd * per * self.rank + sd * self.n_local]
         t_mine = tangent_gathered[td * per * self.rank : td * per * self.rank + td * self.n_local]
         self.evaluate_local(t, del_t, grad_local, s_mine, t_mine, history_local)
-        self.allgather(s_mine, stress_gathered, sd)
-        self.allgather(t_mine, tangent_gathered, td)
+        gather = self.allgather_direct if direct else self.allgather
+        gather(s_mine, stress_gathered, sd)
+        gather(t_mine, tangent_gathered, td)
         return self.compact(stress_gathered, sd), self.compact(tangent_gathered, td)

@@ -31,7 +31,7 @@ def make_inputs(n):
             {"eps_n": np.zeros(6 * n), "alpha": rng.uniform(0, 0.02, size=n)})
 
 
-def worker(rank, world, port, n, out_dir):
+def worker(rank, world, port, n, out_dir, direct=False):
     from fenics_constitutive_amd.sharded import ShardedEvaluator
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -48,7 +48,7 @@ def worker(rank, world, port, n, out_dir):
         hl = {"eps_n": torch.from_numpy(ev.local_view(h["eps_n"], 6).copy()),
               "alpha": torch.from_numpy(ev.local_view(h["alpha"], 1).copy())}
         gl = torch.from_numpy(ev.local_view(g, 9).copy())
-        s_all, t_all = ev.evaluate_and_gather(0.0, 1.0, gl, sg, tg, hl)
+        s_all, t_all = ev.evaluate_and_gather(0.0, 1.0, gl, sg, tg, hl, direct=direct)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), stress=s_all.numpy(), tangent=t_all.numpy(),
                  alpha=hl["alpha"].numpy(), lo=ev.lo, hi=ev.hi)
     finally:
@@ -61,10 +61,10 @@ def free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("world,direct", [(2, False), (2, True), (3, True)])
 @pytest.mark.parametrize("n", [1000, 128, 65])
-def test_sharded_equals_unsharded_world2(n, tmp_path):
-    world = 2
-    mp.spawn(worker, args=(world, free_port(), n, str(tmp_path)), nprocs=world, join=True)
+def test_sharded_equals_unsharded(n, world, direct, tmp_path):
+    mp.spawn(worker, args=(world, free_port(), n, str(tmp_path), direct), nprocs=world, join=True)
     g, s, h = make_inputs(n)
     t = np.zeros(36 * n)
     O.von_mises_3d(VM_P, 0.0, 1.0, g, s, t, h)
