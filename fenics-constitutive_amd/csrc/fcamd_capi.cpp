@@ -315,7 +315,11 @@ void fill_constants(const fcamd_model* m, double del_t, EvalArgs* a) {
             sc.s[8] = std::sqrt(2.0 / 3.0);
             sc.s[9] = 1.0 / (4.0 * mu);    // isotropic_elastic_tangent_inv, mandel.rs:130-141
             sc.s[10] = 1.0 / (9.0 * kappa);
-            for (int i = 0; i < 36; ++i) tb.c[i] = (2.0 * mu) * pdev[i] + (3.0 * kappa) * pvol[i];  // E (symmetric)
+            for (int i = 0; i < 36; ++i) {
+                tb.a[i] = soo[i];
+                tb.b[i] = pdev[i];
+                tb.c[i] = (2.0 * mu) * pdev[i] + (3.0 * kappa) * pvol[i];  // E (symmetric)
+            }
             break;
         }
     }

@@ -38,8 +38,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
-// wave-private LDS region: 64 points x 10 doubles (largest user: tangent parameters)
-constexpr int kRegionDoubles = 64 * 10;
+// wave-private LDS region: 64 points x 14 doubles (largest user: Drucker-Prager tangent parameters)
+constexpr int kRegionDoubles = 64 * 14;
 
 // ---------------------------------------------------------------------------------------
 // wave-level helpers
@@ -742,108 +742,79 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
 
 // --- comfe-rs general return mapping with the Drucker-Prager yield surfaces -------------------
 // Reference: comfe-rs/src/plasticity/general.rs:105-266 (Newton on sigma(6), lambda, kappa; maxit
-// 25, atol = rtol = 1e-8; consistent tangent from the inverse of the last Jacobian),
+// 25, atol = rtol = 1e-8; consistent tangent = (last Jacobian)^-1 [0:6,0:6] . E),
 // drucker_prager_classic.rs:62-116, drucker_prager_hyperbolic.rs:64-114.
-// The 8x8 Newton system of the reference has a zero kappa column in its first seven rows
-// (df/dkappa = dg/dkappa = 0 for both surfaces), so it is solved here as a 7x7 system for
-// (sigma, lambda) plus one back-substitution for kappa; the leading block is I + (SPD) and needs
-// no pivoting.  E.(dg/dsigma) = 2 mu (dg/dsigma) and E.g = 2 mu c1 s + 3 kappa b_flow 1 are used
-// as identities (dg/dsigma maps into the deviatoric space).  Quirks kept as read: the kappa
-// residual carries no del_lambda (alpha converges to alpha_0 + sqrt(2/3)|g|).
+//
+// The same Newton iteration in invariant coordinates.  Both surfaces are isotropic: g and df/dsigma
+// lie in span{1, s}, the Jacobian block I + 2 mu dl (c2 s s^T + c1 P_dev) maps that plane to itself,
+// and the iteration starts at sigma_tr -- so every iterate is sigma = (I1/3) 1 + rho s_tr and the
+// reference's 8 unknowns collapse, step for step, to (I1, rho, lambda, kappa):
+//     vol :  dv + 3 kappa b_flow dlam                   = rv      (sigma residual = rv 1 + rd s_tr)
+//     dev :  A_d dd + 2 mu c1 rho dlam                  = rd      A_d = 1 + w (c1 + c2 rho^2 |s_tr|^2)
+//     f   :  3 b dv + c1 rho |s_tr|^2 dd                = f
+//     kap :  dkap = res_k + dl (dk/dsigma . dsigma) + k dlam      (kappa column of rows 0..6 is zero)
+// with w = 2 mu dl.  Convergence tests use the same norms (|a 1 + c s_tr|^2 = 3 a^2 + c^2 |s_tr|^2).
+// The inverse of the bordered Jacobian is closed-form (Sherman-Morrison on the deviatoric block, Schur
+// complement for the f row), which makes the tangent a five-term isotropic form
+//     T = t11 1x1 + tP P_dev + tss s x s + t1s 1 x s + ts1 s x 1         (not symmetric if b != b_flow)
+// that the tile writes exactly like the Mises tangents: 11 doubles per point through LDS, every
+// lane rebuilding the two entries of the 16-byte chunk it stores.  The law is HBM-bound like the
+// others.  Quirk kept as read: the kappa residual carries no del_lambda (general.rs:222).
 // scalars: s[0]=strain factor, s[1]=mu, s[2]=kappa, s[3]=a, s[4]=b, s[5]=b_flow, s[6]=d*d,
-//          s[7]=2*mu, s[8]=sqrt(2/3), s[9]=1/(4 mu) , s[10]=1/(9 kappa)   tables: c = E (tangent)
-struct DPModel {
-    double f, k, c1, c2;
-    double s[6];  // deviator of sigma
+//          s[7]=2*mu, s[8]=sqrt(2/3), s[9]=1/(4 mu), s[10]=1/(9 kappa)
+// tables:  a = sym_id (x) sym_id, b = P_dev, c = E
+constexpr int kDpStride = 14;  // doubles per point of the published tangent parameters (conflict-free b128)
+
+struct DPInv {  // model state at (I1, rho)
+    double f, c1, c2, root;
 };
 
 template <bool HYPER>
-__device__ __forceinline__ void dp_state(const double (&sig)[6], double a_, double b, double dsq, DPModel& m,
-                                         bool& tip) {
-    const double i_1 = (sig[0] + sig[1]) + sig[2];
-    const double vol = i_1 / 3.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) m.s[i] = i < 3 ? sig[i] + (-vol) : sig[i];
-    double n2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) n2 = i == 0 ? m.s[0] * m.s[0] : n2 + m.s[i] * m.s[i];
-    const double j_2 = 0.5 * n2;
+__device__ __forceinline__ DPInv dp_state(double I1, double rho, double n2, double a_, double b, double dsq,
+                                          bool& tip) {
+    DPInv m;
+    const double j_2 = 0.5 * (rho * rho) * n2;
     if constexpr (HYPER) {
-        const double root = sqrt(j_2 + dsq);
-        m.f = root + b * i_1 - a_;
-        m.c1 = 0.5 * (1.0 / root);
-        m.c2 = -0.25 / ((j_2 + dsq) * root);
+        m.root = sqrt(j_2 + dsq);
+        m.c1 = 0.5 * (1.0 / m.root);
+        m.c2 = -0.25 / ((j_2 + dsq) * m.root);
     } else {
-        tip = tip || !(i_1 < a_ / b);
-        const double root = sqrt(j_2);
-        m.f = root + b * i_1 - a_;
-        m.c1 = 0.5 / root;
-        m.c2 = -0.25 / (j_2 * root);
+        tip = tip || !(I1 < a_ / b);
+        m.root = sqrt(j_2);
+        m.c1 = 0.5 / m.root;
+        m.c2 = -0.25 / (j_2 * m.root);
     }
+    m.f = m.root + b * I1 - a_;
+    return m;
 }
 
-// dg/dsigma (symmetric): (s_i c2) s_j + c1 P_dev[i][j]
-__device__ __forceinline__ double dp_dgs(const DPModel& m, int i, int j) {
-    const double pd = (i == j ? 1.0 : 0.0) - ((i < 3 && j < 3) ? (1.0 / 3.0) : 0.0);
-    return (m.s[i] * m.c2) * m.s[j] + m.c1 * pd;
-}
-
-// Fill the 7x7 Newton block M, the kappa row r[0..6] and k for the state m and multiplier dl.
-__device__ __forceinline__ void dp_newton_matrix(const DPModel& m, double dl, double b, double bflow, double two_mu,
-                                                 double kappa, double s23, double (&M)[7][7], double (&r)[7],
-                                                 double& k) {
-    double g[6];
+// T[i][j..j+1] for chunk q of the tile from the published parameters
+template <bool IDX, bool FULL, bool NT>
+__device__ __forceinline__ void tangent_dp(const double* tp, const double* t11tab, const double* pdtab,
+                                           double* tangent, long long p0, const int* rows_lds, int npts,
+                                           int lane) {
+    const int nchunks = npts * 18;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) g[i] = (i < 3 ? bflow : 0.0) + m.c1 * m.s[i];
-    double gn2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gn2 = i == 0 ? g[0] * g[0] : gn2 + g[i] * g[i];
-    const double gnorm = sqrt(gn2);
-    k = s23 * gnorm;
-    const double w = two_mu * dl;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) M[i][j] = (i == j ? 1.0 : 0.0) + w * dp_dgs(m, i, j);
-        M[i][6] = two_mu * (m.c1 * m.s[i]) + (i < 3 ? 3.0 * kappa * bflow : 0.0);  // E g
-        M[6][i] = (i < 3 ? b : 0.0) + m.c1 * m.s[i];                             // df/dsigma
-    }
-    M[6][6] = 0.0;
-    const double cg = s23 / gnorm;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        double acc = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc = i == 0 ? (cg * g[0]) * dp_dgs(m, 0, j) : acc + (cg * g[i]) * dp_dgs(m, i, j);
-        r[j] = (-dl) * acc;  // -del_lambda dk/dsigma
-    }
-    r[6] = -k;
-}
-
-// In-place LU of the 7x7 block without pivoting (L unit lower, U upper; see header comment).
-__device__ __forceinline__ void dp_lu7(double (&M)[7][7]) {
-#pragma unroll
-    for (int c = 0; c < 7; ++c) {
-        const double inv = 1.0 / M[c][c];
-#pragma unroll
-        for (int i = c + 1; i < 7; ++i) {
-            const double l = M[i][c] * inv;
-            M[i][c] = l;
-#pragma unroll
-            for (int j = c + 1; j < 7; ++j) M[i][j] = M[i][j] - l * M[c][j];
-        }
-    }
-}
-__device__ __forceinline__ void dp_solve7(const double (&M)[7][7], double (&x)[7]) {
-#pragma unroll
-    for (int i = 1; i < 7; ++i)
-#pragma unroll
-        for (int j = 0; j < i; ++j) x[i] = x[i] - M[i][j] * x[j];
-#pragma unroll
-    for (int i = 6; i >= 0; --i) {
-#pragma unroll
-        for (int j = i + 1; j < 7; ++j) x[i] = x[i] - M[i][j] * x[j];
-        x[i] = x[i] / M[i][i];
+    for (int k = 0; k < 18; ++k) {
+        const int q = k * kWave + lane;
+        const int p = q / 18;
+        const int r = q - 18 * p;
+        const int i = r / 3;
+        const int j = 2 * (r - 3 * i);
+        const double* t = tp + kDpStride * p;
+        const d2 c0 = reinterpret_cast<const d2*>(t)[0];  // t11, tP
+        const d2 c1 = reinterpret_cast<const d2*>(t)[1];  // tss, t1s
+        const double ts1 = t[4];
+        const double si = t[6 + i];
+        const d2 sj = *reinterpret_cast<const d2*>(t + 6 + j);
+        const d2 o = *reinterpret_cast<const d2*>(t11tab + 6 * i + j);  // (1 x 1)[i][j]
+        const d2 pd = *reinterpret_cast<const d2*>(pdtab + 6 * i + j);
+        const double oi = i < 3 ? 1.0 : 0.0;
+        d2 v;
+        v.x = (c0.x * o.x + c0.y * pd.x) + ((c1.x * si) * sj.x + (c1.y * oi) * sj.x + (ts1 * si) * (j < 3 ? 1.0 : 0.0));
+        v.y = (c0.x * o.y + c0.y * pd.y) + ((c1.x * si) * sj.y + (c1.y * oi) * sj.y + (ts1 * si) * (j + 1 < 3 ? 1.0 : 0.0));
+        if (FULL || q < nchunks) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -868,21 +839,25 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     const double kappa = a.sc.s[2], a_ = a.sc.s[3], b = a.sc.s[4], bflow = a.sc.s[5], dsq = a.sc.s[6],
                  two_mu = a.sc.s[7], s23 = a.sc.s[8], inv4mu = a.sc.s[9], inv9k = a.sc.s[10];
 
-    // sigma_tr = E d_eps + sigma_0  (E v = 2 mu dev v + kappa tr(v) 1)
-    double sig_tr[6], sig1[6];
+    // sigma_tr = E d_eps + sigma_0 = (I1_tr/3) 1 + s_tr      (E v = 2 mu dev v + kappa tr(v) 1)
+    double sig1[6], s_tr[6];
     {
         const double tr = (e[0] + e[1]) + e[2], vol = tr / 3.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
-            sig_tr[i] = (i < 3 ? two_mu * (e[i] + (-vol)) + kappa * tr : two_mu * e[i]) + sig0[i];
+            sig1[i] = (i < 3 ? two_mu * (e[i] + (-vol)) + kappa * tr : two_mu * e[i]) + sig0[i];
     }
-    DPModel m;
+    const double I1_tr = (sig1[0] + sig1[1]) + sig1[2];
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        s_tr[i] = i < 3 ? sig1[i] + (-(I1_tr / 3.0)) : sig1[i];
+        n2 = i == 0 ? s_tr[0] * s_tr[0] : n2 + s_tr[i] * s_tr[i];
+    }
     bool tip = false;
-    dp_state<HYPER>(sig_tr, a_, b, dsq, m, tip);
+    DPInv m = dp_state<HYPER>(I1_tr, 1.0, n2, a_, b, dsq, tip);
     const bool plastic = live && (m.f > 0.0);
     const unsigned long long mask = __ballot(plastic);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sig1[i] = sig_tr[i];
 
     if (mask == 0ull) {
         // fully elastic tile: stress = sigma_tr, tangent = E, history untouched
@@ -896,48 +871,43 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
         return;
     }
 
-    double M[7][7], r[7], kk = 0.0;
+    // tangent parameters: elastic lanes T = E = kappa 1x1 + 2 mu P_dev
+    double t11 = kappa, tP = two_mu, tss = 0.0, t1s = 0.0, ts1 = 0.0, rho = 1.0;
     if (plastic) {
         const double alpha_0 = h[0];
-        double alpha_1 = alpha_0, dl = 0.0;
-        double res[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, m.f};
-        double res_kappa = 0.0;
-        dp_newton_matrix(m, 0.0, b, bflow, two_mu, kappa, s23, M, r, kk);
+        double I1 = I1_tr, dl = 0.0, alpha_1 = alpha_0;
+        double rv = 0.0, rd = 0.0, rf = m.f, rk = 0.0;
         int it = 0;
         bool failed = false;
         for (;;) {
-            double x[7];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) x[i] = res[i];
-            dp_lu7(M);
-            dp_solve7(M, x);
-            double dk = res_kappa;  // kappa row: r . x + 1 * dk = res_kappa
-#pragma unroll
-            for (int j = 0; j < 7; ++j) dk = dk - r[j] * x[j];
-            double dsig2 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                sig1[i] = sig1[i] - x[i];
-                dsig2 = i == 0 ? x[0] * x[0] : dsig2 + x[i] * x[i];
-            }
-            const double dl_prev = dl, al_prev = alpha_1;
-            dl = dl - x[6];
-            alpha_1 = alpha_1 - dk;
-            dp_state<HYPER>(sig1, a_, b, dsq, m, tip);
-            dp_newton_matrix(m, dl, b, bflow, two_mu, kappa, s23, M, r, kk);
-            // residuals: sigma_1 - sigma_tr + dl E g ;  alpha_1 - alpha_0 - k ;  f
-            double rs2 = 0.0, s1n2 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                res[i] = (sig1[i] - sig_tr[i]) + dl * M[i][6];
-                rs2 = i == 0 ? res[0] * res[0] : rs2 + res[i] * res[i];
-                s1n2 = i == 0 ? sig1[0] * sig1[0] : s1n2 + sig1[i] * sig1[i];
-            }
-            res[6] = m.f;
-            res_kappa = (alpha_1 - alpha_0) - kk;
+            // Newton step with the Jacobian of the current state (m, rho, dl)
+            const double w = two_mu * dl;
+            const double Ad = 1.0 + w * (m.c1 + m.c2 * (rho * rho) * n2);
+            const double gn2 = 3.0 * (bflow * bflow) + (m.c1 * m.c1) * (rho * rho) * n2;
+            const double gnorm = sqrt(gn2), kk = s23 * gnorm;
+            const double cr = m.c1 * rho;  // coefficient of s_tr in g and df/dsigma
+            const double dlam = ((3.0 * b) * rv + (cr * n2) * (rd / Ad) - rf) /
+                                ((9.0 * kappa) * (b * bflow) + two_mu * (cr * cr) * n2 / Ad);
+            const double dv = rv - (3.0 * kappa * bflow) * dlam;
+            const double dd = (rd - (two_mu * cr) * dlam) / Ad;
+            const double dkds = (s23 / gnorm) * m.c1 * (m.c1 + m.c2 * (rho * rho) * n2) * rho * n2 * dd;
+            const double dkap = rk + dl * dkds + kk * dlam;
+            const double I1_prev = I1, rho_prev = rho, dl_prev = dl, al_prev = alpha_1;
+            I1 = I1 - 3.0 * dv;
+            rho = rho - dd;
+            dl = dl - dlam;
+            alpha_1 = alpha_1 - dkap;
+            m = dp_state<HYPER>(I1, rho, n2, a_, b, dsq, tip);
+            // residuals at the new state
+            const double gn2n = 3.0 * (bflow * bflow) + (m.c1 * m.c1) * (rho * rho) * n2;
+            rv = (I1 - I1_tr) / 3.0 + dl * (3.0 * kappa * bflow);
+            rd = (rho - 1.0) + dl * (two_mu * m.c1) * rho;
+            rf = m.f;
+            rk = (alpha_1 - alpha_0) - s23 * sqrt(gn2n);
             const double atol = 1e-8, rtol = 1e-8;
-            const bool conv_res = sqrt(rs2) < atol && fabs(res_kappa) < atol && fabs(m.f) < atol;
-            const bool conv_inc = sqrt(dsig2) < atol + rtol * sqrt(s1n2) &&
+            const double dI = (I1 - I1_prev) / 3.0, dr = rho - rho_prev;
+            const bool conv_res = sqrt(3.0 * rv * rv + rd * rd * n2) < atol && fabs(rk) < atol && fabs(rf) < atol;
+            const bool conv_inc = sqrt(3.0 * dI * dI + dr * dr * n2) < atol + rtol * sqrt(I1 * I1 / 3.0 + rho * rho * n2) &&
                                   fabs(alpha_1 - al_prev) < atol + rtol * fabs(alpha_1) &&
                                   fabs(dl - dl_prev) < atol + rtol * fabs(dl);
             if (conv_res || conv_inc) break;
@@ -949,7 +919,9 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
         }
         st.iters += (unsigned long long)(it + 1);
         st.nonconv += failed ? 1ull : 0ull;
-        // history: alpha ; plastic_strain += d_eps - E^-1 (sigma_1 - sigma_0)
+        // converged stress, history
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sig1[i] = (i < 3 ? I1 / 3.0 : 0.0) + rho * s_tr[i];
         h[0] = alpha_1;
         {
             double ds[6];
@@ -958,42 +930,25 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
             const double tr = (ds[0] + ds[1]) + ds[2], vol = tr / 3.0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                // E^-1 v = (1/(4 mu)) * 2 dev v + (1/(9 kappa)) * ... : isotropic_elastic_tangent(1/(4mu), 1/(9kappa))
+                // plastic_strain += d_eps - E^-1 (sigma_1 - sigma_0),  E^-1 = isotropic_elastic_tangent(1/(4 mu), 1/(9 kappa))
                 const double einv = i < 3 ? (2.0 * inv4mu) * (ds[i] + (-vol)) + (3.0 * inv9k) * vol : (2.0 * inv4mu) * ds[i];
                 h[1 + i] = h[1 + i] + (e[i] - einv);
             }
         }
-        // tangent = (dres^-1)[0:6,0:6] . E with dres = last Jacobian.  Column c of the inverse block X
-        // comes from one 7x7 solve; (X E)_ic = 2 mu X_ic + [c < 3] lam (X_i0 + X_i1 + X_i2).  Entries are
-        // stored as they are produced (8-byte stores into this point's own 288-byte row: this law is
-        // bound by FP64 issue, not by HBM), which keeps the register footprint at M plus three columns.
-        if (sb.tan) {
-            long long row = p0 + lane;
-            if constexpr (IDX) row = sr.row;
-            double* tp = sb.tan + row * 36;
-            dp_lu7(M);
-            double X3[3][6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double x[7];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) x[i] = i == c ? 1.0 : 0.0;
-                dp_solve7(M, x);
-                if (c < 3) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) X3[c][i] = x[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) tp[6 * i + c] = two_mu * x[i];
-                }
-            }
-            const double lam = kappa - two_mu / 3.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double rs = lam * ((X3[0][i] + X3[1][i]) + X3[2][i]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) tp[6 * i + c] = two_mu * X3[c][i] + rs;
-            }
+        // tangent from the inverse of the Jacobian at the final state (s = rho s_tr)
+        {
+            const double w = two_mu * dl, s2 = (rho * rho) * n2;
+            const double Ad = 1.0 + w * (m.c1 + m.c2 * s2);
+            const double alpha_d = 1.0 / (1.0 + w * m.c1);
+            const double beta = alpha_d * w * m.c2 / Ad;
+            const double uv = 3.0 * kappa * bflow, ud = two_mu * m.c1 / Ad;  // A^-1 E g       = uv 1 + ud s
+            const double vv = b, vd = m.c1 / Ad;                              // df/dsigma A^-1 = vv 1^T + vd s^T
+            const double D = 3.0 * vv * uv + vd * s2 * (two_mu * m.c1);
+            t11 = kappa - 3.0 * kappa * uv * vv / D;
+            tP = two_mu * alpha_d;
+            tss = -two_mu * beta - two_mu * ud * vd / D;
+            t1s = -two_mu * uv * vd / D;
+            ts1 = -3.0 * kappa * ud * vv / D;
         }
     }
     st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
@@ -1002,13 +957,24 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     sr.put(sb, region, lane, sig1, p0, npts);
     transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
 
-    // elastic lanes of a tile that has plastic points: tangent = E, written to their own row
-    if (sb.tan && live && !plastic) {
-        long long row = p0 + lane;
-        if constexpr (IDX) row = sr.row;
-        double* tp = sb.tan + row * 36;
+    if (sb.tan) {
+        double* t = region + kDpStride * lane;
+        d2 v;
+        v.x = t11, v.y = tP;
+        reinterpret_cast<d2*>(t)[0] = v;
+        v.x = tss, v.y = t1s;
+        reinterpret_cast<d2*>(t)[1] = v;
+        v.x = ts1, v.y = 0.0;
+        reinterpret_cast<d2*>(t)[2] = v;
 #pragma unroll
-        for (int q = 0; q < 18; ++q) store16<NT>(tp + 2 * q, reinterpret_cast<const d2*>(T->c)[q]);
+        for (int i = 0; i < 3; ++i) {
+            v.x = rho * s_tr[2 * i];
+            v.y = rho * s_tr[2 * i + 1];
+            reinterpret_cast<d2*>(t)[3 + i] = v;
+        }
+        wave_sync();
+        tangent_dp<IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane);
+        wave_sync();
     }
 }
 
@@ -1219,7 +1185,7 @@ __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& 
 // Main kernel: all full 64-point tiles.  Persistent: wave w of the grid takes tiles
 // w, w + W, w + 2W, ...
 template <int LAW, bool NT, bool IDX, bool SPARSE = false>
-__global__ void __launch_bounds__(kBlock, (LAW >= LAW_COMFE_DP ? 1 : 4)) evaluate_kernel(const EvalArgs a) {
+__global__ void __launch_bounds__(kBlock, (LAW >= LAW_COMFE_DP ? 3 : 4)) evaluate_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     __shared__ int rows_all[IDX ? kWavesPerBlock : 1][kWave];
