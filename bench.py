@@ -349,6 +349,24 @@ def main():
             gather["direct_p2p_recv_GBs_per_gpu"] = round(shard_bytes * (world - 1) / t_direct / 1e9, 1)
         del out_s, out_t
 
+    # "achievable" next to "peak" (SURVEY 8d): a plain device copy over half of the tangent array
+    # (read + write counted), after everything that still needs the arrays
+    copy_gbs = None
+    try:
+        half = (tangent.numel() // 2) & ~1
+        cs, ce = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = None
+        for _ in range(4):
+            cs.record()
+            tangent[:half].copy_(tangent[half : 2 * half])
+            ce.record()
+            ce.synchronize()
+            ms = cs.elapsed_time(ce)
+            best = ms if best is None else min(best, ms)
+        copy_gbs = 2 * 8 * half / (best * 1e-3) / 1e9
+    except Exception:  # the probe is informational only
+        copy_gbs = None
+
     if rank == 0:
         total_pts = n * world * args.steps
         value = total_pts / elapsed / 1e6
@@ -386,6 +404,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms_avg": round(kernel_avg_ms, 4), "kernel_ms_min": round(kernel_ms[0], 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic_GBs": None if traffic is None else round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1),
+                         "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
                          "bytes_per_point": {"elastic": b_el, "plastic": b_pl}},
         }
         if gather:
