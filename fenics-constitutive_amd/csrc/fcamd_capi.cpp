@@ -411,6 +411,54 @@ int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
     return FCAMD_OK;
 }
 
+// chunk slots of the host-staged entries: sizes the slots, creates the streams, returns the chunk
+// length.  Enough chunks in flight to keep both DMA directions busy.  Measured on MI355X / PCIe
+// gen5 (tools/host_path_bench.py): page-locked caller arrays like many small chunks in flight
+// (4 x 128 Ki points: 116 Mpts/s); pageable arrays are staged by the runtime and prefer large
+// chunks (512 Ki points: 93 Mpts/s).  FCAMD_HOST_CHUNK / FCAMD_HOST_SLOTS override (experiments).
+int prepare_chunks(fcamd_context* c, const void* probe_host_ptr, int64_t n, int64_t* chunk_out) {
+    {
+        const char* e = getenv("FCAMD_HOST_CHUNK");
+        const bool pinned = c->registered.count(const_cast<void*>(probe_host_ptr)) != 0;
+        c->chunk_points = e ? std::max<int64_t>(64, (atoll(e) / 64) * 64) : (pinned ? (1 << 17) : (1 << 19));
+        const char* sl = getenv("FCAMD_HOST_SLOTS");
+        if (sl) c->slots = std::min(fcamd_context::kSlots, std::max(1, atoi(sl)));
+    }
+    const int nslots = c->slots;
+    const int64_t chunk = std::min<int64_t>(c->chunk_points, ((n + 63) / 64) * 64);
+    if (chunk > 0 && ((size_t)chunk > c->dchunk_points || !c->dchunk[nslots - 1])) {
+        for (int i = 0; i < fcamd_context::kSlots; ++i) {
+            if (c->dchunk[i]) HIP_TRY(hipFree(c->dchunk[i]));
+            c->dchunk[i] = nullptr;
+        }
+        c->dchunk_points = 0;
+        for (int i = 0; i < nslots; ++i)
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dchunk[i]), (size_t)chunk * 66 * sizeof(double)));
+        c->dchunk_points = (size_t)chunk;
+    }
+    for (int i = 0; i < nslots; ++i)
+        if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
+    *chunk_out = chunk;
+    return FCAMD_OK;
+}
+
+// wait for all chunk streams, read the counters, map them to the reference's error conventions
+int finish_chunks(fcamd_model* m, fcamd_stats* stats) {
+    fcamd_context* c = m->ctx;
+    for (int i = 0; i < c->slots; ++i) HIP_TRY(hipStreamSynchronize(c->hstream[i]));
+    fcamd_stats local;
+    int st = read_stats(m, c->hstream[0], &local);
+    if (st != FCAMD_OK) return st;
+    if (stats) *stats = local;
+    if (local.n_domain > 0)
+        return fail(FCAMD_ERR_DOMAIN, "non-differentiable tip of Drucker-Prager surface reached");
+    if (local.n_nonconverged > 0)
+        return fail(FCAMD_ERR_NONCONVERGED,
+                    m->law >= FCAMD_COMFE_DRUCKER_PRAGER ? "Plasticity3D: Newton-Raphson did not converge."
+                                                         : "Newton-Raphson method did not converge for plastic multiplier.");
+    return FCAMD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -764,31 +812,10 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     HIP_TRY(hipSetDevice(c->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
 
-    // chunking: enough chunks in flight to keep both DMA directions busy.  Measured on MI355X / PCIe
-    // gen5 (tools/host_path_bench.py): page-locked caller arrays like many small chunks in flight
-    // (4 x 128 Ki points: 116 Mpts/s); pageable arrays are staged by the runtime and prefer large
-    // chunks (512 Ki points: 93 Mpts/s).  FCAMD_HOST_CHUNK / FCAMD_HOST_SLOTS override (experiments).
-    {
-        const char* e = getenv("FCAMD_HOST_CHUNK");
-        const bool pinned = c->registered.count(const_cast<double*>(grad)) != 0;
-        c->chunk_points = e ? std::max<int64_t>(64, (atoll(e) / 64) * 64) : (pinned ? (1 << 17) : (1 << 19));
-        const char* sl = getenv("FCAMD_HOST_SLOTS");
-        if (sl) c->slots = std::min(fcamd_context::kSlots, std::max(1, atoi(sl)));
-    }
+    int64_t chunk = 0;
+    st = prepare_chunks(c, grad, n, &chunk);
+    if (st != FCAMD_OK) return st;
     const int nslots = c->slots;
-    const int64_t chunk = std::min<int64_t>(c->chunk_points, ((n + 63) / 64) * 64);
-    if (chunk > 0 && ((size_t)chunk > c->dchunk_points || !c->dchunk[nslots - 1])) {
-        for (int i = 0; i < fcamd_context::kSlots; ++i) {
-            if (c->dchunk[i]) HIP_TRY(hipFree(c->dchunk[i]));
-            c->dchunk[i] = nullptr;
-        }
-        c->dchunk_points = 0;
-        for (int i = 0; i < nslots; ++i)
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dchunk[i]), (size_t)chunk * 66 * sizeof(double)));
-        c->dchunk_points = (size_t)chunk;
-    }
-    for (int i = 0; i < nslots; ++i)
-        if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
 
     HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
     HIP_TRY(hipStreamSynchronize(c->hstream[0]));
@@ -826,18 +853,65 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
             HIP_TRY(hipMemcpyAsync(hist[k] + d * p0, d_hist[k], (size_t)np * d * sizeof(double), hipMemcpyDeviceToHost, s));
         }
     }
-    for (int i = 0; i < nslots; ++i) HIP_TRY(hipStreamSynchronize(c->hstream[i]));
-    fcamd_stats local;
-    st = read_stats(m, c->hstream[0], &local);
+    return finish_chunks(m, stats);
+}
+
+int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
+                            const double* stress_prev, double* stress, const double* const* hist_prev,
+                            double* const* hist, int n_hist, uint64_t* history_mask,
+                            double* stress_host, double* tangent_host, fcamd_stats* stats) {
+    (void)t;
+    int st = validate_call(m, del_t, n, grad, stress_prev, stress,
+                           reinterpret_cast<const void* const*>(hist_prev),
+                           reinterpret_cast<const void* const*>(hist), n_hist);
     if (st != FCAMD_OK) return st;
-    if (stats) *stats = local;
-    if (local.n_domain > 0)
-        return fail(FCAMD_ERR_DOMAIN, "non-differentiable tip of Drucker-Prager surface reached");
-    if (local.n_nonconverged > 0)
-        return fail(FCAMD_ERR_NONCONVERGED,
-                    m->law >= FCAMD_COMFE_DRUCKER_PRAGER ? "Plasticity3D: Newton-Raphson did not converge."
-                                                         : "Newton-Raphson method did not converge for plastic multiplier.");
-    return FCAMD_OK;
+    if (history_mask && m->law != FCAMD_VON_MISES_3D)
+        return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for VonMises3D only");
+    if (!aligned16(stress) || !aligned16(stress_prev))
+        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
+    for (int k = 0; k < m->info.n_hist; ++k)
+        if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
+            return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
+    fcamd_context* c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the state arrays may have work queued on the caller's stream
+    int64_t chunk = 0;
+    st = prepare_chunks(c, grad, n, &chunk);
+    if (st != FCAMD_OK) return st;
+    const int nslots = c->slots;
+    HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
+    HIP_TRY(hipStreamSynchronize(c->hstream[0]));
+
+    const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
+    int slot = 0;
+    for (int64_t p0 = 0; p0 < n; p0 += chunk, slot = (slot + 1) % nslots) {
+        const int64_t np = std::min<int64_t>(chunk, n - p0);
+        hipStream_t s = c->hstream[slot];
+        double* d_grad = c->dchunk[slot];
+        double* d_tan = d_grad + 10 * c->dchunk_points;
+        // chunk offsets are multiples of 64 points: every sub-array stays 16-byte aligned and the
+        // per-tile mask words line up
+        const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+        double* hc[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+        for (int k = 0; k < m->info.n_hist; ++k) {
+            const size_t d = (size_t)m->info.hist[k].dim;
+            hp[k] = hist_prev[k] + d * p0;
+            hc[k] = hist[k] + d * p0;
+        }
+        HIP_TRY(hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
+        st = enqueue(m, del_t, np, d_grad, stress_prev + SD * p0, stress + SD * p0, tangent_host ? d_tan : nullptr,
+                     hp, hc, s, false, nullptr,
+                     history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr);
+        if (st != FCAMD_OK) return st;
+        if (stress_host)
+            HIP_TRY(hipMemcpyAsync(stress_host + SD * p0, stress + SD * p0, (size_t)np * SD * sizeof(double),
+                                   hipMemcpyDeviceToHost, s));
+        if (tangent_host)
+            HIP_TRY(hipMemcpyAsync(tangent_host + TD * p0, d_tan, (size_t)np * TD * sizeof(double),
+                                   hipMemcpyDeviceToHost, s));
+    }
+    return finish_chunks(m, stats);
 }
 
 }  // extern "C"

@@ -12,7 +12,11 @@ iterations of one increment only ``grad_del_u`` changes.
   ``fcamd_evaluate_device_from``); only ``grad`` crosses PCIe when it is a NumPy array;
 * ``update()``: the commit is a pointer swap -- no copy at all;
 * ``stress`` / ``tangent`` / ``history`` expose the trial state as device tensors (for a device
-  assembler) and ``download_*`` copy them into the caller's NumPy arrays (for dolfinx).
+  assembler);
+* ``evaluate_into(t, del_t, grad, stress_out, tangent_out)`` is the host assembler's call
+  (dolfinx): one chunk-pipelined pass (``fcamd_evaluate_resident``) uploads ``grad``, evaluates on
+  the resident state and streams stress and tangent into the caller's NumPy arrays while later
+  chunks are still in flight; no n-sized gradient or tangent array exists on the device.
 
 Per Newton iteration this moves 72 B/pt up and (if the host assembles) 336 B/pt down instead of
 176 + 392 B/pt, and removes every host-side state copy.
@@ -38,8 +42,8 @@ class ResidentState:
         gd2, sd = law.geometric_dim**2, law.stress_strain_dim
         self._gd2, self._sd = gd2, sd
         f = dict(dtype=torch.float64, device=self.device)
-        self.grad = torch.zeros(gd2 * n, **f)
-        self.tangent = torch.zeros(sd * sd * n, **f)
+        self._f = f
+        self._grad = self._tangent = None  # device-assembler mode only; allocated on first use
         self._stress = [torch.zeros(sd * n, **f), torch.zeros(sd * n, **f)]
         hd = law.history_dim
         self._hist = None if hd is None else [{k: torch.zeros(d * n, **f) for k, d in hd.items()} for _ in range(2)]
@@ -62,6 +66,22 @@ class ResidentState:
         import torch
 
         return a if _is_torch(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    @property
+    def grad(self):
+        if self._grad is None:
+            import torch
+
+            self._grad = torch.zeros(self._gd2 * self.n, **self._f)
+        return self._grad
+
+    @property
+    def tangent(self):
+        if self._tangent is None:
+            import torch
+
+            self._tangent = torch.zeros(self._sd * self._sd * self.n, **self._f)
+        return self._tangent
 
     # committed (previous) and trial (current) views -------------------------------------------
     @property
@@ -92,6 +112,38 @@ class ResidentState:
         self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, self.tangent,
                                self.history_committed, self.history, history_mask=self._mask)
         self._evaluated = True
+
+    def evaluate_into(self, t: float, del_t: float, grad_del_u: np.ndarray, stress: np.ndarray | None = None,
+                      tangent: np.ndarray | None = None):
+        """The host assembler's Newton-iteration call: trial state <- law(committed state,
+        grad_del_u) with ``grad_del_u`` a NumPy array, and the trial stress / tangent written into
+        the caller's NumPy arrays, all in one chunk-pipelined pass.  Synchronous; raises the
+        reference's exceptions (non-convergence) like the ndarray ``evaluate``.  Page-lock the
+        three arrays once (``Context.register_host_buffer``) for full PCIe rate."""
+        from . import _capi
+        from .device import _check_numpy
+
+        _check_numpy("grad_del_u", grad_del_u)
+        assert grad_del_u.size == self._gd2 * self.n, "grad_del_u has the wrong length"
+        if stress is not None:
+            _check_numpy("stress", stress)
+            assert stress.size == self._sd * self.n, "stress has the wrong length"
+        if tangent is not None:
+            _check_numpy("tangent", tangent)
+            assert tangent.size == self._sd * self._sd * self.n, "tangent has the wrong length"
+        dev = self.device.index or 0
+        m = self.law._handle(dev)
+        import torch
+
+        m.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        hp = [] if self._hist is None else [self.history_committed[k].data_ptr() for k, _ in m.history_fields]
+        hc = [] if self._hist is None else [self.history[k].data_ptr() for k, _ in m.history_fields]
+        self._evaluated = True  # the trial state is touched even if the call raises
+        self.law.last_stats = m.evaluate_resident(
+            t, del_t, self.n, grad_del_u.ctypes.data, self.stress_committed.data_ptr(), self.stress.data_ptr(),
+            hp, hc, None if self._mask is None else self._mask.data_ptr(),
+            None if stress is None else stress.ctypes.data, None if tangent is None else tangent.ctypes.data)
+        return self.law.last_stats
 
     def update(self) -> None:
         """Commit the trial state (``IncrSmallStrainProblem.update``, solver/_solver.py:149-159):

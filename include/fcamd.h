@@ -186,6 +186,24 @@ int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
                         const double* grad_del_u, double* stress, double* tangent,
                         double* const* history, int n_hist, fcamd_stats* stats);
 
+/* Resident-state evaluate for a host assembler (replaces the per-iteration copies of
+   solver/_lawonsubmesh.py:58-61,84-95 and solver/_history.py:64-79): the committed and trial
+   copies of stress and history are DEVICE arrays of n points (as in fcamd_evaluate_device_from,
+   committed is read, trial is written), while what must cross PCIe in every Newton iteration
+   stays on the host: `grad_del_u_host` (gd2*n) is uploaded chunk by chunk, each chunk is
+   evaluated on the device-resident state, and the chunk's trial stress and tangent are
+   downloaded into `stress_host` (sd*n) / `tangent_host` (sd*sd*n) while the next chunks are in
+   flight (either may be NULL).  The tangent never exists as an n-sized device array.  72 B/pt
+   up and 336 B/pt down instead of 176 + 392, and no host-side state copies.
+   `history_mask` (nullable) selects the sparse trial-history protocol of
+   fcamd_evaluate_device_from_sparse (VonMises3D).  Synchronous; waits for work queued on the
+   context stream before touching the state arrays.  Status and `stats` as fcamd_evaluate_host. */
+int fcamd_evaluate_resident(fcamd_model* model, double t, double del_t, int64_t n,
+                            const double* grad_del_u_host, const double* stress_prev,
+                            double* stress, const double* const* history_prev,
+                            double* const* history, int n_hist, uint64_t* history_mask,
+                            double* stress_host, double* tangent_host, fcamd_stats* stats);
+
 /* Mandel strain from displacement gradient, FULL (utils.py:132-151,187-208).
    rust_factor = 0: factor 1/2**0.5 (Python); 1: FRAC_1_SQRT_2 (mandel.rs:147). */
 int fcamd_strain_from_grad_u_device(fcamd_context* ctx, int64_t n, const double* grad_u,

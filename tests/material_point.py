@@ -101,22 +101,27 @@ class HostState:
 class ResidentAdapter:
     """The engine's device-resident state behind the same four calls."""
 
-    def __init__(self, law, n):
+    def __init__(self, law, n, host_assembler=False):
         from fenics_constitutive_amd.resident import ResidentState
 
         self.rs, self.n = ResidentState(law, n), n
         self.sd = law.stress_strain_dim
         self._s, self._t = np.zeros(self.sd * n), np.zeros(self.sd * self.sd * n)
+        self.host_assembler = host_assembler  # True: the pipelined fcamd_evaluate_resident pass
 
     def evaluate(self, t, del_t, grad):
-        self.rs.evaluate(t, del_t, grad)
+        if self.host_assembler:
+            self.rs.evaluate_into(t, del_t, grad, self._s, self._t)
+        else:
+            self.rs.evaluate(t, del_t, grad)
 
     def update(self):
         self.rs.check()
         self.rs.update()
 
     def fetch(self):
-        self.rs.download(self._s, self._t)
+        if not self.host_assembler:
+            self.rs.download(self._s, self._t)
         return self._s.reshape(self.n, self.sd), self._t.reshape(self.n, self.sd, self.sd)
 
     def history_of(self, key):

@@ -1,7 +1,8 @@
 """The reference's FE-level model assertions on the HIP path (through the model classes and the C
 ABI): the same material-point scenarios as tests/test_material_point_oracle.py, once with NumPy
 arrays through the in-place host path (the unchanged solver's call protocol) and once with the
-device-resident committed/trial state (ResidentState, pointer-swap commit)."""
+device-resident committed/trial state (ResidentState, pointer-swap commit; device tensors, and
+the host assembler's pipelined ``evaluate_into``)."""
 
 import numpy as np
 import pytest
@@ -36,13 +37,13 @@ def make_law(kind, params, constraint):
 def builder(mode):
     def build(kind, params, constraint, n):
         law = make_law(kind, params, constraint)
-        state = HostState(law, n) if mode == "host" else ResidentAdapter(law, n)
+        state = HostState(law, n) if mode == "host" else ResidentAdapter(law, n, host_assembler=(mode == "resident_host"))
         return MaterialPoints(state, constraint, tol=1e-11)
 
     return build
 
 
-MODES = ["host", "resident"]
+MODES = ["host", "resident", "resident_host"]
 
 
 @pytest.mark.parametrize("mode", MODES)

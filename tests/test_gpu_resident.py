@@ -89,3 +89,49 @@ def test_sparse_history_equals_full_history(n):
         sp.check()
         sp.update()
         fu.update()
+
+
+@pytest.mark.parametrize("chunk", [None, "128"])
+def test_evaluate_into_replays_golden_sequence(chunk, monkeypatch):
+    """fcamd_evaluate_resident: NumPy grad in, NumPy stress/tangent out, state on the device;
+    with a 128-point chunk the 1000+ points go through many chunks and all four slots."""
+    if chunk:
+        monkeypatch.setenv("FCAMD_HOST_CHUNK", chunk)
+    calls = {c.name: c for c in load_calls("von_mises_3d.npz")}
+    c0 = calls["mixed_step0_iter0"]
+    law = fc.VonMises3D(c0.params)
+    st = ResidentState(law, c0.n, stress0=c0.stress_in, history0=c0.hist_in)
+    s, t = np.empty(6 * c0.n), np.empty(36 * c0.n)
+    for k in range(4):
+        for it in (0, 1):
+            c = calls[f"mixed_step{k}_iter{it}"]
+            stats = st.evaluate_into(0.0, c.del_t, c.grad, s, t)
+            assert rel_err(s, c.stress_out) <= 1e-11 and rel_err(t, c.tangent_out) <= 1e-6
+            for key in c.hist_out:
+                assert rel_err(st.history[key].cpu().numpy(), c.hist_out[key]) <= 1e-6
+            assert np.array_equal(st.stress_committed.cpu().numpy(), c.stress_in)
+            assert stats.n_plastic > 0
+        st.update()
+    assert st._grad is None and st._tangent is None  # no n-sized gradient / tangent on the device
+
+
+def test_evaluate_into_equals_device_evaluate_sls():
+    calls = {c.name: c for c in load_calls("spring_kelvin.npz")}
+    c0 = calls["step0_iter0"]
+    law = fc.SpringKelvinModel(c0.params, FULL)
+    a = ResidentState(law, c0.n, stress0=c0.stress_in, history0=c0.hist_in)
+    b = ResidentState(law, c0.n, stress0=c0.stress_in, history0=c0.hist_in)
+    s, t = np.empty(6 * c0.n), np.empty(36 * c0.n)
+    for k in range(5):
+        c = calls[f"step{k}_iter1"]
+        a.evaluate(0.0, c.del_t, c.grad)
+        b.evaluate_into(0.0, c.del_t, c.grad, s, t)
+        assert np.array_equal(a.stress.cpu().numpy(), s) and np.array_equal(a.tangent.cpu().numpy(), t)
+        for key in a.history:
+            assert np.array_equal(a.history[key].cpu().numpy(), b.history[key].cpu().numpy())
+        a.update()
+        b.update()
+    with pytest.raises(AssertionError):
+        b.evaluate_into(0.0, 1.0, c.grad[:-9], s, t)
+    with pytest.raises(AssertionError):  # SLS: del_t must be positive
+        b.evaluate_into(0.0, 0.0, c.grad, s, t)

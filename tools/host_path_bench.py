@@ -44,8 +44,35 @@ def run(n, register):
             "GB_s_pcie": round(n * 568 / best / 1e9, 2)}
 
 
+def run_resident(n, register):
+    """ResidentState.evaluate_into: grad up, stress + tangent down, state on the device."""
+    from fenics_constitutive_amd.resident import ResidentState
+
+    rng = np.random.default_rng(0)
+    law = fc.VonMises3D(VM_P)
+    g = rng.normal(size=9 * n) * np.repeat(10 ** rng.uniform(-4, -2, size=n), 9)
+    s, t = np.zeros(6 * n), np.zeros(36 * n)
+    st = ResidentState(law, n, history0={"eps_n": np.zeros(6 * n), "alpha": rng.uniform(0, 0.02, size=n)})
+    ctx = law._handle(0).ctx
+    if register:
+        for a in (g, s, t):
+            ctx.register_host_buffer(a)
+    times = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        st.evaluate_into(0.0, 1.0, g, s, t)
+        times.append(time.perf_counter() - t0)
+    if register:
+        for a in (g, s, t):
+            ctx.unregister_host_buffer(a)
+    best = min(times[1:])
+    return {"path": "resident", "n": n, "registered": register, "ms": round(best * 1e3, 2),
+            "Mpts_s": round(n / best / 1e6, 1), "GB_s_pcie": round(n * 408 / best / 1e9, 2)}
+
+
 if __name__ == "__main__":
     ns = (10_000_000,) if "--big" in sys.argv else (1_000_000, 10_000_000)
     for n in ns:
         for reg in (False, True):
             print(json.dumps(run(n, reg)), flush=True)
+            print(json.dumps(run_resident(n, reg)), flush=True)
