@@ -36,13 +36,16 @@ LE_P = {"E": 42.0, "nu": 0.3}
 # workload -> (law kind, strain scale spec, bytes/pt elastic, bytes/pt plastic, history dims)
 WORKLOADS = {
     "von_mises_mixed": ("von_mises_3d", "loguniform", 464, 568),
+    # the same 22 % of plastic points, but in contiguous zones of 4096 points (what a mesh-ordered
+    # plastic zone looks like) instead of a random mixture in every 64-point tile
+    "von_mises_zoned": ("von_mises_3d", "zoned", 464, 568),
     "von_mises_plastic": ("von_mises_3d", 1e-2, 464, 568),
     "von_mises_elastic": ("von_mises_3d", 1e-4, 464, 568),
     "linear_elasticity": ("linear_elasticity", 1e-3, 456, 456),
     "spring_maxwell": ("spring_maxwell", 1e-3, 648, 648),
     "spring_kelvin": ("spring_kelvin", 1e-3, 648, 648),
     "comfe_mises_mixed": ("comfe_mises_plasticity", "loguniform", 464, 568),
-    # general return mapping (7x7 Newton per plastic point), bound by FP64 issue rather than HBM
+    # general return mapping (Newton per plastic point, invariant coordinates)
     "drucker_prager_mixed": ("comfe_drucker_prager", "isochoric", 464, 568),
 }
 DP_P = {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02}
@@ -81,6 +84,12 @@ def synth_inputs(kind, scale_spec, n, seed, device):
         g = torch.randn(9 * n, dtype=torch.float64, device=device, generator=gen)
         if scale_spec == "loguniform":
             sc = torch.pow(10.0, torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 2.0 - 4.0)
+            g.view(n, 9).mul_(sc[:, None])
+        elif scale_spec == "zoned":
+            zone = 4096
+            nz = (n + zone - 1) // zone
+            pl = torch.rand(nz, dtype=torch.float64, device=device, generator=gen) < 0.22
+            sc = torch.where(pl, 1e-2, 1e-4).to(torch.float64).repeat_interleave(zone)[:n]
             g.view(n, 9).mul_(sc[:, None])
         elif scale_spec == "isochoric":
             # Drucker-Prager: mostly isochoric increments, scale log-uniform in [1e-4, 5e-3] (keeps the
