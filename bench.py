@@ -47,6 +47,8 @@ WORKLOADS = {
     "comfe_mises_mixed": ("comfe_mises_plasticity", "loguniform", 464, 568),
     # general return mapping (Newton per plastic point, invariant coordinates)
     "drucker_prager_mixed": ("comfe_drucker_prager", "isochoric", 464, 568),
+    "drucker_prager_zoned": ("comfe_drucker_prager", "isochoric_zoned", 464, 568),
+    "comfe_mises_zoned": ("comfe_mises_plasticity", "zoned", 464, 568),
 }
 DP_P = {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02}
 
@@ -91,10 +93,16 @@ def synth_inputs(kind, scale_spec, n, seed, device):
             pl = torch.rand(nz, dtype=torch.float64, device=device, generator=gen) < 0.22
             sc = torch.where(pl, 1e-2, 1e-4).to(torch.float64).repeat_interleave(zone)[:n]
             g.view(n, 9).mul_(sc[:, None])
-        elif scale_spec == "isochoric":
+        elif scale_spec in ("isochoric", "isochoric_zoned"):
             # Drucker-Prager: mostly isochoric increments, scale log-uniform in [1e-4, 5e-3] (keeps the
-            # trial states away from the tip of the classic surface)
-            sc = torch.pow(10.0, torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 1.7 - 4.0)
+            # trial states away from the tip of the classic surface); zoned: 4096-point zones, 22 % of
+            # them at 5e-3, the others at 1e-4
+            if scale_spec == "isochoric":
+                sc = torch.pow(10.0, torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 1.7 - 4.0)
+            else:
+                zone = 4096
+                pl = torch.rand((n + zone - 1) // zone, dtype=torch.float64, device=device, generator=gen) < 0.22
+                sc = torch.where(pl, 5e-3, 1e-4).to(torch.float64).repeat_interleave(zone)[:n]
             gv = g.view(n, 9)
             gv.mul_(sc[:, None])
             tr = (gv[:, 0] + gv[:, 4] + gv[:, 8]) * (0.95 / 3.0)
@@ -269,7 +277,8 @@ def main():
 
     hmask = None
     if args.sparse_history:
-        assert kind == "von_mises_3d", "--sparse-history is a VonMises3D protocol"
+        assert kind in ("von_mises_3d", "comfe_mises_plasticity", "comfe_drucker_prager"), \
+            "--sparse-history is a protocol of the plasticity laws"
         for k in hist_c:
             hist_t[k].copy_(hist_c[k])  # contract: trial == committed where the mask is clear
         hmask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)

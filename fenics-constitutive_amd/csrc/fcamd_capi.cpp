@@ -325,6 +325,9 @@ void fill_constants(const fcamd_model* m, double del_t, EvalArgs* a) {
     }
 }
 
+// laws whose history changes only at plastic points (elastic points keep theirs bit for bit)
+bool has_sparse_history(int law) { return law == FCAMD_VON_MISES_3D || law >= FCAMD_COMFE_MISES_PLASTICITY; }
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* grad,
@@ -680,8 +683,8 @@ int fcamd_evaluate_device_from_sparse(fcamd_model* m, double t, double del_t, in
                            reinterpret_cast<const void* const*>(hist_prev),
                            reinterpret_cast<const void* const*>(hist), n_hist);
     if (st != FCAMD_OK) return st;
-    if (m->law != FCAMD_VON_MISES_3D)
-        return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for VonMises3D only");
+    if (!has_sparse_history(m->law))
+        return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
     if (n > 0 && !history_mask) return fail(FCAMD_ERR_BAD_ARG, "history_mask is NULL");
     if (!aligned16(grad) || !aligned16(stress) || !aligned16(stress_prev) || !aligned16(tangent))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
@@ -865,8 +868,8 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
                            reinterpret_cast<const void* const*>(hist_prev),
                            reinterpret_cast<const void* const*>(hist), n_hist);
     if (st != FCAMD_OK) return st;
-    if (history_mask && m->law != FCAMD_VON_MISES_3D)
-        return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for VonMises3D only");
+    if (history_mask && !has_sparse_history(m->law))
+        return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
     if (!aligned16(stress) || !aligned16(stress_prev))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
     for (int k = 0; k < m->info.n_hist; ++k)

@@ -650,6 +650,21 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     }
 }
 
+// History write policy of the laws with one [alpha, eps_p(6)] row per point (comfe-rs Mises and
+// Drucker-Prager).  In place: only tiles with a plastic point change.  Out of place: every tile is
+// copied -- unless the caller runs the sparse trial-history protocol (a.hmask != nullptr, see
+// tile_von_mises): the trial array equals the committed one wherever the tile's mask word is clear,
+// so a tile is written only if it has a plastic point now (new values) or had one at the previous
+// evaluate (stale rows: the whole-tile write restores them).  The 56-byte rows share their DRAM
+// sectors with their neighbours, so the granularity is the tile, not the row.
+__device__ __forceinline__ bool history_tile_needs_write(const EvalArgs& a, long long p0, unsigned long long mask,
+                                                         bool hist_in_place, int lane) {
+    if (a.hmask == nullptr) return mask != 0ull || !hist_in_place;
+    const unsigned long long m_old = a.hmask[p0 >> 6];
+    if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
+    return (mask | m_old) != 0ull;
+}
+
 // --- comfe-rs MisesPlasticity3D: linear hardening, closed-form radial return ---------------
 // scalars: s[0]=strain factor (FRAC_1_SQRT_2), s[1]=mu, s[2]=kappa, s[3]=y_0, s[4]=h,
 //          s[5]=2*mu, s[6]=3*mu+h, s[7]=sqrt(3/2), s[8]=3*mu, s[9]=1/(1+h/(3 mu))
@@ -726,7 +741,7 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
         s[i] = i < 3 ? p_1 + ts : ts;
     }
     sr.put(sb, region, lane, s, p0, npts);
-    if (mask != 0ull || !hist_in_place)
+    if (history_tile_needs_write(a, p0, mask, hist_in_place, lane))
         transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
 
     if (sb.tan) {
@@ -862,7 +877,8 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     if (mask == 0ull) {
         // fully elastic tile: stress = sigma_tr, tangent = E, history untouched
         sr.put(sb, region, lane, sig1, p0, npts);
-        if (!hist_in_place) transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+        if (history_tile_needs_write(a, p0, 0ull, hist_in_place, lane))
+            transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
         if (sb.tan) {
             if constexpr (IDX) wave_sync();
             tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
@@ -955,6 +971,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     st.domain += (live && tip) ? 1ull : 0ull;  // tip of the classic surface reached (reference: assert!)
 
     sr.put(sb, region, lane, sig1, p0, npts);
+    (void)history_tile_needs_write(a, p0, mask, hist_in_place, lane);  // records the mask; this tile is written
     transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
 
     if (sb.tan) {

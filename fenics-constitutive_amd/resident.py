@@ -54,11 +54,12 @@ class ResidentState:
             for k in self._hist[0]:
                 self._hist[0][k].copy_(self._as_dev(history0[k]))
                 self._hist[1][k].copy_(self._hist[0][k])  # trial == committed (sparse-history contract)
-        # VonMises3D: sparse trial history (fcamd_evaluate_device_from_sparse).  Elastic points keep
+        # Plasticity laws: sparse trial history (fcamd_evaluate_device_from_sparse).  Elastic points keep
         # their history, so only plastic / formerly plastic points are written; the mask (one word
         # per 64-point tile) survives the pointer swap of update().
         self._mask = None
-        if sparse_history and type(law).__name__ == "VonMises3D":
+        if sparse_history and type(law).__name__ in ("VonMises3D", "MisesPlasticityLinearHardening3D",
+                                                     "DruckerPrager3D", "DruckerPragerHyperbolic3D"):
             self._mask = torch.zeros((self.n + 63) // 64, dtype=torch.int64, device=self.device)
         self._evaluated = False
 

@@ -146,7 +146,9 @@ int fcamd_evaluate_device_from(fcamd_model* model, double t, double del_t, int64
                                int n_hist);
 
 /* Sparse-trial-history form of fcamd_evaluate_device_from for device-resident Newton loops
-   (VonMises3D).  Contract: on entry the trial history arrays equal the committed ones except at
+   (the plasticity laws: VonMises3D per point; the comfe-rs Mises and Drucker-Prager laws, whose
+   history is one 7-double row per point, per 64-point tile: a tile is written when it has or had
+   a plastic point).  Contract: on entry the trial history arrays equal the committed ones except at
    the points whose bit is set in `history_mask` (one uint64 per 64-point tile, bit l = point
    64*tile + l; all zero initially).  On return the trial history is exactly what
    fcamd_evaluate_device_from would have written -- but only plastic points (new value) and
@@ -196,7 +198,7 @@ int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
    flight (either may be NULL).  The tangent never exists as an n-sized device array.  72 B/pt
    up and 336 B/pt down instead of 176 + 392, and no host-side state copies.
    `history_mask` (nullable) selects the sparse trial-history protocol of
-   fcamd_evaluate_device_from_sparse (VonMises3D).  Synchronous; waits for work queued on the
+   fcamd_evaluate_device_from_sparse (plasticity laws).  Synchronous; waits for work queued on the
    context stream before touching the state arrays.  Status and `stats` as fcamd_evaluate_host. */
 int fcamd_evaluate_resident(fcamd_model* model, double t, double del_t, int64_t n,
                             const double* grad_del_u_host, const double* stress_prev,

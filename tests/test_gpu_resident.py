@@ -63,32 +63,72 @@ def test_update_without_evaluate_raises():
     st.update()
 
 
+def _sparse_case(law_name, n, rng):
+    """(law, stress0, history0, grad generator) with plastic sets that vary from call to call."""
+    if law_name == "VonMises3D":
+        law = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
+        s0 = rng.normal(scale=30.0, size=6 * n)
+        h0 = {"eps_n": rng.normal(scale=1e-3, size=6 * n), "alpha": rng.uniform(0, 0.02, size=n)}
+    else:
+        h = rng.normal(scale=1e-3, size=7 * n)
+        h.reshape(-1, 7)[:, 0] = rng.uniform(0, 0.02, size=n)
+        h0 = {"history": h}
+        if law_name == "MisesPlasticityLinearHardening3D":
+            law = fc.MisesPlasticityLinearHardening3D(
+                {k: np.array([v]) for k, v in {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0}.items()})
+            s0 = rng.normal(scale=30.0, size=6 * n)
+        else:
+            p = {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02}
+            if law_name == "DruckerPragerHyperbolic3D":
+                p = {"mu": p["mu"], "kappa": p["kappa"], "a": p["a"], "b": p["b"], "d": 40.0, "b_flow": p["b_flow"]}
+            law = getattr(fc, law_name)({k: np.array([v]) for k, v in p.items()})
+            s0 = rng.normal(scale=30.0, size=6 * n)
+            s0.reshape(-1, 6)[:, :3] -= 1000.0  # compressive prestress keeps the classic surface off its tip
+
+    hi = -2.3 if law_name.startswith("Drucker") else -1.6  # log10 of the largest strain scale
+
+    def grad(all_elastic, zoned):
+        # random per-point scale (every tile mixed) or plastic zones of 256 points (many tiles all elastic)
+        if zoned:
+            scale = np.repeat(10 ** rng.uniform(hi - 3.2, hi, size=(n + 255) // 256), 256)[:n]
+        else:
+            scale = 10 ** rng.uniform(hi - 2.7, hi, size=n)
+        g = (rng.normal(size=9 * n) * np.repeat(scale * (0.0 if all_elastic else 1.0), 9)).reshape(-1, 9)
+        if law_name.startswith("Drucker"):
+            g[:, [0, 4, 8]] -= (0.95 * g[:, [0, 4, 8]].sum(axis=1) / 3.0)[:, None]  # mostly isochoric
+        return torch.from_numpy(g.reshape(-1).copy()).cuda()
+
+    return law, s0, h0, grad
+
+
+@pytest.mark.parametrize("law_name", ["VonMises3D", "MisesPlasticityLinearHardening3D", "DruckerPrager3D",
+                                      "DruckerPragerHyperbolic3D"])
 @pytest.mark.parametrize("n", [64 * 40 + 17, 5000])
-def test_sparse_history_equals_full_history(n):
-    """The sparse trial-history protocol (only plastic / formerly plastic points touch eps_n) must give
-    the same trial state as the full out-of-place evaluate at every Newton iteration of every
-    increment, with plastic sets that grow, shrink and move, across pointer-swap commits."""
+def test_sparse_history_equals_full_history(n, law_name):
+    """The sparse trial-history protocol (VonMises3D: only plastic / formerly plastic points touch
+    eps_n; comfe-rs laws: only tiles with such points are written) must give the same trial state as
+    the full out-of-place evaluate at every Newton iteration of every increment, with plastic sets
+    that grow, shrink and move, across pointer-swap commits."""
     rng = np.random.default_rng(n)
-    law = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
-    s0 = rng.normal(scale=30.0, size=6 * n)
-    h0 = {"eps_n": rng.normal(scale=1e-3, size=6 * n), "alpha": rng.uniform(0, 0.02, size=n)}
+    law, s0, h0, grad = _sparse_case(law_name, n, rng)
     sp = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=True)
     fu = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False)
     assert sp._mask is not None and fu._mask is None
+    n_plastic = []
     for inc in range(5):
         for it in range(3):
-            # very different plastic sets from call to call: random per-point scale, some calls all elastic
-            scale = 10 ** rng.uniform(-5, -2, size=n) * (0.0 if (inc == 2 and it == 1) else 1.0)
-            g = torch.from_numpy(rng.normal(size=9 * n) * np.repeat(scale, 9)).cuda()
+            g = grad(all_elastic=(inc == 2 and it == 1), zoned=(inc % 2 == 1))
             sp.evaluate(0.0, 1.0, g)
             fu.evaluate(0.0, 1.0, g)
+            n_plastic.append(int(law.device_stats().n_plastic))
             assert torch.equal(sp.stress, fu.stress) and torch.equal(sp.tangent, fu.tangent)
-            for k in ("eps_n", "alpha"):
+            for k in h0:
                 assert torch.equal(sp.history[k], fu.history[k]), (inc, it, k)
                 assert torch.equal(sp.history_committed[k], fu.history_committed[k]), (inc, it, k)
         sp.check()
         sp.update()
         fu.update()
+    assert max(n_plastic) > 0.1 * n and min(n_plastic) < 0.5 * max(n_plastic)  # the sets really changed
 
 
 @pytest.mark.parametrize("chunk", [None, "128"])
