@@ -32,7 +32,8 @@ __all__ = ["ResidentState"]
 
 
 class ResidentState:
-    def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True):
+    def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
+                 reuse_constant_tangent: bool = True):
         import torch
 
         self.law, self.n = law, int(n)
@@ -62,6 +63,16 @@ class ResidentState:
                                                      "DruckerPrager3D", "DruckerPragerHyperbolic3D"):
             self._mask = torch.zeros((self.n + 63) // 64, dtype=torch.int64, device=self.device)
         self._evaluated = False
+        # Linear elasticity and the SLS laws have one tangent for all points, a function of the
+        # parameters (and del_t) only -- the reference tiles it into the array on every call
+        # (linear_elasticity_model.py:45, spring_maxwell_model.py:84-86, spring_kelvin_model.py:85-86).
+        # The device tangent array is owned by this object, so once it holds the tangent of a given
+        # del_t it is not rewritten: 288 of the 456 / 648 bytes per point disappear from every further
+        # Newton iteration and increment.  (Writing into ``.tangent`` from outside voids this: pass
+        # reuse_constant_tangent=False then.)
+        self._const_tangent = reuse_constant_tangent and type(law).__name__ in (
+            "LinearElasticityModel", "LinearElasticity3D", "SpringMaxwellModel", "SpringKelvinModel")
+        self._tangent_key = None  # del_t for which the tangent array is valid
 
     def _as_dev(self, a):
         import torch
@@ -110,7 +121,13 @@ class ResidentState:
             self.grad.copy_(self._as_dev(g), non_blocking=True)
             g = self.grad
         assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
-        self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, self.tangent,
+        tangent = self.tangent
+        if self._const_tangent:
+            key = float(del_t) if type(self.law).__name__.startswith("Spring") else 0.0
+            if self._tangent_key == key:
+                tangent = None  # already holds exactly what this launch would write
+            self._tangent_key = key
+        self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, tangent,
                                self.history_committed, self.history, history_mask=self._mask)
         self._evaluated = True
 
@@ -119,7 +136,9 @@ class ResidentState:
         """The host assembler's Newton-iteration call: trial state <- law(committed state,
         grad_del_u) with ``grad_del_u`` a NumPy array, and the trial stress / tangent written into
         the caller's NumPy arrays, all in one chunk-pipelined pass.  Synchronous; raises the
-        reference's exceptions (non-convergence) like the ndarray ``evaluate``.  Page-lock the
+        reference's exceptions (non-convergence) like the ndarray ``evaluate``.  For the laws
+        with a point-independent tangent (linear elasticity, SLS at a fixed ``del_t``) the caller may
+        pass ``tangent`` once and ``None`` afterwards: 288 of the 336 downloaded bytes per point.  Page-lock the
         three arrays once (``Context.register_host_buffer``) for full PCIe rate."""
         from . import _capi
         from .device import _check_numpy

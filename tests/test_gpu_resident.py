@@ -175,3 +175,31 @@ def test_evaluate_into_equals_device_evaluate_sls():
         b.evaluate_into(0.0, 1.0, c.grad[:-9], s, t)
     with pytest.raises(AssertionError):  # SLS: del_t must be positive
         b.evaluate_into(0.0, 0.0, c.grad, s, t)
+
+
+@pytest.mark.parametrize("cls", ["LinearElasticityModel", "SpringKelvinModel", "SpringMaxwellModel"])
+def test_constant_tangent_is_written_once_per_del_t(cls):
+    """LE / SLS: the device tangent array keeps the (point-independent) tangent of the current del_t
+    and is not rewritten; results are bit-identical to the state that rewrites it every call."""
+    n = 64 * 9 + 5
+    rng = np.random.default_rng(5)
+    params = {"E": 42.0, "nu": 0.3} if cls == "LinearElasticityModel" else {"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}
+    law = getattr(fc, cls)(params, FULL)
+    a = ResidentState(law, n)
+    b = ResidentState(law, n, reuse_constant_tangent=False)
+    assert a._const_tangent and not b._const_tangent
+    for k, dt in enumerate([2.0, 2.0, 2.0, 0.5, 0.5, 2.0]):
+        g = rng.normal(scale=1e-3, size=9 * n)
+        a.evaluate(0.0, dt, g)
+        b.evaluate(0.0, dt, g)
+        assert torch.equal(a.stress, b.stress) and torch.equal(a.tangent, b.tangent), (k, dt)
+        if k == 1:  # the second call with the same del_t must not have touched the array
+            a.tangent[:36].fill_(-1.0)
+            a.evaluate(0.0, dt, g)
+            assert bool((a.tangent[:36] == -1.0).all())
+            a._tangent_key = None  # invalidate: the next call rewrites it
+        a.update()
+        b.update()
+    # the plasticity laws never skip
+    vm = ResidentState(fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}), n)
+    assert not vm._const_tangent
