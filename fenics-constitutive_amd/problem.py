@@ -1,0 +1,156 @@
+"""Device-resident counterpart of the state that ``IncrSmallStrainProblem`` keeps around the hot
+path (SURVEY 8f-1 + 8f-2 together): several laws on disjoint sets of quadrature points of one mesh.
+
+What the reference does on the host for every Newton iteration (``solver/_solver.py:130-147``,
+``solver/_lawonsubmesh.py:72-95``): for each law, gather the committed stress of its cells from the
+global array (``SubSpaceMap.map_to_sub``), reset its trial history, evaluate, scatter stress and
+tangent back into the global arrays (``map_to_parent``, ``solver/maps.py:82-123``); and on
+``update()`` (``solver/_solver.py:149-159``) copy trial -> committed for the stress and every
+history.  Here the global ("parent") stress pair and tangent and every law's history pair live on
+the GPU; one fused launch per law does gather + evaluate + scatter
+(``fcamd_evaluate_device_indexed``), and the commit swaps pointers.
+
+Names follow the reference's backward-compatibility properties (``stress_0``, ``stress_1``,
+``_history_0``, ``_history_1``, ``_time``, ``_del_t``; ``solver/_solver.py:165-219``).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .device import DeviceLaw, _is_torch
+
+__all__ = ["ResidentProblemState", "rows_of_cells"]
+
+
+def rows_of_cells(cells: np.ndarray, points_per_cell: int) -> np.ndarray:
+    """Quadrature-point rows of a set of cells: the dofs of the reference's quadrature spaces are
+    numbered cell by cell (``solver/maps.py:43-79`` builds exactly this map)."""
+    cells = np.asarray(cells, dtype=np.int64)
+    return (cells[:, None] * points_per_cell + np.arange(points_per_cell)[None, :]).reshape(-1).astype(np.int32)
+
+
+class _LawState:
+    def __init__(self, law, rows, n, f, device):
+        import torch
+
+        self.law, self.n = law, n
+        self.rows = None if rows is None else torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(device)
+        hd = law.history_dim
+        self.hist = None if hd is None else [{k: torch.zeros(d * n, **f) for k, d in hd.items()} for _ in range(2)]
+        self.grad = None  # staging buffer for NumPy gradients
+
+
+class ResidentProblemState:
+    """``laws``: one ``DeviceLaw`` (covers all ``n_points``) or a list of ``(law, rows)`` with
+    ``rows`` the quadrature-point rows of that law in the parent arrays (disjoint; see
+    ``rows_of_cells``).  All laws are FULL 3-D, as the fused indexed kernel requires."""
+
+    def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None):
+        import torch
+
+        from . import _capi
+
+        self.device = torch.device("cuda", _capi.default_device()) if device is None else torch.device(device)
+        self.n = int(n_points)
+        f = dict(dtype=torch.float64, device=self.device)
+        self._f = f
+        if isinstance(laws, DeviceLaw):
+            laws = [(laws, None)]
+        self._laws = []
+        covered = np.zeros(self.n, dtype=np.int64)
+        for law, rows in laws:
+            assert law.constraint.name == "FULL", "ResidentProblemState: FULL 3-D laws only"
+            if rows is None:
+                assert len(laws) == 1, "rows=None (all points) is for a single law"
+                n_k = self.n
+                covered += 1
+            else:
+                rows = np.asarray(rows)
+                n_k = rows.size
+                assert rows.min(initial=0) >= 0 and rows.max(initial=-1) < self.n, "row out of range"
+                np.add.at(covered, rows, 1)
+            self._laws.append(_LawState(law, rows, n_k, f, self.device))
+        assert covered.max(initial=0) <= 1, "a quadrature point belongs to more than one law"
+        self._stress = [torch.zeros(6 * self.n, **f), torch.zeros(6 * self.n, **f)]
+        self.tangent = torch.zeros(36 * self.n, **f)
+        self._c = 0
+        self._time, self._del_t = 0.0, float(del_t)
+        self._evaluated = False
+
+    # reference-compatible views ----------------------------------------------------------------------
+    @property
+    def stress_0(self):
+        """Committed stress (``IncrementalStress.previous``)."""
+        return self._stress[self._c]
+
+    @property
+    def stress_1(self):
+        """Trial stress (``IncrementalStress.current``)."""
+        return self._stress[1 - self._c]
+
+    @property
+    def _history_0(self):
+        return [None if ls.hist is None else ls.hist[self._c] for ls in self._laws]
+
+    @property
+    def _history_1(self):
+        return [None if ls.hist is None else ls.hist[1 - self._c] for ls in self._laws]
+
+    def set_state(self, stress=None, history=None) -> None:
+        """Initial committed state: parent stress (6 n) and a list of per-law history dicts."""
+        import torch
+
+        if stress is not None:
+            self.stress_0.copy_(stress if _is_torch(stress) else torch.from_numpy(np.ascontiguousarray(stress)).to(self.device))
+        if history is not None:
+            for ls, h in zip(self._laws, history):
+                if ls.hist is None:
+                    continue
+                for k in ls.hist[self._c]:
+                    v = h[k]
+                    ls.hist[self._c][k].copy_(v if _is_torch(v) else torch.from_numpy(np.ascontiguousarray(v)).to(self.device))
+
+    # the Newton-iteration call (IncrSmallStrainProblem.form, solver/_solver.py:130-147) ------------------
+    def evaluate(self, grads) -> None:
+        """``grads``: one local ``grad_del_u`` array per law (9 n_k; NumPy or device tensor), what
+        ``evaluate_local_incremental_gradient`` fills for the law's cells."""
+        import torch
+
+        if not isinstance(grads, (list, tuple)):
+            grads = [grads]
+        assert len(grads) == len(self._laws), "one gradient array per law"
+        for ls, g in zip(self._laws, grads):
+            if not _is_torch(g):
+                if ls.grad is None:
+                    ls.grad = torch.empty(9 * ls.n, **self._f)
+                ls.grad.copy_(torch.from_numpy(np.ascontiguousarray(g, dtype=np.float64)), non_blocking=True)
+                g = ls.grad
+            hp = None if ls.hist is None else ls.hist[self._c]
+            hc = None if ls.hist is None else ls.hist[1 - self._c]
+            if ls.rows is None:
+                ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, self.tangent, hp, hc)
+            else:
+                ls.law.evaluate_indexed(self._time, self._del_t, g, self.stress_0, self.stress_1, self.tangent,
+                                        ls.rows, hp, hc)
+        self._evaluated = True
+
+    def check(self) -> None:
+        """Synchronise; raises the reference's exceptions (Newton non-convergence) per law."""
+        dev = self.device.index or 0
+        for ls in self._laws:
+            ls.law.device_stats(dev)
+
+    # the commit (IncrSmallStrainProblem.update, solver/_solver.py:149-159) -------------------------------
+    def update(self) -> None:
+        if not self._evaluated:
+            raise RuntimeError("update() before any evaluate() of this increment")
+        self._c = 1 - self._c  # stress and every history: trial becomes committed
+        self._time += self._del_t
+        self._evaluated = False
+
+    def download(self, stress: np.ndarray | None = None, tangent: np.ndarray | None = None) -> None:
+        if stress is not None:
+            stress[:] = self.stress_1.cpu().numpy()
+        if tangent is not None:
+            tangent[:] = self.tangent.cpu().numpy()
