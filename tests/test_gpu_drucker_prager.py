@@ -68,3 +68,26 @@ def test_tip_is_reported():
     s.reshape(-1, 6)[37, :3] = 700.0  # i_1 = 2100 > a / b = 2000
     with pytest.raises(RuntimeError, match="non-differentiable tip"):
         law.evaluate(0.0, 1.0, g, s, np.zeros(3600), h)
+
+
+def test_hyperbolic_hydrostatic_states():
+    """Purely hydrostatic trial states (|s_tr| = 0), also beyond the apex of the classic cone
+    (i_1 > a / b): the smoothed surface returns along the hydrostatic axis; the invariant-coordinate
+    kernel must follow the 8x8 Newton of the oracle there too."""
+    law, p = make(True)
+    n = 64 * 3 + 9
+    i1 = np.linspace(-600.0, 3000.0, n)  # f_tr > 0 from i_1 = 1200 on
+    s0 = np.zeros((n, 6))
+    s0[:, :3] = (i1 / 3.0)[:, None]
+    g = np.zeros((n, 9))
+    g[:, [0, 4, 8]] = np.linspace(-1e-4, 3e-4, n)[:, None]
+    g[::7, 1] = 1e-9  # a few points with a minute deviatoric part
+    h0 = {"history": np.zeros(7 * n)}
+    s_ref, t_ref, h_ref = s0.reshape(-1).copy(), np.zeros(36 * n), {"history": h0["history"].copy()}
+    npl, _ = O.comfe_drucker_prager(p, 0, 1, g.reshape(-1), s_ref, t_ref, h_ref, hyperbolic=True)
+    assert 0.3 * n < npl < 0.8 * n
+    s, t, h = s0.reshape(-1).copy(), np.full(36 * n, np.nan), {"history": h0["history"].copy()}
+    law.evaluate(0.0, 1.0, g.reshape(-1), s, t, h)
+    assert law.last_stats.n_plastic == npl
+    assert not np.isnan(t).any() and not np.isnan(s).any()
+    assert rel_err(s, s_ref) <= 1e-9 and rel_err(t, t_ref) <= 1e-7 and rel_err(h["history"], h_ref["history"]) <= 1e-6
