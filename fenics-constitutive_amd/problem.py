@@ -39,6 +39,12 @@ class _LawState:
         hd = law.history_dim
         self.hist = None if hd is None else [{k: torch.zeros(d * n, **f) for k, d in hd.items()} for _ in range(2)]
         self.grad = None  # staging buffer for NumPy gradients
+        # LE / SLS: the law's tangent rows are point-independent and change only with del_t; the
+        # parent tangent array is owned by the problem state, so they are written once per del_t
+        # (see ResidentState)
+        self.const_tangent = type(law).__name__ in ("LinearElasticityModel", "LinearElasticity3D",
+                                                    "SpringMaxwellModel", "SpringKelvinModel")
+        self.tangent_key = None
 
 
 class ResidentProblemState:
@@ -46,7 +52,7 @@ class ResidentProblemState:
     ``rows`` the quadrature-point rows of that law in the parent arrays (disjoint; see
     ``rows_of_cells``).  All laws are FULL 3-D, as the fused indexed kernel requires."""
 
-    def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None):
+    def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None, reuse_constant_tangent: bool = True):
         import torch
 
         from . import _capi
@@ -77,6 +83,7 @@ class ResidentProblemState:
         self._c = 0
         self._time, self._del_t = 0.0, float(del_t)
         self._evaluated = False
+        self.reuse_constant_tangent = reuse_constant_tangent
 
     # reference-compatible views ----------------------------------------------------------------------
     @property
@@ -128,10 +135,16 @@ class ResidentProblemState:
                 g = ls.grad
             hp = None if ls.hist is None else ls.hist[self._c]
             hc = None if ls.hist is None else ls.hist[1 - self._c]
+            tangent = self.tangent
+            if ls.const_tangent and self.reuse_constant_tangent:
+                key = self._del_t if type(ls.law).__name__.startswith("Spring") else 0.0
+                if ls.tangent_key == key:
+                    tangent = None
+                ls.tangent_key = key
             if ls.rows is None:
-                ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, self.tangent, hp, hc)
+                ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent, hp, hc)
             else:
-                ls.law.evaluate_indexed(self._time, self._del_t, g, self.stress_0, self.stress_1, self.tangent,
+                ls.law.evaluate_indexed(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent,
                                         ls.rows, hp, hc)
         self._evaluated = True
 

@@ -59,6 +59,8 @@ def test_three_materials_replay_reference_protocol(layout):
         st.update()
         stress_0, hist_0 = stress_1, hist_1
         assert st._time == pytest.approx((inc + 1) * del_t)
+    # the LE and Maxwell rows of the tangent were written once (del_t never changed), VonMises3D's every time
+    assert [ls.tangent_key for ls in st._laws] == [0.0, None, del_t]
     s_out, t_out = np.empty(6 * n), np.empty(36 * n)
     st.evaluate(grads)
     st.download(s_out, t_out)
