@@ -698,6 +698,29 @@ int fcamd_evaluate_device_from_sparse(fcamd_model* m, double t, double del_t, in
                    reinterpret_cast<unsigned long long*>(history_mask));
 }
 
+int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, const fcamd_eval_args* x) {
+    (void)t;
+    if (!x) return fail(FCAMD_ERR_BAD_ARG, "args is NULL");
+    int st = validate_call(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress,
+                           reinterpret_cast<const void* const*>(x->history_prev),
+                           reinterpret_cast<const void* const*>(x->history), x->n_hist);
+    if (st != FCAMD_OK) return st;
+    if (x->parent_rows && m->constraint != FCAMD_FULL)
+        return fail(FCAMD_ERR_UNSUPPORTED, "the indexed form exists for StressStrainConstraint.FULL only");
+    if (x->history_mask && !has_sparse_history(m->law))
+        return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
+    if (!aligned16(x->grad_del_u) || !aligned16(x->stress) || !aligned16(x->stress_prev) || !aligned16(x->tangent))
+        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
+    for (int k = 0; k < m->info.n_hist; ++k)
+        if (!aligned16(x->history[k]) || !aligned16(x->history_prev[k]))
+            return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
+    fcamd_context* c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    m->timed = false;
+    return enqueue(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history,
+                   c->stream, true, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask));
+}
+
 int fcamd_evaluate_device(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
                           double* stress, double* tangent, double* const* hist, int n_hist) {
     return fcamd_evaluate_device_from(m, t, del_t, n, grad, stress, stress, tangent,

@@ -202,7 +202,7 @@ class DeviceLaw(IncrSmallStrainModel):
             [h.data_ptr() for h in hist], history_mask.data_ptr())
 
     def evaluate_indexed(self, t, del_t, grad_del_u, stress_prev_parent, stress_parent, tangent_parent,
-                         parent_rows, history_prev, history) -> None:
+                         parent_rows, history_prev, history, history_mask=None) -> None:
         """Multi-material form: this law owns ``n = len(parent_rows)`` points whose stress/tangent
         rows live in PARENT arrays at ``parent_rows`` (int32 device tensor).  Reads the committed
         stress from ``stress_prev_parent`` rows, writes stress and tangent into the parent rows;
@@ -224,10 +224,17 @@ class DeviceLaw(IncrSmallStrainModel):
         dev = grad_del_u.device.index or 0
         m = self._handle(dev)
         m.ctx.set_stream(_current_stream_ptr(dev))
-        m.evaluate_device_indexed(
-            t, del_t, n, grad_del_u.data_ptr(), stress_prev_parent.data_ptr(), stress_parent.data_ptr(),
-            None if tangent_parent is None else _check_torch("tangent", tangent_parent).data_ptr(),
-            parent_rows.data_ptr(), [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist])
+        tan_ptr = None if tangent_parent is None else _check_torch("tangent", tangent_parent).data_ptr()
+        if history_mask is None:
+            m.evaluate_device_indexed(
+                t, del_t, n, grad_del_u.data_ptr(), stress_prev_parent.data_ptr(), stress_parent.data_ptr(),
+                tan_ptr, parent_rows.data_ptr(), [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist])
+            return
+        # sparse trial history on a submesh (fcamd_evaluate_device_ex): mask and history are local to the law
+        assert history_mask.dtype == torch.int64 and history_mask.is_cuda and history_mask.numel() >= (n + 63) // 64
+        m.evaluate_device_ex(
+            t, del_t, n, grad_del_u.data_ptr(), stress_prev_parent.data_ptr(), stress_parent.data_ptr(), tan_ptr,
+            [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist], parent_rows.data_ptr(), history_mask.data_ptr())
 
     def device_stats(self, device: int = 0):
         """Synchronise and return the counters of the last device-path launch; raises

@@ -31,7 +31,7 @@ def rows_of_cells(cells: np.ndarray, points_per_cell: int) -> np.ndarray:
 
 
 class _LawState:
-    def __init__(self, law, rows, n, f, device):
+    def __init__(self, law, rows, n, f, device, sparse_history):
         import torch
 
         self.law, self.n = law, n
@@ -45,6 +45,11 @@ class _LawState:
         self.const_tangent = type(law).__name__ in ("LinearElasticityModel", "LinearElasticity3D",
                                                     "SpringMaxwellModel", "SpringKelvinModel")
         self.tangent_key = None
+        # plasticity laws: sparse trial history (see ResidentState); the mask survives the pointer swap
+        self.mask = None
+        if sparse_history and type(law).__name__ in ("VonMises3D", "MisesPlasticityLinearHardening3D",
+                                                     "DruckerPrager3D", "DruckerPragerHyperbolic3D"):
+            self.mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
 
 
 class ResidentProblemState:
@@ -52,7 +57,8 @@ class ResidentProblemState:
     ``rows`` the quadrature-point rows of that law in the parent arrays (disjoint; see
     ``rows_of_cells``).  All laws are FULL 3-D, as the fused indexed kernel requires."""
 
-    def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None, reuse_constant_tangent: bool = True):
+    def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None, reuse_constant_tangent: bool = True,
+                 sparse_history: bool = True):
         import torch
 
         from . import _capi
@@ -76,7 +82,7 @@ class ResidentProblemState:
                 n_k = rows.size
                 assert rows.min(initial=0) >= 0 and rows.max(initial=-1) < self.n, "row out of range"
                 np.add.at(covered, rows, 1)
-            self._laws.append(_LawState(law, rows, n_k, f, self.device))
+            self._laws.append(_LawState(law, rows, n_k, f, self.device, sparse_history))
         assert covered.max(initial=0) <= 1, "a quadrature point belongs to more than one law"
         self._stress = [torch.zeros(6 * self.n, **f), torch.zeros(6 * self.n, **f)]
         self.tangent = torch.zeros(36 * self.n, **f)
@@ -117,6 +123,9 @@ class ResidentProblemState:
                 for k in ls.hist[self._c]:
                     v = h[k]
                     ls.hist[self._c][k].copy_(v if _is_torch(v) else torch.from_numpy(np.ascontiguousarray(v)).to(self.device))
+                    ls.hist[1 - self._c][k].copy_(ls.hist[self._c][k])  # trial == committed (sparse-history contract)
+                if ls.mask is not None:
+                    ls.mask.zero_()
 
     # the Newton-iteration call (IncrSmallStrainProblem.form, solver/_solver.py:130-147) ------------------
     def evaluate(self, grads) -> None:
@@ -142,10 +151,11 @@ class ResidentProblemState:
                     tangent = None
                 ls.tangent_key = key
             if ls.rows is None:
-                ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent, hp, hc)
+                ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent, hp, hc,
+                                     history_mask=ls.mask)
             else:
                 ls.law.evaluate_indexed(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent,
-                                        ls.rows, hp, hc)
+                                        ls.rows, hp, hc, history_mask=ls.mask)
         self._evaluated = True
 
     def check(self) -> None:

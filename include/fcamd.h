@@ -177,6 +177,24 @@ int fcamd_evaluate_device_indexed(fcamd_model* model, double t, double del_t, in
                                   const double* const* history_prev, double* const* history,
                                   int n_hist);
 
+/* General device entry: every option of the forms above in one call.  `parent_rows` (nullable)
+   selects the submesh-indexed addressing of stress / tangent, `history_mask` (nullable) the sparse
+   trial-history protocol (plasticity laws; the mask and the history arrays are local to the
+   law's n points also when parent_rows is given); prev pointers may alias the outputs. */
+typedef struct fcamd_eval_args {
+    const double* grad_del_u;
+    const double* stress_prev;
+    double* stress;
+    double* tangent;                    /* nullable */
+    const double* const* history_prev;
+    double* const* history;
+    int n_hist;
+    const int32_t* parent_rows;         /* nullable */
+    uint64_t* history_mask;             /* nullable */
+} fcamd_eval_args;
+int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_t, int64_t n,
+                             const fcamd_eval_args* args);
+
 /* Host evaluate: the ndarray entry.  Pointers are host arrays laid out as above; the
    library stages them chunk by chunk (two chunk slots on two streams: H2D / kernel / D2H of
    one chunk overlap the other's when the arrays are page-locked, see

@@ -18,8 +18,9 @@ def test_rows_of_cells():
     assert rows_of_cells(np.array([2, 0]), 4).tolist() == [8, 9, 10, 11, 0, 1, 2, 3]
 
 
+@pytest.mark.parametrize("sparse", [True, False])
 @pytest.mark.parametrize("layout", ["interleaved_cells", "blocks"])
-def test_three_materials_replay_reference_protocol(layout):
+def test_three_materials_replay_reference_protocol(layout, sparse):
     kinds = ["linear_elasticity", "von_mises_3d", "spring_maxwell"]
     q, n_cells = 4, 1500
     n = q * n_cells
@@ -34,11 +35,14 @@ def test_three_materials_replay_reference_protocol(layout):
     for r, c in zip(rows, cases):
         stress_0.reshape(-1, 6)[r] = c[2].reshape(-1, 6)
     hist_0 = [None if c[3] is None else {k: v.copy() for k, v in c[3].items()} for c in cases]
-    st = ResidentProblemState(list(zip(laws, rows)), n, del_t=del_t)
+    st = ResidentProblemState(list(zip(laws, rows)), n, del_t=del_t, sparse_history=sparse)
+    assert (st._laws[1].mask is not None) == sparse and st._laws[0].mask is None
     st.set_state(stress_0, hist_0)
     for inc in range(3):
         for it in range(2):
-            grads = [rng.normal(size=9 * r.size) * np.repeat(10 ** rng.uniform(-4, -2, size=r.size), 9) for r in rows]
+            # plastic sets that change from call to call (some calls nearly all elastic)
+            hi = -2.0 if (inc + it) % 2 == 0 else -3.2
+            grads = [rng.normal(size=9 * r.size) * np.repeat(10 ** rng.uniform(-4, hi, size=r.size), 9) for r in rows]
             # reference protocol on the host
             stress_1, tangent, hist_1 = stress_0.copy(), np.zeros(36 * n), []
             for kind, c, r, g, h0 in zip(kinds, cases, rows, grads, hist_0):
