@@ -177,7 +177,8 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
             fn(params, 0.0, del_t, g[: 9 * m], s, tan[: 36 * m], h)
             return round(m / (time.perf_counter() - t0) / 1e6, 4)
 
-        extra = {"numpy_port_Mpts_s": time_np(NO.MODELS[kind], min(ns, 500_000)), "threads": "NumPy/OpenBLAS default"}
+        extra = {"numpy_port_Mpts_s": time_np(NO.MODELS[kind], min(ns, 100_000 if kind == "comfe_drucker_prager" else 500_000)),
+                 "threads": "NumPy/OpenBLAS default"}
         if kind == "von_mises_3d":
             extra["python_per_point_loop_port_Mpts_s"] = time_np(NO.von_mises_3d_loop, min(ns, 30_000))
         # the same C loop on all host cores (OpenMP over points), for scale only
@@ -195,27 +196,6 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
     except Exception as e:  # the extra figures are informational only
         out["extra"] = {"error": str(e)}
     return out
-
-
-def cpu_baseline_numpy_dp(params, grad, stress, hist, budget_s=10.0):
-    """Drucker-Prager has no C restatement: time the NumPy port of comfe-rs general.rs (batched LAPACK
-    solves, oracle/numpy_oracle.py) on a bounded sample."""
-    import numpy as np
-
-    from oracle import numpy_oracle as NO
-
-    ns = min(grad.numel() // 9, 200_000)
-    g, s0, h0 = grad[: 9 * ns].cpu().numpy(), stress[: 6 * ns].cpu().numpy(), hist["history"][: 7 * ns].cpu().numpy()
-    tan = np.zeros(36 * ns)
-    reps, t_total = 0, 0.0
-    while t_total < budget_s and reps < 50:
-        s, h = s0.copy(), {"history": h0.copy()}
-        t0 = time.perf_counter()
-        NO.comfe_drucker_prager(params, 0.0, 1.0, g, s, tan, h)
-        t_total += time.perf_counter() - t0
-        reps += 1
-    return {"value": round(ns * reps / t_total / 1e6, 4), "unit": "Mpts/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"oracle/numpy_oracle.py comfe_drucker_prager (NumPy/LAPACK default threads), first {ns} points x {reps} passes ({t_total:.1f} s)"}
 
 
 def main():
@@ -428,9 +408,7 @@ def main():
         }
         if gather:
             out["allgather"] = gather
-        if not args.no_cpu_baseline and world == 1 and kind == "comfe_drucker_prager":
-            out["cpu_baseline"] = cpu_baseline_numpy_dp(params, grad, stress_c, hist_c)
-        elif not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kind, params, grad, stress_c, hist_c, del_t)
         elif world == 1:
             out["cpu_baseline"] = None

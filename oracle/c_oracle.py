@@ -44,6 +44,7 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(LIB)
         _lib.oracle_von_mises_3d.restype = C.c_longlong
         _lib.oracle_comfe_mises.restype = C.c_longlong
+        _lib.oracle_comfe_drucker_prager.restype = C.c_longlong
     return _lib
 
 
@@ -107,6 +108,20 @@ def comfe_mises_plasticity(p, t, del_t, grad, stress, tangent, history):
                                     _p(grad), _p(stress), _p(tangent), _p(history["history"]))
 
 
+def comfe_drucker_prager(p, t, del_t, grad, stress, tangent, history, hyperbolic=False):
+    """Returns (n_plastic, total Newton iterations); raises like numpy_oracle.comfe_drucker_prager."""
+    nit, flags = C.c_longlong(0), C.c_int(0)
+    npl = lib().oracle_comfe_drucker_prager(
+        C.c_int(1 if hyperbolic else 0), _d(p["mu"]), _d(p["kappa"]), _d(p["a"]), _d(p["b"]), _d(p.get("d", 0.0)),
+        _d(p["b_flow"]), C.c_longlong(grad.size // 9), _p(grad), _p(stress), _p(tangent), _p(history["history"]),
+        C.byref(nit), C.byref(flags))
+    if flags.value & 1:
+        raise AssertionError("non-differentiable tip of Drucker-Prager surface reached")
+    if flags.value & 6:
+        raise RuntimeError("Plasticity3D: Newton-Raphson did not converge.")
+    return int(npl), int(nit.value)
+
+
 MODELS = {
     "linear_elasticity": linear_elasticity,
     "von_mises_3d": von_mises_3d,
@@ -114,4 +129,5 @@ MODELS = {
     "spring_kelvin": spring_kelvin,
     "comfe_linear_elasticity": comfe_linear_elasticity,
     "comfe_mises_plasticity": comfe_mises_plasticity,
+    "comfe_drucker_prager": comfe_drucker_prager,
 }

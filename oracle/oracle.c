@@ -312,3 +312,229 @@ long long oracle_comfe_mises(double mu, double kappa, double y_0, double h, long
     }
     return npl;
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+   f4: comfe-rs general return mapping with the Drucker-Prager surfaces, per point as the Rust loop
+   does it (comfe-rs/src/plasticity/general.rs:105-266; drucker_prager_classic.rs:62-116;
+   drucker_prager_hyperbolic.rs:64-114; driven by interfaces.rs:441-455).  8 unknowns
+   [sigma(6), del_lambda, alpha]; nalgebra's LU with partial pivoting is restated as Doolittle LU with
+   row pivoting on the 8x8 matrix; the consistent tangent is (dres^-1)[0:6,0:6] . E, transposed and then
+   stored column-major (= row-major of the product).  PARITY UNPINNED (see numpy_oracle.py): this is a
+   second, independent restatement; tests compare the two.
+   status (return value): number of plastic points; *flags |= 1 tip of the classic surface reached,
+   |= 2 Newton did not converge, |= 4 singular system. */
+typedef struct {
+    double f, dfs[6], g[6], dgs[36], k, dks[6];
+} dp_model;
+
+static void dp_set_state(int hyper, double a_, double b, double bf, double dsq, const double* pdev,
+                         const double* sig, dp_model* m, int* flags) {
+    const double i_1 = (sig[0] + sig[1]) + sig[2];
+    double s[6];
+    for (int i = 0; i < 6; ++i) s[i] = i < 3 ? sig[i] + (-(i_1 / 3.0)) : sig[i];
+    double j_2 = 0.0;
+    for (int i = 0; i < 6; ++i) j_2 += s[i] * s[i];
+    j_2 *= 0.5;
+    double df_dj2, df_dj2j2, root;
+    if (hyper) {
+        root = sqrt(j_2 + dsq);
+        df_dj2 = 0.5 * (1.0 / root);
+        df_dj2j2 = -1.0 / 4.0 * pow(j_2 + dsq, -3.0 / 2.0);
+    } else {
+        if (!(i_1 < a_ / b)) *flags |= 1;
+        root = sqrt(j_2);
+        df_dj2 = 0.5 / root;
+        df_dj2j2 = -0.25 / (j_2 * root);
+    }
+    m->f = root + b * i_1 - a_;
+    double gn2 = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        const double id = i < 3 ? 1.0 : 0.0;
+        m->dfs[i] = b * id + df_dj2 * s[i];
+        m->g[i] = bf * id + df_dj2 * s[i];
+        gn2 += m->g[i] * m->g[i];
+    }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) m->dgs[6 * i + j] = (s[i] * df_dj2j2) * s[j] + df_dj2 * pdev[6 * i + j];
+    const double g_norm = sqrt(gn2), s23 = sqrt(2.0 / 3.0);
+    m->k = s23 * g_norm;
+    for (int j = 0; j < 6; ++j) {
+        double acc = 0.0;
+        for (int i = 0; i < 6; ++i) acc += m->g[i] * m->dgs[6 * i + j];
+        m->dks[j] = (s23 / g_norm) * acc;
+    }
+}
+
+static void dp_newton_matrix(const double* E, double dl, const dp_model* m, double* J) {
+    for (int i = 0; i < 64; ++i) J[i] = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 6; ++k) acc += (E[6 * i + k] * dl) * m->dgs[6 * k + j];
+            J[8 * i + j] = (i == j ? 1.0 : 0.0) + acc;
+        }
+        double eg = 0.0;
+        for (int k = 0; k < 6; ++k) eg += E[6 * i + k] * m->g[k];
+        J[8 * i + 6] = eg;
+        J[8 * 6 + i] = m->dfs[i];
+        J[8 * 7 + i] = (-dl) * m->dks[i];
+    }
+    J[8 * 7 + 6] = -m->k;
+    J[8 * 7 + 7] = 1.0;
+}
+
+/* in-place LU with partial pivoting; returns 0 if singular */
+static int lu8(double* A, int* piv) {
+    for (int c = 0; c < 8; ++c) {
+        int p = c;
+        double best = fabs(A[8 * c + c]);
+        for (int r = c + 1; r < 8; ++r)
+            if (fabs(A[8 * r + c]) > best) best = fabs(A[8 * r + c]), p = r;
+        if (best == 0.0) return 0;
+        piv[c] = p;
+        if (p != c)
+            for (int j = 0; j < 8; ++j) {
+                const double t = A[8 * c + j];
+                A[8 * c + j] = A[8 * p + j];
+                A[8 * p + j] = t;
+            }
+        for (int r = c + 1; r < 8; ++r) {
+            const double l = A[8 * r + c] / A[8 * c + c];
+            A[8 * r + c] = l;
+            for (int j = c + 1; j < 8; ++j) A[8 * r + j] -= l * A[8 * c + j];
+        }
+    }
+    return 1;
+}
+
+static void lu8_solve(const double* LU, const int* piv, double* x) {
+    for (int c = 0; c < 8; ++c)
+        if (piv[c] != c) {
+            const double t = x[c];
+            x[c] = x[piv[c]];
+            x[piv[c]] = t;
+        }
+    for (int r = 1; r < 8; ++r)
+        for (int j = 0; j < r; ++j) x[r] -= LU[8 * r + j] * x[j];
+    for (int r = 7; r >= 0; --r) {
+        for (int j = r + 1; j < 8; ++j) x[r] -= LU[8 * r + j] * x[j];
+        x[r] /= LU[8 * r + r];
+    }
+}
+
+long long oracle_comfe_drucker_prager(int hyper, double mu, double kappa, double a_, double b, double d,
+                                      double b_flow, long long n, const double* grad, double* stress,
+                                      double* tangent, double* hist, long long* n_iter, int* flags_out) {
+    double soo[36], pvol[36], pdev[36], E[36], Einv[36];
+    comfe_proj(soo, pvol, pdev);
+    for (int i = 0; i < 36; ++i) {
+        E[i] = (2.0 * mu) * pdev[i] + (3.0 * kappa) * pvol[i];
+        Einv[i] = (2.0 * (1.0 / (4.0 * mu))) * pdev[i] + (3.0 * (1.0 / (9.0 * kappa))) * pvol[i];
+    }
+    const double dsq = d * d, atol = 1e-8, rtol = 1e-8;
+    long long npl = 0, nit = 0;
+    int flags = 0;
+    _Pragma("omp parallel for schedule(static) num_threads(g_threads) reduction(+ : npl, nit) reduction(| : flags)")
+    for (long long p = 0; p < n; ++p) {
+        double e[6], sig_tr[6], sig0[6];
+        double* s = stress + 6 * p;
+        double* hp = hist + 7 * p;
+        strain6(grad + 9 * p, F_RS, e);
+        for (int i = 0; i < 6; ++i) {
+            double acc = 0.0;
+            for (int k = 0; k < 6; ++k) acc += E[6 * i + k] * e[k];
+            sig0[i] = s[i];
+            sig_tr[i] = acc + s[i];
+        }
+        dp_model m;
+        int fl = 0;
+        dp_set_state(hyper, a_, b, b_flow, dsq, pdev, sig_tr, &m, &fl);
+        if (m.f <= 0.0) {
+            for (int i = 0; i < 6; ++i) s[i] = sig_tr[i];
+            if (tangent)
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) tangent[36 * p + 6 * i + j] = E[6 * j + i]; /* column-major .data.0 */
+            flags |= fl;
+            continue;
+        }
+        ++npl;
+        const double alpha_0 = hp[0];
+        double sol1[8], sol0[8], res[8], J[64], LU[64];
+        int piv[8];
+        for (int i = 0; i < 6; ++i) sol1[i] = sig_tr[i], res[i] = 0.0;
+        sol1[6] = 0.0, sol1[7] = alpha_0;
+        res[6] = m.f, res[7] = 0.0;
+        dp_newton_matrix(E, 0.0, &m, J);
+        int it = 0;
+        for (;;) {
+            ++nit;
+            for (int i = 0; i < 8; ++i) sol0[i] = sol1[i];
+            for (int i = 0; i < 64; ++i) LU[i] = J[i];
+            double x[8];
+            for (int i = 0; i < 8; ++i) x[i] = res[i];
+            if (!lu8(LU, piv)) {
+                fl |= 4;
+                break;
+            }
+            lu8_solve(LU, piv, x);
+            for (int i = 0; i < 8; ++i) sol1[i] = sol0[i] - x[i];
+            const double dl = sol1[6];
+            dp_set_state(hyper, a_, b, b_flow, dsq, pdev, sol1, &m, &fl);
+            dp_newton_matrix(E, dl, &m, J);
+            double rs2 = 0.0, ds2 = 0.0, s2 = 0.0;
+            for (int i = 0; i < 6; ++i) {
+                double eg = 0.0;
+                for (int k = 0; k < 6; ++k) eg += E[6 * i + k] * m.g[k];
+                res[i] = (sol1[i] - sig_tr[i]) + dl * eg;
+                rs2 += res[i] * res[i];
+                ds2 += (sol1[i] - sol0[i]) * (sol1[i] - sol0[i]);
+                s2 += sol1[i] * sol1[i];
+            }
+            res[6] = m.f;
+            res[7] = (sol1[7] - alpha_0) - m.k;
+            const int conv_res = sqrt(rs2) < atol && fabs(res[7]) < atol && fabs(res[6]) < atol;
+            const int conv_inc = sqrt(ds2) < atol + rtol * sqrt(s2) &&
+                                 fabs(sol1[7] - sol0[7]) < atol + rtol * fabs(sol1[7]) &&
+                                 fabs(dl - sol0[6]) < atol + rtol * fabs(dl);
+            if (conv_res || conv_inc) break;
+            if (it > 25) {
+                fl |= 2;
+                break;
+            }
+            ++it;
+        }
+        flags |= fl;
+        for (int i = 0; i < 6; ++i) s[i] = sol1[i];
+        hp[0] = sol1[7];
+        for (int i = 0; i < 6; ++i) { /* plastic_strain += d_eps - E^-1 (sigma_1 - sigma_0) */
+            double acc = 0.0;
+            for (int k = 0; k < 6; ++k) acc += Einv[6 * i + k] * (sol1[k] - sig0[k]);
+            hp[1 + i] += e[i] - acc;
+        }
+        if (tangent) {
+            /* inverse of the last Jacobian, column by column */
+            double inv[64];
+            for (int i = 0; i < 64; ++i) LU[i] = J[i];
+            if (!lu8(LU, piv)) {
+                flags |= 4;
+                continue;
+            }
+            for (int c = 0; c < 8; ++c) {
+                double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                x[c] = 1.0;
+                lu8_solve(LU, piv, x);
+                for (int r = 0; r < 8; ++r) inv[8 * r + c] = x[r];
+            }
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    double acc = 0.0;
+                    for (int k = 0; k < 6; ++k) acc += inv[8 * i + k] * E[6 * k + j];
+                    tangent[36 * p + 6 * i + j] = acc; /* transpose, then column-major = row-major of the product */
+                }
+        }
+    }
+    if (n_iter) *n_iter = nit;
+    if (flags_out) *flags_out = flags;
+    return npl;
+}
