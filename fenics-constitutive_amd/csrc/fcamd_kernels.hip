@@ -806,8 +806,8 @@ __device__ __forceinline__ DPInv dp_state(double I1, double rho, double n2, doub
 // T[i][j..j+1] for chunk q of the tile from the published parameters
 template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11tab, const double* pdtab,
-                                           double* tangent, long long p0, const int* rows_lds, int npts,
-                                           int lane) {
+                                           const double* etab, double* tangent, long long p0,
+                                           const int* rows_lds, int npts, int lane) {
     const int nchunks = npts * 18;
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
@@ -819,7 +819,8 @@ __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11ta
         const double* t = tp + kDpStride * p;
         const d2 c0 = reinterpret_cast<const d2*>(t)[0];  // t11, tP
         const d2 c1 = reinterpret_cast<const d2*>(t)[1];  // tss, t1s
-        const double ts1 = t[4];
+        const d2 c2 = reinterpret_cast<const d2*>(t)[2];  // ts1, plastic flag
+        const double ts1 = c2.x;
         const double si = t[6 + i];
         const d2 sj = *reinterpret_cast<const d2*>(t + 6 + j);
         const d2 o = *reinterpret_cast<const d2*>(t11tab + 6 * i + j);  // (1 x 1)[i][j]
@@ -828,6 +829,10 @@ __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11ta
         d2 v;
         v.x = (c0.x * o.x + c0.y * pd.x) + ((c1.x * si) * sj.x + (c1.y * oi) * sj.x + (ts1 * si) * (j < 3 ? 1.0 : 0.0));
         v.y = (c0.x * o.y + c0.y * pd.y) + ((c1.x * si) * sj.y + (c1.y * oi) * sj.y + (ts1 * si) * (j + 1 < 3 ? 1.0 : 0.0));
+        // elastic points of a mixed tile: the reference returns elastic_tangent() itself (general.rs:131-135),
+        // i.e. the host-computed 2 mu P_dev + 3 kappa P_vol bit for bit, not kappa 1x1 + 2 mu P_dev
+        const d2 el = *reinterpret_cast<const d2*>(etab + 6 * i + j);
+        if (c2.y == 0.0) v = el;
         if (FULL || q < nchunks) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);
     }
@@ -981,7 +986,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
         reinterpret_cast<d2*>(t)[0] = v;
         v.x = tss, v.y = t1s;
         reinterpret_cast<d2*>(t)[1] = v;
-        v.x = ts1, v.y = 0.0;
+        v.x = ts1, v.y = plastic ? 1.0 : 0.0;
         reinterpret_cast<d2*>(t)[2] = v;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -990,7 +995,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
             reinterpret_cast<d2*>(t)[3 + i] = v;
         }
         wave_sync();
-        tangent_dp<IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane);
+        tangent_dp<IDX, FULL, NT>(region, T->a, T->b, T->c, sb.tan, p0, rows_lds, npts, lane);
         wave_sync();
     }
 }
