@@ -203,3 +203,19 @@ def test_constant_tangent_is_written_once_per_del_t(cls):
     # the plasticity laws never skip
     vm = ResidentState(fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}), n)
     assert not vm._const_tangent
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 65])
+def test_evaluate_into_tiny_sizes(n):
+    from test_gpu_parity import oracle_run, random_case
+
+    p, g, s0, h0 = random_case("von_mises_3d", n, seed=n + 1)
+    law = fc.VonMises3D(p)
+    st = ResidentState(law, n, stress0=s0, history0=h0)
+    s, t = np.full(6 * n, np.nan), np.full(36 * n, np.nan)
+    st.evaluate_into(0.0, 1.0, g, s, t)
+    ref = oracle_run("von_mises_3d", p, 1.0, g, s0, h0)
+    if n:
+        assert rel_err(s, ref[0]) <= 1e-9 and rel_err(t, ref[1]) <= 1e-6
+        st.update()
+        assert rel_err(st.history_committed["alpha"].cpu().numpy(), ref[2]["alpha"]) <= 1e-6
