@@ -159,3 +159,26 @@ def test_default_device_selection(monkeypatch):
         assert _capi.default_device() == 5
     monkeypatch.setenv("FCAMD_DEVICE", "2")
     assert _capi.default_device() == 2
+
+
+def test_rows_of_cells_matches_quadrature_numbering():
+    """Quadrature dofs are numbered cell by cell (solver/maps.py:43-79): cell c, point q -> c*Q + q."""
+    from fenics_constitutive_amd.problem import rows_of_cells
+
+    rows = rows_of_cells(np.array([5, 0, 2]), 3)
+    assert rows.dtype == np.int32 and rows.tolist() == [15, 16, 17, 0, 1, 2, 6, 7, 8]
+    assert rows_of_cells(np.array([], dtype=np.int32), 4).size == 0
+
+
+def test_eval_args_struct_layout_matches_header():
+    """ctypes mirror of fcamd_eval_args: nine fields in the header's order, pointer-sized except n_hist."""
+    import ctypes as C
+    import re
+
+    from fenics_constitutive_amd import _capi
+
+    hdr = open(os.path.join(ROOT, "include", "fcamd.h")).read()
+    body = re.search(r"typedef struct fcamd_eval_args \{(.*?)\} fcamd_eval_args;", hdr, re.S).group(1)
+    names = re.findall(r"(\w+);", body)
+    assert names == [f[0] for f in _capi.EvalArgs._fields_]
+    assert C.sizeof(_capi.EvalArgs) == 9 * C.sizeof(C.c_void_p)  # n_hist padded to pointer size
