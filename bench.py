@@ -204,7 +204,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="von_mises_mixed", choices=sorted(WORKLOADS))
-    ap.add_argument("--n", type=int, default=100_000_000, help="quadrature points per GPU")
+    ap.add_argument("--n", "--points", dest="n", type=int, default=100_000_000,
+                    help="quadrature points per GPU (use --points under torch.distributed.run, whose parser claims --n)")
     ap.add_argument("--grid", type=int, default=0, help="override the launch grid (workgroups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sparse-history", action="store_true",
@@ -214,6 +215,9 @@ def main():
                     help="N>1: also time the one-hop point-to-point gather (batched isend/irecv to all peers)")
     ap.add_argument("--gather-points", type=int, default=20_000_000,
                     help="points per rank of the separately timed stress/tangent all-gather (N>1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo only to exercise the multi-rank control flow on a box "
+                         "with fewer GPUs than ranks (ranks then share GPUs; the all-gather leg is skipped)")
     args = ap.parse_args()
 
     import torch
@@ -227,14 +231,18 @@ def main():
             sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # identity on a node with one GPU per rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     # launched by torch.distributed.run (RANK set): one rank per GPU over RCCL, also for world 1
     distributed = "RANK" in os.environ
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     kind, scale_spec, b_el, b_pl = WORKLOADS[args.workload]
     n = args.n
@@ -253,7 +261,7 @@ def main():
     stress_t = torch.empty_like(stress_c)
     hist_t = None if hist_c is None else {k: torch.empty_like(v) for k, v in hist_c.items()}
     if args.grid:
-        law._handle(local_rank).ctx.set_grid(args.grid)
+        law._handle(dev_index).ctx.set_grid(args.grid)
 
     hmask = None
     if args.sparse_history:
@@ -269,7 +277,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    st = law.device_stats(local_rank)
+    st = law.device_stats(dev_index)
     n_pl = int(st.n_plastic) if kind in ("von_mises_3d", "comfe_mises_plasticity", "comfe_drucker_prager") else 0
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -295,7 +303,7 @@ def main():
 
     # optional exchange step, timed separately (never part of `value`)
     gather = None
-    if distributed:
+    if distributed and args.backend == "nccl":
         from fenics_constitutive_amd.sharded import ShardPlan
 
         ng = min(args.gather_points, n)
