@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rows(pattern):
-    f = glob.glob(os.path.join(src, pattern))
-    return list(csv.DictReader(open(f[0]))) if f else []
+    f = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)  # newest run if several were merged
+    return list(csv.DictReader(open(f[-1]))) if f else []
 
 
 stats = rows("kt/*/*_kernel_stats.csv")

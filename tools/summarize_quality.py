@@ -11,7 +11,7 @@ from collections import defaultdict
 src, rnd, workload = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 vals = defaultdict(list)
-for f in sorted(glob.glob(os.path.join(src, "q_*", "*", "*_counter_collection.csv"))):
+for f in sorted(glob.glob(os.path.join(src, "q_*", "*", "*_counter_collection.csv")), key=os.path.getmtime):
     rows = [r for r in csv.DictReader(open(f)) if "fcamd::evaluate_kernel" in r["Kernel_Name"]]
     by_counter = defaultdict(list)
     for r in rows:
