@@ -145,6 +145,12 @@ class DeviceLaw(IncrSmallStrainModel):
             except RuntimeError:
                 pinned[key] = None  # e.g. overlaps another registration: keep the staged path
 
+    def pin_host_arrays(self, *arrays) -> None:
+        """Page-lock caller-owned NumPy arrays that will be passed to ``evaluate`` repeatedly (the
+        dolfinx ``Function.x.array`` views of one problem): the host path then DMAs directly.  The law
+        keeps the arrays alive until ``unpin_arrays()``."""
+        self._pin(self._handle(_capi.default_device()).ctx, [_check_numpy("array", a) for a in arrays])
+
     def unpin_arrays(self) -> None:
         """Undo ``auto_pin`` registrations and drop the references that kept the arrays alive."""
         pinned = self.__dict__.pop("_pinned", {})
