@@ -1,0 +1,66 @@
+"""Attach device-resident state to an (unchanged) reference ``IncrSmallStrainProblem``.
+
+``use_resident_state(problem)`` is the "patch of ``LawOnSubMesh.evaluate`` / ``update_history``"
+that INTEGRATION.md describes, applied at run time to the problem's own objects: for every
+``LawOnSubMesh`` (``solver/_lawonsubmesh.py:47-110``) whose law is one of this package's
+GPU-backed laws it
+
+* creates a ``ResidentState`` from the committed state the problem holds (the law's rows of
+  ``problem.stress.previous`` through ``submesh_map.map_to_sub``; ``history.history_0``),
+* replaces ``evaluate`` by: incremental gradient (unchanged dolfinx call) ->
+  ``ResidentState.evaluate_into`` (gradient up, trial stress + tangent straight into the law's
+  ``stress`` / ``local_tangent`` arrays) -> ``map_to_parent`` (unchanged),
+* replaces ``update_history`` by the pointer-swap commit (optionally mirroring the committed
+  history into the host ``Function``s once per increment, for post-processing code that reads them).
+
+The host-side copies of every Newton iteration (``local_stress``: ``map_to_sub``;
+``History.reset_trial_state``) and the history copy of every commit disappear; PCIe carries 72 + 336
+bytes per point and iteration instead of 176 + 392.  Only attribute access is used, no dolfinx
+import: anything that looks like the reference's dataclasses works (``tests/test_gpu_integration.py``
+drives it with stand-ins).
+"""
+
+from __future__ import annotations
+
+import types
+
+from .device import DeviceLaw
+from .resident import ResidentState
+
+__all__ = ["use_resident_state"]
+
+
+def use_resident_state(problem, sync_history: bool = True, pin: bool = True) -> list[ResidentState]:
+    """Returns the created states (one per GPU-backed law of ``problem._law_on_submeshs``)."""
+    states = []
+    for los in problem._law_on_submeshs:
+        law = los.law
+        if not isinstance(law, DeviceLaw):
+            continue
+        sd = law.stress_strain_dim
+        n = los.stress.x.array.size // sd
+        stress0 = los.local_stress(problem.stress).copy()  # committed stress of this law's cells
+        hist0 = None if los.history is None else {k: f.x.array for k, f in los.history.history_0.items()}
+        state = ResidentState(law, n, stress0=stress0, history0=hist0)
+        if pin:
+            law.pin_host_arrays(los.displacement_gradient_fn.x.array, los.stress.x.array, los.local_tangent.x.array)
+
+        def evaluate(self, sim_time, incr_disp, global_stress, global_tangent, _state=state):
+            incr_disp.evaluate_local_incremental_gradient(self.cells, self.displacement_gradient_fn)
+            _state.evaluate_into(sim_time.current, sim_time.dt, self.displacement_gradient_fn.x.array,
+                                 self.stress.x.array, self.local_tangent.x.array)
+            self.map_to_parent(global_stress, global_tangent)
+
+        def update_history(self, _state=state, _sync=sync_history):
+            _state.update()
+            if _sync and self.history is not None:
+                committed = _state.history_committed
+                for key, fn in self.history.history_0.items():
+                    fn.x.array[:] = committed[key].cpu().numpy()
+                    self.history.history_1[key].x.array[:] = fn.x.array
+
+        los.evaluate = types.MethodType(evaluate, los)
+        los.update_history = types.MethodType(update_history, los)
+        los.resident_state = state
+        states.append(state)
+    return states

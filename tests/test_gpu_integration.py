@@ -1,0 +1,156 @@
+"""use_resident_state(problem): the run-time patch of the reference's LawOnSubMesh objects, driven
+with stand-ins that restate the reference's host protocol (solver/_solver.py:130-159,
+solver/_lawonsubmesh.py:47-110, solver/_history.py:37-90, solver/_incrementalunknowns.py:54-80,
+solver/maps.py:82-123) -- dolfinx is not needed, only the attributes the patch touches.  The patched
+problem must produce the same global stress / tangent / histories as the unpatched one."""
+
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import fenics_constitutive_amd as fc  # noqa: E402
+from fenics_constitutive_amd.integration import use_resident_state  # noqa: E402
+
+
+class Fn:
+    def __init__(self, size):
+        self.x = SimpleNamespace(array=np.zeros(size), scatter_forward=lambda: None)
+
+
+class SubMap:
+    def __init__(self, rows):
+        self.rows = rows
+
+    def map_to_sub(self, parent, sub):
+        d = sub.x.array.size // self.rows.size
+        sub.x.array.reshape(-1, d)[:] = parent.x.array.reshape(-1, d)[self.rows]
+
+    def map_to_parent(self, sub, parent):
+        d = sub.x.array.size // self.rows.size
+        parent.x.array.reshape(-1, d)[self.rows] = sub.x.array.reshape(-1, d)
+
+
+class Stress:
+    def __init__(self, n):
+        self.current, self.previous = Fn(6 * n), Fn(6 * n)
+
+    def update_previous(self):
+        self.previous.x.array[:] = self.current.x.array
+
+
+class History:
+    def __init__(self, dims, n):
+        self.history_0 = {k: Fn(d * n) for k, d in dims.items()}
+        self.history_1 = {k: Fn(d * n) for k, d in dims.items()}
+
+    def reset_trial_state(self):
+        for k in self.history_0:
+            self.history_1[k].x.array[:] = self.history_0[k].x.array
+        return {k: f.x.array for k, f in self.history_1.items()}
+
+    def update(self):
+        for k in self.history_0:
+            self.history_0[k].x.array[:] = self.history_1[k].x.array
+
+
+class LawOnSubMesh:
+    def __init__(self, law, cells, rows):
+        n = rows.size
+        self.law, self.cells = law, cells
+        self.displacement_gradient_fn, self.stress, self.local_tangent = Fn(9 * n), Fn(6 * n), Fn(36 * n)
+        self.submesh_map = SubMap(rows)
+        self.history = None if law.history_dim is None else History(law.history_dim, n)
+
+    def local_stress(self, stress):
+        self.submesh_map.map_to_sub(stress.previous, self.stress)
+        return self.stress.x.array
+
+    def map_to_parent(self, global_stress, global_tangent):
+        self.submesh_map.map_to_parent(self.stress, global_stress.current)
+        self.submesh_map.map_to_parent(self.local_tangent, global_tangent)
+
+    def evaluate(self, sim_time, incr_disp, global_stress, global_tangent):
+        incr_disp.evaluate_local_incremental_gradient(self.cells, self.displacement_gradient_fn)
+        h = self.history.reset_trial_state() if self.history is not None else None
+        self.law.evaluate(sim_time.current, sim_time.dt, self.displacement_gradient_fn.x.array,
+                          self.local_stress(global_stress), self.local_tangent.x.array, h)
+        self.map_to_parent(global_stress, global_tangent)
+
+    def update_history(self):
+        if self.history is not None:
+            self.history.update()
+
+
+class IncrDisp:
+    def __init__(self):
+        self.grads = {}
+
+    def evaluate_local_incremental_gradient(self, cells, fn):
+        fn.x.array[:] = self.grads[cells.tobytes()]
+
+
+class Problem:
+    def __init__(self, laws, n):
+        self.stress, self.tangent = Stress(n), Fn(36 * n)
+        self._law_on_submeshs = [LawOnSubMesh(law, cells, rows) for law, cells, rows in laws]
+        self.sim_time = SimpleNamespace(current=0.0, dt=0.5)
+        self.incr_disp = IncrDisp()
+
+    def form(self):
+        for los in self._law_on_submeshs:
+            los.evaluate(self.sim_time, self.incr_disp, self.stress, self.tangent)
+
+    def update(self):
+        self.stress.update_previous()
+        for los in self._law_on_submeshs:
+            los.update_history()
+        self.sim_time.current += self.sim_time.dt
+
+
+def build(n_cells, q, rng_seed):
+    rng = np.random.default_rng(rng_seed)
+    owner = rng.integers(0, 2, size=n_cells)
+    vm = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
+    mx = fc.SpringMaxwellModel({"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}, fc.StressStrainConstraint.FULL)
+    laws = []
+    for k, law in enumerate((vm, mx)):
+        cells = np.flatnonzero(owner == k).astype(np.int32)
+        rows = (cells[:, None] * q + np.arange(q)[None, :]).reshape(-1)
+        laws.append((law, cells, rows))
+    p = Problem(laws, n_cells * q)
+    p.stress.previous.x.array[:] = rng.normal(scale=5.0, size=6 * n_cells * q)
+    p._law_on_submeshs[0].history.history_0["alpha"].x.array[:] = rng.uniform(0, 0.02, size=laws[0][2].size)
+    return p
+
+
+def test_patched_problem_equals_unpatched():
+    n_cells, q = 700, 4
+    a, b = build(n_cells, q, 3), build(n_cells, q, 3)
+    states = use_resident_state(b)
+    assert len(states) == 2 and all(hasattr(los, "resident_state") for los in b._law_on_submeshs)
+    rng = np.random.default_rng(8)
+    for inc in range(3):
+        for it in range(3):
+            for los_a, los_b in zip(a._law_on_submeshs, b._law_on_submeshs):
+                m = los_a.stress.x.array.size // 6
+                scale = 10 ** rng.uniform(-4, -1.8 if it else -3.5, size=m)
+                g = rng.normal(size=9 * m) * np.repeat(scale, 9)
+                a.incr_disp.grads[los_a.cells.tobytes()] = g
+                b.incr_disp.grads[los_b.cells.tobytes()] = g
+            a.form()
+            b.form()
+            assert np.array_equal(a.stress.current.x.array, b.stress.current.x.array), (inc, it)
+            assert np.array_equal(a.tangent.x.array, b.tangent.x.array), (inc, it)
+        a.update()
+        b.update()
+        for los_a, los_b in zip(a._law_on_submeshs, b._law_on_submeshs):
+            for k in los_a.history.history_0:
+                assert np.array_equal(los_a.history.history_0[k].x.array, los_b.history.history_0[k].x.array), (inc, k)
+        assert np.array_equal(a.stress.previous.x.array, b.stress.previous.x.array)
+    assert b._law_on_submeshs[0].law.last_stats.n_plastic > 0
+    for los in b._law_on_submeshs:
+        los.law.unpin_arrays()
