@@ -182,3 +182,42 @@ def test_eval_args_struct_layout_matches_header():
     names = re.findall(r"(\w+);", body)
     assert names == [f[0] for f in _capi.EvalArgs._fields_]
     assert C.sizeof(_capi.EvalArgs) == 9 * C.sizeof(C.c_void_p)  # n_hist padded to pointer size
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
+def test_drop_in_mode_subclasses_the_reference_interface():
+    """With the reference importable (here: its NumPy part, dolfinx / the compiled bindings stubbed as
+    in SURVEY Appendix A) the GPU-backed laws are subclasses of the REFERENCE ABC and carry the
+    REFERENCE enum, which is what IncrSmallStrainProblem checks (solver/_solver.py:67-75)."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent(
+        """
+        import sys, types
+        df = types.ModuleType("dolfinx"); common = types.ModuleType("dolfinx.common")
+        common.timed = lambda name: (lambda f: f); df.common = common
+        sys.modules["dolfinx"] = df; sys.modules["dolfinx.common"] = common
+        b = types.ModuleType("fenics_constitutive._bindings")
+        for n in ("PyDruckerPrager3D", "PyDruckerPragerHyperbolic3D", "PyLinearElasticity3D", "PyMisesPlasticity3D"):
+            setattr(b, n, type(n, (), {}))
+        sys.modules["fenics_constitutive._bindings"] = b
+        sys.path.insert(0, "/root/reference/src")
+        sys.path.insert(0, %r)
+        import fenics_constitutive.models as ref
+        import fenics_constitutive_amd as fc
+        from fenics_constitutive_amd import interfaces
+        assert interfaces.REFERENCE_INTERFACES
+        assert fc.IncrSmallStrainModel is ref.IncrSmallStrainModel and fc.StressStrainConstraint is ref.StressStrainConstraint
+        vm = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
+        le = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, ref.StressStrainConstraint.PLANE_STRESS)
+        assert isinstance(vm, ref.IncrSmallStrainModel) and isinstance(le, ref.IncrSmallStrainModel)
+        assert vm.constraint is ref.StressStrainConstraint.FULL and le.constraint is ref.StressStrainConstraint.PLANE_STRESS
+        assert vm.history_dim == ref.VonMises3D(dict(p_ka=1.0, p_mu=1.0, p_y0=1.0, p_y00=2.0, p_w=1.0)).history_dim
+        assert le.stress_strain_dim == 4 and le.geometric_dim == 2
+        print("drop-in ok")
+        """
+    ) % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "drop-in ok" in r.stdout, r.stderr[-2000:]
