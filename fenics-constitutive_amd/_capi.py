@@ -32,7 +32,7 @@ SYMBOLS = [
     "fcamd_context_create", "fcamd_context_destroy", "fcamd_context_set_stream",
     "fcamd_context_synchronize", "fcamd_model_create", "fcamd_model_destroy",
     "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_evaluate_device",
-    "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
+    "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
     "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
     "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
     "fcamd_last_error", "fcamd_status_string", "fcamd_version",
@@ -112,6 +112,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_evaluate_device_indexed.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_host.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int, C.POINTER(Stats)]
         lib.fcamd_evaluate_device_ex.argtypes = [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs)]
+        lib.fcamd_evaluate_device_wrapped.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp,
+                                                      C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_resident.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.POINTER(vp),
                                                 C.c_int, vp, vp, vp, C.POINTER(Stats)]
         lib.fcamd_strain_from_grad_u_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int]
@@ -271,6 +273,13 @@ class Model:
         x = EvalArgs(grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr or None, parr, arr, nh, rows_ptr or None,
                      mask_ptr or None)
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
+
+    def evaluate_device_wrapped(self, wrapper_constraint, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, stress3d_ptr,
+                                hist_ptrs) -> None:
+        arr, nh = self._ptr_array(hist_ptrs)
+        check(self._lib.fcamd_evaluate_device_wrapped(
+            self.handle, int(wrapper_constraint), float(t), float(del_t), int(n), C.c_void_p(grad_ptr),
+            C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), C.c_void_p(stress3d_ptr), arr, nh))
 
     def evaluate_resident(self, t, del_t, n, grad_host_ptr, stress_prev_ptr, stress_ptr, hist_prev_ptrs, hist_ptrs,
                           mask_ptr, stress_host_ptr, tangent_host_ptr) -> Stats:

@@ -380,6 +380,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.h1_in = m->info.n_hist > 1 ? hprev[1] : nullptr;
     a.h1_out = m->info.n_hist > 1 ? hcur[1] : nullptr;
     a.rows = rows;
+    a.cache3d = nullptr;
     a.hmask = hmask;
     a.n = n;
     a.counters = m->d_counters;
@@ -719,6 +720,46 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     m->timed = false;
     return enqueue(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history,
                    c->stream, true, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask));
+}
+
+int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double t, double del_t, int64_t n,
+                                  const double* grad_lo, double* stress_lo, double* tangent_lo,
+                                  double* stress_3d, double* const* hist, int n_hist) {
+    (void)t;
+    int st = validate_call(m, del_t, n, grad_lo, stress_lo, stress_lo,
+                           reinterpret_cast<const void* const*>(hist),
+                           reinterpret_cast<const void* const*>(hist), n_hist);
+    if (st != FCAMD_OK) return st;
+    if (m->law != FCAMD_VON_MISES_3D)
+        return fail(FCAMD_ERR_UNSUPPORTED, "the fused 3D wrapper kernel exists for VonMises3D only");
+    const int wrap = wrapper_constraint == FCAMD_UNIAXIAL_STRAIN ? 1 : wrapper_constraint == FCAMD_PLANE_STRAIN ? 2 : 0;
+    if (!wrap) return fail(FCAMD_ERR_BAD_ARG, "wrapper constraint must be UNIAXIAL_STRAIN or PLANE_STRAIN");
+    if (n > 0 && !stress_3d) return fail(FCAMD_ERR_BAD_ARG, "stress_3d is NULL");
+    if (!aligned16(stress_3d) || (wrap == 2 && (!aligned16(grad_lo) || !aligned16(stress_lo) || !aligned16(tangent_lo))))
+        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
+    for (int k = 0; k < m->info.n_hist; ++k)
+        if (!aligned16(hist[k])) return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
+    fcamd_context* c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    m->timed = false;
+    EvalArgs a;
+    a.grad = grad_lo;
+    a.stress_in = stress_lo;
+    a.stress_out = stress_lo;
+    a.tangent = tangent_lo;
+    a.h0_in = a.h0_out = hist[0];
+    a.h1_in = a.h1_out = hist[1];
+    a.rows = nullptr;
+    a.hmask = nullptr;
+    a.cache3d = stress_3d;
+    a.n = n;
+    a.counters = m->d_counters;
+    a.tile_map = 0;
+    fill_constants(m, del_t, &a);
+    HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->stream));
+    if (n == 0) return FCAMD_OK;
+    HIP_TRY(launch_evaluate_wrapped(wrap, a, grid_for(m, n), c->stream));
+    return FCAMD_OK;
 }
 
 int fcamd_evaluate_device(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,

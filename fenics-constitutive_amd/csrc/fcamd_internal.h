@@ -46,6 +46,7 @@ struct EvalArgs {
     double* h1_out;
     unsigned long long* hmask; // nullptr, or sparse-trial-history mask, one word per 64-point tile (VonMises3D)
     const int* rows;           // nullptr, or parent row of every point: stress/tangent are parent arrays
+    double* cache3d;           // fused 3D->1D/2D wrappers only: the wrapper's cached 3-D stress [6n], in place
     long long n;               // quadrature points
     unsigned long long* counters;  // [kCounterSlots][4]: nonconverged, plastic, newton iterations, reserved
     int tile_map;              // 0: tiles dealt round-robin to all waves; 1: one contiguous region per XCD
@@ -56,6 +57,10 @@ struct EvalArgs {
 // Launch the evaluate kernel of `law` on `stream` with `grid` workgroups of 256 threads.
 // dims = geometric dimension of the constraint (3: FULL; 2: plane strain/stress; 1: uniaxial)
 hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hipStream_t stream);
+// Fused 3D -> uniaxial-strain (wrap = 1) / plane-strain (wrap = 2) wrapper around VonMises3D: grad,
+// stress_in/out and tangent are the LOW-dimensional arrays, cache3d the wrapper's 3-D stress, history
+// the 3-D law's (in place).
+hipError_t launch_evaluate_wrapped(int wrap, const EvalArgs& args, int grid, hipStream_t stream);
 // Occupancy-derived default grid (workgroups) for `law` on the current device.
 int default_grid(int law, int num_cu);
 // strain_from_grad_u, FULL.

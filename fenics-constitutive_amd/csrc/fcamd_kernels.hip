@@ -650,6 +650,160 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     }
 }
 
+// --- VonMises3D behind the reference's 3D -> 1D/2D wrappers, fused -----------------------------
+// UniaxialStrainFrom3D / PlaneStrainFrom3D (models/utils.py:211-412) copy the mapped components of the
+// low-dimensional gradient and stress into cached 3-D arrays, call the 3-D law, and copy the mapped
+// components of stress and tangent back.  The cached 3-D stress keeps its unmapped components from
+// the previous call (utils.py:253-266: under uniaxial strain the lateral stresses live only there).
+// Here one kernel does all of it: per tile it reads the low-dimensional gradient and stress plus the
+// cached 3-D stress row, runs the VonMises3D update of tile_von_mises on the padded point, and writes
+// the full row back to the cache and the mapped components to the caller's arrays.  No 3-D gradient
+// or tangent array exists.  WRAP = 1: component 11 of everything; WRAP = 2: gradient (0,1,2,3) ->
+// (0,1,3,4), Mandel components 0..3, tangent block [0:4, 0:4] (utils.py:282-297, 377-412).
+// In place only (the wrappers have no out-of-place form).
+template <int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const Tables* T, double* region,
+                                                       long long p0, int npts, int lane, WaveStats& st) {
+    constexpr int GD = WRAP == 1 ? 1 : 4;  // doubles per point of the low-dimensional gradient
+    constexpr int SD = WRAP == 1 ? 1 : 4;  // ... of the low-dimensional stress
+    const bool live = FULL || lane < npts;
+    Chunks<6> cc;
+    tile_load<6, FULL, NT>(cc, a.cache3d + p0 * 6, npts * 6, lane);
+    double g[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, s[6], e[6];
+    double s_lo[SD];
+    if constexpr (WRAP == 1) {
+        g[0] = live ? a.grad[p0 + lane] : 0.0;
+        s_lo[0] = live ? a.stress_in[p0 + lane] : 0.0;
+    } else {
+        Chunks<GD> cg;
+        Chunks<SD> cs;
+        tile_load<GD, FULL, NT>(cg, a.grad + p0 * GD, npts * GD, lane);
+        tile_load<SD, FULL, NT>(cs, a.stress_in + p0 * SD, npts * SD, lane);
+        double g_lo[GD];
+        transpose_in<GD>(cg, region, lane, g_lo);
+        transpose_in<SD>(cs, region, lane, s_lo);
+        g[0] = g_lo[0], g[1] = g_lo[1], g[3] = g_lo[2], g[4] = g_lo[3];
+    }
+    const double alpha_n = live ? a.h1_in[p0 + lane] : 0.0;
+    transpose_in<6>(cc, region, lane, s);
+#pragma unroll
+    for (int i = 0; i < SD; ++i) s[i] = s_lo[i];  // mapped components come from the caller, the others persist
+    mandel_strain(g, a.sc.s[0], e);
+
+    const double ka = a.sc.s[1], two_mu = a.sc.s[2], s23 = a.sc.s[3], y0 = a.sc.s[4], dy = a.sc.s[5],
+                 mw = a.sc.s[6], m2mu = a.sc.s[7], c23dyw = a.sc.s[8], four_mu2 = a.sc.s[9];
+    const double tr_eps = (e[0] + e[1]) + e[2];
+    const double tr_sig = (s[0] + s[1]) + s[2];
+    const double tr_eps3 = tr_eps / 3.0, tr_sig3 = tr_sig / 3.0;
+    double dsig[6], sigtr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double ed = i < 3 ? e[i] - tr_eps3 : e[i];
+        const double sd = i < 3 ? s[i] - tr_sig3 : s[i];
+        dsig[i] = two_mu * ed;
+        sigtr[i] = sd + dsig[i];
+    }
+    double nn = sigtr[0] * sigtr[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) nn = __builtin_fma(sigtr[i], sigtr[i], nn);
+    const double sigtrn = sqrt(nn);
+    const double phitr = sigtrn - s23 * (y0 + dy * (1.0 - exp(mw * alpha_n)));
+    const bool plastic = live && (phitr > 0.0);
+    const unsigned long long mask = __ballot(plastic);
+
+    Chunks<6> ce;
+    if (mask != 0ull) tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
+    double gamma = 0.0, xc1 = 0.0, xc2 = 0.0;
+    double N[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (mask != 0ull) {
+        if (plastic) {
+            double g0 = 1.0, g1 = 0.0, xr = 1.0, xg;
+            int it = 0;
+            bool failed = false;
+            while (__builtin_fabs(xr) > 1e-12 && __builtin_fabs(g1 - g0) > 1e-8 * __builtin_fabs(g1)) {
+                g0 = g1;
+                ++it;
+                const double ex = exp(mw * (alpha_n + s23 * g0));
+                xr = (sigtrn - two_mu * g0) - s23 * (y0 + dy * (1.0 - ex));
+                xg = m2mu - c23dyw * ex;
+                g1 = g0 - xr / xg;
+                if (it > 100) {
+                    failed = true;
+                    break;
+                }
+            }
+            const double ex = exp(mw * (alpha_n + s23 * g1));
+            xg = m2mu - c23dyw * ex;
+            xc1 = -1.0 / xg;
+            xc2 = g1 / sigtrn;
+            gamma = g1;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) N[i] = sigtr[i] / sigtrn;
+            st.iters += (unsigned long long)it;
+            st.nonconv += failed ? 1ull : 0ull;
+        }
+        st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
+    }
+    const double kt = ka * tr_eps, tmg = two_mu * gamma;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double vol = i < 3 ? kt : kt * 0.0;
+        s[i] = s[i] + ((vol + dsig[i]) - tmg * N[i]);
+    }
+    // the full 3-D row goes back to the wrapper's cache, the mapped components to the caller
+    transpose_out<6, FULL, NT>(s, region, lane, a.cache3d + p0 * 6, npts * 6);
+    if constexpr (WRAP == 1) {
+        if (live) a.stress_out[p0 + lane] = s[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < SD; ++i) s_lo[i] = s[i];
+        transpose_out<SD, FULL, NT>(s_lo, region, lane, a.stress_out + p0 * SD, npts * SD);
+    }
+    if (mask != 0ull) {
+        double ep[6];
+        transpose_in<6>(ce, region, lane, ep);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + gamma * N[i];
+        transpose_out<6, FULL, NT>(ep, region, lane, a.h0_out + p0 * 6, npts * 6);
+        if (live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
+    }
+    if (a.tangent) {
+        const double B = two_mu * (1.0 - two_mu * xc2);
+        const double C = four_mu2 * (xc2 - xc1);
+        if constexpr (WRAP == 1) {
+            // entry [0][0] exactly as tangent_mises forms it
+            if (live) a.tangent[p0 + lane] = (T->a[0] + B * T->b[0]) + C * (N[0] * N[0]);
+        } else {
+            publish_tangent_params(region, lane, B, C, N);
+            wave_sync();
+            // block [0:4, 0:4]: 16 doubles = 8 chunks per point
+            const int nchunks = npts * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int q = k * kWave + lane;
+                const int p = q >> 3, r = q & 7;
+                const int i = r >> 1, j = 2 * (r & 1);
+                const double* t = region + 10 * p;
+                const d2 bc = reinterpret_cast<const d2*>(t)[0];
+                const double ni = t[2 + i];
+                const d2 nj = *reinterpret_cast<const d2*>(t + 2 + j);
+                const d2 ta = *reinterpret_cast<const d2*>(T->a + 6 * i + j);
+                const d2 tb = *reinterpret_cast<const d2*>(T->b + 6 * i + j);
+                d2 v;
+                v.x = (ta.x + bc.x * tb.x) + bc.y * (ni * nj.x);
+                v.y = (ta.y + bc.x * tb.y) + bc.y * (ni * nj.y);
+                if constexpr (FULL) {
+                    store16<NT>(a.tangent + p0 * 16 + 2 * q, v);
+                } else if (q < nchunks) {
+                    a.tangent[p0 * 16 + 2 * q] = v.x;
+                    a.tangent[p0 * 16 + 2 * q + 1] = v.y;
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
 // History write policy of the laws with one [alpha, eps_p(6)] row per point (comfe-rs Mises and
 // Drucker-Prager).  In place: only tiles with a plastic point change.  Out of place: every tile is
 // copied -- unless the caller runs the sparse trial-history protocol (a.hmask != nullptr, see
@@ -1267,6 +1421,36 @@ __global__ void __launch_bounds__(kWave) evaluate_lowdim_tail_kernel(const EvalA
     tile_lowdim<LAW, DIMS, false, false>(a, &T, region, p0, (int)(a.n - p0), (int)threadIdx.x);
 }
 
+// Fused wrapper kernels (VonMises3D under UniaxialStrainFrom3D / PlaneStrainFrom3D).
+template <int WRAP, bool NT>
+__global__ void __launch_bounds__(kBlock, 4) evaluate_wrapped_kernel(const EvalArgs a) {
+    __shared__ __attribute__((aligned(16))) Tables T;
+    __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
+    stage_tables(a, &T);
+    int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const long long nfull = a.n / kWave;
+    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
+    WaveStats st;
+    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride) {
+        asm volatile("" : "+v"(lane));
+        lane &= kWave - 1;
+        tile_von_mises_wrapped<WRAP, true, NT>(a, &T, scratch[wave], tile * kWave, kWave, lane, st);
+    }
+    flush_stats<LAW_VM3D>(a, st, lane);
+}
+
+template <int WRAP>
+__global__ void __launch_bounds__(kWave) evaluate_wrapped_tail_kernel(const EvalArgs a) {
+    __shared__ __attribute__((aligned(16))) Tables T;
+    __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
+    stage_tables(a, &T);
+    const long long p0 = (a.n / kWave) * kWave;
+    WaveStats st;
+    tile_von_mises_wrapped<WRAP, false, false>(a, &T, region, p0, (int)(a.n - p0), (int)threadIdx.x, st);
+    flush_stats<LAW_VM3D>(a, st, (int)threadIdx.x);
+}
+
 // Tail kernel: the last, ragged tile (n % 64 points), one wavefront, guarded 8-byte accesses.
 template <int LAW, bool IDX, bool SPARSE = false>
 __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) {
@@ -1394,6 +1578,22 @@ hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hi
         case LAW_COMFE_DP_HYPER: return launch_law<LAW_COMFE_DP_HYPER>(args, grid, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+template <int WRAP>
+static hipError_t launch_wrapped(const EvalArgs& args, int grid, hipStream_t stream) {
+    if (args.n >= kWave)
+        hipLaunchKernelGGL((evaluate_wrapped_kernel<WRAP, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+    if (args.n % kWave != 0)
+        hipLaunchKernelGGL((evaluate_wrapped_tail_kernel<WRAP>), dim3(1), dim3(kWave), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_evaluate_wrapped(int wrap, const EvalArgs& args, int grid, hipStream_t stream) {
+    if (args.n <= 0) return hipSuccess;
+    if (wrap == 1) return launch_wrapped<1>(args, grid, stream);
+    if (wrap == 2) return launch_wrapped<2>(args, grid, stream);
+    return hipErrorInvalidValue;
 }
 
 int default_grid(int law, int num_cu) {

@@ -4,7 +4,9 @@ Same contract as the reference classes: a FULL (3-D) model is driven with 1-D / 
 copying the mapped components into cached 3-D arrays, evaluating the 3-D model and copying the
 mapped components back; the history is the 3-D model's.  Here the cached 3-D arrays live on
 the GPU and the component maps are device kernels (``fcamd_convert_device``), so a 1-D/2-D
-problem moves only its own small arrays over PCIe:
+problem moves only its own small arrays over PCIe.  Around ``VonMises3D`` the three steps are one
+fused kernel (``fcamd_evaluate_device_wrapped``): only the cached 3-D stress exists, no 3-D
+gradient or tangent array:
 
 * NumPy in  -> low-dimensional arrays are uploaded, expanded, evaluated, shrunk, downloaded;
 * torch ROCm tensors in -> zero copies.
@@ -29,6 +31,8 @@ __all__ = ["UniaxialStrainFrom3D", "PlaneStrainFrom3D"]
 class _From3D(IncrSmallStrainModel):
     _constraint: StressStrainConstraint
     _kinds: tuple[int, int, int, int]  # grad->3d, stress->3d, stress<-3d, tangent<-3d
+    #: use the fused kernel where one exists (VonMises3D); False forces map -> evaluate -> map
+    fused = True
 
     def __init__(self, model: IncrSmallStrainModel) -> None:
         assert model.constraint.name == "FULL"
@@ -71,6 +75,21 @@ class _From3D(IncrSmallStrainModel):
             dev = g_lo.device
         n = g_lo.numel() // gd2
         assert n == s_lo.numel() // sd == t_lo.numel() // (sd * sd)
+        if self.fused and getattr(self.model, "_model_id", None) == _capi.VON_MISES_3D:
+            # fused kernel (fcamd_evaluate_device_wrapped): only the cached 3-D stress exists
+            if self.stress_3d is None or self.stress_3d.numel() != 6 * n or self.stress_3d.device != dev:
+                self.stress_3d = torch.zeros(6 * n, dtype=torch.float64, device=dev)
+            hist = self.model._history_arrays(h_dev)
+            for h in hist:
+                _check_torch("history", h)
+            m = self.model._handle(dev.index or 0)
+            m.ctx.set_stream(_current_stream_ptr(dev.index or 0))
+            m.evaluate_device_wrapped(self._constraint.value, t, del_t, n, g_lo.data_ptr(), s_lo.data_ptr(),
+                                      t_lo.data_ptr(), self.stress_3d.data_ptr(), [h.data_ptr() for h in hist])
+            if host:
+                self.model.device_stats(dev.index or 0)  # raises on Newton non-convergence like the reference
+                self._download(stress, tangent, history, s_lo, t_lo, h_dev)
+            return
         if self.grad_del_u_3d is None or self.grad_del_u_3d.numel() != 9 * n or self.grad_del_u_3d.device != dev:
             # cached 3-D arrays (utils.py:253-266): zero-initialised once, unmapped components persist
             self.grad_del_u_3d = torch.zeros(9 * n, dtype=torch.float64, device=dev)
@@ -85,11 +104,15 @@ class _From3D(IncrSmallStrainModel):
         self._convert(ctx, k_tb, n, self.tangent_3d, t_lo)
         self._convert(ctx, k_sb, n, self.stress_3d, s_lo)
         if host:
-            stress[:] = s_lo.cpu().numpy()
-            tangent[:] = t_lo.cpu().numpy()
-            if history is not None:
-                for k in history:
-                    history[k][:] = h_dev[k].cpu().numpy()
+            self._download(stress, tangent, history, s_lo, t_lo, h_dev)
+
+    @staticmethod
+    def _download(stress, tangent, history, s_lo, t_lo, h_dev):
+        stress[:] = s_lo.cpu().numpy()
+        tangent[:] = t_lo.cpu().numpy()
+        if history is not None:
+            for k in history:
+                history[k][:] = h_dev[k].cpu().numpy()
 
 
 class UniaxialStrainFrom3D(_From3D):

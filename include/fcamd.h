@@ -177,6 +177,19 @@ int fcamd_evaluate_device_indexed(fcamd_model* model, double t, double del_t, in
                                   const double* const* history_prev, double* const* history,
                                   int n_hist);
 
+/* Fused form of the reference's 3D -> 1D/2D wrappers around VonMises3D (UniaxialStrainFrom3D /
+   PlaneStrainFrom3D, models/utils.py:211-412): `grad_lo`, `stress_lo`, `tangent_lo` are the
+   low-dimensional arrays (1 / 1 / 1 doubles per point for FCAMD_UNIAXIAL_STRAIN, 4 / 4 / 16 for
+   FCAMD_PLANE_STRAIN), `stress_3d` (6 n) is the wrapper's cached 3-D stress whose unmapped
+   components persist from call to call (utils.py:253-266; zero-initialised by the caller), the
+   history is the 3-D law's, everything in place.  One kernel replaces map -> evaluate -> map;
+   no 3-D gradient or tangent array exists.  Other laws: FCAMD_ERR_UNSUPPORTED (use
+   fcamd_convert_device around fcamd_evaluate_device). */
+int fcamd_evaluate_device_wrapped(fcamd_model* model, int wrapper_constraint, double t, double del_t,
+                                  int64_t n, const double* grad_lo, double* stress_lo,
+                                  double* tangent_lo, double* stress_3d, double* const* history,
+                                  int n_hist);
+
 /* General device entry: every option of the forms above in one call.  `parent_rows` (nullable)
    selects the submesh-indexed addressing of stress / tangent, `history_mask` (nullable) the sparse
    trial-history protocol (plasticity laws; the mask and the history arrays are local to the

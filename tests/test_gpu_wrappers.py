@@ -64,3 +64,32 @@ def test_plane_strain_equals_constrained_3d():
     fc.PlaneStrainFrom3D(fc.LinearElasticityModel(PARAMS["le"], FULL)).evaluate(0, 1, g2, s2, t2, None)
     assert np.array_equal(s2.reshape(-1, 4), s3.reshape(-1, 6)[:, :4])
     assert np.array_equal(t2.reshape(-1, 4, 4), t3.reshape(-1, 6, 6)[:, :4, :4])
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4097])
+@pytest.mark.parametrize("kind", ["plane_strain", "uniaxial_strain"])
+def test_fused_wrapper_equals_map_evaluate_map(kind, n):
+    """VonMises3D: the fused kernel (fcamd_evaluate_device_wrapped) and the generic map -> 3-D evaluate ->
+    map sequence give bit-identical stress, tangent, history and cached 3-D stress over several calls with
+    growing plastic sets (the cached lateral stresses of the uniaxial wrapper carry over between calls)."""
+    rng = np.random.default_rng(n)
+    W = fc.PlaneStrainFrom3D if kind == "plane_strain" else fc.UniaxialStrainFrom3D
+    a, b = W(fc.VonMises3D(PARAMS["vm"])), W(fc.VonMises3D(PARAMS["vm"]))
+    b.fused = False
+    gd2, sd = a.geometric_dim**2, a.stress_strain_dim
+    d = lambda x: torch.from_numpy(x.copy()).cuda()  # noqa: E731
+    s0 = rng.normal(scale=30.0, size=sd * n)
+    h0 = {"eps_n": rng.normal(scale=1e-3, size=6 * n), "alpha": rng.uniform(0, 0.02, size=n)}
+    sa, sb = d(s0), d(s0)
+    ha, hb = {k: d(v) for k, v in h0.items()}, {k: d(v) for k, v in h0.items()}
+    ta, tb = torch.zeros(sd * sd * n, dtype=torch.float64, device="cuda"), torch.zeros(sd * sd * n, dtype=torch.float64, device="cuda")
+    for call in range(4):
+        g = rng.normal(size=gd2 * n) * np.repeat(10 ** rng.uniform(-4, -2 + 0.1 * call, size=n), gd2)
+        a.evaluate(0.0, 1.0, d(g), sa, ta, ha)
+        b.evaluate(0.0, 1.0, d(g), sb, tb, hb)
+        assert torch.equal(sa, sb) and torch.equal(ta, tb), (kind, n, call)
+        assert torch.equal(a.stress_3d, b.stress_3d)
+        for k in ha:
+            assert torch.equal(ha[k], hb[k]), k
+    assert a.grad_del_u_3d is None and a.tangent_3d is None and b.tangent_3d is not None
+    assert a.model.device_stats().n_plastic > 0 or n < 10
