@@ -730,8 +730,8 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
                            reinterpret_cast<const void* const*>(hist),
                            reinterpret_cast<const void* const*>(hist), n_hist);
     if (st != FCAMD_OK) return st;
-    if (m->law != FCAMD_VON_MISES_3D)
-        return fail(FCAMD_ERR_UNSUPPORTED, "the fused 3D wrapper kernel exists for VonMises3D only");
+    if (m->law != FCAMD_VON_MISES_3D && m->law != FCAMD_COMFE_MISES_PLASTICITY)
+        return fail(FCAMD_ERR_UNSUPPORTED, "the fused 3D wrapper kernel exists for the two Mises laws only");
     const int wrap = wrapper_constraint == FCAMD_UNIAXIAL_STRAIN ? 1 : wrapper_constraint == FCAMD_PLANE_STRAIN ? 2 : 0;
     if (!wrap) return fail(FCAMD_ERR_BAD_ARG, "wrapper constraint must be UNIAXIAL_STRAIN or PLANE_STRAIN");
     if (n > 0 && !stress_3d) return fail(FCAMD_ERR_BAD_ARG, "stress_3d is NULL");
@@ -748,7 +748,7 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
     a.stress_out = stress_lo;
     a.tangent = tangent_lo;
     a.h0_in = a.h0_out = hist[0];
-    a.h1_in = a.h1_out = hist[1];
+    a.h1_in = a.h1_out = m->info.n_hist > 1 ? hist[1] : nullptr;
     a.rows = nullptr;
     a.hmask = nullptr;
     a.cache3d = stress_3d;
@@ -758,7 +758,7 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
     fill_constants(m, del_t, &a);
     HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->stream));
     if (n == 0) return FCAMD_OK;
-    HIP_TRY(launch_evaluate_wrapped(wrap, a, grid_for(m, n), c->stream));
+    HIP_TRY(launch_evaluate_wrapped(m->law, wrap, a, grid_for(m, n), c->stream));
     return FCAMD_OK;
 }
 

@@ -57,10 +57,11 @@ struct EvalArgs {
 // Launch the evaluate kernel of `law` on `stream` with `grid` workgroups of 256 threads.
 // dims = geometric dimension of the constraint (3: FULL; 2: plane strain/stress; 1: uniaxial)
 hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hipStream_t stream);
-// Fused 3D -> uniaxial-strain (wrap = 1) / plane-strain (wrap = 2) wrapper around VonMises3D: grad,
+// Fused 3D -> uniaxial-strain (wrap = 1) / plane-strain (wrap = 2) wrapper around VonMises3D or the
+// comfe-rs Mises law: grad,
 // stress_in/out and tangent are the LOW-dimensional arrays, cache3d the wrapper's 3-D stress, history
 // the 3-D law's (in place).
-hipError_t launch_evaluate_wrapped(int wrap, const EvalArgs& args, int grid, hipStream_t stream);
+hipError_t launch_evaluate_wrapped(int law, int wrap, const EvalArgs& args, int grid, hipStream_t stream);
 // Occupancy-derived default grid (workgroups) for `law` on the current device.
 int default_grid(int law, int num_cu);
 // strain_from_grad_u, FULL.

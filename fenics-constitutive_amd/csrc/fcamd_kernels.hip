@@ -650,44 +650,112 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     }
 }
 
-// --- VonMises3D behind the reference's 3D -> 1D/2D wrappers, fused -----------------------------
+// --- the reference's 3D -> 1D/2D wrappers, fused (VonMises3D, comfe-rs Mises) ---------------------
 // UniaxialStrainFrom3D / PlaneStrainFrom3D (models/utils.py:211-412) copy the mapped components of the
 // low-dimensional gradient and stress into cached 3-D arrays, call the 3-D law, and copy the mapped
 // components of stress and tangent back.  The cached 3-D stress keeps its unmapped components from
 // the previous call (utils.py:253-266: under uniaxial strain the lateral stresses live only there).
 // Here one kernel does all of it: per tile it reads the low-dimensional gradient and stress plus the
-// cached 3-D stress row, runs the VonMises3D update of tile_von_mises on the padded point, and writes
-// the full row back to the cache and the mapped components to the caller's arrays.  No 3-D gradient
-// or tangent array exists.  WRAP = 1: component 11 of everything; WRAP = 2: gradient (0,1,2,3) ->
-// (0,1,3,4), Mandel components 0..3, tangent block [0:4, 0:4] (utils.py:282-297, 377-412).
-// In place only (the wrappers have no out-of-place form).
+// cached 3-D stress row, runs the law's update on the padded point, and writes the full row back to
+// the cache and the mapped components to the caller's arrays.  No 3-D gradient or tangent array
+// exists.  WRAP = 1: component 11 of everything; WRAP = 2: gradient (0,1,2,3) -> (0,1,3,4), Mandel
+// components 0..3, tangent block [0:4, 0:4] (utils.py:282-297, 377-412).  In place only (the wrappers
+// have no out-of-place form).  The per-point arithmetic below repeats tile_von_mises /
+// tile_comfe_mises statement for statement; tests/test_gpu_wrappers.py holds both to bit equality.
+
+// inputs of a wrapped tile: padded gradient g[9] and the 3-D stress row s[6] (cache + mapped components)
 template <int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const Tables* T, double* region,
-                                                       long long p0, int npts, int lane, WaveStats& st) {
-    constexpr int GD = WRAP == 1 ? 1 : 4;  // doubles per point of the low-dimensional gradient
-    constexpr int SD = WRAP == 1 ? 1 : 4;  // ... of the low-dimensional stress
+__device__ __forceinline__ void wrapped_load(const EvalArgs& a, double* region, long long p0, int npts, int lane,
+                                             double (&g)[9], double (&s)[6]) {
+    constexpr int LD = WRAP == 1 ? 1 : 4;  // doubles per point of the low-dimensional gradient and stress
     const bool live = FULL || lane < npts;
     Chunks<6> cc;
     tile_load<6, FULL, NT>(cc, a.cache3d + p0 * 6, npts * 6, lane);
-    double g[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, s[6], e[6];
-    double s_lo[SD];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i] = 0.0;
+    double s_lo[LD];
     if constexpr (WRAP == 1) {
         g[0] = live ? a.grad[p0 + lane] : 0.0;
         s_lo[0] = live ? a.stress_in[p0 + lane] : 0.0;
     } else {
-        Chunks<GD> cg;
-        Chunks<SD> cs;
-        tile_load<GD, FULL, NT>(cg, a.grad + p0 * GD, npts * GD, lane);
-        tile_load<SD, FULL, NT>(cs, a.stress_in + p0 * SD, npts * SD, lane);
-        double g_lo[GD];
-        transpose_in<GD>(cg, region, lane, g_lo);
-        transpose_in<SD>(cs, region, lane, s_lo);
+        Chunks<LD> cg, cs;
+        tile_load<LD, FULL, NT>(cg, a.grad + p0 * LD, npts * LD, lane);
+        tile_load<LD, FULL, NT>(cs, a.stress_in + p0 * LD, npts * LD, lane);
+        double g_lo[LD];
+        transpose_in<LD>(cg, region, lane, g_lo);
+        transpose_in<LD>(cs, region, lane, s_lo);
         g[0] = g_lo[0], g[1] = g_lo[1], g[3] = g_lo[2], g[4] = g_lo[3];
     }
-    const double alpha_n = live ? a.h1_in[p0 + lane] : 0.0;
     transpose_in<6>(cc, region, lane, s);
 #pragma unroll
-    for (int i = 0; i < SD; ++i) s[i] = s_lo[i];  // mapped components come from the caller, the others persist
+    for (int i = 0; i < LD; ++i) s[i] = s_lo[i];  // mapped components come from the caller, the others persist
+}
+
+// the full 3-D row goes back to the wrapper's cache, the mapped components to the caller
+template <int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void wrapped_store_stress(const EvalArgs& a, double* region, long long p0, int npts,
+                                                     int lane, const double (&s)[6]) {
+    transpose_out<6, FULL, NT>(s, region, lane, a.cache3d + p0 * 6, npts * 6);
+    if constexpr (WRAP == 1) {
+        if (FULL || lane < npts) a.stress_out[p0 + lane] = s[0];
+    } else {
+        double s_lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_lo[i] = s[i];
+        transpose_out<4, FULL, NT>(s_lo, region, lane, a.stress_out + p0 * 4, npts * 4);
+    }
+}
+
+// mapped block of the Mises tangents, entries formed exactly as tangent_mises does
+template <bool COMFE, int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void wrapped_tangent_mises(const EvalArgs& a, const Tables* T, double* region,
+                                                      long long p0, int npts, int lane, double B, double C,
+                                                      const double (&N)[6]) {
+    if constexpr (WRAP == 1) {
+        if (FULL || lane < npts)
+            a.tangent[p0 + lane] = COMFE ? (T->a[0] + B * T->b[0]) + (C * N[0]) * N[0]
+                                         : (T->a[0] + B * T->b[0]) + C * (N[0] * N[0]);
+    } else {
+        publish_tangent_params(region, lane, B, C, N);
+        wave_sync();
+        const int nchunks = npts * 8;  // block [0:4, 0:4]: 16 doubles = 8 chunks per point
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = k * kWave + lane;
+            const int p = q >> 3, r = q & 7;
+            const int i = r >> 1, j = 2 * (r & 1);
+            const double* t = region + 10 * p;
+            const d2 bc = reinterpret_cast<const d2*>(t)[0];
+            const double ni = t[2 + i];
+            const d2 nj = *reinterpret_cast<const d2*>(t + 2 + j);
+            const d2 ta = *reinterpret_cast<const d2*>(T->a + 6 * i + j);
+            const d2 tb = *reinterpret_cast<const d2*>(T->b + 6 * i + j);
+            d2 v;
+            if constexpr (COMFE) {
+                v.x = (ta.x + bc.x * tb.x) + (bc.y * nj.x) * ni;
+                v.y = (ta.y + bc.x * tb.y) + (bc.y * nj.y) * ni;
+            } else {
+                v.x = (ta.x + bc.x * tb.x) + bc.y * (ni * nj.x);
+                v.y = (ta.y + bc.x * tb.y) + bc.y * (ni * nj.y);
+            }
+            if constexpr (FULL) {
+                store16<NT>(a.tangent + p0 * 16 + 2 * q, v);
+            } else if (q < nchunks) {
+                a.tangent[p0 * 16 + 2 * q] = v.x;
+                a.tangent[p0 * 16 + 2 * q + 1] = v.y;
+            }
+        }
+        wave_sync();
+    }
+}
+
+template <int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const Tables* T, double* region,
+                                                       long long p0, int npts, int lane, WaveStats& st) {
+    const bool live = FULL || lane < npts;
+    double g[9], s[6], e[6];
+    const double alpha_n = live ? a.h1_in[p0 + lane] : 0.0;
+    wrapped_load<WRAP, FULL, NT>(a, region, p0, npts, lane, g, s);
     mandel_strain(g, a.sc.s[0], e);
 
     const double ka = a.sc.s[1], two_mu = a.sc.s[2], s23 = a.sc.s[3], y0 = a.sc.s[4], dy = a.sc.s[5],
@@ -750,15 +818,7 @@ __device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const 
         const double vol = i < 3 ? kt : kt * 0.0;
         s[i] = s[i] + ((vol + dsig[i]) - tmg * N[i]);
     }
-    // the full 3-D row goes back to the wrapper's cache, the mapped components to the caller
-    transpose_out<6, FULL, NT>(s, region, lane, a.cache3d + p0 * 6, npts * 6);
-    if constexpr (WRAP == 1) {
-        if (live) a.stress_out[p0 + lane] = s[0];
-    } else {
-#pragma unroll
-        for (int i = 0; i < SD; ++i) s_lo[i] = s[i];
-        transpose_out<SD, FULL, NT>(s_lo, region, lane, a.stress_out + p0 * SD, npts * SD);
-    }
+    wrapped_store_stress<WRAP, FULL, NT>(a, region, p0, npts, lane, s);
     if (mask != 0ull) {
         double ep[6];
         transpose_in<6>(ce, region, lane, ep);
@@ -770,37 +830,73 @@ __device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const 
     if (a.tangent) {
         const double B = two_mu * (1.0 - two_mu * xc2);
         const double C = four_mu2 * (xc2 - xc1);
-        if constexpr (WRAP == 1) {
-            // entry [0][0] exactly as tangent_mises forms it
-            if (live) a.tangent[p0 + lane] = (T->a[0] + B * T->b[0]) + C * (N[0] * N[0]);
-        } else {
-            publish_tangent_params(region, lane, B, C, N);
-            wave_sync();
-            // block [0:4, 0:4]: 16 doubles = 8 chunks per point
-            const int nchunks = npts * 8;
+        wrapped_tangent_mises<false, WRAP, FULL, NT>(a, T, region, p0, npts, lane, B, C, N);
+    }
+}
+
+template <int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void tile_comfe_mises_wrapped(const EvalArgs& a, const Tables* T, double* region,
+                                                         long long p0, int npts, int lane, WaveStats& st) {
+    const bool live = FULL || lane < npts;
+    Chunks<7> ch;
+    tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
+    double g[9], s[6], h[7], e[6];
+    wrapped_load<WRAP, FULL, NT>(a, region, p0, npts, lane, g, s);
+    transpose_in<7>(ch, region, lane, h);
+    mandel_strain(g, a.sc.s[0], e);
+
+    const double kappa = a.sc.s[2], y_0 = a.sc.s[3], hh = a.sc.s[4], two_mu = a.sc.s[5],
+                 den = a.sc.s[6], s32 = a.sc.s[7], three_mu = a.sc.s[8], hfac = a.sc.s[9];
+    const double alpha = h[0];
+    const double p_0 = ((s[0] + s[1]) + s[2]) / 3.0;
+    const double eps_trace = (e[0] + e[1]) + e[2];
+    const double eps_vol = eps_trace / 3.0;
+    const double p_1 = p_0 + kappa * eps_trace;
+    double s_tr[6];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int q = k * kWave + lane;
-                const int p = q >> 3, r = q & 7;
-                const int i = r >> 1, j = 2 * (r & 1);
-                const double* t = region + 10 * p;
-                const d2 bc = reinterpret_cast<const d2*>(t)[0];
-                const double ni = t[2 + i];
-                const d2 nj = *reinterpret_cast<const d2*>(t + 2 + j);
-                const d2 ta = *reinterpret_cast<const d2*>(T->a + 6 * i + j);
-                const d2 tb = *reinterpret_cast<const d2*>(T->b + 6 * i + j);
-                d2 v;
-                v.x = (ta.x + bc.x * tb.x) + bc.y * (ni * nj.x);
-                v.y = (ta.y + bc.x * tb.y) + bc.y * (ni * nj.y);
-                if constexpr (FULL) {
-                    store16<NT>(a.tangent + p0 * 16 + 2 * q, v);
-                } else if (q < nchunks) {
-                    a.tangent[p0 * 16 + 2 * q] = v.x;
-                    a.tangent[p0 * 16 + 2 * q + 1] = v.y;
-                }
-            }
-            wave_sync();
+    for (int i = 0; i < 6; ++i) {
+        const double s0 = i < 3 ? s[i] + (-p_0) : s[i];
+        const double ed = i < 3 ? e[i] + (-eps_vol) : e[i];
+        s_tr[i] = s0 + two_mu * ed;
+    }
+    const double v3 = ((s_tr[0] + s_tr[1]) + s_tr[2]) / 3.0;
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double d = i < 3 ? s_tr[i] + (-v3) : s_tr[i];
+        n2 = i == 0 ? d * d : n2 + d * d;
+    }
+    const double q = sqrt(3.0 * (0.5 * n2));
+    const double sigma_y = y_0 + hh * alpha;
+    const bool plastic = live && !(q < sigma_y);
+    const unsigned long long mask = __ballot(plastic);
+
+    double theta = 1.0, sc = 0.0;
+    double nv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (plastic) {
+        const double del_alpha = (q - sigma_y) / den;
+        const double del_gamma = s32 * del_alpha;
+        theta = 1.0 - (three_mu * del_alpha) / q;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            nv[i] = s_tr[i] / q;
+            h[1 + i] = h[1 + i] + del_gamma * nv[i];
         }
+        h[0] = alpha + del_alpha;
+        const double theta_bar = hfac - (1.0 - theta);
+        sc = two_mu * theta_bar;
+    }
+    st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double ts = theta * s_tr[i];
+        s[i] = i < 3 ? p_1 + ts : ts;
+    }
+    wrapped_store_stress<WRAP, FULL, NT>(a, region, p0, npts, lane, s);
+    if (mask != 0ull) transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+    if (a.tangent) {
+        const double B = plastic ? two_mu * theta : two_mu;
+        wrapped_tangent_mises<true, WRAP, FULL, NT>(a, T, region, p0, npts, lane, B, sc, nv);
     }
 }
 
@@ -1422,7 +1518,16 @@ __global__ void __launch_bounds__(kWave) evaluate_lowdim_tail_kernel(const EvalA
 }
 
 // Fused wrapper kernels (VonMises3D under UniaxialStrainFrom3D / PlaneStrainFrom3D).
-template <int WRAP, bool NT>
+template <int LAW, int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void run_wrapped_tile(const EvalArgs& a, const Tables* T, double* region, long long p0,
+                                                 int npts, int lane, WaveStats& st) {
+    if constexpr (LAW == LAW_VM3D)
+        tile_von_mises_wrapped<WRAP, FULL, NT>(a, T, region, p0, npts, lane, st);
+    else
+        tile_comfe_mises_wrapped<WRAP, FULL, NT>(a, T, region, p0, npts, lane, st);
+}
+
+template <int LAW, int WRAP, bool NT>
 __global__ void __launch_bounds__(kBlock, 4) evaluate_wrapped_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
@@ -1435,20 +1540,20 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_wrapped_kernel(const EvalA
     for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride) {
         asm volatile("" : "+v"(lane));
         lane &= kWave - 1;
-        tile_von_mises_wrapped<WRAP, true, NT>(a, &T, scratch[wave], tile * kWave, kWave, lane, st);
+        run_wrapped_tile<LAW, WRAP, true, NT>(a, &T, scratch[wave], tile * kWave, kWave, lane, st);
     }
-    flush_stats<LAW_VM3D>(a, st, lane);
+    flush_stats<LAW>(a, st, lane);
 }
 
-template <int WRAP>
+template <int LAW, int WRAP>
 __global__ void __launch_bounds__(kWave) evaluate_wrapped_tail_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
     stage_tables(a, &T);
     const long long p0 = (a.n / kWave) * kWave;
     WaveStats st;
-    tile_von_mises_wrapped<WRAP, false, false>(a, &T, region, p0, (int)(a.n - p0), (int)threadIdx.x, st);
-    flush_stats<LAW_VM3D>(a, st, (int)threadIdx.x);
+    run_wrapped_tile<LAW, WRAP, false, false>(a, &T, region, p0, (int)(a.n - p0), (int)threadIdx.x, st);
+    flush_stats<LAW>(a, st, (int)threadIdx.x);
 }
 
 // Tail kernel: the last, ragged tile (n % 64 points), one wavefront, guarded 8-byte accesses.
@@ -1580,20 +1685,25 @@ hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hi
     }
 }
 
-template <int WRAP>
+template <int LAW, int WRAP>
 static hipError_t launch_wrapped(const EvalArgs& args, int grid, hipStream_t stream) {
     if (args.n >= kWave)
-        hipLaunchKernelGGL((evaluate_wrapped_kernel<WRAP, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+        hipLaunchKernelGGL((evaluate_wrapped_kernel<LAW, WRAP, true>), dim3(grid), dim3(kBlock), 0, stream, args);
     if (args.n % kWave != 0)
-        hipLaunchKernelGGL((evaluate_wrapped_tail_kernel<WRAP>), dim3(1), dim3(kWave), 0, stream, args);
+        hipLaunchKernelGGL((evaluate_wrapped_tail_kernel<LAW, WRAP>), dim3(1), dim3(kWave), 0, stream, args);
     return hipGetLastError();
 }
 
-hipError_t launch_evaluate_wrapped(int wrap, const EvalArgs& args, int grid, hipStream_t stream) {
+hipError_t launch_evaluate_wrapped(int law, int wrap, const EvalArgs& args, int grid, hipStream_t stream) {
     if (args.n <= 0) return hipSuccess;
-    if (wrap == 1) return launch_wrapped<1>(args, grid, stream);
-    if (wrap == 2) return launch_wrapped<2>(args, grid, stream);
-    return hipErrorInvalidValue;
+    if (wrap != 1 && wrap != 2) return hipErrorInvalidValue;
+    switch (law) {
+        case LAW_VM3D: return wrap == 1 ? launch_wrapped<LAW_VM3D, 1>(args, grid, stream) : launch_wrapped<LAW_VM3D, 2>(args, grid, stream);
+        case LAW_COMFE_MISES:
+            return wrap == 1 ? launch_wrapped<LAW_COMFE_MISES, 1>(args, grid, stream)
+                             : launch_wrapped<LAW_COMFE_MISES, 2>(args, grid, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 int default_grid(int law, int num_cu) {

@@ -66,20 +66,33 @@ def test_plane_strain_equals_constrained_3d():
     assert np.array_equal(t2.reshape(-1, 4, 4), t3.reshape(-1, 6, 6)[:, :4, :4])
 
 
+def _mises_law(lname):
+    if lname == "vm":
+        return fc.VonMises3D(PARAMS["vm"])
+    return fc.MisesPlasticityLinearHardening3D(
+        {k: np.array([v]) for k, v in {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0}.items()})
+
+
+@pytest.mark.parametrize("lname", ["vm", "comfe_mises"])
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4097])
 @pytest.mark.parametrize("kind", ["plane_strain", "uniaxial_strain"])
-def test_fused_wrapper_equals_map_evaluate_map(kind, n):
-    """VonMises3D: the fused kernel (fcamd_evaluate_device_wrapped) and the generic map -> 3-D evaluate ->
+def test_fused_wrapper_equals_map_evaluate_map(kind, n, lname):
+    """The two Mises laws: the fused kernel (fcamd_evaluate_device_wrapped) and the generic map -> 3-D evaluate ->
     map sequence give bit-identical stress, tangent, history and cached 3-D stress over several calls with
     growing plastic sets (the cached lateral stresses of the uniaxial wrapper carry over between calls)."""
     rng = np.random.default_rng(n)
     W = fc.PlaneStrainFrom3D if kind == "plane_strain" else fc.UniaxialStrainFrom3D
-    a, b = W(fc.VonMises3D(PARAMS["vm"])), W(fc.VonMises3D(PARAMS["vm"]))
+    a, b = W(_mises_law(lname)), W(_mises_law(lname))
     b.fused = False
     gd2, sd = a.geometric_dim**2, a.stress_strain_dim
     d = lambda x: torch.from_numpy(x.copy()).cuda()  # noqa: E731
     s0 = rng.normal(scale=30.0, size=sd * n)
-    h0 = {"eps_n": rng.normal(scale=1e-3, size=6 * n), "alpha": rng.uniform(0, 0.02, size=n)}
+    if lname == "vm":
+        h0 = {"eps_n": rng.normal(scale=1e-3, size=6 * n), "alpha": rng.uniform(0, 0.02, size=n)}
+    else:
+        hh = rng.normal(scale=1e-3, size=7 * n)
+        hh.reshape(-1, 7)[:, 0] = rng.uniform(0, 0.02, size=n)
+        h0 = {"history": hh}
     sa, sb = d(s0), d(s0)
     ha, hb = {k: d(v) for k, v in h0.items()}, {k: d(v) for k, v in h0.items()}
     ta, tb = torch.zeros(sd * sd * n, dtype=torch.float64, device="cuda"), torch.zeros(sd * sd * n, dtype=torch.float64, device="cuda")
