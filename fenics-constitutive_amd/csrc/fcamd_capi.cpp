@@ -730,8 +730,8 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
                            reinterpret_cast<const void* const*>(hist),
                            reinterpret_cast<const void* const*>(hist), n_hist);
     if (st != FCAMD_OK) return st;
-    if (m->law != FCAMD_VON_MISES_3D && m->law != FCAMD_COMFE_MISES_PLASTICITY)
-        return fail(FCAMD_ERR_UNSUPPORTED, "the fused 3D wrapper kernel exists for the two Mises laws only");
+    if (!has_sparse_history(m->law))  // = the plasticity laws
+        return fail(FCAMD_ERR_UNSUPPORTED, "the fused 3D wrapper kernel exists for the plasticity laws only");
     const int wrap = wrapper_constraint == FCAMD_UNIAXIAL_STRAIN ? 1 : wrapper_constraint == FCAMD_PLANE_STRAIN ? 2 : 0;
     if (!wrap) return fail(FCAMD_ERR_BAD_ARG, "wrapper constraint must be UNIAXIAL_STRAIN or PLANE_STRAIN");
     if (n > 0 && !stress_3d) return fail(FCAMD_ERR_BAD_ARG, "stress_3d is NULL");

@@ -1088,6 +1088,147 @@ __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11ta
     }
 }
 
+// trial state of one point: sigma_tr = E d_eps + sigma_0 = (I1_tr/3) 1 + s_tr   (E v = 2 mu dev v + kappa tr(v) 1)
+struct DPTrial {
+    double sig1[6], s_tr[6], I1_tr, n2;
+    DPInv m;
+    bool tip;
+};
+
+template <bool HYPER>
+__device__ __forceinline__ void dp_trial(const Scalars& sc, const double (&e)[6], const double (&sig0)[6], DPTrial& t) {
+    const double kappa = sc.s[2], a_ = sc.s[3], b = sc.s[4], dsq = sc.s[6], two_mu = sc.s[7];
+    {
+        const double tr = (e[0] + e[1]) + e[2], vol = tr / 3.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            t.sig1[i] = (i < 3 ? two_mu * (e[i] + (-vol)) + kappa * tr : two_mu * e[i]) + sig0[i];
+    }
+    t.I1_tr = (t.sig1[0] + t.sig1[1]) + t.sig1[2];
+    t.n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        t.s_tr[i] = i < 3 ? t.sig1[i] + (-(t.I1_tr / 3.0)) : t.sig1[i];
+        t.n2 = i == 0 ? t.s_tr[0] * t.s_tr[0] : t.n2 + t.s_tr[i] * t.s_tr[i];
+    }
+    t.tip = false;
+    t.m = dp_state<HYPER>(t.I1_tr, 1.0, t.n2, a_, b, dsq, t.tip);
+}
+
+// coefficients of the five-term tangent and the scale of the deviator (sigma = (I1/3) 1 + rho s_tr);
+// the defaults are the elastic point: T = E = kappa 1x1 + 2 mu P_dev
+struct DPTangent {
+    double t11, tP, tss = 0.0, t1s = 0.0, ts1 = 0.0, rho = 1.0;
+};
+
+// return mapping of one plastic point: Newton in invariant coordinates, converged stress in t.sig1,
+// history h = [alpha, plastic_strain(6)] updated, tangent coefficients in tg
+template <bool HYPER>
+__device__ __forceinline__ void dp_return(const Scalars& sc, const double (&e)[6], const double (&sig0)[6], DPTrial& t,
+                                          double (&h)[7], DPTangent& tg, WaveStats& st) {
+    const double kappa = sc.s[2], a_ = sc.s[3], b = sc.s[4], bflow = sc.s[5], dsq = sc.s[6], two_mu = sc.s[7],
+                 s23 = sc.s[8], inv4mu = sc.s[9], inv9k = sc.s[10];
+    const double I1_tr = t.I1_tr, n2 = t.n2;
+    DPInv m = t.m;
+    double rho = 1.0;
+    const double alpha_0 = h[0];
+    double I1 = I1_tr, dl = 0.0, alpha_1 = alpha_0;
+    double rv = 0.0, rd = 0.0, rf = m.f, rk = 0.0;
+    int it = 0;
+    bool failed = false;
+    for (;;) {
+        // Newton step with the Jacobian of the current state (m, rho, dl)
+        const double w = two_mu * dl;
+        const double Ad = 1.0 + w * (m.c1 + m.c2 * (rho * rho) * n2);
+        const double gn2 = 3.0 * (bflow * bflow) + (m.c1 * m.c1) * (rho * rho) * n2;
+        const double gnorm = sqrt(gn2), kk = s23 * gnorm;
+        const double cr = m.c1 * rho;  // coefficient of s_tr in g and df/dsigma
+        const double dlam = ((3.0 * b) * rv + (cr * n2) * (rd / Ad) - rf) /
+                            ((9.0 * kappa) * (b * bflow) + two_mu * (cr * cr) * n2 / Ad);
+        const double dv = rv - (3.0 * kappa * bflow) * dlam;
+        const double dd = (rd - (two_mu * cr) * dlam) / Ad;
+        const double dkds = (s23 / gnorm) * m.c1 * (m.c1 + m.c2 * (rho * rho) * n2) * rho * n2 * dd;
+        const double dkap = rk + dl * dkds + kk * dlam;
+        const double I1_prev = I1, rho_prev = rho, dl_prev = dl, al_prev = alpha_1;
+        I1 = I1 - 3.0 * dv;
+        rho = rho - dd;
+        dl = dl - dlam;
+        alpha_1 = alpha_1 - dkap;
+        m = dp_state<HYPER>(I1, rho, n2, a_, b, dsq, t.tip);
+        // residuals at the new state
+        const double gn2n = 3.0 * (bflow * bflow) + (m.c1 * m.c1) * (rho * rho) * n2;
+        rv = (I1 - I1_tr) / 3.0 + dl * (3.0 * kappa * bflow);
+        rd = (rho - 1.0) + dl * (two_mu * m.c1) * rho;
+        rf = m.f;
+        rk = (alpha_1 - alpha_0) - s23 * sqrt(gn2n);
+        const double atol = 1e-8, rtol = 1e-8;
+        const double dI = (I1 - I1_prev) / 3.0, dr = rho - rho_prev;
+        const bool conv_res = sqrt(3.0 * rv * rv + rd * rd * n2) < atol && fabs(rk) < atol && fabs(rf) < atol;
+        const bool conv_inc = sqrt(3.0 * dI * dI + dr * dr * n2) < atol + rtol * sqrt(I1 * I1 / 3.0 + rho * rho * n2) &&
+                              fabs(alpha_1 - al_prev) < atol + rtol * fabs(alpha_1) &&
+                              fabs(dl - dl_prev) < atol + rtol * fabs(dl);
+        if (conv_res || conv_inc) break;
+        if (it > 25) {
+            failed = true;
+            break;
+        }
+        ++it;
+    }
+    st.iters += (unsigned long long)(it + 1);
+    st.nonconv += failed ? 1ull : 0ull;
+    // converged stress, history
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t.sig1[i] = (i < 3 ? I1 / 3.0 : 0.0) + rho * t.s_tr[i];
+    h[0] = alpha_1;
+    {
+        double ds[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ds[i] = t.sig1[i] - sig0[i];
+        const double tr = (ds[0] + ds[1]) + ds[2], vol = tr / 3.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            // plastic_strain += d_eps - E^-1 (sigma_1 - sigma_0),  E^-1 = isotropic_elastic_tangent(1/(4 mu), 1/(9 kappa))
+            const double einv = i < 3 ? (2.0 * inv4mu) * (ds[i] + (-vol)) + (3.0 * inv9k) * vol : (2.0 * inv4mu) * ds[i];
+            h[1 + i] = h[1 + i] + (e[i] - einv);
+        }
+    }
+    // tangent from the inverse of the Jacobian at the final state (s = rho s_tr)
+    {
+        const double w = two_mu * dl, s2 = (rho * rho) * n2;
+        const double Ad = 1.0 + w * (m.c1 + m.c2 * s2);
+        const double alpha_d = 1.0 / (1.0 + w * m.c1);
+        const double beta = alpha_d * w * m.c2 / Ad;
+        const double uv = 3.0 * kappa * bflow, ud = two_mu * m.c1 / Ad;  // A^-1 E g       = uv 1 + ud s
+        const double vv = b, vd = m.c1 / Ad;                              // df/dsigma A^-1 = vv 1^T + vd s^T
+        const double D = 3.0 * vv * uv + vd * s2 * (two_mu * m.c1);
+        tg.t11 = kappa - 3.0 * kappa * uv * vv / D;
+        tg.tP = two_mu * alpha_d;
+        tg.tss = -two_mu * beta - two_mu * ud * vd / D;
+        tg.t1s = -two_mu * uv * vd / D;
+        tg.ts1 = -3.0 * kappa * ud * vv / D;
+        tg.rho = rho;
+    }
+}
+
+// this lane's 11 tangent parameters (+ plastic flag) into the wave's LDS region, stride kDpStride
+__device__ __forceinline__ void dp_publish(double* region, int lane, const DPTangent& tg, const double (&s_tr)[6],
+                                           bool plastic) {
+    double* t = region + kDpStride * lane;
+    d2 v;
+    v.x = tg.t11, v.y = tg.tP;
+    reinterpret_cast<d2*>(t)[0] = v;
+    v.x = tg.tss, v.y = tg.t1s;
+    reinterpret_cast<d2*>(t)[1] = v;
+    v.x = tg.ts1, v.y = plastic ? 1.0 : 0.0;
+    reinterpret_cast<d2*>(t)[2] = v;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v.x = tg.rho * s_tr[2 * i];
+        v.y = tg.rho * s_tr[2 * i + 1];
+        reinterpret_cast<d2*>(t)[3 + i] = v;
+    }
+}
+
 template <bool HYPER, bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBases& sb, const Tables* T,
                                               double* region, int* rows_lds, long long p0, int npts, int lane,
@@ -1106,147 +1247,105 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     sr.get(region, lane, sig0);
     transpose_in<7>(ch, region, lane, h);
     mandel_strain(g9, a.sc.s[0], e);
-    const double kappa = a.sc.s[2], a_ = a.sc.s[3], b = a.sc.s[4], bflow = a.sc.s[5], dsq = a.sc.s[6],
-                 two_mu = a.sc.s[7], s23 = a.sc.s[8], inv4mu = a.sc.s[9], inv9k = a.sc.s[10];
 
-    // sigma_tr = E d_eps + sigma_0 = (I1_tr/3) 1 + s_tr      (E v = 2 mu dev v + kappa tr(v) 1)
-    double sig1[6], s_tr[6];
-    {
-        const double tr = (e[0] + e[1]) + e[2], vol = tr / 3.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            sig1[i] = (i < 3 ? two_mu * (e[i] + (-vol)) + kappa * tr : two_mu * e[i]) + sig0[i];
-    }
-    const double I1_tr = (sig1[0] + sig1[1]) + sig1[2];
-    double n2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        s_tr[i] = i < 3 ? sig1[i] + (-(I1_tr / 3.0)) : sig1[i];
-        n2 = i == 0 ? s_tr[0] * s_tr[0] : n2 + s_tr[i] * s_tr[i];
-    }
-    bool tip = false;
-    DPInv m = dp_state<HYPER>(I1_tr, 1.0, n2, a_, b, dsq, tip);
-    const bool plastic = live && (m.f > 0.0);
+    DPTrial t;
+    dp_trial<HYPER>(a.sc, e, sig0, t);
+    const bool plastic = live && (t.m.f > 0.0);
     const unsigned long long mask = __ballot(plastic);
 
     if (mask == 0ull) {
         // fully elastic tile: stress = sigma_tr, tangent = E, history untouched
-        sr.put(sb, region, lane, sig1, p0, npts);
+        sr.put(sb, region, lane, t.sig1, p0, npts);
         if (history_tile_needs_write(a, p0, 0ull, hist_in_place, lane))
             transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
         if (sb.tan) {
             if constexpr (IDX) wave_sync();
             tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
         }
-        st.domain += (live && tip) ? 1ull : 0ull;
+        st.domain += (live && t.tip) ? 1ull : 0ull;
         return;
     }
 
-    // tangent parameters: elastic lanes T = E = kappa 1x1 + 2 mu P_dev
-    double t11 = kappa, tP = two_mu, tss = 0.0, t1s = 0.0, ts1 = 0.0, rho = 1.0;
-    if (plastic) {
-        const double alpha_0 = h[0];
-        double I1 = I1_tr, dl = 0.0, alpha_1 = alpha_0;
-        double rv = 0.0, rd = 0.0, rf = m.f, rk = 0.0;
-        int it = 0;
-        bool failed = false;
-        for (;;) {
-            // Newton step with the Jacobian of the current state (m, rho, dl)
-            const double w = two_mu * dl;
-            const double Ad = 1.0 + w * (m.c1 + m.c2 * (rho * rho) * n2);
-            const double gn2 = 3.0 * (bflow * bflow) + (m.c1 * m.c1) * (rho * rho) * n2;
-            const double gnorm = sqrt(gn2), kk = s23 * gnorm;
-            const double cr = m.c1 * rho;  // coefficient of s_tr in g and df/dsigma
-            const double dlam = ((3.0 * b) * rv + (cr * n2) * (rd / Ad) - rf) /
-                                ((9.0 * kappa) * (b * bflow) + two_mu * (cr * cr) * n2 / Ad);
-            const double dv = rv - (3.0 * kappa * bflow) * dlam;
-            const double dd = (rd - (two_mu * cr) * dlam) / Ad;
-            const double dkds = (s23 / gnorm) * m.c1 * (m.c1 + m.c2 * (rho * rho) * n2) * rho * n2 * dd;
-            const double dkap = rk + dl * dkds + kk * dlam;
-            const double I1_prev = I1, rho_prev = rho, dl_prev = dl, al_prev = alpha_1;
-            I1 = I1 - 3.0 * dv;
-            rho = rho - dd;
-            dl = dl - dlam;
-            alpha_1 = alpha_1 - dkap;
-            m = dp_state<HYPER>(I1, rho, n2, a_, b, dsq, tip);
-            // residuals at the new state
-            const double gn2n = 3.0 * (bflow * bflow) + (m.c1 * m.c1) * (rho * rho) * n2;
-            rv = (I1 - I1_tr) / 3.0 + dl * (3.0 * kappa * bflow);
-            rd = (rho - 1.0) + dl * (two_mu * m.c1) * rho;
-            rf = m.f;
-            rk = (alpha_1 - alpha_0) - s23 * sqrt(gn2n);
-            const double atol = 1e-8, rtol = 1e-8;
-            const double dI = (I1 - I1_prev) / 3.0, dr = rho - rho_prev;
-            const bool conv_res = sqrt(3.0 * rv * rv + rd * rd * n2) < atol && fabs(rk) < atol && fabs(rf) < atol;
-            const bool conv_inc = sqrt(3.0 * dI * dI + dr * dr * n2) < atol + rtol * sqrt(I1 * I1 / 3.0 + rho * rho * n2) &&
-                                  fabs(alpha_1 - al_prev) < atol + rtol * fabs(alpha_1) &&
-                                  fabs(dl - dl_prev) < atol + rtol * fabs(dl);
-            if (conv_res || conv_inc) break;
-            if (it > 25) {
-                failed = true;
-                break;
-            }
-            ++it;
-        }
-        st.iters += (unsigned long long)(it + 1);
-        st.nonconv += failed ? 1ull : 0ull;
-        // converged stress, history
-#pragma unroll
-        for (int i = 0; i < 6; ++i) sig1[i] = (i < 3 ? I1 / 3.0 : 0.0) + rho * s_tr[i];
-        h[0] = alpha_1;
-        {
-            double ds[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ds[i] = sig1[i] - sig0[i];
-            const double tr = (ds[0] + ds[1]) + ds[2], vol = tr / 3.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                // plastic_strain += d_eps - E^-1 (sigma_1 - sigma_0),  E^-1 = isotropic_elastic_tangent(1/(4 mu), 1/(9 kappa))
-                const double einv = i < 3 ? (2.0 * inv4mu) * (ds[i] + (-vol)) + (3.0 * inv9k) * vol : (2.0 * inv4mu) * ds[i];
-                h[1 + i] = h[1 + i] + (e[i] - einv);
-            }
-        }
-        // tangent from the inverse of the Jacobian at the final state (s = rho s_tr)
-        {
-            const double w = two_mu * dl, s2 = (rho * rho) * n2;
-            const double Ad = 1.0 + w * (m.c1 + m.c2 * s2);
-            const double alpha_d = 1.0 / (1.0 + w * m.c1);
-            const double beta = alpha_d * w * m.c2 / Ad;
-            const double uv = 3.0 * kappa * bflow, ud = two_mu * m.c1 / Ad;  // A^-1 E g       = uv 1 + ud s
-            const double vv = b, vd = m.c1 / Ad;                              // df/dsigma A^-1 = vv 1^T + vd s^T
-            const double D = 3.0 * vv * uv + vd * s2 * (two_mu * m.c1);
-            t11 = kappa - 3.0 * kappa * uv * vv / D;
-            tP = two_mu * alpha_d;
-            tss = -two_mu * beta - two_mu * ud * vd / D;
-            t1s = -two_mu * uv * vd / D;
-            ts1 = -3.0 * kappa * ud * vv / D;
-        }
-    }
+    DPTangent tg;
+    tg.t11 = a.sc.s[2], tg.tP = a.sc.s[7];
+    if (plastic) dp_return<HYPER>(a.sc, e, sig0, t, h, tg, st);
     st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
-    st.domain += (live && tip) ? 1ull : 0ull;  // tip of the classic surface reached (reference: assert!)
+    st.domain += (live && t.tip) ? 1ull : 0ull;  // tip of the classic surface reached (reference: assert!)
 
-    sr.put(sb, region, lane, sig1, p0, npts);
+    sr.put(sb, region, lane, t.sig1, p0, npts);
     (void)history_tile_needs_write(a, p0, mask, hist_in_place, lane);  // records the mask; this tile is written
     transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
 
     if (sb.tan) {
-        double* t = region + kDpStride * lane;
-        d2 v;
-        v.x = t11, v.y = tP;
-        reinterpret_cast<d2*>(t)[0] = v;
-        v.x = tss, v.y = t1s;
-        reinterpret_cast<d2*>(t)[1] = v;
-        v.x = ts1, v.y = plastic ? 1.0 : 0.0;
-        reinterpret_cast<d2*>(t)[2] = v;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            v.x = rho * s_tr[2 * i];
-            v.y = rho * s_tr[2 * i + 1];
-            reinterpret_cast<d2*>(t)[3 + i] = v;
-        }
+        dp_publish(region, lane, tg, t.s_tr, plastic);
         wave_sync();
         tangent_dp<IDX, FULL, NT>(region, T->a, T->b, T->c, sb.tan, p0, rows_lds, npts, lane);
         wave_sync();
+    }
+}
+
+// fused 3D -> 1D/2D wrapper around the Drucker-Prager laws (see the Mises versions above)
+template <bool HYPER, int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void tile_comfe_dp_wrapped(const EvalArgs& a, const Tables* T, double* region,
+                                                      long long p0, int npts, int lane, WaveStats& st) {
+    const bool live = FULL || lane < npts;
+    Chunks<7> ch;
+    tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
+    double g[9], sig0[6], h[7], e[6];
+    wrapped_load<WRAP, FULL, NT>(a, region, p0, npts, lane, g, sig0);
+    transpose_in<7>(ch, region, lane, h);
+    mandel_strain(g, a.sc.s[0], e);
+
+    DPTrial t;
+    dp_trial<HYPER>(a.sc, e, sig0, t);
+    const bool plastic = live && (t.m.f > 0.0);
+    const unsigned long long mask = __ballot(plastic);
+    DPTangent tg;
+    tg.t11 = a.sc.s[2], tg.tP = a.sc.s[7];
+    if (plastic) dp_return<HYPER>(a.sc, e, sig0, t, h, tg, st);
+    st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
+    st.domain += (live && t.tip) ? 1ull : 0ull;
+
+    wrapped_store_stress<WRAP, FULL, NT>(a, region, p0, npts, lane, t.sig1);
+    if (mask != 0ull) transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+    if (a.tangent) {
+        if constexpr (WRAP == 1) {
+            // entry [0][0] exactly as tangent_dp forms it; elastic points carry E[0][0] itself
+            const double s0 = tg.rho * t.s_tr[0];
+            const double v = (tg.t11 * T->a[0] + tg.tP * T->b[0]) + ((tg.tss * s0) * s0 + (tg.t1s * 1.0) * s0 + (tg.ts1 * s0) * 1.0);
+            if (live) a.tangent[p0 + lane] = plastic ? v : T->c[0];
+        } else {
+            dp_publish(region, lane, tg, t.s_tr, plastic);
+            wave_sync();
+            const int nchunks = npts * 8;  // block [0:4, 0:4]
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int q = k * kWave + lane;
+                const int p = q >> 3, r = q & 7;
+                const int i = r >> 1, j = 2 * (r & 1);
+                const double* tp = region + kDpStride * p;
+                const d2 c0 = reinterpret_cast<const d2*>(tp)[0];
+                const d2 c1 = reinterpret_cast<const d2*>(tp)[1];
+                const d2 c2 = reinterpret_cast<const d2*>(tp)[2];
+                const double si = tp[6 + i];
+                const d2 sj = *reinterpret_cast<const d2*>(tp + 6 + j);
+                const d2 o = *reinterpret_cast<const d2*>(T->a + 6 * i + j);
+                const d2 pd = *reinterpret_cast<const d2*>(T->b + 6 * i + j);
+                const double oi = i < 3 ? 1.0 : 0.0;
+                d2 v;
+                v.x = (c0.x * o.x + c0.y * pd.x) + ((c1.x * si) * sj.x + (c1.y * oi) * sj.x + (c2.x * si) * (j < 3 ? 1.0 : 0.0));
+                v.y = (c0.x * o.y + c0.y * pd.y) + ((c1.x * si) * sj.y + (c1.y * oi) * sj.y + (c2.x * si) * (j + 1 < 3 ? 1.0 : 0.0));
+                const d2 el = *reinterpret_cast<const d2*>(T->c + 6 * i + j);
+                if (c2.y == 0.0) v = el;
+                if constexpr (FULL) {
+                    store16<NT>(a.tangent + p0 * 16 + 2 * q, v);
+                } else if (q < nchunks) {
+                    a.tangent[p0 * 16 + 2 * q] = v.x;
+                    a.tangent[p0 * 16 + 2 * q + 1] = v.y;
+                }
+            }
+            wave_sync();
+        }
     }
 }
 
@@ -1523,12 +1622,16 @@ __device__ __forceinline__ void run_wrapped_tile(const EvalArgs& a, const Tables
                                                  int npts, int lane, WaveStats& st) {
     if constexpr (LAW == LAW_VM3D)
         tile_von_mises_wrapped<WRAP, FULL, NT>(a, T, region, p0, npts, lane, st);
+    else if constexpr (LAW == LAW_COMFE_DP)
+        tile_comfe_dp_wrapped<false, WRAP, FULL, NT>(a, T, region, p0, npts, lane, st);
+    else if constexpr (LAW == LAW_COMFE_DP_HYPER)
+        tile_comfe_dp_wrapped<true, WRAP, FULL, NT>(a, T, region, p0, npts, lane, st);
     else
         tile_comfe_mises_wrapped<WRAP, FULL, NT>(a, T, region, p0, npts, lane, st);
 }
 
 template <int LAW, int WRAP, bool NT>
-__global__ void __launch_bounds__(kBlock, 4) evaluate_wrapped_kernel(const EvalArgs a) {
+__global__ void __launch_bounds__(kBlock, (LAW >= LAW_COMFE_DP ? 3 : 4)) evaluate_wrapped_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     stage_tables(a, &T);
@@ -1702,6 +1805,11 @@ hipError_t launch_evaluate_wrapped(int law, int wrap, const EvalArgs& args, int 
         case LAW_COMFE_MISES:
             return wrap == 1 ? launch_wrapped<LAW_COMFE_MISES, 1>(args, grid, stream)
                              : launch_wrapped<LAW_COMFE_MISES, 2>(args, grid, stream);
+        case LAW_COMFE_DP:
+            return wrap == 1 ? launch_wrapped<LAW_COMFE_DP, 1>(args, grid, stream) : launch_wrapped<LAW_COMFE_DP, 2>(args, grid, stream);
+        case LAW_COMFE_DP_HYPER:
+            return wrap == 1 ? launch_wrapped<LAW_COMFE_DP_HYPER, 1>(args, grid, stream)
+                             : launch_wrapped<LAW_COMFE_DP_HYPER, 2>(args, grid, stream);
         default: return hipErrorInvalidValue;
     }
 }
