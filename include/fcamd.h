@@ -79,7 +79,9 @@ typedef enum fcamd_model_id {
     FCAMD_COMFE_DRUCKER_PRAGER_HYPERBOLIC = 8
 } fcamd_model_id;
 
-/* StressStrainConstraint values -- models/interfaces.py:14-28. Only FULL has kernels. */
+/* StressStrainConstraint values -- models/interfaces.py:14-28.  Linear elasticity and the two SLS
+   laws have kernels for all five (array widths per point then follow stress_strain_dim /
+   geometric_dim: 1/1, 4/4, 6/9); the plasticity laws are FULL only, as in the reference. */
 typedef enum fcamd_constraint {
     FCAMD_UNIAXIAL_STRAIN = 1,
     FCAMD_UNIAXIAL_STRESS = 2,
