@@ -245,8 +245,57 @@ def main_constraints():
     print("constraints.npz", idx, "calls")
 
 
+def main_material_point():
+    """Load paths of the reference's own model classes under the material-point harness
+    (tests/material_point.py): the 100-step uniaxial-stress test and the sine cycle of
+    tests/models/test_plasticity.py, relaxation and creep of tests/models/test_viscoelasticity.py --
+    whole multi-increment Newton histories of the *reference*, stored as curves."""
+    m = import_reference()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    sys.path.insert(0, root)
+    import material_point_cases as cases
+    from material_point import HostState, MaterialPoints
+
+    C = m.StressStrainConstraint
+
+    class RefLaw:  # the reference class + the two attributes the harness reads
+        def __init__(self, law):
+            self.law, self.history_dim, self.constraint = law, law.history_dim, law.constraint
+
+        def evaluate(self, *a):
+            self.law.evaluate(*a)
+
+    def build(kind, params, constraint, n):
+        c = C[constraint]
+        law = {"von_mises_3d": lambda: m.VonMises3D(params),
+               "spring_maxwell": lambda: m.SpringMaxwellModel(params, c),
+               "spring_kelvin": lambda: m.SpringKelvinModel(params, c),
+               "linear_elasticity": lambda: m.LinearElasticityModel(params, c)}[kind]()
+        return MaterialPoints(HostState(RefLaw(law), n), constraint, tol=1e-11)
+
+    d = {}
+    load, disp = cases.uniaxial_stress_3d(build, "von_mises_3d", n=8)
+    d["uniaxial_stress_3d.load"], d["uniaxial_stress_3d.disp"] = load, disp
+    load, disp = cases.uniaxial_cyclic_strain_3d(build, n=4)
+    d["uniaxial_cyclic_strain_3d.load"], d["uniaxial_cyclic_strain_3d.disp"] = load, disp
+    for kind in ("spring_kelvin", "spring_maxwell"):
+        for constraint in ("UNIAXIAL_STRESS", "PLANE_STRESS", "FULL"):
+            d[f"relaxation.{kind}.{constraint}"] = cases.relaxation(build, kind, constraint, n=5)
+        for constraint in ("PLANE_STRESS", "FULL"):
+            d[f"creep.{kind}.{constraint}"] = cases.creep(build, kind, constraint, n=5)
+    cases.kelvin_vs_maxwell(build)
+    for kind in ("spring_kelvin", "spring_maxwell"):
+        cases.plane_strain_vs_3d(build, kind)
+    cases.elasticity_constraints(build)
+    np.savez_compressed(os.path.join(OUT, "material_point.npz"), **d)
+    print("material_point.npz", len(d), "curves (every scenario's assertions also held for the reference classes)")
+
+
 if __name__ == "__main__":
-    if "--constraints" in sys.argv:
+    if "--material-point" in sys.argv:
+        main_material_point()
+    elif "--constraints" in sys.argv:
         main_constraints()
     elif "--wrappers" in sys.argv:
         main_wrappers()
@@ -254,3 +303,4 @@ if __name__ == "__main__":
         main()
         main_wrappers()
         main_constraints()
+        main_material_point()

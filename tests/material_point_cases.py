@@ -248,3 +248,18 @@ def drucker_prager_uniaxial(build, hyperbolic, n=6):
     assert np.all(np.abs(np.sqrt(s * s / 3 + dsq) + b * s - a) < 1e-7)  # on the yield surface
     assert np.all(np.abs(load[-1] - load[-2]) < 1e-7)  # perfect plasticity: the load has saturated
     return load
+
+
+def golden_curves():
+    """Curves of the same scenarios driven with the REFERENCE's own classes (oracle/gen_golden.py
+    --material-point, imported reference): whole multi-increment Newton histories."""
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "material_point.npz"))
+
+
+def assert_matches_reference_curve(key, curve, tol):
+    ref = golden_curves()[key]
+    assert curve.shape == ref.shape, (key, curve.shape, ref.shape)
+    err = np.max(np.abs(curve - ref)) / np.max(np.abs(ref))
+    assert err <= tol, (key, err)

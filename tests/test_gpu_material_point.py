@@ -55,25 +55,30 @@ def test_uniaxial_stress_3d(kind, mode):
 
     ref, _ = cases.uniaxial_stress_3d(oracle_build, kind, n=70)
     assert np.max(np.abs(load - ref)) < 1e-6 * np.max(np.abs(ref))
+    if kind == "von_mises_3d":  # and, at the fixture's 8 amplitudes, with the reference's own class
+        load8, _ = cases.uniaxial_stress_3d(builder(mode), kind, n=8)
+        cases.assert_matches_reference_curve("uniaxial_stress_3d.load", load8, 1e-6)
 
 
 @pytest.mark.parametrize("mode", MODES)
 def test_uniaxial_cyclic_strain_3d(mode):
     cases.uniaxial_cyclic_strain_3d(builder(mode), n=6)
+    load, _ = cases.uniaxial_cyclic_strain_3d(builder(mode), n=4)
+    cases.assert_matches_reference_curve("uniaxial_cyclic_strain_3d.load", load, 1e-6)
 
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("kind", ["spring_kelvin", "spring_maxwell"])
 @pytest.mark.parametrize("constraint", ["UNIAXIAL_STRESS", "PLANE_STRESS", "FULL"])
 def test_relaxation(kind, constraint, mode):
-    cases.relaxation(builder(mode), kind, constraint)
+    cases.assert_matches_reference_curve(f"relaxation.{kind}.{constraint}", cases.relaxation(builder(mode), kind, constraint), 1e-10)
 
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("kind", ["spring_kelvin", "spring_maxwell"])
 @pytest.mark.parametrize("constraint", ["PLANE_STRESS", "FULL"])
 def test_creep(kind, constraint, mode):
-    cases.creep(builder(mode), kind, constraint)
+    cases.assert_matches_reference_curve(f"creep.{kind}.{constraint}", cases.creep(builder(mode), kind, constraint), 1e-10)
 
 
 @pytest.mark.parametrize("mode", MODES)

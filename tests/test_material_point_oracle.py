@@ -33,23 +33,26 @@ def build(kind, params, constraint, n):
 
 @pytest.mark.parametrize("kind", ["von_mises_3d", "comfe_mises_plasticity"])
 def test_uniaxial_stress_3d(kind):
-    cases.uniaxial_stress_3d(build, kind)
+    load, _ = cases.uniaxial_stress_3d(build, kind)
+    if kind == "von_mises_3d":  # the curve of the reference's own VonMises3D class
+        cases.assert_matches_reference_curve("uniaxial_stress_3d.load", load, 1e-9)
 
 
 def test_uniaxial_cyclic_strain_3d():
-    cases.uniaxial_cyclic_strain_3d(build)
+    load, _ = cases.uniaxial_cyclic_strain_3d(build)
+    cases.assert_matches_reference_curve("uniaxial_cyclic_strain_3d.load", load, 1e-9)
 
 
 @pytest.mark.parametrize("kind", ["spring_kelvin", "spring_maxwell"])
 @pytest.mark.parametrize("constraint", ["UNIAXIAL_STRESS", "PLANE_STRESS", "FULL"])
 def test_relaxation(kind, constraint):
-    cases.relaxation(build, kind, constraint)
+    cases.assert_matches_reference_curve(f"relaxation.{kind}.{constraint}", cases.relaxation(build, kind, constraint), 1e-11)
 
 
 @pytest.mark.parametrize("kind", ["spring_kelvin", "spring_maxwell"])
 @pytest.mark.parametrize("constraint", ["PLANE_STRESS", "FULL"])
 def test_creep(kind, constraint):
-    cases.creep(build, kind, constraint)
+    cases.assert_matches_reference_curve(f"creep.{kind}.{constraint}", cases.creep(build, kind, constraint), 1e-11)
 
 
 def test_kelvin_vs_maxwell():
