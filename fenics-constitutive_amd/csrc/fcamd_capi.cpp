@@ -730,8 +730,10 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
                            reinterpret_cast<const void* const*>(hist),
                            reinterpret_cast<const void* const*>(hist), n_hist);
     if (st != FCAMD_OK) return st;
-    if (!has_sparse_history(m->law))  // = the plasticity laws
-        return fail(FCAMD_ERR_UNSUPPORTED, "the fused 3D wrapper kernel exists for the plasticity laws only");
+    if (!has_sparse_history(m->law) && m->law != FCAMD_LINEAR_ELASTICITY)
+        return fail(FCAMD_ERR_UNSUPPORTED, "the fused 3D wrapper kernel exists for LinearElasticityModel and the plasticity laws");
+    if (m->constraint != FCAMD_FULL)
+        return fail(FCAMD_ERR_UNSUPPORTED, "the wrapped model must be a FULL (3-D) one");
     const int wrap = wrapper_constraint == FCAMD_UNIAXIAL_STRAIN ? 1 : wrapper_constraint == FCAMD_PLANE_STRAIN ? 2 : 0;
     if (!wrap) return fail(FCAMD_ERR_BAD_ARG, "wrapper constraint must be UNIAXIAL_STRAIN or PLANE_STRAIN");
     if (n > 0 && !stress_3d) return fail(FCAMD_ERR_BAD_ARG, "stress_3d is NULL");
@@ -747,7 +749,7 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
     a.stress_in = stress_lo;
     a.stress_out = stress_lo;
     a.tangent = tangent_lo;
-    a.h0_in = a.h0_out = hist[0];
+    a.h0_in = a.h0_out = m->info.n_hist > 0 ? hist[0] : nullptr;
     a.h1_in = a.h1_out = m->info.n_hist > 1 ? hist[1] : nullptr;
     a.rows = nullptr;
     a.hmask = nullptr;

@@ -749,6 +749,43 @@ __device__ __forceinline__ void wrapped_tangent_mises(const EvalArgs& a, const T
     }
 }
 
+// mapped block of a point-independent tangent table (LE): [0][0] or the block [0:4, 0:4]
+template <int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void wrapped_tangent_const(const EvalArgs& a, const double* tab, long long p0, int npts,
+                                                      int lane) {
+    if constexpr (WRAP == 1) {
+        if (FULL || lane < npts) a.tangent[p0 + lane] = tab[0];
+    } else {
+        const int nchunks = npts * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = k * kWave + lane;
+            const int r = q & 7;
+            const d2 v = *reinterpret_cast<const d2*>(tab + 6 * (r >> 1) + 2 * (r & 1));
+            if constexpr (FULL) {
+                store16<NT>(a.tangent + p0 * 16 + 2 * q, v);
+            } else if (q < nchunks) {
+                a.tangent[p0 * 16 + 2 * q] = v.x;
+                a.tangent[p0 * 16 + 2 * q + 1] = v.y;
+            }
+        }
+    }
+}
+
+// LinearElasticityModel behind the wrappers (what the reference's own tests wrap, test_elasticity.py:206,278)
+template <int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void tile_linear_elasticity_wrapped(const EvalArgs& a, const Tables* T, double* region,
+                                                               long long p0, int npts, int lane) {
+    if (a.tangent) wrapped_tangent_const<WRAP, FULL, NT>(a, T->c, p0, npts, lane);
+    double g[9], s[6], e[6], ds[6];
+    wrapped_load<WRAP, FULL, NT>(a, region, p0, npts, lane, g, s);
+    mandel_strain(g, a.sc.s[0], e);
+    row_times_matrix_fma(e, T->a, ds);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s[i] = s[i] + ds[i];
+    wrapped_store_stress<WRAP, FULL, NT>(a, region, p0, npts, lane, s);
+}
+
 template <int WRAP, bool FULL, bool NT>
 __device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const Tables* T, double* region,
                                                        long long p0, int npts, int lane, WaveStats& st) {
@@ -1622,6 +1659,8 @@ __device__ __forceinline__ void run_wrapped_tile(const EvalArgs& a, const Tables
                                                  int npts, int lane, WaveStats& st) {
     if constexpr (LAW == LAW_VM3D)
         tile_von_mises_wrapped<WRAP, FULL, NT>(a, T, region, p0, npts, lane, st);
+    else if constexpr (LAW == LAW_LE)
+        tile_linear_elasticity_wrapped<WRAP, FULL, NT>(a, T, region, p0, npts, lane);
     else if constexpr (LAW == LAW_COMFE_DP)
         tile_comfe_dp_wrapped<false, WRAP, FULL, NT>(a, T, region, p0, npts, lane, st);
     else if constexpr (LAW == LAW_COMFE_DP_HYPER)
@@ -1802,6 +1841,7 @@ hipError_t launch_evaluate_wrapped(int law, int wrap, const EvalArgs& args, int 
     if (wrap != 1 && wrap != 2) return hipErrorInvalidValue;
     switch (law) {
         case LAW_VM3D: return wrap == 1 ? launch_wrapped<LAW_VM3D, 1>(args, grid, stream) : launch_wrapped<LAW_VM3D, 2>(args, grid, stream);
+        case LAW_LE: return wrap == 1 ? launch_wrapped<LAW_LE, 1>(args, grid, stream) : launch_wrapped<LAW_LE, 2>(args, grid, stream);
         case LAW_COMFE_MISES:
             return wrap == 1 ? launch_wrapped<LAW_COMFE_MISES, 1>(args, grid, stream)
                              : launch_wrapped<LAW_COMFE_MISES, 2>(args, grid, stream);

@@ -31,7 +31,7 @@ __all__ = ["UniaxialStrainFrom3D", "PlaneStrainFrom3D"]
 class _From3D(IncrSmallStrainModel):
     _constraint: StressStrainConstraint
     _kinds: tuple[int, int, int, int]  # grad->3d, stress->3d, stress<-3d, tangent<-3d
-    #: use the fused kernel where one exists (the plasticity laws); False forces map -> evaluate -> map
+    #: use the fused kernel where one exists (LinearElasticityModel, the plasticity laws); False forces map -> evaluate -> map
     fused = True
 
     def __init__(self, model: IncrSmallStrainModel) -> None:
@@ -75,7 +75,7 @@ class _From3D(IncrSmallStrainModel):
             dev = g_lo.device
         n = g_lo.numel() // gd2
         assert n == s_lo.numel() // sd == t_lo.numel() // (sd * sd)
-        if self.fused and getattr(self.model, "_model_id", None) in (_capi.VON_MISES_3D, _capi.COMFE_MISES_PLASTICITY,
+        if self.fused and getattr(self.model, "_model_id", None) in (_capi.LINEAR_ELASTICITY, _capi.VON_MISES_3D, _capi.COMFE_MISES_PLASTICITY,
                                                                       _capi.COMFE_DRUCKER_PRAGER, _capi.COMFE_DRUCKER_PRAGER_HYPERBOLIC):
             # fused kernel (fcamd_evaluate_device_wrapped): only the cached 3-D stress exists
             if self.stress_3d is None or self.stress_3d.numel() != 6 * n or self.stress_3d.device != dev:

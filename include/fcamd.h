@@ -179,7 +179,7 @@ int fcamd_evaluate_device_indexed(fcamd_model* model, double t, double del_t, in
                                   const double* const* history_prev, double* const* history,
                                   int n_hist);
 
-/* Fused form of the reference's 3D -> 1D/2D wrappers around the plasticity laws (UniaxialStrainFrom3D /
+/* Fused form of the reference's 3D -> 1D/2D wrappers around LinearElasticityModel and the plasticity laws (UniaxialStrainFrom3D /
    PlaneStrainFrom3D, models/utils.py:211-412): `grad_lo`, `stress_lo`, `tangent_lo` are the
    low-dimensional arrays (1 / 1 / 1 doubles per point for FCAMD_UNIAXIAL_STRAIN, 4 / 4 / 16 for
    FCAMD_PLANE_STRAIN), `stress_3d` (6 n) is the wrapper's cached 3-D stress whose unmapped
