@@ -125,3 +125,38 @@ def test_fused_wrapper_equals_map_evaluate_map(kind, n, lname):
             assert torch.equal(ha[k], hb[k]), k
     assert a.grad_del_u_3d is None and a.tangent_3d is None and b.tangent_3d is not None
     assert lname == "le" or a.model.device_stats().n_plastic > 0 or n < 10
+
+
+@pytest.mark.parametrize("kind", ["plane_strain", "uniaxial_strain"])
+def test_wrapped_3d_law_equals_native_constraint(kind):
+    """tests/models/test_elasticity.py:157-298 in array form: LinearElasticityModel(FULL) behind the
+    wrapper gives the stresses of LinearElasticityModel(UNIAXIAL_STRAIN / PLANE_STRAIN), the analytical
+    uniaxial-strain stress, a non-zero out-of-plane stress under plane strain, and no shear in the
+    cached 3-D stress."""
+    C = fc.StressStrainConstraint
+    E, nu = PARAMS["le"]["E"], PARAMS["le"]["nu"]
+    n = 64 * 3 + 11
+    rng = np.random.default_rng(4)
+    if kind == "uniaxial_strain":
+        native, W, gd2, sd = fc.LinearElasticityModel(PARAMS["le"], C.UNIAXIAL_STRAIN), fc.UniaxialStrainFrom3D, 1, 1
+        g = np.full(n, 0.01) * np.linspace(0.5, 1.0, n)
+    else:
+        native, W, gd2, sd = fc.LinearElasticityModel(PARAMS["le"], C.PLANE_STRAIN), fc.PlaneStrainFrom3D, 4, 4
+        g = np.zeros((n, 4))
+        g[:, 0] = 0.01 * np.linspace(0.5, 1.0, n)
+        g[:, 3] = rng.normal(scale=1e-3, size=n)
+        g = g.reshape(-1)
+    wrapped = W(fc.LinearElasticityModel(PARAMS["le"], FULL))
+    s_n, t_n = np.zeros(sd * n), np.zeros(sd * sd * n)
+    s_w, t_w = np.zeros(sd * n), np.zeros(sd * sd * n)
+    native.evaluate(0.0, 1.0, g, s_n, t_n, None)
+    wrapped.evaluate(0.0, 1.0, g, s_w, t_w, None)
+    assert rel_err(s_w, s_n) < 1e-10 and rel_err(t_w, t_n) < 1e-10
+    if kind == "uniaxial_strain":
+        analytical = E * (1.0 - nu) / ((1.0 + nu) * (1.0 - 2.0 * nu)) * g
+        assert np.max(np.abs(s_w - analytical)) < 1e-10 / analytical.max()
+    else:
+        assert np.abs(s_w.reshape(-1, 4)[:, 2]).min() > 1e-3  # sigma_33 is not zero under plane strain
+    s3 = wrapped.stress_3d.cpu().numpy().reshape(-1, 6)
+    assert np.abs(s3[:, 3 if kind == "uniaxial_strain" else 4:]).max() < 1e-14
+    assert np.abs(s3[:, 1:3]).min() > 0  # lateral stresses live in the cached 3-D stress
