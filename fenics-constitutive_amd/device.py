@@ -286,3 +286,36 @@ def strain_from_grad_u_full(grad_u):
         raise RuntimeError("strain_from_grad_u(FULL) runs on the GPU and no HIP device is available")
     d = torch.from_numpy(g).to(torch.device("cuda", _capi.default_device()))
     return strain_from_grad_u_full(d).cpu().numpy()
+
+
+def strain_from_grad_u_lowdim(grad_u, constraint):
+    """1-D / 2-D ``strain_from_grad_u`` (utils.py:153-186) on the GPU with the kernels that already
+    exist: expand the gradient to 3-D (``fcamd_convert_device``), run the FULL strain kernel, keep the
+    mapped Mandel components -- [g0] resp. [g0, g3, 0, f (g1 + g2)], the reference's formulas."""
+    import ctypes as C
+
+    import torch
+
+    lib = _capi.load()
+    uniaxial = constraint.name.startswith("UNIAXIAL")
+    gd2, sd = (1, 1) if uniaxial else (4, 4)
+    host = not _is_torch(grad_u)
+    if host:
+        if not torch.cuda.is_available():
+            raise RuntimeError("strain_from_grad_u runs on the GPU and no HIP device is available")
+        g = torch.from_numpy(np.ascontiguousarray(np.asarray(grad_u, dtype=np.float64)).reshape(-1)).to(
+            torch.device("cuda", _capi.default_device()))
+    else:
+        g = _check_torch("grad_u", grad_u).reshape(-1)
+    n = g.numel() // gd2
+    dev = g.device.index or 0
+    ctx = _capi.get_context(dev)
+    ctx.set_stream(_current_stream_ptr(dev))
+    g3 = torch.zeros(9 * n, dtype=torch.float64, device=g.device)
+    e3 = torch.empty(6 * n, dtype=torch.float64, device=g.device)
+    out = torch.empty(sd * n, dtype=torch.float64, device=g.device)
+    up, down = (_capi.GRAD_1D_TO_3D, _capi.STRESS_3D_TO_1D) if uniaxial else (_capi.GRAD_2D_TO_3D, _capi.STRESS_3D_TO_2D)
+    _capi.check(lib.fcamd_convert_device(ctx.handle, up, n, C.c_void_p(g.data_ptr()), C.c_void_p(g3.data_ptr())))
+    _capi.check(lib.fcamd_strain_from_grad_u_device(ctx.handle, n, C.c_void_p(g3.data_ptr()), C.c_void_p(e3.data_ptr()), 0))
+    _capi.check(lib.fcamd_convert_device(ctx.handle, down, n, C.c_void_p(e3.data_ptr()), C.c_void_p(out.data_ptr())))
+    return out.cpu().numpy() if host else out

@@ -2,7 +2,8 @@
 
 ``lame_parameters`` / ``get_elastic_tangent`` / ``get_identity`` are tiny per-model
 constants (host, once per model).  ``strain_from_grad_u`` is array-sized and runs on the
-GPU (``fcamd_strain_from_grad_u_device``) for the FULL constraint.
+GPU (``fcamd_strain_from_grad_u_device``, with the component maps of ``fcamd_convert_device``
+for the 1-D / 2-D constraints).
 """
 
 from __future__ import annotations
@@ -58,26 +59,16 @@ def get_identity(stress_strain_dim: int, constraint: StressStrainConstraint) -> 
 def strain_from_grad_u(grad_u, constraint: StressStrainConstraint):
     """Mandel strain from the displacement gradient (utils.py:132-208).
 
-    FULL runs on the GPU: NumPy in -> NumPy out (staged), torch CUDA tensor in -> CUDA
-    tensor out (zero copy).  The 1-D/2-D constraints are host-side index shuffles of a few
-    values per point and stay in NumPy, exactly as the reference has them.
+    Runs on the GPU for every constraint: NumPy in -> NumPy out (staged), torch CUDA tensor in ->
+    CUDA tensor out (zero copy).
     """
     name = constraint.name
     if name == "FULL":
         from .device import strain_from_grad_u_full
 
         return strain_from_grad_u_full(grad_u)
-    g = np.asarray(grad_u, dtype=np.float64)
-    gdim, sdim = constraint.geometric_dim, constraint.stress_strain_dim
-    n = int(g.size / gdim**2)
-    strain = np.zeros(sdim * n)
-    gv, sv = g.reshape(-1, gdim**2), strain.reshape(-1, sdim)
-    if name in ("UNIAXIAL_STRAIN", "UNIAXIAL_STRESS"):
-        sv[:, 0] = gv[:, 0]
-    elif name in ("PLANE_STRAIN", "PLANE_STRESS"):
-        sv[:, 0] = gv[:, 0]
-        sv[:, 1] = gv[:, 3]
-        sv[:, 3] = 1 / 2**0.5 * (gv[:, 1] + gv[:, 2])
-    else:
-        raise NotImplementedError("Constraint not supported.")
-    return strain
+    if name in ("UNIAXIAL_STRAIN", "UNIAXIAL_STRESS", "PLANE_STRAIN", "PLANE_STRESS"):
+        from .device import strain_from_grad_u_lowdim
+
+        return strain_from_grad_u_lowdim(grad_u, constraint)
+    raise NotImplementedError("Constraint not supported.")

@@ -367,3 +367,22 @@ def test_host_path_many_chunks_ragged(kind):
     compare(got, ref, STRICT[CLASS[kind]], "strict " + kind)
     if kind == "von_mises_3d":
         assert law.last_stats.n_plastic == int(np.sum(ref[2]["alpha"] > h["alpha"]))
+
+
+def test_strain_from_grad_u_low_dimensional():
+    """tests/models/test_conversions.py:14-28 and the oracle, NumPy in / out and device tensors."""
+    C = fc.StressStrainConstraint
+    assert np.array_equal(fc.strain_from_grad_u(np.array([[1.0]]), C.UNIAXIAL_STRAIN), [1.0])
+    assert np.array_equal(fc.strain_from_grad_u(np.array([[1.0]]), C.UNIAXIAL_STRESS), [1.0])
+    g = np.array([[1.0, 2.0], [3.0, 4.0]])
+    for c in (C.PLANE_STRAIN, C.PLANE_STRESS):
+        assert np.allclose(fc.strain_from_grad_u(g, c), [1.0, 4.0, 0.0, 0.5 * 5.0 * 2**0.5], rtol=1e-15)
+    rng = np.random.default_rng(3)
+    for c in C:
+        if c.name == "FULL":
+            continue
+        gg = rng.normal(size=c.geometric_dim**2 * 1003)
+        ref = O.strain_from_grad_u(gg, c.name)
+        assert np.array_equal(fc.strain_from_grad_u(gg, c), ref)
+        dev = fc.strain_from_grad_u(torch.from_numpy(gg).cuda(), c)
+        assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), ref)
