@@ -300,6 +300,12 @@ def main():
         elapsed = float(tt.item())
     kernel_ms = sorted(ev0[i].elapsed_time(ev1[i]) for i in range(args.steps))
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    per_rank_ms = None
+    if distributed:  # every rank's own average kernel time: shows the balance behind the max-over-ranks wall time
+        tk = torch.zeros(world, dtype=torch.float64, device=device)
+        tk[rank] = kernel_avg_ms
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(x), 4) for x in tk.tolist()]
 
     # optional exchange step, timed separately (never part of `value`)
     gather = None
@@ -414,6 +420,8 @@ def main():
                          "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
                          "bytes_per_point": {"elastic": b_el, "plastic": b_pl}},
         }
+        if per_rank_ms is not None:
+            out["per_rank_kernel_ms"] = per_rank_ms
         if gather:
             out["allgather"] = gather
         if not args.no_cpu_baseline and world == 1:
