@@ -227,8 +227,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # convenience: started without the launcher -> start it as a child (nothing has touched the
+            # GPU in this process yet) and pass its exit code on
+            import subprocess
+
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
+                   os.path.abspath(__file__)] + [a if a != "--n" else "--points" for a in sys.argv[1:]]
+            sys.exit(subprocess.run(cmd).returncode)
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     dev_index = local_rank % torch.cuda.device_count()  # identity on a node with one GPU per rank
