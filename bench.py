@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+METRIC = "quadrature-point stress updates/sec (Mpts/s) + % HBM roofline, 1/2/4/8 GPU"  # BASELINE.json "metric"
 
 VM_P = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}
 RS_P = {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0}
@@ -404,7 +405,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "quadrature-point stress updates/sec (Mpts/s) + % HBM roofline",
+            "metric": METRIC,
             "value": round(value, 1),
             "unit": "Mpts/s",
             "n_gpus": world,
