@@ -10,6 +10,7 @@ torch = pytest.importorskip("torch")
 
 import fenics_constitutive_amd as fc  # noqa: E402
 from oracle import c_oracle as CO  # noqa: E402
+from oracle import numpy_oracle as O  # noqa: E402
 
 N = 100_000_000
 FULL = fc.StressStrainConstraint.FULL
@@ -145,3 +146,18 @@ def test_spring_maxwell_1e8():
                            ("strain_visco", gather(ev, idx, 6), hs["strain_visco"]), ("strain", gather(en, idx, 6), hs["strain"])]:
         assert rel_err(got, ref) <= 1e-10, name
         assert rel_err(got, ref) <= 1e-14, "strict " + name
+
+
+def test_cfg1_linear_elasticity_1e5_ndarray_path():
+    """BASELINE.json configs[0]: LinearElasticityModel FULL-3D, 1e5 points, NumPy arrays
+    through the drop-in ``evaluate`` -- E=42, nu=0.3, grad ~ N(0, 1e-3^2), sigma_in = 0, seed 0 --
+    bit for bit against the NumPy restatement of the reference."""
+    n = 100_000
+    rng = np.random.default_rng(0)
+    g = rng.normal(scale=1e-3, size=9 * n)
+    law = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, FULL)
+    s, t = np.zeros(6 * n), np.full(36 * n, np.nan)
+    law.evaluate(0.0, 1.0, g, s, t, None)
+    s_ref, t_ref = np.zeros(6 * n), np.zeros(36 * n)
+    O.linear_elasticity({"E": 42.0, "nu": 0.3}, 0.0, 1.0, g, s_ref, t_ref, None)
+    assert np.array_equal(s, s_ref) and np.array_equal(t, t_ref)
