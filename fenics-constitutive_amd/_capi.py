@@ -23,6 +23,9 @@ OK, ERR_SIZE, ERR_NULL_HISTORY, ERR_DEL_T, ERR_NONCONVERGED, ERR_HIP, ERR_BAD_AR
 
 MAX_HISTORY = 2
 
+# fcamd_context_last_host_mode flags (include/fcamd.h)
+HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT = 1, 2
+
 # conversion kinds (include/fcamd.h)
 (GRAD_1D_TO_3D, STRESS_1D_TO_3D, STRESS_3D_TO_1D, TANGENT_3D_TO_1D,
  GRAD_2D_TO_3D, STRESS_2D_TO_3D, STRESS_3D_TO_2D, TANGENT_3D_TO_2D) = range(1, 9)
@@ -34,6 +37,7 @@ SYMBOLS = [
     "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_evaluate_device",
     "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
     "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
+    "fcamd_context_last_host_mode",
     "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
     "fcamd_last_error", "fcamd_status_string", "fcamd_version",
 ]
@@ -123,6 +127,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_model_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         lib.fcamd_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
         lib.fcamd_unregister_host_buffer.argtypes = [vp, vp]
+        lib.fcamd_context_last_host_mode.argtypes = [vp, C.POINTER(C.c_int)]
         lib.fcamd_last_error.restype = C.c_char_p
         lib.fcamd_status_string.restype = C.c_char_p
         lib.fcamd_status_string.argtypes = [C.c_int]
@@ -186,6 +191,13 @@ class Context:
 
     def unregister_host_buffer(self, arr: np.ndarray) -> None:
         check(self._lib.fcamd_unregister_host_buffer(self.handle, C.c_void_p(arr.ctypes.data)))
+
+    def last_host_mode(self) -> int:
+        """Data path of the last host-entry call: bit 0 = inputs, bit 1 = results moved by the kernel
+        itself (zero copy on page-locked caller arrays); 0 = staged through device buffers."""
+        mode = C.c_int()
+        check(self._lib.fcamd_context_last_host_mode(self.handle, C.byref(mode)))
+        return int(mode.value)
 
     def close(self) -> None:
         if self.handle:

@@ -58,8 +58,9 @@ class DeviceLaw(IncrSmallStrainModel):
 
     #: set by subclasses
     _model_id: int = 0
-    #: Opt-in: page-lock the caller's NumPy arrays the first time they are passed so that the host
-    #: path DMAs directly (93 -> 116 Mpts/s).  Meant for the dolfinx loop, which hands over the same
+    #: Opt-in: page-lock (and map) the caller's NumPy arrays the first time they are passed; once every
+    #: array of a call is registered the kernel runs directly on them (zero copy: 93 -> 140 Mpts/s at
+    #: 1e7 points, 145 -> 40 us per call at 1e3 points).  Meant for the dolfinx loop, which hands over the same
     #: ``Function.x.array`` views every Newton iteration (solver/_lawonsubmesh.py:87-94).  The law
     #: keeps a reference to every pinned array until ``unpin_arrays()``: page-locked memory must not
     #: be freed while registered (a later array at the same address would DMA through stale pages).
@@ -137,7 +138,7 @@ class DeviceLaw(IncrSmallStrainModel):
         pinned = self.__dict__.setdefault("_pinned", {})  # (ptr, nbytes) -> array (kept alive) | None
         for a in arrays:
             key = (a.ctypes.data, a.nbytes)
-            if key in pinned or a.nbytes < (1 << 20):
+            if key in pinned or a.nbytes < (1 << 16):
                 continue
             try:
                 ctx.register_host_buffer(a)
@@ -160,6 +161,15 @@ class DeviceLaw(IncrSmallStrainModel):
         for a in pinned.values():
             if a is not None:
                 ctx.unregister_host_buffer(a)
+
+    def __del__(self):
+        # The law holds the only references that keep auto-pinned arrays alive; once it is gone they may
+        # be freed, and a registration that outlives its memory would make later accesses at the same
+        # address go through stale pages.  Unregister first (best effort at interpreter shutdown).
+        try:
+            self.unpin_arrays()
+        except Exception:
+            pass
 
     def _evaluate_device(self, t, del_t, n, grad, stress, tangent, hist,
                          stress_prev=None, hist_prev=None) -> None:

@@ -210,13 +210,17 @@ typedef struct fcamd_eval_args {
 int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_t, int64_t n,
                              const fcamd_eval_args* args);
 
-/* Host evaluate: the ndarray entry.  Pointers are host arrays laid out as above; the
-   library stages them chunk by chunk (two chunk slots on two streams: H2D / kernel / D2H of
-   one chunk overlap the other's when the arrays are page-locked, see
-   fcamd_register_host_buffer), runs the device path and writes stress / tangent / history
-   back in place.  Synchronous.  Validates like the reference and returns the matching
-   status; on FCAMD_ERR_NONCONVERGED the outputs hold the values the kernel produced
-   (the reference raises mid-loop). `stats` may be NULL. */
+/* Host evaluate: the ndarray entry.  Pointers are host arrays laid out as above; results are
+   written back in place.  Two data paths, chosen per call:
+     zero copy -- every array of the call lies inside ranges page-locked with
+                  fcamd_register_host_buffer (and is 16-byte aligned): ONE kernel launch runs
+                  directly on the caller's arrays; the GPU reads the inputs and writes the
+                  results over PCIe itself, both directions at once, no staging buffers;
+     staged    -- otherwise: chunk by chunk through device buffers (four chunk slots on four
+                  streams: H2D / kernel / D2H of one chunk overlap the others').
+   Both produce bit-identical results.  Synchronous.  Validates like the reference and returns
+   the matching status; on FCAMD_ERR_NONCONVERGED the outputs hold the values the kernel
+   produced (the reference raises mid-loop). `stats` may be NULL. */
 int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
                         const double* grad_del_u, double* stress, double* tangent,
                         double* const* history, int n_hist, fcamd_stats* stats);
@@ -230,6 +234,9 @@ int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
    downloaded into `stress_host` (sd*n) / `tangent_host` (sd*sd*n) while the next chunks are in
    flight (either may be NULL).  The tangent never exists as an n-sized device array.  72 B/pt
    up and 336 B/pt down instead of 176 + 392, and no host-side state copies.
+   A `grad_del_u_host` / `tangent_host` array inside a range page-locked with
+   fcamd_register_host_buffer is read / written by the kernel itself (zero copy, as in
+   fcamd_evaluate_host) instead of passing through the chunk buffers.
    `history_mask` (nullable) selects the sparse trial-history protocol of
    fcamd_evaluate_device_from_sparse (plasticity laws).  Synchronous; waits for work queued on the
    context stream before touching the state arrays.  Status and `stats` as fcamd_evaluate_host. */
@@ -274,12 +281,18 @@ int fcamd_map_rows_device(fcamd_context* ctx, int64_t n_rows, int row_size, cons
 int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
 
 /* Caller arrays are stable across Newton iterations (views of Function.x.array,
-   solver/_lawonsubmesh.py:87-94): page-lock them once so evaluate_host can DMA
-   directly instead of being staged by the runtime.  The caller must unregister a buffer BEFORE
-   freeing it: a registration that outlives its memory makes later DMA at the same address go
-   through stale pages. */
+   solver/_lawonsubmesh.py:87-94): page-lock and map them once.  fcamd_evaluate_host /
+   fcamd_evaluate_resident then run their kernels directly on them (zero copy; any sub-range of
+   a registered range qualifies), and the staged path DMAs without the runtime's bounce
+   buffers.  The caller must unregister a buffer BEFORE freeing it: a registration that
+   outlives its memory makes later accesses at the same address go through stale pages. */
 int fcamd_register_host_buffer(fcamd_context* ctx, void* ptr, size_t bytes);
 int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
+/* Data path the last fcamd_evaluate_host / fcamd_evaluate_resident call of this context took:
+   a bit mask of the flags below (0 = everything staged). */
+#define FCAMD_HOST_ZERO_COPY_IN 1  /* inputs read by the kernel from the caller's host arrays */
+#define FCAMD_HOST_ZERO_COPY_OUT 2 /* results written by the kernel into the caller's host arrays */
+int fcamd_context_last_host_mode(fcamd_context* ctx, int* mode);
 
 /* ---- tuning / introspection -------------------------------------------------- */
 /* Override the launch grid (number of 256-thread workgroups; 0 = automatic). */

@@ -1,0 +1,224 @@
+"""Zero-copy host path: with every array of a call inside page-locked, GPU-mapped ranges
+(``fcamd_register_host_buffer``) ``fcamd_evaluate_host`` launches the kernel directly on the caller's
+NumPy arrays.  The results must be bit-identical to the staged path (same kernel, same inputs) and
+therefore within the parity tolerances of the oracle; anything that is not fully registered or not
+16-byte aligned must fall back to the staged path and still be right."""
+
+import numpy as np
+import pytest
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import fenics_constitutive_amd as fc  # noqa: E402
+from fenics_constitutive_amd import _capi  # noqa: E402
+from fenics_constitutive_amd.resident import ResidentState  # noqa: E402
+from oracle import c_oracle as CO  # noqa: E402
+from test_gpu_parity import CLASS, KINDS, STRICT, TOL, compare, make_law, oracle_run, random_case  # noqa: E402
+
+ZC = _capi.HOST_ZERO_COPY_IN | _capi.HOST_ZERO_COPY_OUT
+
+
+class Pinned:
+    """Registers arrays with the law's context for the duration of a ``with`` block."""
+
+    def __init__(self, law, arrays):
+        self.ctx, self.arrays = law._handle(_capi.default_device()).ctx, [a for a in arrays if a is not None and a.size]
+
+    def __enter__(self):
+        for a in self.arrays:
+            self.ctx.register_host_buffer(a)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        for a in self.arrays:
+            self.ctx.unregister_host_buffer(a)
+
+
+def own(a):
+    """Copy of ``a`` in a buffer of its own pages, 16-byte aligned."""
+    import mmap
+
+    if a is None:
+        return None
+    m = mmap.mmap(-1, max(a.nbytes, 8))
+    out = np.frombuffer(m, dtype=np.float64, count=a.size)
+    out[:] = a
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 1000, 70_001])
+@pytest.mark.parametrize("kind", KINDS)
+def test_zero_copy_equals_staged_and_oracle(kind, n):
+    p, g, s, h = random_case(kind, n, seed=100 + n)
+    ref = oracle_run(kind, p, 1.3, g, s, h, mod=CO)
+    law = make_law(kind, p)
+    # staged
+    s1, t1 = s.copy(), np.full(36 * n, np.nan)
+    h1 = None if h is None else {k: v.copy() for k, v in h.items()}
+    law.evaluate(0.0, 1.3, g, s1, t1, h1)
+    ctx = law._handle(_capi.default_device()).ctx
+    assert ctx.last_host_mode() == 0
+    # zero copy: every array in its own page-locked mapping
+    g2, s2, t2 = own(g), own(s), own(np.full(36 * n, np.nan))
+    h2 = None if h is None else {k: own(v) for k, v in h.items()}
+    with Pinned(law, [g2, s2, t2] + ([] if h2 is None else list(h2.values()))):
+        law.evaluate(0.0, 1.3, g2, s2, t2, h2)
+        assert ctx.last_host_mode() == ZC
+        assert law.last_stats is not None
+    assert np.array_equal(s1, s2) and np.array_equal(t1, t2), f"{kind} n={n}: zero copy differs from staged"
+    if h is not None:
+        for k in h:
+            assert np.array_equal(h1[k], h2[k]), k
+    compare((s2, t2, h2), ref, TOL[CLASS[kind]], f"{kind} n={n} zero copy")
+    compare((s2, t2, h2), ref, STRICT[CLASS[kind]], f"strict {kind} n={n} zero copy")
+    assert np.array_equal(g2, g), "the gradient is read-only"
+
+
+def test_zero_copy_without_tangent_and_n_zero():
+    law = make_law("comfe_mises_plasticity", {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0})
+    n = 5000
+    p, g, s, h = random_case("comfe_mises_plasticity", n, seed=4)
+    ref = oracle_run("comfe_mises_plasticity", p, 1.0, g, s, h, mod=CO)
+    g2, s2, hh = own(g), own(s), own(h["history"])
+    with Pinned(law, [g2, s2, hh]) as ctx:
+        law.evaluate(0.0, 1.0, g2, s2, None, {"history": hh})  # Rust binding: tangent=None skips it
+        assert ctx.last_host_mode() == ZC
+        law.evaluate(0.0, 1.0, g2[:0], s2[:0], None, {"history": hh[:0]})  # n = 0: nothing to launch
+    assert rel_err(s2, ref[0]) <= 1e-11 and rel_err(hh, ref[2]["history"]) <= 1e-11
+
+
+def test_sub_ranges_of_one_registration_take_the_zero_copy_path():
+    """dolfinx hands over views; any sub-range of a registered range qualifies (also several arrays
+    carved from one registered slab)."""
+    n = 3000
+    p, g, s, h = random_case("von_mises_3d", n, seed=8)
+    ref = oracle_run("von_mises_3d", p, 1.0, g, s, h, mod=CO)
+    law = make_law("von_mises_3d", p)
+    slab = own(np.zeros(2 + 9 * n + 6 * n + 36 * n + 6 * n + n + 64))
+    o = 2  # 16-byte aligned offset into the slab
+    views = []
+    for k in (9 * n, 6 * n, 36 * n, 6 * n, n):
+        views.append(slab[o : o + k])
+        o += k + (k % 2)
+    gv, sv, tv, ev, av = views
+    gv[:], sv[:], ev[:], av[:] = g, s, h["eps_n"], h["alpha"]
+    with Pinned(law, [slab]) as ctx:
+        law.evaluate(0.0, 1.0, gv, sv, tv, {"eps_n": ev, "alpha": av})
+        assert ctx.last_host_mode() == ZC
+    compare((sv, tv, {"eps_n": ev, "alpha": av}), ref, STRICT["pl"], "slab views")
+
+
+def test_fallbacks_to_the_staged_path():
+    n = 2000
+    p, g, s, h = random_case("spring_maxwell", n, seed=12)
+    ref = oracle_run("spring_maxwell", p, 0.5, g, s, h, mod=CO)
+    law = make_law("spring_maxwell", p)
+    ctx = law._handle(_capi.default_device()).ctx
+
+    def fresh():
+        return own(g), own(s), own(np.full(36 * n, np.nan)), {k: own(v) for k, v in h.items()}
+
+    # (1) one array of the call is not registered
+    g2, s2, t2, h2 = fresh()
+    with Pinned(law, [g2, s2, t2, h2["strain"]]):
+        law.evaluate(0.0, 0.5, g2, s2, t2, h2)
+        assert ctx.last_host_mode() == 0
+    compare((s2, t2, h2), ref, STRICT["sls"], "partly registered")
+    # (2) registered but 8 bytes off the 16-byte grid: the kernel's vector accesses need alignment
+    slab = own(np.zeros(6 * n + 1))
+    s3 = slab[1:]
+    s3[:] = s
+    g2, _, t2, h2 = fresh()
+    with Pinned(law, [g2, slab, t2] + list(h2.values())):
+        law.evaluate(0.0, 0.5, g2, s3, t2, h2)
+        assert ctx.last_host_mode() == 0
+    compare((s3, t2, h2), ref, STRICT["sls"], "misaligned")
+    # (3) a view that reaches beyond its registered range is never handed to the kernel: the HIP runtime
+    # refuses to DMA a partly page-locked range, the call fails loudly and nothing is computed
+    both = own(np.zeros(12 * n))
+    g2, _, t2, h2 = fresh()
+    s4 = both[: 6 * n]
+    s4[:] = s
+    half = both[: 3 * n]
+    with Pinned(law, [g2, half, t2] + list(h2.values())):
+        with pytest.raises(RuntimeError, match="hipMemcpyAsync"):
+            law.evaluate(0.0, 0.5, g2, s4, t2, h2)
+        assert ctx.last_host_mode() == 0
+    assert np.array_equal(s4, s)
+    # (4) after unregistering everything the same arrays go through the staged path again
+    g2, s2, t2, h2 = fresh()
+    with Pinned(law, [g2, s2, t2] + list(h2.values())):
+        pass
+    law.evaluate(0.0, 0.5, g2, s2, t2, h2)
+    assert ctx.last_host_mode() == 0
+    compare((s2, t2, h2), ref, STRICT["sls"], "unregistered again")
+
+
+@pytest.mark.parametrize("cname", ["UNIAXIAL_STRESS", "PLANE_STRAIN"])
+def test_zero_copy_low_dimensional_constraints(cname):
+    from oracle import numpy_oracle as O
+    from wrappers_util import CPARAMS
+
+    c = fc.StressStrainConstraint[cname]
+    n = 10_007
+    rng = np.random.default_rng(5)
+    gdim, sd = O.DIMS[cname]
+    g = rng.normal(scale=1e-3, size=gdim * gdim * n)
+    s0 = rng.normal(size=sd * n)
+    h0 = {"strain_visco": rng.normal(scale=1e-4, size=sd * n), "strain": rng.normal(scale=1e-3, size=sd * n)}
+    s_ref, t_ref, h_ref = s0.copy(), np.zeros(sd * sd * n), {k: v.copy() for k, v in h0.items()}
+    O.MODELS_C["kelvin"](CPARAMS["kelvin"], cname, 0.0, 0.7, g, s_ref, t_ref, h_ref)
+    law = fc.SpringKelvinModel(CPARAMS["kelvin"], c)
+    g2, s2, t2 = own(g), own(s0), own(np.full(sd * sd * n, np.nan))
+    h2 = {k: own(v) for k, v in h0.items()}
+    with Pinned(law, [g2, s2, t2] + list(h2.values())) as ctx:
+        law.evaluate(0.0, 0.7, g2, s2, t2, h2)
+        assert ctx.last_host_mode() == ZC
+    assert rel_err(s2, s_ref) <= 1e-14 and rel_err(t2, t_ref) <= 1e-14
+    for k in h2:
+        assert rel_err(h2[k], h_ref[k]) <= 1e-14
+
+
+def test_nonconvergence_is_reported_on_the_zero_copy_path():
+    from test_oracle_c import NONCONVERGING, nonconverging_inputs
+
+    law = fc.VonMises3D(NONCONVERGING)
+    g, s, t, h = nonconverging_inputs(70)
+    g, s, t, h = own(g), own(s), own(t), {k: own(v) for k, v in h.items()}
+    with Pinned(law, [g, s, t] + list(h.values())) as ctx:
+        with pytest.raises(RuntimeError, match="did not converge"):
+            law.evaluate(0, 1.0, g, s, t, h)
+        assert ctx.last_host_mode() == ZC
+
+
+@pytest.mark.parametrize("kind", ["von_mises_3d", "linear_elasticity"])
+def test_resident_evaluate_into_zero_copy(kind):
+    """ResidentState.evaluate_into with page-locked gradient / tangent arrays: the kernel reads the
+    gradient from and writes the tangent to the caller's arrays; same numbers as with pageable ones."""
+    n = 200_003
+    p, g, s, h = random_case(kind, n, seed=41)
+    law = make_law(kind, p)
+    out = {}
+    for mode in ("staged", "zero_copy"):
+        st = ResidentState(law, n, stress0=s, history0=h)
+        gg, so, to = own(g), own(np.zeros(6 * n)), own(np.full(36 * n, np.nan))
+        ctx = law._handle(_capi.default_device()).ctx
+        if mode == "zero_copy":
+            with Pinned(law, [gg, so, to]):
+                st.evaluate_into(0.0, 1.0, gg, so, to)
+                assert ctx.last_host_mode() == ZC
+        else:
+            st.evaluate_into(0.0, 1.0, gg, so, to)
+            assert ctx.last_host_mode() == 0
+        hist = None if st.history is None else {k: v.cpu().numpy() for k, v in st.history.items()}
+        out[mode] = (so.copy(), to.copy(), hist, st.stress.cpu().numpy())
+    a, b = out["staged"], out["zero_copy"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    assert np.array_equal(b[0], b[3]), "host stress == device trial stress"
+    if a[2] is not None:
+        for k in a[2]:
+            assert np.array_equal(a[2][k], b[2][k])
+    ref = oracle_run(kind, p, 1.0, g, s, h, mod=CO)
+    compare((b[0], b[1], b[2]), ref, TOL[CLASS[kind]], f"resident zero copy {kind}")

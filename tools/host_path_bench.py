@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the ndarray (host) path: evaluate() on NumPy arrays, staged by
 fcamd_evaluate_host.  Reported in DESIGN.md next to the device-resident number; never the
-bench `value`."""
+bench `value`.  Registered (page-locked) arrays take the zero-copy path; FCAMD_ZERO_COPY=0 in the
+environment keeps them on the staged path (the A/B of DESIGN.md)."""
 import json
 import os
 import sys
@@ -36,11 +37,12 @@ def run(n, register):
         t0 = time.perf_counter()
         law.evaluate(0.0, 1.0, g, s, t, h)
         times.append(time.perf_counter() - t0)
+    mode = ctx.last_host_mode()
     if register:
         for a in arrays:
             ctx.unregister_host_buffer(a)
     best = min(times[1:])
-    return {"n": n, "registered": register, "ms": round(best * 1e3, 2), "Mpts_s": round(n / best / 1e6, 1),
+    return {"n": n, "registered": register, "zero_copy_mode": mode, "ms": round(best * 1e3, 2), "Mpts_s": round(n / best / 1e6, 1),
             "GB_s_pcie": round(n * 568 / best / 1e9, 2)}
 
 
@@ -62,11 +64,12 @@ def run_resident(n, register):
         t0 = time.perf_counter()
         st.evaluate_into(0.0, 1.0, g, s, t)
         times.append(time.perf_counter() - t0)
+    mode = ctx.last_host_mode()
     if register:
         for a in (g, s, t):
             ctx.unregister_host_buffer(a)
     best = min(times[1:])
-    return {"path": "resident", "n": n, "registered": register, "ms": round(best * 1e3, 2),
+    return {"path": "resident", "n": n, "registered": register, "zero_copy_mode": mode, "ms": round(best * 1e3, 2),
             "Mpts_s": round(n / best / 1e6, 1), "GB_s_pcie": round(n * 408 / best / 1e9, 2)}
 
 
