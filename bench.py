@@ -182,6 +182,21 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
                  "threads": "NumPy/OpenBLAS default"}
         if kind == "von_mises_3d":
             extra["python_per_point_loop_port_Mpts_s"] = time_np(NO.von_mises_3d_loop, min(ns, 30_000))
+            # BASELINE config 3 compares with the comfe-rs CPU path: our C restatement of the serial
+            # evaluate_model loop around MisesPlasticity3D (interfaces.rs:354-456, mises_plasticity.rs:58-126;
+            # mu, kappa, y_0 as above, h = 200 as in tests/models/test_plasticity.py:26-31) on the same
+            # gradients and stresses, 1 thread
+            hr = np.zeros(7 * ns)
+            hr.reshape(-1, 7)[:, 0] = h0["alpha"]
+            rs_p = {"mu": params["p_mu"], "kappa": params["p_ka"], "y_0": params["p_y0"], "h": 200.0}
+            tt, rr = 0.0, 0
+            while tt < 2.0 and rr < 100:
+                s, hh = s0.copy(), {"history": hr.copy()}
+                t0 = time.perf_counter()
+                CO.MODELS["comfe_mises_plasticity"](rs_p, 0.0, del_t, g, s, tan, hh)
+                tt += time.perf_counter() - t0
+                rr += 1
+            extra["comfe_rs_mises_c_port_1_thread_Mpts_s"] = round(ns * rr / tt / 1e6, 2)
         # the same C loop on all host cores (OpenMP over points), for scale only
         nthr = min(CO.max_threads(), os.cpu_count() or 1)
         CO.set_num_threads(nthr)
@@ -199,6 +214,64 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
     return out
 
 
+def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent):
+    """The optional exchange step of the single-assembler mode, timed separately on a
+    bounded slice and never part of `value`: in-place all-gather of stress + tangent slices over RCCL,
+    and (--gather-direct) the one-hop point-to-point variant."""
+    from fenics_constitutive_amd.sharded import ShardPlan
+
+    ng = min(args.gather_points, n)
+    plan = ShardPlan.create(ng * world, world)
+    per = plan.per_rank
+    out_s = torch.empty(6 * per * world, dtype=torch.float64, device=device)
+    out_t = torch.empty(36 * per * world, dtype=torch.float64, device=device)
+    out_s[6 * per * rank : 6 * per * (rank + 1)].copy_(stress_t[: 6 * per])
+    out_t[36 * per * rank : 36 * per * (rank + 1)].copy_(tangent[: 36 * per])
+
+    def time_gather(fn):
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_ = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t_
+            best = dt_ if best is None else min(best, dt_)
+        tt_ = torch.tensor([best], dtype=torch.float64, device=device)
+        dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+        return float(tt_.item())
+
+    def ring():
+        dist.all_gather_into_tensor(out_s, out_s[6 * per * rank : 6 * per * (rank + 1)])
+        dist.all_gather_into_tensor(out_t, out_t[36 * per * rank : 36 * per * (rank + 1)])
+
+    def direct():  # one-hop point-to-point transfers, all peers at once (sharded.allgather_direct)
+        for buf, dim in ((out_s, 6), (out_t, 36)):
+            mine = buf[dim * per * rank : dim * per * (rank + 1)]
+            ops = []
+            for shift in range(1, world):
+                dst, src = (rank + shift) % world, (rank - shift) % world
+                ops.append(dist.P2POp(dist.isend, mine, dst))
+                ops.append(dist.P2POp(dist.irecv, buf[dim * per * src : dim * per * (src + 1)], src))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+
+    shard_bytes = 42 * 8 * per
+    t_ring = time_gather(ring)
+    gather = {"points_per_rank": per, "shard_GB": round(shard_bytes / 1e9, 3),
+              "rccl_all_gather_ms": round(t_ring * 1e3, 3),
+              "rccl_all_gather_recv_GBs_per_gpu": round(shard_bytes * (world - 1) / t_ring / 1e9, 1),
+              "note": "in-place all_gather_into_tensor of stress+tangent slices, outside the timed steps"}
+    if args.gather_direct:
+        t_direct = time_gather(direct)
+        gather["direct_p2p_ms"] = round(t_direct * 1e3, 3)
+        gather["direct_p2p_recv_GBs_per_gpu"] = round(shard_bytes * (world - 1) / t_direct / 1e9, 1)
+    del out_s, out_t
+    return gather
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,9 +282,15 @@ def main():
                     help="quadrature points per GPU (use --points under torch.distributed.run, whose parser claims --n)")
     ap.add_argument("--grid", type=int, default=0, help="override the launch grid (workgroups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sparse-history", action="store_true",
-                    help="VonMises3D: sparse trial-history protocol of device-resident Newton loops "
-                         "(fcamd_evaluate_device_from_sparse); same results, elastic points cost no history traffic")
+    ap.add_argument("--history", choices=["sparse", "full"], default="sparse",
+                    help="plasticity laws: how the trial history is written.  sparse (default) = the protocol of the "
+                         "product's device-resident Newton loop (ResidentState, fcamd_evaluate_device_from_sparse): trial "
+                         "== committed except at plastic / formerly plastic points, so elastic points cost no history "
+                         "traffic; full = every launch rewrites the whole trial history (fcamd_evaluate_device_from)")
+    ap.add_argument("--sparse-history", action="store_true", help="same as --history sparse (kept for old command lines)")
+    ap.add_argument("--placement-tries", type=int, default=4,
+                    help="candidate allocations of the tangent array, timed with the real kernel before the run; the "
+                         "fastest is kept (fenics_constitutive_amd.placement, DESIGN.md 6).  1 = take what the driver gives")
     ap.add_argument("--gather-direct", action="store_true",
                     help="N>1: also time the one-hop point-to-point gather (batched isend/irecv to all peers)")
     ap.add_argument("--gather-points", type=int, default=20_000_000,
@@ -264,7 +343,12 @@ def main():
     g_warm = grad_array()
     law.evaluate(0.0, del_t, g_warm, stress_c, tangent, hist_c)
     del g_warm
-    grad = grad_array()
+    # Two Newton iterates of one increment, evaluated alternately: between the iterations of the
+    # reference's Newton loop only grad_del_u changes (solver/_solver.py:130-147), and with it the
+    # plastic set at its margin -- so the sparse protocol sees new and stale points as it does in use.
+    grads = [grad_array()]
+    grads.append(grads[0] if os.environ.get("BENCH_SINGLE_ITERATE") == "1" else grads[0] * 1.03)  # knob: A/B only
+    grad = grads[0]
     # trial-state arrays: every timed step reads the committed state and writes the trial state
     # (same traffic as in place, stationary workload)
     stress_t = torch.empty_like(stress_c)
@@ -272,22 +356,43 @@ def main():
     if args.grid:
         law._handle(dev_index).ctx.set_grid(args.grid)
 
+    plasticity = kind in ("von_mises_3d", "comfe_mises_plasticity", "comfe_drucker_prager")
+    sparse = plasticity and (args.history == "sparse" or args.sparse_history)
     hmask = None
-    if args.sparse_history:
-        assert kind in ("von_mises_3d", "comfe_mises_plasticity", "comfe_drucker_prager"), \
-            "--sparse-history is a protocol of the plasticity laws"
+    if sparse:
         for k in hist_c:
             hist_t[k].copy_(hist_c[k])  # contract: trial == committed where the mask is clear
         hmask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
 
-    def step():
-        law.evaluate_from(0.0, del_t, grad, stress_c, stress_t, tangent, hist_c, hist_t, history_mask=hmask)
+    # placement of the tangent (the dominant write stream): a few candidate allocations, the real
+    # kernel timed on each, the fastest kept -- what a long-running simulation does once at start-up
+    placement = None
+    if args.placement_tries > 1:
+        from fenics_constitutive_amd.placement import fastest_allocation
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    st = law.device_stats(dev_index)
-    n_pl = int(st.n_plastic) if kind in ("von_mises_3d", "comfe_mises_plasticity", "comfe_drucker_prager") else 0
+        tangent, placement = fastest_allocation(
+            36 * n, lambda tan: law.evaluate_from(0.0, del_t, grads[0], stress_c, stress_t, tan, hist_c, hist_t,
+                                                  history_mask=hmask),
+            tries=args.placement_tries, device=device, first=tangent)
+
+    def step(i):
+        law.evaluate_from(0.0, del_t, grads[i & 1], stress_c, stress_t, tangent, hist_c, hist_t, history_mask=hmask)
+
+    for i in range(args.warmup):
+        step(i)
+    # plastic counts of the two iterates (two more untimed launches)
+    n_pl_ab, its_ab = [], []
+    for i in (0, 1):
+        step(i)
+        torch.cuda.synchronize()
+        st = law.device_stats(dev_index)
+        n_pl_ab.append(int(st.n_plastic) if plasticity else 0)
+        its_ab.append(int(st.n_newton_iters))
+    # averaged over the timed steps (step i evaluates iterate i & 1)
+    n_b = args.steps // 2
+    n_a = args.steps - n_b
+    n_pl = (n_a * n_pl_ab[0] + n_b * n_pl_ab[1]) / args.steps
+    n_its = (n_a * its_ab[0] + n_b * its_ab[1]) / args.steps
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -297,7 +402,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev0[i].record()
-        step()
+        step(i)
         ev1[i].record()
     torch.cuda.synchronize()
     if distributed:
@@ -319,56 +424,10 @@ def main():
     # optional exchange step, timed separately (never part of `value`)
     gather = None
     if distributed and args.backend == "nccl":
-        from fenics_constitutive_amd.sharded import ShardPlan
-
-        ng = min(args.gather_points, n)
-        plan = ShardPlan.create(ng * world, world)
-        per = plan.per_rank
-        out_s = torch.empty(6 * per * world, dtype=torch.float64, device=device)
-        out_t = torch.empty(36 * per * world, dtype=torch.float64, device=device)
-        out_s[6 * per * rank : 6 * per * (rank + 1)].copy_(stress_t[: 6 * per])
-        out_t[36 * per * rank : 36 * per * (rank + 1)].copy_(tangent[: 36 * per])
-        def time_gather(fn):
-            best = None
-            for _ in range(3):
-                torch.cuda.synchronize()
-                dist.barrier()
-                t_ = time.perf_counter()
-                fn()
-                torch.cuda.synchronize()
-                dt_ = time.perf_counter() - t_
-                best = dt_ if best is None else min(best, dt_)
-            tt_ = torch.tensor([best], dtype=torch.float64, device=device)
-            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-            return float(tt_.item())
-
-        def ring():
-            dist.all_gather_into_tensor(out_s, out_s[6 * per * rank : 6 * per * (rank + 1)])
-            dist.all_gather_into_tensor(out_t, out_t[36 * per * rank : 36 * per * (rank + 1)])
-
-        def direct():  # one-hop point-to-point transfers, all peers at once (sharded.allgather_direct)
-            for buf, dim in ((out_s, 6), (out_t, 36)):
-                mine = buf[dim * per * rank : dim * per * (rank + 1)]
-                ops = []
-                for shift in range(1, world):
-                    dst, src = (rank + shift) % world, (rank - shift) % world
-                    ops.append(dist.P2POp(dist.isend, mine, dst))
-                    ops.append(dist.P2POp(dist.irecv, buf[dim * per * src : dim * per * (src + 1)], src))
-                if ops:
-                    for req in dist.batch_isend_irecv(ops):
-                        req.wait()
-
-        shard_bytes = 42 * 8 * per
-        t_ring = time_gather(ring)
-        gather = {"points_per_rank": per, "shard_GB": round(shard_bytes / 1e9, 3),
-                  "rccl_all_gather_ms": round(t_ring * 1e3, 3),
-                  "rccl_all_gather_recv_GBs_per_gpu": round(shard_bytes * (world - 1) / t_ring / 1e9, 1),
-                  "note": "in-place all_gather_into_tensor of stress+tangent slices, outside the timed steps"}
-        if args.gather_direct:
-            t_direct = time_gather(direct)
-            gather["direct_p2p_ms"] = round(t_direct * 1e3, 3)
-            gather["direct_p2p_recv_GBs_per_gpu"] = round(shard_bytes * (world - 1) / t_direct / 1e9, 1)
-        del out_s, out_t
+        try:
+            gather = time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent)
+        except Exception as e:  # e.g. out of memory on every rank alike: the step timing above stands
+            gather = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # "achievable" next to "peak" (SURVEY 8d): a plain device copy over half of the tangent array
     # (read + write counted), after everything that still needs the arrays
@@ -391,7 +450,7 @@ def main():
     if rank == 0:
         total_pts = n * world * args.steps
         value = total_pts / elapsed / 1e6
-        alg_bytes = (n - n_pl) * b_el + n_pl * b_pl
+        alg_bytes = int(round((n - n_pl) * b_el + n_pl * b_pl))
         achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -399,7 +458,7 @@ def main():
             try:
                 with open(tf) as f:
                     tj = json.load(f)
-                e = tj.get(args.workload + ("_sparse" if args.sparse_history else ""))
+                e = tj.get(args.workload + ("_full" if plasticity and not sparse else ""))
                 if e and int(e.get("n", 0)) == n:
                     traffic = e.get("hbm_bytes_per_launch")
             except Exception:
@@ -418,8 +477,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {kind} FULL-3D, {n} quadrature points per GPU, device-resident AoS, "
-                                   f"committed->trial evaluate{' (sparse trial history)' if args.sparse_history else ''}", "points_per_gpu": n, "plastic_fraction": round(n_pl / n, 4),
-                       "mean_newton_iters": round(st.n_newton_iters / max(n_pl, 1), 3) if kind in ("von_mises_3d", "comfe_drucker_prager") else None,
+                                   f"committed->trial evaluate of two alternating Newton iterates"
+                                   f"{', sparse trial history (ResidentState protocol)' if sparse else (', full trial history' if plasticity else '')}",
+                       "points_per_gpu": n, "plastic_fraction": round(n_pl / n, 4),
+                       "mean_newton_iters": round(n_its / max(n_pl, 1), 3) if kind in ("von_mises_3d", "comfe_drucker_prager") else None,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -429,6 +490,8 @@ def main():
                          "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
                          "bytes_per_point": {"elastic": b_el, "plastic": b_pl}},
         }
+        if placement is not None:
+            out["placement"] = {"tangent_" + k: v for k, v in placement.items()}
         if per_rank_ms is not None:
             out["per_rank_kernel_ms"] = per_rank_ms
         if gather:

@@ -541,30 +541,43 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     //
     // Sparse trial history (a.hmask != nullptr; device-resident Newton loops): the trial arrays
     // are kept equal to the committed ones except at the points recorded in hmask (one 64-bit
-    // word per tile = the plastic ballot of the previous evaluate).  Then only plastic lanes
-    // (new trial value) and stale lanes (plastic last time, elastic now: restore the committed
-    // value) touch their own 48-byte eps_n row; elastic points cost no history traffic at all,
-    // which is exactly the algorithmic byte count (464 B/pt elastic, 568 B/pt plastic).
+    // word per tile = the plastic ballot of the previous evaluate).  Then only plastic points
+    // (new trial value) and stale points (plastic last time, elastic now: restore the committed
+    // value) need their 48-byte eps_n row touched; elastic points cost no history traffic at all,
+    // which is exactly the algorithmic byte count (464 B/pt elastic, 568 B/pt plastic).  The plain
+    // in-place call (the reference contract) is the same case without stale points.
+    //
+    // Row-masked tile access: a 48-byte row is exactly three 16-byte chunks of the tile's linear
+    // image (chunk q belongs to row q / 3), so the tile keeps its three wave-wide, address-ordered
+    // load and store instructions and every lane simply skips the chunks of untouched rows.  HBM
+    // sees the touched rows only (reads at the 128-byte line granularity of the memory side), the
+    // instruction count does not depend on how many rows are touched, and a fully plastic tile
+    // degenerates to the plain coalesced tile access.
     Chunks<6> ce;
     constexpr bool sparse = SPARSE;
     unsigned long long m_old = 0ull;
     if constexpr (sparse) m_old = a.hmask[p0 >> 6];
-    // Row accesses pay per touched lane (three scattered 16-byte loads and stores, 64-byte DRAM
-    // sectors); above ~1/5 of the lanes the coalesced tile path is cheaper (measured: rows win by
-    // 16 % on all-elastic data, lose 27 % on all-plastic data), so tiles with many touched lanes
-    // take the dense path -- which also restores stale lanes, since it writes the whole tile.
-    constexpr int kSparseRowMax = 12;
     const unsigned long long need_mask = mask | m_old;
-    // The same row path serves the plain in-place call (the reference contract): there only the
-    // plastic lanes of a tile change their history, no mask is needed.
-    const bool use_rows = (sparse || hist_in_place) && (need_mask != 0ull) &&
-                          (__popcll(need_mask) <= kSparseRowMax);
-    const bool need_row = use_rows && (plastic || (((m_old >> lane) & 1ull) != 0ull));
-    const bool touch_eps = !use_rows && (sparse ? (need_mask != 0ull) : ((mask != 0ull) || !hist_in_place));
-    if (touch_eps) tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
-    if (need_row) {
+    const bool masked = FULL && (sparse || hist_in_place);
+    const bool touch_eps = masked ? (need_mask != 0ull)
+                                  : (sparse ? (need_mask != 0ull) : ((mask != 0ull) || !hist_in_place));
+    bool row_live[3] = {true, true, true};  // per chunk of this lane: its row is touched
+    if (masked) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ce.v[k] = load16<NT>(a.h0_in + (p0 + lane) * 6 + 2 * k);
+        for (int k = 0; k < 3; ++k) row_live[k] = ((need_mask >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
+    }
+    if (touch_eps) {
+        if (masked) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d2 z;
+                z.x = 0.0;
+                z.y = 0.0;
+                ce.v[k] = row_live[k] ? load16<NT>(a.h0_in + p0 * 6 + 2 * (k * kWave + lane)) : z;
+            }
+        } else {
+            tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
+        }
     }
 
     double gamma = 0.0, xc1 = 0.0, xc2 = 0.0;
@@ -616,23 +629,26 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
             transpose_in<6>(ce, region, lane, ep);
 #pragma unroll
             for (int i = 0; i < 6; ++i) ep[i] = ep[i] + gamma * N[i];
-            transpose_out<6, FULL, NT>(ep, region, lane, a.h0_out + p0 * 6, npts * 6);
+            if (masked) {
+                lds_put_point<6>(region, lane, ep);
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int q = k * kWave + lane;
+                    if (row_live[k]) store16<NT>(a.h0_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+                }
+                wave_sync();
+            } else {
+                transpose_out<6, FULL, NT>(ep, region, lane, a.h0_out + p0 * 6, npts * 6);
+            }
+        } else if (masked) {  // only stale rows: restore the committed values
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (row_live[k]) store16<NT>(a.h0_out + p0 * 6 + 2 * (k * kWave + lane), ce.v[k]);
         } else {
             tile_store<6, FULL, NT>(ce, a.h0_out + p0 * 6, npts * 6, lane);
         }
-        if (live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
-    }
-    if (use_rows) {
-        if (need_row) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                d2 v;
-                v.x = ce.v[k].x + gamma * N[2 * k];
-                v.y = ce.v[k].y + gamma * N[2 * k + 1];
-                store16<NT>(a.h0_out + (p0 + lane) * 6 + 2 * k, v);
-            }
-        }
-        // alpha: one coalesced 512-byte store per tile that has (or had) a plastic point
+        // alpha: one coalesced 512-byte store per touched tile
         if (live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
     }
     if constexpr (sparse) {

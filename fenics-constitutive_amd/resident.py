@@ -131,6 +131,30 @@ class ResidentState:
                                self.history_committed, self.history, history_mask=self._mask)
         self._evaluated = True
 
+    def tune_placement(self, t: float, del_t: float, grad_del_u, tries: int = 4) -> dict:
+        """Device-assembler mode: choose the placement of the tangent array (the dominant write
+        stream) by timing this state's own evaluate on a few candidate allocations and keeping the
+        fastest (``placement.fastest_allocation``; on MI355X the kernel time follows where the
+        written arrays live, by up to 20 %).  Call once, before the Newton loops; leaves a valid
+        trial state for ``grad_del_u``.  Returns the candidate timings."""
+        from .placement import fastest_allocation
+
+        g = grad_del_u
+        if not _is_torch(g):
+            self.grad.copy_(self._as_dev(g), non_blocking=True)
+            g = self.grad
+        assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
+        first, self._tangent = self._tangent, None
+        self._tangent, info = fastest_allocation(
+            self._sd * self._sd * self.n,
+            lambda tan: self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, tan,
+                                               self.history_committed, self.history, history_mask=self._mask),
+            tries=tries, device=self.device, first=first)
+        del first
+        self._tangent_key = None  # a constant tangent has to be written into the chosen array
+        self.evaluate(t, del_t, g)
+        return info
+
     def evaluate_into(self, t: float, del_t: float, grad_del_u: np.ndarray, stress: np.ndarray | None = None,
                       tangent: np.ndarray | None = None):
         """The host assembler's Newton-iteration call: trial state <- law(committed state,

@@ -219,3 +219,34 @@ def test_evaluate_into_tiny_sizes(n):
         assert rel_err(s, ref[0]) <= 1e-9 and rel_err(t, ref[1]) <= 1e-6
         st.update()
         assert rel_err(st.history_committed["alpha"].cpu().numpy(), ref[2]["alpha"]) <= 1e-6
+
+
+def test_tune_placement_keeps_results():
+    """ResidentState.tune_placement picks the tangent allocation by timing; numbers are unaffected."""
+    from fenics_constitutive_amd.placement import fastest_allocation
+    from oracle import c_oracle as CO
+    from test_gpu_parity import LE_P, make_law, oracle_run, random_case
+
+    n = 200_000
+    p, g, s, h = random_case("von_mises_3d", n, seed=77)
+    ref = oracle_run("von_mises_3d", p, 1.0, g, s, h, mod=CO)
+    for kind, pp in (("von_mises_3d", p), ("linear_elasticity", LE_P)):
+        law = make_law(kind, pp)
+        hh = h if kind == "von_mises_3d" else None
+        a = ResidentState(law, n, stress0=s, history0=hh)
+        b = ResidentState(law, n, stress0=s, history0=hh)
+        a.evaluate(0.0, 1.0, g)
+        info = b.tune_placement(0.0, 1.0, g, tries=3)
+        assert len(info["candidate_ms"]) == 3 and 0 <= info["chosen"] < 3 and min(info["candidate_ms"]) > 0
+        torch.cuda.synchronize()
+        assert torch.equal(a.stress, b.stress) and torch.equal(a.tangent, b.tangent)
+        if hh is not None:
+            for k in hh:
+                assert torch.equal(a.history[k], b.history[k])
+            assert rel_err(b.tangent.cpu().numpy(), ref[1]) <= 1e-11
+        b.evaluate(0.0, 1.0, g)  # constant-tangent laws: the chosen array holds the tangent
+        torch.cuda.synchronize()
+        assert torch.equal(a.tangent, b.tangent)
+    # the helper alone
+    t, info = fastest_allocation(1 << 20, lambda x: x.fill_(1.0), tries=2)
+    assert t.numel() == 1 << 20 and t.dtype == torch.float64 and len(info["candidate_ms"]) == 2

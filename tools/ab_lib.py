@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B two builds of libfcamd.so in ONE process on identical buffers (interleaved rounds):
     python tools/ab_lib.py libA.so libB.so [n ...]
-VonMises3D mixed workload, committed->trial evaluate."""
+VonMises3D mixed workload, committed->trial evaluate.  AB_SPARSE=1: sparse trial-history protocol
+(fcamd_evaluate_device_from_sparse, VonMises3D only); AB_ZONED=1: plastic points in contiguous
+4096-point zones instead of a random mixture."""
 import ctypes as C
 import sys
 
@@ -11,6 +13,8 @@ import os
 libs = sys.argv[1:3]
 sizes = [int(float(x)) for x in sys.argv[3:]] or [1_000_000, 10_000_000, 100_000_000]
 LAW = os.environ.get("AB_LAW", "vm")  # vm | le | maxwell
+SPARSE = os.environ.get("AB_SPARSE", "0") == "1"
+ZONED = os.environ.get("AB_ZONED", "0") == "1"
 MODEL = {"vm": (2, [175000.0, 80769.0, 1200.0, 2500.0, 200.0], 2), "le": (1, [42.0, 0.3], 0), "maxwell": (3, [42.0, 10.0, 10.0, 0.2], 2)}[LAW]
 dev = torch.device("cuda", 0)
 torch.zeros(1, device=dev)
@@ -28,9 +32,21 @@ class Lib:
         assert self.l.fcamd_model_create(self.ctx, MODEL[0], 5, P, len(MODEL[1]), C.byref(self.m)) == 0
         self.l.fcamd_evaluate_device_from.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64] + [C.c_void_p] * 4 + [C.POINTER(C.c_void_p)] * 2 + [C.c_int]
 
+        self.l.fcamd_evaluate_device_from_sparse.argtypes = self.l.fcamd_evaluate_device_from.argtypes + [C.c_void_p]
+        self.mask = None
+
     def run(self, n, g, s0, s1, t, h0, h1):
         a0 = (C.c_void_p * 2)(h0[0].data_ptr(), h0[1].data_ptr())
         a1 = (C.c_void_p * 2)(h1[0].data_ptr(), h1[1].data_ptr())
+        if SPARSE:
+            if self.mask is None or self.mask.numel() != (n + 63) // 64:
+                # protocol: trial == committed wherever the mask is clear
+                h1[0].copy_(h0[0]), h1[1].copy_(h0[1])
+                self.mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+            rc = self.l.fcamd_evaluate_device_from_sparse(self.m, 0.0, 1.0, n, g.data_ptr(), s0.data_ptr(), s1.data_ptr(),
+                                                          t.data_ptr(), a0, a1, MODEL[2], self.mask.data_ptr())
+            assert rc == 0, rc
+            return
         rc = self.l.fcamd_evaluate_device_from(self.m, 0.0, 1.0, n, g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, MODEL[2])
         assert rc == 0, rc
 
@@ -40,7 +56,11 @@ f = dict(dtype=torch.float64, device=dev)
 for n in sizes:
     gen = torch.Generator(device=dev).manual_seed(1)
     g = torch.randn(9 * n, generator=gen, **f)
-    g.view(n, 9).mul_(torch.pow(10.0, torch.rand(n, generator=gen, **f) * 2 - 4)[:, None])
+    if ZONED:
+        pl = torch.rand((n + 4095) // 4096, generator=gen, **f) < 0.22
+        g.view(n, 9).mul_(torch.where(pl, 1e-2, 1e-4).to(torch.float64).repeat_interleave(4096)[:n][:, None])
+    else:
+        g.view(n, 9).mul_(torch.pow(10.0, torch.rand(n, generator=gen, **f) * 2 - 4)[:, None])
     s0, s1 = torch.zeros(6 * n, **f), torch.empty(6 * n, **f)
     if LAW == "maxwell":
         h0 = [torch.zeros(6 * n, **f), torch.zeros(6 * n, **f)]
