@@ -16,6 +16,8 @@ import os
 import sys
 
 src, rnd, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+extra_args = sys.argv[4] if len(sys.argv) > 4 else ""  # bench flags beyond --workload (e.g. "--history full")
+is_default = workload == "default_bench"  # tools/profile_default.sh: `python3 bench.py`, kernel trace only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -48,8 +50,17 @@ alg = bench.get("roofline", {}).get("algorithmic_bytes_per_launch", 0)
 out = os.path.join(ROOT, "profiles", f"r{rnd}_{workload}_rocprof.md")
 with open(out, "w") as f:
     f.write(f"# rocprofv3 summary, round {rnd}, workload `{workload}`\n\n")
-    f.write("Command (tools/profile_gpu.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
-            f"--steps 10 --warmup 2 --no-cpu-baseline --workload {workload}` and one `--pmc FETCH_SIZE`, one `--pmc WRITE_SIZE` pass.\n\n")
+    if is_default:
+        f.write("Command (tools/profile_default.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py` "
+                "-- the default bench command, no flags.\n\n")
+    else:
+        wl = workload[:-5] if workload.endswith("_full") else workload
+        f.write("Command (tools/profile_gpu.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
+                f"--steps 10 --warmup 2 --no-cpu-baseline --workload {wl} {extra_args}` and one `--pmc FETCH_SIZE`, one "
+                "`--pmc WRITE_SIZE` pass (`--steps 4 --warmup 2`).\n\n")
+    f.write("Launch sequence of one bench run: 1 in-place warm step (kernel variant `<..., false>`), 4 placement candidates "
+            "x 4 launches (bench.py --placement-tries, the slower candidates are part of the `kernel_stats` average below), "
+            "the warm-up steps, 2 launches that read the plastic counts of the two Newton iterates, then the timed steps.\n\n")
     f.write("## kernel stats (`*_kernel_stats.csv`, top rows)\n\n| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|\n")
     for r in stats[:6]:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} | {int(r['MinNs'])/1e6:.4f} | {int(r['MaxNs'])/1e6:.4f} |\n")
@@ -62,16 +73,22 @@ with open(out, "w") as f:
     if timed:
         f.write(f"timed launches (last {len(timed)}): avg **{sum(timed)/len(timed):.4f} ms**, min {min(timed):.4f} ms; "
                 f"bench.py's own HIP-event average in the same run: {bench.get('roofline', {}).get('kernel_ms_avg')} ms\n\n")
-    f.write("## HBM traffic per launch (PMC, corrected)\n\n")
-    f.write(f"* FETCH_SIZE avg {sum(fk)/max(len(fk),1):.1f} KiB -> x1024 x2 (gfx950 wide-read correction) = **{fetch_b/1e9:.3f} GB read**\n")
-    f.write(f"* WRITE_SIZE avg {sum(wk)/max(len(wk),1):.1f} KiB -> x1024 = **{write_b/1e9:.3f} GB written**\n")
-    f.write(f"* total **{(fetch_b+write_b)/1e9:.3f} GB** per launch; algorithmic bytes (bench.py) {alg/1e9:.3f} GB; ratio {(fetch_b+write_b)/max(alg,1):.3f}\n")
-    if n:
+    if is_default:
+        f.write("HBM traffic (PMC passes) of this workload: `r%s_von_mises_mixed_rocprof.md`.\n" % rnd)
+    else:
+      f.write("## HBM traffic per launch (PMC, corrected)\n\n")
+      f.write(f"* FETCH_SIZE avg {sum(fk)/max(len(fk),1):.1f} KiB -> x1024 x2 (gfx950 wide-read correction) = **{fetch_b/1e9:.3f} GB read**\n")
+      f.write(f"* WRITE_SIZE avg {sum(wk)/max(len(wk),1):.1f} KiB -> x1024 = **{write_b/1e9:.3f} GB written**\n")
+      f.write(f"* total **{(fetch_b+write_b)/1e9:.3f} GB** per launch; algorithmic bytes (bench.py) {alg/1e9:.3f} GB; ratio {(fetch_b+write_b)/max(alg,1):.3f}\n")
+      if n:
         f.write(f"* per point: {fetch_b/n:.1f} B read + {write_b/n:.1f} B written = {(fetch_b+write_b)/n:.1f} B\n")
     if bench:
         f.write("\n## bench line of the profiled run\n\n```json\n" + json.dumps(bench) + "\n```\n")
 tj = os.path.join(ROOT, "profiles", "traffic.json")
 d = json.load(open(tj)) if os.path.exists(tj) else {}
+if is_default:
+    print(out)
+    sys.exit(0)
 d[workload] = {"n": n, "hbm_bytes_per_launch": int(fetch_b + write_b), "read_bytes": int(fetch_b), "write_bytes": int(write_b),
                "round": rnd, "source": os.path.basename(out)}
 json.dump(d, open(tj, "w"), indent=1, sort_keys=True)
