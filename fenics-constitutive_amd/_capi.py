@@ -91,7 +91,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
-        path = _build.LIB
+        path = os.environ.get("FCAMD_LIBRARY") or _build.LIB  # override: A/B of two builds (tools/)
         if not os.path.exists(path):
             if not build_if_missing:
                 raise RuntimeError(f"{path} is missing; run __graft_entry__.build()")

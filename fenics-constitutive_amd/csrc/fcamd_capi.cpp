@@ -28,6 +28,15 @@ using namespace fcamd;
 
 namespace {
 
+// Row-masked history access (fcamd_kernels.hip: tile_von_mises, history7_store) pays off while few rows
+// of a tile are touched: every skipped row saves its bytes, but holes turn full-line writes into partial
+// ones.  Tiles with more touched rows than this take the dense tile path.  Measured at 5e7 points
+// (tools/masked_threshold_probe.py, random mixtures, sparse protocol; dense = 5.55 ms for VonMises3D):
+// 5 % plastic 4.75 ms, 10 % 4.93, 19 % 5.23, 33 % 5.52 with thresholds 16-24, while "always masked" loses
+// 4-6 % from 47 % plastic on; the 56-byte rows of the comfe-rs laws straddle chunks and turn earlier.
+constexpr int kMaskedRowMaxVonMises = 20;
+constexpr int kMaskedRowMaxRows7 = 16;
+
 constexpr size_t kCounterBytes = (size_t)fcamd::kCounterSlots * 4 * sizeof(unsigned long long);
 
 thread_local std::string g_last_error;
@@ -419,6 +428,8 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
         const char* e = getenv("FCAMD_TILE_MAP");
         const int tm = e ? atoi(e) : 0;
         a.tile_map = tm;
+        const char* mm = getenv("FCAMD_MASKED_MAX");  // experiments (tools/masked_threshold_probe.py)
+        a.masked_max = mm ? atoi(mm) : (m->law == FCAMD_VON_MISES_3D ? kMaskedRowMaxVonMises : kMaskedRowMaxRows7);
     }
     fill_constants(m, del_t, &a);
     // only the plasticity laws count anything: skip the extra launch for the others
@@ -793,6 +804,7 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
     a.n = n;
     a.counters = m->d_counters;
     a.tile_map = 0;
+    a.masked_max = 0;  // the wrapped tile bodies have no row-masked path
     fill_constants(m, del_t, &a);
     HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->stream));
     if (n == 0) return FCAMD_OK;

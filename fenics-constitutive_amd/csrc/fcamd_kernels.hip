@@ -558,7 +558,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     unsigned long long m_old = 0ull;
     if constexpr (sparse) m_old = a.hmask[p0 >> 6];
     const unsigned long long need_mask = mask | m_old;
-    const bool masked = FULL && (sparse || hist_in_place);
+    const bool masked = FULL && (sparse || hist_in_place) && (__popcll(need_mask) <= a.masked_max);
     const bool touch_eps = masked ? (need_mask != 0ull)
                                   : (sparse ? (need_mask != 0ull) : ((mask != 0ull) || !hist_in_place));
     bool row_live[3] = {true, true, true};  // per chunk of this lane: its row is touched
@@ -954,18 +954,44 @@ __device__ __forceinline__ void tile_comfe_mises_wrapped(const EvalArgs& a, cons
 }
 
 // History write policy of the laws with one [alpha, eps_p(6)] row per point (comfe-rs Mises and
-// Drucker-Prager).  In place: only tiles with a plastic point change.  Out of place: every tile is
-// copied -- unless the caller runs the sparse trial-history protocol (a.hmask != nullptr, see
-// tile_von_mises): the trial array equals the committed one wherever the tile's mask word is clear,
-// so a tile is written only if it has a plastic point now (new values) or had one at the previous
-// evaluate (stale rows: the whole-tile write restores them).  The 56-byte rows share their DRAM
-// sectors with their neighbours, so the granularity is the tile, not the row.
-__device__ __forceinline__ bool history_tile_needs_write(const EvalArgs& a, long long p0, unsigned long long mask,
-                                                         bool hist_in_place, int lane) {
-    if (a.hmask == nullptr) return mask != 0ull || !hist_in_place;
-    const unsigned long long m_old = a.hmask[p0 >> 6];
-    if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
-    return (mask | m_old) != 0ull;
+// Drucker-Prager; the row is always READ: alpha enters the yield function).  Which rows change:
+//   in place                      : the plastic points of this evaluate (ballot `mask`);
+//   out of place                  : every row is copied;
+//   out of place, sparse protocol : (a.hmask != nullptr, see tile_von_mises) the trial array equals the
+//                                   committed one wherever the tile's mask word is clear, so the rows
+//                                   of the points that are plastic now (new values) or were plastic at
+//                                   the previous evaluate (stale: restore the committed values).
+// Row-masked tile store: the tile keeps its four wave-wide, address-ordered store instructions and a
+// lane skips the 16-byte chunks that lie entirely in untouched rows (chunk q holds doubles 2q and
+// 2q + 1 of the tile image, i.e. parts of rows 2q / 7 and (2q + 1) / 7; a chunk straddling a touched
+// and an untouched row rewrites 8 bytes of the latter with the value it already has).
+template <bool FULL, bool NT>
+__device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, int npts, int lane,
+                                               unsigned long long mask, bool hist_in_place, double* region,
+                                               const double (&h)[7]) {
+    unsigned long long need = ~0ull;
+    if (a.hmask != nullptr) {
+        const unsigned long long m_old = a.hmask[p0 >> 6];
+        if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
+        need = mask | m_old;
+    } else if (hist_in_place) {
+        need = mask;
+    }
+    if (need == 0ull) return;
+    if (!FULL || need == ~0ull || __popcll(need) > a.masked_max) {
+        transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+        return;
+    }
+    lds_put_point<7>(region, lane, h);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < Chunks<7>::K; ++k) {
+        const int q = k * kWave + lane;
+        const bool touched = (((need >> ((2 * q) / 7)) | (need >> ((2 * q + 1) / 7))) & 1ull) != 0ull;
+        if (chunk_live<7>(k, lane) && touched)
+            store16<NT>(a.h0_out + p0 * 7 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+    }
+    wave_sync();
 }
 
 // --- comfe-rs MisesPlasticity3D: linear hardening, closed-form radial return ---------------
@@ -1044,8 +1070,7 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
         s[i] = i < 3 ? p_1 + ts : ts;
     }
     sr.put(sb, region, lane, s, p0, npts);
-    if (history_tile_needs_write(a, p0, mask, hist_in_place, lane))
-        transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+    history7_store<FULL, NT>(a, p0, npts, lane, mask, hist_in_place, region, h);
 
     if (sb.tan) {
         const double B = plastic ? two_mu * theta : two_mu;
@@ -1309,8 +1334,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     if (mask == 0ull) {
         // fully elastic tile: stress = sigma_tr, tangent = E, history untouched
         sr.put(sb, region, lane, t.sig1, p0, npts);
-        if (history_tile_needs_write(a, p0, 0ull, hist_in_place, lane))
-            transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+        history7_store<FULL, NT>(a, p0, npts, lane, 0ull, hist_in_place, region, h);
         if (sb.tan) {
             if constexpr (IDX) wave_sync();
             tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
@@ -1326,8 +1350,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     st.domain += (live && t.tip) ? 1ull : 0ull;  // tip of the classic surface reached (reference: assert!)
 
     sr.put(sb, region, lane, t.sig1, p0, npts);
-    (void)history_tile_needs_write(a, p0, mask, hist_in_place, lane);  // records the mask; this tile is written
-    transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+    history7_store<FULL, NT>(a, p0, npts, lane, mask, hist_in_place, region, h);
 
     if (sb.tan) {
         dp_publish(region, lane, tg, t.s_tr, plastic);
