@@ -158,6 +158,26 @@ class ResidentProblemState:
                                         ls.rows, hp, hc, history_mask=ls.mask)
         self._evaluated = True
 
+    def tune_placement(self, grads, tries: int = 4) -> dict:
+        """Choose the placement of the parent tangent array (the dominant write stream of every law's
+        launch) by timing one full ``evaluate(grads)`` on a few candidate allocations and keeping the
+        fastest (``placement.fastest_allocation``, DESIGN.md 6).  Call once before the Newton loops;
+        leaves a valid trial state for ``grads``."""
+        from .placement import fastest_allocation
+
+        def probe(tan):
+            self.tangent = tan
+            for ls in self._laws:
+                ls.tangent_key = None  # constant tangents have to be written into the candidate
+            self.evaluate(grads)
+
+        first, self.tangent = self.tangent, None
+        chosen, info = fastest_allocation(36 * self.n, probe, tries=tries, device=self.device, first=first)
+        del first
+        chosen.zero_()  # rows of points that belong to no law stay zero, as in a freshly built state
+        probe(chosen)
+        return info
+
     def check(self) -> None:
         """Synchronise; raises the reference's exceptions (Newton non-convergence) per law."""
         dev = self.device.index or 0

@@ -85,3 +85,34 @@ def test_single_law_and_guards():
     assert np.array_equal(st.stress_0.cpu().numpy(), st._stress[st._c].cpu().numpy())
     with pytest.raises(AssertionError):  # overlapping rows
         ResidentProblemState([(law, np.array([0, 1])), (law, np.array([1, 2]))], 3)
+
+
+def test_tune_placement_keeps_results():
+    """ResidentProblemState.tune_placement swaps the parent tangent array for the fastest of a few
+    candidate allocations; stress, tangent (incl. the rows no law owns) and histories are unaffected."""
+    n = 6000
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n)
+    rows = [np.sort(perm[:2500]).astype(np.int32), np.sort(perm[2500:5200]).astype(np.int32)]  # 800 points unowned
+    kinds = ["linear_elasticity", "von_mises_3d"]
+    cases = [random_case(k, r.size, seed=11 + i) for i, (k, r) in enumerate(zip(kinds, rows))]
+    laws = [make_law(k, c[0]) for k, c in zip(kinds, cases)]
+    grads = [c[1] for c in cases]
+    stress = rng.normal(size=6 * n)
+    hist = [c[3] for c in cases]
+    a = ResidentProblemState(list(zip(laws, rows)), n, del_t=1.0)
+    b = ResidentProblemState(list(zip(laws, rows)), n, del_t=1.0)
+    for st in (a, b):
+        st.set_state(stress, hist)
+    a.evaluate(grads)
+    info = b.tune_placement(grads, tries=3)
+    assert len(info["candidate_ms"]) == 3
+    torch.cuda.synchronize()
+    assert torch.equal(a.stress_1, b.stress_1) and torch.equal(a.tangent, b.tangent)
+    for ha, hb in zip(a._history_1, b._history_1):
+        if ha is not None:
+            for k in ha:
+                assert torch.equal(ha[k], hb[k])
+    b.evaluate(grads)  # the constant LE rows are not rewritten and still there
+    torch.cuda.synchronize()
+    assert torch.equal(a.tangent, b.tangent)
