@@ -288,6 +288,10 @@ def main():
                          "== committed except at plastic / formerly plastic points, so elastic points cost no history "
                          "traffic; full = every launch rewrites the whole trial history (fcamd_evaluate_device_from)")
     ap.add_argument("--sparse-history", action="store_true", help="same as --history sparse (kept for old command lines)")
+    ap.add_argument("--sparse-tangent", action="store_true",
+                    help="with --history sparse: also the sparse-tangent protocol of ResidentState (FCAMD_EVAL_SPARSE_TANGENT: "
+                         "rows of points that stay elastic are not rewritten).  Not the reference contract -- the reported "
+                         "bytes stay the interface's 464/568 B/pt, so `frac` is an equivalent, not a traffic, figure")
     ap.add_argument("--placement-tries", type=int, default=4,
                     help="candidate allocations of the tangent array, timed with the real kernel before the run; the "
                          "fastest is kept (fenics_constitutive_amd.placement, DESIGN.md 6).  1 = take what the driver gives")
@@ -375,8 +379,11 @@ def main():
                                                   history_mask=hmask),
             tries=args.placement_tries, device=device, first=tangent)
 
+    sparse_tangent = bool(args.sparse_tangent and sparse)
+
     def step(i):
-        law.evaluate_from(0.0, del_t, grads[i & 1], stress_c, stress_t, tangent, hist_c, hist_t, history_mask=hmask)
+        law.evaluate_from(0.0, del_t, grads[i & 1], stress_c, stress_t, tangent, hist_c, hist_t, history_mask=hmask,
+                          sparse_tangent=sparse_tangent)
 
     for i in range(args.warmup):
         step(i)
@@ -478,7 +485,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {kind} FULL-3D, {n} quadrature points per GPU, device-resident AoS, "
                                    f"committed->trial evaluate of two alternating Newton iterates"
-                                   f"{', sparse trial history (ResidentState protocol)' if sparse else (', full trial history' if plasticity else '')}",
+                                   f"{', sparse trial history (ResidentState protocol)' if sparse else (', full trial history' if plasticity else '')}"
+                                   f"{', sparse tangent (rows of points that stay elastic are not rewritten)' if sparse_tangent else ''}",
                        "points_per_gpu": n, "plastic_fraction": round(n_pl / n, 4),
                        "mean_newton_iters": round(n_its / max(n_pl, 1), 3) if kind in ("von_mises_3d", "comfe_drucker_prager") else None,
                        "parallelism": f"shard{world}"},

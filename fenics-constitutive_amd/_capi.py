@@ -23,6 +23,9 @@ OK, ERR_SIZE, ERR_NULL_HISTORY, ERR_DEL_T, ERR_NONCONVERGED, ERR_HIP, ERR_BAD_AR
 
 MAX_HISTORY = 2
 
+# fcamd_eval_args.flags / fcamd_evaluate_resident flags (include/fcamd.h)
+EVAL_SPARSE_TANGENT = 1
+
 # fcamd_context_last_host_mode flags (include/fcamd.h)
 HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT = 1, 2
 
@@ -48,7 +51,7 @@ class EvalArgs(C.Structure):
 
     _fields_ = [("grad_del_u", C.c_void_p), ("stress_prev", C.c_void_p), ("stress", C.c_void_p),
                 ("tangent", C.c_void_p), ("history_prev", C.POINTER(C.c_void_p)), ("history", C.POINTER(C.c_void_p)),
-                ("n_hist", C.c_int), ("parent_rows", C.c_void_p), ("history_mask", C.c_void_p)]
+                ("n_hist", C.c_int), ("parent_rows", C.c_void_p), ("history_mask", C.c_void_p), ("flags", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -119,7 +122,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_evaluate_device_wrapped.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp,
                                                       C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_resident.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.POINTER(vp),
-                                                C.c_int, vp, vp, vp, C.POINTER(Stats)]
+                                                C.c_int, vp, C.c_int, vp, vp, C.POINTER(Stats)]
         lib.fcamd_strain_from_grad_u_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int]
         lib.fcamd_convert_device.argtypes = [vp, C.c_int, C.c_int64, vp, vp]
         lib.fcamd_map_rows_device.argtypes = [vp, C.c_int64, C.c_int, vp, vp, vp, vp]
@@ -279,11 +282,11 @@ class Model:
             C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), parr, arr, nh))
 
     def evaluate_device_ex(self, t, del_t, n, grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr, hist_prev_ptrs,
-                           hist_ptrs, rows_ptr=None, mask_ptr=None) -> None:
+                           hist_ptrs, rows_ptr=None, mask_ptr=None, flags: int = 0) -> None:
         arr, nh = self._ptr_array(hist_ptrs)
         parr, _ = self._ptr_array(hist_prev_ptrs)
         x = EvalArgs(grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr or None, parr, arr, nh, rows_ptr or None,
-                     mask_ptr or None)
+                     mask_ptr or None, int(flags))
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
 
     def evaluate_device_wrapped(self, wrapper_constraint, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, stress3d_ptr,
@@ -294,13 +297,13 @@ class Model:
             C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), C.c_void_p(stress3d_ptr), arr, nh))
 
     def evaluate_resident(self, t, del_t, n, grad_host_ptr, stress_prev_ptr, stress_ptr, hist_prev_ptrs, hist_ptrs,
-                          mask_ptr, stress_host_ptr, tangent_host_ptr) -> Stats:
+                          mask_ptr, stress_host_ptr, tangent_host_ptr, flags: int = 0) -> Stats:
         arr, nh = self._ptr_array(hist_ptrs)
         parr, _ = self._ptr_array(hist_prev_ptrs)
         st = Stats()
         status = self._lib.fcamd_evaluate_resident(self.handle, float(t), float(del_t), int(n), C.c_void_p(grad_host_ptr),
                                                    C.c_void_p(stress_prev_ptr), C.c_void_p(stress_ptr), parr, arr, nh,
-                                                   C.c_void_p(mask_ptr or 0), C.c_void_p(stress_host_ptr or 0),
+                                                   C.c_void_p(mask_ptr or 0), int(flags), C.c_void_p(stress_host_ptr or 0),
                                                    C.c_void_p(tangent_host_ptr or 0), C.byref(st))
         check(status)
         return st

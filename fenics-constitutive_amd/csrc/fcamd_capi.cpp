@@ -409,7 +409,7 @@ int grid_for(fcamd_model* m, int64_t n) {
 int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
             double* stress, double* tangent, const double* const* hprev, double* const* hcur,
             hipStream_t stream, bool reset_counters, const int* rows = nullptr,
-            unsigned long long* hmask = nullptr) {
+            unsigned long long* hmask = nullptr, int flags = 0) {
     EvalArgs a;
     a.grad = grad;
     a.stress_in = stress_prev;
@@ -422,6 +422,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.rows = rows;
     a.cache3d = nullptr;
     a.hmask = hmask;
+    a.flags = (hmask && tangent) ? flags : 0;
     a.n = n;
     a.counters = m->d_counters;
     {
@@ -757,6 +758,8 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
         return fail(FCAMD_ERR_UNSUPPORTED, "the indexed form exists for StressStrainConstraint.FULL only");
     if (x->history_mask && !has_sparse_history(m->law))
         return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
+    if ((x->flags & FCAMD_EVAL_SPARSE_TANGENT) && (!x->history_mask || !x->tangent))
+        return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_SPARSE_TANGENT needs history_mask and tangent");
     if (!aligned16(x->grad_del_u) || !aligned16(x->stress) || !aligned16(x->stress_prev) || !aligned16(x->tangent))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
     for (int k = 0; k < m->info.n_hist; ++k)
@@ -766,7 +769,7 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     HIP_TRY(hipSetDevice(c->device));
     m->timed = false;
     return enqueue(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history,
-                   c->stream, true, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask));
+                   c->stream, true, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask), x->flags);
 }
 
 int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double t, double del_t, int64_t n,
@@ -805,6 +808,7 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
     a.counters = m->d_counters;
     a.tile_map = 0;
     a.masked_max = 0;  // the wrapped tile bodies have no row-masked path
+    a.flags = 0;
     fill_constants(m, del_t, &a);
     HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->stream));
     if (n == 0) return FCAMD_OK;
@@ -1020,7 +1024,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
 
 int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
                             const double* stress_prev, double* stress, const double* const* hist_prev,
-                            double* const* hist, int n_hist, uint64_t* history_mask,
+                            double* const* hist, int n_hist, uint64_t* history_mask, int flags,
                             double* stress_host, double* tangent_host, fcamd_stats* stats) {
     (void)t;
     int st = validate_call(m, del_t, n, grad, stress_prev, stress,
@@ -1072,7 +1076,8 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
             HIP_TRY(hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
         st = enqueue(m, del_t, np, k_grad, stress_prev + SD * p0, stress + SD * p0, k_tan,
                      hp, hc, s, false, nullptr,
-                     history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr);
+                     history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
+                     z_tan ? flags : 0);  // the staging buffer of a chunk holds no previous tangent: full rows
         if (st != FCAMD_OK) return st;
         if (stress_host)
             HIP_TRY(hipMemcpyAsync(stress_host + SD * p0, stress + SD * p0, (size_t)np * SD * sizeof(double),

@@ -314,16 +314,46 @@ __device__ __forceinline__ void tangent_const(const double* tab, double* tangent
     }
 }
 
+// The same for the points in `tneed` only (elastic tiles of the Drucker-Prager laws under the
+// sparse-tangent protocol: rows of formerly plastic points get the elastic tangent back).
+template <bool IDX, bool FULL, bool NT>
+__device__ __forceinline__ void tangent_const_masked(const double* tab, double* tangent, long long p0,
+                                                     const int* rows_lds, int npts, int lane,
+                                                     unsigned long long tneed) {
+    const int nchunks = npts * 18;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const int q = k * kWave + lane;
+        const int p = q / 18;
+        d2 v = reinterpret_cast<const d2*>(tab)[q - 18 * p];
+        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+    }
+}
+
+// Sparse-tangent protocol (EvalArgs::flags & kFlagSparseTangent, with the sparse trial-history protocol):
+// the caller owns the tangent array across evaluates and it holds the tangent of the PREVIOUS evaluate
+// of this state.  The tangent of an elastic point is one constant for all points and calls, so a row has
+// to be written only if its point is plastic now (new tangent) or was plastic at the previous evaluate
+// (back to the elastic tangent) -- the same `mask | m_old` set as the history rows.  Rows of points that
+// stay elastic, 288 of their 464 bytes, are not touched.  Ragged last tiles are written in full.
+constexpr int kFlagSparseTangent = 1;
+template <bool FULL>
+__device__ __forceinline__ unsigned long long sparse_tangent_need(const EvalArgs& a, unsigned long long need) {
+    return (FULL && (a.flags & kFlagSparseTangent) != 0 && a.hmask != nullptr) ? need : ~0ull;
+}
+
 // Point-dependent tangent of the two Mises laws.  Lane p has published
 //   tp[10p + 0] = B, tp[10p + 1] = C, tp[10p + 2 .. 7] = N   (stride 10: conflict-free b128)
 // and the tile's tangent is   T[p][i][j] = (ta[i][j] + B * tb[i][j]) + third(i, j)  with
 //   VonMises3D:   third = C * (N_i * N_j)      (aah, mises_plasticity_isotropic_hardening.py:170-175)
 //   comfe Mises:  third = (C * N_j) * N_i      (column-major .data.0 of ((2 mu theta_bar) n) n^T,
 //                                               mises_plasticity.rs:118-123)
+// `tneed`: the points of the tile whose tangent rows are written (all ones unless the caller runs the
+// sparse-tangent protocol, see sparse_tangent_need()).
 template <bool COMFE, bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta, const double* tb,
                                               double* tangent, long long p0, const int* rows_lds,
-                                              int npts, int lane) {
+                                              int npts, int lane, unsigned long long tneed) {
     const int nchunks = npts * 18;
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
@@ -346,7 +376,7 @@ __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta
             v.x = (a.x + bc.x * b.x) + bc.y * (ni * nj.x);
             v.y = (a.y + bc.x * b.y) + bc.y * (ni * nj.y);
         }
-        if (FULL || q < nchunks) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         // bound the register pressure: let the scheduler interleave at most 3 chunks
         if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);
     }
@@ -656,12 +686,13 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     }
 
     // tangent: ka xioi + 2 mu (1 - 2 mu xc2) xpp + 4 mu^2 (xc2 - xc1) N (x) N
-    if (sb.tan) {
+    const unsigned long long tneed = sparse_tangent_need<FULL>(a, need_mask);
+    if (sb.tan && tneed != 0ull) {
         const double B = two_mu * (1.0 - two_mu * xc2);
         const double C = four_mu2 * (xc2 - xc1);
         publish_tangent_params(region, lane, B, C, N);
         wave_sync();
-        tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane);
+        tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed);
         wave_sync();
     }
 }
@@ -965,18 +996,21 @@ __device__ __forceinline__ void tile_comfe_mises_wrapped(const EvalArgs& a, cons
 // lane skips the 16-byte chunks that lie entirely in untouched rows (chunk q holds doubles 2q and
 // 2q + 1 of the tile image, i.e. parts of rows 2q / 7 and (2q + 1) / 7; a chunk straddling a touched
 // and an untouched row rewrites 8 bytes of the latter with the value it already has).
+// plastic | formerly plastic points of the tile under the sparse protocol; records the new ballot
+__device__ __forceinline__ unsigned long long sparse_need(const EvalArgs& a, long long p0, unsigned long long mask,
+                                                          int lane) {
+    if (a.hmask == nullptr) return mask;
+    const unsigned long long m_old = a.hmask[p0 >> 6];
+    if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
+    return mask | m_old;
+}
+
+// `touched`: sparse_need() of the tile
 template <bool FULL, bool NT>
 __device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, int npts, int lane,
-                                               unsigned long long mask, bool hist_in_place, double* region,
+                                               unsigned long long touched, bool hist_in_place, double* region,
                                                const double (&h)[7]) {
-    unsigned long long need = ~0ull;
-    if (a.hmask != nullptr) {
-        const unsigned long long m_old = a.hmask[p0 >> 6];
-        if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
-        need = mask | m_old;
-    } else if (hist_in_place) {
-        need = mask;
-    }
+    const unsigned long long need = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
     if (need == 0ull) return;
     if (!FULL || need == ~0ull || __popcll(need) > a.masked_max) {
         transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
@@ -987,8 +1021,8 @@ __device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, 
 #pragma unroll
     for (int k = 0; k < Chunks<7>::K; ++k) {
         const int q = k * kWave + lane;
-        const bool touched = (((need >> ((2 * q) / 7)) | (need >> ((2 * q + 1) / 7))) & 1ull) != 0ull;
-        if (chunk_live<7>(k, lane) && touched)
+        const bool hit = (((need >> ((2 * q) / 7)) | (need >> ((2 * q + 1) / 7))) & 1ull) != 0ull;
+        if (chunk_live<7>(k, lane) && hit)
             store16<NT>(a.h0_out + p0 * 7 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
     }
     wave_sync();
@@ -1070,13 +1104,15 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
         s[i] = i < 3 ? p_1 + ts : ts;
     }
     sr.put(sb, region, lane, s, p0, npts);
-    history7_store<FULL, NT>(a, p0, npts, lane, mask, hist_in_place, region, h);
+    const unsigned long long touched = sparse_need(a, p0, mask, lane);
+    history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
 
-    if (sb.tan) {
+    const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
+    if (sb.tan && tneed != 0ull) {
         const double B = plastic ? two_mu * theta : two_mu;
         publish_tangent_params(region, lane, B, sc, nv);
         wave_sync();
-        tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane);
+        tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed);
         wave_sync();
     }
 }
@@ -1135,7 +1171,7 @@ __device__ __forceinline__ DPInv dp_state(double I1, double rho, double n2, doub
 template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11tab, const double* pdtab,
                                            const double* etab, double* tangent, long long p0,
-                                           const int* rows_lds, int npts, int lane) {
+                                           const int* rows_lds, int npts, int lane, unsigned long long tneed) {
     const int nchunks = npts * 18;
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
@@ -1161,7 +1197,7 @@ __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11ta
         // i.e. the host-computed 2 mu P_dev + 3 kappa P_vol bit for bit, not kappa 1x1 + 2 mu P_dev
         const d2 el = *reinterpret_cast<const d2*>(etab + 6 * i + j);
         if (c2.y == 0.0) v = el;
-        if (FULL || q < nchunks) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -1334,10 +1370,15 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     if (mask == 0ull) {
         // fully elastic tile: stress = sigma_tr, tangent = E, history untouched
         sr.put(sb, region, lane, t.sig1, p0, npts);
-        history7_store<FULL, NT>(a, p0, npts, lane, 0ull, hist_in_place, region, h);
-        if (sb.tan) {
+        const unsigned long long touched = sparse_need(a, p0, 0ull, lane);
+        history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
+        const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
+        if (sb.tan && tneed != 0ull) {
             if constexpr (IDX) wave_sync();
-            tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
+            if (tneed == ~0ull)
+                tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
+            else
+                tangent_const_masked<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, tneed);
         }
         st.domain += (live && t.tip) ? 1ull : 0ull;
         return;
@@ -1350,12 +1391,14 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     st.domain += (live && t.tip) ? 1ull : 0ull;  // tip of the classic surface reached (reference: assert!)
 
     sr.put(sb, region, lane, t.sig1, p0, npts);
-    history7_store<FULL, NT>(a, p0, npts, lane, mask, hist_in_place, region, h);
+    const unsigned long long touched = sparse_need(a, p0, mask, lane);
+    history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
 
-    if (sb.tan) {
+    const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
+    if (sb.tan && tneed != 0ull) {
         dp_publish(region, lane, tg, t.s_tr, plastic);
         wave_sync();
-        tangent_dp<IDX, FULL, NT>(region, T->a, T->b, T->c, sb.tan, p0, rows_lds, npts, lane);
+        tangent_dp<IDX, FULL, NT>(region, T->a, T->b, T->c, sb.tan, p0, rows_lds, npts, lane, tneed);
         wave_sync();
     }
 }

@@ -190,11 +190,13 @@ class DeviceLaw(IncrSmallStrainModel):
         )
 
     def evaluate_from(self, t, del_t, grad_del_u, stress_prev, stress, tangent, history_prev, history,
-                      history_mask=None) -> None:
+                      history_mask=None, sparse_tangent: bool = False) -> None:
         """Out-of-place device evaluate: read the committed state (``stress_prev``,
         ``history_prev``), write the trial state (``stress``, ``history``).  Fuses the two
         copies the reference makes before every call (solver/_lawonsubmesh.py:58-61,
-        solver/_history.py:64-79).  Device tensors only."""
+        solver/_history.py:64-79).  Device tensors only.  ``sparse_tangent`` (with ``history_mask``):
+        ``tangent`` holds the tangent of the previous evaluate with this mask; only the rows of plastic /
+        formerly plastic points are rewritten (FCAMD_EVAL_SPARSE_TANGENT, include/fcamd.h)."""
         hist = self._history_arrays(history)
         hprev = self._history_arrays(history_prev)
         gd2, sd = self.geometric_dim**2, self.stress_strain_dim
@@ -212,13 +214,19 @@ class DeviceLaw(IncrSmallStrainModel):
         dev = grad_del_u.device.index or 0
         m = self._handle(dev)
         m.ctx.set_stream(_current_stream_ptr(dev))
+        if sparse_tangent and tangent is not None:
+            m.evaluate_device_ex(
+                t, del_t, n, grad_del_u.data_ptr(), stress_prev.data_ptr(), stress.data_ptr(),
+                _check_torch("tangent", tangent).data_ptr(), [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist],
+                None, history_mask.data_ptr(), _capi.EVAL_SPARSE_TANGENT)
+            return
         m.evaluate_device_from_sparse(
             t, del_t, n, grad_del_u.data_ptr(), stress_prev.data_ptr(), stress.data_ptr(),
             None if tangent is None else tangent.data_ptr(), [h.data_ptr() for h in hprev],
             [h.data_ptr() for h in hist], history_mask.data_ptr())
 
     def evaluate_indexed(self, t, del_t, grad_del_u, stress_prev_parent, stress_parent, tangent_parent,
-                         parent_rows, history_prev, history, history_mask=None) -> None:
+                         parent_rows, history_prev, history, history_mask=None, sparse_tangent: bool = False) -> None:
         """Multi-material form: this law owns ``n = len(parent_rows)`` points whose stress/tangent
         rows live in PARENT arrays at ``parent_rows`` (int32 device tensor).  Reads the committed
         stress from ``stress_prev_parent`` rows, writes stress and tangent into the parent rows;
@@ -250,7 +258,8 @@ class DeviceLaw(IncrSmallStrainModel):
         assert history_mask.dtype == torch.int64 and history_mask.is_cuda and history_mask.numel() >= (n + 63) // 64
         m.evaluate_device_ex(
             t, del_t, n, grad_del_u.data_ptr(), stress_prev_parent.data_ptr(), stress_parent.data_ptr(), tan_ptr,
-            [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist], parent_rows.data_ptr(), history_mask.data_ptr())
+            [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist], parent_rows.data_ptr(), history_mask.data_ptr(),
+            _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tan_ptr is not None) else 0)
 
     def device_stats(self, device: int = 0):
         """Synchronise and return the counters of the last device-path launch; raises

@@ -50,6 +50,8 @@ class _LawState:
         if sparse_history and type(law).__name__ in ("VonMises3D", "MisesPlasticityLinearHardening3D",
                                                      "DruckerPrager3D", "DruckerPragerHyperbolic3D"):
             self.mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
+        # sparse tangent (see ResidentState): true once the parent array holds this law's previous tangent
+        self.tangent_current = False
 
 
 class ResidentProblemState:
@@ -58,7 +60,7 @@ class ResidentProblemState:
     ``rows_of_cells``).  All laws are FULL 3-D, as the fused indexed kernel requires."""
 
     def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None, reuse_constant_tangent: bool = True,
-                 sparse_history: bool = True):
+                 sparse_history: bool = True, sparse_tangent: bool = True):
         import torch
 
         from . import _capi
@@ -90,6 +92,7 @@ class ResidentProblemState:
         self._time, self._del_t = 0.0, float(del_t)
         self._evaluated = False
         self.reuse_constant_tangent = reuse_constant_tangent
+        self.sparse_tangent = sparse_tangent
 
     # reference-compatible views ----------------------------------------------------------------------
     @property
@@ -126,6 +129,7 @@ class ResidentProblemState:
                     ls.hist[1 - self._c][k].copy_(ls.hist[self._c][k])  # trial == committed (sparse-history contract)
                 if ls.mask is not None:
                     ls.mask.zero_()
+                ls.tangent_current = False  # the mask no longer remembers which rows hold plastic tangents
 
     # the Newton-iteration call (IncrSmallStrainProblem.form, solver/_solver.py:130-147) ------------------
     def evaluate(self, grads) -> None:
@@ -150,12 +154,14 @@ class ResidentProblemState:
                 if ls.tangent_key == key:
                     tangent = None
                 ls.tangent_key = key
+            st = self.sparse_tangent and ls.mask is not None and ls.tangent_current
             if ls.rows is None:
                 ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent, hp, hc,
-                                     history_mask=ls.mask)
+                                     history_mask=ls.mask, sparse_tangent=st)
             else:
                 ls.law.evaluate_indexed(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent,
-                                        ls.rows, hp, hc, history_mask=ls.mask)
+                                        ls.rows, hp, hc, history_mask=ls.mask, sparse_tangent=st)
+            ls.tangent_current = True
         self._evaluated = True
 
     def tune_placement(self, grads, tries: int = 4) -> dict:
@@ -169,6 +175,7 @@ class ResidentProblemState:
             self.tangent = tan
             for ls in self._laws:
                 ls.tangent_key = None  # constant tangents have to be written into the candidate
+                ls.tangent_current = False  # ... and every row of the point-dependent ones
             self.evaluate(grads)
 
         first, self.tangent = self.tangent, None

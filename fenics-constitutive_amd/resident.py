@@ -33,7 +33,7 @@ __all__ = ["ResidentState"]
 
 class ResidentState:
     def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
-                 reuse_constant_tangent: bool = True):
+                 reuse_constant_tangent: bool = True, sparse_tangent: bool = True):
         import torch
 
         self.law, self.n = law, int(n)
@@ -73,6 +73,13 @@ class ResidentState:
         self._const_tangent = reuse_constant_tangent and type(law).__name__ in (
             "LinearElasticityModel", "LinearElasticity3D", "SpringMaxwellModel", "SpringKelvinModel")
         self._tangent_key = None  # del_t for which the tangent array is valid
+        # Plasticity laws, the same idea per point: the tangent of an elastic point is one constant, so once
+        # an array holds the tangent of the previous evaluate only the rows of plastic / formerly plastic
+        # points are rewritten (FCAMD_EVAL_SPARSE_TANGENT; rows of points that stay elastic keep 288 of
+        # their 464 bytes off the bus).  ``_tangent_target`` names the array that received the previous
+        # evaluate's tangent ("dev" or the address of the host assembler's array): only that one is current.
+        self._sparse_tangent = bool(sparse_tangent) and self._mask is not None
+        self._tangent_target = None
 
     def _as_dev(self, a):
         import torch
@@ -128,7 +135,9 @@ class ResidentState:
                 tangent = None  # already holds exactly what this launch would write
             self._tangent_key = key
         self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, tangent,
-                               self.history_committed, self.history, history_mask=self._mask)
+                               self.history_committed, self.history, history_mask=self._mask,
+                               sparse_tangent=self._sparse_tangent and self._tangent_target == "dev")
+        self._tangent_target = "dev"
         self._evaluated = True
 
     def tune_placement(self, t: float, del_t: float, grad_del_u, tries: int = 4) -> dict:
@@ -152,6 +161,7 @@ class ResidentState:
             tries=tries, device=self.device, first=first)
         del first
         self._tangent_key = None  # a constant tangent has to be written into the chosen array
+        self._tangent_target = None  # ... and every row of a point-dependent one
         self.evaluate(t, del_t, g)
         return info
 
@@ -183,10 +193,18 @@ class ResidentState:
         hp = [] if self._hist is None else [self.history_committed[k].data_ptr() for k, _ in m.history_fields]
         hc = [] if self._hist is None else [self.history[k].data_ptr() for k, _ in m.history_fields]
         self._evaluated = True  # the trial state is touched even if the call raises
+        # sparse tangent: only into the very array that received the previous evaluate's tangent, and only
+        # when the kernel writes it directly (page-locked array; the C side ignores the flag otherwise --
+        # then every row is downloaded and the array is current as well)
+        target = None if tangent is None else ("host", tangent.ctypes.data, tangent.nbytes)
+        flags = _capi.EVAL_SPARSE_TANGENT if (self._sparse_tangent and target is not None
+                                              and self._tangent_target == target) else 0
+        self._tangent_target = None
         self.law.last_stats = m.evaluate_resident(
             t, del_t, self.n, grad_del_u.ctypes.data, self.stress_committed.data_ptr(), self.stress.data_ptr(),
             hp, hc, None if self._mask is None else self._mask.data_ptr(),
-            None if stress is None else stress.ctypes.data, None if tangent is None else tangent.ctypes.data)
+            None if stress is None else stress.ctypes.data, None if tangent is None else tangent.ctypes.data, flags)
+        self._tangent_target = target
         return self.law.last_stats
 
     def update(self) -> None:

@@ -206,7 +206,15 @@ typedef struct fcamd_eval_args {
     int n_hist;
     const int32_t* parent_rows;         /* nullable */
     uint64_t* history_mask;             /* nullable */
+    int flags;                          /* FCAMD_EVAL_* */
 } fcamd_eval_args;
+/* Sparse-tangent protocol (plasticity laws, needs history_mask and a tangent array): the caller owns
+   `tangent` across evaluates and it holds the tangent written by the PREVIOUS evaluate with the same
+   history_mask (the first one without this flag).  The tangent of an elastic point is one constant for
+   all points and calls, so only the rows of points that are plastic now or were plastic at the previous
+   evaluate are written; rows of points that stay elastic -- 288 of their 464 bytes -- are not touched.
+   Same array contents as without the flag (tests/test_gpu_resident.py). */
+#define FCAMD_EVAL_SPARSE_TANGENT 1
 int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_t, int64_t n,
                              const fcamd_eval_args* args);
 
@@ -238,12 +246,15 @@ int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
    fcamd_register_host_buffer is read / written by the kernel itself (zero copy, as in
    fcamd_evaluate_host) instead of passing through the chunk buffers.
    `history_mask` (nullable) selects the sparse trial-history protocol of
-   fcamd_evaluate_device_from_sparse (plasticity laws).  Synchronous; waits for work queued on the
+   fcamd_evaluate_device_from_sparse (plasticity laws).  `flags`: FCAMD_EVAL_SPARSE_TANGENT applies the
+   sparse-tangent protocol to `tangent_host` when the kernel writes it directly (page-locked array):
+   only the rows of plastic / formerly plastic points cross PCIe; ignored on the staged path, which
+   downloads every row.  Synchronous; waits for work queued on the
    context stream before touching the state arrays.  Status and `stats` as fcamd_evaluate_host. */
 int fcamd_evaluate_resident(fcamd_model* model, double t, double del_t, int64_t n,
                             const double* grad_del_u_host, const double* stress_prev,
                             double* stress, const double* const* history_prev,
-                            double* const* history, int n_hist, uint64_t* history_mask,
+                            double* const* history, int n_hist, uint64_t* history_mask, int flags,
                             double* stress_host, double* tangent_host, fcamd_stats* stats);
 
 /* Mandel strain from displacement gradient, FULL (utils.py:132-151,187-208).

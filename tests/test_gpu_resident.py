@@ -114,6 +114,7 @@ def test_sparse_history_equals_full_history(n, law_name):
     sp = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=True)
     fu = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False)
     assert sp._mask is not None and fu._mask is None
+    assert sp._sparse_tangent and not fu._sparse_tangent  # sp also runs the sparse-tangent protocol
     n_plastic = []
     for inc in range(5):
         for it in range(3):

@@ -222,3 +222,38 @@ def test_resident_evaluate_into_zero_copy(kind):
             assert np.array_equal(a[2][k], b[2][k])
     ref = oracle_run(kind, p, 1.0, g, s, h, mod=CO)
     compare((b[0], b[1], b[2]), ref, TOL[CLASS[kind]], f"resident zero copy {kind}")
+
+
+@pytest.mark.parametrize("law_name", ["von_mises_3d", "comfe_mises_plasticity"])
+def test_sparse_tangent_into_page_locked_host_array(law_name):
+    """evaluate_into with a page-locked tangent array: from the second call on only the rows of plastic /
+    formerly plastic points cross PCIe (FCAMD_EVAL_SPARSE_TANGENT).  The array must equal, at every
+    Newton iteration, what a state that downloads every row produces -- with plastic sets that grow,
+    shrink and vanish, across commits, and when device-side evaluates come in between."""
+    n = 50_000 + 37
+    p, g0, s, h = random_case(law_name, n, seed=5)
+    law = make_law(law_name, p)
+    rng = np.random.default_rng(9)
+    sp = ResidentState(law, n, stress0=s, history0=h)                          # sparse tangent (default)
+    fu = ResidentState(law, n, stress0=s, history0=h, sparse_tangent=False)    # every row, every call
+    assert sp._sparse_tangent and not fu._sparse_tangent
+    gg, s_sp, t_sp = own(g0), own(np.zeros(6 * n)), own(np.full(36 * n, np.nan))
+    s_fu, t_fu = np.zeros(6 * n), np.full(36 * n, np.nan)
+    ctx = law._handle(_capi.default_device()).ctx
+    scales = [1.0, 1.4, 0.02, 0.7, 0.0, 1.2, 1.2, 0.3]   # 0.02 / 0.0: (nearly) everything elastic again
+    with Pinned(law, [gg, s_sp, t_sp]):
+        for k, sc in enumerate(scales):
+            gg[:] = g0 * sc * (1.0 + 0.2 * rng.standard_normal(1)[0])
+            if k == 5:  # a device-side evaluate in between: the host array misses one update ...
+                sp.evaluate(0.0, 1.0, gg)
+                fu.evaluate(0.0, 1.0, gg)
+                assert torch.equal(sp.tangent, fu.tangent)
+            sp.evaluate_into(0.0, 1.0, gg, s_sp, t_sp)   # ... so this call has to write every row again
+            assert ctx.last_host_mode() == ZC
+            fu.evaluate_into(0.0, 1.0, gg, s_fu, t_fu)
+            assert np.array_equal(t_sp, t_fu), f"call {k}: sparse tangent differs"
+            assert np.array_equal(s_sp, s_fu)
+            if k in (2, 6):
+                sp.update()
+                fu.update()
+    assert 0 < law.last_stats.n_plastic < n
