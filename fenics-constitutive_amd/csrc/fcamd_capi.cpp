@@ -466,18 +466,22 @@ int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
 // gen5 (tools/host_path_bench.py): page-locked caller arrays like many small chunks in flight
 // (4 x 128 Ki points: 116 Mpts/s); pageable arrays are staged by the runtime and prefer large
 // chunks (512 Ki points: 93 Mpts/s).  FCAMD_HOST_CHUNK / FCAMD_HOST_SLOTS override (experiments).
-int prepare_chunks(fcamd_context* c, const void* probe_host_ptr, int64_t n, int64_t* chunk_out) {
+// `staging` = false: every per-chunk array is read / written by the kernel in the caller's page-locked
+// memory (zero copy), the chunks only pipeline the small stress download behind the next launch: no
+// device buffers, and large chunks (2 Mi points: 472 instead of 404 Mpts/s for the resident pass).
+int prepare_chunks(fcamd_context* c, const void* probe_host_ptr, int64_t n, int64_t* chunk_out, bool staging = true) {
     {
         const char* e = getenv("FCAMD_HOST_CHUNK");
         const bool pinned = mapped(c, probe_host_ptr, 8) != nullptr ||
                             c->registered.count(static_cast<char*>(const_cast<void*>(probe_host_ptr))) != 0;
-        c->chunk_points = e ? std::max<int64_t>(64, (atoll(e) / 64) * 64) : (pinned ? (1 << 17) : (1 << 19));
+        c->chunk_points = e ? std::max<int64_t>(64, (atoll(e) / 64) * 64)
+                            : (!staging ? (1 << 21) : (pinned ? (1 << 17) : (1 << 19)));
         const char* sl = getenv("FCAMD_HOST_SLOTS");
         if (sl) c->slots = std::min(fcamd_context::kSlots, std::max(1, atoi(sl)));
     }
     const int nslots = c->slots;
     const int64_t chunk = std::min<int64_t>(c->chunk_points, ((n + 63) / 64) * 64);
-    if (chunk > 0 && ((size_t)chunk > c->dchunk_points || !c->dchunk[nslots - 1])) {
+    if (staging && chunk > 0 && ((size_t)chunk > c->dchunk_points || !c->dchunk[nslots - 1])) {
         for (int i = 0; i < fcamd_context::kSlots; ++i) {
             if (c->dchunk[i]) HIP_TRY(hipFree(c->dchunk[i]));
             c->dchunk[i] = nullptr;
@@ -1042,24 +1046,24 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     HIP_TRY(hipSetDevice(c->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
     HIP_TRY(hipStreamSynchronize(c->stream));  // the state arrays may have work queued on the caller's stream
+    const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
+    const bool zc = n > 0 && zero_copy_enabled(c);
+    const char* zg = getenv("FCAMD_ZERO_COPY_GRAD");  // experiments: 0 = upload the gradient by DMA even if page-locked
+    const double* z_grad = (zc && !(zg && atoi(zg) == 0)) ? mapped(c, grad, (size_t)n * GD2 * sizeof(double)) : nullptr;
+    double* z_tan = (zc && tangent_host) ? mapped(c, tangent_host, (size_t)n * TD * sizeof(double)) : nullptr;
+    c->last_host_mode = (z_grad ? FCAMD_HOST_ZERO_COPY_IN : 0) | (z_tan ? FCAMD_HOST_ZERO_COPY_OUT : 0);
     int64_t chunk = 0;
-    st = prepare_chunks(c, grad, n, &chunk);
+    st = prepare_chunks(c, grad, n, &chunk, /*staging=*/!(z_grad && (z_tan || !tangent_host)));
     if (st != FCAMD_OK) return st;
     const int nslots = c->slots;
     HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
     HIP_TRY(hipStreamSynchronize(c->hstream[0]));
-
-    const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
-    const bool zc = n > 0 && zero_copy_enabled(c);
-    const double* z_grad = zc ? mapped(c, grad, (size_t)n * GD2 * sizeof(double)) : nullptr;
-    double* z_tan = (zc && tangent_host) ? mapped(c, tangent_host, (size_t)n * TD * sizeof(double)) : nullptr;
-    c->last_host_mode = (z_grad ? FCAMD_HOST_ZERO_COPY_IN : 0) | (z_tan ? FCAMD_HOST_ZERO_COPY_OUT : 0);
     int slot = 0;
     for (int64_t p0 = 0; p0 < n; p0 += chunk, slot = (slot + 1) % nslots) {
         const int64_t np = std::min<int64_t>(chunk, n - p0);
         hipStream_t s = c->hstream[slot];
-        double* d_grad = c->dchunk[slot];
-        double* d_tan = d_grad + 10 * c->dchunk_points;
+        double* d_grad = c->dchunk[slot];  // unused (possibly null) when gradient and tangent are zero copy
+        double* d_tan = d_grad ? d_grad + 10 * c->dchunk_points : nullptr;
         // chunk offsets are multiples of 64 points: every sub-array stays 16-byte aligned and the
         // per-tile mask words line up
         const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
