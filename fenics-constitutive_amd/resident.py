@@ -80,6 +80,7 @@ class ResidentState:
         # evaluate's tangent ("dev" or the address of the host assembler's array): only that one is current.
         self._sparse_tangent = bool(sparse_tangent) and self._mask is not None
         self._tangent_target = None
+        self._host_tangent_key = None  # (address, bytes, del_t) of the host array that holds the constant tangent
 
     def _as_dev(self, a):
         import torch
@@ -170,10 +171,15 @@ class ResidentState:
         """The host assembler's Newton-iteration call: trial state <- law(committed state,
         grad_del_u) with ``grad_del_u`` a NumPy array, and the trial stress / tangent written into
         the caller's NumPy arrays, all in one chunk-pipelined pass.  Synchronous; raises the
-        reference's exceptions (non-convergence) like the ndarray ``evaluate``.  For the laws
-        with a point-independent tangent (linear elasticity, SLS at a fixed ``del_t``) the caller may
-        pass ``tangent`` once and ``None`` afterwards: 288 of the 336 downloaded bytes per point.  Page-lock the
-        three arrays once (``Context.register_host_buffer``) for full PCIe rate."""
+        reference's exceptions (non-convergence) like the ndarray ``evaluate``.  The caller's tangent
+        array is taken to be left alone between calls (the assembler only reads it): for the laws with a
+        point-independent tangent (linear elasticity, SLS at a fixed ``del_t``) it is downloaded once and
+        not again while ``del_t`` and the array stay the same (288 of the 336 bytes per point); for the
+        plasticity laws with a page-locked array only the rows of plastic / formerly plastic points are
+        written from the second call on (``sparse_tangent``).  Construct the state with
+        ``reuse_constant_tangent=False`` / ``sparse_tangent=False`` if the array is modified in between.
+        Page-lock the three arrays once (``law.pin_host_arrays`` / ``Context.register_host_buffer``): the
+        kernel then reads the gradient from and writes the tangent to them directly."""
         from . import _capi
         from .device import _check_numpy
 
@@ -196,6 +202,16 @@ class ResidentState:
         # sparse tangent: only into the very array that received the previous evaluate's tangent, and only
         # when the kernel writes it directly (page-locked array; the C side ignores the flag otherwise --
         # then every row is downloaded and the array is current as well)
+        if tangent is not None and self._const_tangent:
+            # LE / SLS: the caller's array already holds the tangent of this del_t (written by an earlier call
+            # into the very same array): nothing to download, 288 of the 336 bytes per point stay off PCIe
+            key = (tangent.ctypes.data, tangent.nbytes, float(del_t) if type(self.law).__name__.startswith("Spring") else 0.0)
+            if self._host_tangent_key == key:
+                tangent = None
+            else:
+                self._host_tangent_key = None  # set below, once the call has succeeded
+        else:
+            key = None
         target = None if tangent is None else ("host", tangent.ctypes.data, tangent.nbytes)
         flags = _capi.EVAL_SPARSE_TANGENT if (self._sparse_tangent and target is not None
                                               and self._tangent_target == target) else 0
@@ -205,6 +221,8 @@ class ResidentState:
             hp, hc, None if self._mask is None else self._mask.data_ptr(),
             None if stress is None else stress.ctypes.data, None if tangent is None else tangent.ctypes.data, flags)
         self._tangent_target = target
+        if key is not None and tangent is not None:
+            self._host_tangent_key = key
         return self.law.last_stats
 
     def update(self) -> None:

@@ -251,3 +251,36 @@ def test_tune_placement_keeps_results():
     # the helper alone
     t, info = fastest_allocation(1 << 20, lambda x: x.fill_(1.0), tries=2)
     assert t.numel() == 1 << 20 and t.dtype == torch.float64 and len(info["candidate_ms"]) == 2
+
+
+def test_evaluate_into_downloads_a_constant_tangent_once():
+    """LE / SLS host assembler: the caller's tangent array is written when it is first seen and again only
+    when del_t (SLS) or the array changes; reuse_constant_tangent=False rewrites it on every call."""
+    from test_gpu_parity import LE_P, SLS_P, make_law, random_case
+
+    n = 3000
+    _, g, s, _ = random_case("linear_elasticity", n, seed=2)
+    for kind, p in (("linear_elasticity", LE_P), ("spring_maxwell", SLS_P)):
+        law = make_law(kind, p)
+        h = None if kind == "linear_elasticity" else {"strain_visco": np.zeros(6 * n), "strain": np.zeros(6 * n)}
+        st = ResidentState(law, n, stress0=s, history0=h)
+        so, t = np.empty(6 * n), np.full(36 * n, np.nan)
+        st.evaluate_into(0.0, 1.0, g, so, t)
+        ref = t.copy()
+        assert not np.isnan(ref).any()
+        t[:] = -7.0                                   # sentinel: a second call must not touch the array
+        st.evaluate_into(0.0, 1.0, g, so, t)
+        assert np.all(t == -7.0)
+        st.evaluate_into(0.0, 0.5, g, so, t)          # new del_t: SLS tangent changes, LE's does not
+        if kind == "linear_elasticity":
+            assert np.all(t == -7.0)
+        else:
+            assert not np.any(t == -7.0) and not np.array_equal(t, ref)
+        t2 = np.full(36 * n, np.nan)                  # another array: written
+        st.evaluate_into(0.0, 1.0, g, so, t2)
+        assert np.array_equal(t2, ref)
+        st2 = ResidentState(law, n, stress0=s, history0=h, reuse_constant_tangent=False)
+        st2.evaluate_into(0.0, 1.0, g, so, t)
+        t[:] = -7.0
+        st2.evaluate_into(0.0, 1.0, g, so, t)
+        assert np.array_equal(t, ref)
