@@ -81,6 +81,7 @@ class ResidentState:
         self._sparse_tangent = bool(sparse_tangent) and self._mask is not None
         self._tangent_target = None
         self._host_tangent_key = None  # (address, bytes, del_t) of the host array that holds the constant tangent
+        self._host_tangent_ref = None  # the last host tangent array (kept alive, see evaluate_into)
 
     def _as_dev(self, a):
         import torch
@@ -223,6 +224,10 @@ class ResidentState:
         self._tangent_target = target
         if key is not None and tangent is not None:
             self._host_tangent_key = key
+        if tangent is not None:
+            # The two shortcuts above identify the caller's array by address.  Holding a reference keeps its
+            # memory from being freed and handed out again for a different array at the same address.
+            self._host_tangent_ref = tangent
         return self.law.last_stats
 
     def update(self) -> None:
