@@ -161,3 +161,36 @@ def test_cfg1_linear_elasticity_1e5_ndarray_path():
     s_ref, t_ref = np.zeros(6 * n), np.zeros(36 * n)
     O.linear_elasticity({"E": 42.0, "nu": 0.3}, 0.0, 1.0, g, s_ref, t_ref, None)
     assert np.array_equal(s, s_ref) and np.array_equal(t, t_ref)
+
+
+def test_resident_protocols_1e8():
+    """bench.py's default step at full size: the sparse trial-history and sparse-tangent protocols of
+    ResidentState over three Newton iterates with moving plastic sets must leave exactly the arrays that
+    rewriting everything leaves (size-independent property: equality of the two states)."""
+    from fenics_constitutive_amd.resident import ResidentState
+
+    need_memory(120)
+    gen = torch.Generator(device="cuda").manual_seed(19)
+    g = torch.randn(9 * N, dtype=torch.float64, device="cuda", generator=gen)
+    g.view(N, 9).mul_(torch.pow(10.0, torch.rand(N, dtype=torch.float64, device="cuda", generator=gen) * 2 - 4)[:, None])
+    a0 = torch.rand(N, dtype=torch.float64, device="cuda", generator=gen) * 0.02
+    h0 = {"eps_n": torch.zeros(6 * N, dtype=torch.float64, device="cuda"), "alpha": a0}
+    law = fc.VonMises3D(VM_P)
+    sp = ResidentState(law, N, history0=h0)
+    fu = ResidentState(law, N, history0=h0, sparse_history=False, sparse_tangent=False)
+    assert sp._sparse_tangent and sp._mask is not None and fu._mask is None
+    fractions = []
+    for k, scale in enumerate((1.0, 0.5, 1.6)):   # plastic set shrinks, then grows beyond the first one
+        gk = g if scale == 1.0 else g * scale
+        sp.evaluate(0.0, 1.0, gk)
+        fu.evaluate(0.0, 1.0, gk)
+        fractions.append(law.device_stats().n_plastic / N)
+        assert torch.equal(sp.stress, fu.stress), k
+        assert torch.equal(sp.tangent, fu.tangent), k
+        for key in h0:
+            assert torch.equal(sp.history[key], fu.history[key]), (k, key)
+        del gk
+        if k == 1:
+            sp.update()
+            fu.update()
+    assert fractions[1] < fractions[0] < fractions[2] and fractions[0] > 0.1
