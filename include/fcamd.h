@@ -148,9 +148,9 @@ int fcamd_evaluate_device_from(fcamd_model* model, double t, double del_t, int64
                                int n_hist);
 
 /* Sparse-trial-history form of fcamd_evaluate_device_from for device-resident Newton loops
-   (the plasticity laws: VonMises3D per point; the comfe-rs Mises and Drucker-Prager laws, whose
-   history is one 7-double row per point, per 64-point tile: a tile is written when it has or had
-   a plastic point).  Contract: on entry the trial history arrays equal the committed ones except at
+   (the plasticity laws; history rows are touched per point -- tiles in which more than 20 (VonMises3D)
+   / 16 (comfe-rs laws) rows are touched are written as a whole, which restores stale rows as well).
+   Contract: on entry the trial history arrays equal the committed ones except at
    the points whose bit is set in `history_mask` (one uint64 per 64-point tile, bit l = point
    64*tile + l; all zero initially).  On return the trial history is exactly what
    fcamd_evaluate_device_from would have written -- but only plastic points (new value) and
