@@ -409,11 +409,12 @@ int grid_for(fcamd_model* m, int64_t n) {
 int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
             double* stress, double* tangent, const double* const* hprev, double* const* hcur,
             hipStream_t stream, bool reset_counters, const int* rows = nullptr,
-            unsigned long long* hmask = nullptr, int flags = 0) {
+            unsigned long long* hmask = nullptr, int flags = 0, double* stress2 = nullptr) {
     EvalArgs a;
     a.grad = grad;
     a.stress_in = stress_prev;
     a.stress_out = stress;
+    a.stress_out2 = stress2;
     a.tangent = tangent;
     a.h0_in = m->info.n_hist > 0 ? hprev[0] : nullptr;
     a.h0_out = m->info.n_hist > 0 ? hcur[0] : nullptr;
@@ -802,6 +803,7 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
     a.grad = grad_lo;
     a.stress_in = stress_lo;
     a.stress_out = stress_lo;
+    a.stress_out2 = nullptr;
     a.tangent = tangent_lo;
     a.h0_in = a.h0_out = m->info.n_hist > 0 ? hist[0] : nullptr;
     a.h1_in = a.h1_out = m->info.n_hist > 1 ? hist[1] : nullptr;
@@ -1052,6 +1054,19 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     const double* z_grad = (zc && !(zg && atoi(zg) == 0)) ? mapped(c, grad, (size_t)n * GD2 * sizeof(double)) : nullptr;
     double* z_tan = (zc && tangent_host) ? mapped(c, tangent_host, (size_t)n * TD * sizeof(double)) : nullptr;
     c->last_host_mode = (z_grad ? FCAMD_HOST_ZERO_COPY_IN : 0) | (z_tan ? FCAMD_HOST_ZERO_COPY_OUT : 0);
+    // Everything the pass moves lies in page-locked caller memory and the law is a 3-D one (whose stress
+    // store can feed two destinations): ONE launch reads the gradient from and writes stress and tangent
+    // to the host arrays while it updates the device-resident state -- no chunks, no copies.
+    double* z_stress = (zc && stress_host && m->dims.gdim == 3) ? mapped(c, stress_host, (size_t)n * SD * sizeof(double)) : nullptr;
+    if (z_grad && (z_tan || !tangent_host) && (z_stress || !stress_host) && m->dims.gdim == 3) {
+        if (!c->hstream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
+        hipStream_t s = c->hstream[0];
+        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
+        st = enqueue(m, del_t, n, z_grad, stress_prev, stress, z_tan, hist_prev, hist, s, false, nullptr,
+                     reinterpret_cast<unsigned long long*>(history_mask), flags, z_stress);
+        if (st != FCAMD_OK) return st;
+        return finish_chunks(m, stats);
+    }
     int64_t chunk = 0;
     st = prepare_chunks(c, grad, n, &chunk, /*staging=*/!(z_grad && (z_tan || !tangent_host)));
     if (st != FCAMD_OK) return st;

@@ -39,6 +39,7 @@ struct EvalArgs {
     const double* grad;        // [9n]
     const double* stress_in;   // [6n] committed stress (may alias stress_out)
     double* stress_out;        // [6n]
+    double* stress_out2;       // nullptr, or a second destination of the stress (the host assembler's page-locked array)
     double* tangent;           // [36n] or nullptr
     const double* h0_in;       // first history field (may alias h0_out) or nullptr
     double* h0_out;

@@ -206,6 +206,7 @@ struct StressBases {
     const double* sin;
     double* sout;
     double* tan;
+    double* sout2 = nullptr;  // second copy of the stress rows (EvalArgs::stress_out2; contiguous tiles only)
 };
 
 template <bool IDX, bool FULL, bool NT>
@@ -253,8 +254,14 @@ struct StressRows {
                     store16<NT>(sb.sout + row * 6 + 2 * k, v);
                 }
             }
-        } else {
+        } else if (sb.sout2 == nullptr) {
             transpose_out<6, FULL, NT>(s, region, lane, sb.sout + p0 * 6, npts * 6);
+        } else {  // resident state on the device + the host assembler's array: one LDS image, two streams
+            lds_put_point<6>(region, lane, s);
+            wave_sync();
+            lds_to_global<6, FULL, NT>(region, sb.sout + p0 * 6, npts * 6, lane);
+            lds_to_global<6, FULL, NT>(region, sb.sout2 + p0 * 6, npts * 6, lane);
+            wave_sync();
         }
     }
 };
@@ -1630,7 +1637,7 @@ __device__ __forceinline__ void run_tile(const EvalArgs& a, const StressBases& s
 template <int LAW, bool IDX, bool NT, bool SPARSE>
 __device__ __forceinline__ void run_full_tile(const EvalArgs& a, const Tables* T, double* region,
                                               int* rows_lds, long long p0, int lane, int r0, WaveStats& st) {
-    const StressBases sb{a.stress_in, a.stress_out, a.tangent};
+    const StressBases sb{a.stress_in, a.stress_out, a.tangent, a.stress_out2};
     if constexpr (IDX) {
         const int row = a.rows[p0 + lane];
         const int row0 = __builtin_amdgcn_readfirstlane(row);
@@ -1790,7 +1797,7 @@ __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) 
     const int lane = threadIdx.x;
     const long long p0 = (a.n / kWave) * kWave;
     WaveStats st;
-    const StressBases sb{a.stress_in, a.stress_out, a.tangent};
+    const StressBases sb{a.stress_in, a.stress_out, a.tangent, a.stress_out2};
     run_tile<LAW, IDX, false, false, SPARSE>(a, sb, &T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
     flush_stats<LAW>(a, st, lane);
 }

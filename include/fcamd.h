@@ -244,7 +244,9 @@ int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
    up and 336 B/pt down instead of 176 + 392, and no host-side state copies.
    A `grad_del_u_host` / `tangent_host` array inside a range page-locked with
    fcamd_register_host_buffer is read / written by the kernel itself (zero copy, as in
-   fcamd_evaluate_host) instead of passing through the chunk buffers.
+   fcamd_evaluate_host) instead of passing through the chunk buffers; when all host arrays of the
+   call are page-locked (3-D laws) the whole pass is one launch that writes the stress both to the
+   device-resident trial array and to `stress_host`.
    `history_mask` (nullable) selects the sparse trial-history protocol of
    fcamd_evaluate_device_from_sparse (plasticity laws).  `flags`: FCAMD_EVAL_SPARSE_TANGENT applies the
    sparse-tangent protocol to `tangent_host` when the kernel writes it directly (page-locked array):
