@@ -349,6 +349,13 @@ __device__ __forceinline__ unsigned long long sparse_tangent_need(const EvalArgs
     return (FULL && (a.flags & kFlagSparseTangent) != 0 && a.hmask != nullptr) ? need : ~0ull;
 }
 
+// The tangent chunks of a tile are computed and stored in groups: the scheduler may interleave the LDS
+// reads, the arithmetic and the stores of one group, not across groups (bounds the register pressure).
+#ifndef FCAMD_TANGENT_GROUP
+#define FCAMD_TANGENT_GROUP 3
+#endif
+constexpr int kTangentGroup = FCAMD_TANGENT_GROUP;
+
 // Point-dependent tangent of the two Mises laws.  Lane p has published
 //   tp[10p + 0] = B, tp[10p + 1] = C, tp[10p + 2 .. 7] = N   (stride 10: conflict-free b128)
 // and the tile's tangent is   T[p][i][j] = (ta[i][j] + B * tb[i][j]) + third(i, j)  with
@@ -385,7 +392,7 @@ __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta
         }
         if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         // bound the register pressure: let the scheduler interleave at most 3 chunks
-        if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -1205,7 +1212,7 @@ __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11ta
         const d2 el = *reinterpret_cast<const d2*>(etab + 6 * i + j);
         if (c2.y == 0.0) v = el;
         if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
-        if (k % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 

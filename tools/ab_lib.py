@@ -10,8 +10,8 @@ import sys
 import torch
 
 import os
-libs = sys.argv[1:3]
-sizes = [int(float(x)) for x in sys.argv[3:]] or [1_000_000, 10_000_000, 100_000_000]
+libs = [a for a in sys.argv[1:] if a.endswith('.so')]
+sizes = [int(float(x)) for x in sys.argv[1:] if not x.endswith('.so')] or [1_000_000, 10_000_000, 100_000_000]
 LAW = os.environ.get("AB_LAW", "vm")  # vm | le | maxwell
 SPARSE = os.environ.get("AB_SPARSE", "0") == "1"
 ZONED = os.environ.get("AB_ZONED", "0") == "1"
@@ -69,6 +69,23 @@ for n in sizes:
         h0 = [torch.zeros(6 * n, **f), torch.rand(n, generator=gen, **f) * 0.02]
         h1 = [torch.empty(6 * n, **f), torch.empty(n, **f)]
     t = torch.empty(36 * n, **f)
+    ncand = int(os.environ.get("AB_TANGENT_CANDS", "0"))
+    if ncand:  # placement study: every build on the same candidate allocations of the tangent
+        cands = [t] + [torch.empty(36 * n, **f) for _ in range(ncand - 1)]
+        for ci, tc in enumerate(cands):
+            row = []
+            for lib in L:
+                lib.run(n, g, s0, s1, tc, h0, h1)
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+                for a, b in ev:
+                    a.record()
+                    lib.run(n, g, s0, s1, tc, h0, h1)
+                    b.record()
+                torch.cuda.synchronize()
+                row.append(min(a.elapsed_time(b) for a, b in ev))
+            print(f"n={n} cand {ci:2d}: " + "  ".join(f"{libs[i].split('/')[-1]} {x:7.3f}" for i, x in enumerate(row)), flush=True)
+        del cands
+        continue
     outs = []
     res = [[] for _ in L]
     reps = 5 if n >= 10**8 else 20
