@@ -30,8 +30,14 @@ from .resident import ResidentState
 __all__ = ["use_resident_state"]
 
 
-def use_resident_state(problem, sync_history: bool = True, pin: bool = True) -> list[ResidentState]:
-    """Returns the created states (one per GPU-backed law of ``problem._law_on_submeshs``)."""
+def use_resident_state(problem, sync_history: bool = True, pin: bool = True, direct_global: bool = True) -> list[ResidentState]:
+    """Returns the created states (one per GPU-backed law of ``problem._law_on_submeshs``).
+
+    ``direct_global``: a law whose submesh map is the reference's ``IdentityMap`` (one material on the
+    whole mesh: ``map_to_parent`` is ``parent.x.array[:] = sub.x.array[:]``, solver/maps.py:29-47) writes
+    its stress and tangent straight into the problem's global arrays -- the host copy of 336 B per point
+    and Newton iteration disappears as well (the law's local ``stress`` / ``local_tangent`` Functions are
+    then no longer updated)."""
     states = []
     for los in problem._law_on_submeshs:
         law = los.law
@@ -42,11 +48,22 @@ def use_resident_state(problem, sync_history: bool = True, pin: bool = True) -> 
         stress0 = los.local_stress(problem.stress).copy()  # committed stress of this law's cells
         hist0 = None if los.history is None else {k: f.x.array for k, f in los.history.history_0.items()}
         state = ResidentState(law, n, stress0=stress0, history0=hist0)
+        direct = bool(direct_global) and type(los.submesh_map).__name__ == "IdentityMap"
         if pin:
-            law.pin_host_arrays(los.displacement_gradient_fn.x.array, los.stress.x.array, los.local_tangent.x.array)
+            if direct:
+                law.pin_host_arrays(los.displacement_gradient_fn.x.array, problem.stress.current.x.array,
+                                    problem.tangent.x.array)
+            else:
+                law.pin_host_arrays(los.displacement_gradient_fn.x.array, los.stress.x.array, los.local_tangent.x.array)
 
-        def evaluate(self, sim_time, incr_disp, global_stress, global_tangent, _state=state):
+        def evaluate(self, sim_time, incr_disp, global_stress, global_tangent, _state=state, _direct=direct):
             incr_disp.evaluate_local_incremental_gradient(self.cells, self.displacement_gradient_fn)
+            if _direct:
+                _state.evaluate_into(sim_time.current, sim_time.dt, self.displacement_gradient_fn.x.array,
+                                     global_stress.current.x.array, global_tangent.x.array)
+                global_stress.current.x.scatter_forward()  # what IdentityMap.map_to_parent does after its copy
+                global_tangent.x.scatter_forward()
+                return
             _state.evaluate_into(sim_time.current, sim_time.dt, self.displacement_gradient_fn.x.array,
                                  self.stress.x.array, self.local_tangent.x.array)
             self.map_to_parent(global_stress, global_tangent)

@@ -154,3 +154,56 @@ def test_patched_problem_equals_unpatched():
     assert b._law_on_submeshs[0].law.last_stats.n_plastic > 0
     for los in b._law_on_submeshs:
         los.law.unpin_arrays()
+
+
+class IdentityMap:  # name as in the reference (solver/maps.py:29): what use_resident_state keys on
+    def map_to_sub(self, parent, sub):
+        sub.x.array[:] = parent.x.array[:]
+
+    def map_to_parent(self, sub, parent):
+        parent.x.array[:] = sub.x.array[:]
+
+
+def build_single(n_cells, q, seed):
+    rng = np.random.default_rng(seed)
+    vm = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
+    cells = np.arange(n_cells, dtype=np.int32)
+    rows = np.arange(n_cells * q)
+    p = Problem([(vm, cells, rows)], n_cells * q)
+    p._law_on_submeshs[0].submesh_map = IdentityMap()
+    p.stress.previous.x.array[:] = rng.normal(scale=5.0, size=6 * n_cells * q)
+    p._law_on_submeshs[0].history.history_0["alpha"].x.array[:] = rng.uniform(0, 0.02, size=n_cells * q)
+    return p
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_single_material_writes_the_global_arrays_directly(direct):
+    """IdentityMap (one law on the whole mesh): with direct_global the patched evaluate writes stress and
+    tangent into the problem's global arrays itself (no map_to_parent copy); same numbers either way."""
+    n_cells, q = 900, 4
+    a, b = build_single(n_cells, q, 5), build_single(n_cells, q, 5)
+    (state,) = use_resident_state(b, direct_global=direct)
+    los_b = b._law_on_submeshs[0]
+    calls = []
+    orig = los_b.map_to_parent
+    los_b.map_to_parent = lambda *args: (calls.append(1), orig(*args))
+    rng = np.random.default_rng(2)
+    for inc in range(3):
+        for it in range(3):
+            m = n_cells * q
+            g = rng.normal(size=9 * m) * np.repeat(10 ** rng.uniform(-4, -1.8 if it else -3.5, size=m), 9)
+            a.incr_disp.grads[a._law_on_submeshs[0].cells.tobytes()] = g
+            b.incr_disp.grads[los_b.cells.tobytes()] = g
+            a.form()
+            b.form()
+            assert np.array_equal(a.stress.current.x.array, b.stress.current.x.array), (inc, it)
+            assert np.array_equal(a.tangent.x.array, b.tangent.x.array), (inc, it)
+        a.update()
+        b.update()
+        assert np.array_equal(a._law_on_submeshs[0].history.history_0["eps_n"].x.array,
+                              los_b.history.history_0["eps_n"].x.array)
+    assert (len(calls) == 0) == direct
+    from fenics_constitutive_amd import _capi
+
+    assert los_b.law._handle(_capi.default_device()).ctx.last_host_mode() == 3  # pinned: the kernel moved everything
+    los_b.law.unpin_arrays()
