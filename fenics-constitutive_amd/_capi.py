@@ -40,7 +40,7 @@ SYMBOLS = [
     "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_evaluate_device",
     "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
     "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
-    "fcamd_context_last_host_mode",
+    "fcamd_context_last_host_mode", "fcamd_host_device_pointer",
     "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
     "fcamd_last_error", "fcamd_status_string", "fcamd_version",
 ]
@@ -51,7 +51,7 @@ class EvalArgs(C.Structure):
 
     _fields_ = [("grad_del_u", C.c_void_p), ("stress_prev", C.c_void_p), ("stress", C.c_void_p),
                 ("tangent", C.c_void_p), ("history_prev", C.POINTER(C.c_void_p)), ("history", C.POINTER(C.c_void_p)),
-                ("n_hist", C.c_int), ("parent_rows", C.c_void_p), ("history_mask", C.c_void_p), ("flags", C.c_int)]
+                ("n_hist", C.c_int), ("parent_rows", C.c_void_p), ("history_mask", C.c_void_p), ("flags", C.c_int), ("stress2", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -131,6 +131,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
         lib.fcamd_unregister_host_buffer.argtypes = [vp, vp]
         lib.fcamd_context_last_host_mode.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.fcamd_host_device_pointer.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
         lib.fcamd_last_error.restype = C.c_char_p
         lib.fcamd_status_string.restype = C.c_char_p
         lib.fcamd_status_string.argtypes = [C.c_int]
@@ -194,6 +195,13 @@ class Context:
 
     def unregister_host_buffer(self, arr: np.ndarray) -> None:
         check(self._lib.fcamd_unregister_host_buffer(self.handle, C.c_void_p(arr.ctypes.data)))
+
+    def device_pointer(self, arr: np.ndarray) -> int:
+        """Address at which device launches see the (page-locked, registered) NumPy array; ValueError if it
+        is not inside a registered range."""
+        d = C.c_void_p()
+        check(self._lib.fcamd_host_device_pointer(self.handle, C.c_void_p(arr.ctypes.data), arr.nbytes, C.byref(d)))
+        return int(d.value)
 
     def last_host_mode(self) -> int:
         """Data path of the last host-entry call: bit 0 = inputs, bit 1 = results moved by the kernel
@@ -282,11 +290,11 @@ class Model:
             C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), parr, arr, nh))
 
     def evaluate_device_ex(self, t, del_t, n, grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr, hist_prev_ptrs,
-                           hist_ptrs, rows_ptr=None, mask_ptr=None, flags: int = 0) -> None:
+                           hist_ptrs, rows_ptr=None, mask_ptr=None, flags: int = 0, stress2_ptr=None) -> None:
         arr, nh = self._ptr_array(hist_ptrs)
         parr, _ = self._ptr_array(hist_prev_ptrs)
         x = EvalArgs(grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr or None, parr, arr, nh, rows_ptr or None,
-                     mask_ptr or None, int(flags))
+                     mask_ptr or None, int(flags), stress2_ptr or None)
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
 
     def evaluate_device_wrapped(self, wrapper_constraint, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, stress3d_ptr,

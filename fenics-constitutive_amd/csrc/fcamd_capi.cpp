@@ -773,8 +773,10 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     fcamd_context* c = m->ctx;
     HIP_TRY(hipSetDevice(c->device));
     m->timed = false;
+    if (!aligned16(x->stress2)) return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
     return enqueue(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history,
-                   c->stream, true, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask), x->flags);
+                   c->stream, true, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask), x->flags,
+                   x->stress2);
 }
 
 int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double t, double del_t, int64_t n,
@@ -927,6 +929,14 @@ int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
 int fcamd_context_last_host_mode(fcamd_context* c, int* mode) {
     if (!c || !mode) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     *mode = c->last_host_mode;
+    return FCAMD_OK;
+}
+
+int fcamd_host_device_pointer(fcamd_context* c, const void* host_ptr, size_t bytes, void** device_ptr) {
+    if (!c || !host_ptr || !device_ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    double* d = mapped(c, host_ptr, bytes);
+    if (!d) return fail(FCAMD_ERR_BAD_ARG, "host range is not inside a registered, mapped buffer (or not 16-byte aligned)");
+    *device_ptr = d;
     return FCAMD_OK;
 }
 

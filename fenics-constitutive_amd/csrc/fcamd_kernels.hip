@@ -252,6 +252,7 @@ struct StressRows {
                     v.x = s[2 * k];
                     v.y = s[2 * k + 1];
                     store16<NT>(sb.sout + row * 6 + 2 * k, v);
+                    if (sb.sout2 != nullptr) store16<NT>(sb.sout2 + row * 6 + 2 * k, v);
                 }
             }
         } else if (sb.sout2 == nullptr) {
@@ -1651,7 +1652,8 @@ __device__ __forceinline__ void run_full_tile(const EvalArgs& a, const Tables* T
         if (__all(row == row0 + lane)) {
             const long long shift = (long long)row0 - p0;
             const StressBases sc{a.stress_in + shift * 6, a.stress_out + shift * 6,
-                                 a.tangent ? a.tangent + shift * 36 : nullptr};
+                                 a.tangent ? a.tangent + shift * 36 : nullptr,
+                                 a.stress_out2 ? a.stress_out2 + shift * 6 : nullptr};
             run_tile<LAW, false, true, NT, SPARSE>(a, sc, T, region, rows_lds, p0, kWave, lane, r0, st);
             return;
         }

@@ -24,10 +24,13 @@ from __future__ import annotations
 
 import types
 
+import numpy as np
+
 from .device import DeviceLaw
+from .problem import ResidentProblemState
 from .resident import ResidentState
 
-__all__ = ["use_resident_state"]
+__all__ = ["use_resident_state", "use_resident_problem_state"]
 
 
 def use_resident_state(problem, sync_history: bool = True, pin: bool = True, direct_global: bool = True) -> list[ResidentState]:
@@ -81,3 +84,71 @@ def use_resident_state(problem, sync_history: bool = True, pin: bool = True, dir
         los.resident_state = state
         states.append(state)
     return states
+
+
+def _parent_rows(los, n_local: int):
+    """Parent row of every local quadrature point of a law: ``parent_array[map.parent] = sub_array[map.sub]``
+    (solver/maps.py:98-100) read as local point ``sub[i]`` -> parent row ``parent[i]``; ``None`` for the
+    reference's ``IdentityMap``."""
+    m = los.submesh_map
+    if type(m).__name__ == "IdentityMap":
+        return None
+    rows = np.empty(n_local, dtype=np.int64)
+    rows[np.asarray(m.sub)] = np.asarray(m.parent)
+    return rows
+
+
+def use_resident_problem_state(problem, sync_history: bool = True, pin: bool = True) -> ResidentProblemState:
+    """Multi-material form of ``use_resident_state``: ONE ``ResidentProblemState`` for all GPU-backed (FULL
+    3-D) laws of ``problem`` -- the committed / trial stress of the whole mesh and every law's history on the
+    GPU -- and every ``LawOnSubMesh.evaluate`` replaced by: incremental gradient (unchanged dolfinx call) ->
+    ``ResidentProblemState.evaluate_law_into``, whose kernel reads the law's gradient from the host array and
+    writes the law's rows of the problem's GLOBAL ``stress.current`` / ``tangent`` arrays itself.  Besides
+    the state copies this removes both submesh maps of every Newton iteration (``local_stress``:
+    ``map_to_sub``; ``map_to_parent``: fancy-indexed host copies of 48 + 336 bytes per point,
+    solver/maps.py:82-123) and the per-law local stress / tangent arrays.  The laws of one iteration are
+    launched back to back and synchronised once, after the last one.  ``update_history`` of the first law
+    commits the shared state (pointer swap); laws that are not GPU-backed keep the reference's path."""
+    gpu = [(i, los) for i, los in enumerate(problem._law_on_submeshs) if isinstance(los.law, DeviceLaw)]
+    assert gpu, "no GPU-backed law in this problem"
+    assert all(los.law.constraint.name == "FULL" for _, los in gpu), "use_resident_problem_state: FULL 3-D laws only"
+    n = problem.stress.current.x.array.size // 6
+    laws = []
+    for _, los in gpu:
+        n_k = los.displacement_gradient_fn.x.array.size // 9
+        laws.append((los.law, _parent_rows(los, n_k)))
+    single_identity = len(laws) == 1 and laws[0][1] is None
+    state = ResidentProblemState(laws[0][0] if single_identity else laws, n, del_t=problem.sim_time.dt)
+    state.set_state(problem.stress.previous.x.array,
+                    [None if los.history is None else {k: f.x.array for k, f in los.history.history_0.items()}
+                     for _, los in gpu])
+    if pin:
+        first = gpu[0][1].law
+        first.pin_host_arrays(problem.stress.current.x.array, problem.tangent.x.array)
+        for _, los in gpu:
+            los.law.pin_host_arrays(los.displacement_gradient_fn.x.array)
+    last = len(gpu) - 1
+
+    for k, (_, los) in enumerate(gpu):
+        def evaluate(self, sim_time, incr_disp, global_stress, global_tangent, _k=k):
+            incr_disp.evaluate_local_incremental_gradient(self.cells, self.displacement_gradient_fn)
+            state._time, state._del_t = sim_time.current, sim_time.dt
+            state.evaluate_law_into(_k, self.displacement_gradient_fn.x.array, global_stress.current.x.array,
+                                    global_tangent.x.array, sync=(_k == last))
+            if _k == last:
+                global_stress.current.x.scatter_forward()  # as the reference's map_to_parent does per law
+                global_tangent.x.scatter_forward()
+
+        def update_history(self, _k=k):
+            if _k == 0:
+                state.update()
+            if sync_history and self.history is not None:
+                committed = state._history_0[_k]
+                for key, fn in self.history.history_0.items():
+                    fn.x.array[:] = committed[key].cpu().numpy()
+                    self.history.history_1[key].x.array[:] = fn.x.array
+
+        los.evaluate = types.MethodType(evaluate, los)
+        los.update_history = types.MethodType(update_history, los)
+    problem.resident_problem_state = state
+    return state

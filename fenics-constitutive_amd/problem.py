@@ -50,8 +50,10 @@ class _LawState:
         if sparse_history and type(law).__name__ in ("VonMises3D", "MisesPlasticityLinearHardening3D",
                                                      "DruckerPrager3D", "DruckerPragerHyperbolic3D"):
             self.mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
-        # sparse tangent (see ResidentState): true once the parent array holds this law's previous tangent
-        self.tangent_current = False
+        # sparse tangent (see ResidentState): the array that received this law's previous tangent --
+        # "dev" (the state's device array) or the address of the host assembler's parent array
+        self.tangent_target = None
+        self.host_tangent_key = None  # constant-tangent laws: (host address, del_t) the host array is valid for
 
 
 class ResidentProblemState:
@@ -87,12 +89,25 @@ class ResidentProblemState:
             self._laws.append(_LawState(law, rows, n_k, f, self.device, sparse_history))
         assert covered.max(initial=0) <= 1, "a quadrature point belongs to more than one law"
         self._stress = [torch.zeros(6 * self.n, **f), torch.zeros(6 * self.n, **f)]
-        self.tangent = torch.zeros(36 * self.n, **f)
+        self._tangent = None  # parent tangent on the device: allocated on first use (device-assembler mode only)
         self._c = 0
         self._time, self._del_t = 0.0, float(del_t)
         self._evaluated = False
         self.reuse_constant_tangent = reuse_constant_tangent
         self.sparse_tangent = sparse_tangent
+
+    @property
+    def tangent(self):
+        """Parent tangent array on the device (rows of points that belong to no law stay zero)."""
+        if self._tangent is None:
+            import torch
+
+            self._tangent = torch.zeros(36 * self.n, **self._f)
+        return self._tangent
+
+    @tangent.setter
+    def tangent(self, value):
+        self._tangent = value
 
     # reference-compatible views ----------------------------------------------------------------------
     @property
@@ -129,7 +144,7 @@ class ResidentProblemState:
                     ls.hist[1 - self._c][k].copy_(ls.hist[self._c][k])  # trial == committed (sparse-history contract)
                 if ls.mask is not None:
                     ls.mask.zero_()
-                ls.tangent_current = False  # the mask no longer remembers which rows hold plastic tangents
+                ls.tangent_target = None  # the mask no longer remembers which rows hold plastic tangents
 
     # the Newton-iteration call (IncrSmallStrainProblem.form, solver/_solver.py:130-147) ------------------
     def evaluate(self, grads) -> None:
@@ -154,15 +169,74 @@ class ResidentProblemState:
                 if ls.tangent_key == key:
                     tangent = None
                 ls.tangent_key = key
-            st = self.sparse_tangent and ls.mask is not None and ls.tangent_current
+            st = self.sparse_tangent and ls.mask is not None and ls.tangent_target == "dev"
             if ls.rows is None:
                 ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent, hp, hc,
                                      history_mask=ls.mask, sparse_tangent=st)
             else:
                 ls.law.evaluate_indexed(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent,
                                         ls.rows, hp, hc, history_mask=ls.mask, sparse_tangent=st)
-            ls.tangent_current = True
+            ls.tangent_target = "dev"
         self._evaluated = True
+
+    # the host assembler's Newton-iteration call, law by law (LawOnSubMesh.evaluate, solver/_lawonsubmesh.py:72-95)
+    def evaluate_law_into(self, k: int, grad_del_u: np.ndarray, stress_parent: np.ndarray,
+                          tangent_parent: np.ndarray | None, sync: bool = True) -> None:
+        """Law ``k`` only: trial state <- law(committed state, ``grad_del_u``) with the law's LOCAL gradient
+        as a NumPy array, and the law's rows of the host assembler's PARENT arrays ``stress_parent`` (6 n)
+        / ``tangent_parent`` (36 n; optional) written by the kernel itself, over PCIe -- the reference's
+        ``map_to_sub`` / ``map_to_parent`` copies (solver/maps.py:82-123) and its per-law local stress and
+        tangent arrays have no counterpart.  The two parent arrays must be page-locked
+        (``law.pin_host_arrays`` / ``Context.register_host_buffer``) and are taken to be left alone between
+        calls, as in ``ResidentState.evaluate_into``: constant tangents are written once per ``del_t``,
+        point-dependent ones row by row (sparse tangent).  A page-locked gradient array is read in place,
+        a pageable one is uploaded first.  ``sync=False`` returns after the launch (several laws in flight;
+        the last call of a Newton iteration must synchronise before the host reads the arrays)."""
+        import torch
+
+        from . import _capi
+        from .device import _check_numpy, _current_stream_ptr
+
+        ls = self._laws[k]
+        _check_numpy("grad_del_u", grad_del_u), _check_numpy("stress_parent", stress_parent)
+        assert grad_del_u.size == 9 * ls.n, "grad_del_u has the wrong length"
+        assert stress_parent.size == 6 * self.n, "stress_parent has the wrong length"
+        dev = self.device.index or 0
+        m = ls.law._handle(dev)
+        ctx = m.ctx
+        ctx.set_stream(_current_stream_ptr(dev))
+        sptr = ctx.device_pointer(stress_parent)  # ValueError: not registered
+        tptr = None
+        if tangent_parent is not None:
+            _check_numpy("tangent_parent", tangent_parent)
+            assert tangent_parent.size == 36 * self.n, "tangent_parent has the wrong length"
+            tptr = ctx.device_pointer(tangent_parent)
+        try:
+            gptr = ctx.device_pointer(grad_del_u)
+        except ValueError:  # pageable gradient: upload
+            if ls.grad is None:
+                ls.grad = torch.empty(9 * ls.n, **self._f)
+            ls.grad.copy_(torch.from_numpy(grad_del_u), non_blocking=True)
+            gptr = ls.grad.data_ptr()
+        flags, target = 0, None if tptr is None else ("host", tptr)
+        if tptr is not None and ls.const_tangent and self.reuse_constant_tangent:
+            key = (tptr, self._del_t if type(ls.law).__name__.startswith("Spring") else 0.0)
+            if ls.host_tangent_key == key:
+                tptr = None  # the parent array already holds this law's rows
+            ls.host_tangent_key = key
+        elif tptr is not None and self.sparse_tangent and ls.mask is not None and ls.tangent_target == target:
+            flags = _capi.EVAL_SPARSE_TANGENT
+        hp = [] if ls.hist is None else [ls.hist[self._c][name].data_ptr() for name, _ in m.history_fields]
+        hc = [] if ls.hist is None else [ls.hist[1 - self._c][name].data_ptr() for name, _ in m.history_fields]
+        ls.tangent_target = None
+        m.evaluate_device_ex(self._time, self._del_t, ls.n, gptr, self.stress_0.data_ptr(), self.stress_1.data_ptr(), tptr,
+                             hp, hc, None if ls.rows is None else ls.rows.data_ptr(),
+                             None if ls.mask is None else ls.mask.data_ptr(), flags, stress2_ptr=sptr)
+        ls.tangent_target = target
+        self._host_refs = (stress_parent, tangent_parent)  # identified by address above: keep them alive
+        self._evaluated = True
+        if sync:
+            self.check()
 
     def tune_placement(self, grads, tries: int = 4) -> dict:
         """Choose the placement of the parent tangent array (the dominant write stream of every law's
@@ -175,7 +249,7 @@ class ResidentProblemState:
             self.tangent = tan
             for ls in self._laws:
                 ls.tangent_key = None  # constant tangents have to be written into the candidate
-                ls.tangent_current = False  # ... and every row of the point-dependent ones
+                ls.tangent_target = None  # ... and every row of the point-dependent ones
             self.evaluate(grads)
 
         first, self.tangent = self.tangent, None

@@ -207,6 +207,9 @@ typedef struct fcamd_eval_args {
     const int32_t* parent_rows;         /* nullable */
     uint64_t* history_mask;             /* nullable */
     int flags;                          /* FCAMD_EVAL_* */
+    double* stress2;                    /* nullable: second destination of the stress rows, addressed like
+                                           `stress` (the host assembler's page-locked array, see
+                                           fcamd_host_device_pointer) */
 } fcamd_eval_args;
 /* Sparse-tangent protocol (plasticity laws, needs history_mask and a tangent array): the caller owns
    `tangent` across evaluates and it holds the tangent written by the PREVIOUS evaluate with the same
@@ -306,6 +309,14 @@ int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
 #define FCAMD_HOST_ZERO_COPY_IN 1  /* inputs read by the kernel from the caller's host arrays */
 #define FCAMD_HOST_ZERO_COPY_OUT 2 /* results written by the kernel into the caller's host arrays */
 int fcamd_context_last_host_mode(fcamd_context* ctx, int* mode);
+/* Address at which the device entries (fcamd_evaluate_device*) can read / write the host range
+   [host_ptr, host_ptr + bytes): it must lie inside one range registered with
+   fcamd_register_host_buffer and be 16-byte aligned (FCAMD_ERR_BAD_ARG otherwise).  With it a device
+   launch can take the host assembler's arrays as operands -- e.g. the PARENT stress / tangent arrays
+   of a multi-material problem as `stress2` / `tangent` of fcamd_evaluate_device_ex with `parent_rows`:
+   the reference's map_to_parent copies (solver/maps.py:82-101) then happen inside the kernel, over
+   PCIe.  The caller synchronises (fcamd_context_synchronize) before the host reads the results. */
+int fcamd_host_device_pointer(fcamd_context* ctx, const void* host_ptr, size_t bytes, void** device_ptr);
 
 /* ---- tuning / introspection -------------------------------------------------- */
 /* Override the launch grid (number of 256-thread workgroups; 0 = automatic). */

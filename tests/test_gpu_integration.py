@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 import fenics_constitutive_amd as fc  # noqa: E402
-from fenics_constitutive_amd.integration import use_resident_state  # noqa: E402
+from fenics_constitutive_amd.integration import use_resident_problem_state, use_resident_state  # noqa: E402
 
 
 class Fn:
@@ -22,16 +22,19 @@ class Fn:
 
 
 class SubMap:
-    def __init__(self, rows):
-        self.rows = rows
+    """SubSpaceMap of the reference (solver/maps.py:60-123): ``parent`` / ``sub`` index arrays."""
+
+    def __init__(self, rows, sub=None):
+        self.parent = rows
+        self.sub = np.arange(rows.size) if sub is None else sub
 
     def map_to_sub(self, parent, sub):
-        d = sub.x.array.size // self.rows.size
-        sub.x.array.reshape(-1, d)[:] = parent.x.array.reshape(-1, d)[self.rows]
+        d = sub.x.array.size // self.parent.size
+        sub.x.array.reshape(-1, d)[self.sub] = parent.x.array.reshape(-1, d)[self.parent]
 
     def map_to_parent(self, sub, parent):
-        d = sub.x.array.size // self.rows.size
-        parent.x.array.reshape(-1, d)[self.rows] = sub.x.array.reshape(-1, d)
+        d = sub.x.array.size // self.parent.size
+        parent.x.array.reshape(-1, d)[self.parent] = sub.x.array.reshape(-1, d)[self.sub]
 
 
 class Stress:
@@ -207,3 +210,47 @@ def test_single_material_writes_the_global_arrays_directly(direct):
 
     assert los_b.law._handle(_capi.default_device()).ctx.last_host_mode() == 3  # pinned: the kernel moved everything
     los_b.law.unpin_arrays()
+
+
+@pytest.mark.parametrize("permuted", [False, True])
+def test_fused_problem_state_equals_unpatched(permuted):
+    """use_resident_problem_state: two laws on interleaved cells, the kernels write their rows of the global
+    stress / tangent arrays themselves (no map_to_sub / map_to_parent, no local arrays); with ``permuted`` the
+    submesh numbers its points in another order than the parent (general SubSpaceMap.sub)."""
+    n_cells, q = 800, 4
+    a, b = build(n_cells, q, 13), build(n_cells, q, 13)
+    if permuted:
+        rng_p = np.random.default_rng(1)
+        for pa, pb in zip(a._law_on_submeshs, b._law_on_submeshs):
+            perm = rng_p.permutation(pa.submesh_map.parent.size)
+            pa.submesh_map.sub, pb.submesh_map.sub = perm, perm.copy()
+            # local histories follow the local numbering
+            for k, f in pa.history.history_0.items():
+                d = f.x.array.size // perm.size
+                v = f.x.array.reshape(-1, d).copy()
+                f.x.array.reshape(-1, d)[perm] = v
+                pb.history.history_0[k].x.array[:] = f.x.array
+    for los in b._law_on_submeshs:   # no map call may survive the patch
+        los.submesh_map.map_to_sub = los.submesh_map.map_to_parent = None
+    state = use_resident_problem_state(b)
+    rng = np.random.default_rng(8)
+    for inc in range(3):
+        for it in range(3):
+            for los_a, los_b in zip(a._law_on_submeshs, b._law_on_submeshs):
+                m = los_a.stress.x.array.size // 6
+                scale = 10 ** rng.uniform(-4, -1.8 if it else -3.5, size=m)
+                g = rng.normal(size=9 * m) * np.repeat(scale, 9)
+                a.incr_disp.grads[los_a.cells.tobytes()] = g
+                b.incr_disp.grads[los_b.cells.tobytes()] = g
+            a.form()
+            b.form()
+            assert np.array_equal(a.stress.current.x.array, b.stress.current.x.array), (inc, it)
+            assert np.array_equal(a.tangent.x.array, b.tangent.x.array), (inc, it)
+        a.update()
+        b.update()
+        for los_a, los_b in zip(a._law_on_submeshs, b._law_on_submeshs):
+            for k in los_a.history.history_0:
+                assert np.array_equal(los_a.history.history_0[k].x.array, los_b.history.history_0[k].x.array), (inc, k)
+    assert state._tangent is None  # the parent tangent never existed on the device
+    for los in b._law_on_submeshs:
+        los.law.unpin_arrays()

@@ -174,7 +174,7 @@ def test_rows_of_cells_matches_quadrature_numbering():
 
 
 def test_eval_args_struct_layout_matches_header():
-    """ctypes mirror of fcamd_eval_args: ten fields in the header's order, pointer-sized except n_hist / flags."""
+    """ctypes mirror of fcamd_eval_args: eleven fields in the header's order, pointer-sized except n_hist / flags."""
     import ctypes as C
     import re
 
@@ -184,7 +184,7 @@ def test_eval_args_struct_layout_matches_header():
     body = re.search(r"typedef struct fcamd_eval_args \{(.*?)\} fcamd_eval_args;", hdr, re.S).group(1)
     names = re.findall(r"(\w+);", body)
     assert names == [f[0] for f in _capi.EvalArgs._fields_]
-    assert C.sizeof(_capi.EvalArgs) == 10 * C.sizeof(C.c_void_p)  # n_hist and flags each padded to pointer size
+    assert C.sizeof(_capi.EvalArgs) == 11 * C.sizeof(C.c_void_p)  # n_hist and flags each padded to pointer size
     assert _capi.EvalArgs.flags.offset == 9 * C.sizeof(C.c_void_p)
 
 
