@@ -53,3 +53,32 @@ def run(mode):
 
 for mode in ("reference protocol, GPU laws on ndarrays", "resident per law", "resident problem state"):
     print(json.dumps(run(mode)), flush=True)
+
+
+def run_single(mode):
+    """One material on the whole mesh (IdentityMap: the maps are plain copies)."""
+    p = T.build_single(n_cells, q, 3)
+    los = p._law_on_submeshs[0]
+    if mode != "reference protocol":
+        use_resident_state(p, direct_global=(mode == "resident, direct to the global arrays"))
+    else:
+        los.law.auto_pin = True
+    rng = np.random.default_rng(0)
+    m = n_cells * q
+    g = rng.normal(size=9 * m) * np.repeat(10 ** rng.uniform(-4, -2, size=m), 9)
+    times = []
+    for it in range(6):
+        p.incr_disp.grads[los.cells.tobytes()] = g * (1.0 + 0.01 * it)
+        t0 = time.perf_counter()
+        p.form()
+        times.append(time.perf_counter() - t0)
+        if it == 2:
+            p.update()
+    best = min(times[1:])
+    los.law.unpin_arrays()
+    return {"mode": "single material: " + mode, "points": m, "form_ms": round(best * 1e3, 2), "Mpts_s": round(m / best / 1e6, 1),
+            "checksum": float(p.stress.current.x.array.sum())}
+
+
+for mode in ("reference protocol", "resident, local arrays + map_to_parent", "resident, direct to the global arrays"):
+    print(json.dumps(run_single(mode)), flush=True)
