@@ -292,7 +292,7 @@ def main():
                     help="with --history sparse: also the sparse-tangent protocol of ResidentState (FCAMD_EVAL_SPARSE_TANGENT: "
                          "rows of points that stay elastic are not rewritten).  Not the reference contract -- the reported "
                          "bytes stay the interface's 464/568 B/pt, so `frac` is an equivalent, not a traffic, figure")
-    ap.add_argument("--placement-tries", type=int, default=4,
+    ap.add_argument("--placement-tries", type=int, default=6,
                     help="candidate allocations of the tangent array, timed with the real kernel before the run; the "
                          "fastest is kept (fenics_constitutive_amd.placement, DESIGN.md 6).  1 = take what the driver gives")
     ap.add_argument("--gather-direct", action="store_true",

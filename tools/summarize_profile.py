@@ -58,7 +58,7 @@ with open(out, "w") as f:
         f.write("Command (tools/profile_gpu.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
                 f"--steps 10 --warmup 2 --no-cpu-baseline --workload {wl} {extra_args}` and one `--pmc FETCH_SIZE`, one "
                 "`--pmc WRITE_SIZE` pass (`--steps 4 --warmup 2`).\n\n")
-    f.write("Launch sequence of one bench run: 1 in-place warm step (kernel variant `<..., false>`), 4 placement candidates "
+    f.write("Launch sequence of one bench run: 1 in-place warm step (kernel variant `<..., false>`), the placement candidates "
             "x 4 launches (bench.py --placement-tries, the slower candidates are part of the `kernel_stats` average below), "
             "the warm-up steps, 2 launches that read the plastic counts of the two Newton iterates, then the timed steps.\n\n")
     f.write("## kernel stats (`*_kernel_stats.csv`, top rows)\n\n| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|\n")
