@@ -4,9 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--n POINTS]
 
 One "step" = one ``evaluate`` pass of one constitutive law over n synthetic quadrature points
-per GPU, device-resident (inputs already in HBM when the timed region starts).  Default
-workload at N = 1: BASELINE.json's target configuration, VonMises3D return mapping, 1e8
-points, mixed elastic/plastic (SURVEY.md 8d cfg3 "mixed").  For N > 1 (launched by
+per GPU, device-resident (inputs already in HBM when the timed region starts), committed state in,
+trial state out -- the call of the product's device-resident Newton loop (ResidentState.evaluate;
+for the plasticity laws with the sparse trial-history protocol, --history full for the mask-less
+form).  The steps alternate between two Newton iterates of the increment.  Default workload at
+N = 1: BASELINE.json's target configuration, VonMises3D return mapping, 1e8 points, mixed
+elastic/plastic (SURVEY.md 8d cfg3 "mixed").  Before the warm-up the placement of the tangent array
+is chosen out of a few candidate allocations.  For N > 1 (launched by
 torch.distributed.run, one rank per GPU) every rank evaluates its own contiguous shard of
 n points (weak scaling, no data-path collective: SURVEY.md 8e); the optional stress/tangent
 all-gather of the single-assembler mode is timed separately and reported under "allgather".
