@@ -432,6 +432,18 @@ def main():
         dist.all_reduce(tk, op=dist.ReduceOp.SUM)
         per_rank_ms = [round(float(x), 4) for x in tk.tolist()]
 
+    # next to the headline: the same step without the sparse protocol (every launch rewrites the whole trial
+    # history, fcamd_evaluate_device_from) -- five extra launches after the timed region
+    full_ms = None
+    if sparse:
+        evf = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
+        for i, (e0_, e1_) in enumerate(evf):
+            e0_.record()
+            law.evaluate_from(0.0, del_t, grads[i & 1], stress_c, stress_t, tangent, hist_c, hist_t)
+            e1_.record()
+        torch.cuda.synchronize()
+        full_ms = sum(a_.elapsed_time(b_) for a_, b_ in evf[1:]) / (len(evf) - 1)
+
     # optional exchange step, timed separately (never part of `value`)
     gather = None
     if distributed and args.backend == "nccl":
@@ -502,6 +514,10 @@ def main():
                          "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
                          "bytes_per_point": {"elastic": b_el, "plastic": b_pl}},
         }
+        if full_ms is not None:
+            out["full_trial_history"] = {"kernel_ms_avg": round(full_ms, 4),
+                                         "frac": round(alg_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "note": "same step, whole trial history rewritten by every launch (--history full)"}
         if placement is not None:
             out["placement"] = {"tangent_" + k: v for k, v in placement.items()}
         if per_rank_ms is not None:
