@@ -205,12 +205,17 @@ class ResidentProblemState:
         m = ls.law._handle(dev)
         ctx = m.ctx
         ctx.set_stream(_current_stream_ptr(dev))
-        sptr = ctx.device_pointer(stress_parent)  # ValueError: not registered
-        tptr = None
         if tangent_parent is not None:
             _check_numpy("tangent_parent", tangent_parent)
             assert tangent_parent.size == 36 * self.n, "tangent_parent has the wrong length"
-            tptr = ctx.device_pointer(tangent_parent)
+        try:
+            sptr = ctx.device_pointer(stress_parent)
+            tptr = None if tangent_parent is None else ctx.device_pointer(tangent_parent)
+        except ValueError:
+            # parent arrays that are not page-locked (e.g. too small to be worth pinning): evaluate on the
+            # device arrays and copy this law's rows down -- correct for any array, meant for small problems
+            self._evaluate_law_staged(k, grad_del_u, stress_parent, tangent_parent)
+            return
         try:
             gptr = ctx.device_pointer(grad_del_u)
         except ValueError:  # pageable gradient: upload
@@ -237,6 +242,35 @@ class ResidentProblemState:
         self._evaluated = True
         if sync:
             self.check()
+
+    def _evaluate_law_staged(self, k, grad_del_u, stress_parent, tangent_parent) -> None:
+        import torch
+
+        ls = self._laws[k]
+        if ls.grad is None:
+            ls.grad = torch.empty(9 * ls.n, **self._f)
+        ls.grad.copy_(torch.from_numpy(grad_del_u))
+        hp = None if ls.hist is None else ls.hist[self._c]
+        hc = None if ls.hist is None else ls.hist[1 - self._c]
+        ls.tangent_key = ls.host_tangent_key = None
+        ls.tangent_target = None
+        tan = None if tangent_parent is None else self.tangent
+        if ls.rows is None:
+            ls.law.evaluate_from(self._time, self._del_t, ls.grad, self.stress_0, self.stress_1, tan, hp, hc,
+                                 history_mask=ls.mask)
+            stress_parent[:] = self.stress_1.cpu().numpy()
+            if tan is not None:
+                tangent_parent[:] = tan.cpu().numpy()
+        else:
+            ls.law.evaluate_indexed(self._time, self._del_t, ls.grad, self.stress_0, self.stress_1, tan, ls.rows, hp, hc,
+                                    history_mask=ls.mask)
+            rows = ls.rows.long()
+            rows_h = rows.cpu().numpy()
+            stress_parent.reshape(-1, 6)[rows_h] = self.stress_1.view(-1, 6)[rows].cpu().numpy()
+            if tan is not None:
+                tangent_parent.reshape(-1, 36)[rows_h] = tan.view(-1, 36)[rows].cpu().numpy()
+        self._evaluated = True
+        self.check()
 
     def tune_placement(self, grads, tries: int = 4) -> dict:
         """Choose the placement of the parent tangent array (the dominant write stream of every law's

@@ -254,3 +254,27 @@ def test_fused_problem_state_equals_unpatched(permuted):
     assert state._tangent is None  # the parent tangent never existed on the device
     for los in b._law_on_submeshs:
         los.law.unpin_arrays()
+
+
+def test_fused_problem_state_on_a_tiny_unpinned_problem():
+    """Arrays too small to be page-locked (the reference's own tests run on a handful of cells): the fused
+    flow falls back to evaluating on the device arrays and copying each law's rows down."""
+    n_cells, q = 40, 4
+    a, b = build(n_cells, q, 21), build(n_cells, q, 21)
+    use_resident_problem_state(b)
+    rng = np.random.default_rng(4)
+    for inc in range(2):
+        for it in range(2):
+            for los_a, los_b in zip(a._law_on_submeshs, b._law_on_submeshs):
+                m = los_a.stress.x.array.size // 6
+                g = rng.normal(size=9 * m) * np.repeat(10 ** rng.uniform(-4, -2, size=m), 9)
+                a.incr_disp.grads[los_a.cells.tobytes()] = g
+                b.incr_disp.grads[los_b.cells.tobytes()] = g
+            a.form()
+            b.form()
+            assert np.array_equal(a.stress.current.x.array, b.stress.current.x.array), (inc, it)
+            assert np.array_equal(a.tangent.x.array, b.tangent.x.array), (inc, it)
+        a.update()
+        b.update()
+    for los in b._law_on_submeshs:
+        los.law.unpin_arrays()
