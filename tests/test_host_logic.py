@@ -225,3 +225,26 @@ def test_drop_in_mode_subclasses_the_reference_interface():
     ) % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "drop-in ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_parent_rows_of_a_subspace_map():
+    """integration._parent_rows: SubSpaceMap (solver/maps.py:98-100: parent_array[parent] = sub_array[sub])
+    read as local point sub[i] -> parent row parent[i]; IdentityMap -> None."""
+    from types import SimpleNamespace
+
+    from fenics_constitutive_amd.integration import _parent_rows
+
+    class IdentityMap:
+        pass
+
+    assert _parent_rows(SimpleNamespace(submesh_map=IdentityMap()), 5) is None
+    parent = np.array([7, 3, 9, 0])
+    sub = np.array([2, 0, 3, 1])
+    rows = _parent_rows(SimpleNamespace(submesh_map=SimpleNamespace(parent=parent, sub=sub)), 4)
+    # map_to_parent with these rows == the reference's fancy-index statement
+    sub_array = np.arange(4.0) * 10
+    a = np.zeros(10)
+    a[parent] = sub_array[sub]
+    b = np.zeros(10)
+    b[rows] = sub_array
+    assert np.array_equal(a, b) and rows.tolist() == [3, 0, 7, 9]
