@@ -105,3 +105,48 @@ def test_c_program_runs(tmp_path, lib):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max error" in r.stdout
+
+
+def test_host_mapping_and_flag_errors(lib):
+    """fcamd_host_device_pointer / FCAMD_EVAL_SPARSE_TANGENT argument checks, raw."""
+    import mmap
+
+    from fenics_constitutive_amd import _capi
+
+    ctx, mdl = C.c_void_p(), C.c_void_p()
+    assert lib.fcamd_context_create(0, None, C.byref(ctx)) == 0
+    a = np.frombuffer(mmap.mmap(-1, 1 << 20), dtype=np.float64)
+    dptr = C.c_void_p()
+    lib.fcamd_host_device_pointer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    assert lib.fcamd_host_device_pointer(ctx, C.c_void_p(a.ctypes.data), a.nbytes, C.byref(dptr)) == _capi.ERR_BAD_ARG
+    assert b"registered" in lib.fcamd_last_error()
+    lib.fcamd_register_host_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    assert lib.fcamd_register_host_buffer(ctx, C.c_void_p(a.ctypes.data), a.nbytes) == 0
+    assert lib.fcamd_host_device_pointer(ctx, C.c_void_p(a.ctypes.data), a.nbytes, C.byref(dptr)) == 0 and dptr.value
+    sub = C.c_void_p()
+    assert lib.fcamd_host_device_pointer(ctx, C.c_void_p(a.ctypes.data + 4096), 8192, C.byref(sub)) == 0
+    assert sub.value - dptr.value == 4096                                       # sub-range of one registration
+    assert lib.fcamd_host_device_pointer(ctx, C.c_void_p(a.ctypes.data + 8), 64, C.byref(sub)) == _capi.ERR_BAD_ARG  # alignment
+    assert lib.fcamd_host_device_pointer(ctx, C.c_void_p(a.ctypes.data), a.nbytes + 8, C.byref(sub)) == _capi.ERR_BAD_ARG
+    lib.fcamd_unregister_host_buffer.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.fcamd_unregister_host_buffer(ctx, C.c_void_p(a.ctypes.data)) == 0
+    assert lib.fcamd_host_device_pointer(ctx, C.c_void_p(a.ctypes.data), a.nbytes, C.byref(dptr)) == _capi.ERR_BAD_ARG
+    # sparse tangent needs the history mask and a tangent array
+    p = (C.c_double * 5)(175000.0, 80769.0, 1200.0, 2500.0, 200.0)
+    assert lib.fcamd_model_create(ctx, 2, 5, p, 5, C.byref(mdl)) == 0
+    n = 128
+    f = dict(dtype=torch.float64, device="cuda")
+    g, s0, s1, t = torch.zeros(9 * n, **f), torch.zeros(6 * n, **f), torch.zeros(6 * n, **f), torch.zeros(36 * n, **f)
+    e0, a0, e1, a1 = torch.zeros(6 * n, **f), torch.zeros(n, **f), torch.zeros(6 * n, **f), torch.zeros(n, **f)
+    hp = (C.c_void_p * 2)(e0.data_ptr(), a0.data_ptr())
+    hc = (C.c_void_p * 2)(e1.data_ptr(), a1.data_ptr())
+    x = _capi.EvalArgs(g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), hp, hc, 2, None, None,
+                       _capi.EVAL_SPARSE_TANGENT, None)
+    lib.fcamd_evaluate_device_ex.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.POINTER(_capi.EvalArgs)]
+    assert lib.fcamd_evaluate_device_ex(mdl, 0.0, 1.0, n, C.byref(x)) == _capi.ERR_BAD_ARG
+    assert b"history_mask" in lib.fcamd_last_error()
+    mask = torch.zeros(2, dtype=torch.int64, device="cuda")
+    x.history_mask = mask.data_ptr()
+    assert lib.fcamd_evaluate_device_ex(mdl, 0.0, 1.0, n, C.byref(x)) == 0
+    assert lib.fcamd_context_synchronize(ctx) == 0
+    assert lib.fcamd_model_destroy(mdl) == 0 and lib.fcamd_context_destroy(ctx) == 0
