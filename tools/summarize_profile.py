@@ -37,11 +37,27 @@ if os.path.exists(bj) and os.path.getsize(bj):
 
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in trace]
 # the first dispatch is the untimed in-place warm step of bench.py (different state); the timed
-# launches are the last `steps` ones
+# launches are the last `steps` ones of the variant the timed region runs -- after it bench.py issues six
+# launches of the mask-less variant (another template instance) for its "full_trial_history" figure
 steps = bench.get("steps", 10)
-timed = dur[-steps:]
-fk = [float(r["Counter_Value"]) for r in fetch][1:]  # drop the warm step
-wk = [float(r["Counter_Value"]) for r in write][1:]
+names = [r["Kernel_Name"] for r in trace]
+main = max(set(names), key=names.count) if names else None
+timed = [d for d, nm in zip(dur, names) if nm == main][-steps:]
+
+
+def main_variant(rows_):
+    """Counter values of the kernel variant the timed region runs (the most frequent one), without the
+    first dispatch of the run (the in-place warm step) when that is the same variant."""
+    nm = [r["Kernel_Name"] for r in rows_]
+    if not nm:
+        return []
+    top = max(set(nm), key=nm.count)
+    vals = [float(r["Counter_Value"]) for r in rows_ if r["Kernel_Name"] == top]
+    return vals[1:] if nm[0] == top else vals
+
+
+fk = main_variant(fetch)
+wk = main_variant(write)
 fetch_b = 2.0 * 1024.0 * sum(fk) / max(len(fk), 1)
 write_b = 1024.0 * sum(wk) / max(len(wk), 1)
 n = bench.get("config", {}).get("points_per_gpu", 0)
@@ -60,7 +76,8 @@ with open(out, "w") as f:
                 "`--pmc WRITE_SIZE` pass (`--steps 4 --warmup 2`).\n\n")
     f.write("Launch sequence of one bench run: 1 in-place warm step (kernel variant `<..., false>`), the placement candidates "
             "x 4 launches (bench.py --placement-tries, the slower candidates are part of the `kernel_stats` average below), "
-            "the warm-up steps, 2 launches that read the plastic counts of the two Newton iterates, then the timed steps.\n\n")
+            "the warm-up steps, 2 launches that read the plastic counts of the two Newton iterates, the timed steps, and "
+            "(sparse protocol only) six launches of the mask-less kernel variant for the `full_trial_history` figure.\n\n")
     f.write("## kernel stats (`*_kernel_stats.csv`, top rows)\n\n| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|\n")
     for r in stats[:6]:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} | {int(r['MinNs'])/1e6:.4f} | {int(r['MaxNs'])/1e6:.4f} |\n")
