@@ -1,0 +1,87 @@
+"""Randomised call sequences on ResidentState: every shortcut on (sparse trial history, sparse tangent,
+constant tangent written / downloaded once, zero-copy host arrays, placement tuning) against a state with
+every shortcut off.  After every call the arrays a caller can see must be identical."""
+
+import mmap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from fenics_constitutive_amd import _capi  # noqa: E402
+from fenics_constitutive_amd.resident import ResidentState  # noqa: E402
+from test_gpu_parity import make_law, random_case  # noqa: E402
+
+
+def own(k):
+    return np.frombuffer(mmap.mmap(-1, max(8 * k, 8)), dtype=np.float64, count=k)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["von_mises_3d", "comfe_mises_plasticity", "linear_elasticity", "spring_maxwell"])
+def test_random_call_sequences(kind, seed):
+    n = 64 * 90 + 17
+    p, g0, s, h = random_case(kind, n, seed=seed)
+    law = make_law(kind, p)
+    opt = ResidentState(law, n, stress0=s, history0=h)
+    ref = ResidentState(law, n, stress0=s, history0=h, sparse_history=False, sparse_tangent=False,
+                        reuse_constant_tangent=False)
+    rng = np.random.default_rng(100 + seed)
+    ctx = law._handle(_capi.default_device()).ctx
+    # host array sets of the optimised state: pageable, and page-locked (zero copy)
+    pageable = {"g": np.empty(9 * n), "s": np.empty(6 * n), "t": np.full(36 * n, np.nan)}
+    pinned = {"g": own(9 * n), "s": own(6 * n), "t": own(36 * n)}
+    pinned["t"][:] = np.nan
+    for a in pinned.values():
+        ctx.register_host_buffer(a)
+    s_ref, t_ref = np.empty(6 * n), np.empty(36 * n)
+    del_t, evaluated = 1.0, False
+    try:
+        for step in range(40):
+            op = rng.choice(["dev", "host_pageable", "host_pinned", "host_pinned", "update", "del_t", "tune"],
+                            p=[0.2, 0.15, 0.2, 0.15, 0.15, 0.1, 0.05])
+            scale = rng.choice([0.0, 0.02, 0.5, 1.0, 1.7])
+            g = g0 * scale * (1.0 + 0.1 * rng.standard_normal())
+            if op == "dev":
+                opt.evaluate(0.0, del_t, g)
+                ref.evaluate(0.0, del_t, g)
+                torch.cuda.synchronize()
+                assert torch.equal(opt.tangent, ref.tangent), (step, op)
+                evaluated = True
+            elif op in ("host_pageable", "host_pinned"):
+                arrs = pageable if op == "host_pageable" else pinned
+                arrs["g"][:] = g
+                with_tangent = rng.random() < 0.8
+                opt.evaluate_into(0.0, del_t, arrs["g"], arrs["s"], arrs["t"] if with_tangent else None)
+                ref.evaluate_into(0.0, del_t, g, s_ref, t_ref)
+                assert np.array_equal(arrs["s"], s_ref), (step, op)
+                if with_tangent:
+                    assert np.array_equal(arrs["t"], t_ref), (step, op)
+                evaluated = True
+            elif op == "update" and evaluated:
+                opt.update()
+                ref.update()
+                evaluated = False
+            elif op == "del_t":
+                del_t = float(rng.choice([0.5, 1.0, 2.0]))
+                continue
+            elif op == "tune":
+                opt.tune_placement(0.0, del_t, g, tries=2)
+                ref.evaluate(0.0, del_t, g)
+                torch.cuda.synchronize()
+                assert torch.equal(opt.tangent, ref.tangent), (step, op)
+                evaluated = True
+            else:
+                continue
+            torch.cuda.synchronize()
+            assert torch.equal(opt.stress, ref.stress), (step, op)
+            assert torch.equal(opt.stress_committed, ref.stress_committed), (step, op)
+            if h is not None:
+                for k in h:
+                    assert torch.equal(opt.history[k], ref.history[k]) or not evaluated, (step, op, k)
+                    assert torch.equal(opt.history_committed[k], ref.history_committed[k]), (step, op, k)
+    finally:
+        for a in pinned.values():
+            ctx.unregister_host_buffer(a)
