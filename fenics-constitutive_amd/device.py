@@ -14,6 +14,8 @@ built library and a GPU, evaluation raises.
 
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 
 from . import _capi
@@ -69,7 +71,7 @@ class DeviceLaw(IncrSmallStrainModel):
     def __init__(self, parameter_vector, constraint: StressStrainConstraint = None):
         self._constraint = constraint if constraint is not None else StressStrainConstraint.FULL
         self._parameter_vector = [float(p) for p in parameter_vector]
-        self._handles: dict[int, _capi.Model] = {}
+        self._handles: dict[tuple[int, int], _capi.Model] = {}  # (device, thread) -> C model handle
         self.last_stats = None
 
     # -- interface properties --------------------------------------------------------------
@@ -79,11 +81,14 @@ class DeviceLaw(IncrSmallStrainModel):
 
     # -- C handle ---------------------------------------------------------------------------
     def _handle(self, device: int = 0) -> _capi.Model:
-        h = self._handles.get(device)
+        # one C handle per (device, thread): contexts are per thread (staging buffers, streams, the
+        # registry of page-locked ranges), so a law object shared by several threads stays thread-compatible
+        key = (device, threading.get_ident())
+        h = self._handles.get(key)
         if h is None:
             ctx = _capi.get_context(device)
-            h = self._handles[device] = _capi.Model(ctx, self._model_id, self._constraint.value,
-                                                    self._parameter_vector)
+            h = self._handles[key] = _capi.Model(ctx, self._model_id, self._constraint.value,
+                                                 self._parameter_vector)
         return h
 
     def _history_arrays(self, history):
@@ -135,14 +140,14 @@ class DeviceLaw(IncrSmallStrainModel):
         )
 
     def _pin(self, ctx, arrays) -> None:
-        pinned = self.__dict__.setdefault("_pinned", {})  # (ptr, nbytes) -> array (kept alive) | None
+        pinned = self.__dict__.setdefault("_pinned", {})  # (ptr, nbytes) -> (array kept alive, its context) | None
         for a in arrays:
             key = (a.ctypes.data, a.nbytes)
             if key in pinned or a.nbytes < (1 << 16):
                 continue
             try:
                 ctx.register_host_buffer(a)
-                pinned[key] = a
+                pinned[key] = (a, ctx)
             except RuntimeError:
                 pinned[key] = None  # e.g. overlaps another registration: keep the staged path
 
@@ -155,11 +160,9 @@ class DeviceLaw(IncrSmallStrainModel):
     def unpin_arrays(self) -> None:
         """Undo ``auto_pin`` registrations and drop the references that kept the arrays alive."""
         pinned = self.__dict__.pop("_pinned", {})
-        if not any(a is not None for a in pinned.values()):
-            return
-        ctx = self._handle(_capi.default_device()).ctx
-        for a in pinned.values():
-            if a is not None:
+        for entry in pinned.values():
+            if entry is not None:
+                a, ctx = entry  # the context (thread) that registered it, whichever thread runs this
                 ctx.unregister_host_buffer(a)
 
     def __del__(self):

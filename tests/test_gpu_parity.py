@@ -386,3 +386,34 @@ def test_strain_from_grad_u_low_dimensional():
         assert np.array_equal(fc.strain_from_grad_u(gg, c), ref)
         dev = fc.strain_from_grad_u(torch.from_numpy(gg).cuda(), c)
         assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), ref)
+
+
+def test_one_law_object_from_two_threads():
+    """Contexts (streams, staging buffers, registry of page-locked ranges) are per thread; a law object used
+    from two Python threads at once gets one C handle per thread and both get the right numbers."""
+    import threading
+
+    n = 200_000
+    p, g, s, h = random_case("von_mises_3d", n, seed=6)
+    ref = oracle_run("von_mises_3d", p, 1.0, g, s, h, mod=CO)
+    law = make_law("von_mises_3d", p)
+    results, errors = {}, []
+
+    def work(tag):
+        try:
+            for _ in range(3):
+                sc, t, hc = s.copy(), np.full(36 * n, np.nan), {k: v.copy() for k, v in h.items()}
+                law.evaluate(0.0, 1.0, g, sc, t, hc)
+            results[tag] = (sc, t, hc)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert len(law._handles) == 2
+    for tag in (0, 1):
+        compare(results[tag], ref, STRICT["pl"], f"thread {tag}")
