@@ -950,9 +950,9 @@ int fcamd_unregister_host_buffer(fcamd_context* c, void* ptr) {
     return FCAMD_OK;
 }
 
-// Host (ndarray) entry: chunked H2D -> kernel -> D2H, two chunk slots on two streams so that
-// the copies of one chunk overlap the kernel of the other when the caller's arrays are
-// page-locked (fcamd_register_host_buffer); pageable arrays are staged by the HIP runtime.
+// Host (ndarray) entry.  Page-locked, mapped caller arrays (fcamd_register_host_buffer): one launch
+// directly on them (zero copy).  Otherwise: chunked H2D -> kernel -> D2H over up to four chunk slots on
+// four streams, so that the copies of one chunk overlap the kernel and the copies of the others.
 int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
                         double* stress, double* tangent, double* const* hist, int n_hist,
                         fcamd_stats* stats) {
