@@ -22,6 +22,7 @@ OK, ERR_SIZE, ERR_NULL_HISTORY, ERR_DEL_T, ERR_NONCONVERGED, ERR_HIP, ERR_BAD_AR
  COMFE_DRUCKER_PRAGER, COMFE_DRUCKER_PRAGER_HYPERBOLIC) = range(1, 9)
 
 MAX_HISTORY = 2
+COUNTER_SLOTS, COUNTER_WORDS = 64, 256  # FCAMD_COUNTER_SLOTS / FCAMD_COUNTER_WORDS
 
 # fcamd_eval_args.flags / fcamd_evaluate_resident flags (include/fcamd.h)
 EVAL_SPARSE_TANGENT = 1
@@ -33,17 +34,26 @@ HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT = 1, 2
 (GRAD_1D_TO_3D, STRESS_1D_TO_3D, STRESS_3D_TO_1D, TANGENT_3D_TO_1D,
  GRAD_2D_TO_3D, STRESS_2D_TO_3D, STRESS_3D_TO_2D, TANGENT_3D_TO_2D) = range(1, 9)
 
-#: every symbol include/fcamd.h declares (checked by tests/test_capi_symbols.py)
+#: every symbol include/fcamd.h declares (checked by tests/test_host_logic.py::test_library_exports_every_declared_symbol)
 SYMBOLS = [
     "fcamd_context_create", "fcamd_context_destroy", "fcamd_context_set_stream",
     "fcamd_context_synchronize", "fcamd_model_create", "fcamd_model_destroy",
-    "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_evaluate_device",
+    "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_model_constraint", "fcamd_model_dims",
+    "fcamd_evaluate_device",
     "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
     "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
     "fcamd_context_last_host_mode", "fcamd_host_device_pointer",
+    "fcamd_shard_slot_points", "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_export", "fcamd_ipc_open",
+    "fcamd_ipc_close", "fcamd_enable_peer_access", "fcamd_allgather_direct", "fcamd_allgather_direct_wait",
+    "fcamd_device_alloc_set", "fcamd_device_free",
     "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
+    "fcamd_context_set_option", "fcamd_context_get_option", "fcamd_context_trim",
     "fcamd_last_error", "fcamd_status_string", "fcamd_version",
 ]
+
+IPC_HANDLE_BYTES = 64
+GATHER_PULL = 1
+ALLOC_SEQUENTIAL, ALLOC_INTERLEAVED = 0, 1
 
 
 class EvalArgs(C.Structure):
@@ -51,7 +61,8 @@ class EvalArgs(C.Structure):
 
     _fields_ = [("grad_del_u", C.c_void_p), ("stress_prev", C.c_void_p), ("stress", C.c_void_p),
                 ("tangent", C.c_void_p), ("history_prev", C.POINTER(C.c_void_p)), ("history", C.POINTER(C.c_void_p)),
-                ("n_hist", C.c_int), ("parent_rows", C.c_void_p), ("history_mask", C.c_void_p), ("flags", C.c_int), ("stress2", C.c_void_p)]
+                ("n_hist", C.c_int), ("parent_rows", C.c_void_p), ("history_mask", C.c_void_p), ("flags", C.c_int), ("stress2", C.c_void_p),
+                ("counters", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -94,11 +105,16 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
-        path = os.environ.get("FCAMD_LIBRARY") or _build.LIB  # override: A/B of two builds (tools/)
+        path = os.environ.get("FCAMD_LIBRARY")  # override: A/B of two builds (tools/)
+        if not path:
+            path = _build.LIB
+            # Rebuild when the sources changed since the library was built (content hash, _build._stale):
+            # tests and bench.py must never run against stale kernels.  A no-op when the hash matches; on a
+            # box without hipcc an up-to-date prebuilt library is used as it is.
+            if build_if_missing and (_build._stale() if os.path.isdir(_build.CSRC) else not os.path.exists(path)):
+                _build.build_library()
         if not os.path.exists(path):
-            if not build_if_missing:
-                raise RuntimeError(f"{path} is missing; run __graft_entry__.build()")
-            _build.build_library()
+            raise RuntimeError(f"{path} is missing; run __graft_entry__.build()")
         _share_hip_runtime_with_torch()
         lib = C.CDLL(path)
         dp = C.POINTER(C.c_double)
@@ -113,6 +129,24 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_model_destroy.argtypes = [vp]
         lib.fcamd_model_history_count.argtypes = [vp, C.POINTER(C.c_int)]
         lib.fcamd_model_history_field.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+        lib.fcamd_model_constraint.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.fcamd_model_dims.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        i64p = C.POINTER(C.c_int64)
+        lib.fcamd_shard_slot_points.argtypes = [C.c_int64, C.c_int, i64p]
+        lib.fcamd_shard_bounds.argtypes = [C.c_int64, C.c_int, C.c_int, i64p, i64p]
+        lib.fcamd_gather_chunk_plan.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_size_t, C.c_int, i64p, i64p]
+        lib.fcamd_ipc_export.argtypes = [vp, vp, C.c_char_p, C.POINTER(C.c_size_t)]
+        lib.fcamd_ipc_open.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp)]
+        lib.fcamd_ipc_close.argtypes = [vp, vp, C.c_size_t]
+        lib.fcamd_enable_peer_access.argtypes = [vp, C.c_int]
+        lib.fcamd_allgather_direct.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.c_size_t,
+                                               C.c_size_t, C.c_size_t, C.c_int]
+        lib.fcamd_allgather_direct_wait.argtypes = [vp, C.c_int]
+        lib.fcamd_device_alloc_set.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.POINTER(vp)]
+        lib.fcamd_device_free.argtypes = [vp, vp]
+        lib.fcamd_context_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+        lib.fcamd_context_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
+        lib.fcamd_context_trim.argtypes = [vp]
         lib.fcamd_evaluate_device.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_device_from.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_device_from_sparse.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int, vp]
@@ -164,11 +198,8 @@ def check(status: int) -> None:
 
 
 # ---------------------------------------------------------------------------------------
-# contexts: one per (device, thread); the launch stream is re-bound per call
+# contexts: one per (device, thread), held in thread-local storage; the launch stream is re-bound per call
 # ---------------------------------------------------------------------------------------
-_contexts: dict[tuple[int, int], "Context"] = {}
-
-
 class Context:
     def __init__(self, device: int = 0):
         lib = load()
@@ -190,6 +221,20 @@ class Context:
     def set_timing(self, enabled: bool) -> None:
         check(self._lib.fcamd_context_set_timing(self.handle, int(bool(enabled))))
 
+    def set_option(self, name: str, value: int) -> None:
+        """Launch / data-path knob (``fcamd_context_set_option``; the FCAMD_* environment variables are only
+        the defaults, read once when the context is created)."""
+        check(self._lib.fcamd_context_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_longlong()
+        check(self._lib.fcamd_context_get_option(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def trim(self) -> None:
+        """Release the staging buffers of the pageable host path."""
+        check(self._lib.fcamd_context_trim(self.handle))
+
     def register_host_buffer(self, arr: np.ndarray) -> None:
         check(self._lib.fcamd_register_host_buffer(self.handle, C.c_void_p(arr.ctypes.data), arr.nbytes))
 
@@ -210,10 +255,88 @@ class Context:
         check(self._lib.fcamd_context_last_host_mode(self.handle, C.byref(mode)))
         return int(mode.value)
 
+    # -- multi-GPU ----------------------------------------------------------------------------
+    def ipc_export(self, device_ptr: int) -> tuple[bytes, int]:
+        """(64-byte handle of the allocation ``device_ptr`` lies in, offset of the pointer inside it)."""
+        buf = C.create_string_buffer(IPC_HANDLE_BYTES)
+        off = C.c_size_t()
+        check(self._lib.fcamd_ipc_export(self.handle, C.c_void_p(device_ptr), buf, C.byref(off)))
+        return buf.raw, int(off.value)
+
+    def ipc_open(self, handle: bytes, offset: int) -> int:
+        out = C.c_void_p()
+        check(self._lib.fcamd_ipc_open(self.handle, handle, int(offset), C.byref(out)))
+        return int(out.value)
+
+    def ipc_close(self, device_ptr: int, offset: int) -> None:
+        check(self._lib.fcamd_ipc_close(self.handle, C.c_void_p(device_ptr), int(offset)))
+
+    def enable_peer_access(self, peer_device: int) -> None:
+        check(self._lib.fcamd_enable_peer_access(self.handle, int(peer_device)))
+
+    def allgather_direct(self, world: int, rank: int, gathered_ptrs, slot_bytes: int, offset_bytes: int = 0,
+                         nbytes: int | None = None, devices=None, pull: bool = False) -> None:
+        """``fcamd_allgather_direct``: world-1 peer copies on world-1 streams (asynchronous)."""
+        arr = (C.c_void_p * world)(*[C.c_void_p(int(p)) for p in gathered_ptrs])
+        dev = None if devices is None else (C.c_int * world)(*[int(d) for d in devices])
+        check(self._lib.fcamd_allgather_direct(self.handle, int(world), int(rank), arr, dev, int(slot_bytes),
+                                               int(offset_bytes), int(slot_bytes - offset_bytes if nbytes is None else nbytes),
+                                               GATHER_PULL if pull else 0))
+
+    def allgather_direct_wait(self, host_sync: bool = True) -> None:
+        check(self._lib.fcamd_allgather_direct_wait(self.handle, int(bool(host_sync))))
+
+    # -- device memory ------------------------------------------------------------------------
+    def alloc_set(self, nbytes: list[int], granule: int = 0, interleaved: bool = True) -> list[int]:
+        """``fcamd_device_alloc_set``: base addresses of a working set placed through the VMM API."""
+        k = len(nbytes)
+        sizes = (C.c_size_t * k)(*[int(b) for b in nbytes])
+        out = (C.c_void_p * k)()
+        check(self._lib.fcamd_device_alloc_set(self.handle, k, sizes, int(granule),
+                                               ALLOC_INTERLEAVED if interleaved else ALLOC_SEQUENTIAL, out))
+        return [int(p) for p in out]
+
+    def free(self, ptr: int) -> None:
+        check(self._lib.fcamd_device_free(self.handle, C.c_void_p(ptr)))
+
     def close(self) -> None:
         if self.handle:
             self._lib.fcamd_context_destroy(self.handle)
             self.handle = C.c_void_p()
+
+    def __del__(self):
+        # The context of a thread dies with the thread's local storage (get_context) once the model handles
+        # and page-locked registrations that refer to it are gone: streams and staging buffers are released
+        # instead of accumulating with every short-lived worker thread.
+        import sys
+
+        if sys.is_finalizing():  # process exit releases everything; the HIP runtime may already be going down
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
+    """``fcamd_shard_bounds``: [lo, hi) of rank's contiguous, 64-aligned slice of [0, n)."""
+    lo, hi = C.c_int64(), C.c_int64()
+    check(load().fcamd_shard_bounds(int(n), int(world), int(rank), C.byref(lo), C.byref(hi)))
+    return int(lo.value), int(hi.value)
+
+
+def shard_slot_points(n: int, world: int) -> int:
+    per = C.c_int64()
+    check(load().fcamd_shard_slot_points(int(n), int(world), C.byref(per)))
+    return int(per.value)
+
+
+def gather_chunk_plan(slot_points: int, world: int, values_per_point: int, budget_bytes: int, n_buffers: int = 2) -> tuple[int, int]:
+    """``fcamd_gather_chunk_plan``: (chunk_points, n_chunks); AssertionError if the budget holds no tile."""
+    c, k = C.c_int64(), C.c_int64()
+    check(load().fcamd_gather_chunk_plan(int(slot_points), int(world), int(values_per_point), int(budget_bytes),
+                                         int(n_buffers), C.byref(c), C.byref(k)))
+    return int(c.value), int(k.value)
 
 
 def default_device() -> int:
@@ -233,11 +356,17 @@ def default_device() -> int:
     return 0
 
 
+# Thread-local: a context (4 chunk streams, up to ~1.1 GB of staging buffers, the registry of page-locked
+# ranges) belongs to the thread that created it and is released when that thread ends -- a dict keyed by
+# threading.get_ident() would keep it for ever and hand it to a later thread that recycles the ident.
+_tls = threading.local()
+
+
 def get_context(device: int = 0) -> Context:
-    key = (int(device), threading.get_ident())
-    ctx = _contexts.get(key)
+    ctxs = _tls.__dict__.setdefault("contexts", {})
+    ctx = ctxs.get(int(device))
     if ctx is None:
-        ctx = _contexts[key] = Context(device)
+        ctx = ctxs[int(device)] = Context(device)
     return ctx
 
 
@@ -259,6 +388,20 @@ class Model:
             name, dim = C.c_char_p(), C.c_int()
             check(self._lib.fcamd_model_history_field(h, k, C.byref(name), C.byref(dim)))
             self.history_fields.append((name.value.decode(), dim.value))
+
+    @property
+    def constraint(self) -> int:
+        """``fcamd_model_constraint``: the StressStrainConstraint value of the handle."""
+        v = C.c_int()
+        check(self._lib.fcamd_model_constraint(self.handle, C.byref(v)))
+        return int(v.value)
+
+    @property
+    def dims(self) -> tuple[int, int]:
+        """``fcamd_model_dims``: (stress_strain_dim, geometric_dim)."""
+        sd, gd = C.c_int(), C.c_int()
+        check(self._lib.fcamd_model_dims(self.handle, C.byref(sd), C.byref(gd)))
+        return int(sd.value), int(gd.value)
 
     def _ptr_array(self, ptrs):
         if not ptrs:
@@ -290,11 +433,12 @@ class Model:
             C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), parr, arr, nh))
 
     def evaluate_device_ex(self, t, del_t, n, grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr, hist_prev_ptrs,
-                           hist_ptrs, rows_ptr=None, mask_ptr=None, flags: int = 0, stress2_ptr=None) -> None:
+                           hist_ptrs, rows_ptr=None, mask_ptr=None, flags: int = 0, stress2_ptr=None,
+                           counters_ptr=None) -> None:
         arr, nh = self._ptr_array(hist_ptrs)
         parr, _ = self._ptr_array(hist_prev_ptrs)
         x = EvalArgs(grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr or None, parr, arr, nh, rows_ptr or None,
-                     mask_ptr or None, int(flags), stress2_ptr or None)
+                     mask_ptr or None, int(flags), stress2_ptr or None, counters_ptr or None)
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
 
     def evaluate_device_wrapped(self, wrapper_constraint, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, stress3d_ptr,

@@ -9,35 +9,21 @@
 //   SpringMaxwellModel / SpringKelvinModel  models/spring_maxwell_model.py:24-38,72-86,
 //                                           models/spring_kelvin_model.py:24-41,73-86
 //   comfe-rs projections / tangents         comfe-rs/src/consts.rs:6-115, mandel.rs:126-128
-#include "../../include/fcamd.h"
-
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
 #include <new>
 #include <string>
-#include <vector>
 
-#include "fcamd_internal.h"
+#include "fcamd_host.h"
 
 using namespace fcamd;
 
-namespace {
-
-// Row-masked history access (fcamd_kernels.hip: tile_von_mises, history7_store) pays off while few rows
-// of a tile are touched: every skipped row saves its bytes, but holes turn full-line writes into partial
-// ones.  Tiles with more touched rows than this take the dense tile path.  Measured at 5e7 points
-// (tools/masked_threshold_probe.py, random mixtures, sparse protocol; dense = 5.55 ms for VonMises3D):
-// 5 % plastic 4.75 ms, 10 % 4.93, 19 % 5.23, 33 % 5.52 with thresholds 16-24, while "always masked" loses
-// 4-6 % from 47 % plastic on; the 56-byte rows of the comfe-rs laws straddle chunks and turn earlier.
-constexpr int kMaskedRowMaxVonMises = 20;
-constexpr int kMaskedRowMaxRows7 = 16;
-
-constexpr size_t kCounterBytes = (size_t)fcamd::kCounterSlots * 4 * sizeof(unsigned long long);
+namespace fcamd {
 
 thread_local std::string g_last_error;
 
@@ -51,31 +37,25 @@ int fail(int status, const char* fmt, ...) {
     return status;
 }
 
-#define HIP_TRY(expr)                                                                  \
-    do {                                                                               \
-        hipError_t e_ = (expr);                                                        \
-        if (e_ != hipSuccess) {                                                        \
-            (void)hipGetLastError(); /* reported here: do not leave it for a later launch check */ \
-            return fail(FCAMD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                           \
-        }                                                                              \
-    } while (0)
+}  // namespace fcamd
+
+namespace {
+
+// Row-masked history access (fcamd_kernels.hip: tile_von_mises, history7_store) pays off while few rows
+// of a tile are touched: every skipped row saves its bytes, but holes turn full-line writes into partial
+// ones.  Tiles with more touched rows than this take the dense tile path.  Measured at 5e7 points
+// (tools/masked_threshold_probe.py, random mixtures, sparse protocol; dense = 5.55 ms for VonMises3D):
+// 5 % plastic 4.75 ms, 10 % 4.93, 19 % 5.23, 33 % 5.52 with thresholds 16-24, while "always masked" loses
+// 4-6 % from 47 % plastic on; the 56-byte rows of the comfe-rs laws straddle chunks and turn earlier.
+constexpr int kMaskedRowMaxVonMises = 20;
+constexpr int kMaskedRowMaxRows7 = 16;
+
+constexpr size_t kCounterBytes = (size_t)fcamd::kCounterSlots * 4 * sizeof(unsigned long long);
+static_assert(fcamd::kCounterSlots == FCAMD_COUNTER_SLOTS, "public and internal counter layout differ");
 
 // Python "1 / 2**0.5" and Rust FRAC_1_SQRT_2 differ by one ULP.
 constexpr double kFactorPy = 0x1.6a09e667f3bccp-1;
 constexpr double kFactorRs = 0x1.6a09e667f3bcdp-1;
-
-struct HistField {
-    const char* name;
-    int dim;
-};
-
-struct LawInfo {
-    int n_params;
-    int n_hist;
-    HistField hist[FCAMD_MAX_HISTORY];
-    bool needs_del_t;
-};
 
 bool law_info(int id, LawInfo* li) {
     switch (id) {
@@ -106,10 +86,6 @@ void elastic_tangent_full(double E, double nu, double D[36]) {
         for (int j = 0; j < 3; ++j) D[6 * i + j] = (i == j) ? 2.0 * mu + lam : lam;
     for (int i = 3; i < 6; ++i) D[6 * i + i] = 2.0 * mu;
 }
-
-struct Dims {
-    int gd2, sd, gdim;
-};
 
 // stress_strain_dim / geometric_dim of a constraint (models/interfaces.py:30-73)
 Dims dims_of(int constraint) {
@@ -166,50 +142,10 @@ void comfe_projections(double soo[36], double pvol[36], double pdev[36]) {
 
 }  // namespace
 
-struct fcamd_context {
-    int device = 0;
-    int num_cu = 256;
-    hipStream_t stream = nullptr;
-    bool owns_stream = false;
-    int grid_override = 0;
-    bool timing = false;
-    // host path: kSlots chunk slots, each with its own stream and device buffers
-    static constexpr int kSlots = 4;
-    hipStream_t hstream[kSlots] = {nullptr, nullptr, nullptr, nullptr};
-    double* dchunk[kSlots] = {nullptr, nullptr, nullptr, nullptr};
-    size_t dchunk_points = 0;
-    int slots = 4;             // slots in use (FCAMD_HOST_SLOTS, 1..kSlots)
-    int64_t chunk_points = 0;  // points per chunk (FCAMD_HOST_CHUNK), 0 = default
-    // page-locked caller ranges: host base -> {bytes, address the GPU sees the base at}
-    struct Pinned {
-        size_t bytes;
-        char* dev;
-    };
-    std::map<char*, Pinned> registered;
-    int last_host_mode = 0;  // FCAMD_HOST_ZERO_COPY_* flags of the last host-entry call
-    int zero_copy = -1;  // -1: not read yet; FCAMD_ZERO_COPY=0 keeps registered arrays on the staged path
-};
-
-struct fcamd_model {
-    fcamd_context* ctx = nullptr;
-    int law = 0;
-    int constraint = FCAMD_FULL;
-    Dims dims{9, 6, 3};
-    LawInfo info{};
-    double params[8] = {0};
-    unsigned long long* d_counters = nullptr;  // [4] device
-    unsigned long long* h_counters = nullptr;  // [4] pinned host
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    int grid_auto = 0;
-};
-
 namespace {
 
-// Fill scalars and tables of `args` for one call (del_t enters the SLS constants).
-void fill_constants(const fcamd_model* m, double del_t, EvalArgs* a) {
-    Scalars& sc = a->sc;
-    Tables& tb = a->tb;
+// Scalars and tables of the law for one del_t (del_t enters the SLS constants only).
+void fill_constants(const fcamd_model* m, double del_t, Scalars& sc, Tables& tb) {
     std::memset(&sc, 0, sizeof(sc));
     std::memset(&tb, 0, sizeof(tb));
     const double* p = m->params;
@@ -362,12 +298,49 @@ double* mapped(const fcamd_context* c, const void* p, size_t bytes) {
     return aligned16(d) ? reinterpret_cast<double*>(d) : nullptr;
 }
 
-bool zero_copy_enabled(fcamd_context* c) {
-    if (c->zero_copy < 0) {
-        const char* e = getenv("FCAMD_ZERO_COPY");
-        c->zero_copy = (e && atoi(e) == 0) ? 0 : 1;
+bool zero_copy_enabled(const fcamd_context* c) { return c->opt.zero_copy != 0; }
+
+// FCAMD_* environment defaults of a new context: read here, once, never on the launch path
+void options_from_env(Options* o) {
+    auto geti = [](const char* name, long long dflt) {
+        const char* e = getenv(name);
+        return (e && *e) ? atoll(e) : dflt;
+    };
+    o->tile_map = (int)geti("FCAMD_TILE_MAP", 0);
+    o->masked_max = (int)geti("FCAMD_MASKED_MAX", -1);
+    o->nontemporal = geti("FCAMD_NT", 1) != 0;
+    o->host_chunk = geti("FCAMD_HOST_CHUNK", 0);
+    o->host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, geti("FCAMD_HOST_SLOTS", fcamd_context::kSlots)));
+    o->zero_copy = geti("FCAMD_ZERO_COPY", 1) != 0;
+    o->zero_copy_grad = geti("FCAMD_ZERO_COPY_GRAD", 1) != 0;
+}
+
+// the law's host constants, recomputed only when del_t changes (SLS) -- not once per launch
+void constants_for(fcamd_model* m, double del_t) {
+    if (m->const_valid && (m->const_del_t == del_t || !m->info.needs_del_t)) return;
+    fill_constants(m, del_t, m->sc, m->tb);
+    m->const_del_t = del_t;
+    m->const_valid = true;
+}
+
+bool law_counts(int law) { return law == FCAMD_VON_MISES_3D || law >= FCAMD_COMFE_MISES_PLASTICITY; }
+
+// HIP-event bracket of the device entries (fcamd_context_set_timing; the analogue of the reference's
+// Timer("constitutive-law-evaluation") around the hot call, solver/_lawonsubmesh.py:86).  The counters
+// are reset before the timed window so that the events bracket the kernel(s) only.
+int timing_begin(fcamd_model* m) {
+    fcamd_context* c = m->ctx;
+    m->timed = c->timing;
+    m->host_ms = -1.0f;
+    if (m->timed) {
+        if (law_counts(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->stream));
+        HIP_TRY(hipEventRecord(m->ev0, c->stream));
     }
-    return c->zero_copy == 1;
+    return FCAMD_OK;
+}
+int timing_end(fcamd_model* m) {
+    if (m->timed) HIP_TRY(hipEventRecord(m->ev1, m->ctx->stream));
+    return FCAMD_OK;
 }
 
 int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* grad,
@@ -409,7 +382,8 @@ int grid_for(fcamd_model* m, int64_t n) {
 int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
             double* stress, double* tangent, const double* const* hprev, double* const* hcur,
             hipStream_t stream, bool reset_counters, const int* rows = nullptr,
-            unsigned long long* hmask = nullptr, int flags = 0, double* stress2 = nullptr) {
+            unsigned long long* hmask = nullptr, int flags = 0, double* stress2 = nullptr,
+            unsigned long long* counters = nullptr) {
     EvalArgs a;
     a.grad = grad;
     a.stress_in = stress_prev;
@@ -425,18 +399,17 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.hmask = hmask;
     a.flags = (hmask && tangent) ? flags : 0;
     a.n = n;
-    a.counters = m->d_counters;
-    {
-        const char* e = getenv("FCAMD_TILE_MAP");
-        const int tm = e ? atoi(e) : 0;
-        a.tile_map = tm;
-        const char* mm = getenv("FCAMD_MASKED_MAX");  // experiments (tools/masked_threshold_probe.py)
-        a.masked_max = mm ? atoi(mm) : (m->law == FCAMD_VON_MISES_3D ? kMaskedRowMaxVonMises : kMaskedRowMaxRows7);
-    }
-    fill_constants(m, del_t, &a);
+    a.counters = counters ? counters : m->d_counters;  // caller-owned counters are always reset here
+    const Options& o = m->ctx->opt;
+    a.tile_map = o.tile_map;
+    a.nontemporal = o.nontemporal;
+    a.masked_max = o.masked_max >= 0 ? o.masked_max
+                                     : (m->law == FCAMD_VON_MISES_3D ? kMaskedRowMaxVonMises : kMaskedRowMaxRows7);
+    constants_for(m, del_t);
+    a.sc = m->sc;
+    a.tb = m->tb;
     // only the plasticity laws count anything: skip the extra launch for the others
-    const bool counts = (m->law == FCAMD_VON_MISES_3D || m->law >= FCAMD_COMFE_MISES_PLASTICITY);
-    if (reset_counters && counts) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, stream));
+    if ((reset_counters || counters) && law_counts(m->law)) HIP_TRY(hipMemsetAsync(a.counters, 0, kCounterBytes, stream));
     if (n == 0) return FCAMD_OK;
     const int grid = grid_for(m, n);
     // the launchers report hipGetLastError(): drop whatever an earlier, unrelated call of this thread
@@ -472,15 +445,12 @@ int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
 // device buffers, and large chunks (2 Mi points: 472 instead of 404 Mpts/s for the resident pass).
 int prepare_chunks(fcamd_context* c, const void* probe_host_ptr, int64_t n, int64_t* chunk_out, bool staging = true) {
     {
-        const char* e = getenv("FCAMD_HOST_CHUNK");
         const bool pinned = mapped(c, probe_host_ptr, 8) != nullptr ||
                             c->registered.count(static_cast<char*>(const_cast<void*>(probe_host_ptr))) != 0;
-        c->chunk_points = e ? std::max<int64_t>(64, (atoll(e) / 64) * 64)
-                            : (!staging ? (1 << 21) : (pinned ? (1 << 17) : (1 << 19)));
-        const char* sl = getenv("FCAMD_HOST_SLOTS");
-        if (sl) c->slots = std::min(fcamd_context::kSlots, std::max(1, atoi(sl)));
+        c->chunk_points = c->opt.host_chunk > 0 ? std::max<int64_t>(64, (c->opt.host_chunk / 64) * 64)
+                                                : (!staging ? (1 << 21) : (pinned ? (1 << 17) : (1 << 19)));
     }
-    const int nslots = c->slots;
+    const int nslots = c->opt.host_slots;
     const int64_t chunk = std::min<int64_t>(c->chunk_points, ((n + 63) / 64) * 64);
     if (staging && chunk > 0 && ((size_t)chunk > c->dchunk_points || !c->dchunk[nslots - 1])) {
         for (int i = 0; i < fcamd_context::kSlots; ++i) {
@@ -501,7 +471,7 @@ int prepare_chunks(fcamd_context* c, const void* probe_host_ptr, int64_t n, int6
 // wait for all chunk streams, read the counters, map them to the reference's error conventions
 int finish_chunks(fcamd_model* m, fcamd_stats* stats) {
     fcamd_context* c = m->ctx;
-    for (int i = 0; i < c->slots; ++i)
+    for (int i = 0; i < fcamd_context::kSlots; ++i)
         if (c->hstream[i]) HIP_TRY(hipStreamSynchronize(c->hstream[i]));
     fcamd_stats local;
     int st = read_stats(m, c->hstream[0], &local);
@@ -551,27 +521,92 @@ int fcamd_context_create(int device, void* stream, fcamd_context** out) {
     fcamd_context* c = new (std::nothrow) fcamd_context();
     if (!c) return fail(FCAMD_ERR_BAD_ARG, "out of host memory");
     c->device = device;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (stream) {
-        c->stream = static_cast<hipStream_t>(stream);
-    } else {
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->owns_stream = true;
+    options_from_env(&c->opt);
+    const int st = [&]() -> int {  // any failure below must not leak the context
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (stream) {
+            c->stream = static_cast<hipStream_t>(stream);
+        } else {
+            HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->owns_stream = true;
+        }
+        return FCAMD_OK;
+    }();
+    if (st != FCAMD_OK) {
+        delete c;
+        return st;
     }
     *out = c;
+    return FCAMD_OK;
+}
+
+// release the staging buffers of the pageable host path (up to 4 slots x 512 Ki points x 66 doubles)
+static void free_staging(fcamd_context* c) {
+    for (int i = 0; i < fcamd_context::kSlots; ++i) {
+        if (c->dchunk[i]) (void)hipFree(c->dchunk[i]);
+        c->dchunk[i] = nullptr;
+    }
+    c->dchunk_points = 0;
+}
+
+int fcamd_context_trim(fcamd_context* c) {
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < fcamd_context::kSlots; ++i)
+        if (c->hstream[i]) HIP_TRY(hipStreamSynchronize(c->hstream[i]));
+    free_staging(c);
+    return FCAMD_OK;
+}
+
+int fcamd_context_set_option(fcamd_context* c, const char* name, long long value) {
+    if (!c || !name) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    const std::string k(name);
+    Options& o = c->opt;
+    if (k == "tile_map") o.tile_map = (int)value;
+    else if (k == "masked_max") o.masked_max = (int)value;
+    else if (k == "nontemporal") o.nontemporal = value != 0;
+    else if (k == "host_chunk") o.host_chunk = value;
+    else if (k == "host_slots") o.host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, value));
+    else if (k == "zero_copy") o.zero_copy = value != 0;
+    else if (k == "zero_copy_grad") o.zero_copy_grad = value != 0;
+    else return fail(FCAMD_ERR_BAD_ARG, "unknown option '%s'", name);
+    return FCAMD_OK;
+}
+
+int fcamd_context_get_option(fcamd_context* c, const char* name, long long* value) {
+    if (!c || !name || !value) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    const std::string k(name);
+    const Options& o = c->opt;
+    if (k == "tile_map") *value = o.tile_map;
+    else if (k == "masked_max") *value = o.masked_max;
+    else if (k == "nontemporal") *value = o.nontemporal;
+    else if (k == "host_chunk") *value = o.host_chunk;
+    else if (k == "host_slots") *value = o.host_slots;
+    else if (k == "zero_copy") *value = o.zero_copy;
+    else if (k == "zero_copy_grad") *value = o.zero_copy_grad;
+    else return fail(FCAMD_ERR_BAD_ARG, "unknown option '%s'", name);
     return FCAMD_OK;
 }
 
 int fcamd_context_destroy(fcamd_context* c) {
     if (!c) return FCAMD_OK;
     (void)hipSetDevice(c->device);
-    for (auto& kv : c->registered) (void)hipHostUnregister(kv.first);  // best effort
-    for (int i = 0; i < fcamd_context::kSlots; ++i) {
-        if (c->dchunk[i]) (void)hipFree(c->dchunk[i]);
-        if (c->hstream[i]) (void)hipStreamDestroy(c->hstream[i]);
+    {
+        std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+        for (auto& kv : c->registered) (void)hipHostUnregister(kv.first);  // best effort
+        c->registered.clear();
     }
+    free_staging(c);
+    for (int i = 0; i < fcamd_context::kSlots; ++i)
+        if (c->hstream[i]) (void)hipStreamDestroy(c->hstream[i]);
+    for (hipStream_t s : c->peer_streams)
+        if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : c->peer_events)
+        if (e) (void)hipEventDestroy(e);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FCAMD_OK;
@@ -674,6 +709,19 @@ int fcamd_model_history_field(const fcamd_model* m, int k, const char** name, in
     return FCAMD_OK;
 }
 
+int fcamd_model_constraint(const fcamd_model* m, int* constraint) {
+    if (!m || !constraint) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    *constraint = m->constraint;
+    return FCAMD_OK;
+}
+
+int fcamd_model_dims(const fcamd_model* m, int* stress_strain_dim, int* geometric_dim) {
+    if (!m || !stress_strain_dim || !geometric_dim) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    *stress_strain_dim = m->dims.sd;
+    *geometric_dim = m->dims.gdim;
+    return FCAMD_OK;
+}
+
 int fcamd_evaluate_device_from(fcamd_model* m, double t, double del_t, int64_t n,
                                const double* grad, const double* stress_prev, double* stress,
                                double* tangent, const double* const* hist_prev,
@@ -690,17 +738,11 @@ int fcamd_evaluate_device_from(fcamd_model* m, double t, double del_t, int64_t n
             return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
     fcamd_context* c = m->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    m->timed = c->timing;
-    if (m->timed) {
-        // counters are reset before the timed window so that the events bracket the kernel only
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->stream));
-        HIP_TRY(hipEventRecord(m->ev0, c->stream));
-    }
+    if ((st = timing_begin(m)) != FCAMD_OK) return st;
     st = enqueue(m, del_t, n, grad, stress_prev, stress, tangent, hist_prev, hist, c->stream,
                  !m->timed);
     if (st != FCAMD_OK) return st;
-    if (m->timed) HIP_TRY(hipEventRecord(m->ev1, c->stream));
-    return FCAMD_OK;
+    return timing_end(m);
 }
 
 int fcamd_evaluate_device_indexed(fcamd_model* m, double t, double del_t, int64_t n,
@@ -723,9 +765,11 @@ int fcamd_evaluate_device_indexed(fcamd_model* m, double t, double del_t, int64_
             return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
     fcamd_context* c = m->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    m->timed = false;
-    return enqueue(m, del_t, n, grad, stress_prev_parent, stress_parent, tangent_parent, hist_prev, hist,
-                   c->stream, true, parent_rows);
+    if ((st = timing_begin(m)) != FCAMD_OK) return st;
+    st = enqueue(m, del_t, n, grad, stress_prev_parent, stress_parent, tangent_parent, hist_prev, hist,
+                 c->stream, !m->timed, parent_rows);
+    if (st != FCAMD_OK) return st;
+    return timing_end(m);
 }
 
 int fcamd_evaluate_device_from_sparse(fcamd_model* m, double t, double del_t, int64_t n,
@@ -747,9 +791,11 @@ int fcamd_evaluate_device_from_sparse(fcamd_model* m, double t, double del_t, in
             return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
     fcamd_context* c = m->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    m->timed = false;
-    return enqueue(m, del_t, n, grad, stress_prev, stress, tangent, hist_prev, hist, c->stream, true, nullptr,
-                   reinterpret_cast<unsigned long long*>(history_mask));
+    if ((st = timing_begin(m)) != FCAMD_OK) return st;
+    st = enqueue(m, del_t, n, grad, stress_prev, stress, tangent, hist_prev, hist, c->stream, !m->timed, nullptr,
+                 reinterpret_cast<unsigned long long*>(history_mask));
+    if (st != FCAMD_OK) return st;
+    return timing_end(m);
 }
 
 int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, const fcamd_eval_args* x) {
@@ -772,11 +818,13 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
             return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
     fcamd_context* c = m->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    m->timed = false;
     if (!aligned16(x->stress2)) return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
-    return enqueue(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history,
-                   c->stream, true, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask), x->flags,
-                   x->stress2);
+    if ((st = timing_begin(m)) != FCAMD_OK) return st;
+    st = enqueue(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history,
+                 c->stream, !m->timed, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask), x->flags,
+                 x->stress2, reinterpret_cast<unsigned long long*>(x->counters));
+    if (st != FCAMD_OK) return st;
+    return timing_end(m);
 }
 
 int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double t, double del_t, int64_t n,
@@ -800,7 +848,6 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
         if (!aligned16(hist[k])) return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
     fcamd_context* c = m->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    m->timed = false;
     EvalArgs a;
     a.grad = grad_lo;
     a.stress_in = stress_lo;
@@ -815,14 +862,19 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
     a.n = n;
     a.counters = m->d_counters;
     a.tile_map = 0;
+    a.nontemporal = 1;
     a.masked_max = 0;  // the wrapped tile bodies have no row-masked path
     a.flags = 0;
-    fill_constants(m, del_t, &a);
-    HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->stream));
-    if (n == 0) return FCAMD_OK;
-    (void)hipGetLastError();  // as in enqueue()
-    HIP_TRY(launch_evaluate_wrapped(m->law, wrap, a, grid_for(m, n), c->stream));
-    return FCAMD_OK;
+    constants_for(m, del_t);
+    a.sc = m->sc;
+    a.tb = m->tb;
+    if ((st = timing_begin(m)) != FCAMD_OK) return st;
+    if (!m->timed && law_counts(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->stream));
+    if (n > 0) {
+        (void)hipGetLastError();  // as in enqueue()
+        HIP_TRY(launch_evaluate_wrapped(m->law, wrap, a, grid_for(m, n), c->stream));
+    }
+    return timing_end(m);
 }
 
 int fcamd_evaluate_device(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
@@ -839,7 +891,12 @@ int fcamd_model_last_stats(fcamd_model* m, fcamd_stats* stats) {
 
 int fcamd_model_last_kernel_ms(fcamd_model* m, float* ms) {
     if (!m || !ms) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    if (m->host_ms >= 0.0f) {  // the last entry was a (synchronous) host entry: its wall-clock
+        *ms = m->host_ms;
+        return FCAMD_OK;
+    }
     if (!m->timed) return fail(FCAMD_ERR_BAD_ARG, "timing was not enabled for the last launch");
+    HIP_TRY(hipSetDevice(m->ctx->device));
     HIP_TRY(hipEventSynchronize(m->ev1));
     HIP_TRY(hipEventElapsedTime(ms, m->ev0, m->ev1));
     return FCAMD_OK;
@@ -908,6 +965,7 @@ int fcamd_map_rows_device(fcamd_context* c, int64_t n_rows, int row_size, const 
 
 int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
     if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
     HIP_TRY(hipSetDevice(c->device));
     char* base = static_cast<char*>(ptr);
     if (c->registered.count(base)) {
@@ -934,6 +992,7 @@ int fcamd_context_last_host_mode(fcamd_context* c, int* mode) {
 
 int fcamd_host_device_pointer(fcamd_context* c, const void* host_ptr, size_t bytes, void** device_ptr) {
     if (!c || !host_ptr || !device_ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
     double* d = mapped(c, host_ptr, bytes);
     if (!d) return fail(FCAMD_ERR_BAD_ARG, "host range is not inside a registered, mapped buffer (or not 16-byte aligned)");
     *device_ptr = d;
@@ -942,6 +1001,8 @@ int fcamd_host_device_pointer(fcamd_context* c, const void* host_ptr, size_t byt
 
 int fcamd_unregister_host_buffer(fcamd_context* c, void* ptr) {
     if (!c || !ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    // waits for a host entry in progress on another thread (it holds host_mu for the whole synchronous call)
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
     auto it = c->registered.find(static_cast<char*>(ptr));
     if (it == c->registered.end()) return FCAMD_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -949,6 +1010,48 @@ int fcamd_unregister_host_buffer(fcamd_context* c, void* ptr) {
     c->registered.erase(it);
     return FCAMD_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+// A host entry that fails half-way must not return while copies into or out of the CALLER's arrays are
+// still in flight on other chunk streams (the caller may free or reuse them as soon as it sees the error).
+int drain_and_return(fcamd_context* c, int status) {
+    for (int i = 0; i < fcamd_context::kSlots; ++i)
+        if (c->hstream[i]) (void)hipStreamSynchronize(c->hstream[i]);
+    (void)hipGetLastError();
+    return status;
+}
+
+// as HIP_TRY, inside the chunk loops of the host entries
+#define HIP_TRY_DRAIN(c, expr)                                                                          \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            (void)hipGetLastError();                                                                    \
+            return drain_and_return(c, fail(FCAMD_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                                            hipGetErrorString(e_), __FILE__, __LINE__));                \
+        }                                                                                               \
+    } while (0)
+
+// wall-clock of a synchronous host entry, reported by fcamd_model_last_kernel_ms when timing is on
+struct HostTimer {
+    fcamd_model* m;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(fcamd_model* m_) : m(m_), t0(std::chrono::steady_clock::now()) {
+        m->timed = false;
+        m->host_ms = -1.0f;
+    }
+    ~HostTimer() {
+        if (m->ctx->timing)
+            m->host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+}  // namespace
+
+extern "C" {
 
 // Host (ndarray) entry.  Page-locked, mapped caller arrays (fcamd_register_host_buffer): one launch
 // directly on them (zero copy).  Otherwise: chunked H2D -> kernel -> D2H over up to four chunk slots on
@@ -962,6 +1065,8 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
                            reinterpret_cast<const void* const*>(hist), n_hist);
     if (st != FCAMD_OK) return st;
     fcamd_context* c = m->ctx;
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    HostTimer timer(m);
     HIP_TRY(hipSetDevice(c->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
     const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
@@ -990,7 +1095,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
             hipStream_t s = c->hstream[0];
             HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
             st = enqueue(m, del_t, n, z_grad, z_stress, z_stress, z_tan, z_hist, z_hist, s, false);
-            if (st != FCAMD_OK) return st;
+            if (st != FCAMD_OK) return drain_and_return(c, st);
             return finish_chunks(m, stats);
         }
     }
@@ -998,7 +1103,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     int64_t chunk = 0;
     st = prepare_chunks(c, grad, n, &chunk);
     if (st != FCAMD_OK) return st;
-    const int nslots = c->slots;
+    const int nslots = c->opt.host_slots;
 
     HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
     HIP_TRY(hipStreamSynchronize(c->hstream[0]));
@@ -1019,20 +1124,20 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
             // keep 16-byte alignment for odd per-point dimensions (alpha: 1, comfe history: 7)
             if ((reinterpret_cast<uintptr_t>(cur) & 15u) != 0) cur += 1;
         }
-        HIP_TRY(hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_stress, stress + SD * p0, (size_t)np * SD * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY_DRAIN(c, hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY_DRAIN(c, hipMemcpyAsync(d_stress, stress + SD * p0, (size_t)np * SD * sizeof(double), hipMemcpyHostToDevice, s));
         for (int k = 0; k < m->info.n_hist; ++k) {
             const size_t d = (size_t)m->info.hist[k].dim;
-            HIP_TRY(hipMemcpyAsync(d_hist[k], hist[k] + d * p0, (size_t)np * d * sizeof(double), hipMemcpyHostToDevice, s));
+            HIP_TRY_DRAIN(c, hipMemcpyAsync(d_hist[k], hist[k] + d * p0, (size_t)np * d * sizeof(double), hipMemcpyHostToDevice, s));
         }
         st = enqueue(m, del_t, np, d_grad, d_stress, d_stress, tangent ? d_tan : nullptr, d_hist, d_hist, s, false);
-        if (st != FCAMD_OK) return st;
-        HIP_TRY(hipMemcpyAsync(stress + SD * p0, d_stress, (size_t)np * SD * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (st != FCAMD_OK) return drain_and_return(c, st);
+        HIP_TRY_DRAIN(c, hipMemcpyAsync(stress + SD * p0, d_stress, (size_t)np * SD * sizeof(double), hipMemcpyDeviceToHost, s));
         if (tangent)
-            HIP_TRY(hipMemcpyAsync(tangent + TD * p0, d_tan, (size_t)np * TD * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY_DRAIN(c, hipMemcpyAsync(tangent + TD * p0, d_tan, (size_t)np * TD * sizeof(double), hipMemcpyDeviceToHost, s));
         for (int k = 0; k < m->info.n_hist; ++k) {
             const size_t d = (size_t)m->info.hist[k].dim;
-            HIP_TRY(hipMemcpyAsync(hist[k] + d * p0, d_hist[k], (size_t)np * d * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY_DRAIN(c, hipMemcpyAsync(hist[k] + d * p0, d_hist[k], (size_t)np * d * sizeof(double), hipMemcpyDeviceToHost, s));
         }
     }
     return finish_chunks(m, stats);
@@ -1055,13 +1160,14 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
             return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
     fcamd_context* c = m->ctx;
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    HostTimer timer(m);
     HIP_TRY(hipSetDevice(c->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
     HIP_TRY(hipStreamSynchronize(c->stream));  // the state arrays may have work queued on the caller's stream
     const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
     const bool zc = n > 0 && zero_copy_enabled(c);
-    const char* zg = getenv("FCAMD_ZERO_COPY_GRAD");  // experiments: 0 = upload the gradient by DMA even if page-locked
-    const double* z_grad = (zc && !(zg && atoi(zg) == 0)) ? mapped(c, grad, (size_t)n * GD2 * sizeof(double)) : nullptr;
+    const double* z_grad = (zc && c->opt.zero_copy_grad) ? mapped(c, grad, (size_t)n * GD2 * sizeof(double)) : nullptr;
     double* z_tan = (zc && tangent_host) ? mapped(c, tangent_host, (size_t)n * TD * sizeof(double)) : nullptr;
     c->last_host_mode = (z_grad ? FCAMD_HOST_ZERO_COPY_IN : 0) | (z_tan ? FCAMD_HOST_ZERO_COPY_OUT : 0);
     // Everything the pass moves lies in page-locked caller memory and the law is a 3-D one (whose stress
@@ -1074,13 +1180,13 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         st = enqueue(m, del_t, n, z_grad, stress_prev, stress, z_tan, hist_prev, hist, s, false, nullptr,
                      reinterpret_cast<unsigned long long*>(history_mask), flags, z_stress);
-        if (st != FCAMD_OK) return st;
+        if (st != FCAMD_OK) return drain_and_return(c, st);
         return finish_chunks(m, stats);
     }
     int64_t chunk = 0;
     st = prepare_chunks(c, grad, n, &chunk, /*staging=*/!(z_grad && (z_tan || !tangent_host)));
     if (st != FCAMD_OK) return st;
-    const int nslots = c->slots;
+    const int nslots = c->opt.host_slots;
     HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
     HIP_TRY(hipStreamSynchronize(c->hstream[0]));
     int slot = 0;
@@ -1102,18 +1208,18 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         const double* k_grad = z_grad ? z_grad + GD2 * p0 : d_grad;
         double* k_tan = !tangent_host ? nullptr : (z_tan ? z_tan + TD * p0 : d_tan);
         if (!z_grad)
-            HIP_TRY(hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
+            HIP_TRY_DRAIN(c, hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
         st = enqueue(m, del_t, np, k_grad, stress_prev + SD * p0, stress + SD * p0, k_tan,
                      hp, hc, s, false, nullptr,
                      history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
                      z_tan ? flags : 0);  // the staging buffer of a chunk holds no previous tangent: full rows
-        if (st != FCAMD_OK) return st;
+        if (st != FCAMD_OK) return drain_and_return(c, st);
         if (stress_host)
-            HIP_TRY(hipMemcpyAsync(stress_host + SD * p0, stress + SD * p0, (size_t)np * SD * sizeof(double),
-                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY_DRAIN(c, hipMemcpyAsync(stress_host + SD * p0, stress + SD * p0, (size_t)np * SD * sizeof(double),
+                                            hipMemcpyDeviceToHost, s));
         if (tangent_host && !z_tan)
-            HIP_TRY(hipMemcpyAsync(tangent_host + TD * p0, d_tan, (size_t)np * TD * sizeof(double),
-                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY_DRAIN(c, hipMemcpyAsync(tangent_host + TD * p0, d_tan, (size_t)np * TD * sizeof(double),
+                                            hipMemcpyDeviceToHost, s));
     }
     return finish_chunks(m, stats);
 }

@@ -1,0 +1,108 @@
+// Host-side internals shared by the translation units of the C-ABI layer (fcamd_capi.cpp,
+// fcamd_multigpu.cpp, fcamd_memory.cpp): context / model structs, error reporting.
+// Not installed; the public boundary is include/fcamd.h.
+#pragma once
+#include "../../include/fcamd.h"
+
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "fcamd_internal.h"
+
+namespace fcamd {
+
+// thread-local message behind fcamd_last_error(); returns `status`
+int fail(int status, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            (void)hipGetLastError(); /* reported here: do not leave it for a later launch check */ \
+            return ::fcamd::fail(FCAMD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                 __FILE__, __LINE__);                                  \
+        }                                                                              \
+    } while (0)
+
+struct HistField {
+    const char* name;
+    int dim;
+};
+
+struct LawInfo {
+    int n_params;
+    int n_hist;
+    HistField hist[FCAMD_MAX_HISTORY];
+    bool needs_del_t;
+};
+
+struct Dims {
+    int gd2, sd, gdim;
+};
+
+// Launch / data-path knobs of a context.  Defaults come from the FCAMD_* environment variables, read
+// ONCE when the context is created (never on the launch path); fcamd_context_set_option changes them
+// afterwards (experiments: tools/ab_*.py).
+struct Options {
+    int tile_map = 0;          // FCAMD_TILE_MAP      0: tiles round-robin over all waves; 1: one region per XCD
+    int masked_max = -1;       // FCAMD_MASKED_MAX    row-masked history access up to this many touched rows; -1: per-law default
+    int nontemporal = 1;       // FCAMD_NT            non-temporal global accesses of the main kernel
+    long long host_chunk = 0;  // FCAMD_HOST_CHUNK    points per chunk of the staged host entries; 0: automatic
+    int host_slots = 4;        // FCAMD_HOST_SLOTS    chunk slots in flight (1..4)
+    int zero_copy = 1;         // FCAMD_ZERO_COPY     0 keeps page-locked caller arrays on the staged path
+    int zero_copy_grad = 1;    // FCAMD_ZERO_COPY_GRAD 0: fcamd_evaluate_resident uploads the gradient by DMA even if page-locked
+};
+
+}  // namespace fcamd
+
+struct fcamd_context {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int grid_override = 0;
+    bool timing = false;
+    fcamd::Options opt;
+    // host path: kSlots chunk slots, each with its own stream and device buffers
+    static constexpr int kSlots = 4;
+    hipStream_t hstream[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    double* dchunk[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t dchunk_points = 0;
+    int64_t chunk_points = 0;  // points per chunk of the call in progress
+    // page-locked caller ranges: host base -> {bytes, address the GPU sees the base at}
+    struct Pinned {
+        size_t bytes;
+        char* dev;
+    };
+    std::map<char*, Pinned> registered;
+    // Guards `registered` and serialises the host entries with (un)registration: Python's garbage collector
+    // may unregister a buffer from another thread while the owning thread is inside a host call (ctypes
+    // releases the GIL); the unregistration then waits for that call instead of racing it.
+    std::recursive_mutex host_mu;
+    int last_host_mode = 0;  // FCAMD_HOST_ZERO_COPY_* flags of the last host-entry call
+    // direct all-gather (fcamd_multigpu.cpp): one copy stream per peer, created on first use
+    std::vector<hipStream_t> peer_streams;
+    std::vector<hipEvent_t> peer_events;
+};
+
+struct fcamd_model {
+    fcamd_context* ctx = nullptr;
+    int law = 0;
+    int constraint = FCAMD_FULL;
+    fcamd::Dims dims{9, 6, 3};
+    fcamd::LawInfo info{};
+    double params[8] = {0};
+    unsigned long long* d_counters = nullptr;  // [kCounterSlots][4] device
+    unsigned long long* h_counters = nullptr;  // the same, pinned host
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;     // the last entry was bracketed by ev0 / ev1 (device entries) ...
+    float host_ms = -1.0f;  // ... or, host entries: wall-clock of the synchronous call
+    int grid_auto = 0;
+    // host constants of the law for `const_del_t` (fill_constants): recomputed only when del_t changes
+    bool const_valid = false;
+    double const_del_t = 0.0;
+    fcamd::Scalars sc;
+    fcamd::Tables tb;
+};

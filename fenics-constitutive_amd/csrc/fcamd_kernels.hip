@@ -1849,12 +1849,6 @@ __global__ void __launch_bounds__(kBlock)
 // ---------------------------------------------------------------------------------------
 constexpr bool kNT = true;
 
-// Tuning knob for experiments: FCAMD_NT=0 selects plain (temporal) global loads/stores.
-static bool use_nontemporal() {
-    const char* e = getenv("FCAMD_NT");  // re-read per launch: lets tools/ab_probe*.py A/B in one process
-    return !(e && e[0] == '0');
-}
-
 template <int LAW>
 static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream) {
     if constexpr (LAW == LAW_VM3D) {
@@ -1881,7 +1875,7 @@ static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream)
         return hipGetLastError();
     }
     if (args.n >= kWave) {
-        if (use_nontemporal())
+        if (args.nontemporal)  // experiments: Options::nontemporal = 0 selects plain (temporal) accesses
             hipLaunchKernelGGL((evaluate_kernel<LAW, true, false>), dim3(grid), dim3(kBlock), 0, stream, args);
         else
             hipLaunchKernelGGL((evaluate_kernel<LAW, false, false>), dim3(grid), dim3(kBlock), 0, stream, args);

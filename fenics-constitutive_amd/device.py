@@ -71,7 +71,10 @@ class DeviceLaw(IncrSmallStrainModel):
     def __init__(self, parameter_vector, constraint: StressStrainConstraint = None):
         self._constraint = constraint if constraint is not None else StressStrainConstraint.FULL
         self._parameter_vector = [float(p) for p in parameter_vector]
-        self._handles: dict[tuple[int, int], _capi.Model] = {}  # (device, thread) -> C model handle
+        # C model handles, one per (thread, device), in thread-local storage: they are destroyed -- and with
+        # the last of them the thread's context -- when the thread that created them ends
+        self._tls = threading.local()
+        self.n_handles_created = 0
         self.last_stats = None
 
     # -- interface properties --------------------------------------------------------------
@@ -83,12 +86,12 @@ class DeviceLaw(IncrSmallStrainModel):
     def _handle(self, device: int = 0) -> _capi.Model:
         # one C handle per (device, thread): contexts are per thread (staging buffers, streams, the
         # registry of page-locked ranges), so a law object shared by several threads stays thread-compatible
-        key = (device, threading.get_ident())
-        h = self._handles.get(key)
+        handles = self._tls.__dict__.setdefault("handles", {})
+        h = handles.get(device)
         if h is None:
             ctx = _capi.get_context(device)
-            h = self._handles[key] = _capi.Model(ctx, self._model_id, self._constraint.value,
-                                                 self._parameter_vector)
+            h = handles[device] = _capi.Model(ctx, self._model_id, self._constraint.value, self._parameter_vector)
+            self.n_handles_created += 1
         return h
 
     def _history_arrays(self, history):
@@ -105,9 +108,15 @@ class DeviceLaw(IncrSmallStrainModel):
         return [] if hd is None else list(hd.items())
 
     # -- the hot call --------------------------------------------------------------------------
-    def evaluate(self, t, del_t, grad_del_u, stress, tangent, history) -> None:
+    def evaluate(self, t, del_t, grad_del_u, stress, tangent, history, check: bool = False) -> None:
         """``IncrSmallStrainModel.evaluate`` (interfaces.py:82-101): overwrite ``stress``,
-        ``tangent`` and every history array in place."""
+        ``tangent`` and every history array in place.
+
+        NumPy arrays: synchronous, raises the reference's exceptions itself.  Device tensors: the launch is
+        asynchronous on torch's current stream; ``check=True`` synchronises and raises the reference's
+        ``RuntimeError`` on Newton non-convergence right here, as the reference does inside ``evaluate``
+        (mises_plasticity_isotropic_hardening.py:141-143) -- otherwise call ``device_stats()`` (or let
+        ``ResidentState.update()`` do it) before the results are committed."""
         hist = self._history_arrays(history)
         gd2 = self.geometric_dim**2
         sd = self.stress_strain_dim
@@ -121,6 +130,8 @@ class DeviceLaw(IncrSmallStrainModel):
             assert _size(h) == n * dim, f"history '{name}' has the wrong length"
         if _is_torch(grad_del_u):
             self._evaluate_device(t, del_t, n, grad_del_u, stress, tangent, hist)
+            if check:
+                self.device_stats(grad_del_u.device.index or 0)
         else:
             self._evaluate_host(t, del_t, n, grad_del_u, stress, tangent, hist)
 
@@ -193,35 +204,42 @@ class DeviceLaw(IncrSmallStrainModel):
         )
 
     def evaluate_from(self, t, del_t, grad_del_u, stress_prev, stress, tangent, history_prev, history,
-                      history_mask=None, sparse_tangent: bool = False) -> None:
+                      history_mask=None, sparse_tangent: bool = False, counters=None) -> None:
         """Out-of-place device evaluate: read the committed state (``stress_prev``,
         ``history_prev``), write the trial state (``stress``, ``history``).  Fuses the two
         copies the reference makes before every call (solver/_lawonsubmesh.py:58-61,
         solver/_history.py:64-79).  Device tensors only.  ``sparse_tangent`` (with ``history_mask``):
         ``tangent`` holds the tangent of the previous evaluate with this mask; only the rows of plastic /
-        formerly plastic points are rewritten (FCAMD_EVAL_SPARSE_TANGENT, include/fcamd.h)."""
+        formerly plastic points are rewritten (FCAMD_EVAL_SPARSE_TANGENT, include/fcamd.h).  ``counters``:
+        caller-owned int64 device tensor of ``_capi.COUNTER_WORDS`` words that receives this launch's
+        statistics instead of the law's own counters (``fcamd_eval_args.counters``; read it with
+        ``read_counters``)."""
         hist = self._history_arrays(history)
         hprev = self._history_arrays(history_prev)
         gd2, sd = self.geometric_dim**2, self.stress_strain_dim
         n = _size(grad_del_u) // gd2
         assert n == _size(stress) // sd == _size(stress_prev) // sd and (tangent is None or n == _size(tangent) // (sd * sd))
-        if history_mask is None:
+        if history_mask is None and counters is None:
             self._evaluate_device(t, del_t, n, grad_del_u, stress, tangent, hist, stress_prev, hprev)
             return
         # sparse trial history (fcamd_evaluate_device_from_sparse): see ResidentState
         import torch
 
-        assert history_mask.dtype == torch.int64 and history_mask.is_cuda and history_mask.numel() >= (n + 63) // 64
+        if history_mask is not None:
+            assert history_mask.dtype == torch.int64 and history_mask.is_cuda and history_mask.numel() >= (n + 63) // 64
         for x in (grad_del_u, stress, stress_prev):
             _check_torch("array", x)
         dev = grad_del_u.device.index or 0
         m = self._handle(dev)
         m.ctx.set_stream(_current_stream_ptr(dev))
-        if sparse_tangent and tangent is not None:
+        if (sparse_tangent and tangent is not None) or counters is not None:
             m.evaluate_device_ex(
                 t, del_t, n, grad_del_u.data_ptr(), stress_prev.data_ptr(), stress.data_ptr(),
-                _check_torch("tangent", tangent).data_ptr(), [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist],
-                None, history_mask.data_ptr(), _capi.EVAL_SPARSE_TANGENT)
+                None if tangent is None else _check_torch("tangent", tangent).data_ptr(),
+                [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist],
+                None, None if history_mask is None else history_mask.data_ptr(),
+                _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tangent is not None and history_mask is not None) else 0,
+                counters_ptr=_counters_ptr(counters))
             return
         m.evaluate_device_from_sparse(
             t, del_t, n, grad_del_u.data_ptr(), stress_prev.data_ptr(), stress.data_ptr(),
@@ -229,7 +247,8 @@ class DeviceLaw(IncrSmallStrainModel):
             [h.data_ptr() for h in hist], history_mask.data_ptr())
 
     def evaluate_indexed(self, t, del_t, grad_del_u, stress_prev_parent, stress_parent, tangent_parent,
-                         parent_rows, history_prev, history, history_mask=None, sparse_tangent: bool = False) -> None:
+                         parent_rows, history_prev, history, history_mask=None, sparse_tangent: bool = False,
+                         counters=None) -> None:
         """Multi-material form: this law owns ``n = len(parent_rows)`` points whose stress/tangent
         rows live in PARENT arrays at ``parent_rows`` (int32 device tensor).  Reads the committed
         stress from ``stress_prev_parent`` rows, writes stress and tangent into the parent rows;
@@ -252,28 +271,61 @@ class DeviceLaw(IncrSmallStrainModel):
         m = self._handle(dev)
         m.ctx.set_stream(_current_stream_ptr(dev))
         tan_ptr = None if tangent_parent is None else _check_torch("tangent", tangent_parent).data_ptr()
-        if history_mask is None:
+        if history_mask is None and counters is None:
             m.evaluate_device_indexed(
                 t, del_t, n, grad_del_u.data_ptr(), stress_prev_parent.data_ptr(), stress_parent.data_ptr(),
                 tan_ptr, parent_rows.data_ptr(), [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist])
             return
         # sparse trial history on a submesh (fcamd_evaluate_device_ex): mask and history are local to the law
-        assert history_mask.dtype == torch.int64 and history_mask.is_cuda and history_mask.numel() >= (n + 63) // 64
+        if history_mask is not None:
+            assert history_mask.dtype == torch.int64 and history_mask.is_cuda and history_mask.numel() >= (n + 63) // 64
         m.evaluate_device_ex(
             t, del_t, n, grad_del_u.data_ptr(), stress_prev_parent.data_ptr(), stress_parent.data_ptr(), tan_ptr,
-            [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist], parent_rows.data_ptr(), history_mask.data_ptr(),
-            _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tan_ptr is not None) else 0)
+            [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist], parent_rows.data_ptr(),
+            None if history_mask is None else history_mask.data_ptr(),
+            _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tan_ptr is not None and history_mask is not None) else 0,
+            counters_ptr=_counters_ptr(counters))
+
+    def raise_for_stats(self, st) -> None:
+        """The reference's errors for the counters of a finished launch: the Drucker-Prager tip
+        (drucker_prager_classic.rs:82) and Newton non-convergence (general.rs:186 resp.
+        mises_plasticity_isotropic_hardening.py:141-143; same messages as the host entries)."""
+        if getattr(st, "n_domain", 0):
+            raise RuntimeError("non-differentiable tip of Drucker-Prager surface reached")
+        if st.n_nonconverged:
+            raise RuntimeError("Plasticity3D: Newton-Raphson did not converge." if self._model_id >= _capi.COMFE_DRUCKER_PRAGER
+                               else "Newton-Raphson method did not converge for plastic multiplier.")
 
     def device_stats(self, device: int = 0):
         """Synchronise and return the counters of the last device-path launch; raises
         RuntimeError like the reference if a Newton iteration did not converge."""
         st = self._handle(device).last_stats()
         self.last_stats = st
-        if getattr(st, "n_domain", 0):
-            raise RuntimeError("non-differentiable tip of Drucker-Prager surface reached")
-        if st.n_nonconverged:
-            raise RuntimeError("Newton-Raphson method did not converge for plastic multiplier.")
+        self.raise_for_stats(st)
         return st
+
+
+def _counters_ptr(counters):
+    if counters is None:
+        return None
+    import torch
+
+    assert counters.dtype == torch.int64 and counters.is_cuda and counters.is_contiguous() and \
+        counters.numel() >= _capi.COUNTER_WORDS, "counters: contiguous int64 device tensor of COUNTER_WORDS words"
+    return counters.data_ptr()
+
+
+def new_counters(device):
+    """Caller-owned counter buffer for ``evaluate_from`` / ``evaluate_indexed`` (``fcamd_eval_args.counters``)."""
+    import torch
+
+    return torch.zeros(_capi.COUNTER_WORDS, dtype=torch.int64, device=device)
+
+
+def read_counters(counters) -> "_capi.Stats":
+    """Synchronise with the launches that wrote ``counters`` (on the current stream) and sum the slots."""
+    c = counters[: _capi.COUNTER_WORDS].cpu().view(_capi.COUNTER_SLOTS, 4).sum(dim=0).tolist()
+    return _capi.Stats(int(c[0]), int(c[1]), int(c[2]), int(c[3]))
 
 
 def _size(a) -> int:

@@ -97,11 +97,11 @@ class _SpringBase(DeviceLaw):
     def history_dim(self) -> dict[str, int]:
         return {"strain_visco": self.stress_strain_dim, "strain": self.stress_strain_dim}
 
-    def evaluate(self, t, del_t, grad_del_u, stress, tangent, history) -> None:
+    def evaluate(self, t, del_t, grad_del_u, stress, tangent, history, check: bool = False) -> None:
         if history is None:
             raise ValueError("history must not be None")
         assert del_t > 0, "Time step must be defined and positive."
-        super().evaluate(t, del_t, grad_del_u, stress, tangent, history)
+        super().evaluate(t, del_t, grad_del_u, stress, tangent, history, check=check)
 
 
 class SpringMaxwellModel(_SpringBase):

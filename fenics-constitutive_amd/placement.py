@@ -13,7 +13,7 @@ same arrays for thousands of Newton iterations this costs a few launches once.
 
 from __future__ import annotations
 
-__all__ = ["fastest_allocation"]
+__all__ = ["fastest_allocation", "max_tries_for_memory", "VmmArraySet", "tensor_from_pointer"]
 
 
 def fastest_allocation(numel: int, probe, tries: int = 4, device=None, first=None, launches: int = 3):
@@ -34,11 +34,13 @@ def fastest_allocation(numel: int, probe, tries: int = 4, device=None, first=Non
             t = first
         else:
             free, _ = torch.cuda.mem_get_info(dev)
-            if k > 0 and free < 8 * numel + (2 << 30):
+            if cands and free < 8 * numel + (2 << 30):
                 break
             try:
                 t = torch.empty(numel, dtype=torch.float64, device=dev)
             except torch.OutOfMemoryError:
+                if not cands:
+                    raise  # not even one array fits: that is the caller's out-of-memory, not a tuning result
                 break
         probe(t)  # warm
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
@@ -54,3 +56,62 @@ def fastest_allocation(numel: int, probe, tries: int = 4, device=None, first=Non
     del cands, t
     torch.cuda.empty_cache()
     return out, {"candidate_ms": [round(x, 4) for x in times], "chosen": best}
+
+
+def max_tries_for_memory(numel: int, tries: int, device=None, reserve_bytes: int = 8 << 30) -> int:
+    """Largest number of candidates (<= ``tries``) whose simultaneous allocation leaves ``reserve_bytes`` of the
+    device free -- the candidates are alive together while they are timed.  Used where the working set is
+    sized against the whole device (``bench.py --gpus N`` next to the gather buffers)."""
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    free, _ = torch.cuda.mem_get_info(dev)
+    fit = int(max(free - reserve_bytes, 0) // (8 * numel))
+    return max(1, min(int(tries), 1 + fit))  # candidate 0 is the array that exists already
+
+
+
+class _RawDeviceArray:
+    """Minimal ``__cuda_array_interface__`` carrier: lets torch wrap device memory it did not allocate."""
+
+    def __init__(self, ptr: int, numel: int, typestr: str = "<f8"):
+        self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def tensor_from_pointer(ptr: int, numel: int, device, dtype_str: str = "<f8"):
+    """float64 device tensor over ``numel`` doubles at ``ptr`` (no copy, no ownership: the memory must
+    outlive the tensor)."""
+    import torch
+
+    return torch.as_tensor(_RawDeviceArray(ptr, numel, dtype_str), device=torch.device(device))
+
+
+class VmmArraySet:
+    """A working set placed through the virtual-memory API (``fcamd_device_alloc_set``): one float64 array
+    per entry of ``numels`` (name -> element count), physical handles of ``granule`` bytes created array
+    after array or interleaved over all arrays.  ``set[name]`` is a torch view of the array; ``free()``
+    releases the memory (drop the views first).  The experiment behind it: DESIGN.md 6, "VMM placement"."""
+
+    def __init__(self, ctx, numels: dict, granule: int = 0, interleaved: bool = True, device=None):
+        import torch
+
+        self.ctx = ctx
+        self.device = torch.device("cuda", ctx.device) if device is None else torch.device(device)
+        self.names = list(numels)
+        self.numels = {k: int(v) for k, v in numels.items()}
+        self.ptrs = dict(zip(self.names, ctx.alloc_set([8 * self.numels[k] for k in self.names], granule, interleaved)))
+
+    def __getitem__(self, name):
+        return tensor_from_pointer(self.ptrs[name], self.numels[name], self.device)
+
+    def free(self) -> None:
+        for k, p in list(self.ptrs.items()):
+            self.ctx.free(p)
+            del self.ptrs[k]
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -53,7 +53,13 @@ class _LawState:
         # sparse tangent (see ResidentState): the array that received this law's previous tangent --
         # "dev" (the state's device array) or the address of the host assembler's parent array
         self.tangent_target = None
-        self.host_tangent_key = None  # constant-tangent laws: (host address, del_t) the host array is valid for
+        self.host_tangent_key = None  # constant-tangent laws: (host address, bytes, del_t) the host array is valid for
+        # the state's own counters of this law's launches (see ResidentState): read before every commit
+        from .device import new_counters
+
+        self.counters = new_counters(device) if self.mask is not None or type(law).__name__ in (
+            "VonMises3D", "MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D") else None
+        self.stats_pending = False
 
 
 class ResidentProblemState:
@@ -61,8 +67,12 @@ class ResidentProblemState:
     ``rows`` the quadrature-point rows of that law in the parent arrays (disjoint; see
     ``rows_of_cells``).  All laws are FULL 3-D, as the fused indexed kernel requires."""
 
+    #: device-assembler mode: tune the placement of the parent tangent array on the first ``evaluate`` when it
+    #: is at least this large (see ResidentState)
+    AUTO_TUNE_MIN_BYTES = 256 << 20
+
     def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None, reuse_constant_tangent: bool = True,
-                 sparse_history: bool = True, sparse_tangent: bool = True):
+                 sparse_history: bool = True, sparse_tangent: bool = True, auto_tune_placement: bool = True):
         import torch
 
         from . import _capi
@@ -95,6 +105,12 @@ class ResidentProblemState:
         self._evaluated = False
         self.reuse_constant_tangent = reuse_constant_tangent
         self.sparse_tangent = sparse_tangent
+        self._failed = None  # the error of the last evaluate, if it raised: nothing to commit
+        # placement of the parent tangent array: tuned on the first device-assembler evaluate unless every
+        # law writes its tangent rows only once per del_t
+        self._auto_tune = bool(auto_tune_placement) and not (
+            reuse_constant_tangent and all(ls.const_tangent for ls in self._laws))
+        self.placement = None
 
     @property
     def tangent(self):
@@ -145,6 +161,9 @@ class ResidentProblemState:
                 if ls.mask is not None:
                     ls.mask.zero_()
                 ls.tangent_target = None  # the mask no longer remembers which rows hold plastic tangents
+        for ls in self._laws:
+            ls.stats_pending = False
+        self._failed = None
 
     # the Newton-iteration call (IncrSmallStrainProblem.form, solver/_solver.py:130-147) ------------------
     def evaluate(self, grads) -> None:
@@ -155,6 +174,10 @@ class ResidentProblemState:
         if not isinstance(grads, (list, tuple)):
             grads = [grads]
         assert len(grads) == len(self._laws), "one gradient array per law"
+        if self._auto_tune and 8 * 36 * self.n >= self.AUTO_TUNE_MIN_BYTES:
+            self.tune_placement(grads)  # ends with the evaluate of this call
+            return
+        self._failed = None
         for ls, g in zip(self._laws, grads):
             if not _is_torch(g):
                 if ls.grad is None:
@@ -164,19 +187,23 @@ class ResidentProblemState:
             hp = None if ls.hist is None else ls.hist[self._c]
             hc = None if ls.hist is None else ls.hist[1 - self._c]
             tangent = self.tangent
+            key = None
             if ls.const_tangent and self.reuse_constant_tangent:
                 key = self._del_t if type(ls.law).__name__.startswith("Spring") else 0.0
                 if ls.tangent_key == key:
                     tangent = None
-                ls.tangent_key = key
+                ls.tangent_key = None  # valid again only once the launch below has been enqueued
             st = self.sparse_tangent and ls.mask is not None and ls.tangent_target == "dev"
+            ls.tangent_target = None
             if ls.rows is None:
                 ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent, hp, hc,
-                                     history_mask=ls.mask, sparse_tangent=st)
+                                     history_mask=ls.mask, sparse_tangent=st, counters=ls.counters)
             else:
                 ls.law.evaluate_indexed(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent,
-                                        ls.rows, hp, hc, history_mask=ls.mask, sparse_tangent=st)
+                                        ls.rows, hp, hc, history_mask=ls.mask, sparse_tangent=st, counters=ls.counters)
+            ls.tangent_key = key
             ls.tangent_target = "dev"
+            ls.stats_pending = ls.counters is not None
         self._evaluated = True
 
     # the host assembler's Newton-iteration call, law by law (LawOnSubMesh.evaluate, solver/_lawonsubmesh.py:72-95)
@@ -223,23 +250,29 @@ class ResidentProblemState:
                 ls.grad = torch.empty(9 * ls.n, **self._f)
             ls.grad.copy_(torch.from_numpy(grad_del_u), non_blocking=True)
             gptr = ls.grad.data_ptr()
-        flags, target = 0, None if tptr is None else ("host", tptr)
+        flags, target = 0, None if tptr is None else ("host", tptr, tangent_parent.nbytes)
+        key = None
         if tptr is not None and ls.const_tangent and self.reuse_constant_tangent:
-            key = (tptr, self._del_t if type(ls.law).__name__.startswith("Spring") else 0.0)
+            key = (tptr, tangent_parent.nbytes, self._del_t if type(ls.law).__name__.startswith("Spring") else 0.0)
             if ls.host_tangent_key == key:
                 tptr = None  # the parent array already holds this law's rows
-            ls.host_tangent_key = key
+            ls.host_tangent_key = None  # valid again only once the launch below has been enqueued
         elif tptr is not None and self.sparse_tangent and ls.mask is not None and ls.tangent_target == target:
             flags = _capi.EVAL_SPARSE_TANGENT
         hp = [] if ls.hist is None else [ls.hist[self._c][name].data_ptr() for name, _ in m.history_fields]
         hc = [] if ls.hist is None else [ls.hist[1 - self._c][name].data_ptr() for name, _ in m.history_fields]
         ls.tangent_target = None
+        self._failed = None
+        self._evaluated = True  # the trial state is touched even if the launch fails
         m.evaluate_device_ex(self._time, self._del_t, ls.n, gptr, self.stress_0.data_ptr(), self.stress_1.data_ptr(), tptr,
                              hp, hc, None if ls.rows is None else ls.rows.data_ptr(),
-                             None if ls.mask is None else ls.mask.data_ptr(), flags, stress2_ptr=sptr)
+                             None if ls.mask is None else ls.mask.data_ptr(), flags, stress2_ptr=sptr,
+                             counters_ptr=None if ls.counters is None else ls.counters.data_ptr())
+        ls.host_tangent_key = key
         ls.tangent_target = target
-        self._host_refs = (stress_parent, tangent_parent)  # identified by address above: keep them alive
-        self._evaluated = True
+        ls.stats_pending = ls.counters is not None
+        # the arrays of every law are identified by address above: keep them alive
+        self.__dict__.setdefault("_host_refs", {})[k] = (stress_parent, tangent_parent)
         if sync:
             self.check()
 
@@ -254,16 +287,18 @@ class ResidentProblemState:
         hc = None if ls.hist is None else ls.hist[1 - self._c]
         ls.tangent_key = ls.host_tangent_key = None
         ls.tangent_target = None
+        self._failed = None
         tan = None if tangent_parent is None else self.tangent
+        ls.stats_pending = ls.counters is not None
         if ls.rows is None:
             ls.law.evaluate_from(self._time, self._del_t, ls.grad, self.stress_0, self.stress_1, tan, hp, hc,
-                                 history_mask=ls.mask)
+                                 history_mask=ls.mask, counters=ls.counters)
             stress_parent[:] = self.stress_1.cpu().numpy()
             if tan is not None:
                 tangent_parent[:] = tan.cpu().numpy()
         else:
             ls.law.evaluate_indexed(self._time, self._del_t, ls.grad, self.stress_0, self.stress_1, tan, ls.rows, hp, hc,
-                                    history_mask=ls.mask)
+                                    history_mask=ls.mask, counters=ls.counters)
             rows = ls.rows.long()
             rows_h = rows.cpu().numpy()
             stress_parent.reshape(-1, 6)[rows_h] = self.stress_1.view(-1, 6)[rows].cpu().numpy()
@@ -279,6 +314,8 @@ class ResidentProblemState:
         leaves a valid trial state for ``grads``."""
         from .placement import fastest_allocation
 
+        self._auto_tune = False
+
         def probe(tan):
             self.tangent = tan
             for ls in self._laws:
@@ -291,18 +328,33 @@ class ResidentProblemState:
         del first
         chosen.zero_()  # rows of points that belong to no law stay zero, as in a freshly built state
         probe(chosen)
+        self.placement = info
         return info
 
     def check(self) -> None:
-        """Synchronise; raises the reference's exceptions (Newton non-convergence) per law."""
-        dev = self.device.index or 0
+        """Synchronise with the last launches and look at every law's counters (read once per evaluate);
+        raises the reference's exceptions (Newton non-convergence, Drucker-Prager tip) per law."""
+        from .device import read_counters
+
+        if self._failed is not None and not any(ls.stats_pending for ls in self._laws):
+            raise self._failed
         for ls in self._laws:
-            ls.law.device_stats(dev)
+            if not ls.stats_pending:
+                continue
+            ls.law.last_stats = st = read_counters(ls.counters)
+            ls.stats_pending = False
+            try:
+                ls.law.raise_for_stats(st)
+            except RuntimeError as e:
+                self._failed = e
+        if self._failed is not None:
+            raise self._failed
 
     # the commit (IncrSmallStrainProblem.update, solver/_solver.py:149-159) -------------------------------
     def update(self) -> None:
         if not self._evaluated:
             raise RuntimeError("update() before any evaluate() of this increment")
+        self.check()  # a trial state with a non-converged point raises the reference's error instead of being committed
         self._c = 1 - self._c  # stress and every history: trial becomes committed
         self._time += self._del_t
         self._evaluated = False

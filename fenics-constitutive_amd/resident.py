@@ -32,8 +32,12 @@ __all__ = ["ResidentState"]
 
 
 class ResidentState:
+    #: device-assembler mode: tune the placement of the tangent array on the first ``evaluate`` when it
+    #: is at least this large (below, launches are latency-bound and the placement does not show)
+    AUTO_TUNE_MIN_BYTES = 256 << 20
+
     def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
-                 reuse_constant_tangent: bool = True, sparse_tangent: bool = True):
+                 reuse_constant_tangent: bool = True, sparse_tangent: bool = True, auto_tune_placement: bool = True):
         import torch
 
         self.law, self.n = law, int(n)
@@ -82,6 +86,24 @@ class ResidentState:
         self._tangent_target = None
         self._host_tangent_key = None  # (address, bytes, del_t) of the host array that holds the constant tangent
         self._host_tangent_ref = None  # the last host tangent array (kept alive, see evaluate_into)
+        # Non-convergence must not be committed (the reference raises inside evaluate,
+        # mises_plasticity_isotropic_hardening.py:141-143; general.rs:186; the Drucker-Prager tip,
+        # drucker_prager_classic.rs:82).  The device launches are asynchronous, so the state owns the counters
+        # of its launches (fcamd_eval_args.counters: states sharing one law object cannot read each other's)
+        # and update() reads them -- one 2 KB copy -- before it swaps the pointers.
+        self._counts = type(law).__name__ in ("VonMises3D", "MisesPlasticityLinearHardening3D",
+                                              "DruckerPrager3D", "DruckerPragerHyperbolic3D")
+        from .device import new_counters
+
+        self._counters = new_counters(self.device) if self._counts else None
+        self._stats_pending = False  # a device launch whose counters have not been looked at yet
+        self._failed = None          # the error of the last evaluate, if it raised: nothing to commit
+        # Placement of the tangent array: on MI355X the kernel time follows where the driver
+        # puts the dominant write stream, by up to 20 %.  The first device-assembler evaluate therefore times
+        # a few candidate allocations with its own launch and keeps the fastest (tune_placement); laws whose
+        # tangent is written once per del_t have nothing to gain.
+        self._auto_tune = bool(auto_tune_placement) and not self._const_tangent
+        self.placement = None  # candidate timings of the tuning, once it has run
 
     def _as_dev(self, a):
         import torch
@@ -107,6 +129,7 @@ class ResidentState:
     # committed (previous) and trial (current) views -------------------------------------------
     @property
     def stress_committed(self):
+        """Committed stress (live tensor).  To (re)initialise the state use ``set_state``."""
         return self._stress[self._c]
 
     @property
@@ -115,39 +138,75 @@ class ResidentState:
 
     @property
     def history_committed(self):
+        """Committed history (live tensors).  Invariant of the sparse protocol: the trial history equals
+        the committed one wherever the mask is clear -- do not write initial / restart values into these
+        tensors, ``set_state`` writes both copies."""
         return None if self._hist is None else self._hist[self._c]
 
     @property
     def history(self):
         return None if self._hist is None else self._hist[1 - self._c]
 
+    def set_state(self, stress=None, history=None) -> None:
+        """(Re)initialise the committed state -- initial conditions, a restart -- from NumPy arrays or device
+        tensors.  Both copies of the history are written: the sparse trial-history protocol needs trial ==
+        committed wherever the mask is clear, so writing into ``history_committed`` alone would let ``update()``
+        commit stale rows at points that stay elastic.  Every shortcut that refers to earlier evaluates (mask,
+        tangent bookkeeping) is reset."""
+        if stress is not None:
+            self.stress_committed.copy_(self._as_dev(stress))
+        if history is not None and self._hist is not None:
+            for k in self._hist[self._c]:
+                self._hist[self._c][k].copy_(self._as_dev(history[k]))
+                self._hist[1 - self._c][k].copy_(self._hist[self._c][k])
+        if self._mask is not None:
+            self._mask.zero_()
+        self._tangent_target = self._tangent_key = self._host_tangent_key = None
+        self._evaluated = False
+        self._stats_pending = False
+        self._failed = None
+
     # the Newton-iteration call --------------------------------------------------------------------
+    def _launch(self, t, del_t, g, tangent, sparse_tangent=False) -> None:
+        self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, tangent,
+                               self.history_committed, self.history, history_mask=self._mask,
+                               sparse_tangent=sparse_tangent, counters=self._counters)
+
     def evaluate(self, t: float, del_t: float, grad_del_u) -> None:
         """Trial state <- law(committed state, grad_del_u).  May be called any number of times per
-        increment; the committed state is never modified."""
+        increment; the committed state is never modified.  Asynchronous; Newton non-convergence surfaces at
+        ``check()`` / ``update()``."""
         g = grad_del_u
         if not _is_torch(g):
             self.grad.copy_(self._as_dev(g), non_blocking=True)
             g = self.grad
         assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
+        if self._auto_tune and 8 * self._sd * self._sd * self.n >= self.AUTO_TUNE_MIN_BYTES:
+            self.tune_placement(t, del_t, g)  # ends with the evaluate of this call
+            return
         tangent = self.tangent
+        key = None
         if self._const_tangent:
             key = float(del_t) if type(self.law).__name__.startswith("Spring") else 0.0
             if self._tangent_key == key:
                 tangent = None  # already holds exactly what this launch would write
-            self._tangent_key = key
-        self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, tangent,
-                               self.history_committed, self.history, history_mask=self._mask,
-                               sparse_tangent=self._sparse_tangent and self._tangent_target == "dev")
+            self._tangent_key = None  # valid again only once the launch below has been enqueued
+        sparse = self._sparse_tangent and self._tangent_target == "dev"
+        self._tangent_target = None
+        self._failed = None
+        self._launch(t, del_t, g, tangent, sparse)
+        self._tangent_key = key
         self._tangent_target = "dev"
         self._evaluated = True
+        self._stats_pending = self._counts
 
     def tune_placement(self, t: float, del_t: float, grad_del_u, tries: int = 4) -> dict:
         """Device-assembler mode: choose the placement of the tangent array (the dominant write
         stream) by timing this state's own evaluate on a few candidate allocations and keeping the
         fastest (``placement.fastest_allocation``; on MI355X the kernel time follows where the
-        written arrays live, by up to 20 %).  Call once, before the Newton loops; leaves a valid
-        trial state for ``grad_del_u``.  Returns the candidate timings."""
+        written arrays live, by up to 20 %).  Runs by itself on the first ``evaluate`` of a large state
+        (``auto_tune_placement``); leaves a valid trial state for ``grad_del_u``.  Returns the candidate
+        timings (also kept as ``self.placement``)."""
         from .placement import fastest_allocation
 
         g = grad_del_u
@@ -155,15 +214,15 @@ class ResidentState:
             self.grad.copy_(self._as_dev(g), non_blocking=True)
             g = self.grad
         assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
+        self._auto_tune = False
         first, self._tangent = self._tangent, None
+        self._tangent_target = None  # the candidates hold no previous tangent: every probe writes every row
         self._tangent, info = fastest_allocation(
-            self._sd * self._sd * self.n,
-            lambda tan: self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, tan,
-                                               self.history_committed, self.history, history_mask=self._mask),
+            self._sd * self._sd * self.n, lambda tan: self._launch(t, del_t, g, tan),
             tries=tries, device=self.device, first=first)
         del first
         self._tangent_key = None  # a constant tangent has to be written into the chosen array
-        self._tangent_target = None  # ... and every row of a point-dependent one
+        self.placement = info
         self.evaluate(t, del_t, g)
         return info
 
@@ -217,10 +276,16 @@ class ResidentState:
         flags = _capi.EVAL_SPARSE_TANGENT if (self._sparse_tangent and target is not None
                                               and self._tangent_target == target) else 0
         self._tangent_target = None
-        self.law.last_stats = m.evaluate_resident(
-            t, del_t, self.n, grad_del_u.ctypes.data, self.stress_committed.data_ptr(), self.stress.data_ptr(),
-            hp, hc, None if self._mask is None else self._mask.data_ptr(),
-            None if stress is None else stress.ctypes.data, None if tangent is None else tangent.ctypes.data, flags)
+        self._stats_pending = False  # synchronous: the call itself reports
+        try:
+            self.law.last_stats = m.evaluate_resident(
+                t, del_t, self.n, grad_del_u.ctypes.data, self.stress_committed.data_ptr(), self.stress.data_ptr(),
+                hp, hc, None if self._mask is None else self._mask.data_ptr(),
+                None if stress is None else stress.ctypes.data, None if tangent is None else tangent.ctypes.data, flags)
+        except Exception as e:
+            self._failed = e  # the trial state is not fit to be committed: update() raises until a clean evaluate
+            raise
+        self._failed = None
         self._tangent_target = target
         if key is not None and tangent is not None:
             self._host_tangent_key = key
@@ -232,9 +297,13 @@ class ResidentState:
 
     def update(self) -> None:
         """Commit the trial state (``IncrSmallStrainProblem.update``, solver/_solver.py:149-159):
-        a pointer swap."""
+        a pointer swap -- after the counters of the last evaluate have been looked at: a trial state with
+        a non-converged (or out-of-domain) point raises the reference's error instead of being committed."""
         if not self._evaluated:
             raise RuntimeError("update() before any evaluate() of this increment")
+        if self._failed is not None:
+            raise RuntimeError(f"the last evaluate failed, nothing to commit: {self._failed}")
+        self.check()
         self._c = 1 - self._c
         self._evaluated = False
 
@@ -251,5 +320,22 @@ class ResidentState:
                 history[k][:] = self.history[k].cpu().numpy()
 
     def check(self):
-        """Synchronise; raises the reference's RuntimeError on Newton non-convergence."""
-        return self.law.device_stats(self.device.index or 0)
+        """Synchronise with this state's last device evaluate and return its counters; raises the
+        reference's RuntimeError on Newton non-convergence / the Drucker-Prager tip.  Cheap when nothing
+        is pending (the counters are read once per evaluate)."""
+        if self._counters is None:
+            return None
+        if self._stats_pending:
+            from .device import read_counters
+
+            self._stats = read_counters(self._counters)
+            self.law.last_stats = self._stats
+            self._stats_pending = False
+            try:
+                self.law.raise_for_stats(self._stats)
+            except RuntimeError as e:
+                self._failed = e
+                raise
+        elif self._failed is not None:
+            raise self._failed
+        return getattr(self, "_stats", None)

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define FCAMD_VERSION_MAJOR 0
-#define FCAMD_VERSION_MINOR 1
+#define FCAMD_VERSION_MINOR 2
 
 /* ---- status codes (mapped to Python exceptions by the ctypes shim) -------- */
 typedef enum fcamd_status {
@@ -125,6 +125,12 @@ int fcamd_model_destroy(fcamd_model* model);
 int fcamd_model_history_count(const fcamd_model* model, int* n_fields);
 int fcamd_model_history_field(const fcamd_model* model, int k, const char** name, int* dim);
 
+/* The other getters of the reference's native model classes (bindings/src/lib.rs:137-148:
+   `constraint`, `stress_strain_dim`, `geometric_dim` next to `history_dim`; models/interfaces.py:103-131).
+   `constraint` receives an fcamd_constraint value (= StressStrainConstraint value). */
+int fcamd_model_constraint(const fcamd_model* model, int* constraint);
+int fcamd_model_dims(const fcamd_model* model, int* stress_strain_dim, int* geometric_dim);
+
 /* ---- the hot path ------------------------------------------------------------- */
 
 /* Device-resident evaluate (roofline path): all pointers are device pointers, 16-byte
@@ -210,7 +216,16 @@ typedef struct fcamd_eval_args {
     double* stress2;                    /* nullable: second destination of the stress rows, addressed like
                                            `stress` (the host assembler's page-locked array, see
                                            fcamd_host_device_pointer) */
+    uint64_t* counters;                 /* nullable: caller-owned device counters of this launch instead of the
+                                           model's own (FCAMD_COUNTER_WORDS words, reset by the call) -- every
+                                           resident state keeps its own, so that states sharing one model
+                                           handle cannot read each other's non-convergence */
 } fcamd_eval_args;
+/* Layout of a counter buffer: FCAMD_COUNTER_SLOTS slots of 4 words {non-converged points, plastic
+   points, Newton iterations, points outside the law's domain}; the totals (fcamd_stats) are the sums
+   over the slots (waves add to slot = workgroup % slots, which keeps the atomics off one address). */
+#define FCAMD_COUNTER_SLOTS 64
+#define FCAMD_COUNTER_WORDS (4 * FCAMD_COUNTER_SLOTS)
 /* Sparse-tangent protocol (plasticity laws, needs history_mask and a tangent array): the caller owns
    `tangent` across evaluates and it holds the tangent written by the PREVIOUS evaluate with the same
    history_mask (the first one without this flag).  The tangent of an elastic point is one constant for
@@ -318,14 +333,97 @@ int fcamd_context_last_host_mode(fcamd_context* ctx, int* mode);
    PCIe.  The caller synchronises (fcamd_context_synchronize) before the host reads the results. */
 int fcamd_host_device_pointer(fcamd_context* ctx, const void* host_ptr, size_t bytes, void** device_ptr);
 
+/* ---- multi-GPU: contiguous shards + all-gather ------------------------ */
+/* The quadrature-point axis [0, n) is cut into `world` contiguous slices that start on 64-point
+   (wavefront-tile) boundaries and are padded to one common length, the SLOT (fcamd_shard_slot_points):
+   rank r owns [lo, hi) = [min(r*slot, n), min(r*slot + slot, n)); trailing ranks may be empty.  Every
+   array slices by dim*lo.  Evaluation needs no collective and the history stays sharded; the only
+   exchange is the optional all-gather of stress (6/pt) and tangent (36/pt) for ONE assembling process
+   (under dolfinx/MPI every rank assembles its own cells: the reference's only exchange is its ghost
+   forwarding, solver/_solver.py:146-147).  A gathered buffer has world*slot*dim doubles, rank r's slice
+   in slot r; because every rank before the last non-empty one is full, its first dim*n doubles are the
+   global array. */
+int fcamd_shard_slot_points(int64_t n, int world, int64_t* per_rank);
+int fcamd_shard_bounds(int64_t n, int world, int rank, int64_t* lo, int64_t* hi);
+
+/* Chunked gather for shards whose gathered tangent does not fit next to the working set (config 5:
+   8 x 1e8 points = 230 GB of gathered tangent per GPU): the assembler consumes the gathered array chunk
+   by chunk, chunk k = points [k*chunk, (k+1)*chunk) of EVERY rank's slot, through `n_buffers` chunk
+   buffers of world*chunk*values_per_point doubles each (2 = double buffering).  Returns the largest
+   tile-aligned chunk length whose buffers fit into `budget_bytes` (then equalised over the chunks) and
+   the number of chunks; FCAMD_ERR_SIZE if not even one tile per rank fits -- the budget is checked up
+   front, before anything is allocated. */
+int fcamd_gather_chunk_plan(int64_t slot_points, int world, int values_per_point, size_t budget_bytes,
+                            int n_buffers, int64_t* chunk_points, int64_t* n_chunks);
+
+/* One rank per process: a peer's gathered buffer is mapped through HIP IPC.  fcamd_ipc_export gives
+   the handle of the ALLOCATION `device_ptr` lies in plus its offset inside it (the pointer may be a
+   sub-block of a caching allocator, e.g. a torch tensor); the 64 bytes + offset travel to the peers by
+   any host channel (torch.distributed.all_gather_object, MPI); fcamd_ipc_open maps it there.  A mapping
+   is closed with the same offset it was opened with, before the owner frees the memory. */
+#define FCAMD_IPC_HANDLE_BYTES 64
+int fcamd_ipc_export(fcamd_context* ctx, const void* device_ptr, unsigned char handle[FCAMD_IPC_HANDLE_BYTES],
+                     size_t* offset_bytes);
+int fcamd_ipc_open(fcamd_context* ctx, const unsigned char handle[FCAMD_IPC_HANDLE_BYTES], size_t offset_bytes,
+                   void** device_ptr);
+int fcamd_ipc_close(fcamd_context* ctx, void* device_ptr, size_t offset_bytes);
+/* One process driving several GPUs: let the context's device access `peer_device`'s memory directly. */
+int fcamd_enable_peer_access(fcamd_context* ctx, int peer_device);
+
+/* Direct (one-hop) all-gather, in place: `gathered[p]` is the address, in THIS process, of rank p's
+   gathered buffer (own allocation for p == rank; an IPC mapping or an allocation on another device of
+   this process otherwise), `devices[p]` its HIP device ordinal (NULL: all on the context's device or
+   reachable by unified addressing).  Bytes [offset_bytes, offset_bytes + bytes) of a slot of slot_bytes
+   are exchanged (offset / bytes select one chunk of a chunked gather).
+     push (default):    this rank's slot is copied into the same slot of every peer's buffer;
+     FCAMD_GATHER_PULL: every peer's slot is copied from the peer's buffer into this rank's buffer.
+   world-1 copies on world-1 streams, issued in staggered peer order (step s: rank r <-> rank r+s), so
+   the transfers of one GPU leave over different xGMI links at once -- a ring all-gather forwards every
+   slice world-1 times over one link per step.  The copies start after the work queued on the context's
+   stream (the evaluate that produces the slot).  Asynchronous: fcamd_allgather_direct_wait(host_sync=1)
+   blocks until THIS rank's copies have completed, (host_sync=0) makes the context's stream wait for
+   them.  Completion of the peers' copies into / out of this rank's buffer is the caller's cross-rank
+   barrier: after wait + barrier every rank's buffer is complete (push); before a pull every rank must
+   have passed a barrier after producing its slot. */
+#define FCAMD_GATHER_PULL 1
+int fcamd_allgather_direct(fcamd_context* ctx, int world, int rank, void* const* gathered, const int* devices,
+                           size_t slot_bytes, size_t offset_bytes, size_t bytes, int flags);
+int fcamd_allgather_direct_wait(fcamd_context* ctx, int host_sync);
+
+/* ---- device memory -------------------------------------------------------------- */
+/* A working set whose physical placement is chosen by the call: `n_arrays` address ranges of bytes[k]
+   bytes (rounded up to the granule), backed by physical handles of `granule_bytes` (0 = the device's
+   recommended granularity, 2 MiB) created either array after array (FCAMD_ALLOC_SEQUENTIAL) or
+   interleaved over all arrays in proportion to their sizes (FCAMD_ALLOC_INTERLEAVED) through
+   hipMemAddressReserve / hipMemCreate / hipMemMap.  Background: on MI355X the kernel time follows where
+   the written arrays live.  ptrs[k] receives the base of array k; each array is released
+   on its own with fcamd_device_free (which synchronises the device). */
+#define FCAMD_ALLOC_SEQUENTIAL 0
+#define FCAMD_ALLOC_INTERLEAVED 1
+int fcamd_device_alloc_set(fcamd_context* ctx, int n_arrays, const size_t* bytes, size_t granule_bytes, int order,
+                           void** ptrs);
+int fcamd_device_free(fcamd_context* ctx, void* ptr);
+
 /* ---- tuning / introspection -------------------------------------------------- */
 /* Override the launch grid (number of 256-thread workgroups; 0 = automatic). */
 int fcamd_context_set_grid(fcamd_context* ctx, int n_workgroups);
-/* Time of the last evaluate_device* kernel in milliseconds, measured with HIP events
-   on the context's stream (synchronises). */
+/* Timing of the hot call -- the counterpart of the reference's Timer("constitutive-law-evaluation")
+   around evaluate (solver/_lawonsubmesh.py:86).  With timing enabled (default off) EVERY device entry
+   (fcamd_evaluate_device, _from, _from_sparse, _indexed, _ex, _wrapped) is bracketed by HIP events on
+   the context's stream and fcamd_model_last_kernel_ms returns the kernel time of the model's last
+   entry (synchronises); after a host entry (fcamd_evaluate_host, fcamd_evaluate_resident -- they are
+   synchronous) it returns the wall-clock of that call, copies included. */
 int fcamd_model_last_kernel_ms(fcamd_model* model, float* ms);
-/* Enable/disable HIP-event timing around each launch (default off). */
 int fcamd_context_set_timing(fcamd_context* ctx, int enabled);
+/* Launch / data-path knobs (experiments; the defaults are the measured optimum).  Names and their
+   FCAMD_* environment defaults, which are read ONCE, when the context is created:
+     "tile_map" (FCAMD_TILE_MAP, 0), "masked_max" (FCAMD_MASKED_MAX, -1 = per law), "nontemporal"
+     (FCAMD_NT, 1), "host_chunk" (FCAMD_HOST_CHUNK, 0 = automatic), "host_slots" (FCAMD_HOST_SLOTS, 4),
+     "zero_copy" (FCAMD_ZERO_COPY, 1), "zero_copy_grad" (FCAMD_ZERO_COPY_GRAD, 1). */
+int fcamd_context_set_option(fcamd_context* ctx, const char* name, long long value);
+int fcamd_context_get_option(fcamd_context* ctx, const char* name, long long* value);
+/* Release the staging buffers the pageable host path keeps between calls (up to ~1.1 GB). */
+int fcamd_context_trim(fcamd_context* ctx);
 
 const char* fcamd_last_error(void);
 const char* fcamd_status_string(int status);

@@ -83,7 +83,8 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_capi.library_path()) if os.path.exists(_capi.library_path()) else _capi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert _capi.load().fcamd_version() == 1
+    major, minor = (int(re.search(rf"#define FCAMD_VERSION_{k} (\d+)", hdr).group(1)) for k in ("MAJOR", "MINOR"))
+    assert _capi.load().fcamd_version() == 1000 * major + minor
     assert _capi.load().fcamd_status_string(4).decode().startswith("Newton-Raphson")
 
 
@@ -174,7 +175,7 @@ def test_rows_of_cells_matches_quadrature_numbering():
 
 
 def test_eval_args_struct_layout_matches_header():
-    """ctypes mirror of fcamd_eval_args: eleven fields in the header's order, pointer-sized except n_hist / flags."""
+    """ctypes mirror of fcamd_eval_args: twelve fields in the header's order, pointer-sized except n_hist / flags."""
     import ctypes as C
     import re
 
@@ -184,7 +185,7 @@ def test_eval_args_struct_layout_matches_header():
     body = re.search(r"typedef struct fcamd_eval_args \{(.*?)\} fcamd_eval_args;", hdr, re.S).group(1)
     names = re.findall(r"(\w+);", body)
     assert names == [f[0] for f in _capi.EvalArgs._fields_]
-    assert C.sizeof(_capi.EvalArgs) == 11 * C.sizeof(C.c_void_p)  # n_hist and flags each padded to pointer size
+    assert C.sizeof(_capi.EvalArgs) == 12 * C.sizeof(C.c_void_p)  # n_hist and flags each padded to pointer size
     assert _capi.EvalArgs.flags.offset == 9 * C.sizeof(C.c_void_p)
 
 
