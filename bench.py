@@ -7,13 +7,20 @@ One "step" = one ``evaluate`` pass of one constitutive law over n synthetic quad
 per GPU, device-resident (inputs already in HBM when the timed region starts), committed state in,
 trial state out -- the call of the product's device-resident Newton loop (ResidentState.evaluate;
 for the plasticity laws with the sparse trial-history protocol, --history full for the mask-less
-form).  The steps alternate between two Newton iterates of the increment.  Default workload at
-N = 1: BASELINE.json's target configuration, VonMises3D return mapping, 1e8 points, mixed
-elastic/plastic (SURVEY.md 8d cfg3 "mixed").  Before the warm-up the placement of the tangent array
-is chosen out of a few candidate allocations.  For N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank evaluates its own contiguous shard of
-n points (weak scaling, no data-path collective: SURVEY.md 8e); the optional stress/tangent
-all-gather of the single-assembler mode is timed separately and reported under "allgather".
+form).  The steps alternate between two Newton iterates of the increment.  Headline workload:
+BASELINE.json's target configuration, VonMises3D return mapping, 1e8 points, mixed elastic/plastic
+(SURVEY.md 8d cfg3 "mixed").  Before the warm-up the placement of the tangent array is chosen out of a
+few candidate allocations -- the line carries the chosen, the FIRST (what an untuned
+caller gets) and the median candidate.
+
+With no --workload (the driver's command) and N = 1 the same run then times every other single-GPU
+configuration of BASELINE.json / SURVEY.md 8d with the same method -- LinearElasticity (cfg2),
+VonMises3D all-plastic and all-elastic (cfg3 sub-cases), Maxwell (cfg4), Kelvin -- and reports them
+under "configs".  For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank evaluates
+its own contiguous shard of n points (weak scaling, no data-path collective: SURVEY.md 8e); the
+stress/tangent all-gather of the single-assembler mode (config 5) is timed separately on the whole
+shard -- stress in one piece, tangent in chunks that fit next to the working set -- and reported under
+"allgather", never inside `value`.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
@@ -37,8 +44,9 @@ VM_P = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w
 RS_P = {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0}
 SLS_P = {"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}
 LE_P = {"E": 42.0, "nu": 0.3}
+DP_P = {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02}
 
-# workload -> (law kind, strain scale spec, bytes/pt elastic, bytes/pt plastic, history dims)
+# workload -> (law kind, strain scale spec, bytes/pt elastic, bytes/pt plastic)   [SURVEY.md 8d]
 WORKLOADS = {
     "von_mises_mixed": ("von_mises_3d", "loguniform", 464, 568),
     # the same 22 % of plastic points, but in contiguous zones of 4096 points (what a mesh-ordered
@@ -55,7 +63,12 @@ WORKLOADS = {
     "drucker_prager_zoned": ("comfe_drucker_prager", "isochoric_zoned", 464, 568),
     "comfe_mises_zoned": ("comfe_mises_plasticity", "zoned", 464, 568),
 }
-DP_P = {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02}
+HEADLINE = "von_mises_mixed"
+# the other single-GPU configurations of BASELINE.json, timed after the headline in the default run
+EXTRA_CONFIGS = ["linear_elasticity", "von_mises_plastic", "von_mises_elastic", "spring_maxwell", "spring_kelvin"]
+BASELINE_CONFIG = {"linear_elasticity": "configs[1]", "von_mises_mixed": "configs[2] (mixed)", "von_mises_plastic": "configs[2] (all-plastic)",
+                   "von_mises_elastic": "configs[2] (all-elastic)", "spring_maxwell": "configs[3]", "spring_kelvin": "configs[3] (Kelvin twin)"}
+PLASTICITY = ("von_mises_3d", "comfe_mises_plasticity", "comfe_drucker_prager")
 
 
 def make_law(kind):
@@ -81,7 +94,7 @@ def make_law(kind):
 
 def synth_inputs(kind, scale_spec, n, seed, device):
     """Synthetic state, generated on the device: returns
-    (grad, committed stress, committed history dict, warm-up grad)."""
+    (gradient generator, committed stress, committed history dict)."""
     import torch
 
     gen = torch.Generator(device=device)
@@ -137,7 +150,156 @@ def synth_inputs(kind, scale_spec, n, seed, device):
     return grad_array, stress, hist
 
 
-def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
+class Workload:
+    """One law on n synthetic device-resident points: the committed state, two Newton iterates of the
+    gradient, the trial arrays, and the launch every timed step issues."""
+
+    def __init__(self, name, n, seed, device, dev_index, history="sparse", sparse_tangent=False, grid=0):
+        import torch
+
+        self.torch = torch
+        self.name, self.n, self.device, self.dev_index = name, n, device, dev_index
+        self.kind, scale_spec, self.b_el, self.b_pl = WORKLOADS[name]
+        self.del_t = 2.0
+        self.law, self.params = make_law(self.kind)
+        self.launch_log = []  # [phase, evaluate launches]: lets tools/summarize_profile.py slice a kernel trace
+        grad_array, self.stress_c, self.hist_c = synth_inputs(self.kind, scale_spec, n, seed, device)
+        # one in-place warm step from the initial state gives a committed state "from a previous step"
+        self.tangent = torch.empty(36 * n, dtype=torch.float64, device=device)
+        g_warm = grad_array()
+        self.law.evaluate(0.0, self.del_t, g_warm, self.stress_c, self.tangent, self.hist_c)
+        self.launch_log.append(["warm_in_place", 1])
+        del g_warm
+        # Two Newton iterates of one increment, evaluated alternately: between the iterations of the
+        # reference's Newton loop only grad_del_u changes (solver/_solver.py:130-147), and with it the
+        # plastic set at its margin -- so the sparse protocol sees new and stale points as it does in use.
+        self.grads = [grad_array()]
+        self.grads.append(self.grads[0] if os.environ.get("BENCH_SINGLE_ITERATE") == "1" else self.grads[0] * 1.03)  # knob: A/B only
+        # trial-state arrays: every timed step reads the committed state and writes the trial state
+        # (same traffic as in place, stationary workload)
+        self.stress_t = torch.empty_like(self.stress_c)
+        self.hist_t = None if self.hist_c is None else {k: torch.empty_like(v) for k, v in self.hist_c.items()}
+        if grid:
+            self.law._handle(dev_index).ctx.set_grid(grid)
+        self.plasticity = self.kind in PLASTICITY
+        self.sparse = self.plasticity and history == "sparse"
+        self.sparse_tangent = bool(sparse_tangent and self.sparse)
+        self.hmask = None
+        if self.sparse:
+            for k in self.hist_c:
+                self.hist_t[k].copy_(self.hist_c[k])  # contract: trial == committed where the mask is clear
+            self.hmask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
+        self.placement = None
+        self.n_pl_ab, self.its_ab = [0, 0], [0, 0]
+
+    def launch(self, i, tangent=None, full_history=False, sparse_tangent=None):
+        self.law.evaluate_from(0.0, self.del_t, self.grads[i & 1], self.stress_c, self.stress_t,
+                               self.tangent if tangent is None else tangent, self.hist_c, self.hist_t,
+                               history_mask=None if full_history else self.hmask,
+                               sparse_tangent=self.sparse_tangent if sparse_tangent is None else sparse_tangent)
+
+    def tune_placement(self, tries):
+        """Placement of the tangent (the dominant write stream): a few candidate allocations, the real kernel
+        timed on each, the fastest kept -- what ResidentState does on its first evaluate.  Candidate 0 is the
+        array that exists already, i.e. what an untuned caller would run on."""
+        if tries <= 1:
+            return
+        from fenics_constitutive_amd.placement import fastest_allocation
+
+        self.tangent, self.placement = fastest_allocation(
+            36 * self.n, lambda tan: self.launch(0, tangent=tan, sparse_tangent=False), tries=tries, device=self.device,
+            first=self.tangent)
+        self.launch_log.append(["placement_candidates", 4 * len(self.placement["candidate_ms"])])
+
+    def count_plastic(self):
+        """Plastic counts / Newton iterations of the two iterates (two more untimed launches)."""
+        for i in (0, 1):
+            self.launch(i)
+            self.torch.cuda.synchronize()
+            if self.plasticity:
+                st = self.law.device_stats(self.dev_index)
+                self.n_pl_ab[i], self.its_ab[i] = int(st.n_plastic), int(st.n_newton_iters)
+        self.launch_log.append(["plastic_counts", 2])
+
+    def alg_bytes(self, n_pl):
+        """Algorithmic bytes of one launch: interface-mandated traffic."""
+        return int(round((self.n - n_pl) * self.b_el + n_pl * self.b_pl))
+
+    def mean_plastic(self, steps):
+        n_b = steps // 2
+        n_a = steps - n_b
+        return (n_a * self.n_pl_ab[0] + n_b * self.n_pl_ab[1]) / steps, (n_a * self.its_ab[0] + n_b * self.its_ab[1]) / steps
+
+    def warmup(self, w):
+        for i in range(w):
+            self.launch(i)
+        self.launch_log.append(["warmup", w])
+
+    def timed_events(self, steps, phase="timed", **kw):
+        """`steps` launches bracketed one by one with events on the launch stream (the library launches on
+        torch's current stream); returns the per-launch kernel times in ms after a synchronise."""
+        torch = self.torch
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for i, (a, b) in enumerate(ev):
+            a.record()
+            self.launch(i, **kw)
+            b.record()
+        torch.cuda.synchronize()
+        self.launch_log.append([phase, steps])
+        return [a.elapsed_time(b) for a, b in ev]
+
+    def config_text(self):
+        return (f"{self.name}: {self.kind} FULL-3D, {self.n} quadrature points per GPU, device-resident AoS, "
+                f"committed->trial evaluate of two alternating Newton iterates"
+                f"{', sparse trial history (ResidentState protocol)' if self.sparse else (', full trial history' if self.plasticity else '')}"
+                f"{', sparse tangent (rows of points that stay elastic are not rewritten)' if self.sparse_tangent else ''}")
+
+    def free(self):
+        for k in ("grads", "stress_c", "stress_t", "hist_c", "hist_t", "tangent", "hmask"):
+            setattr(self, k, None)
+        self.torch.cuda.empty_cache()
+
+
+def placement_fracs(wl, alg0):
+    """Roofline fraction of the first (untuned), median, worst and chosen tangent candidate (iterate 0)."""
+    if not wl.placement:
+        return {}
+    ms = wl.placement["candidate_ms"]
+    frac = lambda t: round(alg0 / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)  # noqa: E731
+    srt = sorted(ms)
+    med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    return {"frac_first_allocation": frac(ms[0]), "frac_median_candidate": frac(med), "frac_worst_candidate": frac(srt[-1]),
+            "frac_best_candidate": frac(srt[0])}
+
+
+def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse"):
+    """One extra configuration, same method as the headline: tune, warm up, count, >= 5 event-timed launches."""
+    wl = Workload(name, n, seed, device, dev_index, history=history)
+    try:
+        wl.tune_placement(tries)
+        wl.warmup(warmup)
+        wl.count_plastic()
+        ms = wl.timed_events(steps)
+        n_pl, n_its = wl.mean_plastic(steps)
+        alg = wl.alg_bytes(n_pl)
+        avg = sum(ms) / len(ms)
+        out = {"baseline_config": BASELINE_CONFIG.get(name), "workload": wl.config_text(), "launches": steps,
+               "kernel_ms_avg": round(avg, 4), "kernel_ms_min": round(min(ms), 4),
+               "Mpts_s": round(n / (avg * 1e-3) / 1e6, 1), "algorithmic_bytes_per_launch": alg,
+               "achieved_GBs": round(alg / (avg * 1e-3) / 1e9, 1), "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "plastic_fraction": round(n_pl / n, 4),
+               "mean_newton_iters": round(n_its / max(n_pl, 1), 3) if wl.kind in ("von_mises_3d", "comfe_drucker_prager") else None,
+               "bytes_per_point": {"elastic": wl.b_el, "plastic": wl.b_pl}}
+        out.update(placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])))
+        if wl.placement:
+            out["placement_candidate_ms"] = wl.placement["candidate_ms"]
+        out["launch_log"] = wl.launch_log
+        return out
+    finally:
+        wl.free()
+
+
+def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
     """Time the C oracle ("port": serial per-point loop, 1 thread -- what the reference does per
     MPI rank) on a bounded sample of the same workload."""
     import numpy as np
@@ -169,7 +331,7 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
         "unit": "Mpts/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"oracle/oracle.c serial loop, first {ns} points of the same workload x {reps} passes ({t_total:.1f} s)",
+        "sample": f"oracle/oracle.c serial loop ({CO.build_flags()}), first {ns} points of the headline workload x {reps} passes ({t_total:.1f} s)",
     }
     # the reference's own NumPy code path, restated (oracle/numpy_oracle.py): a few seconds, for scale
     try:
@@ -185,7 +347,7 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
         extra = {"numpy_port_Mpts_s": time_np(NO.MODELS[kind], min(ns, 100_000 if kind == "comfe_drucker_prager" else 500_000)),
                  "threads": "NumPy/OpenBLAS default"}
         if kind == "von_mises_3d":
-            extra["python_per_point_loop_port_Mpts_s"] = time_np(NO.von_mises_3d_loop, min(ns, 30_000))
+            extra["python_per_point_loop_port_Mpts_s"] = time_np(NO.von_mises_3d_loop, min(ns, 20_000))
             # BASELINE config 3 compares with the comfe-rs CPU path: our C restatement of the serial
             # evaluate_model loop around MisesPlasticity3D (interfaces.rs:354-456, mises_plasticity.rs:58-126;
             # mu, kappa, y_0 as above, h = 200 as in tests/models/test_plasticity.py:26-31) on the same
@@ -194,7 +356,7 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
             hr.reshape(-1, 7)[:, 0] = h0["alpha"]
             rs_p = {"mu": params["p_mu"], "kappa": params["p_ka"], "y_0": params["p_y0"], "h": 200.0}
             tt, rr = 0.0, 0
-            while tt < 2.0 and rr < 100:
+            while tt < 1.5 and rr < 100:
                 s, hh = s0.copy(), {"history": hr.copy()}
                 t0 = time.perf_counter()
                 CO.MODELS["comfe_mises_plasticity"](rs_p, 0.0, del_t, g, s, tan, hh)
@@ -206,7 +368,7 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
         CO.set_num_threads(nthr)
         one_pass()
         tt, rr = 0.0, 0
-        while tt < 2.0 and rr < 200:
+        while tt < 1.5 and rr < 200:
             tt += one_pass()
             rr += 1
         CO.set_num_threads(1)
@@ -219,61 +381,110 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=12.0):
 
 
 def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent):
-    """The optional exchange step of the single-assembler mode, timed separately on a
-    bounded slice and never part of `value`: in-place all-gather of stress + tangent slices over RCCL,
-    and (--gather-direct) the one-hop point-to-point variant."""
-    from fenics_constitutive_amd.sharded import ShardPlan
+    """The exchange step of the single-assembler mode (BASELINE config 5), timed separately
+    and never part of `value`: every rank's stress slice (6/pt) in one piece and its tangent slice (36/pt)
+    in chunks through two chunk buffers that are sized against the free device memory up front
+    (fcamd_gather_chunk_plan) -- at 8 x 1e8 points the gathered tangent alone would be 230 GB.
+      rccl_*    in-place all_gather_into_tensor (RCCL);
+      direct_*  the C ABI's peer copies (fcamd_allgather_direct on IPC-mapped buffers): world-1 concurrent
+                copies per rank, one per xGMI link;
+      p2p_*     (--gather-direct) one batched isend/irecv group to all peers (RCCL point-to-point)."""
+    from fenics_constitutive_amd.sharded import ChunkedGather, PeerBuffers, ShardedEvaluator
 
-    ng = min(args.gather_points, n)
-    plan = ShardPlan.create(ng * world, world)
-    per = plan.per_rank
+    ng = ((min(args.gather_points, n) if args.gather_points > 0 else n) // 64) * 64  # whole tiles: every slot is full
+    if ng == 0:
+        raise ValueError("fewer than 64 points per rank: nothing to gather")
+    ev = ShardedEvaluator(None, ng * world)
+    per = ev.plan.per_rank
+    assert per == ng == ev.n_local
+    shard_bytes = 42 * 8 * ng
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(device)
+    reserve = 8 << 30
+    out_s_bytes = 6 * per * world * 8
+    budget = free - reserve - out_s_bytes
+    if budget <= 0:
+        raise MemoryError(f"{free / 1e9:.1f} GB free: no room for the gathered stress ({out_s_bytes / 1e9:.1f} GB) + {reserve >> 30} GiB reserve")
     out_s = torch.empty(6 * per * world, dtype=torch.float64, device=device)
-    out_t = torch.empty(36 * per * world, dtype=torch.float64, device=device)
-    out_s[6 * per * rank : 6 * per * (rank + 1)].copy_(stress_t[: 6 * per])
-    out_t[36 * per * rank : 36 * per * (rank + 1)].copy_(tangent[: 36 * per])
+    s_mine = out_s[6 * per * rank : 6 * per * rank + 6 * ng]
+    s_mine.copy_(stress_t[: 6 * ng])
+    t_mine = tangent[: 36 * ng]
+    nccl = args.backend == "nccl"
+    result = {"points_per_rank": ng, "shard_GB": round(shard_bytes / 1e9, 3), "free_GB_before": round(free / 1e9, 1),
+              "note": "stress gathered whole (in place), tangent through 2 chunk buffers sized against free memory; outside the timed steps"}
 
-    def time_gather(fn):
+    def timed(fn, reps=2):
         best = None
-        for _ in range(3):
+        for _ in range(reps):
             torch.cuda.synchronize()
             dist.barrier()
             t_ = time.perf_counter()
             fn()
             torch.cuda.synchronize()
+            dist.barrier()
             dt_ = time.perf_counter() - t_
             best = dt_ if best is None else min(best, dt_)
-        tt_ = torch.tensor([best], dtype=torch.float64, device=device)
+        tt_ = torch.tensor([best], dtype=torch.float64, device=device if nccl else "cpu")
         dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
         return float(tt_.item())
 
-    def ring():
-        dist.all_gather_into_tensor(out_s, out_s[6 * per * rank : 6 * per * (rank + 1)])
-        dist.all_gather_into_tensor(out_t, out_t[36 * per * rank : 36 * per * (rank + 1)])
+    def report(prefix, t):
+        result[prefix + "_ms"] = round(t * 1e3, 3)
+        result[prefix + "_recv_GBs_per_gpu"] = round(shard_bytes * (world - 1) / t / 1e9, 1)
 
-    def direct():  # one-hop point-to-point transfers, all peers at once (sharded.allgather_direct)
-        for buf, dim in ((out_s, 6), (out_t, 36)):
-            mine = buf[dim * per * rank : dim * per * (rank + 1)]
-            ops = []
-            for shift in range(1, world):
-                dst, src = (rank + shift) % world, (rank - shift) % world
-                ops.append(dist.P2POp(dist.isend, mine, dst))
-                ops.append(dist.P2POp(dist.irecv, buf[dim * per * src : dim * per * (src + 1)], src))
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
+    for variant in (["rccl"] if nccl else []) + ["direct"] + (["p2p"] if (nccl and args.gather_direct) else []):
+        peer = variant == "direct"
+        cg = ChunkedGather(ev, 36, budget, like=tangent, peer_copies=peer)  # raises up front if the budget holds no tile
+        result["tangent_chunks"], result["chunk_points"] = cg.plan.n_chunks, cg.plan.chunk
+        result["chunk_buffers_GB"] = round(2 * cg.plan.buffer_numel * 8 / 1e9, 2)
+        peers_s = PeerBuffers(out_s) if peer else None
 
-    shard_bytes = 42 * 8 * per
-    t_ring = time_gather(ring)
-    gather = {"points_per_rank": per, "shard_GB": round(shard_bytes / 1e9, 3),
-              "rccl_all_gather_ms": round(t_ring * 1e3, 3),
-              "rccl_all_gather_recv_GBs_per_gpu": round(shard_bytes * (world - 1) / t_ring / 1e9, 1),
-              "note": "in-place all_gather_into_tensor of stress+tangent slices, outside the timed steps"}
-    if args.gather_direct:
-        t_direct = time_gather(direct)
-        gather["direct_p2p_ms"] = round(t_direct * 1e3, 3)
-        gather["direct_p2p_recv_GBs_per_gpu"] = round(shard_bytes * (world - 1) / t_direct / 1e9, 1)
-    del out_s, out_t
-    return gather
+        def run():
+            if peer:
+                ev.allgather_peer(s_mine, out_s, 6, peers_s)
+            elif variant == "p2p":
+                ev.allgather_direct(s_mine, out_s, 6)
+            else:
+                ev.allgather(s_mine, out_s, 6)
+            for _k, _view in cg.chunks(t_mine):
+                pass  # the consumer (the assembler) would read _view here
+
+        try:
+            report(variant, timed(run))
+        finally:
+            if peers_s is not None:
+                peers_s.close()
+            cg.close()
+            del cg
+            torch.cuda.empty_cache()
+    del out_s
+    return result
+
+
+def library_hash():
+    """Content hash of the sources libfcamd.so was built from (fenics_constitutive_amd/_build.py)."""
+    try:
+        from fenics_constitutive_amd import _build
+
+        with open(_build.HASHFILE) as f:
+            return f.read().strip()
+    except Exception:
+        return None
+
+
+def read_traffic(workload_key, n):
+    """PMC-measured HBM bytes per launch (profiles/traffic.json, written by tools/summarize_profile.py) --
+    only if they were measured with THIS build of the library (same source hash) at this size; a kernel
+    change makes the figure stale and the line then says null."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(tf) as f:
+            e = json.load(f).get(workload_key)
+        if e and int(e.get("n", 0)) == n and e.get("srchash") and e.get("srchash") == library_hash():
+            return e.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -281,7 +492,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="von_mises_mixed", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help=f"time this workload only (default: {HEADLINE}, followed at N = 1 by the other BASELINE configurations)")
+    ap.add_argument("--configs", choices=["auto", "all", "none"], default="auto",
+                    help="the other single-GPU BASELINE configurations after the headline: auto = when no --workload is given and N = 1")
+    ap.add_argument("--config-steps", type=int, default=6, help="timed launches per extra configuration (>= 5)")
     ap.add_argument("--n", "--points", dest="n", type=int, default=100_000_000,
                     help="quadrature points per GPU (use --points under torch.distributed.run, whose parser claims --n)")
     ap.add_argument("--grid", type=int, default=0, help="override the launch grid (workgroups)")
@@ -300,14 +515,18 @@ def main():
                     help="candidate allocations of the tangent array, timed with the real kernel before the run; the "
                          "fastest is kept (fenics_constitutive_amd.placement, DESIGN.md 6).  1 = take what the driver gives")
     ap.add_argument("--gather-direct", action="store_true",
-                    help="N>1: also time the one-hop point-to-point gather (batched isend/irecv to all peers)")
-    ap.add_argument("--gather-points", type=int, default=20_000_000,
-                    help="points per rank of the separately timed stress/tangent all-gather (N>1)")
+                    help="N>1: also time the batched isend/irecv gather (RCCL point-to-point) next to RCCL's all-gather "
+                         "and the C ABI's peer copies")
+    ap.add_argument("--gather-points", type=int, default=0,
+                    help="points per rank of the separately timed stress/tangent all-gather (N>1); 0 = the whole shard")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo only to exercise the multi-rank control flow on a box "
-                         "with fewer GPUs than ranks (ranks then share GPUs; the all-gather leg is skipped)")
+                         "with fewer GPUs than ranks (ranks then share GPUs; of the gather variants only the C ABI's "
+                         "peer copies run)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL, fcamd_ipc_*)
     import torch
     import torch.distributed as dist
 
@@ -340,70 +559,22 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    kind, scale_spec, b_el, b_pl = WORKLOADS[args.workload]
+    t_start = time.perf_counter()
+    name = args.workload or HEADLINE
+    history = "sparse" if args.sparse_history else args.history
     n = args.n
-    del_t = 2.0
-    law, params = make_law(kind)
-    grad_array, stress_c, hist_c = synth_inputs(kind, scale_spec, n, seed=1234 + rank, device=device)
+    wl = Workload(name, n, seed=1234 + rank, device=device, dev_index=dev_index, history=history,
+                  sparse_tangent=args.sparse_tangent, grid=args.grid)
+    tries = args.placement_tries
+    if world > 1 and tries > 1:
+        # the candidates are alive together while they are timed: never more than fit next to the working set
+        from fenics_constitutive_amd.placement import max_tries_for_memory
 
-    # one in-place warm step from the initial state gives a committed state "from a previous step"
-    tangent = torch.empty(36 * n, dtype=torch.float64, device=device)
-    g_warm = grad_array()
-    law.evaluate(0.0, del_t, g_warm, stress_c, tangent, hist_c)
-    del g_warm
-    # Two Newton iterates of one increment, evaluated alternately: between the iterations of the
-    # reference's Newton loop only grad_del_u changes (solver/_solver.py:130-147), and with it the
-    # plastic set at its margin -- so the sparse protocol sees new and stale points as it does in use.
-    grads = [grad_array()]
-    grads.append(grads[0] if os.environ.get("BENCH_SINGLE_ITERATE") == "1" else grads[0] * 1.03)  # knob: A/B only
-    grad = grads[0]
-    # trial-state arrays: every timed step reads the committed state and writes the trial state
-    # (same traffic as in place, stationary workload)
-    stress_t = torch.empty_like(stress_c)
-    hist_t = None if hist_c is None else {k: torch.empty_like(v) for k, v in hist_c.items()}
-    if args.grid:
-        law._handle(dev_index).ctx.set_grid(args.grid)
-
-    plasticity = kind in ("von_mises_3d", "comfe_mises_plasticity", "comfe_drucker_prager")
-    sparse = plasticity and (args.history == "sparse" or args.sparse_history)
-    hmask = None
-    if sparse:
-        for k in hist_c:
-            hist_t[k].copy_(hist_c[k])  # contract: trial == committed where the mask is clear
-        hmask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
-
-    # placement of the tangent (the dominant write stream): a few candidate allocations, the real
-    # kernel timed on each, the fastest kept -- what a long-running simulation does once at start-up
-    placement = None
-    if args.placement_tries > 1:
-        from fenics_constitutive_amd.placement import fastest_allocation
-
-        tangent, placement = fastest_allocation(
-            36 * n, lambda tan: law.evaluate_from(0.0, del_t, grads[0], stress_c, stress_t, tan, hist_c, hist_t,
-                                                  history_mask=hmask),
-            tries=args.placement_tries, device=device, first=tangent)
-
-    sparse_tangent = bool(args.sparse_tangent and sparse)
-
-    def step(i):
-        law.evaluate_from(0.0, del_t, grads[i & 1], stress_c, stress_t, tangent, hist_c, hist_t, history_mask=hmask,
-                          sparse_tangent=sparse_tangent)
-
-    for i in range(args.warmup):
-        step(i)
-    # plastic counts of the two iterates (two more untimed launches)
-    n_pl_ab, its_ab = [], []
-    for i in (0, 1):
-        step(i)
-        torch.cuda.synchronize()
-        st = law.device_stats(dev_index)
-        n_pl_ab.append(int(st.n_plastic) if plasticity else 0)
-        its_ab.append(int(st.n_newton_iters))
-    # averaged over the timed steps (step i evaluates iterate i & 1)
-    n_b = args.steps // 2
-    n_a = args.steps - n_b
-    n_pl = (n_a * n_pl_ab[0] + n_b * n_pl_ab[1]) / args.steps
-    n_its = (n_a * its_ab[0] + n_b * its_ab[1]) / args.steps
+        tries = max_tries_for_memory(36 * n, tries, device, reserve_bytes=16 << 30)
+    wl.tune_placement(tries)
+    wl.warmup(args.warmup)
+    wl.count_plastic()
+    n_pl, n_its = wl.mean_plastic(args.steps)
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -413,79 +584,94 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev0[i].record()
-        step(i)
+        wl.launch(i)
         ev1[i].record()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    wl.launch_log.append(["timed", args.steps])
+    red_dev = device if args.backend == "nccl" else "cpu"
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = sorted(ev0[i].elapsed_time(ev1[i]) for i in range(args.steps))
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
     per_rank_ms = None
     if distributed:  # every rank's own average kernel time: shows the balance behind the max-over-ranks wall time
-        tk = torch.zeros(world, dtype=torch.float64, device=device)
+        tk = torch.zeros(world, dtype=torch.float64, device=red_dev)
         tk[rank] = kernel_avg_ms
         dist.all_reduce(tk, op=dist.ReduceOp.SUM)
         per_rank_ms = [round(float(x), 4) for x in tk.tolist()]
 
     # next to the headline: the same step without the sparse protocol (every launch rewrites the whole trial
-    # history, fcamd_evaluate_device_from) -- five extra launches after the timed region
+    # history, fcamd_evaluate_device_from) -- six extra launches after the timed region
     full_ms = None
-    if sparse:
-        evf = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
-        for i, (e0_, e1_) in enumerate(evf):
-            e0_.record()
-            law.evaluate_from(0.0, del_t, grads[i & 1], stress_c, stress_t, tangent, hist_c, hist_t)
-            e1_.record()
-        torch.cuda.synchronize()
-        full_ms = sum(a_.elapsed_time(b_) for a_, b_ in evf[1:]) / (len(evf) - 1)
-
-    # optional exchange step, timed separately (never part of `value`)
-    gather = None
-    if distributed and args.backend == "nccl":
-        try:
-            gather = time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent)
-        except Exception as e:  # e.g. out of memory on every rank alike: the step timing above stands
-            gather = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if wl.sparse:
+        ms = wl.timed_events(6, phase="full_trial_history", full_history=True, sparse_tangent=False)
+        full_ms = sum(ms[1:]) / (len(ms) - 1)
 
     # "achievable" next to "peak" (SURVEY 8d): a plain device copy over half of the tangent array
-    # (read + write counted), after everything that still needs the arrays
+    # (read + write counted)
     copy_gbs = None
     try:
-        half = (tangent.numel() // 2) & ~1
+        half = (wl.tangent.numel() // 2) & ~1
         cs, ce = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best = None
         for _ in range(4):
             cs.record()
-            tangent[:half].copy_(tangent[half : 2 * half])
+            wl.tangent[:half].copy_(wl.tangent[half : 2 * half])
             ce.record()
             ce.synchronize()
-            ms = cs.elapsed_time(ce)
-            best = ms if best is None else min(best, ms)
+            ms_ = cs.elapsed_time(ce)
+            best = ms_ if best is None else min(best, ms_)
         copy_gbs = 2 * 8 * half / (best * 1e-3) / 1e9
     except Exception:  # the probe is informational only
         copy_gbs = None
 
+    # the exchange step of config 5, timed separately (never part of `value`)
+    gather = None
+    if distributed and world > 1 and not args.no_gather:
+        try:
+            wl.launch(0, sparse_tangent=False)  # a complete trial stress / tangent for the gather to move
+            keep_s, keep_t = wl.stress_t, wl.tangent
+            wl.grads = wl.hist_t = wl.hmask = None  # the gather needs the room, the step timing is done
+            torch.cuda.empty_cache()
+            gather = time_allgather(args, dist, torch, device, rank, world, n, keep_s, keep_t)
+        except Exception as e:  # e.g. no room on every rank alike: the step timing above stands
+            gather = {"error": f"{type(e).__name__}: {e}"[:400]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # sample of the headline arrays, taken before they are released for the other configurations
+        cpu_args = (wl.kind, wl.params, wl.grads[0][: 9 * 2_000_000].clone(), wl.stress_c[: 12_000_000].clone(),
+                    None if wl.hist_c is None else {k: v[: {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}[k] * 2_000_000].clone()
+                                                    for k, v in wl.hist_c.items()}, wl.del_t)
+    headline = {"placement": wl.placement, "launch_log": wl.launch_log, "config_text": wl.config_text(), "kind": wl.kind,
+                "b_el": wl.b_el, "b_pl": wl.b_pl, "alg": wl.alg_bytes(n_pl), "alg0": wl.alg_bytes(wl.n_pl_ab[0]),
+                "fracs": placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])), "sparse": wl.sparse, "plasticity": wl.plasticity}
+    wl.free()
+
+    # every other single-GPU configuration of BASELINE.json, same method, >= 5 event-timed launches each
+    configs = None
+    do_configs = args.configs == "all" or (args.configs == "auto" and args.workload is None and world == 1)
+    if do_configs and rank == 0:
+        configs = {}
+        for k, cname in enumerate(EXTRA_CONFIGS):
+            try:
+                configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
+                                            min(tries, 4), history=history)
+            except Exception as e:  # one configuration failing must not lose the line
+                configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+
     if rank == 0:
         total_pts = n * world * args.steps
         value = total_pts / elapsed / 1e6
-        alg_bytes = int(round((n - n_pl) * b_el + n_pl * b_pl))
+        alg_bytes = headline["alg"]
         achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                with open(tf) as f:
-                    tj = json.load(f)
-                e = tj.get(args.workload + ("_full" if plasticity and not sparse else ""))
-                if e and int(e.get("n", 0)) == n:
-                    traffic = e.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = read_traffic(name + ("_full" if headline["plasticity"] and not headline["sparse"] else ""), n)
         out = {
             "metric": METRIC,
             "value": round(value, 1),
@@ -499,12 +685,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {kind} FULL-3D, {n} quadrature points per GPU, device-resident AoS, "
-                                   f"committed->trial evaluate of two alternating Newton iterates"
-                                   f"{', sparse trial history (ResidentState protocol)' if sparse else (', full trial history' if plasticity else '')}"
-                                   f"{', sparse tangent (rows of points that stay elastic are not rewritten)' if sparse_tangent else ''}",
+            "config": {"workload": headline["config_text"],
+                       "baseline_config": BASELINE_CONFIG.get(name),
                        "points_per_gpu": n, "plastic_fraction": round(n_pl / n, 4),
-                       "mean_newton_iters": round(n_its / max(n_pl, 1), 3) if kind in ("von_mises_3d", "comfe_drucker_prager") else None,
+                       "mean_newton_iters": round(n_its / max(n_pl, 1), 3) if headline["kind"] in ("von_mises_3d", "comfe_drucker_prager") else None,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -512,22 +696,29 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "traffic_GBs": None if traffic is None else round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1),
                          "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
-                         "bytes_per_point": {"elastic": b_el, "plastic": b_pl}},
+                         "bytes_per_point": {"elastic": headline["b_el"], "plastic": headline["b_pl"]},
+                         "placement_note": "frac = timed steps on the chosen tangent allocation; frac_first_allocation = candidate 0, "
+                                           "what a caller gets without tuning (min of 3 launches, iterate 0)"},
         }
+        out["roofline"].update(headline["fracs"])
         if full_ms is not None:
             out["full_trial_history"] = {"kernel_ms_avg": round(full_ms, 4),
                                          "frac": round(alg_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          "note": "same step, whole trial history rewritten by every launch (--history full)"}
-        if placement is not None:
-            out["placement"] = {"tangent_" + k: v for k, v in placement.items()}
+        if headline["placement"] is not None:
+            out["placement"] = {"tangent_" + k: v for k, v in headline["placement"].items()}
+            out["placement"]["tries"] = tries
         if per_rank_ms is not None:
             out["per_rank_kernel_ms"] = per_rank_ms
         if gather:
             out["allgather"] = gather
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(kind, params, grad, stress_c, hist_c, del_t)
-        elif world == 1:
-            out["cpu_baseline"] = None
+        if configs is not None:
+            out["configs"] = configs
+        out["launch_log"] = headline["launch_log"]
+        out["library"] = {"srchash": library_hash()}
+        if world == 1:
+            out["cpu_baseline"] = cpu_baseline(*cpu_args) if not args.no_cpu_baseline else None
+        out["wall_s"] = round(time.perf_counter() - t_start, 1)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

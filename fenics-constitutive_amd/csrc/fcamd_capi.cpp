@@ -607,6 +607,7 @@ int fcamd_context_destroy(fcamd_context* c) {
         if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : c->peer_events)
         if (e) (void)hipEventDestroy(e);
+    for (auto& kv : c->ipc_open) (void)hipIpcCloseMemHandle(kv.second.base);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FCAMD_OK;

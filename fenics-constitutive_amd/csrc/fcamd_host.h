@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "fcamd_internal.h"
@@ -85,6 +86,13 @@ struct fcamd_context {
     // direct all-gather (fcamd_multigpu.cpp): one copy stream per peer, created on first use
     std::vector<hipStream_t> peer_streams;
     std::vector<hipEvent_t> peer_events;
+    // IPC allocations mapped into this process: handle bytes -> {base address here, open count}.  One
+    // allocation (e.g. a caching allocator's segment) may back several exported buffers; it is opened once.
+    struct IpcMapping {
+        void* base;
+        int refs;
+    };
+    std::map<std::string, IpcMapping> ipc_open;
 };
 
 struct fcamd_model {

@@ -102,19 +102,35 @@ int fcamd_ipc_open(fcamd_context* c, const unsigned char handle[FCAMD_IPC_HANDLE
                    void** device_ptr) {
     if (!c || !handle || !device_ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
-    hipIpcMemHandle_t h;
-    std::memcpy(&h, handle, sizeof(h));
-    void* base = nullptr;
-    HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
-    *device_ptr = static_cast<char*>(base) + offset_bytes;
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    const std::string key(reinterpret_cast<const char*>(handle), FCAMD_IPC_HANDLE_BYTES);
+    auto it = c->ipc_open.find(key);
+    if (it == c->ipc_open.end()) {
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handle, sizeof(h));
+        void* base = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+        it = c->ipc_open.emplace(key, fcamd_context::IpcMapping{base, 0}).first;
+    }
+    ++it->second.refs;
+    *device_ptr = static_cast<char*>(it->second.base) + offset_bytes;
     return FCAMD_OK;
 }
 
 int fcamd_ipc_close(fcamd_context* c, void* device_ptr, size_t offset_bytes) {
     if (!c || !device_ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipIpcCloseMemHandle(static_cast<char*>(device_ptr) - offset_bytes));
-    return FCAMD_OK;
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    void* base = static_cast<char*>(device_ptr) - offset_bytes;
+    for (auto it = c->ipc_open.begin(); it != c->ipc_open.end(); ++it) {
+        if (it->second.base != base) continue;
+        if (--it->second.refs == 0) {
+            c->ipc_open.erase(it);
+            HIP_TRY(hipIpcCloseMemHandle(base));
+        }
+        return FCAMD_OK;
+    }
+    return fail(FCAMD_ERR_BAD_ARG, "pointer was not returned by fcamd_ipc_open of this context");
 }
 
 int fcamd_enable_peer_access(fcamd_context* c, int peer_device) {

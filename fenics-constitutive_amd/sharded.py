@@ -10,6 +10,19 @@ cells and no gather is needed.
 Slices are aligned to 64 points (one wavefront tile) and padded to a common length so the
 gather is a single in-place ``all_gather_into_tensor`` per array (one large message per
 peer: xGMI is point-to-point, so fewer, larger transfers are what it wants).
+
+Three gather variants, same result (``tests/test_sharded_gloo.py``, ``tests/test_gpu_sharded.py``):
+
+* ``allgather``         RCCL's all-gather (``all_gather_into_tensor``, in place);
+* ``allgather_direct``  one batched group of point-to-point sends/receives (RCCL ``isend``/``irecv``);
+* ``allgather_peer``    the C ABI's ``fcamd_allgather_direct``: every peer's gathered buffer is mapped
+  into this process through HIP IPC (``PeerBuffers``) and the rank's slice is pushed into all of them by
+  world-1 concurrent peer copies on world-1 streams -- no collective library on the data path.
+
+``ChunkedGather`` serves shards whose gathered tangent does not fit next to the working set (config 5:
+8 x 1e8 points -> 230 GB of tangent per GPU): the consumer receives the gathered array chunk by chunk
+through two chunk buffers; the memory budget is checked before anything is allocated.
+The rule for the slices (``ShardPlan``) is the C ABI's ``fcamd_shard_bounds``.
 """
 
 from __future__ import annotations
@@ -108,6 +121,25 @@ class ShardedEvaluator:
             req.wait()
         return gathered
 
+    def allgather_peer(self, local, gathered, dim: int, peers: "PeerBuffers", offset: int = 0, count: int | None = None,
+                       pull: bool = False):
+        """Same result as :meth:`allgather` through the C ABI (``fcamd_allgather_direct``): ``peers`` holds
+        every rank's ``gathered`` buffer mapped into this process (HIP IPC); this rank's slice -- or
+        ``count`` values of it from ``offset`` on -- is copied into its slot of all of them by world-1
+        concurrent peer copies.  Ends with a barrier: on return every rank's buffer is complete."""
+        per = dim * self.plan.per_rank
+        mine = gathered[per * self.rank : per * (self.rank + 1)]
+        if local.data_ptr() != mine.data_ptr():
+            mine[: local.numel()].copy_(local)
+        count = per - offset if count is None else count
+        if pull:  # every slot must be complete before anybody reads it
+            peers.ctx.synchronize()
+            self.dist.barrier(group=self.group)
+        peers.gather(8 * per, 8 * offset, 8 * count, pull=pull)
+        peers.ctx.allgather_direct_wait(host_sync=True)
+        self.dist.barrier(group=self.group)
+        return gathered
+
     def compact(self, gathered, dim: int):
         """View of the n valid points.  Every rank before the last non-empty one is full, so
         rank r's slot offset ``r * per_rank`` equals its global offset: the valid points are
@@ -115,16 +147,152 @@ class ShardedEvaluator:
         return gathered[: dim * self.plan.n]
 
     def evaluate_and_gather(self, t, del_t, grad_local, stress_gathered, tangent_gathered, history_local,
-                            direct: bool = False):
+                            direct: bool = False, peers=None):
         """Evaluate directly into this rank's slice of the gathered buffers, then all-gather
         both in place (no staging copy: sendbuf = recvbuf + rank*count).  ``direct`` selects the
-        one-hop point-to-point variant."""
+        one-hop point-to-point variant; ``peers = (PeerBuffers of stress_gathered, PeerBuffers of
+        tangent_gathered)`` the C ABI's peer copies."""
         sd, td = 6, 36
         per = self.plan.per_rank
         s_mine = stress_gathered[sd * per * self.rank : sd * per * self.rank + sd * self.n_local]
         t_mine = tangent_gathered[td * per * self.rank : td * per * self.rank + td * self.n_local]
         self.evaluate_local(t, del_t, grad_local, s_mine, t_mine, history_local)
-        gather = self.allgather_direct if direct else self.allgather
-        gather(s_mine, stress_gathered, sd)
-        gather(t_mine, tangent_gathered, td)
+        if peers is not None:
+            self.allgather_peer(s_mine, stress_gathered, sd, peers[0])
+            self.allgather_peer(t_mine, tangent_gathered, td, peers[1])
+        else:
+            gather = self.allgather_direct if direct else self.allgather
+            gather(s_mine, stress_gathered, sd)
+            gather(t_mine, tangent_gathered, td)
         return self.compact(stress_gathered, sd), self.compact(tangent_gathered, td)
+
+
+class PeerBuffers:
+    """Every rank's copy of one gathered buffer, mapped into this process (one rank per process: HIP IPC,
+    ``fcamd_ipc_export`` / ``fcamd_ipc_open``; the 64-byte handles travel through
+    ``all_gather_object``).  ``close()`` unmaps the peers' buffers; call it on every rank before any rank
+    frees its buffer."""
+
+    def __init__(self, gathered, group=None, ctx=None):
+        import torch
+        import torch.distributed as dist
+
+        from . import _capi
+        from .device import _current_stream_ptr
+
+        assert gathered.is_cuda and gathered.is_contiguous()
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        dev = gathered.device.index or 0
+        self.ctx = ctx if ctx is not None else _capi.get_context(dev)
+        self.ctx.set_stream(_current_stream_ptr(dev))
+        self._own = gathered  # kept alive while mapped elsewhere
+        handle, offset = self.ctx.ipc_export(gathered.data_ptr())
+        infos = [None] * self.world
+        dist.all_gather_object(infos, (handle, offset, gathered.numel() * gathered.element_size()), group=group)
+        assert all(i[2] == infos[0][2] for i in infos), "every rank's gathered buffer must have the same size"
+        self.ptrs, self._opened = [], []
+        for p, (h, off, _) in enumerate(infos):
+            if p == self.rank:
+                self.ptrs.append(gathered.data_ptr())
+            else:
+                ptr = self.ctx.ipc_open(h, off)
+                self.ptrs.append(ptr)
+                self._opened.append((ptr, off))
+        torch.cuda.synchronize(gathered.device)
+        dist.barrier(group=group)
+
+    def gather(self, slot_bytes: int, offset_bytes: int = 0, nbytes: int | None = None, pull: bool = False) -> None:
+        """Enqueue the world-1 peer copies of this rank (asynchronous; see ``Context.allgather_direct_wait``)."""
+        from .device import _current_stream_ptr
+
+        self.ctx.set_stream(_current_stream_ptr(self._own.device.index or 0))
+        self.ctx.allgather_direct(self.world, self.rank, self.ptrs, slot_bytes, offset_bytes, nbytes, pull=pull)
+
+    def close(self) -> None:
+        if self._opened:
+            self.ctx.allgather_direct_wait(host_sync=True)
+            self.dist.barrier(group=self.group)  # nobody is still copying into / out of a mapping
+            for ptr, off in self._opened:
+                self.ctx.ipc_close(ptr, off)
+            self._opened = []
+            self.dist.barrier(group=self.group)
+
+
+@dataclass(frozen=True)
+class GatherChunks:
+    """Plan of a chunked gather (``fcamd_gather_chunk_plan``): chunk k covers points
+    [k*chunk, min((k+1)*chunk, per_rank)) of EVERY rank's slot."""
+
+    per_rank: int
+    world: int
+    dim: int
+    chunk: int
+    n_chunks: int
+    n_buffers: int
+
+    @staticmethod
+    def create(per_rank: int, world: int, dim: int, budget_bytes: int, n_buffers: int = 2) -> "GatherChunks":
+        from . import _capi
+
+        chunk, k = _capi.gather_chunk_plan(per_rank, world, dim, budget_bytes, n_buffers)
+        return GatherChunks(int(per_rank), int(world), int(dim), chunk, k, int(n_buffers))
+
+    @property
+    def buffer_numel(self) -> int:
+        """Elements of one chunk buffer: ``world`` slices of ``chunk`` points."""
+        return self.world * self.chunk * self.dim
+
+    def span(self, k: int) -> tuple[int, int]:
+        """[lo, hi) of chunk k in slot-local points."""
+        lo = k * self.chunk
+        return lo, min(lo + self.chunk, self.per_rank)
+
+    def slot_offset(self, rank: int) -> int:
+        """Element offset of rank's slice inside a chunk buffer."""
+        return rank * self.chunk * self.dim
+
+
+class ChunkedGather:
+    """All-gather of a per-point array (``dim`` values per point) that is consumed chunk by chunk:
+    ``for k, view in cg.chunks(local): consume(view)`` -- ``view[r]`` is rank r's points of chunk k, shape
+    (world, points, dim).  Two chunk buffers alternate, so the gather of chunk k+1 may be enqueued while
+    the consumer still reads chunk k.  The buffers are sized against ``budget_bytes`` up front
+    (``GatherChunks.create`` raises AssertionError when not even one tile per rank fits)."""
+
+    def __init__(self, evaluator: ShardedEvaluator, dim: int, budget_bytes: int, like, n_buffers: int = 2,
+                 peer_copies: bool = False):
+        """``peer_copies``: move the chunks with the C ABI's peer copies (``fcamd_allgather_direct`` on
+        IPC-mapped chunk buffers) instead of the process group's all-gather."""
+        import torch
+
+        self.ev, self.dim = evaluator, dim
+        self.plan = GatherChunks.create(evaluator.plan.per_rank, evaluator.world, dim, budget_bytes, n_buffers)
+        self.buffers = [torch.empty(self.plan.buffer_numel, dtype=like.dtype, device=like.device) for _ in range(n_buffers)]
+        self.peers = [PeerBuffers(b, evaluator.group) for b in self.buffers] if peer_copies else None
+
+    def close(self) -> None:
+        for p in self.peers or []:
+            p.close()
+        self.peers = None
+
+    def chunks(self, local):
+        """``local``: this rank's slice (dim * n_local values).  Yields (k, view of the gathered chunk)."""
+        p, ev = self.plan, self.ev
+        for k in range(p.n_chunks):
+            lo, hi = p.span(k)
+            buf = self.buffers[k % len(self.buffers)]
+            mine = buf[p.slot_offset(ev.rank) : p.slot_offset(ev.rank) + p.chunk * p.dim]
+            have = max(0, min(hi, ev.n_local) - lo)  # the last rank's slice may end inside (or before) the chunk
+            if have:
+                mine[: have * p.dim].copy_(local[lo * p.dim : (lo + have) * p.dim])
+            if self.peers is None:
+                ev.dist.all_gather_into_tensor(buf, mine, group=ev.group)
+            else:
+                # pushing chunk k into buffer b overwrites chunk k - n_buffers there: every rank has consumed
+                # it, because it passed the barrier of chunk k - 1 only after leaving that iteration
+                peer = self.peers[k % len(self.buffers)]
+                peer.gather(8 * p.chunk * p.dim)
+                peer.ctx.allgather_direct_wait(host_sync=True)
+                ev.dist.barrier(group=ev.group)
+            yield k, buf.view(p.world, p.chunk, p.dim)[:, : hi - lo]

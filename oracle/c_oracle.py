@@ -37,6 +37,15 @@ def build(force: bool = False) -> str:
     return LIB
 
 
+def build_flags() -> str:
+    """Compiler and flags of the build (the CFLAGS line of oracle/Makefile), for bench.py's cpu_baseline.sample."""
+    import re
+
+    mk = open(os.path.join(HERE, "Makefile")).read()
+    cc = re.search(r"^CC \?= (.*)$", mk, re.M).group(1).strip()
+    return f"{os.environ.get('CC', cc)} {os.environ.get('CFLAGS', re.search(r'^CFLAGS [?]= (.*)$', mk, re.M).group(1).strip())}"
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:

@@ -148,6 +148,52 @@ def test_spring_maxwell_1e8():
         assert rel_err(got, ref) <= 1e-14, "strict " + name
 
 
+def test_spring_kelvin_1e8():
+    """The second SLS update north_star names (SpringKelvinModel, models/spring_kelvin_model.py:43-88), 1e8 points:
+    constant tangent, strain history = running sum, strided sample against the oracle."""
+    need_memory(80)
+    SLS_P = {"E0": 42.0, "E1": 10.0, "tau": 10.0, "nu": 0.2}
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    g = torch.randn(9 * N, dtype=torch.float64, device="cuda", generator=gen) * 1e-3
+    s0 = torch.randn(6 * N, dtype=torch.float64, device="cuda", generator=gen)
+    ev0 = torch.randn(6 * N, dtype=torch.float64, device="cuda", generator=gen) * 1e-4
+    en0 = torch.randn(6 * N, dtype=torch.float64, device="cuda", generator=gen) * 1e-3
+    s, ev, en = s0.clone(), ev0.clone(), en0.clone()
+    t = torch.full((36 * N,), float("nan"), dtype=torch.float64, device="cuda")
+    law = fc.SpringKelvinModel(SLS_P, FULL)
+    law.evaluate(0.0, 2.0, g, s, t, {"strain_visco": ev, "strain": en})
+    torch.cuda.synchronize()
+    # property 1: one tangent for all points
+    tv = t.view(N, 36)
+    assert torch.equal(tv.min(dim=0).values, tv.max(dim=0).values)
+    del tv
+    # property 2: strain history is the running sum of Mandel strain increments, exactly
+    de = fc.strain_from_grad_u(g, FULL)
+    assert torch.equal(en, en0 + de)
+    del de
+    # property 3: strided sample against the oracle
+    idx = sample_points(N)
+    gs, ss = gather(g, idx, 9), gather(s0, idx, 6)
+    hs = {"strain_visco": gather(ev0, idx, 6), "strain": gather(en0, idx, 6)}
+    ts = np.zeros(36 * idx.numel())
+    CO.spring_kelvin(SLS_P, 0, 2.0, gs, ss, ts, hs)
+    for name, got, ref in [("stress", gather(s, idx, 6), ss), ("tangent", gather(t, idx, 36), ts),
+                           ("strain_visco", gather(ev, idx, 6), hs["strain_visco"]), ("strain", gather(en, idx, 6), hs["strain"])]:
+        assert rel_err(got, ref) <= 1e-10, name
+        assert rel_err(got, ref) <= 1e-14, "strict " + name
+    # property 4 (Kelvin): the viscous strain rate uses the stress BEFORE the update (:74-83) -- with zero
+    # gradient increment the stress changes by exactly -2 mu0 d_eps_v and the strain history not at all
+    del t
+    z = torch.zeros(9 * N, dtype=torch.float64, device="cuda")
+    s2, ev2, en2 = s0.clone(), ev0.clone(), en0.clone()
+    law.evaluate(0.0, 2.0, z, s2, None, {"strain_visco": ev2, "strain": en2})
+    torch.cuda.synchronize()
+    assert torch.equal(en2, en0)
+    mu0 = SLS_P["E0"] / (2.0 * (1.0 + SLS_P["nu"]))
+    m = 6_000_000
+    assert rel_err((s2[:m] - s0[:m]).cpu().numpy(), (-(2 * mu0) * (ev2[:m] - ev0[:m])).cpu().numpy()) <= 1e-12
+
+
 def test_cfg1_linear_elasticity_1e5_ndarray_path():
     """BASELINE.json configs[0]: LinearElasticityModel FULL-3D, 1e5 points, NumPy arrays
     through the drop-in ``evaluate`` -- E=42, nu=0.3, grad ~ N(0, 1e-3^2), sigma_in = 0, seed 0 --

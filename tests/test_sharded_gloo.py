@@ -73,3 +73,82 @@ def test_sharded_equals_unsharded(n, world, direct, tmp_path):
         assert np.array_equal(z["stress"], s), f"rank {r} gathered stress"
         assert np.array_equal(z["tangent"], t), f"rank {r} gathered tangent"
         assert np.array_equal(z["alpha"], h["alpha"][int(z["lo"]) : int(z["hi"])])  # history stays sharded
+
+
+# ---- the C ABI's shard rule and the chunked config-5 gather (host logic, no GPU) --------------------------
+
+@pytest.mark.parametrize("n,world", [(0, 2), (1, 2), (64, 2), (65, 2), (1000, 3), (10**8, 8), (8 * 10**8, 8), (129, 8), (7, 1)])
+def test_c_shard_bounds_equal_the_python_plan(n, world):
+    """fcamd_shard_bounds / fcamd_shard_slot_points (include/fcamd.h) are the rule ShardPlan implements."""
+    from fenics_constitutive_amd import _capi
+    from fenics_constitutive_amd.sharded import ShardPlan
+
+    plan = ShardPlan.create(n, world)
+    assert _capi.shard_slot_points(n, world) == plan.per_rank
+    covered = 0
+    for r in range(world):
+        assert _capi.shard_bounds(n, world, r) == plan.bounds(r)
+        covered += plan.count(r)
+    assert covered == n
+    with pytest.raises(ValueError):
+        _capi.shard_bounds(n, world, world)
+
+
+def test_gather_chunk_plan_config5_fits_next_to_the_working_set():
+    """Config 5 (8 x 1e8 points): the gathered tangent would be 230.4 GB per GPU.  Next to the 56.8 GB
+    working set and the 38.4 GB gathered stress the chunk buffers get what is left of 288 GB minus a
+    reserve; the plan must cover every point exactly once with tile-aligned, equalised chunks."""
+    from fenics_constitutive_amd.sharded import GatherChunks
+
+    per, world = 10**8, 8
+    budget = int(288e9 - 56.8e9 - 38.4e9 - 16e9)
+    p = GatherChunks.create(per, world, 36, budget)
+    assert p.chunk % 64 == 0 and p.n_chunks * p.chunk >= per > (p.n_chunks - 1) * p.chunk
+    assert p.n_buffers * p.buffer_numel * 8 <= budget
+    assert p.n_chunks == 3  # two buffers of <= 88 GB each: three chunks of 33.3 M points
+    spans = [p.span(k) for k in range(p.n_chunks)]
+    assert spans[0][0] == 0 and spans[-1][1] == per and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans[:-1]) == 0  # equalised
+    assert [p.slot_offset(r) for r in range(3)] == [0, 36 * p.chunk, 72 * p.chunk]
+    # the budget is asserted up front: one tile per rank in two buffers needs 8*36*8*64*2 bytes
+    with pytest.raises(AssertionError, match="holds not even one"):
+        GatherChunks.create(per, world, 36, 8 * 36 * 8 * 64 * 2 - 1)
+    assert GatherChunks.create(per, world, 36, 8 * 36 * 8 * 64 * 2).chunk == 64
+    # everything fits: one chunk
+    assert GatherChunks.create(1000, 2, 6, 1 << 30).n_chunks == 1
+
+
+def chunk_worker(rank, world, port, n, budget, out_dir):
+    from fenics_constitutive_amd.sharded import ChunkedGather, ShardedEvaluator
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(36 * n, dtype=torch.float64)
+        ev = ShardedEvaluator(OracleLaw(), n)
+        local = ev.local_view(full, 36).clone()
+        cg = ChunkedGather(ev, 36, budget, like=local)
+        out = torch.full((world, ev.plan.per_rank, 36), -1.0, dtype=torch.float64)
+        for k, view in cg.chunks(local):
+            lo, hi = cg.plan.span(k)
+            out[:, lo:hi] = view
+        # rank r's slot holds its n_r valid points first: the global array is the concatenation of the valid parts
+        parts = [out[r, : ev.plan.count(r)].reshape(-1) for r in range(world)]
+        np.save(os.path.join(out_dir, f"chunked{rank}.npy"), torch.cat(parts).numpy())
+        np.save(os.path.join(out_dir, f"nchunks{rank}.npy"), np.array([cg.plan.n_chunks, cg.plan.chunk]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,tiles_per_chunk", [(1000, 2, 2), (1000, 3, 1), (130, 2, 8), (64 * 7 + 1, 2, 3)])
+def test_chunked_gather_equals_the_global_array(n, world, tiles_per_chunk, tmp_path):
+    """ChunkedGather: every point of every rank arrives exactly once, whatever the chunk length (ragged
+    last rank, last chunk shorter than the others, slices that end inside a chunk)."""
+    budget = world * 36 * 8 * 64 * tiles_per_chunk * 2
+    mp.spawn(chunk_worker, args=(world, free_port(), n, budget, str(tmp_path)), nprocs=world, join=True)
+    ref = np.arange(36 * n, dtype=np.float64)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"chunked{r}.npy"), ref), f"rank {r}"
+        k, chunk = np.load(tmp_path / f"nchunks{r}.npy")
+        assert chunk <= 64 * tiles_per_chunk and (k > 1 or n <= world * chunk)
