@@ -190,6 +190,7 @@ class Workload:
                 self.hist_t[k].copy_(self.hist_c[k])  # contract: trial == committed where the mask is clear
             self.hmask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
         self.placement = None
+        self._vmm, self.vmm_info = None, None
         self.n_pl_ab, self.its_ab = [0, 0], [0, 0]
 
     def launch(self, i, tangent=None, full_history=False, sparse_tangent=None):
@@ -199,9 +200,9 @@ class Workload:
                                sparse_tangent=self.sparse_tangent if sparse_tangent is None else sparse_tangent)
 
     def tune_placement(self, tries):
-        """Placement of the tangent (the dominant write stream): a few candidate allocations, the real kernel
-        timed on each, the fastest kept -- what ResidentState does on its first evaluate.  Candidate 0 is the
-        array that exists already, i.e. what an untuned caller would run on."""
+        """hipMalloc placements of the tangent (the dominant write stream): a few candidate allocations, the
+        real kernel timed on each, the fastest kept (ResidentState(placement="tune")).  Candidate 0 is the array
+        that exists already, i.e. what a caller runs on who takes what the allocator gives."""
         if tries <= 1:
             return
         from fenics_constitutive_amd.placement import fastest_allocation
@@ -210,6 +211,40 @@ class Workload:
             36 * self.n, lambda tan: self.launch(0, tangent=tan, sparse_tangent=False), tries=tries, device=self.device,
             first=self.tangent)
         self.launch_log.append(["placement_candidates", 4 * len(self.placement["candidate_ms"])])
+
+    def place_vmm(self):
+        """The product's default placement (ResidentState(placement="auto")): every array of the step in ONE
+        working set whose 2 MiB physical handles are interleaved over the arrays (placement.VmmArraySet)."""
+        from fenics_constitutive_amd.placement import VmmArraySet
+
+        n = self.n
+        numels = {"tangent": 36 * n, "stress_c": 6 * n, "stress_t": 6 * n, "grad0": 9 * n}
+        two = self.grads[1] is not self.grads[0]
+        if two:
+            numels["grad1"] = 9 * n
+        for k, v in (self.hist_c or {}).items():
+            numels["hc_" + k] = v.numel()
+            numels["ht_" + k] = v.numel()
+        t0 = time.perf_counter()
+        vmm = VmmArraySet(self.law._handle(self.dev_index).ctx, numels, interleaved=True, device=self.device)
+
+        def moved(name, src):
+            dst = vmm[name]
+            dst.copy_(src)
+            return dst
+
+        self.tangent = vmm["tangent"]  # rewritten by every launch: nothing to copy
+        self.stress_c, self.stress_t = moved("stress_c", self.stress_c), moved("stress_t", self.stress_t)
+        g0 = moved("grad0", self.grads[0])
+        self.grads = [g0, moved("grad1", self.grads[1]) if two else g0]
+        if self.hist_c is not None:
+            self.hist_c = {k: moved("hc_" + k, v) for k, v in self.hist_c.items()}
+            self.hist_t = {k: moved("ht_" + k, v) for k, v in self.hist_t.items()}
+        self.torch.cuda.synchronize()
+        self.torch.cuda.empty_cache()
+        self._vmm = vmm
+        self.vmm_info = {"mode": "vmm_interleaved", "arrays": len(numels), "GB": round(8 * sum(numels.values()) / 1e9, 2),
+                         "granule_MiB": 2, "build_s": round(time.perf_counter() - t0, 2)}
 
     def count_plastic(self):
         """Plastic counts / Newton iterations of the two iterates (two more untimed launches)."""
@@ -255,8 +290,8 @@ class Workload:
                 f"{', sparse tangent (rows of points that stay elastic are not rewritten)' if self.sparse_tangent else ''}")
 
     def free(self):
-        for k in ("grads", "stress_c", "stress_t", "hist_c", "hist_t", "tangent", "hmask"):
-            setattr(self, k, None)
+        for k in ("grads", "stress_c", "stress_t", "hist_c", "hist_t", "tangent", "hmask", "_vmm"):
+            setattr(self, k, None)  # a VMM working set is released with its last view
         self.torch.cuda.empty_cache()
 
 
@@ -272,11 +307,14 @@ def placement_fracs(wl, alg0):
             "frac_best_candidate": frac(srt[0])}
 
 
-def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse"):
-    """One extra configuration, same method as the headline: tune, warm up, count, >= 5 event-timed launches."""
+def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse", placement="vmm"):
+    """One extra configuration, same method as the headline: placement, warm up, count, >= 5 event-timed launches."""
     wl = Workload(name, n, seed, device, dev_index, history=history)
     try:
-        wl.tune_placement(tries)
+        if placement != "first":
+            wl.tune_placement(tries)  # in "vmm" mode only for the record: what the hipMalloc draws would have given
+        if placement == "vmm":
+            wl.place_vmm()
         wl.warmup(warmup)
         wl.count_plastic()
         ms = wl.timed_events(steps)
@@ -293,6 +331,7 @@ def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="
         out.update(placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])))
         if wl.placement:
             out["placement_candidate_ms"] = wl.placement["candidate_ms"]
+        out["placement_mode"] = (wl.vmm_info or {}).get("mode", "tune" if wl.placement else "first")
         out["launch_log"] = wl.launch_log
         return out
     finally:
@@ -511,9 +550,14 @@ def main():
                     help="with --history sparse: also the sparse-tangent protocol of ResidentState (FCAMD_EVAL_SPARSE_TANGENT: "
                          "rows of points that stay elastic are not rewritten).  Not the reference contract -- the reported "
                          "bytes stay the interface's 464/568 B/pt, so `frac` is an equivalent, not a traffic, figure")
+    ap.add_argument("--placement", choices=["vmm", "tune", "first"], default="vmm",
+                    help="where the arrays of the timed steps live (DESIGN.md 6): vmm (default, = ResidentState's default) "
+                         "one working set with 2 MiB physical handles interleaved over the arrays; tune = the fastest of "
+                         "--placement-tries hipMalloc candidates of the tangent; first = what the allocator gives")
     ap.add_argument("--placement-tries", type=int, default=6,
-                    help="candidate allocations of the tangent array, timed with the real kernel before the run; the "
-                         "fastest is kept (fenics_constitutive_amd.placement, DESIGN.md 6).  1 = take what the driver gives")
+                    help="hipMalloc candidate allocations of the tangent array, timed with the real kernel before the run "
+                         "(fenics_constitutive_amd.placement): in tune mode the fastest is kept, in vmm mode they are "
+                         "timed for the record only (frac_first_allocation / frac_median_candidate)")
     ap.add_argument("--gather-direct", action="store_true",
                     help="N>1: also time the batched isend/irecv gather (RCCL point-to-point) next to RCCL's all-gather "
                          "and the C ABI's peer copies")
@@ -571,7 +615,10 @@ def main():
         from fenics_constitutive_amd.placement import max_tries_for_memory
 
         tries = max_tries_for_memory(36 * n, tries, device, reserve_bytes=16 << 30)
-    wl.tune_placement(tries)
+    if args.placement != "first":
+        wl.tune_placement(tries)
+    if args.placement == "vmm":
+        wl.place_vmm()
     wl.warmup(args.warmup)
     wl.count_plastic()
     n_pl, n_its = wl.mean_plastic(args.steps)
@@ -648,7 +695,7 @@ def main():
         cpu_args = (wl.kind, wl.params, wl.grads[0][: 9 * 2_000_000].clone(), wl.stress_c[: 12_000_000].clone(),
                     None if wl.hist_c is None else {k: v[: {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}[k] * 2_000_000].clone()
                                                     for k, v in wl.hist_c.items()}, wl.del_t)
-    headline = {"placement": wl.placement, "launch_log": wl.launch_log, "config_text": wl.config_text(), "kind": wl.kind,
+    headline = {"placement": wl.placement, "vmm_info": wl.vmm_info, "launch_log": wl.launch_log, "config_text": wl.config_text(), "kind": wl.kind,
                 "b_el": wl.b_el, "b_pl": wl.b_pl, "alg": wl.alg_bytes(n_pl), "alg0": wl.alg_bytes(wl.n_pl_ab[0]),
                 "fracs": placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])), "sparse": wl.sparse, "plasticity": wl.plasticity}
     wl.free()
@@ -661,7 +708,7 @@ def main():
         for k, cname in enumerate(EXTRA_CONFIGS):
             try:
                 configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
-                                            min(tries, 4), history=history)
+                                            min(tries, 4), history=history, placement=args.placement)
             except Exception as e:  # one configuration failing must not lose the line
                 configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
@@ -697,16 +744,19 @@ def main():
                          "traffic_GBs": None if traffic is None else round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1),
                          "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
                          "bytes_per_point": {"elastic": headline["b_el"], "plastic": headline["b_pl"]},
-                         "placement_note": "frac = timed steps on the chosen tangent allocation; frac_first_allocation = candidate 0, "
-                                           "what a caller gets without tuning (min of 3 launches, iterate 0)"},
+                         "placement_note": "frac = the timed steps, arrays placed as `placement.mode` says (the product default); "
+                                           "frac_first_allocation = hipMalloc candidate 0, what a caller gets who takes the allocator's "
+                                           "arrays as they come, frac_median/worst/best_candidate = the other hipMalloc draws "
+                                           "(min of 3 launches each, iterate 0)"},
         }
         out["roofline"].update(headline["fracs"])
         if full_ms is not None:
             out["full_trial_history"] = {"kernel_ms_avg": round(full_ms, 4),
                                          "frac": round(alg_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          "note": "same step, whole trial history rewritten by every launch (--history full)"}
+        out["placement"] = dict(headline["vmm_info"] or {"mode": "tune" if headline["placement"] else "first"})
         if headline["placement"] is not None:
-            out["placement"] = {"tangent_" + k: v for k, v in headline["placement"].items()}
+            out["placement"].update({"hipmalloc_tangent_" + k: v for k, v in headline["placement"].items()})
             out["placement"]["tries"] = tries
         if per_rank_ms is not None:
             out["per_rank_kernel_ms"] = per_rank_ms

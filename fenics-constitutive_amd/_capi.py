@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -308,9 +309,7 @@ class Context:
         # The context of a thread dies with the thread's local storage (get_context) once the model handles
         # and page-locked registrations that refer to it are gone: streams and staging buffers are released
         # instead of accumulating with every short-lived worker thread.
-        import sys
-
-        if sys.is_finalizing():  # process exit releases everything; the HIP runtime may already be going down
+        if sys is None or sys.is_finalizing():  # process exit releases everything; the HIP runtime may already be going down
             return
         try:
             self.close()

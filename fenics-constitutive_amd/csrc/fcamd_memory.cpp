@@ -32,9 +32,13 @@ std::mutex g_vmm_mu;
 std::unordered_map<void*, VmmArray> g_vmm;  // base address -> its mapping
 
 void release(void* base, VmmArray& a) {
-    if (base && a.bytes) (void)hipMemUnmap(base, a.bytes);
+    for (size_t g = 0; g < a.handles.size(); ++g) (void)hipMemUnmap(static_cast<char*>(base) + g * a.granule, a.granule);
     for (auto h : a.handles) (void)hipMemRelease(h);
-    if (base && a.bytes) (void)hipMemAddressFree(base, a.bytes);
+    // The address range is NOT returned (hipMemAddressFree): on this stack a range that is reserved again at
+    // the same address and mapped to new handles serves stale data -- the second of two identical sets built
+    // after freeing the first read back wrong values in every trial (tools/vmm_placement_probe.py --selftest
+    // reproduces it with the free enabled).  Address space is plentiful (the physical memory IS released);
+    // a range is simply never reused.
     a.handles.clear();
 }
 
@@ -53,8 +57,10 @@ int fcamd_device_alloc_set(fcamd_context* c, int n_arrays, const size_t* bytes, 
     prop.location.id = c->device;
     size_t min_granule = 0;
     HIP_TRY(hipMemGetAllocationGranularity(&min_granule, &prop, hipMemAllocationGranularityRecommended));
-    if (min_granule == 0) min_granule = 2u << 20;
-    size_t granule = granule_bytes ? granule_bytes : min_granule;
+    if (min_granule == 0) min_granule = 4096;
+    // default: 2 MiB handles (the page-table fragment size of large allocations).  The runtime's own
+    // "recommended" granularity is 4 KiB on this stack -- a million handles for a 4 GB array.
+    size_t granule = granule_bytes ? granule_bytes : std::max<size_t>(min_granule, (size_t)2 << 20);
     granule = ((granule + min_granule - 1) / min_granule) * min_granule;
 
     std::vector<VmmArray> arrs((size_t)n_arrays);
@@ -93,6 +99,11 @@ int fcamd_device_alloc_set(fcamd_context* c, int n_arrays, const size_t* bytes, 
         arrs[k].handles.reserve(total[k]);
         VMM_TRY(hipMemAddressReserve(&bases[k], arrs[k].bytes, granule, nullptr, 0));
     }
+    hipMemAccessDesc acc;
+    std::memset(&acc, 0, sizeof(acc));
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = c->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
     // creation order of the physical handles:
     //   order 0 (FCAMD_ALLOC_SEQUENTIAL): array after array;
     //   order 1 (FCAMD_ALLOC_INTERLEAVED): always the array that is furthest behind its share, so the
@@ -113,15 +124,15 @@ int fcamd_device_alloc_set(fcamd_context* c, int n_arrays, const size_t* bytes, 
         hipMemGenericAllocationHandle_t h;
         VMM_TRY(hipMemCreate(&h, granule, &prop, 0));
         arrs[k].handles.push_back(h);
-        VMM_TRY(hipMemMap(static_cast<char*>(bases[k]) + done[k] * granule, granule, 0, h, 0));
+        char* va = static_cast<char*>(bases[k]) + done[k] * granule;
+        VMM_TRY(hipMemMap(va, granule, 0, h, 0));
+        // Access is granted per mapped handle.  One hipMemSetAccess over a range of several handles is
+        // accepted by this runtime but maps the range as if its handles had been created back to back:
+        // with an interleaved creation order the arrays of the set then alias each other's physical memory
+        // (found with distinct fill patterns, tools/vmm_placement_probe.py --selftest).
+        VMM_TRY(hipMemSetAccess(va, granule, &acc, 1));
         ++done[k];
     }
-    hipMemAccessDesc acc;
-    std::memset(&acc, 0, sizeof(acc));
-    acc.location.type = hipMemLocationTypeDevice;
-    acc.location.id = c->device;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    for (int k = 0; k < n_arrays; ++k) VMM_TRY(hipMemSetAccess(bases[k], arrs[k].bytes, &acc, 1));
 #undef VMM_TRY
     {
         std::lock_guard<std::mutex> lock(g_vmm_mu);

@@ -72,26 +72,55 @@ def max_tries_for_memory(numel: int, tries: int, device=None, reserve_bytes: int
 
 
 class _RawDeviceArray:
-    """Minimal ``__cuda_array_interface__`` carrier: lets torch wrap device memory it did not allocate."""
+    """Minimal ``__cuda_array_interface__`` carrier: lets torch wrap device memory it did not allocate.
+    torch keeps this object alive for as long as any tensor (or view of one) made from it exists, so
+    ``owner`` -- whatever must outlive the memory's users -- rides along."""
 
-    def __init__(self, ptr: int, numel: int, typestr: str = "<f8"):
+    def __init__(self, ptr: int, numel: int, typestr: str = "<f8", owner=None):
         self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": typestr, "data": (int(ptr), False),
                                          "version": 2, "strides": None}
+        self.owner = owner
 
 
-def tensor_from_pointer(ptr: int, numel: int, device, dtype_str: str = "<f8"):
-    """float64 device tensor over ``numel`` doubles at ``ptr`` (no copy, no ownership: the memory must
-    outlive the tensor)."""
+def tensor_from_pointer(ptr: int, numel: int, device, dtype_str: str = "<f8", owner=None):
+    """float64 device tensor over ``numel`` doubles at ``ptr`` (no copy).  The tensor and its views keep
+    ``owner`` alive; without an owner the caller guarantees that the memory outlives them."""
     import torch
 
-    return torch.as_tensor(_RawDeviceArray(ptr, numel, dtype_str), device=torch.device(device))
+    return torch.as_tensor(_RawDeviceArray(ptr, numel, dtype_str, owner), device=torch.device(device))
+
+
+class _VmmMemory:
+    """The physical side of a VmmArraySet: released when the last tensor view and the set itself are gone."""
+
+    def __init__(self, ctx, ptrs):
+        self.ctx, self.ptrs = ctx, list(ptrs)
+
+    def release(self):
+        ptrs, self.ptrs = self.ptrs, []
+        for p in ptrs:
+            self.ctx.free(p)  # synchronises the device first
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class VmmArraySet:
     """A working set placed through the virtual-memory API (``fcamd_device_alloc_set``): one float64 array
-    per entry of ``numels`` (name -> element count), physical handles of ``granule`` bytes created array
-    after array or interleaved over all arrays.  ``set[name]`` is a torch view of the array; ``free()``
-    releases the memory (drop the views first).  The experiment behind it: DESIGN.md 6, "VMM placement"."""
+    per entry of ``numels`` (name -> element count), physical handles of ``granule`` bytes (0 = 2 MiB)
+    created array after array or -- the default -- interleaved over all arrays in proportion to their sizes.
+
+    Why: on MI355X the evaluate kernels run 10-28 % slower on one hipMalloc'ed working set than on another
+    (which HBM banks the concurrent streams share); with the arrays of the step interleaved in
+    2 MiB handles, twelve fresh working sets in four processes were within 1.2 % (all arrays) / 2.6 % (the
+    arrays a resident state owns) of each other, at the level of the better torch draws
+    (profiles/r02_placement_vmm.md).
+
+    ``set[name]`` is a torch view; the memory is released when the set and every view are gone
+    (``free()`` releases it at once -- only when no view is in use any more)."""
 
     def __init__(self, ctx, numels: dict, granule: int = 0, interleaved: bool = True, device=None):
         import torch
@@ -100,18 +129,13 @@ class VmmArraySet:
         self.device = torch.device("cuda", ctx.device) if device is None else torch.device(device)
         self.names = list(numels)
         self.numels = {k: int(v) for k, v in numels.items()}
-        self.ptrs = dict(zip(self.names, ctx.alloc_set([8 * self.numels[k] for k in self.names], granule, interleaved)))
+        ptrs = ctx.alloc_set([8 * self.numels[k] for k in self.names], granule, interleaved)
+        self.ptrs = dict(zip(self.names, ptrs))
+        self._mem = _VmmMemory(ctx, ptrs)
 
     def __getitem__(self, name):
-        return tensor_from_pointer(self.ptrs[name], self.numels[name], self.device)
+        return tensor_from_pointer(self.ptrs[name], self.numels[name], self.device, owner=self._mem)
 
     def free(self) -> None:
-        for k, p in list(self.ptrs.items()):
-            self.ctx.free(p)
-            del self.ptrs[k]
-
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:
-            pass
+        self._mem.release()
+        self.ptrs = {}

@@ -72,7 +72,7 @@ class ResidentProblemState:
     AUTO_TUNE_MIN_BYTES = 256 << 20
 
     def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None, reuse_constant_tangent: bool = True,
-                 sparse_history: bool = True, sparse_tangent: bool = True, auto_tune_placement: bool = True):
+                 sparse_history: bool = True, sparse_tangent: bool = True, placement: str = "auto"):
         import torch
 
         from . import _capi
@@ -106,10 +106,13 @@ class ResidentProblemState:
         self.reuse_constant_tangent = reuse_constant_tangent
         self.sparse_tangent = sparse_tangent
         self._failed = None  # the error of the last evaluate, if it raised: nothing to commit
-        # placement of the parent tangent array: tuned on the first device-assembler evaluate unless every
-        # law writes its tangent rows only once per del_t
-        self._auto_tune = bool(auto_tune_placement) and not (
-            reuse_constant_tangent and all(ls.const_tangent for ls in self._laws))
+        # placement of the arrays the launches stream (see ResidentState): "auto" / "vmm" move the parent
+        # stress pair, the parent tangent and every law's history pair into one interleaved VMM working set on
+        # the first device-assembler evaluate; "tune" times candidate allocations of the tangent; "torch": none
+        assert placement in ("auto", "vmm", "tune", "torch")
+        self._placement_mode = placement
+        self._placed = placement == "torch"
+        self._vmm = None
         self.placement = None
 
     @property
@@ -174,9 +177,10 @@ class ResidentProblemState:
         if not isinstance(grads, (list, tuple)):
             grads = [grads]
         assert len(grads) == len(self._laws), "one gradient array per law"
-        if self._auto_tune and 8 * 36 * self.n >= self.AUTO_TUNE_MIN_BYTES:
-            self.tune_placement(grads)  # ends with the evaluate of this call
-            return
+        if not self._placed:
+            self._placed = True
+            if 8 * 36 * self.n >= self.AUTO_TUNE_MIN_BYTES and self._place(grads):
+                return  # tune_placement ended with the evaluate of this call
         self._failed = None
         for ls, g in zip(self._laws, grads):
             if not _is_torch(g):
@@ -307,6 +311,54 @@ class ResidentProblemState:
         self._evaluated = True
         self.check()
 
+    def _place(self, grads) -> bool:
+        if self._placement_mode in ("auto", "vmm"):
+            try:
+                self._move_to_vmm()
+                return False
+            except Exception as e:  # no VMM support / not enough memory for the move: fall back
+                if self._placement_mode == "vmm":
+                    raise
+                self.placement = {"mode": "tune", "vmm_error": f"{type(e).__name__}: {e}"[:200]}
+        if self.reuse_constant_tangent and all(ls.const_tangent for ls in self._laws):
+            return False  # every tangent row is written once per del_t: nothing to tune
+        info = self.tune_placement(grads)
+        self.placement = {**(self.placement or {}), "mode": "tune", **info}
+        return True
+
+    def _move_to_vmm(self) -> None:
+        from . import _capi
+        from .placement import VmmArraySet
+
+        numels = {"tangent": 36 * self.n, "stress0": 6 * self.n, "stress1": 6 * self.n}
+        for i, ls in enumerate(self._laws):
+            if ls.hist is not None:
+                for k, d in ls.law.history_dim.items():
+                    numels[f"law{i}_h0_{k}"] = d * ls.n
+                    numels[f"law{i}_h1_{k}"] = d * ls.n
+        numels = {k: v for k, v in numels.items() if v > 0}
+        vmm = VmmArraySet(_capi.get_context(self.device.index or 0), numels, interleaved=True, device=self.device)
+        new_stress = [vmm["stress0"], vmm["stress1"]]
+        for i in (0, 1):
+            new_stress[i].copy_(self._stress[i])
+        self._stress = new_stress
+        for i, ls in enumerate(self._laws):
+            if ls.hist is None or ls.n == 0:
+                continue
+            new_hist = [{k: vmm[f"law{i}_h{c}_{k}"] for k in ls.hist[c]} for c in (0, 1)]
+            for c in (0, 1):
+                for k in new_hist[c]:
+                    new_hist[c][k].copy_(ls.hist[c][k])
+            ls.hist = new_hist
+        old = self._tangent
+        self._tangent = vmm["tangent"]
+        if old is not None:
+            self._tangent.copy_(old)
+        else:
+            self._tangent.zero_()  # rows of points that belong to no law stay zero, as in a freshly built state
+        self._vmm = vmm
+        self.placement = {"mode": "vmm_interleaved", "arrays": len(numels), "GB": round(8 * sum(numels.values()) / 1e9, 2)}
+
     def tune_placement(self, grads, tries: int = 4) -> dict:
         """Choose the placement of the parent tangent array (the dominant write stream of every law's
         launch) by timing one full ``evaluate(grads)`` on a few candidate allocations and keeping the
@@ -314,7 +366,7 @@ class ResidentProblemState:
         leaves a valid trial state for ``grads``."""
         from .placement import fastest_allocation
 
-        self._auto_tune = False
+        self._placed = True
 
         def probe(tan):
             self.tangent = tan
@@ -328,7 +380,8 @@ class ResidentProblemState:
         del first
         chosen.zero_()  # rows of points that belong to no law stay zero, as in a freshly built state
         probe(chosen)
-        self.placement = info
+        if self.placement is None:
+            self.placement = {"mode": "tune", **info}
         return info
 
     def check(self) -> None:

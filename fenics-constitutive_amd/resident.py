@@ -32,13 +32,22 @@ __all__ = ["ResidentState"]
 
 
 class ResidentState:
-    #: device-assembler mode: tune the placement of the tangent array on the first ``evaluate`` when it
-    #: is at least this large (below, launches are latency-bound and the placement does not show)
+    #: device-assembler mode: place the state's arrays on the first ``evaluate`` when the tangent is at
+    #: least this large (below, launches are latency-bound and the placement does not show)
     AUTO_TUNE_MIN_BYTES = 256 << 20
 
     def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
-                 reuse_constant_tangent: bool = True, sparse_tangent: bool = True, auto_tune_placement: bool = True):
+                 reuse_constant_tangent: bool = True, sparse_tangent: bool = True, placement: str = "auto"):
+        """``placement`` (device-assembler mode, large states): where the arrays the kernel streams
+        live decides 10-28 % of its time on MI355X.  "vmm": on the first ``evaluate`` the state moves its arrays
+        (both stress / history copies, tangent, gradient staging) into ONE working set whose 2 MiB physical
+        handles are interleaved over the arrays (``placement.VmmArraySet``) -- reproducible to ~2 %, at the
+        level of the better hipMalloc draws; "tune": time a few candidate allocations of the tangent with the
+        state's own launch and keep the fastest (``tune_placement``); "torch": take what the allocator gives;
+        "auto" (default): "vmm", falling back to "tune" if the virtual-memory API is not available."""
         import torch
+
+        assert placement in ("auto", "vmm", "tune", "torch")
 
         self.law, self.n = law, int(n)
         from . import _capi
@@ -98,12 +107,10 @@ class ResidentState:
         self._counters = new_counters(self.device) if self._counts else None
         self._stats_pending = False  # a device launch whose counters have not been looked at yet
         self._failed = None          # the error of the last evaluate, if it raised: nothing to commit
-        # Placement of the tangent array: on MI355X the kernel time follows where the driver
-        # puts the dominant write stream, by up to 20 %.  The first device-assembler evaluate therefore times
-        # a few candidate allocations with its own launch and keeps the fastest (tune_placement); laws whose
-        # tangent is written once per del_t have nothing to gain.
-        self._auto_tune = bool(auto_tune_placement) and not self._const_tangent
-        self.placement = None  # candidate timings of the tuning, once it has run
+        self._placement_mode = placement
+        self._placed = placement == "torch"  # nothing to do
+        self._vmm = None
+        self.placement = None  # what the placement step did, once it has run
 
     def _as_dev(self, a):
         import torch
@@ -181,9 +188,14 @@ class ResidentState:
             self.grad.copy_(self._as_dev(g), non_blocking=True)
             g = self.grad
         assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
-        if self._auto_tune and 8 * self._sd * self._sd * self.n >= self.AUTO_TUNE_MIN_BYTES:
-            self.tune_placement(t, del_t, g)  # ends with the evaluate of this call
-            return
+        if not self._placed:
+            self._placed = True
+            if 8 * self._sd * self._sd * self.n >= self.AUTO_TUNE_MIN_BYTES:
+                if self._place(t, del_t, g, staging=not _is_torch(grad_del_u)):
+                    return  # tune_placement ended with the evaluate of this call
+                if g is not grad_del_u:  # the staging buffer moved: upload again
+                    self.grad.copy_(self._as_dev(grad_del_u), non_blocking=True)
+                    g = self.grad
         tangent = self.tangent
         key = None
         if self._const_tangent:
@@ -200,13 +212,61 @@ class ResidentState:
         self._evaluated = True
         self._stats_pending = self._counts
 
+    def _place(self, t, del_t, g, staging: bool) -> bool:
+        """First large device-assembler evaluate: move the state into an interleaved VMM working set
+        ("vmm" / "auto") or tune the tangent allocation ("tune").  True if the evaluate has been done."""
+        if self._placement_mode in ("auto", "vmm"):
+            try:
+                self._move_to_vmm(staging)
+                return False
+            except Exception as e:  # no VMM support / not enough memory for the move: fall back
+                if self._placement_mode == "vmm":
+                    raise
+                self.placement = {"mode": "tune", "vmm_error": f"{type(e).__name__}: {e}"[:200]}
+        if self._const_tangent:
+            return False  # the tangent is written once per del_t: nothing to tune
+        info = self.tune_placement(t, del_t, g)
+        self.placement = {**(self.placement or {}), "mode": "tune", **info}
+        return True
+
+    def _move_to_vmm(self, staging: bool) -> None:
+        from . import _capi
+        from .placement import VmmArraySet
+
+        n, sd = self.n, self._sd
+        numels = {"tangent": sd * sd * n, "stress0": sd * n, "stress1": sd * n}
+        if self._hist is not None:
+            for k, d in self.law.history_dim.items():
+                numels[f"h0_{k}"] = d * n
+                numels[f"h1_{k}"] = d * n
+        if staging or self._grad is not None:
+            numels["grad"] = self._gd2 * n
+        ctx = _capi.get_context(self.device.index or 0)
+        vmm = VmmArraySet(ctx, numels, interleaved=True, device=self.device)
+        new_stress = [vmm["stress0"], vmm["stress1"]]
+        for i in (0, 1):
+            new_stress[i].copy_(self._stress[i])
+        self._stress = new_stress
+        if self._hist is not None:
+            new_hist = [{k: vmm[f"h{i}_{k}"] for k in self._hist[i]} for i in (0, 1)]
+            for i in (0, 1):
+                for k in new_hist[i]:
+                    new_hist[i][k].copy_(self._hist[i][k])
+            self._hist = new_hist
+        self._tangent = vmm["tangent"]
+        self._tangent_key = self._tangent_target = None  # the new tangent array holds nothing yet
+        if "grad" in numels:
+            self._grad = vmm["grad"]
+        self._vmm = vmm
+        self.placement = {"mode": "vmm_interleaved", "arrays": list(numels), "GB": round(8 * sum(numels.values()) / 1e9, 2)}
+
     def tune_placement(self, t: float, del_t: float, grad_del_u, tries: int = 4) -> dict:
         """Device-assembler mode: choose the placement of the tangent array (the dominant write
         stream) by timing this state's own evaluate on a few candidate allocations and keeping the
         fastest (``placement.fastest_allocation``; on MI355X the kernel time follows where the
-        written arrays live, by up to 20 %).  Runs by itself on the first ``evaluate`` of a large state
-        (``auto_tune_placement``); leaves a valid trial state for ``grad_del_u``.  Returns the candidate
-        timings (also kept as ``self.placement``)."""
+        written arrays live, by up to 20 %).  The ``placement="tune"`` mode of the state (and the fallback
+        of "auto") runs it on the first ``evaluate``; leaves a valid trial state for ``grad_del_u``.
+        Returns the candidate timings."""
         from .placement import fastest_allocation
 
         g = grad_del_u
@@ -214,7 +274,7 @@ class ResidentState:
             self.grad.copy_(self._as_dev(g), non_blocking=True)
             g = self.grad
         assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
-        self._auto_tune = False
+        self._placed = True
         first, self._tangent = self._tangent, None
         self._tangent_target = None  # the candidates hold no previous tangent: every probe writes every row
         self._tangent, info = fastest_allocation(
@@ -222,7 +282,8 @@ class ResidentState:
             tries=tries, device=self.device, first=first)
         del first
         self._tangent_key = None  # a constant tangent has to be written into the chosen array
-        self.placement = info
+        if self.placement is None:
+            self.placement = {"mode": "tune", **info}
         self.evaluate(t, del_t, g)
         return info
 

@@ -392,8 +392,8 @@ int fcamd_allgather_direct_wait(fcamd_context* ctx, int host_sync);
 
 /* ---- device memory -------------------------------------------------------------- */
 /* A working set whose physical placement is chosen by the call: `n_arrays` address ranges of bytes[k]
-   bytes (rounded up to the granule), backed by physical handles of `granule_bytes` (0 = the device's
-   recommended granularity, 2 MiB) created either array after array (FCAMD_ALLOC_SEQUENTIAL) or
+   bytes (rounded up to the granule), backed by physical handles of `granule_bytes` (0 = 2 MiB; rounded up
+   to the device's allocation granularity) created either array after array (FCAMD_ALLOC_SEQUENTIAL) or
    interleaved over all arrays in proportion to their sizes (FCAMD_ALLOC_INTERLEAVED) through
    hipMemAddressReserve / hipMemCreate / hipMemMap.  Background: on MI355X the kernel time follows where
    the written arrays live.  ptrs[k] receives the base of array k; each array is released

@@ -123,14 +123,11 @@ def test_contexts_die_with_their_thread():
         th.start()
         th.join()
     assert law.n_handles_created == 3
-    ctxs = [c for c, _ in seen]
-    assert len({id(c) for c in ctxs}) == 3  # one context per thread, none inherited
-    for _, s in seen:
-        assert np.array_equal(s, seen[0][1])
-    del ctxs
     import weakref
 
-    refs = [weakref.ref(c) for c, _ in seen]
+    assert len({id(pair[0]) for pair in seen}) == 3  # one context per thread, none inherited
+    assert all(np.array_equal(pair[1], seen[0][1]) for pair in seen)
+    refs = [weakref.ref(pair[0]) for pair in seen]
     seen.clear()
     gc.collect()
     assert all(r() is None for r in refs)  # nothing keeps a dead thread's context alive

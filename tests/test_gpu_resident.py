@@ -284,3 +284,38 @@ def test_evaluate_into_downloads_a_constant_tangent_once():
         t[:] = -7.0
         st2.evaluate_into(0.0, 1.0, g, so, t)
         assert np.array_equal(t, ref)
+
+
+@pytest.mark.parametrize("numpy_grad", [False, True])
+def test_vmm_placement_moves_the_state_and_keeps_results(numpy_grad):
+    """placement="vmm" (the default for large device-assembler states): on the first evaluate the state moves
+    both stress / history copies, the tangent (and the gradient staging buffer) into one interleaved VMM
+    working set; every number equals the torch-allocated state's over iterations and commits, and views
+    handed out stay valid after the state is gone."""
+    import gc
+
+    n = 1_000_003  # 288 MB of tangent: above ResidentState.AUTO_TUNE_MIN_BYTES
+    rng = np.random.default_rng(3)
+    law, s0, h0, grad = _sparse_case("VonMises3D", n, rng)
+    a = ResidentState(law, n, stress0=s0, history0=h0, placement="torch")
+    b = ResidentState(law, n, stress0=s0, history0=h0, placement="vmm")
+    assert b.placement is None and b._vmm is None
+    for inc in range(2):
+        for it in range(2):
+            g = grad(all_elastic=False, zoned=(it == 1))
+            gb = g.cpu().numpy() if numpy_grad else g
+            a.evaluate(0.0, 1.0, g)
+            b.evaluate(0.0, 1.0, gb)
+            assert torch.equal(a.stress, b.stress) and torch.equal(a.tangent, b.tangent), (inc, it)
+            for k in h0:
+                assert torch.equal(a.history[k], b.history[k]) and torch.equal(a.history_committed[k], b.history_committed[k])
+        a.update()
+        b.update()
+    assert b.placement["mode"] == "vmm_interleaved" and ("grad" in b.placement["arrays"]) == numpy_grad
+    assert a.placement is None
+    assert b.tangent.data_ptr() % (2 << 20) == 0 and b.stress.data_ptr() % (2 << 20) == 0
+    keep, ref = b.stress_committed, a.stress_committed.clone()
+    del b
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.equal(keep, ref)  # the view keeps the working set's memory alive
