@@ -212,9 +212,27 @@ class Workload:
             first=self.tangent)
         self.launch_log.append(["placement_candidates", 4 * len(self.placement["candidate_ms"])])
 
-    def place_vmm(self):
-        """The product's default placement (ResidentState(placement="auto")): every array of the step in ONE
-        working set whose 2 MiB physical handles are interleaved over the arrays (placement.VmmArraySet)."""
+    def _arrays(self):
+        return {"tangent": self.tangent, "stress_c": self.stress_c, "stress_t": self.stress_t, "grads": self.grads,
+                "hist_c": self.hist_c, "hist_t": self.hist_t}
+
+    def _time_iterate0(self, launches=3):
+        """min of `launches` event-timed launches of iterate 0 (after one warm launch), as fastest_allocation times a candidate"""
+        torch = self.torch
+        self.launch(0, sparse_tangent=False)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for a, b in ev:
+            a.record()
+            self.launch(0, sparse_tangent=False)
+            b.record()
+        torch.cuda.synchronize()
+        return min(a.elapsed_time(b) for a, b in ev)
+
+    def place_vmm(self, keep_if_faster_than=None):
+        """Every array of the step in ONE working set whose 2 MiB physical handles are interleaved over the
+        arrays (placement.VmmArraySet) -- what ResidentState(placement="auto" / "vmm") does with its arrays.
+        `keep_if_faster_than` (ms): "auto" mode -- time iterate 0 on the set and go back to the hipMalloc arrays
+        if they were faster."""
         from fenics_constitutive_amd.placement import VmmArraySet
 
         n = self.n
@@ -233,18 +251,44 @@ class Workload:
             dst.copy_(src)
             return dst
 
+        old = self._arrays()
         self.tangent = vmm["tangent"]  # rewritten by every launch: nothing to copy
-        self.stress_c, self.stress_t = moved("stress_c", self.stress_c), moved("stress_t", self.stress_t)
-        g0 = moved("grad0", self.grads[0])
-        self.grads = [g0, moved("grad1", self.grads[1]) if two else g0]
-        if self.hist_c is not None:
-            self.hist_c = {k: moved("hc_" + k, v) for k, v in self.hist_c.items()}
-            self.hist_t = {k: moved("ht_" + k, v) for k, v in self.hist_t.items()}
+        self.stress_c, self.stress_t = moved("stress_c", old["stress_c"]), moved("stress_t", old["stress_t"])
+        g0 = moved("grad0", old["grads"][0])
+        self.grads = [g0, moved("grad1", old["grads"][1]) if two else g0]
+        if old["hist_c"] is not None:
+            self.hist_c = {k: moved("hc_" + k, v) for k, v in old["hist_c"].items()}
+            self.hist_t = {k: moved("ht_" + k, v) for k, v in old["hist_t"].items()}
         self.torch.cuda.synchronize()
+        info = {"mode": "vmm_interleaved", "arrays": len(numels), "GB": round(8 * sum(numels.values()) / 1e9, 2),
+                "granule_MiB": 2, "build_s": round(time.perf_counter() - t0, 2)}
+        if keep_if_faster_than is not None:
+            info["vmm_ms"] = round(self._time_iterate0(), 4)
+            self.launch_log.append(["vmm_candidate", 4])
+            info["hipmalloc_best_ms"] = round(keep_if_faster_than, 4)
+            if info["vmm_ms"] >= keep_if_faster_than:  # the tuned hipMalloc arrays win: back to them
+                for k, v in old.items():
+                    setattr(self, k, v)
+                del vmm
+                info["mode"] = "hipmalloc_tuned"
+                self.vmm_info = info
+                self.torch.cuda.empty_cache()
+                return
+        del old
         self.torch.cuda.empty_cache()
         self._vmm = vmm
-        self.vmm_info = {"mode": "vmm_interleaved", "arrays": len(numels), "GB": round(8 * sum(numels.values()) / 1e9, 2),
-                         "granule_MiB": 2, "build_s": round(time.perf_counter() - t0, 2)}
+        self.vmm_info = info
+
+    def place(self, mode, tries):
+        """first: what the allocator gives; tune: the fastest of `tries` hipMalloc candidates of the tangent; vmm:
+        the interleaved VMM working set; auto (= ResidentState's default): the faster of the two."""
+        if mode != "first":
+            self.tune_placement(tries)  # in "vmm" mode for the record only: what the hipMalloc draws give
+        if mode == "vmm":
+            self.place_vmm()
+        elif mode == "auto":
+            best = min(self.placement["candidate_ms"]) if self.placement else self._time_iterate0()
+            self.place_vmm(keep_if_faster_than=best)
 
     def count_plastic(self):
         """Plastic counts / Newton iterations of the two iterates (two more untimed launches)."""
@@ -303,18 +347,18 @@ def placement_fracs(wl, alg0):
     frac = lambda t: round(alg0 / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)  # noqa: E731
     srt = sorted(ms)
     med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
-    return {"frac_first_allocation": frac(ms[0]), "frac_median_candidate": frac(med), "frac_worst_candidate": frac(srt[-1]),
-            "frac_best_candidate": frac(srt[0])}
+    out = {"frac_first_allocation": frac(ms[0]), "frac_median_candidate": frac(med), "frac_worst_candidate": frac(srt[-1]),
+           "frac_best_candidate": frac(srt[0])}
+    if wl.vmm_info and "vmm_ms" in wl.vmm_info:
+        out["frac_vmm_set"] = frac(wl.vmm_info["vmm_ms"])
+    return out
 
 
-def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse", placement="vmm"):
+def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse", placement="auto"):
     """One extra configuration, same method as the headline: placement, warm up, count, >= 5 event-timed launches."""
     wl = Workload(name, n, seed, device, dev_index, history=history)
     try:
-        if placement != "first":
-            wl.tune_placement(tries)  # in "vmm" mode only for the record: what the hipMalloc draws would have given
-        if placement == "vmm":
-            wl.place_vmm()
+        wl.place(placement, tries)
         wl.warmup(warmup)
         wl.count_plastic()
         ms = wl.timed_events(steps)
@@ -331,7 +375,9 @@ def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="
         out.update(placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])))
         if wl.placement:
             out["placement_candidate_ms"] = wl.placement["candidate_ms"]
-        out["placement_mode"] = (wl.vmm_info or {}).get("mode", "tune" if wl.placement else "first")
+        out["placement_mode"] = (wl.vmm_info or {}).get("mode", "hipmalloc_tuned" if wl.placement else "first")
+        if wl.vmm_info and "vmm_ms" in wl.vmm_info:
+            out["placement_vmm_ms"] = wl.vmm_info["vmm_ms"]
         out["launch_log"] = wl.launch_log
         return out
     finally:
@@ -550,10 +596,11 @@ def main():
                     help="with --history sparse: also the sparse-tangent protocol of ResidentState (FCAMD_EVAL_SPARSE_TANGENT: "
                          "rows of points that stay elastic are not rewritten).  Not the reference contract -- the reported "
                          "bytes stay the interface's 464/568 B/pt, so `frac` is an equivalent, not a traffic, figure")
-    ap.add_argument("--placement", choices=["vmm", "tune", "first"], default="vmm",
-                    help="where the arrays of the timed steps live (DESIGN.md 6): vmm (default, = ResidentState's default) "
-                         "one working set with 2 MiB physical handles interleaved over the arrays; tune = the fastest of "
-                         "--placement-tries hipMalloc candidates of the tangent; first = what the allocator gives")
+    ap.add_argument("--placement", choices=["auto", "vmm", "tune", "first"], default="auto",
+                    help="where the arrays of the timed steps live (DESIGN.md 6): vmm = one working set with 2 MiB physical "
+                         "handles interleaved over the arrays; tune = the fastest of --placement-tries hipMalloc candidates of "
+                         "the tangent; auto (default, = ResidentState's default) = the faster of the two; first = what the "
+                         "allocator gives")
     ap.add_argument("--placement-tries", type=int, default=6,
                     help="hipMalloc candidate allocations of the tangent array, timed with the real kernel before the run "
                          "(fenics_constitutive_amd.placement): in tune mode the fastest is kept, in vmm mode they are "
@@ -615,10 +662,7 @@ def main():
         from fenics_constitutive_amd.placement import max_tries_for_memory
 
         tries = max_tries_for_memory(36 * n, tries, device, reserve_bytes=16 << 30)
-    if args.placement != "first":
-        wl.tune_placement(tries)
-    if args.placement == "vmm":
-        wl.place_vmm()
+    wl.place(args.placement, tries)
     wl.warmup(args.warmup)
     wl.count_plastic()
     n_pl, n_its = wl.mean_plastic(args.steps)
@@ -754,7 +798,7 @@ def main():
             out["full_trial_history"] = {"kernel_ms_avg": round(full_ms, 4),
                                          "frac": round(alg_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          "note": "same step, whole trial history rewritten by every launch (--history full)"}
-        out["placement"] = dict(headline["vmm_info"] or {"mode": "tune" if headline["placement"] else "first"})
+        out["placement"] = dict(headline["vmm_info"] or {"mode": "hipmalloc_tuned" if headline["placement"] else "first"})
         if headline["placement"] is not None:
             out["placement"].update({"hipmalloc_tangent_" + k: v for k, v in headline["placement"].items()})
             out["placement"]["tries"] = tries

@@ -179,8 +179,8 @@ class ResidentProblemState:
         assert len(grads) == len(self._laws), "one gradient array per law"
         if not self._placed:
             self._placed = True
-            if 8 * 36 * self.n >= self.AUTO_TUNE_MIN_BYTES and self._place(grads):
-                return  # tune_placement ended with the evaluate of this call
+            if 8 * 36 * self.n >= self.AUTO_TUNE_MIN_BYTES:
+                self._place(grads)
         self._failed = None
         for ls, g in zip(self._laws, grads):
             if not _is_torch(g):
@@ -311,20 +311,54 @@ class ResidentProblemState:
         self._evaluated = True
         self.check()
 
-    def _place(self, grads) -> bool:
-        if self._placement_mode in ("auto", "vmm"):
+    def _place(self, grads) -> None:
+        """See ResidentState._place: "tune", "vmm", or ("auto") the faster of the two."""
+        mode, best_ms = self._placement_mode, None
+        if mode in ("auto", "tune") and not (self.reuse_constant_tangent and all(ls.const_tangent for ls in self._laws)):
+            info = self.tune_placement(grads)
+            best_ms = min(info["candidate_ms"])
+            self.placement = {"mode": "hipmalloc_tuned", **info}
+        if mode in ("auto", "vmm"):
+            saved = (self._stress, [ls.hist for ls in self._laws], self._tangent)
+
+            def restore():
+                self._stress, hists, self._tangent = saved
+                for ls, h in zip(self._laws, hists):
+                    ls.hist = h
+                self._vmm = None
+
             try:
                 self._move_to_vmm()
-                return False
-            except Exception as e:  # no VMM support / not enough memory for the move: fall back
-                if self._placement_mode == "vmm":
+                if best_ms is not None:
+                    vmm_ms = self._time_evaluate(grads)
+                    self.placement.update({"vmm_ms": round(vmm_ms, 4), "hipmalloc_best_ms": round(best_ms, 4)})
+                    if vmm_ms >= best_ms:  # the tuned hipMalloc arrays win: back to them
+                        restore()
+                        self.placement["mode"] = "hipmalloc_tuned"
+            except Exception as e:  # no VMM support / no room for the move: keep what there is
+                if mode == "vmm":
                     raise
-                self.placement = {"mode": "tune", "vmm_error": f"{type(e).__name__}: {e}"[:200]}
-        if self.reuse_constant_tangent and all(ls.const_tangent for ls in self._laws):
-            return False  # every tangent row is written once per del_t: nothing to tune
-        info = self.tune_placement(grads)
-        self.placement = {**(self.placement or {}), "mode": "tune", **info}
-        return True
+                restore()
+                self.placement = {**(self.placement or {"mode": "torch"}), "vmm_error": f"{type(e).__name__}: {e}"[:200]}
+            for ls in self._laws:
+                ls.tangent_key = ls.tangent_target = None  # whichever tangent array it is: written in full next
+
+    def _time_evaluate(self, grads, launches: int = 3) -> float:
+        import torch
+
+        def full():
+            for ls in self._laws:
+                ls.tangent_key = ls.tangent_target = None
+            self.evaluate(grads)
+
+        full()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for x, y in ev:
+            x.record()
+            full()
+            y.record()
+        torch.cuda.synchronize(self.device)
+        return min(x.elapsed_time(y) for x, y in ev)
 
     def _move_to_vmm(self) -> None:
         from . import _capi
@@ -357,7 +391,8 @@ class ResidentProblemState:
         else:
             self._tangent.zero_()  # rows of points that belong to no law stay zero, as in a freshly built state
         self._vmm = vmm
-        self.placement = {"mode": "vmm_interleaved", "arrays": len(numels), "GB": round(8 * sum(numels.values()) / 1e9, 2)}
+        self.placement = {**(self.placement or {}), "mode": "vmm_interleaved", "arrays": len(numels),
+                          "GB": round(8 * sum(numels.values()) / 1e9, 2)}
 
     def tune_placement(self, grads, tries: int = 4) -> dict:
         """Choose the placement of the parent tangent array (the dominant write stream of every law's
@@ -381,7 +416,7 @@ class ResidentProblemState:
         chosen.zero_()  # rows of points that belong to no law stay zero, as in a freshly built state
         probe(chosen)
         if self.placement is None:
-            self.placement = {"mode": "tune", **info}
+            self.placement = {"mode": "hipmalloc_tuned", **info}
         return info
 
     def check(self) -> None:

@@ -184,18 +184,17 @@ class ResidentState:
         increment; the committed state is never modified.  Asynchronous; Newton non-convergence surfaces at
         ``check()`` / ``update()``."""
         g = grad_del_u
-        if not _is_torch(g):
+        staging = not _is_torch(g)
+        if staging:
             self.grad.copy_(self._as_dev(g), non_blocking=True)
             g = self.grad
         assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
         if not self._placed:
             self._placed = True
             if 8 * self._sd * self._sd * self.n >= self.AUTO_TUNE_MIN_BYTES:
-                if self._place(t, del_t, g, staging=not _is_torch(grad_del_u)):
-                    return  # tune_placement ended with the evaluate of this call
-                if g is not grad_del_u:  # the staging buffer moved: upload again
-                    self.grad.copy_(self._as_dev(grad_del_u), non_blocking=True)
-                    g = self.grad
+                self._place(t, del_t, g, staging)
+                if staging:
+                    g = self.grad  # the staging buffer may have moved (its contents moved along)
         tangent = self.tangent
         key = None
         if self._const_tangent:
@@ -212,22 +211,46 @@ class ResidentState:
         self._evaluated = True
         self._stats_pending = self._counts
 
-    def _place(self, t, del_t, g, staging: bool) -> bool:
-        """First large device-assembler evaluate: move the state into an interleaved VMM working set
-        ("vmm" / "auto") or tune the tangent allocation ("tune").  True if the evaluate has been done."""
-        if self._placement_mode in ("auto", "vmm"):
+    def _place(self, t, del_t, g, staging: bool) -> None:
+        """First large device-assembler evaluate: "tune" -- the fastest of a few hipMalloc candidates of the
+        tangent; "vmm" -- the state's arrays in one interleaved VMM working set; "auto" -- both, timed with the
+        state's own launch, the faster kept (the hipMalloc draws spread over 10-28 % but their best can beat the
+        VMM set by a few per cent; the VMM set is within ~5 % of that best on every box seen so far)."""
+        mode, best_ms = self._placement_mode, None
+        if mode in ("auto", "tune") and not self._const_tangent:  # a tangent written once per del_t: nothing to tune
+            info = self.tune_placement(t, del_t, g)
+            best_ms = min(info["candidate_ms"])
+            self.placement = {"mode": "hipmalloc_tuned", **info}
+        if mode in ("auto", "vmm"):
+            saved = (self._stress, self._hist, self._tangent, self._grad)
             try:
                 self._move_to_vmm(staging)
-                return False
-            except Exception as e:  # no VMM support / not enough memory for the move: fall back
-                if self._placement_mode == "vmm":
+                if best_ms is not None:
+                    vmm_ms = self._time_launch(t, del_t, self._grad if staging else g)
+                    self.placement.update({"vmm_ms": round(vmm_ms, 4), "hipmalloc_best_ms": round(best_ms, 4)})
+                    if vmm_ms >= best_ms:  # the tuned hipMalloc arrays win: back to them
+                        self._stress, self._hist, self._tangent, self._grad = saved
+                        self._vmm = None
+                        self.placement["mode"] = "hipmalloc_tuned"
+            except Exception as e:  # no VMM support / no room for the move: keep what there is
+                if mode == "vmm":
                     raise
-                self.placement = {"mode": "tune", "vmm_error": f"{type(e).__name__}: {e}"[:200]}
-        if self._const_tangent:
-            return False  # the tangent is written once per del_t: nothing to tune
-        info = self.tune_placement(t, del_t, g)
-        self.placement = {**(self.placement or {}), "mode": "tune", **info}
-        return True
+                self._stress, self._hist, self._tangent, self._grad = saved
+                self._vmm = None
+                self.placement = {**(self.placement or {"mode": "torch"}), "vmm_error": f"{type(e).__name__}: {e}"[:200]}
+            self._tangent_key = self._tangent_target = None  # whichever tangent array it is: written in full next
+
+    def _time_launch(self, t, del_t, g, launches: int = 3) -> float:
+        import torch
+
+        self._launch(t, del_t, g, self.tangent)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for a, b in ev:
+            a.record()
+            self._launch(t, del_t, g, self.tangent)
+            b.record()
+        torch.cuda.synchronize(self.device)
+        return min(a.elapsed_time(b) for a, b in ev)
 
     def _move_to_vmm(self, staging: bool) -> None:
         from . import _capi
@@ -246,19 +269,22 @@ class ResidentState:
         new_stress = [vmm["stress0"], vmm["stress1"]]
         for i in (0, 1):
             new_stress[i].copy_(self._stress[i])
-        self._stress = new_stress
         if self._hist is not None:
             new_hist = [{k: vmm[f"h{i}_{k}"] for k in self._hist[i]} for i in (0, 1)]
             for i in (0, 1):
                 for k in new_hist[i]:
                     new_hist[i][k].copy_(self._hist[i][k])
             self._hist = new_hist
+        self._stress = new_stress
         self._tangent = vmm["tangent"]
-        self._tangent_key = self._tangent_target = None  # the new tangent array holds nothing yet
         if "grad" in numels:
-            self._grad = vmm["grad"]
+            new_grad = vmm["grad"]
+            if self._grad is not None:
+                new_grad.copy_(self._grad)
+            self._grad = new_grad
         self._vmm = vmm
-        self.placement = {"mode": "vmm_interleaved", "arrays": list(numels), "GB": round(8 * sum(numels.values()) / 1e9, 2)}
+        self.placement = {**(self.placement or {}), "mode": "vmm_interleaved", "arrays": list(numels),
+                          "GB": round(8 * sum(numels.values()) / 1e9, 2)}
 
     def tune_placement(self, t: float, del_t: float, grad_del_u, tries: int = 4) -> dict:
         """Device-assembler mode: choose the placement of the tangent array (the dominant write
@@ -283,7 +309,7 @@ class ResidentState:
         del first
         self._tangent_key = None  # a constant tangent has to be written into the chosen array
         if self.placement is None:
-            self.placement = {"mode": "tune", **info}
+            self.placement = {"mode": "hipmalloc_tuned", **info}
         self.evaluate(t, del_t, g)
         return info
 
