@@ -537,6 +537,147 @@ __device__ __forceinline__ void tile_sls(const EvalArgs& a, const StressBases& s
     transpose_out<6, FULL, NT>(en, region, lane, a.h1_out + p0 * 6, npts * 6);
 }
 
+// ---------------------------------------------------------------------------------------
+// Point arithmetic of the two Mises laws, shared by the 3-D tiles and the fused 3D -> 1D/2D wrapper tiles
+// (tile_von_mises / tile_von_mises_wrapped, tile_comfe_mises / tile_comfe_mises_wrapped): every statement
+// of the reference exists once.  Everything is per lane and forced inline.
+// ---------------------------------------------------------------------------------------
+
+// VonMises3D (models/mises_plasticity_isotropic_hardening.py:75-94): trial state of one point
+struct VMTrial {
+    double dsig[6], sigtr[6];  // del_sigtr = 2 mu dev(d_eps), sigtr = dev(sigma_n) + del_sigtr
+    double tr_eps, sigtrn, phitr;
+};
+
+__device__ __forceinline__ void vm_trial(const Scalars& sc, const double (&e)[6], const double (&s)[6], double alpha_n,
+                                         VMTrial& t) {
+    const double two_mu = sc.s[2], s23 = sc.s[3], y0 = sc.s[4], dy = sc.s[5], mw = sc.s[6];
+    t.tr_eps = (e[0] + e[1]) + e[2];
+    const double tr_sig = (s[0] + s[1]) + s[2];
+    const double tr_eps3 = t.tr_eps / 3.0, tr_sig3 = tr_sig / 3.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double ed = i < 3 ? e[i] - tr_eps3 : e[i];
+        const double sd = i < 3 ? s[i] - tr_sig3 : s[i];
+        t.dsig[i] = two_mu * ed;
+        t.sigtr[i] = sd + t.dsig[i];
+    }
+    double nn = t.sigtr[0] * t.sigtr[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) nn = __builtin_fma(t.sigtr[i], t.sigtr[i], nn);  // np.dot == fma chain
+    t.sigtrn = sqrt(nn);
+    t.phitr = t.sigtrn - s23 * (y0 + dy * (1.0 - exp(mw * alpha_n)));
+}
+
+// return mapping of one plastic point (:98-151): Newton on the plastic multiplier with the reference's
+// stopping rule (it tests the residual of the PREVIOUS iterate, so one more update follows convergence)
+struct VMReturn {
+    double gamma = 0.0, xc1 = 0.0, xc2 = 0.0;
+    double N[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+};
+
+__device__ __forceinline__ void vm_return(const Scalars& sc, const VMTrial& t, double alpha_n, VMReturn& r, WaveStats& st) {
+    const double two_mu = sc.s[2], s23 = sc.s[3], y0 = sc.s[4], dy = sc.s[5], mw = sc.s[6], m2mu = sc.s[7], c23dyw = sc.s[8];
+    double g0 = 1.0, g1 = 0.0, xr = 1.0, xg;
+    int it = 0;
+    bool failed = false;
+    while (__builtin_fabs(xr) > 1e-12 && __builtin_fabs(g1 - g0) > 1e-8 * __builtin_fabs(g1)) {
+        g0 = g1;
+        ++it;
+        const double ex = exp(mw * (alpha_n + s23 * g0));
+        xr = (t.sigtrn - two_mu * g0) - s23 * (y0 + dy * (1.0 - ex));
+        xg = m2mu - c23dyw * ex;
+        g1 = g0 - xr / xg;
+        if (it > 100) {
+            failed = true;
+            break;
+        }
+    }
+    const double ex = exp(mw * (alpha_n + s23 * g1));
+    xg = m2mu - c23dyw * ex;
+    r.xc1 = -1.0 / xg;
+    r.xc2 = g1 / t.sigtrn;
+    r.gamma = g1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.N[i] = t.sigtr[i] / t.sigtrn;
+    st.iters += (unsigned long long)it;
+    st.nonconv += failed ? 1ull : 0ull;
+}
+
+// stress (:165-167): sigma += (ka tr_eps) I2 + del_sigtr - (2 mu gamma) N;  tangent coefficients (:170-175)
+__device__ __forceinline__ void vm_stress(const Scalars& sc, const VMTrial& t, const VMReturn& r, double (&s)[6]) {
+    const double kt = sc.s[1] * t.tr_eps, tmg = sc.s[2] * r.gamma;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double vol = i < 3 ? kt : kt * 0.0;
+        s[i] = s[i] + ((vol + t.dsig[i]) - tmg * r.N[i]);
+    }
+}
+__device__ __forceinline__ void vm_tangent_coefficients(const Scalars& sc, const VMReturn& r, double& B, double& C) {
+    const double two_mu = sc.s[2], four_mu2 = sc.s[9];
+    B = two_mu * (1.0 - two_mu * r.xc2);
+    C = four_mu2 * (r.xc2 - r.xc1);
+}
+
+// comfe-rs MisesPlasticity3D (mises_plasticity.rs:58-126): the whole update of one point.  In: e, s (sigma_n),
+// h = [alpha, eps_p(6)].  Out: s (total stress), h (updated if plastic), tangent parameters B, sc2 and the
+// (non-unit) flow direction nv.  Returns whether the point is plastic.
+__device__ __forceinline__ bool cm_point(const Scalars& sc, bool live, const double (&e)[6], double (&s)[6], double (&h)[7],
+                                         double& B, double& sc2, double (&nv)[6]) {
+    const double kappa = sc.s[2], y_0 = sc.s[3], hh = sc.s[4], two_mu = sc.s[5], den = sc.s[6], s32 = sc.s[7],
+                 three_mu = sc.s[8], hfac = sc.s[9];
+    const double alpha = h[0];
+    // (p_0, s_0) = vol_dev(sigma) ; (tr, dev) = trace_dev(d_eps)
+    const double p_0 = ((s[0] + s[1]) + s[2]) / 3.0;
+    const double eps_trace = (e[0] + e[1]) + e[2];
+    const double eps_vol = eps_trace / 3.0;
+    const double p_1 = p_0 + kappa * eps_trace;
+    double s_tr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double s0 = i < 3 ? s[i] + (-p_0) : s[i];
+        const double ed = i < 3 ? e[i] + (-eps_vol) : e[i];
+        s_tr[i] = s0 + two_mu * ed;
+    }
+    // mises_norm(): deviator once more, sqrt(3 * (0.5 * |dev|^2)), sequential sum
+    const double v3 = ((s_tr[0] + s_tr[1]) + s_tr[2]) / 3.0;
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double d = i < 3 ? s_tr[i] + (-v3) : s_tr[i];
+        n2 = i == 0 ? d * d : n2 + d * d;
+    }
+    const double q = sqrt(3.0 * (0.5 * n2));
+    const double sigma_y = y_0 + hh * alpha;
+    const bool plastic = live && !(q < sigma_y);  // strict "<" elastic test (:95)
+
+    double theta = 1.0;
+    sc2 = 0.0;  // 2 mu theta_bar
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nv[i] = 0.0;
+    if (plastic) {
+        const double del_alpha = (q - sigma_y) / den;
+        const double del_gamma = s32 * del_alpha;
+        theta = 1.0 - (three_mu * del_alpha) / q;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            nv[i] = s_tr[i] / q;
+            h[1 + i] = h[1 + i] + del_gamma * nv[i];
+        }
+        h[0] = alpha + del_alpha;
+        const double theta_bar = hfac - (1.0 - theta);
+        sc2 = two_mu * theta_bar;
+    }
+    // total (not incremental) stress:  p_1 1 + theta s_tr   (elastic: theta == 1 exactly)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double ts = theta * s_tr[i];
+        s[i] = i < 3 ? p_1 + ts : ts;
+    }
+    B = plastic ? two_mu * theta : two_mu;
+    return plastic;
+}
+
 // --- VonMises3D: J2 plasticity, saturation hardening, scalar Newton per point -----------------
 // scalars: s[0]=strain factor, s[1]=ka, s[2]=2*mu, s[3]=sqrt(2/3), s[4]=y0, s[5]=y00-y0,
 //          s[6]=-w, s[7]=(-2)*mu, s[8]=((2/3)*(y00-y0))*w, s[9]=(4*mu)*mu
@@ -558,27 +699,9 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     sr.get(region, lane, s);
     mandel_strain(g, a.sc.s[0], e);
 
-    const double ka = a.sc.s[1], two_mu = a.sc.s[2], s23 = a.sc.s[3], y0 = a.sc.s[4], dy = a.sc.s[5],
-                 mw = a.sc.s[6], m2mu = a.sc.s[7], c23dyw = a.sc.s[8], four_mu2 = a.sc.s[9];
-
-    const double tr_eps = (e[0] + e[1]) + e[2];
-    const double tr_sig = (s[0] + s[1]) + s[2];
-    const double tr_eps3 = tr_eps / 3.0, tr_sig3 = tr_sig / 3.0;
-    double dsig[6], sigtr[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double ed = i < 3 ? e[i] - tr_eps3 : e[i];
-        const double sd = i < 3 ? s[i] - tr_sig3 : s[i];
-        dsig[i] = two_mu * ed;
-        sigtr[i] = sd + dsig[i];
-    }
-    double nn = sigtr[0] * sigtr[0];
-#pragma unroll
-    for (int i = 1; i < 6; ++i) nn = __builtin_fma(sigtr[i], sigtr[i], nn);  // np.dot == fma chain
-    const double sigtrn = sqrt(nn);
-    const double phitr = sigtrn - s23 * (y0 + dy * (1.0 - exp(mw * alpha_n)));
-
-    const bool plastic = live && (phitr > 0.0);
+    VMTrial tr;
+    vm_trial(a.sc, e, s, alpha_n, tr);
+    const bool plastic = live && (tr.phitr > 0.0);
     const unsigned long long mask = __ballot(plastic);
 
     // plastic-strain history: needed only by tiles with a plastic point (in place), or always
@@ -603,7 +726,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     unsigned long long m_old = 0ull;
     if constexpr (sparse) m_old = a.hmask[p0 >> 6];
     const unsigned long long need_mask = mask | m_old;
-    const bool masked = FULL && (sparse || hist_in_place) && (__popcll(need_mask) <= a.masked_max);
+    const bool masked = FULL && (sparse || hist_in_place) && ((int)__popcll(need_mask) <= a.masked_max);
     const bool touch_eps = masked ? (need_mask != 0ull)
                                   : (sparse ? (need_mask != 0ull) : ((mask != 0ull) || !hist_in_place));
     bool row_live[3] = {true, true, true};  // per chunk of this lane: its row is touched
@@ -625,46 +748,13 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
         }
     }
 
-    double gamma = 0.0, xc1 = 0.0, xc2 = 0.0;
-    double N[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    VMReturn rm;
     if (mask != 0ull) {
-        if (plastic) {
-            double g0 = 1.0, g1 = 0.0, xr = 1.0, xg;
-            int it = 0;
-            bool failed = false;
-            while (__builtin_fabs(xr) > 1e-12 &&
-                   __builtin_fabs(g1 - g0) > 1e-8 * __builtin_fabs(g1)) {
-                g0 = g1;
-                ++it;
-                const double ex = exp(mw * (alpha_n + s23 * g0));
-                xr = (sigtrn - two_mu * g0) - s23 * (y0 + dy * (1.0 - ex));
-                xg = m2mu - c23dyw * ex;
-                g1 = g0 - xr / xg;
-                if (it > 100) {
-                    failed = true;
-                    break;
-                }
-            }
-            const double ex = exp(mw * (alpha_n + s23 * g1));
-            xg = m2mu - c23dyw * ex;
-            xc1 = -1.0 / xg;
-            xc2 = g1 / sigtrn;
-            gamma = g1;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) N[i] = sigtr[i] / sigtrn;
-            st.iters += (unsigned long long)it;
-            st.nonconv += failed ? 1ull : 0ull;
-        }
+        if (plastic) vm_return(a.sc, tr, alpha_n, rm, st);
         st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
     }
 
-    // stress: sigma += (ka tr_eps) I2 + del_sigtr - (2 mu gamma) N
-    const double kt = ka * tr_eps, tmg = two_mu * gamma;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double vol = i < 3 ? kt : kt * 0.0;
-        s[i] = s[i] + ((vol + dsig[i]) - tmg * N[i]);
-    }
+    vm_stress(a.sc, tr, rm, s);
     sr.put(sb, region, lane, s, p0, npts);
 
     // history: eps_n += gamma N ; alpha += sqrt(2/3) gamma
@@ -673,7 +763,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
             double ep[6];
             transpose_in<6>(ce, region, lane, ep);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ep[i] = ep[i] + gamma * N[i];
+            for (int i = 0; i < 6; ++i) ep[i] = ep[i] + rm.gamma * rm.N[i];
             if (masked) {
                 lds_put_point<6>(region, lane, ep);
                 wave_sync();
@@ -694,7 +784,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
             tile_store<6, FULL, NT>(ce, a.h0_out + p0 * 6, npts * 6, lane);
         }
         // alpha: one coalesced 512-byte store per touched tile
-        if (live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
+        if (live) a.h1_out[p0 + lane] = alpha_n + a.sc.s[3] * rm.gamma;
     }
     if constexpr (sparse) {
         if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
@@ -703,9 +793,9 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     // tangent: ka xioi + 2 mu (1 - 2 mu xc2) xpp + 4 mu^2 (xc2 - xc1) N (x) N
     const unsigned long long tneed = sparse_tangent_need<FULL>(a, need_mask);
     if (sb.tan && tneed != 0ull) {
-        const double B = two_mu * (1.0 - two_mu * xc2);
-        const double C = four_mu2 * (xc2 - xc1);
-        publish_tangent_params(region, lane, B, C, N);
+        double B, C;
+        vm_tangent_coefficients(a.sc, rm, B, C);
+        publish_tangent_params(region, lane, B, C, rm.N);
         wave_sync();
         tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed);
         wave_sync();
@@ -722,8 +812,8 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
 // the cache and the mapped components to the caller's arrays.  No 3-D gradient or tangent array
 // exists.  WRAP = 1: component 11 of everything; WRAP = 2: gradient (0,1,2,3) -> (0,1,3,4), Mandel
 // components 0..3, tangent block [0:4, 0:4] (utils.py:282-297, 377-412).  In place only (the wrappers
-// have no out-of-place form).  The per-point arithmetic below repeats tile_von_mises /
-// tile_comfe_mises statement for statement; tests/test_gpu_wrappers.py holds both to bit equality.
+// have no out-of-place form).  The per-point arithmetic is the 3-D tiles' own (vm_trial / vm_return / vm_stress,
+// cm_point, dp_trial / dp_return); tests/test_gpu_wrappers.py holds wrapper and 3-D law to bit equality.
 
 // inputs of a wrapped tile: padded gradient g[9] and the 3-D stress row s[6] (cache + mapped components)
 template <int WRAP, bool FULL, bool NT>
@@ -857,79 +947,32 @@ __device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const 
     wrapped_load<WRAP, FULL, NT>(a, region, p0, npts, lane, g, s);
     mandel_strain(g, a.sc.s[0], e);
 
-    const double ka = a.sc.s[1], two_mu = a.sc.s[2], s23 = a.sc.s[3], y0 = a.sc.s[4], dy = a.sc.s[5],
-                 mw = a.sc.s[6], m2mu = a.sc.s[7], c23dyw = a.sc.s[8], four_mu2 = a.sc.s[9];
-    const double tr_eps = (e[0] + e[1]) + e[2];
-    const double tr_sig = (s[0] + s[1]) + s[2];
-    const double tr_eps3 = tr_eps / 3.0, tr_sig3 = tr_sig / 3.0;
-    double dsig[6], sigtr[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double ed = i < 3 ? e[i] - tr_eps3 : e[i];
-        const double sd = i < 3 ? s[i] - tr_sig3 : s[i];
-        dsig[i] = two_mu * ed;
-        sigtr[i] = sd + dsig[i];
-    }
-    double nn = sigtr[0] * sigtr[0];
-#pragma unroll
-    for (int i = 1; i < 6; ++i) nn = __builtin_fma(sigtr[i], sigtr[i], nn);
-    const double sigtrn = sqrt(nn);
-    const double phitr = sigtrn - s23 * (y0 + dy * (1.0 - exp(mw * alpha_n)));
-    const bool plastic = live && (phitr > 0.0);
+    VMTrial tr;
+    vm_trial(a.sc, e, s, alpha_n, tr);
+    const bool plastic = live && (tr.phitr > 0.0);
     const unsigned long long mask = __ballot(plastic);
 
     Chunks<6> ce;
     if (mask != 0ull) tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
-    double gamma = 0.0, xc1 = 0.0, xc2 = 0.0;
-    double N[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    VMReturn rm;
     if (mask != 0ull) {
-        if (plastic) {
-            double g0 = 1.0, g1 = 0.0, xr = 1.0, xg;
-            int it = 0;
-            bool failed = false;
-            while (__builtin_fabs(xr) > 1e-12 && __builtin_fabs(g1 - g0) > 1e-8 * __builtin_fabs(g1)) {
-                g0 = g1;
-                ++it;
-                const double ex = exp(mw * (alpha_n + s23 * g0));
-                xr = (sigtrn - two_mu * g0) - s23 * (y0 + dy * (1.0 - ex));
-                xg = m2mu - c23dyw * ex;
-                g1 = g0 - xr / xg;
-                if (it > 100) {
-                    failed = true;
-                    break;
-                }
-            }
-            const double ex = exp(mw * (alpha_n + s23 * g1));
-            xg = m2mu - c23dyw * ex;
-            xc1 = -1.0 / xg;
-            xc2 = g1 / sigtrn;
-            gamma = g1;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) N[i] = sigtr[i] / sigtrn;
-            st.iters += (unsigned long long)it;
-            st.nonconv += failed ? 1ull : 0ull;
-        }
+        if (plastic) vm_return(a.sc, tr, alpha_n, rm, st);
         st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
     }
-    const double kt = ka * tr_eps, tmg = two_mu * gamma;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double vol = i < 3 ? kt : kt * 0.0;
-        s[i] = s[i] + ((vol + dsig[i]) - tmg * N[i]);
-    }
+    vm_stress(a.sc, tr, rm, s);
     wrapped_store_stress<WRAP, FULL, NT>(a, region, p0, npts, lane, s);
     if (mask != 0ull) {
         double ep[6];
         transpose_in<6>(ce, region, lane, ep);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + gamma * N[i];
+        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + rm.gamma * rm.N[i];
         transpose_out<6, FULL, NT>(ep, region, lane, a.h0_out + p0 * 6, npts * 6);
-        if (live) a.h1_out[p0 + lane] = alpha_n + s23 * gamma;
+        if (live) a.h1_out[p0 + lane] = alpha_n + a.sc.s[3] * rm.gamma;
     }
     if (a.tangent) {
-        const double B = two_mu * (1.0 - two_mu * xc2);
-        const double C = four_mu2 * (xc2 - xc1);
-        wrapped_tangent_mises<false, WRAP, FULL, NT>(a, T, region, p0, npts, lane, B, C, N);
+        double B, C;
+        vm_tangent_coefficients(a.sc, rm, B, C);
+        wrapped_tangent_mises<false, WRAP, FULL, NT>(a, T, region, p0, npts, lane, B, C, rm.N);
     }
 }
 
@@ -944,59 +987,13 @@ __device__ __forceinline__ void tile_comfe_mises_wrapped(const EvalArgs& a, cons
     transpose_in<7>(ch, region, lane, h);
     mandel_strain(g, a.sc.s[0], e);
 
-    const double kappa = a.sc.s[2], y_0 = a.sc.s[3], hh = a.sc.s[4], two_mu = a.sc.s[5],
-                 den = a.sc.s[6], s32 = a.sc.s[7], three_mu = a.sc.s[8], hfac = a.sc.s[9];
-    const double alpha = h[0];
-    const double p_0 = ((s[0] + s[1]) + s[2]) / 3.0;
-    const double eps_trace = (e[0] + e[1]) + e[2];
-    const double eps_vol = eps_trace / 3.0;
-    const double p_1 = p_0 + kappa * eps_trace;
-    double s_tr[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double s0 = i < 3 ? s[i] + (-p_0) : s[i];
-        const double ed = i < 3 ? e[i] + (-eps_vol) : e[i];
-        s_tr[i] = s0 + two_mu * ed;
-    }
-    const double v3 = ((s_tr[0] + s_tr[1]) + s_tr[2]) / 3.0;
-    double n2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double d = i < 3 ? s_tr[i] + (-v3) : s_tr[i];
-        n2 = i == 0 ? d * d : n2 + d * d;
-    }
-    const double q = sqrt(3.0 * (0.5 * n2));
-    const double sigma_y = y_0 + hh * alpha;
-    const bool plastic = live && !(q < sigma_y);
+    double B, sc2, nv[6];
+    const bool plastic = cm_point(a.sc, live, e, s, h, B, sc2, nv);
     const unsigned long long mask = __ballot(plastic);
-
-    double theta = 1.0, sc = 0.0;
-    double nv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (plastic) {
-        const double del_alpha = (q - sigma_y) / den;
-        const double del_gamma = s32 * del_alpha;
-        theta = 1.0 - (three_mu * del_alpha) / q;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            nv[i] = s_tr[i] / q;
-            h[1 + i] = h[1 + i] + del_gamma * nv[i];
-        }
-        h[0] = alpha + del_alpha;
-        const double theta_bar = hfac - (1.0 - theta);
-        sc = two_mu * theta_bar;
-    }
     st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double ts = theta * s_tr[i];
-        s[i] = i < 3 ? p_1 + ts : ts;
-    }
     wrapped_store_stress<WRAP, FULL, NT>(a, region, p0, npts, lane, s);
     if (mask != 0ull) transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
-    if (a.tangent) {
-        const double B = plastic ? two_mu * theta : two_mu;
-        wrapped_tangent_mises<true, WRAP, FULL, NT>(a, T, region, p0, npts, lane, B, sc, nv);
-    }
+    if (a.tangent) wrapped_tangent_mises<true, WRAP, FULL, NT>(a, T, region, p0, npts, lane, B, sc2, nv);
 }
 
 // History write policy of the laws with one [alpha, eps_p(6)] row per point (comfe-rs Mises and
@@ -1027,7 +1024,7 @@ __device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, 
                                                const double (&h)[7]) {
     const unsigned long long need = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
     if (need == 0ull) return;
-    if (!FULL || need == ~0ull || __popcll(need) > a.masked_max) {
+    if (!FULL || need == ~0ull || (int)__popcll(need) > a.masked_max) {
         transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
         return;
     }
@@ -1066,66 +1063,18 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
     transpose_in<7>(ch, region, lane, h);
     mandel_strain(g, a.sc.s[0], e);
 
-    const double kappa = a.sc.s[2], y_0 = a.sc.s[3], hh = a.sc.s[4], two_mu = a.sc.s[5],
-                 den = a.sc.s[6], s32 = a.sc.s[7], three_mu = a.sc.s[8], hfac = a.sc.s[9];
-    const double alpha = h[0];
-
-    // (p_0, s_0) = vol_dev(sigma) ; (tr, dev) = trace_dev(d_eps)
-    const double p_0 = ((s[0] + s[1]) + s[2]) / 3.0;
-    const double eps_trace = (e[0] + e[1]) + e[2];
-    const double eps_vol = eps_trace / 3.0;
-    const double p_1 = p_0 + kappa * eps_trace;
-    double s_tr[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double s0 = i < 3 ? s[i] + (-p_0) : s[i];
-        const double ed = i < 3 ? e[i] + (-eps_vol) : e[i];
-        s_tr[i] = s0 + two_mu * ed;
-    }
-    // mises_norm(): deviator once more, sqrt(3 * (0.5 * |dev|^2)), sequential sum
-    const double v3 = ((s_tr[0] + s_tr[1]) + s_tr[2]) / 3.0;
-    double n2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double d = i < 3 ? s_tr[i] + (-v3) : s_tr[i];
-        n2 = i == 0 ? d * d : n2 + d * d;
-    }
-    const double q = sqrt(3.0 * (0.5 * n2));
-    const double sigma_y = y_0 + hh * alpha;
-    const bool plastic = live && !(q < sigma_y);
+    double B, sc2, nv[6];
+    const bool plastic = cm_point(a.sc, live, e, s, h, B, sc2, nv);
     const unsigned long long mask = __ballot(plastic);
-
-    double theta = 1.0, sc = 0.0;  // sc = 2 mu theta_bar
-    double nv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (plastic) {
-        const double del_alpha = (q - sigma_y) / den;
-        const double del_gamma = s32 * del_alpha;
-        theta = 1.0 - (three_mu * del_alpha) / q;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            nv[i] = s_tr[i] / q;
-            h[1 + i] = h[1 + i] + del_gamma * nv[i];
-        }
-        h[0] = alpha + del_alpha;
-        const double theta_bar = hfac - (1.0 - theta);
-        sc = two_mu * theta_bar;
-    }
     st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
 
-    // total (not incremental) stress:  p_1 1 + theta s_tr   (elastic: theta == 1 exactly)
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double ts = theta * s_tr[i];
-        s[i] = i < 3 ? p_1 + ts : ts;
-    }
     sr.put(sb, region, lane, s, p0, npts);
     const unsigned long long touched = sparse_need(a, p0, mask, lane);
     history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
 
     const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
     if (sb.tan && tneed != 0ull) {
-        const double B = plastic ? two_mu * theta : two_mu;
-        publish_tangent_params(region, lane, B, sc, nv);
+        publish_tangent_params(region, lane, B, sc2, nv);
         wave_sync();
         tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed);
         wave_sync();

@@ -136,8 +136,10 @@ def test_sparse_history_equals_full_history(n, law_name):
 def test_evaluate_into_replays_golden_sequence(chunk, monkeypatch):
     """fcamd_evaluate_resident: NumPy grad in, NumPy stress/tangent out, state on the device;
     with a 128-point chunk the 1000+ points go through many chunks and all four slots."""
-    if chunk:
-        monkeypatch.setenv("FCAMD_HOST_CHUNK", chunk)
+    from fenics_constitutive_amd import _capi
+
+    ctx = _capi.get_context(_capi.default_device())
+    ctx.set_option("host_chunk", int(chunk or 0))  # the FCAMD_HOST_CHUNK default is read once, at context creation
     calls = {c.name: c for c in load_calls("von_mises_3d.npz")}
     c0 = calls["mixed_step0_iter0"]
     law = fc.VonMises3D(c0.params)
@@ -153,6 +155,7 @@ def test_evaluate_into_replays_golden_sequence(chunk, monkeypatch):
             assert np.array_equal(st.stress_committed.cpu().numpy(), c.stress_in)
             assert stats.n_plastic > 0
         st.update()
+    ctx.set_option("host_chunk", 0)
     assert st._grad is None and st._tangent is None  # no n-sized gradient / tangent on the device
 
 

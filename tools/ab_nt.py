@@ -19,7 +19,7 @@ for wl in ("linear_elasticity", "spring_maxwell", "spring_kelvin", "von_mises_mi
     res = {"1": [], "0": []}
     for rnd in range(4):
         for nt in ("1", "0"):
-            os.environ["FCAMD_NT"] = nt
+            law._handle(0).ctx.set_option("nontemporal", int(nt))
             for _ in range(2):
                 law.evaluate_from(0, 2.0, g, s0, s1, t, h0, h1)
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Threshold of the row-masked history access: kernel time of the sparse trial-history protocol against
-the plastic fraction p of a random mixture and FCAMD_MASKED_MAX (tiles with more touched rows take the
+the plastic fraction p of a random mixture and the `masked_max` context option (FCAMD_MASKED_MAX) (tiles with more touched rows take the
 dense tile path; 0 = always dense, 64 = always masked).  One process, fixed arrays (fixed placement)."""
 import json
 import os
@@ -42,7 +42,7 @@ for wl in ("von_mises_mixed", "comfe_mises_mixed", "drucker_prager_mixed"):
                 gv[:, c] -= tr
         row = {"workload": wl, "p": p}
         for mm in (0, 8, 16, 24, 32, 48, 64):
-            os.environ["FCAMD_MASKED_MAX"] = str(mm)
+            law._handle(0).ctx.set_option("masked_max", mm)
             for k in h0:
                 h1[k].copy_(h0[k])
             mask.zero_()

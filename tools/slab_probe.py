@@ -28,8 +28,8 @@ for rnd in range(4):
     for k, v in variants:
         if k == "GRID":
             law._handle(0).ctx.set_grid(int(v))
-        else:
-            os.environ[k] = v
+        else:  # FCAMD_TILE_MAP / FCAMD_NT / FCAMD_MASKED_MAX: context options since round 2
+            law._handle(0).ctx.set_option({"FCAMD_TILE_MAP": "tile_map", "FCAMD_NT": "nontemporal", "FCAMD_MASKED_MAX": "masked_max"}[k], int(v))
         for _ in range(2):
             law.evaluate_from(0, 1, g, s0, s1, t, h0, h1)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]

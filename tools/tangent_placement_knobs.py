@@ -43,15 +43,15 @@ def ms_of(t, reps=4):
 cands = [t0] + [torch.empty(36 * n, dtype=torch.float64, device=dev) for _ in range(k - 1)]
 for i, t in enumerate(cands):
     row = {"cand": i}
-    os.environ["FCAMD_NT"], os.environ["FCAMD_TILE_MAP"] = "1", "0"
+    ctx.set_option("nontemporal", 1), ctx.set_option("tile_map", 0)
     ctx.set_grid(0)
     row["default"] = ms_of(t)
-    os.environ["FCAMD_NT"] = "0"
+    ctx.set_option("nontemporal", 0)
     row["nt0"] = ms_of(t)
-    os.environ["FCAMD_NT"] = "1"
-    os.environ["FCAMD_TILE_MAP"] = "1"
+    ctx.set_option("nontemporal", 1)
+    ctx.set_option("tile_map", 1)
     row["xcd_map"] = ms_of(t)
-    os.environ["FCAMD_TILE_MAP"] = "0"
+    ctx.set_option("tile_map", 0)
     for grid in (256, 512, 1024, 2048, 4096):
         ctx.set_grid(grid)
         row[f"grid{grid}"] = ms_of(t)
