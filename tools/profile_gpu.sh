@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): rocprofv3 kernel trace + the two PMC passes for one
 # bench workload, as MI355X_MICROARCH.md prescribes (separate --pmc passes; FETCH_SIZE and
-# WRITE_SIZE do not fit one pass).  Usage: tools/profile_gpu.sh <tag> [bench args...]
+# WRITE_SIZE do not fit one pass).  Usage: tools/profile_gpu.sh <tag> --workload <name> [bench args...]
 # Writes gpurun_out/prof/<tag>/{kt,fetch,write}/... ; summarise with tools/summarize_profile.py.
 set -u
 TAG=${1:?tag}; shift
