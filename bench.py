@@ -474,7 +474,7 @@ def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent)
       direct_*  the C ABI's peer copies (fcamd_allgather_direct on IPC-mapped buffers): world-1 concurrent
                 copies per rank, one per xGMI link;
       p2p_*     (--gather-direct) one batched isend/irecv group to all peers (RCCL point-to-point)."""
-    from fenics_constitutive_amd.sharded import ChunkedGather, PeerBuffers, ShardedEvaluator
+    from fenics_constitutive_amd.sharded import ChunkedGather, PeerBuffers, ShardedEvaluator, shared_empty
 
     ng = ((min(args.gather_points, n) if args.gather_points > 0 else n) // 64) * 64  # whole tiles: every slot is full
     if ng == 0:
@@ -483,18 +483,22 @@ def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent)
     per = ev.plan.per_rank
     assert per == ng == ev.n_local
     shard_bytes = 42 * 8 * ng
+    nccl = args.backend == "nccl"
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info(device)
+    # every rank must derive the SAME chunk plan (the chunks are collectives): the smallest free memory of all ranks
+    fr = torch.tensor([free], dtype=torch.int64, device=device if nccl else "cpu")
+    dist.all_reduce(fr, op=dist.ReduceOp.MIN)
+    free = int(fr.item()) // (1 if nccl else world)  # gloo rehearsal: the ranks share one GPU
     reserve = 8 << 30
     out_s_bytes = 6 * per * world * 8
     budget = free - reserve - out_s_bytes
-    if budget <= 0:
+    if budget <= 0:  # the same on every rank: nobody enters a collective
         raise MemoryError(f"{free / 1e9:.1f} GB free: no room for the gathered stress ({out_s_bytes / 1e9:.1f} GB) + {reserve >> 30} GiB reserve")
-    out_s = torch.empty(6 * per * world, dtype=torch.float64, device=device)
+    out_s = shared_empty(6 * per * world, device)  # mapped by the peers (direct variant): an IPC-safe allocation
     s_mine = out_s[6 * per * rank : 6 * per * rank + 6 * ng]
     s_mine.copy_(stress_t[: 6 * ng])
     t_mine = tangent[: 36 * ng]
-    nccl = args.backend == "nccl"
     result = {"points_per_rank": ng, "shard_GB": round(shard_bytes / 1e9, 3), "free_GB_before": round(free / 1e9, 1),
               "note": "stress gathered whole (in place), tangent through 2 chunk buffers sized against free memory; outside the timed steps"}
 
@@ -519,6 +523,8 @@ def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent)
 
     for variant in (["rccl"] if nccl else []) + ["direct"] + (["p2p"] if (nccl and args.gather_direct) else []):
         peer = variant == "direct"
+        if rank == 0:
+            print(f"# allgather leg: {variant}, {ng} points per rank, budget {budget / 1e9:.1f} GB", file=sys.stderr, flush=True)
         cg = ChunkedGather(ev, 36, budget, like=tangent, peer_copies=peer)  # raises up front if the budget holds no tile
         result["tangent_chunks"], result["chunk_points"] = cg.plan.n_chunks, cg.plan.chunk
         result["chunk_buffers_GB"] = round(2 * cg.plan.buffer_numel * 8 / 1e9, 2)
@@ -615,8 +621,14 @@ def main():
                     help="process-group backend; gloo only to exercise the multi-rank control flow on a box "
                          "with fewer GPUs than ranks (ranks then share GPUs; of the gather variants only the C ABI's "
                          "peer copies run)")
+    ap.add_argument("--verbose", action="store_true", help="stage-by-stage progress lines on stderr (every rank)")
     args = ap.parse_args()
 
+    def stage(msg):
+        if args.verbose:
+            print(f"# [rank {os.environ.get('RANK', '0')} +{time.perf_counter() - t_prog:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    t_prog = time.perf_counter()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL, fcamd_ipc_*)
     import torch
     import torch.distributed as dist
@@ -650,6 +662,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    stage("process group up")
     t_start = time.perf_counter()
     name = args.workload or HEADLINE
     history = "sparse" if args.sparse_history else args.history
@@ -662,10 +675,13 @@ def main():
         from fenics_constitutive_amd.placement import max_tries_for_memory
 
         tries = max_tries_for_memory(36 * n, tries, device, reserve_bytes=16 << 30)
+    stage(f"workload built, placement {args.placement} with {tries} hipMalloc candidates")
     wl.place(args.placement, tries)
+    stage(f"placed: {wl.vmm_info or wl.placement}")
     wl.warmup(args.warmup)
     wl.count_plastic()
     n_pl, n_its = wl.mean_plastic(args.steps)
+    stage("warm-up and plastic counts done")
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -681,6 +697,7 @@ def main():
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    stage("timed steps done")
     wl.launch_log.append(["timed", args.steps])
     red_dev = device if args.backend == "nccl" else "cpu"
     if distributed:
@@ -725,6 +742,7 @@ def main():
     gather = None
     if distributed and world > 1 and not args.no_gather:
         try:
+            stage("all-gather leg")
             wl.launch(0, sparse_tangent=False)  # a complete trial stress / tangent for the gather to move
             keep_s, keep_t = wl.stress_t, wl.tangent
             wl.grads = wl.hist_t = wl.hmask = None  # the gather needs the room, the step timing is done

@@ -44,7 +44,8 @@ SYMBOLS = [
     "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
     "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
     "fcamd_context_last_host_mode", "fcamd_host_device_pointer",
-    "fcamd_shard_slot_points", "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_export", "fcamd_ipc_open",
+    "fcamd_shard_slot_points", "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_alloc", "fcamd_ipc_free",
+    "fcamd_ipc_export", "fcamd_ipc_open",
     "fcamd_ipc_close", "fcamd_enable_peer_access", "fcamd_allgather_direct", "fcamd_allgather_direct_wait",
     "fcamd_device_alloc_set", "fcamd_device_free",
     "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
@@ -136,6 +137,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_shard_slot_points.argtypes = [C.c_int64, C.c_int, i64p]
         lib.fcamd_shard_bounds.argtypes = [C.c_int64, C.c_int, C.c_int, i64p, i64p]
         lib.fcamd_gather_chunk_plan.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_size_t, C.c_int, i64p, i64p]
+        lib.fcamd_ipc_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        lib.fcamd_ipc_free.argtypes = [vp, vp]
         lib.fcamd_ipc_export.argtypes = [vp, vp, C.c_char_p, C.POINTER(C.c_size_t)]
         lib.fcamd_ipc_open.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp)]
         lib.fcamd_ipc_close.argtypes = [vp, vp, C.c_size_t]
@@ -257,6 +260,15 @@ class Context:
         return int(mode.value)
 
     # -- multi-GPU ----------------------------------------------------------------------------
+    def ipc_alloc(self, nbytes: int) -> int:
+        """``fcamd_ipc_alloc``: device buffer whose size hipIpcOpenMemHandle can map (see include/fcamd.h)."""
+        out = C.c_void_p()
+        check(self._lib.fcamd_ipc_alloc(self.handle, int(nbytes), C.byref(out)))
+        return int(out.value)
+
+    def ipc_free(self, device_ptr: int) -> None:
+        check(self._lib.fcamd_ipc_free(self.handle, C.c_void_p(device_ptr)))
+
     def ipc_export(self, device_ptr: int) -> tuple[bytes, int]:
         """(64-byte handle of the allocation ``device_ptr`` lies in, offset of the pointer inside it)."""
         buf = C.create_string_buffer(IPC_HANDLE_BYTES)

@@ -22,6 +22,14 @@ int64_t slot_points(int64_t n, int world) {
     return ((per + kTile - 1) / kTile) * kTile;
 }
 
+// hipIpcOpenMemHandle of this stack (ROCm 7.2, dmabuf IPC) never returns -- both processes spin in user space --
+// when the exported ALLOCATION's size has bit 31 set, i.e. (size mod 4 GiB) >= 2 GiB: 2, 3, 6, 7, 10, 10.5, 10.73,
+// 11 GiB hang; 1, 4, 5, 5.4, 8, 9, 12, 13, 16, 32, 64 GiB map in under a millisecond (tools/ipc_open_probe.py).
+// Such an allocation is refused at export, and fcamd_ipc_alloc rounds a request up to the next safe size.
+constexpr size_t kFourGiB = (size_t)4 << 30, kTwoGiB = (size_t)2 << 30;
+bool ipc_size_is_safe(size_t bytes) { return (bytes % kFourGiB) < kTwoGiB; }
+size_t ipc_safe_size(size_t bytes) { return ipc_size_is_safe(bytes) ? bytes : ((bytes + kFourGiB - 1) / kFourGiB) * kFourGiB; }
+
 int ensure_peer_streams(fcamd_context* c, int world) {
     while ((int)c->peer_streams.size() < world) {
         hipStream_t s = nullptr;
@@ -90,11 +98,30 @@ int fcamd_ipc_export(fcamd_context* c, const void* device_ptr, unsigned char han
     hipDeviceptr_t base = nullptr;
     size_t size = 0;
     HIP_TRY(hipMemGetAddressRange(&base, &size, const_cast<void*>(device_ptr)));
+    if (!ipc_size_is_safe(size))
+        return fail(FCAMD_ERR_UNSUPPORTED,
+                    "the allocation behind this pointer has %zu bytes: (size mod 4 GiB) >= 2 GiB, which hipIpcOpenMemHandle of this "
+                    "ROCm stack cannot map (it never returns); allocate shared buffers with fcamd_ipc_alloc", size);
     hipIpcMemHandle_t h;
     HIP_TRY(hipIpcGetMemHandle(&h, base));
     std::memset(handle, 0, FCAMD_IPC_HANDLE_BYTES);
     std::memcpy(handle, &h, sizeof(h));
     *offset_bytes = (size_t)(static_cast<const char*>(device_ptr) - static_cast<const char*>(base));
+    return FCAMD_OK;
+}
+
+int fcamd_ipc_alloc(fcamd_context* c, size_t bytes, void** device_ptr) {
+    if (!c || !device_ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(device_ptr, ipc_safe_size(bytes)));
+    return FCAMD_OK;
+}
+
+int fcamd_ipc_free(fcamd_context* c, void* device_ptr) {
+    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
+    if (!device_ptr) return FCAMD_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipFree(device_ptr));  // waits for the device
     return FCAMD_OK;
 }
 

@@ -422,8 +422,13 @@ class ResidentProblemState:
     def check(self) -> None:
         """Synchronise with the last launches and look at every law's counters (read once per evaluate);
         raises the reference's exceptions (Newton non-convergence, Drucker-Prager tip) per law."""
+        import torch
+
         from .device import read_counters
 
+        # Always a synchronisation point: the host assembler reads the arrays the launches wrote (and may free
+        # or unpin them) right after check() -- also when no law of the problem has counters to read.
+        torch.cuda.current_stream(self.device).synchronize()
         if self._failed is not None and not any(ls.stats_pending for ls in self._laws):
             raise self._failed
         for ls in self._laws:

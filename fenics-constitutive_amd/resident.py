@@ -410,7 +410,10 @@ class ResidentState:
         """Synchronise with this state's last device evaluate and return its counters; raises the
         reference's RuntimeError on Newton non-convergence / the Drucker-Prager tip.  Cheap when nothing
         is pending (the counters are read once per evaluate)."""
-        if self._counters is None:
+        if self._counters is None:  # a law without counters: check() is still the synchronisation point it always was
+            import torch
+
+            torch.cuda.current_stream(self.device).synchronize()
             return None
         if self._stats_pending:
             from .device import read_counters

@@ -32,6 +32,16 @@ from dataclasses import dataclass
 TILE = 64
 
 
+def _dbg(msg: str) -> None:
+    """Progress lines of the exchange steps on stderr (FCAMD_GATHER_DEBUG=1): a hang between ranks is otherwise mute."""
+    import os
+    import sys
+    import time
+
+    if os.environ.get("FCAMD_GATHER_DEBUG") == "1":
+        print(f"# [gather rank {os.environ.get('RANK', '?')} t={time.perf_counter():.2f}] {msg}", file=sys.stderr, flush=True)
+
+
 @dataclass(frozen=True)
 class ShardPlan:
     n: int  # global number of points
@@ -135,8 +145,10 @@ class ShardedEvaluator:
         if pull:  # every slot must be complete before anybody reads it
             peers.ctx.synchronize()
             self.dist.barrier(group=self.group)
+        _dbg(f"allgather_peer: {8 * count / 1e9:.2f} GB per slot, {'pull' if pull else 'push'}")
         peers.gather(8 * per, 8 * offset, 8 * count, pull=pull)
         peers.ctx.allgather_direct_wait(host_sync=True)
+        _dbg("allgather_peer: own copies done")
         self.dist.barrier(group=self.group)
         return gathered
 
@@ -167,11 +179,43 @@ class ShardedEvaluator:
         return self.compact(stress_gathered, sd), self.compact(tangent_gathered, td)
 
 
+class _SharedMemory:
+    """Owner of a ``fcamd_ipc_alloc`` buffer: freed when the last tensor view is gone."""
+
+    def __init__(self, ctx, ptr):
+        self.ctx, self.ptr = ctx, ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.ctx.ipc_free(self.ptr)
+                self.ptr = 0
+        except Exception:
+            pass
+
+
+def shared_empty(numel: int, device, ctx=None):
+    """Uninitialised float64 device tensor that peers can map (``PeerBuffers``): allocated through
+    ``fcamd_ipc_alloc``, whose sizes hipIpcOpenMemHandle can handle -- a torch allocation may have a size
+    ((size mod 4 GiB) >= 2 GiB) for which the mapping call of this ROCm stack never returns, and
+    ``fcamd_ipc_export`` refuses those."""
+    import torch
+
+    from . import _capi
+    from .placement import tensor_from_pointer
+
+    device = torch.device(device)
+    ctx = ctx if ctx is not None else _capi.get_context(device.index or 0)
+    ptr = ctx.ipc_alloc(8 * int(numel))
+    return tensor_from_pointer(ptr, int(numel), device, owner=_SharedMemory(ctx, ptr))
+
+
 class PeerBuffers:
     """Every rank's copy of one gathered buffer, mapped into this process (one rank per process: HIP IPC,
     ``fcamd_ipc_export`` / ``fcamd_ipc_open``; the 64-byte handles travel through
     ``all_gather_object``).  ``close()`` unmaps the peers' buffers; call it on every rank before any rank
-    frees its buffer."""
+    frees its buffer.  Allocate the buffers with ``shared_empty``: the export refuses allocations whose size
+    the mapping call of this ROCm stack cannot handle (NotImplementedError) instead of letting the peers hang."""
 
     def __init__(self, gathered, group=None, ctx=None):
         import torch
@@ -187,9 +231,11 @@ class PeerBuffers:
         self.ctx = ctx if ctx is not None else _capi.get_context(dev)
         self.ctx.set_stream(_current_stream_ptr(dev))
         self._own = gathered  # kept alive while mapped elsewhere
+        _dbg(f"PeerBuffers: exporting {gathered.numel() * gathered.element_size() / 1e9:.2f} GB")
         handle, offset = self.ctx.ipc_export(gathered.data_ptr())
         infos = [None] * self.world
         dist.all_gather_object(infos, (handle, offset, gathered.numel() * gathered.element_size()), group=group)
+        _dbg("PeerBuffers: handles exchanged, opening the peers'")
         assert all(i[2] == infos[0][2] for i in infos), "every rank's gathered buffer must have the same size"
         self.ptrs, self._opened = [], []
         for p, (h, off, _) in enumerate(infos):
@@ -199,6 +245,7 @@ class PeerBuffers:
                 ptr = self.ctx.ipc_open(h, off)
                 self.ptrs.append(ptr)
                 self._opened.append((ptr, off))
+        _dbg("PeerBuffers: mapped")
         torch.cuda.synchronize(gathered.device)
         dist.barrier(group=group)
 
@@ -211,6 +258,7 @@ class PeerBuffers:
 
     def close(self) -> None:
         if self._opened:
+            _dbg("PeerBuffers: closing")
             self.ctx.allgather_direct_wait(host_sync=True)
             self.dist.barrier(group=self.group)  # nobody is still copying into / out of a mapping
             for ptr, off in self._opened:
@@ -268,7 +316,10 @@ class ChunkedGather:
 
         self.ev, self.dim = evaluator, dim
         self.plan = GatherChunks.create(evaluator.plan.per_rank, evaluator.world, dim, budget_bytes, n_buffers)
-        self.buffers = [torch.empty(self.plan.buffer_numel, dtype=like.dtype, device=like.device) for _ in range(n_buffers)]
+        if peer_copies:  # the chunk buffers are mapped by the peers: sizes the IPC mapping call can handle
+            self.buffers = [shared_empty(self.plan.buffer_numel, like.device) for _ in range(n_buffers)]
+        else:
+            self.buffers = [torch.empty(self.plan.buffer_numel, dtype=like.dtype, device=like.device) for _ in range(n_buffers)]
         self.peers = [PeerBuffers(b, evaluator.group) for b in self.buffers] if peer_copies else None
 
     def close(self) -> None:
@@ -292,7 +343,9 @@ class ChunkedGather:
                 # pushing chunk k into buffer b overwrites chunk k - n_buffers there: every rank has consumed
                 # it, because it passed the barrier of chunk k - 1 only after leaving that iteration
                 peer = self.peers[k % len(self.buffers)]
+                _dbg(f"chunk {k}: pushing {8 * p.chunk * p.dim / 1e9:.2f} GB")
                 peer.gather(8 * p.chunk * p.dim)
                 peer.ctx.allgather_direct_wait(host_sync=True)
+                _dbg(f"chunk {k}: own copies done")
                 ev.dist.barrier(group=ev.group)
             yield k, buf.view(p.world, p.chunk, p.dim)[:, : hi - lo]

@@ -362,6 +362,13 @@ int fcamd_gather_chunk_plan(int64_t slot_points, int world, int values_per_point
    any host channel (torch.distributed.all_gather_object, MPI); fcamd_ipc_open maps it there.  A mapping
    is closed with the same offset it was opened with, before the owner frees the memory. */
 #define FCAMD_IPC_HANDLE_BYTES 64
+/* Device buffer meant to be mapped by peers.  Plain hipMalloc, with one precaution: on this ROCm stack
+   hipIpcOpenMemHandle never returns for an allocation whose size has bit 31 set ((size mod 4 GiB) >= 2 GiB;
+   measured, tools/ipc_open_probe.py), so such a request is rounded up to the next multiple of 4 GiB.
+   fcamd_ipc_export refuses (FCAMD_ERR_UNSUPPORTED) a pointer whose allocation has such a size instead of
+   letting the peers hang. */
+int fcamd_ipc_alloc(fcamd_context* ctx, size_t bytes, void** device_ptr);
+int fcamd_ipc_free(fcamd_context* ctx, void* device_ptr);
 int fcamd_ipc_export(fcamd_context* ctx, const void* device_ptr, unsigned char handle[FCAMD_IPC_HANDLE_BYTES],
                      size_t* offset_bytes);
 int fcamd_ipc_open(fcamd_context* ctx, const unsigned char handle[FCAMD_IPC_HANDLE_BYTES], size_t offset_bytes,

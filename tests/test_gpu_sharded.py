@@ -49,7 +49,7 @@ def free_port():
 
 
 def worker(rank, world, port, n, out_dir, backend):
-    from fenics_constitutive_amd.sharded import ChunkedGather, PeerBuffers, ShardedEvaluator
+    from fenics_constitutive_amd.sharded import ChunkedGather, PeerBuffers, ShardedEvaluator, shared_empty
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -71,7 +71,10 @@ def worker(rank, world, port, n, out_dir, backend):
         if backend == "nccl":
             variants += [("rccl", None), ("p2p", None)]
         for name, peer_kw in variants:
-            sg, tg = torch.zeros(6 * per * world, **f), torch.full((36 * per * world,), float("nan"), **f)
+            if peer_kw is None:
+                sg, tg = torch.zeros(6 * per * world, **f), torch.full((36 * per * world,), float("nan"), **f)
+            else:  # buffers the peers map: IPC-safe allocations
+                sg, tg = shared_empty(6 * per * world, "cuda:0").zero_(), shared_empty(36 * per * world, "cuda:0").fill_(float("nan"))
             sg[6 * per * rank : 6 * per * rank + 6 * ev.n_local] = dev(ev.local_view(s, 6))
             hl = {"eps_n": dev(ev.local_view(h["eps_n"], 6)), "alpha": dev(ev.local_view(h["alpha"], 1))}
             if peer_kw is None:
@@ -132,3 +135,25 @@ def test_two_ranks_on_one_gpu_exchange_through_ipc_peer_copies(n, tmp_path):
         assert np.array_equal(z["chunked_tangent"], t_ref), r
         assert int(z["n_chunks"]) > 1 or n <= 2 * 64 * 3
         assert np.array_equal(z["alpha"], a_ref[int(z["lo"]) : int(z["hi"])])
+
+
+def test_ipc_export_refuses_sizes_the_mapping_call_cannot_handle():
+    """hipIpcOpenMemHandle of this ROCm stack spins for ever when the exported allocation's size has bit 31
+    set (tools/ipc_open_probe.py); the export refuses such allocations and fcamd_ipc_alloc avoids them."""
+    from fenics_constitutive_amd import _capi
+    from fenics_constitutive_amd.sharded import shared_empty
+
+    ctx = _capi.get_context(0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12 << 30:
+        pytest.skip("needs 12 GiB of free HBM")
+    torch.cuda.empty_cache()
+    bad = torch.empty((3 << 30) // 8, dtype=torch.float64, device="cuda")  # a fresh 3 GiB segment
+    with pytest.raises(NotImplementedError, match="mod 4 GiB"):
+        ctx.ipc_export(bad.data_ptr())
+    del bad
+    good = shared_empty((3 << 30) // 8, "cuda:0")  # rounded up to 4 GiB behind the scenes
+    handle, offset = ctx.ipc_export(good.data_ptr())
+    assert len(handle) == 64 and offset == 0
+    small = shared_empty(1000, "cuda:0")
+    assert ctx.ipc_export(small.data_ptr())[1] == 0
