@@ -37,6 +37,32 @@ def _source_hash() -> str:
     return h.hexdigest()
 
 
+KERNEL_SOURCES = ["fcamd_kernels.hip", "fcamd_internal.h"]
+KERNEL_HASHFILE = os.path.join(LIBDIR, "libfcamd.kernelhash")
+
+
+def kernel_hash() -> str:
+    """Content hash of the DEVICE code alone (kernels, their internal header, arch and flags): what measured
+    HBM traffic depends on.  profiles/traffic.json is keyed by it, so host-side changes of the C ABI layer do not
+    invalidate a PMC measurement, a kernel change does."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join([ARCH, *FLAGS]).encode())
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def built_kernel_hash():
+    """kernel_hash() of the sources the library in lib/ was built from (None if unknown)."""
+    try:
+        with open(KERNEL_HASHFILE) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
 def _stale() -> bool:
     if not (os.path.exists(LIB) and os.path.exists(HASHFILE)):
         return True
@@ -74,6 +100,9 @@ def build_library(force: bool = False, verbose: bool = False, keep_temps: bool =
     with open(HASHFILE + f".{os.getpid()}", "w") as fh:
         fh.write(_source_hash())
     os.replace(HASHFILE + f".{os.getpid()}", HASHFILE)
+    with open(KERNEL_HASHFILE + f".{os.getpid()}", "w") as fh:
+        fh.write(kernel_hash())
+    os.replace(KERNEL_HASHFILE + f".{os.getpid()}", KERNEL_HASHFILE)
     return LIB
 
 

@@ -31,15 +31,25 @@ struct VmmArray {
 std::mutex g_vmm_mu;
 std::unordered_map<void*, VmmArray> g_vmm;  // base address -> its mapping
 
-void release(void* base, VmmArray& a) {
-    for (size_t g = 0; g < a.handles.size(); ++g) (void)hipMemUnmap(static_cast<char*>(base) + g * a.granule, a.granule);
-    for (auto h : a.handles) (void)hipMemRelease(h);
+// returns the first HIP error met (everything is attempted regardless)
+hipError_t release(void* base, VmmArray& a) {
+    hipError_t first = hipSuccess;
+    for (size_t g = 0; g < a.handles.size(); ++g) {
+        const hipError_t e = hipMemUnmap(static_cast<char*>(base) + g * a.granule, a.granule);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    for (auto h : a.handles) {
+        const hipError_t e = hipMemRelease(h);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
     // The address range is NOT returned (hipMemAddressFree): on this stack a range that is reserved again at
     // the same address and mapped to new handles serves stale data -- the second of two identical sets built
     // after freeing the first read back wrong values in every trial (tools/vmm_placement_probe.py --selftest
     // reproduces it with the free enabled).  Address space is plentiful (the physical memory IS released);
     // a range is simply never reused.
     a.handles.clear();
+    (void)hipGetLastError();
+    return first;
 }
 
 }  // namespace
@@ -157,8 +167,8 @@ int fcamd_device_free(fcamd_context* c, void* ptr) {
     }
     HIP_TRY(hipSetDevice(a.device));
     HIP_TRY(hipDeviceSynchronize());  // nothing may still be using the range
-    release(ptr, a);
-    (void)hipGetLastError();
+    const hipError_t e = release(ptr, a);
+    if (e != hipSuccess) return fail(FCAMD_ERR_HIP, "releasing a VMM array failed: %s", hipGetErrorString(e));
     return FCAMD_OK;
 }
 

@@ -6,7 +6,7 @@ summaries:
 
 writes profiles/r<round>_<workload>_rocprof.md (kernel stats, the dispatches of the evaluate kernels sliced
 into the phases bench.py logged -- `launch_log` of its JSON line --, PMC traffic) and updates
-profiles/traffic.json (HBM bytes per launch + the source hash of the library that was profiled: bench.py
+profiles/traffic.json (HBM bytes per launch + the hash of the kernel sources that were profiled: bench.py
 reports `roofline.traffic` only while that hash is the running library's).  PMC corrections per
 MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of
 the bytes of a wide (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane
@@ -126,7 +126,7 @@ with open(out, "w") as f:
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         d = json.load(open(tj)) if os.path.exists(tj) else {}
         d[workload] = {"n": n, "hbm_bytes_per_launch": int(fetch_b + write_b), "read_bytes": int(fetch_b), "write_bytes": int(write_b),
-                       "round": rnd, "source": os.path.basename(out), "srchash": (bench.get("library") or {}).get("srchash")}
+                       "round": rnd, "source": os.path.basename(out), "kernel_hash": (bench.get("library") or {}).get("kernel_hash")}
         json.dump(d, open(tj, "w"), indent=1, sort_keys=True)
     if bench:
         slim = {k: v for k, v in bench.items() if k not in ("configs", "launch_log")}
