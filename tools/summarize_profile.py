@@ -128,6 +128,9 @@ with open(out, "w") as f:
         d[workload] = {"n": n, "hbm_bytes_per_launch": int(fetch_b + write_b), "read_bytes": int(fetch_b), "write_bytes": int(write_b),
                        "round": rnd, "source": os.path.basename(out), "kernel_hash": (bench.get("library") or {}).get("kernel_hash")}
         json.dump(d, open(tj, "w"), indent=1, sort_keys=True)
+    notes = os.path.join(ROOT, "profiles", f"r{rnd}_{workload}_notes.md")  # hand-written analysis kept next to the generated summary
+    if os.path.exists(notes):
+        f.write("\n" + open(notes).read())
     if bench:
         slim = {k: v for k, v in bench.items() if k not in ("configs", "launch_log")}
         if bench.get("configs"):
