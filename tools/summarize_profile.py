@@ -126,7 +126,7 @@ with open(out, "w") as f:
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         d = json.load(open(tj)) if os.path.exists(tj) else {}
         d[workload] = {"n": n, "hbm_bytes_per_launch": int(fetch_b + write_b), "read_bytes": int(fetch_b), "write_bytes": int(write_b),
-                       "round": rnd, "source": os.path.basename(out), "kernel_hash": (bench.get("library") or {}).get("kernel_hash")}
+                       "round": rnd, "source": os.path.basename(out), "kernel_hash": (bench.get("library") or {}).get("kernel_hash") or os.environ.get("TRAFFIC_KERNEL_HASH")}
         json.dump(d, open(tj, "w"), indent=1, sort_keys=True)
     notes = os.path.join(ROOT, "profiles", f"r{rnd}_{workload}_notes.md")  # hand-written analysis kept next to the generated summary
     if os.path.exists(notes):
