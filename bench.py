@@ -536,10 +536,15 @@ def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent)
         peer = variant == "direct"
         if rank == 0:
             print(f"# allgather leg: {variant}, {ng} points per rank, budget {budget / 1e9:.1f} GB", file=sys.stderr, flush=True)
-        cg = ChunkedGather(ev, 36, budget, like=tangent, peer_copies=peer)  # raises up front if the budget holds no tile
+        try:  # set-up failures are raised on all ranks together (PeerBuffers exchanges the outcome of every step)
+            cg = ChunkedGather(ev, 36, budget, like=tangent, peer_copies=peer)  # raises up front if the budget holds no tile
+            peers_s = PeerBuffers(out_s) if peer else None
+        except Exception as e:
+            result[variant + "_error"] = f"{type(e).__name__}: {e}"[:300]
+            torch.cuda.empty_cache()
+            continue
         result["tangent_chunks"], result["chunk_points"] = cg.plan.n_chunks, cg.plan.chunk
         result["chunk_buffers_GB"] = round(2 * cg.plan.buffer_numel * 8 / 1e9, 2)
-        peers_s = PeerBuffers(out_s) if peer else None
 
         def run():
             if peer:
@@ -631,6 +636,8 @@ def main():
     ap.add_argument("--gather-points", type=int, default=0,
                     help="points per rank of the separately timed stress/tangent all-gather (N>1); 0 = the whole shard")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather leg")
+    ap.add_argument("--gather-timeout", type=float, default=240.0,
+                    help="N>1: seconds after which an unfinished all-gather leg is given up (the line is printed without it)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo only to exercise the multi-rank control flow on a box "
                          "with fewer GPUs than ranks (ranks then share GPUs; of the gather variants only the C ABI's "
@@ -752,44 +759,18 @@ def main():
     except Exception:  # the probe is informational only
         copy_gbs = None
 
-    # the exchange step of config 5, timed separately (never part of `value`)
-    gather = None
-    if distributed and world > 1 and not args.no_gather:
-        try:
-            stage("all-gather leg")
-            wl.launch(0, sparse_tangent=False)  # a complete trial stress / tangent for the gather to move
-            keep_s, keep_t = wl.stress_t, wl.tangent
-            wl.grads = wl.hist_t = wl.hmask = None  # the gather needs the room, the step timing is done
-            torch.cuda.empty_cache()
-            gather = time_allgather(args, dist, torch, device, rank, world, n, keep_s, keep_t)
-        except Exception as e:  # e.g. no room on every rank alike: the step timing above stands
-            gather = {"error": f"{type(e).__name__}: {e}"[:400]}
-
-    cpu = None
+    cpu_args = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # sample of the headline arrays, taken before they are released for the other configurations
         cpu_args = (wl.kind, wl.params, wl.grads[0][: 9 * 2_000_000].clone(), wl.stress_c[: 12_000_000].clone(),
                     None if wl.hist_c is None else {k: v[: {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}[k] * 2_000_000].clone()
                                                     for k, v in wl.hist_c.items()}, wl.del_t)
-    headline = {"placement": wl.placement, "vmm_info": wl.vmm_info, "launch_log": wl.launch_log, "config_text": wl.config_text(), "kind": wl.kind,
+    headline = {"placement": wl.placement, "vmm_info": wl.vmm_info, "launch_log": list(wl.launch_log), "config_text": wl.config_text(), "kind": wl.kind,
                 "b_el": wl.b_el, "b_pl": wl.b_pl, "alg": wl.alg_bytes(n_pl), "alg0": wl.alg_bytes(wl.n_pl_ab[0]),
                 "fracs": placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])), "sparse": wl.sparse, "plasticity": wl.plasticity}
-    wl.free()
 
-    # every other single-GPU configuration of BASELINE.json, same method, >= 5 event-timed launches each
-    configs = None
-    do_configs = args.configs == "all" or (args.configs == "auto" and args.workload is None and world == 1)
-    if do_configs and rank == 0:
-        configs = {}
-        for k, cname in enumerate(EXTRA_CONFIGS):
-            try:
-                configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
-                                            min(tries, 4), history=history, placement=args.placement)
-            except Exception as e:  # one configuration failing must not lose the line
-                configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            torch.cuda.empty_cache()
-
-    if rank == 0:
+    out = None
+    if rank == 0:  # the line is complete up to here; what follows only adds to it
         total_pts = n * world * args.steps
         value = total_pts / elapsed / 1e6
         alg_bytes = headline["alg"]
@@ -836,16 +817,61 @@ def main():
             out["placement"]["tries"] = tries
         if per_rank_ms is not None:
             out["per_rank_kernel_ms"] = per_rank_ms
-        if gather:
-            out["allgather"] = gather
-        if configs is not None:
-            out["configs"] = configs
         out["launch_log"] = headline["launch_log"]
         out["library"] = {"srchash": library_hash(), "kernel_hash": library_hash(kernels_only=True)}
-        if world == 1:
-            out["cpu_baseline"] = cpu_baseline(*cpu_args) if not args.no_cpu_baseline else None
+
+    def emit():
         out["wall_s"] = round(time.perf_counter() - t_start, 1)
         print(json.dumps(out), flush=True)
+
+    # the exchange step of config 5, timed separately (never part of `value`)
+    if distributed and world > 1 and not args.no_gather:
+        # An exchange between 8 processes can hang in ways a single GPU cannot rehearse (a peer mapping that never
+        # returns, ranks leaving a collective in different places): the measured line must survive that.  If the leg
+        # has not finished after --gather-timeout seconds, rank 0 prints the line with an error entry and every rank
+        # leaves the process.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["allgather"] = {"error": f"the all-gather leg did not finish within {args.gather_timeout} s; step timing above is complete"}
+                emit()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.gather_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            stage("all-gather leg")
+            wl.launch(0, sparse_tangent=False)  # a complete trial stress / tangent for the gather to move
+            keep_s, keep_t = wl.stress_t, wl.tangent
+            wl.grads = wl.hist_t = wl.hmask = None  # the gather needs the room, the step timing is done
+            torch.cuda.empty_cache()
+            gather = time_allgather(args, dist, torch, device, rank, world, n, keep_s, keep_t)
+        except Exception as e:  # e.g. no room on every rank alike: the step timing above stands
+            gather = {"error": f"{type(e).__name__}: {e}"[:400]}
+        watchdog.cancel()
+        if rank == 0:
+            out["allgather"] = gather
+    wl.free()
+
+    # every other single-GPU configuration of BASELINE.json, same method, >= 5 event-timed launches each
+    do_configs = args.configs == "all" or (args.configs == "auto" and args.workload is None and world == 1)
+    if do_configs and rank == 0:
+        configs = {}
+        for k, cname in enumerate(EXTRA_CONFIGS):
+            try:
+                configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
+                                            min(tries, 4), history=history, placement=args.placement)
+            except Exception as e:  # one configuration failing must not lose the line
+                configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+        out["configs"] = configs
+
+    if rank == 0:
+        if world == 1:
+            out["cpu_baseline"] = cpu_baseline(*cpu_args) if cpu_args is not None else None
+        emit()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

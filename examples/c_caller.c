@@ -5,6 +5,7 @@
  *   gcc -std=c99 -I include examples/c_caller.c -o c_caller -L fenics-constitutive_amd/lib -lfcamd -lm
  */
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -33,7 +34,24 @@ int main(void) {
     fcamd_stats stats;
     CHECK(fcamd_context_create(0, NULL, &ctx));
     CHECK(fcamd_model_create(ctx, FCAMD_LINEAR_ELASTICITY, FCAMD_FULL, params, 2, &law));
+    /* the getters of the reference's native model classes (bindings/src/lib.rs:131-148): nothing is hard-coded */
+    int constraint = 0, sd = 0, gdim = 0, n_hist = -1;
+    CHECK(fcamd_model_constraint(law, &constraint));
+    CHECK(fcamd_model_dims(law, &sd, &gdim));
+    CHECK(fcamd_model_history_count(law, &n_hist));
+    if (constraint != FCAMD_FULL || sd != 6 || gdim != 3 || n_hist != 0) return 3;
+    /* the hot call, timed like the reference's Timer("constitutive-law-evaluation") (solver/_lawonsubmesh.py:86) */
+    CHECK(fcamd_context_set_timing(ctx, 1));
     CHECK(fcamd_evaluate_host(law, 0.0, 1.0, N, grad, stress, tangent, NULL, 0, &stats));
+    float ms = -1.0f;
+    CHECK(fcamd_model_last_kernel_ms(law, &ms));
+    /* contiguous 64-aligned slices of the point axis for 8 ranks (multi-GPU: every rank evaluates its own slice) */
+    int64_t lo = 0, hi = 0, covered = 0;
+    for (int r = 0; r < 8; ++r) {
+        CHECK(fcamd_shard_bounds(N, 8, r, &lo, &hi));
+        covered += hi - lo;
+    }
+    if (covered != N) return 4;
 
     double worst = 0.0;
     for (int i = 0; i < N; ++i) {
@@ -42,7 +60,7 @@ int main(void) {
         worst = fmax(worst, fabs(stress[6 * i + 1] - lam * e));
         worst = fmax(worst, fabs(tangent[36 * i + 21] - 2.0 * mu)); /* D[3][3] */
     }
-    printf("fcamd v%d: %d points, max error %.3e\n", fcamd_version(), N, worst);
+    printf("fcamd v%d: %d points, max error %.3e, call %.3f ms\n", fcamd_version(), N, worst, ms);
     CHECK(fcamd_model_destroy(law));
     CHECK(fcamd_context_destroy(ctx));
     free(grad), free(stress), free(tangent);

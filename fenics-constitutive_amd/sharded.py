@@ -231,20 +231,43 @@ class PeerBuffers:
         self.ctx = ctx if ctx is not None else _capi.get_context(dev)
         self.ctx.set_stream(_current_stream_ptr(dev))
         self._own = gathered  # kept alive while mapped elsewhere
-        _dbg(f"PeerBuffers: exporting {gathered.numel() * gathered.element_size() / 1e9:.2f} GB")
-        handle, offset = self.ctx.ipc_export(gathered.data_ptr())
+        # Every step that can fail on one rank alone (an allocation the export refuses, a mapping error) is
+        # followed by an exchange of the outcome, so that ALL ranks raise together: a rank that left alone
+        # would leave the others waiting in the next collective for ever.
+        nbytes = gathered.numel() * gathered.element_size()
+        _dbg(f"PeerBuffers: exporting {nbytes / 1e9:.2f} GB")
+        try:
+            handle, offset = self.ctx.ipc_export(gathered.data_ptr())
+            mine = ("ok", handle, offset, nbytes)
+        except Exception as e:
+            mine = ("error", f"{type(e).__name__}: {e}")
         infos = [None] * self.world
-        dist.all_gather_object(infos, (handle, offset, gathered.numel() * gathered.element_size()), group=group)
+        dist.all_gather_object(infos, mine, group=group)
+        bad = [f"rank {p}: {i[1]}" for p, i in enumerate(infos) if i[0] != "ok"]
+        if bad:
+            raise RuntimeError("PeerBuffers: export failed -- " + "; ".join(bad)[:600])
+        assert all(i[3] == infos[0][3] for i in infos), "every rank's gathered buffer must have the same size"
         _dbg("PeerBuffers: handles exchanged, opening the peers'")
-        assert all(i[2] == infos[0][2] for i in infos), "every rank's gathered buffer must have the same size"
-        self.ptrs, self._opened = [], []
-        for p, (h, off, _) in enumerate(infos):
+        self.ptrs, self._opened, err = [], [], None
+        for p, (_, h, off, _n) in enumerate(infos):
             if p == self.rank:
                 self.ptrs.append(gathered.data_ptr())
-            else:
+                continue
+            try:
                 ptr = self.ctx.ipc_open(h, off)
                 self.ptrs.append(ptr)
                 self._opened.append((ptr, off))
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"
+                break
+        status = [None] * self.world
+        dist.all_gather_object(status, err, group=group)
+        bad = [f"rank {p}: {e}" for p, e in enumerate(status) if e is not None]
+        if bad:
+            for ptr, off in self._opened:
+                self.ctx.ipc_close(ptr, off)
+            self._opened = []
+            raise RuntimeError("PeerBuffers: mapping a peer's buffer failed -- " + "; ".join(bad)[:600])
         _dbg("PeerBuffers: mapped")
         torch.cuda.synchronize(gathered.device)
         dist.barrier(group=group)
