@@ -68,6 +68,27 @@ __device__ __forceinline__ void store16(double* p, d2 v) {
         *reinterpret_cast<d2*>(p) = v;
 }
 
+// Store policy of the tangent stream (288 of the 456-648 bytes per point), a build-time experiment knob
+// (tools/ab_lib.py A/Bs two builds in one process): 0 = non-temporal (ships: +13 % over plain stores in round 1; `sc1` /
+// `sc0 sc1` write-through stores, which drop the line from the L2 at once, measured no better in round 2).
+#ifndef FCAMD_TANGENT_STORE
+#define FCAMD_TANGENT_STORE 0
+#endif
+template <bool NT>
+__device__ __forceinline__ void store_tangent16(double* p, d2 v) {
+#if FCAMD_TANGENT_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif FCAMD_TANGENT_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif FCAMD_TANGENT_STORE == 3
+    *reinterpret_cast<d2*>(p) = v;
+#elif FCAMD_TANGENT_STORE == 4
+    asm volatile("global_store_dwordx4 %0, %1, off nt sc1" ::"v"(p), "v"(v) : "memory");
+#else
+    store16<NT>(p, v);
+#endif
+}
+
 // A 64-point tile of an AoS array with NC doubles per point is 32*NC contiguous 16-byte
 // chunks; lane l owns chunks l, l+64, ...  (K = ceil(NC/2) per lane, the last one only on
 // lanes < 32 when NC is odd).
@@ -318,7 +339,7 @@ __device__ __forceinline__ void tangent_const(const double* tab, double* tangent
         r = r >= 18 ? r - 18 : r;
         const int q = k * kWave + lane;
         d2 v = reinterpret_cast<const d2*>(tab)[r];
-        if (FULL || q < nchunks) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        if (FULL || q < nchunks) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
     }
 }
 
@@ -334,7 +355,7 @@ __device__ __forceinline__ void tangent_const_masked(const double* tab, double* 
         const int q = k * kWave + lane;
         const int p = q / 18;
         d2 v = reinterpret_cast<const d2*>(tab)[q - 18 * p];
-        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
     }
 }
 
@@ -391,7 +412,7 @@ __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta
             v.x = (a.x + bc.x * b.x) + bc.y * (ni * nj.x);
             v.y = (a.y + bc.x * b.y) + bc.y * (ni * nj.y);
         }
-        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         // bound the register pressure: let the scheduler interleave at most 3 chunks
         if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -1161,7 +1182,7 @@ __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11ta
         // i.e. the host-computed 2 mu P_dev + 3 kappa P_vol bit for bit, not kappa 1x1 + 2 mu P_dev
         const d2 el = *reinterpret_cast<const d2*>(etab + 6 * i + j);
         if (c2.y == 0.0) v = el;
-        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
