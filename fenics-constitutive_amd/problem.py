@@ -315,7 +315,7 @@ class ResidentProblemState:
         """See ResidentState._place: "tune", "vmm", or ("auto") the faster of the two."""
         mode, best_ms = self._placement_mode, None
         if mode in ("auto", "tune") and not (self.reuse_constant_tangent and all(ls.const_tangent for ls in self._laws)):
-            info = self.tune_placement(grads)
+            info = self.tune_placement(grads, tries=6)
             best_ms = min(info["candidate_ms"])
             self.placement = {"mode": "hipmalloc_tuned", **info}
         if mode in ("auto", "vmm"):

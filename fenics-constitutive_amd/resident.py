@@ -218,7 +218,7 @@ class ResidentState:
         VMM set by a few per cent; the VMM set is within ~5 % of that best on every box seen so far)."""
         mode, best_ms = self._placement_mode, None
         if mode in ("auto", "tune") and not self._const_tangent:  # a tangent written once per del_t: nothing to tune
-            info = self.tune_placement(t, del_t, g)
+            info = self.tune_placement(t, del_t, g, tries=6)  # a third of the draws are slow ones (DESIGN.md 6): six, memory permitting
             best_ms = min(info["candidate_ms"])
             self.placement = {"mode": "hipmalloc_tuned", **info}
         if mode in ("auto", "vmm"):

@@ -157,3 +157,34 @@ def test_ipc_export_refuses_sizes_the_mapping_call_cannot_handle():
     assert len(handle) == 64 and offset == 0
     small = shared_empty(1000, "cuda:0")
     assert ctx.ipc_export(small.data_ptr())[1] == 0
+
+
+@pytest.mark.parametrize("pull", [False, True])
+def test_allgather_direct_one_process_several_buffers(pull):
+    """fcamd_allgather_direct in its "one process drives several GPUs" form, rehearsed with three gathered buffers
+    on ONE device (devices[] given explicitly): every "rank" pushes (or pulls) its slot, in two chunks through
+    offset / bytes; afterwards all three buffers hold all slots.  Argument checks included."""
+    from fenics_constitutive_amd import _capi
+
+    world, slot = 3, 64 * 50 * 36
+    ctx = _capi.get_context(0)
+    ctx.set_stream(torch.cuda.current_stream(0).cuda_stream)
+    bufs = [torch.full((world * slot,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(world)]
+    ref = torch.arange(world * slot, dtype=torch.float64, device="cuda")
+    for r in range(world):
+        bufs[r][r * slot:(r + 1) * slot] = ref[r * slot:(r + 1) * slot]  # rank r produced its own slot
+    ptrs = [b.data_ptr() for b in bufs]
+    half = 8 * slot // 2
+    torch.cuda.synchronize()
+    for r in range(world):
+        for off, nb in ((0, half), (half, 8 * slot - half)):  # two chunks of the slot
+            ctx.allgather_direct(world, r, ptrs, 8 * slot, off, nb, devices=[0] * world, pull=pull)
+        ctx.allgather_direct_wait(host_sync=(r % 2 == 0))
+    torch.cuda.synchronize()
+    for b in bufs:
+        assert torch.equal(b, ref)
+    with pytest.raises(AssertionError):  # offset + bytes beyond the slot
+        ctx.allgather_direct(world, 0, ptrs, 8 * slot, 8, 8 * slot)
+    with pytest.raises(ValueError):
+        ctx.allgather_direct(world, world, ptrs, 8 * slot)
+    ctx.allgather_direct(1, 0, ptrs[:1], 8 * slot)  # world 1: nothing to do
