@@ -492,7 +492,7 @@ def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent)
         raise ValueError("fewer than 64 points per rank: nothing to gather")
     ev = ShardedEvaluator(None, ng * world)
     per = ev.plan.per_rank
-    assert per == ng == ev.n_local
+    assert per == ng == ev.n_local  # whole tiles: every slot is full
     shard_bytes = 42 * 8 * ng
     nccl = args.backend == "nccl"
     torch.cuda.empty_cache()

@@ -2,7 +2,6 @@
 """How much headroom is there in placement?  Greedy, array by array (largest stream first): K candidate regions of a pool
 of 2 MiB handles per array, the real kernel timed on each, the best kept, the others fixed.  Start: everything in
 hipMalloc memory.       python tools/vmm_greedy_probe.py [n] [K] [--sparse]"""
-import ctypes as C
 import json
 import os
 import sys
@@ -12,59 +11,25 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from fenics_constitutive_amd.placement import tensor_from_pointer  # noqa: E402
+from vmm_raw import G, create_handles, map_handles, unmap  # noqa: E402
 
-hip = C.CDLL("libamdhip64.so.7")
-
-
-class Loc(C.Structure):
-    _fields_ = [("type", C.c_int), ("id", C.c_int)]
-
-
-class Prop(C.Structure):
-    _fields_ = [("type", C.c_int), ("handle_type", C.c_int), ("location", Loc), ("win32", C.c_void_p),
-                ("compression", C.c_ubyte), ("rdma", C.c_ubyte), ("usage", C.c_ushort)]
-
-
-class Access(C.Structure):
-    _fields_ = [("location", Loc), ("flags", C.c_int)]
-
-
-def chk(e, what):
-    if e != 0:
-        raise RuntimeError(f"{what} -> hip error {e}")
-
-
-G = 2 << 20
 args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(float(args_[0])) if args_ else 50_000_000
 K = int(args_[1]) if len(args_) > 1 else 6
 dev = torch.device("cuda", 0)
 wl = bench.Workload("von_mises_mixed", n, 1234, dev, 0, history="sparse" if "--sparse" in sys.argv else "full")
-prop, acc = Prop(1, 0, Loc(1, 0), None, 0, 0, 0), Access(Loc(1, 0), 3)
 
 
 def new_region(numel):
     """a fresh array of `numel` doubles on its own burst of 2 MiB handles"""
-    cnt = -(-numel * 8 // G)
-    va = C.c_void_p()
-    chk(hip.hipMemAddressReserve(C.byref(va), C.c_size_t(cnt * G), C.c_size_t(G), None, C.c_ulonglong(0)), "reserve")
-    hs = []
-    for i in range(cnt):
-        h = C.c_void_p()
-        chk(hip.hipMemCreate(C.byref(h), C.c_size_t(G), C.byref(prop), C.c_ulonglong(0)), "create")
-        p = C.c_void_p(va.value + i * G)
-        chk(hip.hipMemMap(p, C.c_size_t(G), C.c_size_t(0), h, C.c_ulonglong(0)), "map")
-        chk(hip.hipMemSetAccess(p, C.c_size_t(G), C.byref(acc), C.c_size_t(1)), "access")
-        hs.append(h)
-    return tensor_from_pointer(va.value, numel, dev), (va.value, hs)
+    hs = create_handles(-(-numel * 8 // G))
+    va = map_handles(hs)
+    return tensor_from_pointer(va, numel, dev), (va, hs)
 
 
 def drop(region):
-    torch.cuda.synchronize()
     va, hs = region
-    for i, h in enumerate(hs):
-        chk(hip.hipMemUnmap(C.c_void_p(va + i * G), C.c_size_t(G)), "unmap")
-        chk(hip.hipMemRelease(h), "release")
+    unmap(va, len(hs), release=hs)
 
 
 def get(name):
