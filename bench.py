@@ -365,7 +365,7 @@ def placement_fracs(wl, alg0):
     return out
 
 
-def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse", placement="auto"):
+def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse", placement="auto", cpu=True):
     """One extra configuration, same method as the headline: placement, warm up, count, >= 5 event-timed launches."""
     wl = Workload(name, n, seed, device, dev_index, history=history)
     try:
@@ -390,9 +390,47 @@ def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="
         if wl.vmm_info and "vmm_ms" in wl.vmm_info:
             out["placement_vmm_ms"] = wl.vmm_info["vmm_ms"]
         out["launch_log"] = wl.launch_log
+        if cpu:
+            try:
+                out["cpu"] = cpu_quick(wl)
+            except Exception as e:  # informational
+                out["cpu"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         return out
     finally:
         wl.free()
+
+
+def cpu_quick(wl, budget_s=1.0, ns=1_000_000):
+    """A short CPU figure for one configuration: the C port (oracle/oracle.c, serial loop, 1 thread) and the NumPy
+    restatement of the reference's code path on the first `ns` points of the configuration's own arrays."""
+    import numpy as np
+
+    from oracle import c_oracle as CO
+    from oracle import numpy_oracle as NO
+
+    ns = min(ns, wl.n)
+    dims = {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}
+    g = wl.grads[0][: 9 * ns].cpu().numpy()
+    s0 = wl.stress_c[: 6 * ns].cpu().numpy()
+    h0 = None if wl.hist_c is None else {k: v[: dims[k] * ns].cpu().numpy() for k, v in wl.hist_c.items()}
+    tan = np.zeros(36 * ns)
+    out = {}
+    for label, fn, m in (("c_port_1_thread_Mpts_s", CO.MODELS[wl.kind], ns), ("numpy_port_Mpts_s", NO.MODELS[wl.kind], min(ns, 200_000))):
+        def one_pass():
+            s = s0[: 6 * m].copy()
+            h = None if h0 is None else {k: v[: dims[k] * m].copy() for k, v in h0.items()}
+            t0 = time.perf_counter()
+            fn(wl.params, 0.0, wl.del_t, g[: 9 * m], s, tan[: 36 * m], h)
+            return time.perf_counter() - t0
+
+        one_pass()  # untimed: faults in the pages of the output arrays
+        reps, tt = 0, 0.0
+        while tt < budget_s and reps < 50:
+            tt += one_pass()
+            reps += 1
+        out[label] = round(m * reps / tt / 1e6, 2)
+    out["sample"] = f"first {ns} points of this configuration's arrays, ~{budget_s:.0f} s each"
+    return out
 
 
 def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
@@ -459,6 +497,19 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
                 tt += time.perf_counter() - t0
                 rr += 1
             extra["comfe_rs_mises_c_port_1_thread_Mpts_s"] = round(ns * rr / tt / 1e6, 2)
+        # BASELINE configs[0]: LinearElasticityModel FULL-3D, 1e5 points, the reference's NumPy evaluate() on the CPU --
+        # here its NumPy restatement (and the C port) on the SURVEY 8d cfg1 inputs (grad ~ N(0, 1e-3^2), sigma = 0, E = 42, nu = 0.3, seed 0)
+        rng = np.random.default_rng(0)
+        g0, t0_ = rng.normal(scale=1e-3, size=9 * 100_000), np.zeros(36 * 100_000)
+        for label, f0 in (("config0_le_1e5_numpy_port_Mpts_s", NO.MODELS["linear_elasticity"]), ("config0_le_1e5_c_port_Mpts_s", CO.MODELS["linear_elasticity"])):
+            best = None
+            for _ in range(5):
+                s_ = np.zeros(6 * 100_000)
+                tq = time.perf_counter()
+                f0(LE_P, 0.0, 1.0, g0, s_, t0_, None)
+                dq = time.perf_counter() - tq
+                best = dq if best is None else min(best, dq)
+            extra[label] = round(0.1 / best, 2)
         # the same C loop on all host cores (OpenMP over points), for scale only
         nthr = min(CO.max_threads(), os.cpu_count() or 1)
         CO.set_num_threads(nthr)
@@ -862,7 +913,7 @@ def main():
         for k, cname in enumerate(EXTRA_CONFIGS):
             try:
                 configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
-                                            min(tries, 4), history=history, placement=args.placement)
+                                            min(tries, 4), history=history, placement=args.placement, cpu=not args.no_cpu_baseline)
             except Exception as e:  # one configuration failing must not lose the line
                 configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
