@@ -82,7 +82,7 @@ int fcamd_device_alloc_set(fcamd_context* c, int n_arrays, const size_t* bytes, 
             for (size_t g = 0; g < arrs[k].handles.size(); ++g)
                 (void)hipMemUnmap(static_cast<char*>(bases[k]) + g * granule, granule);
             for (auto h : arrs[k].handles) (void)hipMemRelease(h);
-            if (bases[k]) (void)hipMemAddressFree(bases[k], arrs[k].bytes);
+            // the address range is kept (never reused), as in release(): see there
         }
         (void)hipGetLastError();
     };
