@@ -154,7 +154,7 @@ class Workload:
     """One law on n synthetic device-resident points: the committed state, two Newton iterates of the
     gradient, the trial arrays, and the launch every timed step issues."""
 
-    def __init__(self, name, n, seed, device, dev_index, history="sparse", sparse_tangent=False, grid=0):
+    def __init__(self, name, n, seed, device, dev_index, history="sparse", sparse_tangent=False, grid=0, delta_history=True):
         import torch
 
         self.torch = torch
@@ -184,6 +184,9 @@ class Workload:
         self.plasticity = self.kind in PLASTICITY
         self.sparse = self.plasticity and history == "sparse"
         self.sparse_tangent = bool(sparse_tangent and self.sparse)
+        # VonMises3D under the sparse protocol: ResidentState's default keeps the INCREMENT of eps_n in the trial array
+        # (FCAMD_EVAL_DELTA_HISTORY: eps_n is write-only for the stress update, the committed rows are not read)
+        self.delta = bool(delta_history and self.sparse and self.kind == "von_mises_3d")
         self.hmask = None
         if self.sparse:
             for k in self.hist_c:
@@ -197,7 +200,8 @@ class Workload:
         self.law.evaluate_from(0.0, self.del_t, self.grads[i & 1], self.stress_c, self.stress_t,
                                self.tangent if tangent is None else tangent, self.hist_c, self.hist_t,
                                history_mask=None if full_history else self.hmask,
-                               sparse_tangent=self.sparse_tangent if sparse_tangent is None else sparse_tangent)
+                               sparse_tangent=self.sparse_tangent if sparse_tangent is None else sparse_tangent,
+                               delta_history=self.delta and not full_history)
 
     def tune_placement(self, tries):
         """hipMalloc placements of the tangent (the dominant write stream): a few candidate allocations, the
@@ -342,6 +346,7 @@ class Workload:
         return (f"{self.name}: {self.kind} FULL-3D, {self.n} quadrature points per GPU, device-resident AoS, "
                 f"committed->trial evaluate of two alternating Newton iterates"
                 f"{', sparse trial history (ResidentState protocol)' if self.sparse else (', full trial history' if self.plasticity else '')}"
+                f"{', eps_n kept as increment during the iterations (delta trial history)' if self.delta else ''}"
                 f"{', sparse tangent (rows of points that stay elastic are not rewritten)' if self.sparse_tangent else ''}")
 
     def free(self):
@@ -365,9 +370,9 @@ def placement_fracs(wl, alg0):
     return out
 
 
-def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse", placement="auto", cpu=True):
+def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse", placement="auto", cpu=True, delta_history=True):
     """One extra configuration, same method as the headline: placement, warm up, count, >= 5 event-timed launches."""
-    wl = Workload(name, n, seed, device, dev_index, history=history)
+    wl = Workload(name, n, seed, device, dev_index, history=history, delta_history=delta_history)
     try:
         wl.place(placement, tries)
         wl.warmup(warmup)
@@ -668,6 +673,9 @@ def main():
                          "== committed except at plastic / formerly plastic points, so elastic points cost no history "
                          "traffic; full = every launch rewrites the whole trial history (fcamd_evaluate_device_from)")
     ap.add_argument("--sparse-history", action="store_true", help="same as --history sparse (kept for old command lines)")
+    ap.add_argument("--no-delta-history", action="store_true",
+                    help="VonMises3D, --history sparse: write eps_n + gamma N into the trial array (reads the committed rows) instead "
+                         "of the increment alone (ResidentState(delta_history=False))")
     ap.add_argument("--sparse-tangent", action="store_true",
                     help="with --history sparse: also the sparse-tangent protocol of ResidentState (FCAMD_EVAL_SPARSE_TANGENT: "
                          "rows of points that stay elastic are not rewritten).  Not the reference contract -- the reported "
@@ -740,7 +748,7 @@ def main():
     history = "sparse" if args.sparse_history else args.history
     n = args.n
     wl = Workload(name, n, seed=1234 + rank, device=device, dev_index=dev_index, history=history,
-                  sparse_tangent=args.sparse_tangent, grid=args.grid)
+                  sparse_tangent=args.sparse_tangent, grid=args.grid, delta_history=not args.no_delta_history)
     tries = args.placement_tries
     if world > 1 and tries > 1:
         # the candidates are alive together while they are timed: never more than fit next to the working set
@@ -913,7 +921,8 @@ def main():
         for k, cname in enumerate(EXTRA_CONFIGS):
             try:
                 configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
-                                            min(tries, 4), history=history, placement=args.placement, cpu=not args.no_cpu_baseline)
+                                            min(tries, 4), history=history, placement=args.placement, cpu=not args.no_cpu_baseline,
+                                            delta_history=not args.no_delta_history)
             except Exception as e:  # one configuration failing must not lose the line
                 configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()

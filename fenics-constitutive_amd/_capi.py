@@ -27,6 +27,7 @@ COUNTER_SLOTS, COUNTER_WORDS = 64, 256  # FCAMD_COUNTER_SLOTS / FCAMD_COUNTER_WO
 
 # fcamd_eval_args.flags / fcamd_evaluate_resident flags (include/fcamd.h)
 EVAL_SPARSE_TANGENT = 1
+EVAL_DELTA_HISTORY = 2
 
 # fcamd_context_last_host_mode flags (include/fcamd.h)
 HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT = 1, 2
@@ -41,7 +42,8 @@ SYMBOLS = [
     "fcamd_context_synchronize", "fcamd_model_create", "fcamd_model_destroy",
     "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_model_constraint", "fcamd_model_dims",
     "fcamd_evaluate_device",
-    "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
+    "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex",
+    "fcamd_commit_delta_history", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
     "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
     "fcamd_context_last_host_mode", "fcamd_host_device_pointer",
     "fcamd_shard_slot_points", "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_alloc", "fcamd_ipc_free",
@@ -157,6 +159,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_evaluate_device_indexed.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_host.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int, C.POINTER(Stats)]
         lib.fcamd_evaluate_device_ex.argtypes = [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs)]
+        lib.fcamd_commit_delta_history.argtypes = [vp, C.c_int64, vp, vp, vp]
         lib.fcamd_evaluate_device_wrapped.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp,
                                                       C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_resident.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.POINTER(vp),
@@ -451,6 +454,10 @@ class Model:
         x = EvalArgs(grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr or None, parr, arr, nh, rows_ptr or None,
                      mask_ptr or None, int(flags), stress2_ptr or None, counters_ptr or None)
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
+
+    def commit_delta_history(self, n, committed_ptr, delta_ptr, mask_ptr) -> None:
+        check(self._lib.fcamd_commit_delta_history(self.handle, int(n), C.c_void_p(committed_ptr), C.c_void_p(delta_ptr),
+                                                   C.c_void_p(mask_ptr)))
 
     def evaluate_device_wrapped(self, wrapper_constraint, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, stress3d_ptr,
                                 hist_ptrs) -> None:

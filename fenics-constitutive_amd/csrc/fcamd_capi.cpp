@@ -397,7 +397,11 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.rows = rows;
     a.cache3d = nullptr;
     a.hmask = hmask;
-    a.flags = (hmask && tangent) ? flags : 0;
+    a.flags = 0;
+    if (hmask) {
+        if (tangent) a.flags |= flags & FCAMD_EVAL_SPARSE_TANGENT;  // needs an array that holds the previous tangent
+        if (m->law == FCAMD_VON_MISES_3D) a.flags |= flags & FCAMD_EVAL_DELTA_HISTORY;
+    }
     a.n = n;
     a.counters = counters ? counters : m->d_counters;  // caller-owned counters are always reset here
     const Options& o = m->ctx->opt;
@@ -812,6 +816,13 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
         return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
     if ((x->flags & FCAMD_EVAL_SPARSE_TANGENT) && (!x->history_mask || !x->tangent))
         return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_SPARSE_TANGENT needs history_mask and tangent");
+    if (x->flags & FCAMD_EVAL_DELTA_HISTORY) {
+        if (m->law != FCAMD_VON_MISES_3D)
+            return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_DELTA_HISTORY exists for VonMises3D (eps_n is write-only there)");
+        if (!x->history_mask) return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs history_mask");
+        if (x->history && x->history_prev && x->history[0] == x->history_prev[0])
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial eps_n array of its own");
+    }
     if (!aligned16(x->grad_del_u) || !aligned16(x->stress) || !aligned16(x->stress_prev) || !aligned16(x->tangent))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
     for (int k = 0; k < m->info.n_hist; ++k)
@@ -826,6 +837,27 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
                  x->stress2, reinterpret_cast<unsigned long long*>(x->counters));
     if (st != FCAMD_OK) return st;
     return timing_end(m);
+}
+
+int fcamd_commit_delta_history(fcamd_model* m, int64_t n, double* history_committed0, const double* history_delta0,
+                               const uint64_t* history_mask) {
+    if (!m) return fail(FCAMD_ERR_BAD_ARG, "model handle is NULL");
+    if (m->law != FCAMD_VON_MISES_3D)
+        return fail(FCAMD_ERR_UNSUPPORTED, "delta trial history exists for VonMises3D only");
+    if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
+    if (n == 0) return FCAMD_OK;
+    if (!history_committed0 || !history_delta0 || !history_mask) return fail(FCAMD_ERR_BAD_ARG, "NULL array");
+    if (!aligned16(history_committed0) || !aligned16(history_delta0))
+        return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
+    fcamd_context* c = m->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int grid = c->grid_override > 0 ? c->grid_override : c->num_cu * 16;
+    const int64_t need = ((n + 63) / 64 + 3) / 4;
+    if (need < grid) grid = (int)std::max<int64_t>(need, 1);
+    (void)hipGetLastError();  // as in enqueue()
+    HIP_TRY(launch_commit_delta(history_committed0, history_delta0, reinterpret_cast<const unsigned long long*>(history_mask), n,
+                                grid, c->stream));
+    return FCAMD_OK;
 }
 
 int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double t, double del_t, int64_t n,
@@ -1213,7 +1245,7 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         st = enqueue(m, del_t, np, k_grad, stress_prev + SD * p0, stress + SD * p0, k_tan,
                      hp, hc, s, false, nullptr,
                      history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
-                     z_tan ? flags : 0);  // the staging buffer of a chunk holds no previous tangent: full rows
+                     z_tan ? flags : (flags & ~FCAMD_EVAL_SPARSE_TANGENT));  // the staging buffer of a chunk holds no previous tangent: full rows
         if (st != FCAMD_OK) return drain_and_return(c, st);
         if (stress_host)
             HIP_TRY_DRAIN(c, hipMemcpyAsync(stress_host + SD * p0, stress + SD * p0, (size_t)np * SD * sizeof(double),

@@ -204,7 +204,7 @@ class DeviceLaw(IncrSmallStrainModel):
         )
 
     def evaluate_from(self, t, del_t, grad_del_u, stress_prev, stress, tangent, history_prev, history,
-                      history_mask=None, sparse_tangent: bool = False, counters=None) -> None:
+                      history_mask=None, sparse_tangent: bool = False, counters=None, delta_history: bool = False) -> None:
         """Out-of-place device evaluate: read the committed state (``stress_prev``,
         ``history_prev``), write the trial state (``stress``, ``history``).  Fuses the two
         copies the reference makes before every call (solver/_lawonsubmesh.py:58-61,
@@ -213,7 +213,9 @@ class DeviceLaw(IncrSmallStrainModel):
         formerly plastic points are rewritten (FCAMD_EVAL_SPARSE_TANGENT, include/fcamd.h).  ``counters``:
         caller-owned int64 device tensor of ``_capi.COUNTER_WORDS`` words that receives this launch's
         statistics instead of the law's own counters (``fcamd_eval_args.counters``; read it with
-        ``read_counters``)."""
+        ``read_counters``).  ``delta_history`` (VonMises3D, with ``history_mask``): the trial ``eps_n`` array
+        receives the increment at the plastic points and the committed one is not read
+        (FCAMD_EVAL_DELTA_HISTORY; commit with ``commit_delta_history``)."""
         hist = self._history_arrays(history)
         hprev = self._history_arrays(history_prev)
         gd2, sd = self.geometric_dim**2, self.stress_strain_dim
@@ -232,13 +234,16 @@ class DeviceLaw(IncrSmallStrainModel):
         dev = grad_del_u.device.index or 0
         m = self._handle(dev)
         m.ctx.set_stream(_current_stream_ptr(dev))
-        if (sparse_tangent and tangent is not None) or counters is not None:
+        if (sparse_tangent and tangent is not None) or counters is not None or delta_history:
+            flags = _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tangent is not None and history_mask is not None) else 0
+            if delta_history:
+                assert history_mask is not None, "delta_history needs history_mask"
+                flags |= _capi.EVAL_DELTA_HISTORY
             m.evaluate_device_ex(
                 t, del_t, n, grad_del_u.data_ptr(), stress_prev.data_ptr(), stress.data_ptr(),
                 None if tangent is None else _check_torch("tangent", tangent).data_ptr(),
                 [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist],
-                None, None if history_mask is None else history_mask.data_ptr(),
-                _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tangent is not None and history_mask is not None) else 0,
+                None, None if history_mask is None else history_mask.data_ptr(), flags,
                 counters_ptr=_counters_ptr(counters))
             return
         m.evaluate_device_from_sparse(
@@ -285,6 +290,17 @@ class DeviceLaw(IncrSmallStrainModel):
             None if history_mask is None else history_mask.data_ptr(),
             _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tan_ptr is not None and history_mask is not None) else 0,
             counters_ptr=_counters_ptr(counters))
+
+    def commit_delta_history(self, committed, delta, history_mask) -> None:
+        """``committed[row] += delta[row]`` for the rows of ``history_mask`` (``fcamd_commit_delta_history``): the
+        commit of a trial ``eps_n`` array written with ``delta_history=True``.  Asynchronous on torch's current stream."""
+        _check_torch("committed", committed), _check_torch("delta", delta)
+        n = committed.numel() // 6
+        assert delta.numel() == committed.numel() and history_mask.numel() >= (n + 63) // 64
+        dev = committed.device.index or 0
+        m = self._handle(dev)
+        m.ctx.set_stream(_current_stream_ptr(dev))
+        m.commit_delta_history(n, committed.data_ptr(), delta.data_ptr(), history_mask.data_ptr())
 
     def raise_for_stats(self, st) -> None:
         """The reference's errors for the counters of a finished launch: the Drucker-Prager tip

@@ -322,3 +322,52 @@ def test_vmm_placement_moves_the_state_and_keeps_results(numpy_grad):
     gc.collect()
     torch.cuda.synchronize()
     assert torch.equal(keep, ref)  # the view keeps the working set's memory alive
+
+
+@pytest.mark.parametrize("n", [64 * 30 + 11, 4000])
+def test_delta_trial_history_equals_the_plain_protocols(n):
+    """Delta trial history (FCAMD_EVAL_DELTA_HISTORY, ResidentState's default for VonMises3D): during the Newton
+    iterations the trial eps_n array holds only the increments of the plastic points and the committed rows are never
+    read; update() adds them to the committed array.  Stress, tangent, alpha, the assembled trial eps_n and every
+    committed state must equal the sparse protocol without it and the full protocol bit for bit, over growing,
+    shrinking and vanishing plastic sets, device and host-assembler calls."""
+    rng = np.random.default_rng(n)
+    law, s0, h0, grad = _sparse_case("VonMises3D", n, rng)
+    d = ResidentState(law, n, stress0=s0, history0=h0)                               # delta (default)
+    p = ResidentState(law, n, stress0=s0, history0=h0, delta_history=False)          # sparse, eps_n + gamma N in the trial array
+    f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False)
+    assert d._delta and not p._delta and not f._delta
+    sh, th = np.empty(6 * n), np.empty(36 * n)
+    for inc in range(5):
+        for it in range(3):
+            g = grad(all_elastic=(inc == 2 and it == 1), zoned=(inc % 2 == 1))
+            if (inc, it) == (3, 1):  # one host-assembler pass in between (fcamd_evaluate_resident with the flag)
+                d.evaluate_into(0.0, 1.0, g.cpu().numpy(), sh, th)
+            else:
+                d.evaluate(0.0, 1.0, g)
+            p.evaluate(0.0, 1.0, g)
+            f.evaluate(0.0, 1.0, g)
+            assert torch.equal(d.stress, f.stress) and torch.equal(p.stress, f.stress), (inc, it)
+            if (inc, it) == (3, 1):
+                assert np.array_equal(th, f.tangent.cpu().numpy()) and np.array_equal(sh, f.stress.cpu().numpy())
+            else:
+                assert torch.equal(d.tangent, f.tangent), (inc, it)
+            for k in h0:
+                assert torch.equal(d.history[k], f.history[k]), (inc, it, k)
+                assert torch.equal(d.history_committed[k], f.history_committed[k]), (inc, it, k)
+        d.update(), p.update(), f.update()
+        for k in h0:
+            assert torch.equal(d.history_committed[k], f.history_committed[k]), (inc, k)
+            assert torch.equal(d.history[k], f.history_committed[k]) or k != "eps_n"  # nothing evaluated yet: trial == committed
+    # the flag is VonMises3D's: other laws refuse it, and it needs a trial array of its own
+    rs, s1, h1, grad1 = _sparse_case("MisesPlasticityLinearHardening3D", n, rng)
+    st = ResidentState(rs, n, stress0=s1, history0=h1)
+    assert not st._delta
+    mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    g = grad1(all_elastic=False, zoned=False)
+    with pytest.raises(NotImplementedError, match="DELTA_HISTORY"):
+        rs.evaluate_from(0.0, 1.0, g, st.stress_committed, st.stress, st.tangent, st.history_committed, st.history,
+                         history_mask=mask, delta_history=True)
+    with pytest.raises(ValueError, match="trial eps_n array of its own"):
+        law.evaluate_from(0.0, 1.0, grad(all_elastic=False, zoned=False), f.stress_committed, f.stress, f.tangent,
+                          f.history_committed, f.history_committed, history_mask=mask, delta_history=True)
