@@ -38,7 +38,7 @@ class ResidentState:
 
     def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
                  reuse_constant_tangent: bool = True, sparse_tangent: bool = True, placement: str = "auto",
-                 delta_history: bool = True):
+                 delta_history: bool = False):
         """``placement`` (device-assembler mode, large states): where the arrays the kernel streams
         live decides 10-28 % of its time on MI355X.  "vmm": on the first ``evaluate`` the state moves its arrays
         (both stress / history copies, tangent, gradient staging) into ONE working set whose 2 MiB physical
@@ -49,10 +49,13 @@ class ResidentState:
         import torch
 
         assert placement in ("auto", "vmm", "tune", "torch")
-        # ``delta_history`` (VonMises3D with the sparse protocol): ``eps_n`` is write-only for the stress update, so the
-        # trial array holds the INCREMENT of the plastic points during the Newton iterations, the committed rows are
-        # never read by ``evaluate`` (-3.5 % kernel time on a 22 % plastic mixture) and ``update()`` adds the increments
-        # of the plastic points to the committed array.  ``history`` (the trial view) assembles eps_n on demand.
+        # ``delta_history`` (opt-in; VonMises3D with the sparse protocol): ``eps_n`` is write-only for the stress update
+        # (mises_plasticity_isotropic_hardening.py:161 only adds gamma N to it), so the trial array can hold the INCREMENT
+        # of the plastic points during the Newton iterations: the committed rows are then never read by ``evaluate``
+        # (-0.5 ms of 8.5 ms per launch at 1e8 points, 22-31 % plastic) and ``update()`` adds the increments of the plastic
+        # points to the committed array (one scattered pass, 2.0 ms at 1e8 points).  Measured break-even: 4 Newton
+        # iterations per increment (bench.py "delta_trial_history") -- a gain for long Newton loops only, hence not the
+        # default.  ``history`` (the trial view) assembles eps_n on demand.
 
         self.law, self.n = law, int(n)
         from . import _capi

@@ -326,15 +326,15 @@ def test_vmm_placement_moves_the_state_and_keeps_results(numpy_grad):
 
 @pytest.mark.parametrize("n", [64 * 30 + 11, 4000])
 def test_delta_trial_history_equals_the_plain_protocols(n):
-    """Delta trial history (FCAMD_EVAL_DELTA_HISTORY, ResidentState's default for VonMises3D): during the Newton
+    """Delta trial history (FCAMD_EVAL_DELTA_HISTORY, ResidentState(delta_history=True), VonMises3D): during the Newton
     iterations the trial eps_n array holds only the increments of the plastic points and the committed rows are never
     read; update() adds them to the committed array.  Stress, tangent, alpha, the assembled trial eps_n and every
     committed state must equal the sparse protocol without it and the full protocol bit for bit, over growing,
     shrinking and vanishing plastic sets, device and host-assembler calls."""
     rng = np.random.default_rng(n)
     law, s0, h0, grad = _sparse_case("VonMises3D", n, rng)
-    d = ResidentState(law, n, stress0=s0, history0=h0)                               # delta (default)
-    p = ResidentState(law, n, stress0=s0, history0=h0, delta_history=False)          # sparse, eps_n + gamma N in the trial array
+    d = ResidentState(law, n, stress0=s0, history0=h0, delta_history=True)           # increments in the trial eps_n array
+    p = ResidentState(law, n, stress0=s0, history0=h0)                               # sparse (default), eps_n + gamma N in the trial array
     f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False)
     assert d._delta and not p._delta and not f._delta
     sh, th = np.empty(6 * n), np.empty(36 * n)
@@ -361,7 +361,7 @@ def test_delta_trial_history_equals_the_plain_protocols(n):
             assert torch.equal(d.history[k], f.history_committed[k]) or k != "eps_n"  # nothing evaluated yet: trial == committed
     # the flag is VonMises3D's: other laws refuse it, and it needs a trial array of its own
     rs, s1, h1, grad1 = _sparse_case("MisesPlasticityLinearHardening3D", n, rng)
-    st = ResidentState(rs, n, stress0=s1, history0=h1)
+    st = ResidentState(rs, n, stress0=s1, history0=h1, delta_history=True)
     assert not st._delta
     mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
     g = grad1(all_elastic=False, zoned=False)

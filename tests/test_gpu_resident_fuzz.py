@@ -20,12 +20,15 @@ def own(k):
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
-@pytest.mark.parametrize("kind", ["von_mises_3d", "comfe_mises_plasticity", "linear_elasticity", "spring_maxwell"])
+@pytest.mark.parametrize("kind", ["von_mises_3d", "von_mises_3d+delta_history", "comfe_mises_plasticity", "linear_elasticity",
+                                  "spring_maxwell"])
 def test_random_call_sequences(kind, seed):
     n = 64 * 90 + 17
+    kind, _, option = kind.partition("+")
     p, g0, s, h = random_case(kind, n, seed=seed)
     law = make_law(kind, p)
-    opt = ResidentState(law, n, stress0=s, history0=h)
+    opt = ResidentState(law, n, stress0=s, history0=h, delta_history=option == "delta_history")
+    assert opt._delta == (option == "delta_history")
     ref = ResidentState(law, n, stress0=s, history0=h, sparse_history=False, sparse_tangent=False,
                         reuse_constant_tangent=False)
     rng = np.random.default_rng(100 + seed)
