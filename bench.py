@@ -433,9 +433,9 @@ def cpu_quick(wl, budget_s=1.0, ns=1_000_000):
 
     ns = min(ns, wl.n)
     dims = {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}
-    g = wl.grads[0][: 9 * ns].cpu().numpy()
-    s0 = wl.stress_c[: 6 * ns].cpu().numpy()
-    h0 = None if wl.hist_c is None else {k: v[: dims[k] * ns].cpu().numpy() for k, v in wl.hist_c.items()}
+    g = to_host(wl.grads[0][: 9 * ns])
+    s0 = to_host(wl.stress_c[: 6 * ns])
+    h0 = None if wl.hist_c is None else {k: to_host(v[: dims[k] * ns]) for k, v in wl.hist_c.items()}
     tan = np.zeros(36 * ns)
     out = {}
     for label, fn, m in (("c_port_1_thread_Mpts_s", CO.MODELS[wl.kind], ns), ("numpy_port_Mpts_s", NO.MODELS[wl.kind], min(ns, 200_000))):
@@ -464,10 +464,10 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
     from oracle import c_oracle as CO
 
     ns = min(grad.numel() // 9, 2_000_000)
-    g = grad[: 9 * ns].cpu().numpy()
-    s0 = stress[: 6 * ns].cpu().numpy()
+    g = to_host(grad[: 9 * ns])
+    s0 = to_host(stress[: 6 * ns])
     dims = {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}
-    h0 = None if hist is None else {k: v[: dims[k] * ns].cpu().numpy() for k, v in hist.items()}
+    h0 = None if hist is None else {k: to_host(v[: dims[k] * ns]) for k, v in hist.items()}
     tan = np.zeros(36 * ns)
     fn = CO.MODELS[kind]
 

@@ -30,7 +30,7 @@ EVAL_SPARSE_TANGENT = 1
 EVAL_DELTA_HISTORY = 2
 
 # fcamd_context_last_host_mode flags (include/fcamd.h)
-HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT = 1, 2
+HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT, HOST_TEMP_LOCK, HOST_BOUNCE = 1, 2, 4, 8
 
 # conversion kinds (include/fcamd.h)
 (GRAD_1D_TO_3D, STRESS_1D_TO_3D, STRESS_3D_TO_1D, TANGENT_3D_TO_1D,
@@ -45,7 +45,7 @@ SYMBOLS = [
     "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex",
     "fcamd_commit_delta_history", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
     "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
-    "fcamd_context_last_host_mode", "fcamd_host_device_pointer",
+    "fcamd_context_last_host_mode", "fcamd_host_device_pointer", "fcamd_copy_to_device", "fcamd_copy_to_host",
     "fcamd_shard_slot_points", "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_alloc", "fcamd_ipc_free",
     "fcamd_ipc_export", "fcamd_ipc_open",
     "fcamd_ipc_close", "fcamd_enable_peer_access", "fcamd_allgather_direct", "fcamd_allgather_direct_wait",
@@ -173,6 +173,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_unregister_host_buffer.argtypes = [vp, vp]
         lib.fcamd_context_last_host_mode.argtypes = [vp, C.POINTER(C.c_int)]
         lib.fcamd_host_device_pointer.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
+        lib.fcamd_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
+        lib.fcamd_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
         lib.fcamd_last_error.restype = C.c_char_p
         lib.fcamd_status_string.restype = C.c_char_p
         lib.fcamd_status_string.argtypes = [C.c_int]
@@ -255,9 +257,18 @@ class Context:
         check(self._lib.fcamd_host_device_pointer(self.handle, C.c_void_p(arr.ctypes.data), arr.nbytes, C.byref(d)))
         return int(d.value)
 
+    def copy_to_device(self, dst_device_ptr: int, src: "np.ndarray") -> None:
+        """``fcamd_copy_to_device``: synchronous, ordered after the context stream, never through the HIP
+        runtime's pageable-copy path (include/fcamd.h)."""
+        check(self._lib.fcamd_copy_to_device(self.handle, C.c_void_p(dst_device_ptr), C.c_void_p(src.ctypes.data), src.nbytes))
+
+    def copy_to_host(self, dst: "np.ndarray", src_device_ptr: int) -> None:
+        check(self._lib.fcamd_copy_to_host(self.handle, C.c_void_p(dst.ctypes.data), C.c_void_p(src_device_ptr), dst.nbytes))
+
     def last_host_mode(self) -> int:
-        """Data path of the last host-entry call: bit 0 = inputs, bit 1 = results moved by the kernel
-        itself (zero copy on page-locked caller arrays); 0 = staged through device buffers."""
+        """Data path of the last host-entry call (HOST_* flags): bit 0 = inputs, bit 1 = results moved by the kernel
+        itself (zero copy on page-locked caller arrays), bit 2 = pageable caller arrays were page-locked for the call,
+        bit 3 = moved by the CPU through the context's page-locked scratch; 0 = staged through device buffers."""
         mode = C.c_int()
         check(self._lib.fcamd_context_last_host_mode(self.handle, C.byref(mode)))
         return int(mode.value)

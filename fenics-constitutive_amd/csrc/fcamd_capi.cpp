@@ -313,6 +313,7 @@ void options_from_env(Options* o) {
     o->host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, geti("FCAMD_HOST_SLOTS", fcamd_context::kSlots)));
     o->zero_copy = geti("FCAMD_ZERO_COPY", 1) != 0;
     o->zero_copy_grad = geti("FCAMD_ZERO_COPY_GRAD", 1) != 0;
+    o->bounce_max = std::max<long long>(0, geti("FCAMD_BOUNCE_MAX", 2 << 20));
 }
 
 // the law's host constants, recomputed only when del_t changes (SLS) -- not once per launch
@@ -447,9 +448,10 @@ int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
 // `staging` = false: every per-chunk array is read / written by the kernel in the caller's page-locked
 // memory (zero copy), the chunks only pipeline the small stress download behind the next launch: no
 // device buffers, and large chunks (2 Mi points: 472 instead of 404 Mpts/s for the resident pass).
-int prepare_chunks(fcamd_context* c, const void* probe_host_ptr, int64_t n, int64_t* chunk_out, bool staging = true) {
+int prepare_chunks(fcamd_context* c, const void* probe_host_ptr, int64_t n, int64_t* chunk_out, bool staging = true,
+                   bool locked = false) {
     {
-        const bool pinned = mapped(c, probe_host_ptr, 8) != nullptr ||
+        const bool pinned = locked || mapped(c, probe_host_ptr, 8) != nullptr ||
                             c->registered.count(static_cast<char*>(const_cast<void*>(probe_host_ptr))) != 0;
         c->chunk_points = c->opt.host_chunk > 0 ? std::max<int64_t>(64, (c->opt.host_chunk / 64) * 64)
                                                 : (!staging ? (1 << 21) : (pinned ? (1 << 17) : (1 << 19)));
@@ -553,6 +555,9 @@ static void free_staging(fcamd_context* c) {
         c->dchunk[i] = nullptr;
     }
     c->dchunk_points = 0;
+    if (c->bounce) (void)hipHostFree(c->bounce);
+    c->bounce = c->bounce_dev = nullptr;
+    c->bounce_bytes = 0;
 }
 
 int fcamd_context_trim(fcamd_context* c) {
@@ -577,6 +582,7 @@ int fcamd_context_set_option(fcamd_context* c, const char* name, long long value
     else if (k == "host_slots") o.host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, value));
     else if (k == "zero_copy") o.zero_copy = value != 0;
     else if (k == "zero_copy_grad") o.zero_copy_grad = value != 0;
+    else if (k == "bounce_max") o.bounce_max = std::max<long long>(0, value);
     else return fail(FCAMD_ERR_BAD_ARG, "unknown option '%s'", name);
     return FCAMD_OK;
 }
@@ -592,6 +598,7 @@ int fcamd_context_get_option(fcamd_context* c, const char* name, long long* valu
     else if (k == "host_slots") *value = o.host_slots;
     else if (k == "zero_copy") *value = o.zero_copy;
     else if (k == "zero_copy_grad") *value = o.zero_copy_grad;
+    else if (k == "bounce_max") *value = o.bounce_max;
     else return fail(FCAMD_ERR_BAD_ARG, "unknown option '%s'", name);
     return FCAMD_OK;
 }
@@ -1082,13 +1089,136 @@ struct HostTimer {
     }
 };
 
+// ---- pageable caller arrays ---------------------------------------------------------------------------------
+// The host entries never hand PAGEABLE caller memory to hipMemcpy*.  The HIP runtime moves such memory (above
+// 1 MiB) in pieces it page-locks on the fly and remembers in a cache keyed by address and size.  On this stack a
+// page lock is an attribute of the process's pages (hsa_amd_memory_lock = KFD SVM "accessible in place"; the GPU
+// sees the memory at its host address): memory that appears LATER at a remembered address -- an array that was
+// freed and allocated again, a heap that shrank and grew -- carries no such attribute, the cache still calls it
+// locked, and the DMA engine faults ("Memory access fault by GPU node-N on address <host address>";
+// tools/hsa_lock_probe.c, tools/pageable_copy_probe.py).  Instead:
+//   * calls that move at most `bounce_max` bytes: the CPU copies inputs into / results out of the context's own
+//     page-locked scratch (hipHostMalloc) and the kernel runs on the scratch;
+//   * larger calls: the caller's arrays are page-locked for the duration of the call (hipHostRegister: the
+//     attribute is set on the pages that are there NOW), the kernel runs directly on them, they are unlocked on
+//     return.  Measured against the runtime's pageable path, VonMises3D, 1e7 points: 254 instead of 270 ms on
+//     arrays never seen before, 80.7 instead of 103.9 ms on arrays used before (tools/temp_register_probe.py);
+//   * arrays that cannot be locked (a range that overlaps somebody else's registration): the scratch again, in chunks.
+class CallerArrays {
+  public:
+    explicit CallerArrays(fcamd_context* c) : c_(c) {}
+    CallerArrays(const CallerArrays&) = delete;
+    CallerArrays& operator=(const CallerArrays&) = delete;
+    ~CallerArrays() { release(); }
+
+    // Makes [p, p + bytes) GPU-accessible for the call and returns the address the GPU sees it at in *dev;
+    // false: it cannot be page-locked (-> bounce).  A range inside a fcamd_register_host_buffer range is used as is.
+    bool lock(const void* p, size_t bytes, char** dev) {
+        *dev = nullptr;
+        if (!p || bytes == 0) return true;
+        char* q = static_cast<char*>(const_cast<void*>(p));
+        if (!c_->registered.empty()) {
+            auto it = c_->registered.upper_bound(q);
+            if (it != c_->registered.begin()) {
+                --it;
+                if (q < it->first + it->second.bytes) {  // starts inside a registered range ...
+                    if (q + bytes > it->first + it->second.bytes || !it->second.dev) return false;  // ... must end there
+                    *dev = it->second.dev + (q - it->first);
+                    return true;
+                }
+            }
+        }
+        hipError_t e = hipHostRegister(q, bytes, hipHostRegisterDefault);
+        if (e == hipSuccess) {
+            temp_.push_back(q);
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            *dev = static_cast<char*>(d);
+            return true;
+        }
+        (void)hipGetLastError();
+        if (e == hipErrorHostMemoryAlreadyRegistered) {
+            // page-locked by somebody else (the application's own hipHostRegister / hipHostMalloc): usable if the
+            // whole range is one mapping
+            void *d0 = nullptr, *d1 = nullptr;
+            if (hipHostGetDevicePointer(&d0, q, 0) == hipSuccess && hipHostGetDevicePointer(&d1, q + bytes - 1, 0) == hipSuccess &&
+                static_cast<char*>(d1) - static_cast<char*>(d0) == static_cast<ptrdiff_t>(bytes - 1)) {
+                *dev = static_cast<char*>(d0);
+                return true;
+            }
+            (void)hipGetLastError();
+        }
+        return false;
+    }
+
+    bool temp_locked() const { return !temp_.empty(); }
+
+    // unlock what this call locked -- only once nothing is in flight on the context's chunk streams
+    void release() {
+        if (temp_.empty()) return;
+        for (int i = 0; i < fcamd_context::kSlots; ++i)
+            if (c_->hstream[i]) (void)hipStreamSynchronize(c_->hstream[i]);
+        for (char* q : temp_) (void)hipHostUnregister(q);
+        (void)hipGetLastError();
+        temp_.clear();
+    }
+
+  private:
+    fcamd_context* c_;
+    std::vector<char*> temp_;
+};
+
+int ensure_bounce(fcamd_context* c, size_t bytes) {
+    if (bytes <= c->bounce_bytes) return FCAMD_OK;
+    if (c->bounce) HIP_TRY(hipHostFree(c->bounce));
+    c->bounce = c->bounce_dev = nullptr;
+    c->bounce_bytes = 0;
+    void* h = nullptr;
+    HIP_TRY(hipHostMalloc(&h, bytes, hipHostMallocDefault));
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(h);
+        return fail(FCAMD_ERR_HIP, "the page-locked scratch buffer is not mapped into the device's address space");
+    }
+    c->bounce = static_cast<char*>(h);
+    c->bounce_dev = static_cast<char*>(d);
+    c->bounce_bytes = bytes;
+    return FCAMD_OK;
+}
+
+// carves 256-byte aligned arrays out of the scratch: host address and the address the GPU sees
+struct BounceLayout {
+    size_t used = 0;
+    size_t take(size_t bytes) {
+        const size_t at = used;
+        used += (bytes + 255) & ~(size_t)255;
+        return at;
+    }
+};
+
+constexpr size_t kBounceChunkBytes = (size_t)64 << 20;  // chunk size of the bounce path when the arrays cannot be locked
+
+// points per chunk of a bounce pass over n points of `bytes_per_point` bytes each
+int64_t bounce_chunk(const fcamd_context* c, int64_t n, size_t bytes_per_point) {
+    const int64_t all = ((n + 63) / 64) * 64;
+    if ((size_t)n * bytes_per_point <= (size_t)c->opt.bounce_max) return all;
+    const int64_t chunk = (int64_t)(kBounceChunkBytes / bytes_per_point / 64) * 64;
+    return std::max<int64_t>(64, std::min<int64_t>(chunk, all));
+}
+
 }  // namespace
 
 extern "C" {
 
-// Host (ndarray) entry.  Page-locked, mapped caller arrays (fcamd_register_host_buffer): one launch
-// directly on them (zero copy).  Otherwise: chunked H2D -> kernel -> D2H over up to four chunk slots on
-// four streams, so that the copies of one chunk overlap the kernel and the copies of the others.
+// Host (ndarray) entry.  The kernel runs directly on the caller's arrays (zero copy): on ranges registered with
+// fcamd_register_host_buffer as they are, on pageable arrays after page-locking them for the duration of the call;
+// small calls and arrays that cannot be locked go through the context's page-locked scratch (CallerArrays above).
+// With the "zero_copy" option off (or an array off the 16-byte grid): chunked H2D -> kernel -> D2H over up to four
+// chunk slots on four streams -- DMA from / into the page-locked arrays.
 int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
                         double* stress, double* tangent, double* const* hist, int n_hist,
                         fcamd_stats* stats) {
@@ -1103,38 +1233,94 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     HIP_TRY(hipSetDevice(c->device));
     if (stats) std::memset(stats, 0, sizeof(*stats));
     const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
+    const int NH = m->info.n_hist;
     c->last_host_mode = 0;
+    if (!c->hstream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
+        return finish_chunks(m, stats);
+    }
+    const size_t N = (size_t)n;
+    size_t hist_doubles = 0;
+    for (int k = 0; k < NH; ++k) hist_doubles += (size_t)m->info.hist[k].dim;
+    const size_t bytes_per_point = (GD2 + SD + (tangent ? TD : 0) + hist_doubles) * sizeof(double);
 
-    // Zero copy: when every array of the call lies in page-locked, GPU-mapped memory
-    // (fcamd_register_host_buffer) the kernel runs directly on the caller's arrays -- it reads the
-    // inputs and writes the results over PCIe itself, both directions at once, one launch, no
-    // staging buffers.  Measured on MI355X / PCIe gen5 (tools/zero_copy_probe.py, VonMises3D):
-    // 140 instead of 117 Mpts/s at 1e7 points (55 GB/s of device-to-host traffic), 40 instead of
-    // 145 us per call at 1e3 points.
-    if (n > 0 && zero_copy_enabled(c)) {
-        const size_t N = (size_t)n;
-        double* z_grad = mapped(c, grad, N * GD2 * sizeof(double));
-        double* z_stress = mapped(c, stress, N * SD * sizeof(double));
-        double* z_tan = tangent ? mapped(c, tangent, N * TD * sizeof(double)) : nullptr;
-        double* z_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-        bool all = z_grad && z_stress && (!tangent || z_tan);
-        for (int k = 0; k < m->info.n_hist && all; ++k) {
-            z_hist[k] = mapped(c, hist[k], N * (size_t)m->info.hist[k].dim * sizeof(double));
-            all = z_hist[k] != nullptr;
-        }
-        if (all) {
-            c->last_host_mode = FCAMD_HOST_ZERO_COPY_IN | FCAMD_HOST_ZERO_COPY_OUT;
-            if (!c->hstream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
-            hipStream_t s = c->hstream[0];
-            HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
-            st = enqueue(m, del_t, n, z_grad, z_stress, z_stress, z_tan, z_hist, z_hist, s, false);
-            if (st != FCAMD_OK) return drain_and_return(c, st);
-            return finish_chunks(m, stats);
-        }
+    // every array inside the caller's registered ranges: nothing to lock, whatever the size
+    bool all_registered = mapped(c, grad, N * GD2 * sizeof(double)) && mapped(c, stress, N * SD * sizeof(double)) &&
+                          (!tangent || mapped(c, tangent, N * TD * sizeof(double)));
+    for (int k = 0; k < NH && all_registered; ++k)
+        all_registered = mapped(c, hist[k], N * (size_t)m->info.hist[k].dim * sizeof(double)) != nullptr;
+
+    CallerArrays arrays(c);
+    char *z_grad = nullptr, *z_stress = nullptr, *z_tan = nullptr, *z_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+    bool locked = false;
+    if (all_registered || N * bytes_per_point > (size_t)c->opt.bounce_max) {
+        locked = arrays.lock(grad, N * GD2 * sizeof(double), &z_grad) && arrays.lock(stress, N * SD * sizeof(double), &z_stress) &&
+                 arrays.lock(tangent, tangent ? N * TD * sizeof(double) : 0, &z_tan);
+        for (int k = 0; k < NH && locked; ++k)
+            locked = arrays.lock(hist[k], N * (size_t)m->info.hist[k].dim * sizeof(double), &z_hist[k]);
+        if (!locked) arrays.release();
     }
 
+    if (!locked) {
+        // bounce: CPU copies through the context's page-locked scratch, one launch per chunk
+        c->last_host_mode = FCAMD_HOST_BOUNCE;
+        const int64_t chunk = bounce_chunk(c, n, bytes_per_point);
+        BounceLayout lay;
+        const size_t o_grad = lay.take((size_t)chunk * GD2 * sizeof(double)), o_stress = lay.take((size_t)chunk * SD * sizeof(double));
+        const size_t o_tan = tangent ? lay.take((size_t)chunk * TD * sizeof(double)) : 0;
+        size_t o_hist[FCAMD_MAX_HISTORY] = {0, 0};
+        for (int k = 0; k < NH; ++k) o_hist[k] = lay.take((size_t)chunk * (size_t)m->info.hist[k].dim * sizeof(double));
+        st = ensure_bounce(c, lay.used);
+        if (st != FCAMD_OK) return st;
+        hipStream_t s = c->hstream[0];
+        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
+        for (int64_t p0 = 0; p0 < n; p0 += chunk) {
+            const size_t np = (size_t)std::min<int64_t>(chunk, n - p0);
+            std::memcpy(c->bounce + o_grad, grad + GD2 * p0, np * GD2 * sizeof(double));
+            std::memcpy(c->bounce + o_stress, stress + SD * p0, np * SD * sizeof(double));
+            double* d_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+            for (int k = 0; k < NH; ++k) {
+                const size_t d = (size_t)m->info.hist[k].dim;
+                std::memcpy(c->bounce + o_hist[k], hist[k] + d * p0, np * d * sizeof(double));
+                d_hist[k] = reinterpret_cast<double*>(c->bounce_dev + o_hist[k]);
+            }
+            double* d_stress = reinterpret_cast<double*>(c->bounce_dev + o_stress);
+            st = enqueue(m, del_t, (int64_t)np, reinterpret_cast<const double*>(c->bounce_dev + o_grad), d_stress, d_stress,
+                         tangent ? reinterpret_cast<double*>(c->bounce_dev + o_tan) : nullptr, d_hist, d_hist, s, false);
+            if (st != FCAMD_OK) return drain_and_return(c, st);
+            HIP_TRY_DRAIN(c, hipStreamSynchronize(s));
+            std::memcpy(stress + SD * p0, c->bounce + o_stress, np * SD * sizeof(double));
+            if (tangent) std::memcpy(tangent + TD * p0, c->bounce + o_tan, np * TD * sizeof(double));
+            for (int k = 0; k < NH; ++k) {
+                const size_t d = (size_t)m->info.hist[k].dim;
+                std::memcpy(hist[k] + d * p0, c->bounce + o_hist[k], np * d * sizeof(double));
+            }
+        }
+        return finish_chunks(m, stats);
+    }
+
+    if (arrays.temp_locked()) c->last_host_mode |= FCAMD_HOST_TEMP_LOCK;
+    bool aligned = aligned16(z_grad) && aligned16(z_stress) && (!tangent || aligned16(z_tan));
+    for (int k = 0; k < NH; ++k) aligned = aligned && aligned16(z_hist[k]);
+    // Zero copy: one launch directly on the (page-locked) caller arrays -- the GPU reads the inputs and writes the
+    // results over PCIe itself, both directions at once, no staging buffers.  Measured on MI355X / PCIe gen5
+    // (tools/zero_copy_probe.py, VonMises3D): 140 instead of 117 Mpts/s at 1e7 points (55 GB/s of device-to-host
+    // traffic), 40 instead of 145 us per call at 1e3 points.
+    if (zero_copy_enabled(c) && aligned) {
+        c->last_host_mode |= FCAMD_HOST_ZERO_COPY_IN | FCAMD_HOST_ZERO_COPY_OUT;
+        hipStream_t s = c->hstream[0];
+        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
+        double* zh[FCAMD_MAX_HISTORY] = {reinterpret_cast<double*>(z_hist[0]), reinterpret_cast<double*>(z_hist[1])};
+        double* zs = reinterpret_cast<double*>(z_stress);
+        st = enqueue(m, del_t, n, reinterpret_cast<const double*>(z_grad), zs, zs, reinterpret_cast<double*>(z_tan), zh, zh, s, false);
+        if (st != FCAMD_OK) return drain_and_return(c, st);
+        return finish_chunks(m, stats);
+    }
+
+    // chunked DMA pipeline between the page-locked caller arrays and device buffers
     int64_t chunk = 0;
-    st = prepare_chunks(c, grad, n, &chunk);
+    st = prepare_chunks(c, grad, n, &chunk, /*staging=*/true, /*locked=*/true);
     if (st != FCAMD_OK) return st;
     const int nslots = c->opt.host_slots;
 
@@ -1151,7 +1337,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
         double* d_tan = d_stress + 6 * c->dchunk_points;
         double* d_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
         double* cur = d_tan + 36 * c->dchunk_points;
-        for (int k = 0; k < m->info.n_hist; ++k) {
+        for (int k = 0; k < NH; ++k) {
             d_hist[k] = cur;
             cur += (size_t)m->info.hist[k].dim * c->dchunk_points;
             // keep 16-byte alignment for odd per-point dimensions (alpha: 1, comfe history: 7)
@@ -1159,7 +1345,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
         }
         HIP_TRY_DRAIN(c, hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
         HIP_TRY_DRAIN(c, hipMemcpyAsync(d_stress, stress + SD * p0, (size_t)np * SD * sizeof(double), hipMemcpyHostToDevice, s));
-        for (int k = 0; k < m->info.n_hist; ++k) {
+        for (int k = 0; k < NH; ++k) {
             const size_t d = (size_t)m->info.hist[k].dim;
             HIP_TRY_DRAIN(c, hipMemcpyAsync(d_hist[k], hist[k] + d * p0, (size_t)np * d * sizeof(double), hipMemcpyHostToDevice, s));
         }
@@ -1168,7 +1354,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
         HIP_TRY_DRAIN(c, hipMemcpyAsync(stress + SD * p0, d_stress, (size_t)np * SD * sizeof(double), hipMemcpyDeviceToHost, s));
         if (tangent)
             HIP_TRY_DRAIN(c, hipMemcpyAsync(tangent + TD * p0, d_tan, (size_t)np * TD * sizeof(double), hipMemcpyDeviceToHost, s));
-        for (int k = 0; k < m->info.n_hist; ++k) {
+        for (int k = 0; k < NH; ++k) {
             const size_t d = (size_t)m->info.hist[k].dim;
             HIP_TRY_DRAIN(c, hipMemcpyAsync(hist[k] + d * p0, d_hist[k], (size_t)np * d * sizeof(double), hipMemcpyDeviceToHost, s));
         }
@@ -1199,16 +1385,74 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     if (stats) std::memset(stats, 0, sizeof(*stats));
     HIP_TRY(hipStreamSynchronize(c->stream));  // the state arrays may have work queued on the caller's stream
     const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
-    const bool zc = n > 0 && zero_copy_enabled(c);
-    const double* z_grad = (zc && c->opt.zero_copy_grad) ? mapped(c, grad, (size_t)n * GD2 * sizeof(double)) : nullptr;
-    double* z_tan = (zc && tangent_host) ? mapped(c, tangent_host, (size_t)n * TD * sizeof(double)) : nullptr;
-    c->last_host_mode = (z_grad ? FCAMD_HOST_ZERO_COPY_IN : 0) | (z_tan ? FCAMD_HOST_ZERO_COPY_OUT : 0);
+    c->last_host_mode = 0;
+    if (!c->hstream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
+        return finish_chunks(m, stats);
+    }
+    const size_t N = (size_t)n;
+    const size_t bytes_per_point = (GD2 + (stress_host ? SD : 0) + (tangent_host ? TD : 0)) * sizeof(double);
+    const bool all_registered = mapped(c, grad, N * GD2 * sizeof(double)) &&
+                                (!stress_host || mapped(c, stress_host, N * SD * sizeof(double))) &&
+                                (!tangent_host || mapped(c, tangent_host, N * TD * sizeof(double)));
+    // the host arrays of the pass: ranges the caller registered as they are, pageable ones page-locked for the
+    // duration of the call, small passes through the context's page-locked scratch (CallerArrays)
+    CallerArrays arrays(c);
+    char *l_grad = nullptr, *l_stress = nullptr, *l_tan = nullptr;
+    bool locked = false;
+    if (all_registered || N * bytes_per_point > (size_t)c->opt.bounce_max) {
+        locked = arrays.lock(grad, N * GD2 * sizeof(double), &l_grad) &&
+                 arrays.lock(stress_host, stress_host ? N * SD * sizeof(double) : 0, &l_stress) &&
+                 arrays.lock(tangent_host, tangent_host ? N * TD * sizeof(double) : 0, &l_tan);
+        if (!locked) arrays.release();
+    }
+    if (!locked) {
+        c->last_host_mode = FCAMD_HOST_BOUNCE;
+        const int64_t chunk = bounce_chunk(c, n, bytes_per_point);
+        BounceLayout lay;
+        const size_t o_grad = lay.take((size_t)chunk * GD2 * sizeof(double));
+        const size_t o_stress = stress_host ? lay.take((size_t)chunk * SD * sizeof(double)) : 0;
+        const size_t o_tan = tangent_host ? lay.take((size_t)chunk * TD * sizeof(double)) : 0;
+        st = ensure_bounce(c, lay.used);
+        if (st != FCAMD_OK) return st;
+        hipStream_t s = c->hstream[0];
+        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
+        const bool second_store = stress_host && m->dims.gdim == 3;  // the 3-D kernels can store the stress twice
+        for (int64_t p0 = 0; p0 < n; p0 += chunk) {
+            const size_t np = (size_t)std::min<int64_t>(chunk, n - p0);
+            std::memcpy(c->bounce + o_grad, grad + GD2 * p0, np * GD2 * sizeof(double));
+            const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+            double* hc[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+            for (int k = 0; k < m->info.n_hist; ++k) {
+                const size_t d = (size_t)m->info.hist[k].dim;
+                hp[k] = hist_prev[k] + d * p0;
+                hc[k] = hist[k] + d * p0;
+            }
+            // the scratch holds no previous tangent: every row is written (no sparse tangent)
+            st = enqueue(m, del_t, (int64_t)np, reinterpret_cast<const double*>(c->bounce_dev + o_grad), stress_prev + SD * p0,
+                         stress + SD * p0, tangent_host ? reinterpret_cast<double*>(c->bounce_dev + o_tan) : nullptr, hp, hc, s, false,
+                         nullptr, history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
+                         flags & ~FCAMD_EVAL_SPARSE_TANGENT, second_store ? reinterpret_cast<double*>(c->bounce_dev + o_stress) : nullptr);
+            if (st != FCAMD_OK) return drain_and_return(c, st);
+            if (stress_host && !second_store)
+                HIP_TRY_DRAIN(c, hipMemcpyAsync(c->bounce + o_stress, stress + SD * p0, np * SD * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY_DRAIN(c, hipStreamSynchronize(s));
+            if (stress_host) std::memcpy(stress_host + SD * p0, c->bounce + o_stress, np * SD * sizeof(double));
+            if (tangent_host) std::memcpy(tangent_host + TD * p0, c->bounce + o_tan, np * TD * sizeof(double));
+        }
+        return finish_chunks(m, stats);
+    }
+    if (arrays.temp_locked()) c->last_host_mode |= FCAMD_HOST_TEMP_LOCK;
+    const bool zc = zero_copy_enabled(c);
+    const double* z_grad = (zc && c->opt.zero_copy_grad && aligned16(l_grad)) ? reinterpret_cast<const double*>(l_grad) : nullptr;
+    double* z_tan = (zc && tangent_host && aligned16(l_tan)) ? reinterpret_cast<double*>(l_tan) : nullptr;
+    c->last_host_mode |= (z_grad ? FCAMD_HOST_ZERO_COPY_IN : 0) | (z_tan ? FCAMD_HOST_ZERO_COPY_OUT : 0);
     // Everything the pass moves lies in page-locked caller memory and the law is a 3-D one (whose stress
     // store can feed two destinations): ONE launch reads the gradient from and writes stress and tangent
     // to the host arrays while it updates the device-resident state -- no chunks, no copies.
-    double* z_stress = (zc && stress_host && m->dims.gdim == 3) ? mapped(c, stress_host, (size_t)n * SD * sizeof(double)) : nullptr;
+    double* z_stress = (zc && stress_host && m->dims.gdim == 3 && aligned16(l_stress)) ? reinterpret_cast<double*>(l_stress) : nullptr;
     if (z_grad && (z_tan || !tangent_host) && (z_stress || !stress_host) && m->dims.gdim == 3) {
-        if (!c->hstream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
         hipStream_t s = c->hstream[0];
         HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         st = enqueue(m, del_t, n, z_grad, stress_prev, stress, z_tan, hist_prev, hist, s, false, nullptr,
@@ -1217,7 +1461,7 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         return finish_chunks(m, stats);
     }
     int64_t chunk = 0;
-    st = prepare_chunks(c, grad, n, &chunk, /*staging=*/!(z_grad && (z_tan || !tangent_host)));
+    st = prepare_chunks(c, grad, n, &chunk, /*staging=*/!(z_grad && (z_tan || !tangent_host)), /*locked=*/true);
     if (st != FCAMD_OK) return st;
     const int nslots = c->opt.host_slots;
     HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
@@ -1255,6 +1499,62 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
                                             hipMemcpyDeviceToHost, s));
     }
     return finish_chunks(m, stats);
+}
+
+}  // extern "C"
+
+namespace {
+
+// One synchronous copy between caller host memory and device memory, ordered after the work queued on the
+// context stream, by the rules of the host entries (CallerArrays): never the runtime's pageable-copy path.
+int host_copy(fcamd_context* c, char* dev, char* host, size_t bytes, bool to_device) {
+    if (!c || (bytes && (!dev || !host))) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    if (bytes == 0) return FCAMD_OK;
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    CallerArrays arrays(c);
+    char* z = nullptr;
+    if ((mapped(c, host, 8) || bytes > (size_t)c->opt.bounce_max) && arrays.lock(host, bytes, &z)) {
+        const hipError_t e = to_device ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s)
+                                       : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
+        const hipError_t e2 = hipStreamSynchronize(s);  // before the arrays are unlocked, whatever happened
+        if (e != hipSuccess || e2 != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(FCAMD_ERR_HIP, "copy between page-locked host memory and the device failed: %s",
+                        hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+        return FCAMD_OK;
+    }
+    arrays.release();
+    const size_t piece = std::min(bytes, std::max<size_t>((size_t)c->opt.bounce_max, kBounceChunkBytes));
+    int st = ensure_bounce(c, piece);
+    if (st != FCAMD_OK) return st;
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t nb = std::min(piece, bytes - off);
+        if (to_device) {
+            std::memcpy(c->bounce, host + off, nb);
+            HIP_TRY(hipMemcpyAsync(dev + off, c->bounce, nb, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->bounce, dev + off, nb, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            std::memcpy(host + off, c->bounce, nb);
+        }
+    }
+    return FCAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fcamd_copy_to_device(fcamd_context* c, void* dst_device, const void* src_host, size_t bytes) {
+    return host_copy(c, static_cast<char*>(dst_device), static_cast<char*>(const_cast<void*>(src_host)), bytes, true);
+}
+
+int fcamd_copy_to_host(fcamd_context* c, void* dst_host, const void* src_device, size_t bytes) {
+    return host_copy(c, static_cast<char*>(const_cast<void*>(src_device)), static_cast<char*>(dst_host), bytes, false);
 }
 
 }  // extern "C"

@@ -54,6 +54,8 @@ struct Options {
     int host_slots = 4;        // FCAMD_HOST_SLOTS    chunk slots in flight (1..4)
     int zero_copy = 1;         // FCAMD_ZERO_COPY     0 keeps page-locked caller arrays on the staged path
     int zero_copy_grad = 1;    // FCAMD_ZERO_COPY_GRAD 0: fcamd_evaluate_resident uploads the gradient by DMA even if page-locked
+    long long bounce_max = 2 << 20;  // FCAMD_BOUNCE_MAX  host calls that move at most this many bytes of pageable caller memory go
+                                     // through the context's own page-locked scratch (CPU copies); larger ones page-lock the arrays
 };
 
 }  // namespace fcamd
@@ -82,7 +84,11 @@ struct fcamd_context {
     // may unregister a buffer from another thread while the owning thread is inside a host call (ctypes
     // releases the GIL); the unregistration then waits for that call instead of racing it.
     std::recursive_mutex host_mu;
-    int last_host_mode = 0;  // FCAMD_HOST_ZERO_COPY_* flags of the last host-entry call
+    int last_host_mode = 0;  // FCAMD_HOST_* flags of the last host-entry call
+    // page-locked scratch of the bounce path (hipHostMalloc: pages of its own, locked for its whole life)
+    char* bounce = nullptr;
+    char* bounce_dev = nullptr;  // the address the GPU sees it at
+    size_t bounce_bytes = 0;
     // direct all-gather (fcamd_multigpu.cpp): one copy stream per peer, created on first use
     std::vector<hipStream_t> peer_streams;
     std::vector<hipEvent_t> peer_events;

@@ -374,8 +374,10 @@ def strain_from_grad_u_full(grad_u):
     g = np.ascontiguousarray(np.asarray(grad_u, dtype=np.float64)).reshape(-1)
     if not torch.cuda.is_available():
         raise RuntimeError("strain_from_grad_u(FULL) runs on the GPU and no HIP device is available")
-    d = torch.from_numpy(g).to(torch.device("cuda", _capi.default_device()))
-    return strain_from_grad_u_full(d).cpu().numpy()
+    from .hostio import to_device, to_host
+
+    d = to_device(g, torch.device("cuda", _capi.default_device()))
+    return to_host(strain_from_grad_u_full(d))
 
 
 def strain_from_grad_u_lowdim(grad_u, constraint):
@@ -393,8 +395,9 @@ def strain_from_grad_u_lowdim(grad_u, constraint):
     if host:
         if not torch.cuda.is_available():
             raise RuntimeError("strain_from_grad_u runs on the GPU and no HIP device is available")
-        g = torch.from_numpy(np.ascontiguousarray(np.asarray(grad_u, dtype=np.float64)).reshape(-1)).to(
-            torch.device("cuda", _capi.default_device()))
+        from .hostio import to_device
+
+        g = to_device(np.asarray(grad_u, dtype=np.float64).reshape(-1), torch.device("cuda", _capi.default_device()))
     else:
         g = _check_torch("grad_u", grad_u).reshape(-1)
     n = g.numel() // gd2
@@ -408,4 +411,8 @@ def strain_from_grad_u_lowdim(grad_u, constraint):
     _capi.check(lib.fcamd_convert_device(ctx.handle, up, n, C.c_void_p(g.data_ptr()), C.c_void_p(g3.data_ptr())))
     _capi.check(lib.fcamd_strain_from_grad_u_device(ctx.handle, n, C.c_void_p(g3.data_ptr()), C.c_void_p(e3.data_ptr()), 0))
     _capi.check(lib.fcamd_convert_device(ctx.handle, down, n, C.c_void_p(e3.data_ptr()), C.c_void_p(out.data_ptr())))
-    return out.cpu().numpy() if host else out
+    if host:
+        from .hostio import to_host
+
+        return to_host(out)
+    return out

@@ -27,6 +27,7 @@ import types
 import numpy as np
 
 from .device import DeviceLaw
+from .hostio import assign
 from .problem import ResidentProblemState
 from .resident import ResidentState
 
@@ -76,7 +77,7 @@ def use_resident_state(problem, sync_history: bool = True, pin: bool = True, dir
             if _sync and self.history is not None:
                 committed = _state.history_committed
                 for key, fn in self.history.history_0.items():
-                    fn.x.array[:] = committed[key].cpu().numpy()
+                    assign(fn.x.array, committed[key])
                     self.history.history_1[key].x.array[:] = fn.x.array
 
         los.evaluate = types.MethodType(evaluate, los)
@@ -145,7 +146,7 @@ def use_resident_problem_state(problem, sync_history: bool = True, pin: bool = T
             if sync_history and self.history is not None:
                 committed = state._history_0[_k]
                 for key, fn in self.history.history_0.items():
-                    fn.x.array[:] = committed[key].cpu().numpy()
+                    assign(fn.x.array, committed[key])
                     self.history.history_1[key].x.array[:] = fn.x.array
 
         los.evaluate = types.MethodType(evaluate, los)

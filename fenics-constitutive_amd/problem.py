@@ -19,6 +19,15 @@ from __future__ import annotations
 import numpy as np
 
 from .device import DeviceLaw, _is_torch
+from .hostio import assign, to_device, to_host, upload
+
+
+def _store(dst, src) -> None:
+    """``dst`` (device tensor) <- ``src`` (device tensor or NumPy array)"""
+    if _is_torch(src):
+        dst.copy_(src)
+    else:
+        upload(dst, np.ascontiguousarray(src, dtype=np.float64))
 
 __all__ = ["ResidentProblemState", "rows_of_cells"]
 
@@ -35,7 +44,7 @@ class _LawState:
         import torch
 
         self.law, self.n = law, n
-        self.rows = None if rows is None else torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(device)
+        self.rows = None if rows is None else to_device(rows, device, np.int32)
         hd = law.history_dim
         self.hist = None if hd is None else [{k: torch.zeros(d * n, **f) for k, d in hd.items()} for _ in range(2)]
         self.grad = None  # staging buffer for NumPy gradients
@@ -152,14 +161,14 @@ class ResidentProblemState:
         import torch
 
         if stress is not None:
-            self.stress_0.copy_(stress if _is_torch(stress) else torch.from_numpy(np.ascontiguousarray(stress)).to(self.device))
+            _store(self.stress_0, stress)
         if history is not None:
             for ls, h in zip(self._laws, history):
                 if ls.hist is None:
                     continue
                 for k in ls.hist[self._c]:
                     v = h[k]
-                    ls.hist[self._c][k].copy_(v if _is_torch(v) else torch.from_numpy(np.ascontiguousarray(v)).to(self.device))
+                    _store(ls.hist[self._c][k], v)
                     ls.hist[1 - self._c][k].copy_(ls.hist[self._c][k])  # trial == committed (sparse-history contract)
                 if ls.mask is not None:
                     ls.mask.zero_()
@@ -186,7 +195,7 @@ class ResidentProblemState:
             if not _is_torch(g):
                 if ls.grad is None:
                     ls.grad = torch.empty(9 * ls.n, **self._f)
-                ls.grad.copy_(torch.from_numpy(np.ascontiguousarray(g, dtype=np.float64)), non_blocking=True)
+                upload(ls.grad, np.ascontiguousarray(g, dtype=np.float64))  # synchronous: the caller may free or rewrite g on return
                 g = ls.grad
             hp = None if ls.hist is None else ls.hist[self._c]
             hc = None if ls.hist is None else ls.hist[1 - self._c]
@@ -252,7 +261,7 @@ class ResidentProblemState:
         except ValueError:  # pageable gradient: upload
             if ls.grad is None:
                 ls.grad = torch.empty(9 * ls.n, **self._f)
-            ls.grad.copy_(torch.from_numpy(grad_del_u), non_blocking=True)
+            upload(ls.grad, grad_del_u)
             gptr = ls.grad.data_ptr()
         flags, target = 0, None if tptr is None else ("host", tptr, tangent_parent.nbytes)
         key = None
@@ -286,7 +295,7 @@ class ResidentProblemState:
         ls = self._laws[k]
         if ls.grad is None:
             ls.grad = torch.empty(9 * ls.n, **self._f)
-        ls.grad.copy_(torch.from_numpy(grad_del_u))
+        upload(ls.grad, grad_del_u)
         hp = None if ls.hist is None else ls.hist[self._c]
         hc = None if ls.hist is None else ls.hist[1 - self._c]
         ls.tangent_key = ls.host_tangent_key = None
@@ -297,17 +306,17 @@ class ResidentProblemState:
         if ls.rows is None:
             ls.law.evaluate_from(self._time, self._del_t, ls.grad, self.stress_0, self.stress_1, tan, hp, hc,
                                  history_mask=ls.mask, counters=ls.counters)
-            stress_parent[:] = self.stress_1.cpu().numpy()
+            assign(stress_parent, self.stress_1)
             if tan is not None:
-                tangent_parent[:] = tan.cpu().numpy()
+                assign(tangent_parent, tan)
         else:
             ls.law.evaluate_indexed(self._time, self._del_t, ls.grad, self.stress_0, self.stress_1, tan, ls.rows, hp, hc,
                                     history_mask=ls.mask, counters=ls.counters)
             rows = ls.rows.long()
-            rows_h = rows.cpu().numpy()
-            stress_parent.reshape(-1, 6)[rows_h] = self.stress_1.view(-1, 6)[rows].cpu().numpy()
+            rows_h = to_host(rows)
+            stress_parent.reshape(-1, 6)[rows_h] = to_host(self.stress_1.view(-1, 6)[rows])
             if tan is not None:
-                tangent_parent.reshape(-1, 36)[rows_h] = tan.view(-1, 36)[rows].cpu().numpy()
+                tangent_parent.reshape(-1, 36)[rows_h] = to_host(tan.view(-1, 36)[rows])
         self._evaluated = True
         self.check()
 
@@ -454,6 +463,6 @@ class ResidentProblemState:
 
     def download(self, stress: np.ndarray | None = None, tangent: np.ndarray | None = None) -> None:
         if stress is not None:
-            stress[:] = self.stress_1.cpu().numpy()
+            assign(stress, self.stress_1)
         if tangent is not None:
-            tangent[:] = self.tangent.cpu().numpy()
+            assign(tangent, self.tangent)

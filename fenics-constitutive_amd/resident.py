@@ -27,6 +27,7 @@ from __future__ import annotations
 import numpy as np
 
 from .device import DeviceLaw, _is_torch
+from .hostio import assign, to_device, upload
 
 __all__ = ["ResidentState"]
 
@@ -124,7 +125,7 @@ class ResidentState:
     def _as_dev(self, a):
         import torch
 
-        return a if _is_torch(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+        return a if _is_torch(a) else to_device(a, self.device, np.float64)
 
     @property
     def grad(self):
@@ -214,7 +215,7 @@ class ResidentState:
         g = grad_del_u
         staging = not _is_torch(g)
         if staging:
-            self.grad.copy_(self._as_dev(g), non_blocking=True)
+            upload(self.grad, np.ascontiguousarray(g, dtype=np.float64))  # synchronous: the caller may free or rewrite g on return
             g = self.grad
         assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
         if not self._placed:
@@ -325,7 +326,7 @@ class ResidentState:
 
         g = grad_del_u
         if not _is_torch(g):
-            self.grad.copy_(self._as_dev(g), non_blocking=True)
+            upload(self.grad, np.ascontiguousarray(g, dtype=np.float64))
             g = self.grad
         assert g.numel() == self._gd2 * self.n, "grad_del_u has the wrong length"
         self._placed = True
@@ -435,12 +436,12 @@ class ResidentState:
                  history: dict | None = None) -> None:
         """Copy the trial stress / tangent / history into the caller's NumPy arrays in place."""
         if stress is not None:
-            stress[:] = self.stress.cpu().numpy()
+            assign(stress, self.stress)
         if tangent is not None:
-            tangent[:] = self.tangent.cpu().numpy()
+            assign(tangent, self.tangent)
         if history is not None and self._hist is not None:
             for k in history:
-                history[k][:] = self.history[k].cpu().numpy()
+                assign(history[k], self.history[k])
 
     def check(self):
         """Synchronise with this state's last device evaluate and return its counters; raises the

@@ -65,10 +65,12 @@ class _From3D(IncrSmallStrainModel):
             if not torch.cuda.is_available():
                 raise RuntimeError("the 3D wrappers evaluate on the GPU and no HIP device is available")
             dev = torch.device("cuda", _capi.default_device())
-            g_lo = torch.from_numpy(np.ascontiguousarray(grad_del_u, dtype=np.float64)).to(dev)
-            s_lo = torch.from_numpy(np.ascontiguousarray(stress, dtype=np.float64)).to(dev)
+            from .hostio import to_device
+
+            g_lo = to_device(grad_del_u, dev, np.float64)
+            s_lo = to_device(stress, dev, np.float64)
             t_lo = torch.empty(tangent.size, dtype=torch.float64, device=dev)
-            h_dev = None if history is None else {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in history.items()}
+            h_dev = None if history is None else {k: to_device(v, dev, np.float64) for k, v in history.items()}
         else:
             g_lo, s_lo, t_lo, h_dev = (_check_torch("grad_del_u", grad_del_u), _check_torch("stress", stress),
                                        _check_torch("tangent", tangent), history)
@@ -109,11 +111,13 @@ class _From3D(IncrSmallStrainModel):
 
     @staticmethod
     def _download(stress, tangent, history, s_lo, t_lo, h_dev):
-        stress[:] = s_lo.cpu().numpy()
-        tangent[:] = t_lo.cpu().numpy()
+        from .hostio import assign
+
+        assign(stress, s_lo)
+        assign(tangent, t_lo)
         if history is not None:
             for k in history:
-                history[k][:] = h_dev[k].cpu().numpy()
+                assign(history[k], h_dev[k])
 
 
 class UniaxialStrainFrom3D(_From3D):

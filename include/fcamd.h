@@ -255,8 +255,15 @@ int fcamd_commit_delta_history(fcamd_model* model, int64_t n, double* history_co
                   fcamd_register_host_buffer (and is 16-byte aligned): ONE kernel launch runs
                   directly on the caller's arrays; the GPU reads the inputs and writes the
                   results over PCIe itself, both directions at once, no staging buffers;
-     staged    -- otherwise: chunk by chunk through device buffers (four chunk slots on four
-                  streams: H2D / kernel / D2H of one chunk overlap the others').
+     pageable  -- arrays the caller did not register are page-locked for the duration of the call
+                  (FCAMD_HOST_TEMP_LOCK) and treated the same way; calls that move at most
+                  "bounce_max" bytes (2 MiB), and arrays that cannot be locked, go through the
+                  context's own page-locked scratch with CPU copies instead (FCAMD_HOST_BOUNCE).
+                  Pageable caller memory is never handed to the HIP runtime's copy path (its cache
+                  of on-the-fly page locks goes stale when memory is freed and allocated again);
+     staged    -- option "zero_copy" = 0, or an array off the 16-byte grid: chunk by chunk through
+                  device buffers (four chunk slots on four streams: H2D / kernel / D2H of one chunk
+                  overlap the others'), DMA from / into the page-locked arrays.
    Both produce bit-identical results.  Synchronous.  Validates like the reference and returns
    the matching status; on FCAMD_ERR_NONCONVERGED the outputs hold the values the kernel
    produced (the reference raises mid-loop). `stats` may be NULL. */
@@ -336,6 +343,8 @@ int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
    a bit mask of the flags below (0 = everything staged). */
 #define FCAMD_HOST_ZERO_COPY_IN 1  /* inputs read by the kernel from the caller's host arrays */
 #define FCAMD_HOST_ZERO_COPY_OUT 2 /* results written by the kernel into the caller's host arrays */
+#define FCAMD_HOST_TEMP_LOCK 4     /* pageable caller arrays were page-locked for the duration of the call */
+#define FCAMD_HOST_BOUNCE 8        /* pageable caller arrays were moved by the CPU through the context's page-locked scratch */
 int fcamd_context_last_host_mode(fcamd_context* ctx, int* mode);
 /* Address at which the device entries (fcamd_evaluate_device*) can read / write the host range
    [host_ptr, host_ptr + bytes): it must lie inside one range registered with
@@ -345,6 +354,16 @@ int fcamd_context_last_host_mode(fcamd_context* ctx, int* mode);
    the reference's map_to_parent copies (solver/maps.py:82-101) then happen inside the kernel, over
    PCIe.  The caller synchronises (fcamd_context_synchronize) before the host reads the results. */
 int fcamd_host_device_pointer(fcamd_context* ctx, const void* host_ptr, size_t bytes, void** device_ptr);
+
+/* Synchronous copies between the caller's HOST memory and device memory, ordered after the work queued on the
+   context stream.  Like the host entries they never hand pageable memory to the HIP runtime's copy path (whose cache
+   of on-the-fly page locks is keyed by address and goes stale when memory is freed and allocated again -- a GPU
+   memory fault on this stack): up to "bounce_max" bytes go through the context's own page-locked
+   scratch, larger ranges are page-locked for the duration of the copy, registered ranges are used as they are.
+   What the reference does with `array[:] = other` between NumPy arrays (solver/_history.py:64-79) is, for a
+   device-resident state, one of these. */
+int fcamd_copy_to_device(fcamd_context* ctx, void* dst_device, const void* src_host, size_t bytes);
+int fcamd_copy_to_host(fcamd_context* ctx, void* dst_host, const void* src_device, size_t bytes);
 
 /* ---- multi-GPU: contiguous shards + all-gather ------------------------ */
 /* The quadrature-point axis [0, n) is cut into `world` contiguous slices that start on 64-point
@@ -439,6 +458,7 @@ int fcamd_context_set_timing(fcamd_context* ctx, int enabled);
    FCAMD_* environment defaults, which are read ONCE, when the context is created:
      "tile_map" (FCAMD_TILE_MAP, 0), "masked_max" (FCAMD_MASKED_MAX, -1 = per law), "nontemporal"
      (FCAMD_NT, 1), "host_chunk" (FCAMD_HOST_CHUNK, 0 = automatic), "host_slots" (FCAMD_HOST_SLOTS, 4),
+     "bounce_max" (FCAMD_BOUNCE_MAX, 2 MiB: host calls up to this size go through the page-locked scratch),
      "zero_copy" (FCAMD_ZERO_COPY, 1), "zero_copy_grad" (FCAMD_ZERO_COPY_GRAD, 1). */
 int fcamd_context_set_option(fcamd_context* ctx, const char* name, long long value);
 int fcamd_context_get_option(fcamd_context* ctx, const char* name, long long* value);

@@ -1,8 +1,9 @@
-"""Zero-copy host path: with every array of a call inside page-locked, GPU-mapped ranges
+"""Host (ndarray) data paths: with every array of a call inside page-locked, GPU-mapped ranges
 (``fcamd_register_host_buffer``) ``fcamd_evaluate_host`` launches the kernel directly on the caller's
-NumPy arrays.  The results must be bit-identical to the staged path (same kernel, same inputs) and
-therefore within the parity tolerances of the oracle; anything that is not fully registered or not
-16-byte aligned must fall back to the staged path and still be right."""
+NumPy arrays (zero copy); pageable arrays are page-locked for the duration of the call (large calls) or moved
+through the context's page-locked scratch (small calls, arrays that cannot be locked, arrays off the 16-byte
+grid) -- never handed to the HIP runtime's pageable-copy path.  All paths must be bit-identical (same kernel,
+same inputs) and therefore within the parity tolerances of the oracle."""
 
 import numpy as np
 import pytest
@@ -18,6 +19,13 @@ from oracle import c_oracle as CO  # noqa: E402
 from test_gpu_parity import CLASS, KINDS, STRICT, TOL, compare, make_law, oracle_run, random_case  # noqa: E402
 
 ZC = _capi.HOST_ZERO_COPY_IN | _capi.HOST_ZERO_COPY_OUT
+BOUNCE, TEMP = _capi.HOST_BOUNCE, _capi.HOST_TEMP_LOCK
+BOUNCE_MAX = 2 << 20  # default of the "bounce_max" option
+
+
+def pageable_mode(nbytes):
+    """data path of a call that moves ``nbytes`` of pageable caller memory"""
+    return BOUNCE if nbytes <= BOUNCE_MAX else (ZC | TEMP)
 
 
 class Pinned:
@@ -59,7 +67,8 @@ def test_zero_copy_equals_staged_and_oracle(kind, n):
     h1 = None if h is None else {k: v.copy() for k, v in h.items()}
     law.evaluate(0.0, 1.3, g, s1, t1, h1)
     ctx = law._handle(_capi.default_device()).ctx
-    assert ctx.last_host_mode() == 0
+    moved = g.nbytes + s1.nbytes + t1.nbytes + (0 if h1 is None else sum(v.nbytes for v in h1.values()))
+    assert ctx.last_host_mode() == (pageable_mode(moved) if n else 0)
     # zero copy: every array in its own page-locked mapping
     g2, s2, t2 = own(g), own(s), own(np.full(36 * n, np.nan))
     h2 = None if h is None else {k: own(v) for k, v in h.items()}
@@ -67,7 +76,7 @@ def test_zero_copy_equals_staged_and_oracle(kind, n):
         law.evaluate(0.0, 1.3, g2, s2, t2, h2)
         assert ctx.last_host_mode() == ZC
         assert law.last_stats is not None
-    assert np.array_equal(s1, s2) and np.array_equal(t1, t2), f"{kind} n={n}: zero copy differs from staged"
+    assert np.array_equal(s1, s2) and np.array_equal(t1, t2), f"{kind} n={n}: zero copy differs from the pageable path"
     if h is not None:
         for k in h:
             assert np.array_equal(h1[k], h2[k]), k
@@ -110,7 +119,7 @@ def test_sub_ranges_of_one_registration_take_the_zero_copy_path():
     compare((sv, tv, {"eps_n": ev, "alpha": av}), ref, STRICT["pl"], "slab views")
 
 
-def test_fallbacks_to_the_staged_path():
+def test_fallbacks_to_the_scratch_path():
     n = 2000
     p, g, s, h = random_case("spring_maxwell", n, seed=12)
     ref = oracle_run("spring_maxwell", p, 0.5, g, s, h, mod=CO)
@@ -124,7 +133,7 @@ def test_fallbacks_to_the_staged_path():
     g2, s2, t2, h2 = fresh()
     with Pinned(law, [g2, s2, t2, h2["strain"]]):
         law.evaluate(0.0, 0.5, g2, s2, t2, h2)
-        assert ctx.last_host_mode() == 0
+        assert ctx.last_host_mode() == BOUNCE
     compare((s2, t2, h2), ref, STRICT["sls"], "partly registered")
     # (2) registered but 8 bytes off the 16-byte grid: the kernel's vector accesses need alignment
     slab = own(np.zeros(6 * n + 1))
@@ -133,27 +142,68 @@ def test_fallbacks_to_the_staged_path():
     g2, _, t2, h2 = fresh()
     with Pinned(law, [g2, slab, t2] + list(h2.values())):
         law.evaluate(0.0, 0.5, g2, s3, t2, h2)
-        assert ctx.last_host_mode() == 0
+        assert ctx.last_host_mode() == BOUNCE
     compare((s3, t2, h2), ref, STRICT["sls"], "misaligned")
-    # (3) a view that reaches beyond its registered range is never handed to the kernel: the HIP runtime
-    # refuses to DMA a partly page-locked range, the call fails loudly and nothing is computed
+    # (3) a view that reaches beyond its registered range is never handed to the kernel or to the DMA engines
+    # (a partly page-locked range): the CPU moves it through the scratch
     both = own(np.zeros(12 * n))
     g2, _, t2, h2 = fresh()
     s4 = both[: 6 * n]
     s4[:] = s
     half = both[: 3 * n]
     with Pinned(law, [g2, half, t2] + list(h2.values())):
-        with pytest.raises(RuntimeError, match="hipMemcpyAsync"):
+        law.evaluate(0.0, 0.5, g2, s4, t2, h2)
+        assert ctx.last_host_mode() == BOUNCE
+    compare((s4, t2, h2), ref, STRICT["sls"], "beyond the registered range")
+    # ... also when the call is too large for one pass through the scratch (several chunks)
+    ctx.set_option("bounce_max", 64 * 1024)
+    try:
+        g2, _, t2, h2 = fresh()
+        s4[:] = s
+        with Pinned(law, [g2, half, t2] + list(h2.values())):
             law.evaluate(0.0, 0.5, g2, s4, t2, h2)
-        assert ctx.last_host_mode() == 0
-    assert np.array_equal(s4, s)
-    # (4) after unregistering everything the same arrays go through the staged path again
+            assert ctx.last_host_mode() == BOUNCE
+        compare((s4, t2, h2), ref, STRICT["sls"], "beyond the registered range, chunked scratch")
+        # pageable arrays above the threshold: page-locked for the call, kernel directly on them
+        g2, s2, t2, h2 = fresh()
+        law.evaluate(0.0, 0.5, g2, s2, t2, h2)
+        assert ctx.last_host_mode() == (ZC | TEMP)
+        compare((s2, t2, h2), ref, STRICT["sls"], "temporarily locked")
+        # ... or, with zero copy switched off, DMA between them and the device chunk buffers
+        ctx.set_option("zero_copy", 0)
+        g2, s2, t2, h2 = fresh()
+        law.evaluate(0.0, 0.5, g2, s2, t2, h2)
+        assert ctx.last_host_mode() == TEMP
+        compare((s2, t2, h2), ref, STRICT["sls"], "temporarily locked, chunked DMA")
+    finally:
+        ctx.set_option("bounce_max", BOUNCE_MAX), ctx.set_option("zero_copy", 1)
+    # (4) after unregistering everything the same arrays are pageable again
     g2, s2, t2, h2 = fresh()
     with Pinned(law, [g2, s2, t2] + list(h2.values())):
         pass
     law.evaluate(0.0, 0.5, g2, s2, t2, h2)
-    assert ctx.last_host_mode() == 0
+    assert ctx.last_host_mode() == BOUNCE
     compare((s2, t2, h2), ref, STRICT["sls"], "unregistered again")
+
+
+def test_scratch_path_in_chunks():
+    """Arrays that cannot be page-locked (here: a tangent array that lies only half inside a registered range) and
+    are too large for one pass through the scratch: several chunks, each copied in, evaluated, copied out."""
+    n = 200_003  # linear elasticity moves 408 B/pt: 64 MiB chunks hold 164 480 points
+    p, g, s, h = random_case("linear_elasticity", n, seed=3)
+    ref = oracle_run("linear_elasticity", p, 1.0, g, s, h, mod=CO)
+    law = make_law("linear_elasticity", p)
+    t = own(np.full(36 * n, np.nan))
+    s1 = s.copy()
+    with Pinned(law, [t[: 18 * n]]) as ctx:
+        law.evaluate(0.0, 1.0, g, s1, t, None)
+        assert ctx.last_host_mode() == BOUNCE
+    compare((s1, t, None), ref, STRICT["le"], "chunked scratch")
+    # the same call on pageable arrays: page-locked for the call
+    s2, t2 = s.copy(), np.full(36 * n, np.nan)
+    law.evaluate(0.0, 1.0, g, s2, t2, None)
+    assert ctx.last_host_mode() == (ZC | TEMP)
+    assert np.array_equal(s1, s2) and np.array_equal(t, t2)
 
 
 @pytest.mark.parametrize("cname", ["UNIAXIAL_STRESS", "PLANE_STRAIN"])
@@ -209,9 +259,9 @@ def test_resident_evaluate_into_zero_copy(kind):
             with Pinned(law, [gg, so, to]):
                 st.evaluate_into(0.0, 1.0, gg, so, to)
                 assert ctx.last_host_mode() == ZC
-        else:
+        else:  # pageable, 200 003 points: page-locked for the call
             st.evaluate_into(0.0, 1.0, gg, so, to)
-            assert ctx.last_host_mode() == 0
+            assert ctx.last_host_mode() == (ZC | TEMP)
         hist = None if st.history is None else {k: v.cpu().numpy() for k, v in st.history.items()}
         out[mode] = (so.copy(), to.copy(), hist, st.stress.cpu().numpy())
     a, b = out["staged"], out["zero_copy"]
