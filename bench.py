@@ -428,6 +428,7 @@ def cpu_quick(wl, budget_s=1.0, ns=1_000_000):
     restatement of the reference's code path on the first `ns` points of the configuration's own arrays."""
     import numpy as np
 
+    from fenics_constitutive_amd.hostio import to_host
     from oracle import c_oracle as CO
     from oracle import numpy_oracle as NO
 
@@ -461,6 +462,7 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
     MPI rank) on a bounded sample of the same workload."""
     import numpy as np
 
+    from fenics_constitutive_amd.hostio import to_host
     from oracle import c_oracle as CO
 
     ns = min(grad.numel() // 9, 2_000_000)

@@ -12,5 +12,12 @@ cd "$R"
 LD_PRELOAD="${LD_PRELOAD:+$LD_PRELOAD }/tmp/abort_trace.so" timeout -k 10 900 python -X faulthandler -m pytest tests -x -q -m gpu -p no:cacheprovider --capture=sys "$@" > "$LOG" 2>&1
 rc=$?
 echo "gpu tests exit $rc"
+# a GPU memory fault leaves a GPU core file in the working directory: which kernel, which address
+for core in gpucore.*; do
+    [ -f "$core" ] || continue
+    timeout 120 rocgdb -q -batch -ex "info agents" -ex "info queues" -ex "info dispatches" -ex "info threads" -ex "bt" -c "$core" > "$LOG.gpucore.txt" 2>&1
+    echo "GPU core $core analysed in $LOG.gpucore.txt"
+    break
+done
 grep -v "^  File" "$LOG" | cut -c1-300 | tail -${TAIL:-8}
 exit $rc
