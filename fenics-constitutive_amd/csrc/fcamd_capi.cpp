@@ -1104,6 +1104,18 @@ struct HostTimer {
 //     return.  Measured against the runtime's pageable path, VonMises3D, 1e7 points: 254 instead of 270 ms on
 //     arrays never seen before, 80.7 instead of 103.9 ms on arrays used before (tools/temp_register_probe.py);
 //   * arrays that cannot be locked (a range that overlaps somebody else's registration): the scratch again, in chunks.
+// Page locks taken for the duration of a call are shared by all contexts of the process: two threads (each with a
+// context of its own) may pass the SAME read-only array -- the gradient -- at the same time, and two concurrent
+// hipHostRegister calls on one address both "succeed" in this runtime, the second hipHostUnregister then aborts
+// ("Memobj map does not have ptr").  One registry, one mutex, reference counts.
+struct TempLock {
+    size_t bytes;
+    char* dev;
+    int refs;
+};
+std::mutex g_temp_mu;
+std::map<char*, TempLock> g_temp;  // host base -> lock held by one or more calls in progress
+
 class CallerArrays {
   public:
     explicit CallerArrays(fcamd_context* c) : c_(c) {}
@@ -1128,21 +1140,37 @@ class CallerArrays {
                 }
             }
         }
+        std::lock_guard<std::mutex> g(g_temp_mu);
+        {   // inside a range another call in progress has locked: share it
+            auto it = g_temp.upper_bound(q);
+            if (it != g_temp.begin()) {
+                --it;
+                if (q < it->first + it->second.bytes) {
+                    if (q + bytes > it->first + it->second.bytes) return false;
+                    ++it->second.refs;
+                    temp_.push_back(it->first);
+                    *dev = it->second.dev + (q - it->first);
+                    return true;
+                }
+            }
+        }
         hipError_t e = hipHostRegister(q, bytes, hipHostRegisterDefault);
         if (e == hipSuccess) {
-            temp_.push_back(q);
             void* d = nullptr;
             if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess) {
                 (void)hipGetLastError();
+                (void)hipHostUnregister(q);
                 return false;
             }
+            g_temp[q] = {bytes, static_cast<char*>(d), 1};
+            temp_.push_back(q);
             *dev = static_cast<char*>(d);
             return true;
         }
         (void)hipGetLastError();
         if (e == hipErrorHostMemoryAlreadyRegistered) {
-            // page-locked by somebody else (the application's own hipHostRegister / hipHostMalloc): usable if the
-            // whole range is one mapping
+            // page-locked by somebody else (the application's own hipHostRegister / hipHostMalloc, a range registered
+            // with another context): usable, for as long as that somebody keeps it, if the whole range is one mapping
             void *d0 = nullptr, *d1 = nullptr;
             if (hipHostGetDevicePointer(&d0, q, 0) == hipSuccess && hipHostGetDevicePointer(&d1, q + bytes - 1, 0) == hipSuccess &&
                 static_cast<char*>(d1) - static_cast<char*>(d0) == static_cast<ptrdiff_t>(bytes - 1)) {
@@ -1156,19 +1184,27 @@ class CallerArrays {
 
     bool temp_locked() const { return !temp_.empty(); }
 
-    // unlock what this call locked -- only once nothing is in flight on the context's chunk streams
+    // give back what this call locked -- only once nothing is in flight on the context's chunk streams
     void release() {
         if (temp_.empty()) return;
         for (int i = 0; i < fcamd_context::kSlots; ++i)
             if (c_->hstream[i]) (void)hipStreamSynchronize(c_->hstream[i]);
-        for (char* q : temp_) (void)hipHostUnregister(q);
+        std::lock_guard<std::mutex> g(g_temp_mu);
+        for (char* q : temp_) {
+            auto it = g_temp.find(q);
+            if (it == g_temp.end()) continue;
+            if (--it->second.refs == 0) {
+                (void)hipHostUnregister(q);
+                g_temp.erase(it);
+            }
+        }
         (void)hipGetLastError();
         temp_.clear();
     }
 
   private:
     fcamd_context* c_;
-    std::vector<char*> temp_;
+    std::vector<char*> temp_;  // bases in g_temp this call holds a reference on
 };
 
 int ensure_bounce(fcamd_context* c, size_t bytes) {
