@@ -908,7 +908,7 @@ def main():
                 "evaluate_kernel_ms_avg": round(d_ms, 4), "commit_kernel_ms": round(c_ms, 4),
                 "frac_equivalent": round(alg_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "break_even_newton_iterations": None if saved <= 0 else round(c_ms / saved, 2),
-                "note": "ResidentState's default for VonMises3D (FCAMD_EVAL_DELTA_HISTORY): during the Newton iterations the trial eps_n "
+                "note": "ResidentState(delta_history=True), VonMises3D (FCAMD_EVAL_DELTA_HISTORY; an option, not the default): during the Newton iterations the trial eps_n "
                         "array receives only the increment of the plastic points and the committed rows are not read; update() adds "
                         "the increments to the committed array (commit kernel, once per increment).  The launch then does less than "
                         "the reference's evaluate, so it is not the timed step; frac_equivalent divides the interface's bytes by its time"}
