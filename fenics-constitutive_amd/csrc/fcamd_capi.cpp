@@ -1,4 +1,4 @@
-// C-ABI layer of libfcamd: contexts, model handles, host staging and launches.
+// C-ABI layer of libfcamd: contexts, model handles, law constants and launches (host entries: fcamd_hostpath.cpp).
 // Public contract: include/fcamd.h.  Device code: fcamd_kernels.hip.
 //
 // Everything that depends on material parameters is computed here, on the host, in plain
@@ -50,7 +50,6 @@ namespace {
 constexpr int kMaskedRowMaxVonMises = 20;
 constexpr int kMaskedRowMaxRows7 = 16;
 
-constexpr size_t kCounterBytes = (size_t)fcamd::kCounterSlots * 4 * sizeof(unsigned long long);
 static_assert(fcamd::kCounterSlots == FCAMD_COUNTER_SLOTS, "public and internal counter layout differ");
 
 // Python "1 / 2**0.5" and Rust FRAC_1_SQRT_2 differ by one ULP.
@@ -279,27 +278,6 @@ void fill_constants(const fcamd_model* m, double del_t, Scalars& sc, Tables& tb)
     }
 }
 
-// laws whose history changes only at plastic points (elastic points keep theirs bit for bit)
-bool has_sparse_history(int law) { return law == FCAMD_VON_MISES_3D || law >= FCAMD_COMFE_MISES_PLASTICITY; }
-
-bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-// Address at which the GPU sees the host range [p, p + bytes) when it lies entirely inside ONE
-// range page-locked through fcamd_register_host_buffer and keeps the 16-byte alignment the
-// kernels' vector accesses need; nullptr otherwise (-> staged path).
-double* mapped(const fcamd_context* c, const void* p, size_t bytes) {
-    if (!p || c->registered.empty()) return nullptr;
-    char* q = static_cast<char*>(const_cast<void*>(p));
-    auto it = c->registered.upper_bound(q);
-    if (it == c->registered.begin()) return nullptr;
-    --it;
-    if (q + bytes > it->first + it->second.bytes) return nullptr;
-    char* d = it->second.dev + (q - it->first);
-    return aligned16(d) ? reinterpret_cast<double*>(d) : nullptr;
-}
-
-bool zero_copy_enabled(const fcamd_context* c) { return c->opt.zero_copy != 0; }
-
 // FCAMD_* environment defaults of a new context: read here, once, never on the launch path
 void options_from_env(Options* o) {
     auto geti = [](const char* name, long long dflt) {
@@ -344,6 +322,9 @@ int timing_end(fcamd_model* m) {
     return FCAMD_OK;
 }
 
+}  // namespace
+
+namespace fcamd {
 int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* grad,
                   const void* stress_prev, const void* stress, const void* const* hist_prev,
                   const void* const* hist, int n_hist) {
@@ -365,6 +346,9 @@ int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* gra
         return fail(FCAMD_ERR_BAD_ARG, "grad_del_u / stress pointer is NULL");
     return FCAMD_OK;
 }
+}  // namespace fcamd
+
+namespace {
 
 int grid_for(fcamd_model* m, int64_t n) {
     fcamd_context* c = m->ctx;
@@ -380,11 +364,14 @@ int grid_for(fcamd_model* m, int64_t n) {
 }
 
 // enqueue one launch on `stream`; device pointers already validated
+}  // namespace
+
+namespace fcamd {
 int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
             double* stress, double* tangent, const double* const* hprev, double* const* hcur,
-            hipStream_t stream, bool reset_counters, const int* rows = nullptr,
-            unsigned long long* hmask = nullptr, int flags = 0, double* stress2 = nullptr,
-            unsigned long long* counters = nullptr) {
+            hipStream_t stream, bool reset_counters, const int* rows,
+            unsigned long long* hmask, int flags, double* stress2,
+            unsigned long long* counters) {
     EvalArgs a;
     a.grad = grad;
     a.stress_in = stress_prev;
@@ -423,7 +410,9 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     HIP_TRY(launch_evaluate(m->law, m->dims.gdim, a, grid, stream));
     return FCAMD_OK;
 }
+}  // namespace fcamd
 
+namespace fcamd {
 int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
     HIP_TRY(hipMemcpyAsync(m->h_counters, m->d_counters, kCounterBytes,
                            hipMemcpyDeviceToHost, stream));
@@ -439,60 +428,7 @@ int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
     }
     return FCAMD_OK;
 }
-
-// chunk slots of the host-staged entries: sizes the slots, creates the streams, returns the chunk
-// length.  Enough chunks in flight to keep both DMA directions busy.  Measured on MI355X / PCIe
-// gen5 (tools/host_path_bench.py): page-locked caller arrays like many small chunks in flight
-// (4 x 128 Ki points: 116 Mpts/s); pageable arrays are staged by the runtime and prefer large
-// chunks (512 Ki points: 93 Mpts/s).  FCAMD_HOST_CHUNK / FCAMD_HOST_SLOTS override (experiments).
-// `staging` = false: every per-chunk array is read / written by the kernel in the caller's page-locked
-// memory (zero copy), the chunks only pipeline the small stress download behind the next launch: no
-// device buffers, and large chunks (2 Mi points: 472 instead of 404 Mpts/s for the resident pass).
-int prepare_chunks(fcamd_context* c, const void* probe_host_ptr, int64_t n, int64_t* chunk_out, bool staging = true,
-                   bool locked = false) {
-    {
-        const bool pinned = locked || mapped(c, probe_host_ptr, 8) != nullptr ||
-                            c->registered.count(static_cast<char*>(const_cast<void*>(probe_host_ptr))) != 0;
-        c->chunk_points = c->opt.host_chunk > 0 ? std::max<int64_t>(64, (c->opt.host_chunk / 64) * 64)
-                                                : (!staging ? (1 << 21) : (pinned ? (1 << 17) : (1 << 19)));
-    }
-    const int nslots = c->opt.host_slots;
-    const int64_t chunk = std::min<int64_t>(c->chunk_points, ((n + 63) / 64) * 64);
-    if (staging && chunk > 0 && ((size_t)chunk > c->dchunk_points || !c->dchunk[nslots - 1])) {
-        for (int i = 0; i < fcamd_context::kSlots; ++i) {
-            if (c->dchunk[i]) HIP_TRY(hipFree(c->dchunk[i]));
-            c->dchunk[i] = nullptr;
-        }
-        c->dchunk_points = 0;
-        for (int i = 0; i < nslots; ++i)
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dchunk[i]), (size_t)chunk * 66 * sizeof(double)));
-        c->dchunk_points = (size_t)chunk;
-    }
-    for (int i = 0; i < nslots; ++i)
-        if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
-    *chunk_out = chunk;
-    return FCAMD_OK;
-}
-
-// wait for all chunk streams, read the counters, map them to the reference's error conventions
-int finish_chunks(fcamd_model* m, fcamd_stats* stats) {
-    fcamd_context* c = m->ctx;
-    for (int i = 0; i < fcamd_context::kSlots; ++i)
-        if (c->hstream[i]) HIP_TRY(hipStreamSynchronize(c->hstream[i]));
-    fcamd_stats local;
-    int st = read_stats(m, c->hstream[0], &local);
-    if (st != FCAMD_OK) return st;
-    if (stats) *stats = local;
-    if (local.n_domain > 0)
-        return fail(FCAMD_ERR_DOMAIN, "non-differentiable tip of Drucker-Prager surface reached");
-    if (local.n_nonconverged > 0)
-        return fail(FCAMD_ERR_NONCONVERGED,
-                    m->law >= FCAMD_COMFE_DRUCKER_PRAGER ? "Plasticity3D: Newton-Raphson did not converge."
-                                                         : "Newton-Raphson method did not converge for plastic multiplier.");
-    return FCAMD_OK;
-}
-
-}  // namespace
+}  // namespace fcamd
 
 extern "C" {
 
@@ -548,25 +484,13 @@ int fcamd_context_create(int device, void* stream, fcamd_context** out) {
     return FCAMD_OK;
 }
 
-// release the staging buffers of the pageable host path (up to 4 slots x 512 Ki points x 66 doubles)
-static void free_staging(fcamd_context* c) {
-    for (int i = 0; i < fcamd_context::kSlots; ++i) {
-        if (c->dchunk[i]) (void)hipFree(c->dchunk[i]);
-        c->dchunk[i] = nullptr;
-    }
-    c->dchunk_points = 0;
-    if (c->bounce) (void)hipHostFree(c->bounce);
-    c->bounce = c->bounce_dev = nullptr;
-    c->bounce_bytes = 0;
-}
-
 int fcamd_context_trim(fcamd_context* c) {
     if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
     std::lock_guard<std::recursive_mutex> lock(c->host_mu);
     HIP_TRY(hipSetDevice(c->device));
     for (int i = 0; i < fcamd_context::kSlots; ++i)
         if (c->hstream[i]) HIP_TRY(hipStreamSynchronize(c->hstream[i]));
-    free_staging(c);
+    free_host_staging(c);
     return FCAMD_OK;
 }
 
@@ -611,7 +535,7 @@ int fcamd_context_destroy(fcamd_context* c) {
         for (auto& kv : c->registered) (void)hipHostUnregister(kv.first);  // best effort
         c->registered.clear();
     }
-    free_staging(c);
+    free_host_staging(c);
     for (int i = 0; i < fcamd_context::kSlots; ++i)
         if (c->hstream[i]) (void)hipStreamDestroy(c->hstream[i]);
     for (hipStream_t s : c->peer_streams)
@@ -1001,596 +925,6 @@ int fcamd_map_rows_device(fcamd_context* c, int64_t n_rows, int row_size, const 
     (void)hipGetLastError();  // as in enqueue()
     HIP_TRY(launch_map_rows(src, src_idx, dst, dst_idx, n_rows, row_size, c->stream));
     return FCAMD_OK;
-}
-
-int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
-    if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
-    HIP_TRY(hipSetDevice(c->device));
-    char* base = static_cast<char*>(ptr);
-    if (c->registered.count(base)) {
-        // Same address again: either a repeated call or a NEW buffer that landed where a freed,
-        // still-registered one was.  Re-pin: a stale registration would DMA through old pages.
-        (void)hipHostUnregister(ptr);
-        c->registered.erase(base);
-    }
-    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
-    void* dev = nullptr;
-    if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        dev = nullptr;  // page-locked but not mapped: DMA path only
-    }
-    c->registered[base] = {dev ? bytes : 0, static_cast<char*>(dev)};
-    return FCAMD_OK;
-}
-
-int fcamd_context_last_host_mode(fcamd_context* c, int* mode) {
-    if (!c || !mode) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    *mode = c->last_host_mode;
-    return FCAMD_OK;
-}
-
-int fcamd_host_device_pointer(fcamd_context* c, const void* host_ptr, size_t bytes, void** device_ptr) {
-    if (!c || !host_ptr || !device_ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
-    double* d = mapped(c, host_ptr, bytes);
-    if (!d) return fail(FCAMD_ERR_BAD_ARG, "host range is not inside a registered, mapped buffer (or not 16-byte aligned)");
-    *device_ptr = d;
-    return FCAMD_OK;
-}
-
-int fcamd_unregister_host_buffer(fcamd_context* c, void* ptr) {
-    if (!c || !ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    // waits for a host entry in progress on another thread (it holds host_mu for the whole synchronous call)
-    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
-    auto it = c->registered.find(static_cast<char*>(ptr));
-    if (it == c->registered.end()) return FCAMD_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipHostUnregister(ptr));
-    c->registered.erase(it);
-    return FCAMD_OK;
-}
-
-}  // extern "C"
-
-namespace {
-
-// A host entry that fails half-way must not return while copies into or out of the CALLER's arrays are
-// still in flight on other chunk streams (the caller may free or reuse them as soon as it sees the error).
-int drain_and_return(fcamd_context* c, int status) {
-    for (int i = 0; i < fcamd_context::kSlots; ++i)
-        if (c->hstream[i]) (void)hipStreamSynchronize(c->hstream[i]);
-    (void)hipGetLastError();
-    return status;
-}
-
-// as HIP_TRY, inside the chunk loops of the host entries
-#define HIP_TRY_DRAIN(c, expr)                                                                          \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) {                                                                         \
-            (void)hipGetLastError();                                                                    \
-            return drain_and_return(c, fail(FCAMD_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
-                                            hipGetErrorString(e_), __FILE__, __LINE__));                \
-        }                                                                                               \
-    } while (0)
-
-// wall-clock of a synchronous host entry, reported by fcamd_model_last_kernel_ms when timing is on
-struct HostTimer {
-    fcamd_model* m;
-    std::chrono::steady_clock::time_point t0;
-    explicit HostTimer(fcamd_model* m_) : m(m_), t0(std::chrono::steady_clock::now()) {
-        m->timed = false;
-        m->host_ms = -1.0f;
-    }
-    ~HostTimer() {
-        if (m->ctx->timing)
-            m->host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    }
-};
-
-// ---- pageable caller arrays ---------------------------------------------------------------------------------
-// The host entries never hand PAGEABLE caller memory to hipMemcpy*.  The HIP runtime moves such memory (above
-// 1 MiB) in pieces it page-locks on the fly and remembers in a cache keyed by address and size.  On this stack a
-// page lock is an attribute of the process's pages (hsa_amd_memory_lock = KFD SVM "accessible in place"; the GPU
-// sees the memory at its host address): memory that appears LATER at a remembered address -- an array that was
-// freed and allocated again, a heap that shrank and grew -- carries no such attribute, the cache still calls it
-// locked, and the DMA engine faults ("Memory access fault by GPU node-N on address <host address>";
-// tools/hsa_lock_probe.c, tools/pageable_copy_probe.py).  Instead:
-//   * calls that move at most `bounce_max` bytes: the CPU copies inputs into / results out of the context's own
-//     page-locked scratch (hipHostMalloc) and the kernel runs on the scratch;
-//   * larger calls: the caller's arrays are page-locked for the duration of the call (hipHostRegister: the
-//     attribute is set on the pages that are there NOW), the kernel runs directly on them, they are unlocked on
-//     return.  Measured against the runtime's pageable path, VonMises3D, 1e7 points: 254 instead of 270 ms on
-//     arrays never seen before, 80.7 instead of 103.9 ms on arrays used before (tools/temp_register_probe.py);
-//   * arrays that cannot be locked (a range that overlaps somebody else's registration): the scratch again, in chunks.
-// Page locks taken for the duration of a call are shared by all contexts of the process: two threads (each with a
-// context of its own) may pass the SAME read-only array -- the gradient -- at the same time, and two concurrent
-// hipHostRegister calls on one address both "succeed" in this runtime, the second hipHostUnregister then aborts
-// ("Memobj map does not have ptr").  One registry, one mutex, reference counts.
-struct TempLock {
-    size_t bytes;
-    char* dev;
-    int refs;
-};
-std::mutex g_temp_mu;
-std::map<char*, TempLock> g_temp;  // host base -> lock held by one or more calls in progress
-
-class CallerArrays {
-  public:
-    explicit CallerArrays(fcamd_context* c) : c_(c) {}
-    CallerArrays(const CallerArrays&) = delete;
-    CallerArrays& operator=(const CallerArrays&) = delete;
-    ~CallerArrays() { release(); }
-
-    // Makes [p, p + bytes) GPU-accessible for the call and returns the address the GPU sees it at in *dev;
-    // false: it cannot be page-locked (-> bounce).  A range inside a fcamd_register_host_buffer range is used as is.
-    bool lock(const void* p, size_t bytes, char** dev) {
-        *dev = nullptr;
-        if (!p || bytes == 0) return true;
-        char* q = static_cast<char*>(const_cast<void*>(p));
-        if (!c_->registered.empty()) {
-            auto it = c_->registered.upper_bound(q);
-            if (it != c_->registered.begin()) {
-                --it;
-                if (q < it->first + it->second.bytes) {  // starts inside a registered range ...
-                    if (q + bytes > it->first + it->second.bytes || !it->second.dev) return false;  // ... must end there
-                    *dev = it->second.dev + (q - it->first);
-                    return true;
-                }
-            }
-        }
-        std::lock_guard<std::mutex> g(g_temp_mu);
-        {   // inside a range another call in progress has locked: share it
-            auto it = g_temp.upper_bound(q);
-            if (it != g_temp.begin()) {
-                --it;
-                if (q < it->first + it->second.bytes) {
-                    if (q + bytes > it->first + it->second.bytes) return false;
-                    ++it->second.refs;
-                    temp_.push_back(it->first);
-                    *dev = it->second.dev + (q - it->first);
-                    return true;
-                }
-            }
-        }
-        hipError_t e = hipHostRegister(q, bytes, hipHostRegisterDefault);
-        if (e == hipSuccess) {
-            void* d = nullptr;
-            if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                (void)hipHostUnregister(q);
-                return false;
-            }
-            g_temp[q] = {bytes, static_cast<char*>(d), 1};
-            temp_.push_back(q);
-            *dev = static_cast<char*>(d);
-            return true;
-        }
-        (void)hipGetLastError();
-        if (e == hipErrorHostMemoryAlreadyRegistered) {
-            // page-locked by somebody else (the application's own hipHostRegister / hipHostMalloc, a range registered
-            // with another context): usable, for as long as that somebody keeps it, if the whole range is one mapping
-            void *d0 = nullptr, *d1 = nullptr;
-            if (hipHostGetDevicePointer(&d0, q, 0) == hipSuccess && hipHostGetDevicePointer(&d1, q + bytes - 1, 0) == hipSuccess &&
-                static_cast<char*>(d1) - static_cast<char*>(d0) == static_cast<ptrdiff_t>(bytes - 1)) {
-                *dev = static_cast<char*>(d0);
-                return true;
-            }
-            (void)hipGetLastError();
-        }
-        return false;
-    }
-
-    bool temp_locked() const { return !temp_.empty(); }
-
-    // give back what this call locked -- only once nothing is in flight on the context's chunk streams
-    void release() {
-        if (temp_.empty()) return;
-        for (int i = 0; i < fcamd_context::kSlots; ++i)
-            if (c_->hstream[i]) (void)hipStreamSynchronize(c_->hstream[i]);
-        std::lock_guard<std::mutex> g(g_temp_mu);
-        for (char* q : temp_) {
-            auto it = g_temp.find(q);
-            if (it == g_temp.end()) continue;
-            if (--it->second.refs == 0) {
-                (void)hipHostUnregister(q);
-                g_temp.erase(it);
-            }
-        }
-        (void)hipGetLastError();
-        temp_.clear();
-    }
-
-  private:
-    fcamd_context* c_;
-    std::vector<char*> temp_;  // bases in g_temp this call holds a reference on
-};
-
-int ensure_bounce(fcamd_context* c, size_t bytes) {
-    if (bytes <= c->bounce_bytes) return FCAMD_OK;
-    if (c->bounce) HIP_TRY(hipHostFree(c->bounce));
-    c->bounce = c->bounce_dev = nullptr;
-    c->bounce_bytes = 0;
-    void* h = nullptr;
-    HIP_TRY(hipHostMalloc(&h, bytes, hipHostMallocDefault));
-    void* d = nullptr;
-    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipHostFree(h);
-        return fail(FCAMD_ERR_HIP, "the page-locked scratch buffer is not mapped into the device's address space");
-    }
-    c->bounce = static_cast<char*>(h);
-    c->bounce_dev = static_cast<char*>(d);
-    c->bounce_bytes = bytes;
-    return FCAMD_OK;
-}
-
-// carves 256-byte aligned arrays out of the scratch: host address and the address the GPU sees
-struct BounceLayout {
-    size_t used = 0;
-    size_t take(size_t bytes) {
-        const size_t at = used;
-        used += (bytes + 255) & ~(size_t)255;
-        return at;
-    }
-};
-
-constexpr size_t kBounceChunkBytes = (size_t)64 << 20;  // chunk size of the bounce path when the arrays cannot be locked
-
-// points per chunk of a bounce pass over n points of `bytes_per_point` bytes each
-int64_t bounce_chunk(const fcamd_context* c, int64_t n, size_t bytes_per_point) {
-    const int64_t all = ((n + 63) / 64) * 64;
-    if ((size_t)n * bytes_per_point <= (size_t)c->opt.bounce_max) return all;
-    const int64_t chunk = (int64_t)(kBounceChunkBytes / bytes_per_point / 64) * 64;
-    return std::max<int64_t>(64, std::min<int64_t>(chunk, all));
-}
-
-}  // namespace
-
-extern "C" {
-
-// Host (ndarray) entry.  The kernel runs directly on the caller's arrays (zero copy): on ranges registered with
-// fcamd_register_host_buffer as they are, on pageable arrays after page-locking them for the duration of the call;
-// small calls and arrays that cannot be locked go through the context's page-locked scratch (CallerArrays above).
-// With the "zero_copy" option off (or an array off the 16-byte grid): chunked H2D -> kernel -> D2H over up to four
-// chunk slots on four streams -- DMA from / into the page-locked arrays.
-int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
-                        double* stress, double* tangent, double* const* hist, int n_hist,
-                        fcamd_stats* stats) {
-    (void)t;
-    int st = validate_call(m, del_t, n, grad, stress, stress,
-                           reinterpret_cast<const void* const*>(hist),
-                           reinterpret_cast<const void* const*>(hist), n_hist);
-    if (st != FCAMD_OK) return st;
-    fcamd_context* c = m->ctx;
-    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
-    HostTimer timer(m);
-    HIP_TRY(hipSetDevice(c->device));
-    if (stats) std::memset(stats, 0, sizeof(*stats));
-    const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
-    const int NH = m->info.n_hist;
-    c->last_host_mode = 0;
-    if (!c->hstream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
-    if (n == 0) {
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
-        return finish_chunks(m, stats);
-    }
-    const size_t N = (size_t)n;
-    size_t hist_doubles = 0;
-    for (int k = 0; k < NH; ++k) hist_doubles += (size_t)m->info.hist[k].dim;
-    const size_t bytes_per_point = (GD2 + SD + (tangent ? TD : 0) + hist_doubles) * sizeof(double);
-
-    // every array inside the caller's registered ranges: nothing to lock, whatever the size
-    bool all_registered = mapped(c, grad, N * GD2 * sizeof(double)) && mapped(c, stress, N * SD * sizeof(double)) &&
-                          (!tangent || mapped(c, tangent, N * TD * sizeof(double)));
-    for (int k = 0; k < NH && all_registered; ++k)
-        all_registered = mapped(c, hist[k], N * (size_t)m->info.hist[k].dim * sizeof(double)) != nullptr;
-
-    CallerArrays arrays(c);
-    char *z_grad = nullptr, *z_stress = nullptr, *z_tan = nullptr, *z_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-    bool locked = false;
-    if (all_registered || N * bytes_per_point > (size_t)c->opt.bounce_max) {
-        locked = arrays.lock(grad, N * GD2 * sizeof(double), &z_grad) && arrays.lock(stress, N * SD * sizeof(double), &z_stress) &&
-                 arrays.lock(tangent, tangent ? N * TD * sizeof(double) : 0, &z_tan);
-        for (int k = 0; k < NH && locked; ++k)
-            locked = arrays.lock(hist[k], N * (size_t)m->info.hist[k].dim * sizeof(double), &z_hist[k]);
-        if (!locked) arrays.release();
-    }
-
-    if (!locked) {
-        // bounce: CPU copies through the context's page-locked scratch, one launch per chunk
-        c->last_host_mode = FCAMD_HOST_BOUNCE;
-        const int64_t chunk = bounce_chunk(c, n, bytes_per_point);
-        BounceLayout lay;
-        const size_t o_grad = lay.take((size_t)chunk * GD2 * sizeof(double)), o_stress = lay.take((size_t)chunk * SD * sizeof(double));
-        const size_t o_tan = tangent ? lay.take((size_t)chunk * TD * sizeof(double)) : 0;
-        size_t o_hist[FCAMD_MAX_HISTORY] = {0, 0};
-        for (int k = 0; k < NH; ++k) o_hist[k] = lay.take((size_t)chunk * (size_t)m->info.hist[k].dim * sizeof(double));
-        st = ensure_bounce(c, lay.used);
-        if (st != FCAMD_OK) return st;
-        hipStream_t s = c->hstream[0];
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
-        for (int64_t p0 = 0; p0 < n; p0 += chunk) {
-            const size_t np = (size_t)std::min<int64_t>(chunk, n - p0);
-            std::memcpy(c->bounce + o_grad, grad + GD2 * p0, np * GD2 * sizeof(double));
-            std::memcpy(c->bounce + o_stress, stress + SD * p0, np * SD * sizeof(double));
-            double* d_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-            for (int k = 0; k < NH; ++k) {
-                const size_t d = (size_t)m->info.hist[k].dim;
-                std::memcpy(c->bounce + o_hist[k], hist[k] + d * p0, np * d * sizeof(double));
-                d_hist[k] = reinterpret_cast<double*>(c->bounce_dev + o_hist[k]);
-            }
-            double* d_stress = reinterpret_cast<double*>(c->bounce_dev + o_stress);
-            st = enqueue(m, del_t, (int64_t)np, reinterpret_cast<const double*>(c->bounce_dev + o_grad), d_stress, d_stress,
-                         tangent ? reinterpret_cast<double*>(c->bounce_dev + o_tan) : nullptr, d_hist, d_hist, s, false);
-            if (st != FCAMD_OK) return drain_and_return(c, st);
-            HIP_TRY_DRAIN(c, hipStreamSynchronize(s));
-            std::memcpy(stress + SD * p0, c->bounce + o_stress, np * SD * sizeof(double));
-            if (tangent) std::memcpy(tangent + TD * p0, c->bounce + o_tan, np * TD * sizeof(double));
-            for (int k = 0; k < NH; ++k) {
-                const size_t d = (size_t)m->info.hist[k].dim;
-                std::memcpy(hist[k] + d * p0, c->bounce + o_hist[k], np * d * sizeof(double));
-            }
-        }
-        return finish_chunks(m, stats);
-    }
-
-    if (arrays.temp_locked()) c->last_host_mode |= FCAMD_HOST_TEMP_LOCK;
-    bool aligned = aligned16(z_grad) && aligned16(z_stress) && (!tangent || aligned16(z_tan));
-    for (int k = 0; k < NH; ++k) aligned = aligned && aligned16(z_hist[k]);
-    // Zero copy: one launch directly on the (page-locked) caller arrays -- the GPU reads the inputs and writes the
-    // results over PCIe itself, both directions at once, no staging buffers.  Measured on MI355X / PCIe gen5
-    // (tools/zero_copy_probe.py, VonMises3D): 140 instead of 117 Mpts/s at 1e7 points (55 GB/s of device-to-host
-    // traffic), 40 instead of 145 us per call at 1e3 points.
-    if (zero_copy_enabled(c) && aligned) {
-        c->last_host_mode |= FCAMD_HOST_ZERO_COPY_IN | FCAMD_HOST_ZERO_COPY_OUT;
-        hipStream_t s = c->hstream[0];
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
-        double* zh[FCAMD_MAX_HISTORY] = {reinterpret_cast<double*>(z_hist[0]), reinterpret_cast<double*>(z_hist[1])};
-        double* zs = reinterpret_cast<double*>(z_stress);
-        st = enqueue(m, del_t, n, reinterpret_cast<const double*>(z_grad), zs, zs, reinterpret_cast<double*>(z_tan), zh, zh, s, false);
-        if (st != FCAMD_OK) return drain_and_return(c, st);
-        return finish_chunks(m, stats);
-    }
-
-    // chunked DMA pipeline between the page-locked caller arrays and device buffers
-    int64_t chunk = 0;
-    st = prepare_chunks(c, grad, n, &chunk, /*staging=*/true, /*locked=*/true);
-    if (st != FCAMD_OK) return st;
-    const int nslots = c->opt.host_slots;
-
-    HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
-    HIP_TRY(hipStreamSynchronize(c->hstream[0]));
-
-    int slot = 0;
-    for (int64_t p0 = 0; p0 < n; p0 += chunk, slot = (slot + 1) % nslots) {
-        const int64_t np = std::min<int64_t>(chunk, n - p0);
-        hipStream_t s = c->hstream[slot];
-        // device layout of a slot (each sub-array starts 16-byte aligned: chunk is a multiple of 64)
-        double* d_grad = c->dchunk[slot];
-        double* d_stress = d_grad + 10 * c->dchunk_points;  // slots sized for FULL (9 -> 10: keeps 16-B alignment)
-        double* d_tan = d_stress + 6 * c->dchunk_points;
-        double* d_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-        double* cur = d_tan + 36 * c->dchunk_points;
-        for (int k = 0; k < NH; ++k) {
-            d_hist[k] = cur;
-            cur += (size_t)m->info.hist[k].dim * c->dchunk_points;
-            // keep 16-byte alignment for odd per-point dimensions (alpha: 1, comfe history: 7)
-            if ((reinterpret_cast<uintptr_t>(cur) & 15u) != 0) cur += 1;
-        }
-        HIP_TRY_DRAIN(c, hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY_DRAIN(c, hipMemcpyAsync(d_stress, stress + SD * p0, (size_t)np * SD * sizeof(double), hipMemcpyHostToDevice, s));
-        for (int k = 0; k < NH; ++k) {
-            const size_t d = (size_t)m->info.hist[k].dim;
-            HIP_TRY_DRAIN(c, hipMemcpyAsync(d_hist[k], hist[k] + d * p0, (size_t)np * d * sizeof(double), hipMemcpyHostToDevice, s));
-        }
-        st = enqueue(m, del_t, np, d_grad, d_stress, d_stress, tangent ? d_tan : nullptr, d_hist, d_hist, s, false);
-        if (st != FCAMD_OK) return drain_and_return(c, st);
-        HIP_TRY_DRAIN(c, hipMemcpyAsync(stress + SD * p0, d_stress, (size_t)np * SD * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (tangent)
-            HIP_TRY_DRAIN(c, hipMemcpyAsync(tangent + TD * p0, d_tan, (size_t)np * TD * sizeof(double), hipMemcpyDeviceToHost, s));
-        for (int k = 0; k < NH; ++k) {
-            const size_t d = (size_t)m->info.hist[k].dim;
-            HIP_TRY_DRAIN(c, hipMemcpyAsync(hist[k] + d * p0, d_hist[k], (size_t)np * d * sizeof(double), hipMemcpyDeviceToHost, s));
-        }
-    }
-    return finish_chunks(m, stats);
-}
-
-int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
-                            const double* stress_prev, double* stress, const double* const* hist_prev,
-                            double* const* hist, int n_hist, uint64_t* history_mask, int flags,
-                            double* stress_host, double* tangent_host, fcamd_stats* stats) {
-    (void)t;
-    int st = validate_call(m, del_t, n, grad, stress_prev, stress,
-                           reinterpret_cast<const void* const*>(hist_prev),
-                           reinterpret_cast<const void* const*>(hist), n_hist);
-    if (st != FCAMD_OK) return st;
-    if (history_mask && !has_sparse_history(m->law))
-        return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
-    if (!aligned16(stress) || !aligned16(stress_prev))
-        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
-    for (int k = 0; k < m->info.n_hist; ++k)
-        if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
-            return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
-    fcamd_context* c = m->ctx;
-    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
-    HostTimer timer(m);
-    HIP_TRY(hipSetDevice(c->device));
-    if (stats) std::memset(stats, 0, sizeof(*stats));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the state arrays may have work queued on the caller's stream
-    const size_t GD2 = (size_t)m->dims.gd2, SD = (size_t)m->dims.sd, TD = SD * SD;
-    c->last_host_mode = 0;
-    if (!c->hstream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
-    if (n == 0) {
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
-        return finish_chunks(m, stats);
-    }
-    const size_t N = (size_t)n;
-    const size_t bytes_per_point = (GD2 + (stress_host ? SD : 0) + (tangent_host ? TD : 0)) * sizeof(double);
-    const bool all_registered = mapped(c, grad, N * GD2 * sizeof(double)) &&
-                                (!stress_host || mapped(c, stress_host, N * SD * sizeof(double))) &&
-                                (!tangent_host || mapped(c, tangent_host, N * TD * sizeof(double)));
-    // the host arrays of the pass: ranges the caller registered as they are, pageable ones page-locked for the
-    // duration of the call, small passes through the context's page-locked scratch (CallerArrays)
-    CallerArrays arrays(c);
-    char *l_grad = nullptr, *l_stress = nullptr, *l_tan = nullptr;
-    bool locked = false;
-    if (all_registered || N * bytes_per_point > (size_t)c->opt.bounce_max) {
-        locked = arrays.lock(grad, N * GD2 * sizeof(double), &l_grad) &&
-                 arrays.lock(stress_host, stress_host ? N * SD * sizeof(double) : 0, &l_stress) &&
-                 arrays.lock(tangent_host, tangent_host ? N * TD * sizeof(double) : 0, &l_tan);
-        if (!locked) arrays.release();
-    }
-    if (!locked) {
-        c->last_host_mode = FCAMD_HOST_BOUNCE;
-        const int64_t chunk = bounce_chunk(c, n, bytes_per_point);
-        BounceLayout lay;
-        const size_t o_grad = lay.take((size_t)chunk * GD2 * sizeof(double));
-        const size_t o_stress = stress_host ? lay.take((size_t)chunk * SD * sizeof(double)) : 0;
-        const size_t o_tan = tangent_host ? lay.take((size_t)chunk * TD * sizeof(double)) : 0;
-        st = ensure_bounce(c, lay.used);
-        if (st != FCAMD_OK) return st;
-        hipStream_t s = c->hstream[0];
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
-        const bool second_store = stress_host && m->dims.gdim == 3;  // the 3-D kernels can store the stress twice
-        for (int64_t p0 = 0; p0 < n; p0 += chunk) {
-            const size_t np = (size_t)std::min<int64_t>(chunk, n - p0);
-            std::memcpy(c->bounce + o_grad, grad + GD2 * p0, np * GD2 * sizeof(double));
-            const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-            double* hc[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-            for (int k = 0; k < m->info.n_hist; ++k) {
-                const size_t d = (size_t)m->info.hist[k].dim;
-                hp[k] = hist_prev[k] + d * p0;
-                hc[k] = hist[k] + d * p0;
-            }
-            // the scratch holds no previous tangent: every row is written (no sparse tangent)
-            st = enqueue(m, del_t, (int64_t)np, reinterpret_cast<const double*>(c->bounce_dev + o_grad), stress_prev + SD * p0,
-                         stress + SD * p0, tangent_host ? reinterpret_cast<double*>(c->bounce_dev + o_tan) : nullptr, hp, hc, s, false,
-                         nullptr, history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
-                         flags & ~FCAMD_EVAL_SPARSE_TANGENT, second_store ? reinterpret_cast<double*>(c->bounce_dev + o_stress) : nullptr);
-            if (st != FCAMD_OK) return drain_and_return(c, st);
-            if (stress_host && !second_store)
-                HIP_TRY_DRAIN(c, hipMemcpyAsync(c->bounce + o_stress, stress + SD * p0, np * SD * sizeof(double), hipMemcpyDeviceToHost, s));
-            HIP_TRY_DRAIN(c, hipStreamSynchronize(s));
-            if (stress_host) std::memcpy(stress_host + SD * p0, c->bounce + o_stress, np * SD * sizeof(double));
-            if (tangent_host) std::memcpy(tangent_host + TD * p0, c->bounce + o_tan, np * TD * sizeof(double));
-        }
-        return finish_chunks(m, stats);
-    }
-    if (arrays.temp_locked()) c->last_host_mode |= FCAMD_HOST_TEMP_LOCK;
-    const bool zc = zero_copy_enabled(c);
-    const double* z_grad = (zc && c->opt.zero_copy_grad && aligned16(l_grad)) ? reinterpret_cast<const double*>(l_grad) : nullptr;
-    double* z_tan = (zc && tangent_host && aligned16(l_tan)) ? reinterpret_cast<double*>(l_tan) : nullptr;
-    c->last_host_mode |= (z_grad ? FCAMD_HOST_ZERO_COPY_IN : 0) | (z_tan ? FCAMD_HOST_ZERO_COPY_OUT : 0);
-    // Everything the pass moves lies in page-locked caller memory and the law is a 3-D one (whose stress
-    // store can feed two destinations): ONE launch reads the gradient from and writes stress and tangent
-    // to the host arrays while it updates the device-resident state -- no chunks, no copies.
-    double* z_stress = (zc && stress_host && m->dims.gdim == 3 && aligned16(l_stress)) ? reinterpret_cast<double*>(l_stress) : nullptr;
-    if (z_grad && (z_tan || !tangent_host) && (z_stress || !stress_host) && m->dims.gdim == 3) {
-        hipStream_t s = c->hstream[0];
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
-        st = enqueue(m, del_t, n, z_grad, stress_prev, stress, z_tan, hist_prev, hist, s, false, nullptr,
-                     reinterpret_cast<unsigned long long*>(history_mask), flags, z_stress);
-        if (st != FCAMD_OK) return drain_and_return(c, st);
-        return finish_chunks(m, stats);
-    }
-    int64_t chunk = 0;
-    st = prepare_chunks(c, grad, n, &chunk, /*staging=*/!(z_grad && (z_tan || !tangent_host)), /*locked=*/true);
-    if (st != FCAMD_OK) return st;
-    const int nslots = c->opt.host_slots;
-    HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
-    HIP_TRY(hipStreamSynchronize(c->hstream[0]));
-    int slot = 0;
-    for (int64_t p0 = 0; p0 < n; p0 += chunk, slot = (slot + 1) % nslots) {
-        const int64_t np = std::min<int64_t>(chunk, n - p0);
-        hipStream_t s = c->hstream[slot];
-        double* d_grad = c->dchunk[slot];  // unused (possibly null) when gradient and tangent are zero copy
-        double* d_tan = d_grad ? d_grad + 10 * c->dchunk_points : nullptr;
-        // chunk offsets are multiples of 64 points: every sub-array stays 16-byte aligned and the
-        // per-tile mask words line up
-        const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-        double* hc[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-        for (int k = 0; k < m->info.n_hist; ++k) {
-            const size_t d = (size_t)m->info.hist[k].dim;
-            hp[k] = hist_prev[k] + d * p0;
-            hc[k] = hist[k] + d * p0;
-        }
-        // page-locked, GPU-mapped caller arrays are read / written by the kernel itself (zero copy)
-        const double* k_grad = z_grad ? z_grad + GD2 * p0 : d_grad;
-        double* k_tan = !tangent_host ? nullptr : (z_tan ? z_tan + TD * p0 : d_tan);
-        if (!z_grad)
-            HIP_TRY_DRAIN(c, hipMemcpyAsync(d_grad, grad + GD2 * p0, (size_t)np * GD2 * sizeof(double), hipMemcpyHostToDevice, s));
-        st = enqueue(m, del_t, np, k_grad, stress_prev + SD * p0, stress + SD * p0, k_tan,
-                     hp, hc, s, false, nullptr,
-                     history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
-                     z_tan ? flags : (flags & ~FCAMD_EVAL_SPARSE_TANGENT));  // the staging buffer of a chunk holds no previous tangent: full rows
-        if (st != FCAMD_OK) return drain_and_return(c, st);
-        if (stress_host)
-            HIP_TRY_DRAIN(c, hipMemcpyAsync(stress_host + SD * p0, stress + SD * p0, (size_t)np * SD * sizeof(double),
-                                            hipMemcpyDeviceToHost, s));
-        if (tangent_host && !z_tan)
-            HIP_TRY_DRAIN(c, hipMemcpyAsync(tangent_host + TD * p0, d_tan, (size_t)np * TD * sizeof(double),
-                                            hipMemcpyDeviceToHost, s));
-    }
-    return finish_chunks(m, stats);
-}
-
-}  // extern "C"
-
-namespace {
-
-// One synchronous copy between caller host memory and device memory, ordered after the work queued on the
-// context stream, by the rules of the host entries (CallerArrays): never the runtime's pageable-copy path.
-int host_copy(fcamd_context* c, char* dev, char* host, size_t bytes, bool to_device) {
-    if (!c || (bytes && (!dev || !host))) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    if (bytes == 0) return FCAMD_OK;
-    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    CallerArrays arrays(c);
-    char* z = nullptr;
-    if ((mapped(c, host, 8) || bytes > (size_t)c->opt.bounce_max) && arrays.lock(host, bytes, &z)) {
-        const hipError_t e = to_device ? hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s)
-                                       : hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
-        const hipError_t e2 = hipStreamSynchronize(s);  // before the arrays are unlocked, whatever happened
-        if (e != hipSuccess || e2 != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(FCAMD_ERR_HIP, "copy between page-locked host memory and the device failed: %s",
-                        hipGetErrorString(e != hipSuccess ? e : e2));
-        }
-        return FCAMD_OK;
-    }
-    arrays.release();
-    const size_t piece = std::min(bytes, std::max<size_t>((size_t)c->opt.bounce_max, kBounceChunkBytes));
-    int st = ensure_bounce(c, piece);
-    if (st != FCAMD_OK) return st;
-    for (size_t off = 0; off < bytes; off += piece) {
-        const size_t nb = std::min(piece, bytes - off);
-        if (to_device) {
-            std::memcpy(c->bounce, host + off, nb);
-            HIP_TRY(hipMemcpyAsync(dev + off, c->bounce, nb, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));
-        } else {
-            HIP_TRY(hipMemcpyAsync(c->bounce, dev + off, nb, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            std::memcpy(host + off, c->bounce, nb);
-        }
-    }
-    return FCAMD_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int fcamd_copy_to_device(fcamd_context* c, void* dst_device, const void* src_host, size_t bytes) {
-    return host_copy(c, static_cast<char*>(dst_device), static_cast<char*>(const_cast<void*>(src_host)), bytes, true);
-}
-
-int fcamd_copy_to_host(fcamd_context* c, void* dst_host, const void* src_device, size_t bytes) {
-    return host_copy(c, static_cast<char*>(const_cast<void*>(src_device)), static_cast<char*>(dst_host), bytes, false);
 }
 
 }  // extern "C"

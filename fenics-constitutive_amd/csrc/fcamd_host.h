@@ -120,3 +120,31 @@ struct fcamd_model {
     fcamd::Scalars sc;
     fcamd::Tables tb;
 };
+
+// ---- shared between fcamd_capi.cpp (launching) and fcamd_hostpath.cpp (host entries) ------------------------
+namespace fcamd {
+
+constexpr size_t kCounterBytes = (size_t)kCounterSlots * 4 * sizeof(unsigned long long);
+
+// laws whose history changes only at plastic points (elastic points keep theirs bit for bit)
+inline bool has_sparse_history(int law) { return law == FCAMD_VON_MISES_3D || law >= FCAMD_COMFE_MISES_PLASTICITY; }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// the reference's argument checks (models/interfaces.py:82-101) for one call
+int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* grad, const void* stress_prev,
+                  const void* stress, const void* const* hist_prev, const void* const* hist, int n_hist);
+
+// one evaluate launch of `n` points on `stream` (fcamd_capi.cpp)
+int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev, double* stress,
+            double* tangent, const double* const* hprev, double* const* hcur, hipStream_t stream, bool reset_counters,
+            const int* rows = nullptr, unsigned long long* hmask = nullptr, int flags = 0, double* stress2 = nullptr,
+            unsigned long long* counters = nullptr);
+
+// download and sum the model's counters (synchronises `stream`)
+int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out);
+
+// release the chunk buffers and the page-locked scratch of the host entries (fcamd_hostpath.cpp)
+void free_host_staging(fcamd_context* c);
+
+}  // namespace fcamd

@@ -8,7 +8,7 @@ import sys
 # cache keyed by address and size.  On this stack memory that appears later at a remembered address (a freed and
 # re-allocated array, a heap that shrank and grew) is not GPU-accessible, the cache still calls it locked, and the copy
 # dies with "Memory access fault by GPU" -- it did, intermittently, at different tests of this suite (DESIGN.md 6,
-# tools/hsa_lock_probe.c).  The product never uses that path (csrc/fcamd_capi.cpp: CallerArrays; hostio.py); for
+# tools/hsa_lock_probe.c).  The product never uses that path (csrc/fcamd_hostpath.cpp: CallerArrays; hostio.py); for
 # torch's own copies in the tests the runtime is told to stage everything through its own buffers instead
 # (the unit is MiB; read when HIP initialises, i.e. after this line).
 os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")

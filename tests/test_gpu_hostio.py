@@ -1,4 +1,4 @@
-"""Host <-> device copies and pageable caller arrays (csrc/fcamd_capi.cpp: CallerArrays; hostio.py): the package never
+"""Host <-> device copies and pageable caller arrays (csrc/fcamd_hostpath.cpp: CallerArrays; hostio.py): the package never
 hands pageable memory to the HIP runtime's copy path, whose cache of on-the-fly page locks goes stale when memory is
 freed and allocated again at the same address.  The reference's counterpart of these copies are plain
 NumPy assignments (solver/_history.py:64-79, solver/_lawonsubmesh.py:58-61)."""
