@@ -280,16 +280,18 @@ int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
    downloaded into `stress_host` (sd*n) / `tangent_host` (sd*sd*n) while the next chunks are in
    flight (either may be NULL).  The tangent never exists as an n-sized device array.  72 B/pt
    up and 336 B/pt down instead of 176 + 392, and no host-side state copies.
-   A `grad_del_u_host` / `tangent_host` array inside a range page-locked with
-   fcamd_register_host_buffer is read / written by the kernel itself (zero copy, as in
-   fcamd_evaluate_host) instead of passing through the chunk buffers; when all host arrays of the
-   call are page-locked (3-D laws) the whole pass is one launch that writes the stress both to the
-   device-resident trial array and to `stress_host`.
+   The host arrays are handled as in fcamd_evaluate_host: ranges registered with
+   fcamd_register_host_buffer as they are, pageable arrays page-locked for the duration of the call
+   (passes that move at most "bounce_max" bytes: through the context's page-locked scratch).  A
+   page-locked `grad_del_u_host` / `tangent_host` is read / written by the kernel itself (zero copy)
+   instead of passing through the chunk buffers; when all host arrays of the call are page-locked
+   (3-D laws) the whole pass is one launch that writes the stress both to the device-resident trial
+   array and to `stress_host`.
    `history_mask` (nullable) selects the sparse trial-history protocol of
    fcamd_evaluate_device_from_sparse (plasticity laws).  `flags`: FCAMD_EVAL_SPARSE_TANGENT applies the
-   sparse-tangent protocol to `tangent_host` when the kernel writes it directly (page-locked array):
-   only the rows of plastic / formerly plastic points cross PCIe; ignored on the staged path, which
-   downloads every row.  FCAMD_EVAL_DELTA_HISTORY (VonMises3D, with history_mask) as in fcamd_evaluate_device_ex.  Synchronous; waits for work queued on the
+   sparse-tangent protocol to `tangent_host` when the kernel writes it directly: only the rows of
+   plastic / formerly plastic points cross PCIe (the caller's array must still hold the previous
+   call's tangent); ignored on the chunked and scratch paths, which write every row.  FCAMD_EVAL_DELTA_HISTORY (VonMises3D, with history_mask) as in fcamd_evaluate_device_ex.  Synchronous; waits for work queued on the
    context stream before touching the state arrays.  Status and `stats` as fcamd_evaluate_host. */
 int fcamd_evaluate_resident(fcamd_model* model, double t, double del_t, int64_t n,
                             const double* grad_del_u_host, const double* stress_prev,
