@@ -189,6 +189,26 @@ def test_eval_args_struct_layout_matches_header():
     assert _capi.EvalArgs.flags.offset == 9 * C.sizeof(C.c_void_p)
 
 
+def test_header_constants_match_the_ctypes_module():
+    """Every flag / status / enum value include/fcamd.h defines and _capi.py mirrors has the same value on both sides."""
+    import re
+
+    from fenics_constitutive_amd import _capi
+
+    hdr = open(os.path.join(ROOT, "include", "fcamd.h")).read()
+    defines = {k: int(v, 0) for k, v in re.findall(r"#define (FCAMD_[A-Z_0-9]+) (\d+|0x[0-9a-fA-F]+)\b", hdr)}
+    pairs = {"FCAMD_EVAL_SPARSE_TANGENT": _capi.EVAL_SPARSE_TANGENT, "FCAMD_EVAL_DELTA_HISTORY": _capi.EVAL_DELTA_HISTORY,
+             "FCAMD_HOST_ZERO_COPY_IN": _capi.HOST_ZERO_COPY_IN, "FCAMD_HOST_ZERO_COPY_OUT": _capi.HOST_ZERO_COPY_OUT,
+             "FCAMD_HOST_TEMP_LOCK": _capi.HOST_TEMP_LOCK, "FCAMD_HOST_BOUNCE": _capi.HOST_BOUNCE,
+             "FCAMD_COUNTER_SLOTS": _capi.COUNTER_SLOTS,
+             "FCAMD_MAX_HISTORY": _capi.MAX_HISTORY, "FCAMD_IPC_HANDLE_BYTES": _capi.IPC_HANDLE_BYTES,
+             "FCAMD_GATHER_PULL": _capi.GATHER_PULL, "FCAMD_ALLOC_SEQUENTIAL": _capi.ALLOC_SEQUENTIAL,
+             "FCAMD_ALLOC_INTERLEAVED": _capi.ALLOC_INTERLEAVED}
+    for name, value in pairs.items():
+        assert defines[name] == value, name
+    assert _capi.COUNTER_WORDS == 4 * defines["FCAMD_COUNTER_SLOTS"]  # FCAMD_COUNTER_WORDS is an expression in the header
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
 def test_drop_in_mode_subclasses_the_reference_interface():
     """With the reference importable (here: its NumPy part, dolfinx / the compiled bindings stubbed as
