@@ -409,6 +409,10 @@ def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="
         out.update(placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])))
         if wl.placement:
             out["placement_candidate_ms"] = wl.placement["candidate_ms"]
+        # PMC-measured HBM bytes of this configuration's launch (profiles/traffic.json: its own rocprofv3 passes, same kernels)
+        key = name + ("_full" if wl.plasticity and not wl.sparse else "") + ("_delta" if wl.delta else "")
+        out["traffic"] = read_traffic(key, n)
+        out["traffic_over_algorithmic"] = None if not out["traffic"] else round(out["traffic"] / alg, 4)
         out["placement_mode"] = (wl.vmm_info or {}).get("mode", "hipmalloc_tuned" if wl.placement else "first")
         if wl.vmm_info and "vmm_ms" in wl.vmm_info:
             out["placement_vmm_ms"] = wl.vmm_info["vmm_ms"]
@@ -865,7 +869,7 @@ def main():
         value = total_pts / elapsed / 1e6
         alg_bytes = headline["alg"]
         achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9
-        traffic = read_traffic(name + ("_full" if headline["plasticity"] and not headline["sparse"] else ""), n)
+        traffic = read_traffic(name + ("_full" if headline["plasticity"] and not headline["sparse"] else "") + ("_delta" if wl.delta else ""), n)
         out = {
             "metric": METRIC,
             "value": round(value, 1),
