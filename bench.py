@@ -154,7 +154,8 @@ class Workload:
     """One law on n synthetic device-resident points: the committed state, two Newton iterates of the
     gradient, the trial arrays, and the launch every timed step issues."""
 
-    def __init__(self, name, n, seed, device, dev_index, history="sparse", sparse_tangent=False, grid=0, delta_history=False):
+    def __init__(self, name, n, seed, device, dev_index, history="sparse", sparse_tangent=False, grid=0, delta_history=False,
+                 split_history=True):
         import torch
 
         self.torch = torch
@@ -189,6 +190,14 @@ class Workload:
         # part of the reference evaluate's work (eps_n += gamma N) out of the launch, so it is never part of the timed
         # steps of the default line -- it is measured after them and reported next to the headline, commit included.
         self.delta = bool(delta_history and self.sparse and self.kind == "von_mises_3d")
+        # comfe-rs plasticity laws under the sparse protocol: ResidentState keeps their [scalar, eps_p(6)] history rows as
+        # two arrays (FCAMD_EVAL_SPLIT_HISTORY) -- an internal layout of the device-resident state, same results
+        self.split = bool(split_history and self.sparse and self.kind in ("comfe_mises_plasticity", "comfe_drucker_prager"))
+        if self.split:
+            from fenics_constitutive_amd.device import split_history_rows
+
+            self.hist_c = split_history_rows(self.hist_c["history"])
+            self.hist_t = {k: torch.empty_like(v) for k, v in self.hist_c.items()}
         self.hmask = None
         if self.sparse:
             for k in self.hist_c:
@@ -204,7 +213,15 @@ class Workload:
                                self.tangent if tangent is None else tangent, self.hist_c, self.hist_t,
                                history_mask=None if full_history else self.hmask,
                                sparse_tangent=self.sparse_tangent if sparse_tangent is None else sparse_tangent,
-                               delta_history=bool(delta and not full_history))
+                               delta_history=bool(delta and not full_history), split_history=self.split)
+
+    def reference_history(self):
+        """the committed history in the reference's layout (the split layout joined back into 7-double rows)"""
+        if not self.split:
+            return self.hist_c
+        from fenics_constitutive_amd.device import join_history_rows
+
+        return {"history": join_history_rows(self.hist_c)}
 
     def time_delta_protocol(self, launches=6):
         """ResidentState's delta trial history on this workload: the evaluate launches with the flag (two alternating
@@ -365,6 +382,7 @@ class Workload:
                 f"committed->trial evaluate of two alternating Newton iterates"
                 f"{', sparse trial history (ResidentState protocol)' if self.sparse else (', full trial history' if self.plasticity else '')}"
                 f"{', eps_n kept as increment during the iterations (delta trial history)' if self.delta else ''}"
+                f"{', history kept as [scalar, eps_p rows] in the state (split history)' if self.split else ''}"
                 f"{', sparse tangent (rows of points that stay elastic are not rewritten)' if self.sparse_tangent else ''}")
 
     def free(self):
@@ -440,7 +458,7 @@ def cpu_quick(wl, budget_s=1.0, ns=1_000_000):
     dims = {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}
     g = to_host(wl.grads[0][: 9 * ns])
     s0 = to_host(wl.stress_c[: 6 * ns])
-    h0 = None if wl.hist_c is None else {k: to_host(v[: dims[k] * ns]) for k, v in wl.hist_c.items()}
+    h0 = None if wl.hist_c is None else {k: to_host(v[: dims[k] * ns]) for k, v in wl.reference_history().items()}
     tan = np.zeros(36 * ns)
     out = {}
     for label, fn, m in (("c_port_1_thread_Mpts_s", CO.MODELS[wl.kind], ns), ("numpy_port_Mpts_s", NO.MODELS[wl.kind], min(ns, 200_000))):
@@ -702,6 +720,9 @@ def main():
                          "array receives the increment, the committed rows are not read; the accumulation happens at the commit).  Not "
                          "the reference's evaluate -- never the default line; the default run measures it after the timed steps and "
                          "reports it under \"delta_trial_history\" with the commit kernel's time")
+    ap.add_argument("--no-split-history", action="store_true",
+                    help="comfe-rs plasticity workloads: keep the reference's 7-double history rows in the state instead of "
+                         "ResidentState's [scalar, eps_p rows] layout (FCAMD_EVAL_SPLIT_HISTORY)")
     ap.add_argument("--sparse-tangent", action="store_true",
                     help="with --history sparse: also the sparse-tangent protocol of ResidentState (FCAMD_EVAL_SPARSE_TANGENT: "
                          "rows of points that stay elastic are not rewritten).  Not the reference contract -- the reported "
@@ -774,7 +795,8 @@ def main():
     history = "sparse" if args.sparse_history else args.history
     n = args.n
     wl = Workload(name, n, seed=1234 + rank, device=device, dev_index=dev_index, history=history,
-                  sparse_tangent=args.sparse_tangent, grid=args.grid, delta_history=args.delta_history)
+                  sparse_tangent=args.sparse_tangent, grid=args.grid, delta_history=args.delta_history,
+                  split_history=not args.no_split_history)
     tries = args.placement_tries
     if world > 1 and tries > 1:
         # the candidates are alive together while they are timed: never more than fit next to the working set
@@ -858,7 +880,7 @@ def main():
         # sample of the headline arrays, taken before they are released for the other configurations
         cpu_args = (wl.kind, wl.params, wl.grads[0][: 9 * 2_000_000].clone(), wl.stress_c[: 12_000_000].clone(),
                     None if wl.hist_c is None else {k: v[: {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}[k] * 2_000_000].clone()
-                                                    for k, v in wl.hist_c.items()}, wl.del_t)
+                                                    for k, v in wl.reference_history().items()}, wl.del_t)
     headline = {"placement": wl.placement, "vmm_info": wl.vmm_info, "launch_log": list(wl.launch_log), "config_text": wl.config_text(), "kind": wl.kind,
                 "b_el": wl.b_el, "b_pl": wl.b_pl, "alg": wl.alg_bytes(n_pl), "alg0": wl.alg_bytes(wl.n_pl_ab[0]),
                 "fracs": placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])), "sparse": wl.sparse, "plasticity": wl.plasticity}

@@ -28,6 +28,7 @@ COUNTER_SLOTS, COUNTER_WORDS = 64, 256  # FCAMD_COUNTER_SLOTS / FCAMD_COUNTER_WO
 # fcamd_eval_args.flags / fcamd_evaluate_resident flags (include/fcamd.h)
 EVAL_SPARSE_TANGENT = 1
 EVAL_DELTA_HISTORY = 2
+EVAL_SPLIT_HISTORY = 4
 
 # fcamd_context_last_host_mode flags (include/fcamd.h)
 HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT, HOST_TEMP_LOCK, HOST_BOUNCE = 1, 2, 4, 8

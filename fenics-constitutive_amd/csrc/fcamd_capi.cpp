@@ -327,14 +327,17 @@ int timing_end(fcamd_model* m) {
 namespace fcamd {
 int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* grad,
                   const void* stress_prev, const void* stress, const void* const* hist_prev,
-                  const void* const* hist, int n_hist) {
+                  const void* const* hist, int n_hist, int flags) {
     if (!m) return fail(FCAMD_ERR_BAD_ARG, "model handle is NULL");
     if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
+    if ((flags & FCAMD_EVAL_SPLIT_HISTORY) && !has_split_history(m->law))
+        return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_SPLIT_HISTORY exists for the laws with one [scalar, eps_p(6)] history row per point");
     if (m->info.n_hist > 0) {
+        const int expected = (flags & FCAMD_EVAL_SPLIT_HISTORY) ? 2 : m->info.n_hist;  // split: [scalar (n), rows (6 n)]
         if (!hist || !hist_prev || n_hist == 0)
             return fail(FCAMD_ERR_NULL_HISTORY, "history must not be None");
-        if (n_hist != m->info.n_hist)
-            return fail(FCAMD_ERR_SIZE, "law expects %d history fields, got %d", m->info.n_hist,
+        if (n_hist != expected)
+            return fail(FCAMD_ERR_SIZE, "law expects %d history fields, got %d", expected,
                         n_hist);
         for (int k = 0; k < n_hist; ++k)
             if (n > 0 && (!hist[k] || !hist_prev[k]))
@@ -378,14 +381,16 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.stress_out = stress;
     a.stress_out2 = stress2;
     a.tangent = tangent;
-    a.h0_in = m->info.n_hist > 0 ? hprev[0] : nullptr;
-    a.h0_out = m->info.n_hist > 0 ? hcur[0] : nullptr;
-    a.h1_in = m->info.n_hist > 1 ? hprev[1] : nullptr;
-    a.h1_out = m->info.n_hist > 1 ? hcur[1] : nullptr;
+    const bool split = (flags & FCAMD_EVAL_SPLIT_HISTORY) != 0 && has_split_history(m->law);
+    const int nh = split ? 2 : m->info.n_hist;
+    a.h0_in = nh > 0 ? hprev[0] : nullptr;
+    a.h0_out = nh > 0 ? hcur[0] : nullptr;
+    a.h1_in = nh > 1 ? hprev[1] : nullptr;
+    a.h1_out = nh > 1 ? hcur[1] : nullptr;
     a.rows = rows;
     a.cache3d = nullptr;
     a.hmask = hmask;
-    a.flags = 0;
+    a.flags = split ? FCAMD_EVAL_SPLIT_HISTORY : 0;
     if (hmask) {
         if (tangent) a.flags |= flags & FCAMD_EVAL_SPARSE_TANGENT;  // needs an array that holds the previous tangent
         if (m->law == FCAMD_VON_MISES_3D) a.flags |= flags & FCAMD_EVAL_DELTA_HISTORY;
@@ -395,8 +400,8 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     const Options& o = m->ctx->opt;
     a.tile_map = o.tile_map;
     a.nontemporal = o.nontemporal;
-    a.masked_max = o.masked_max >= 0 ? o.masked_max
-                                     : (m->law == FCAMD_VON_MISES_3D ? kMaskedRowMaxVonMises : kMaskedRowMaxRows7);
+    a.masked_max = o.masked_max >= 0 ? o.masked_max  // split history: 48-byte eps_p rows, as VonMises3D's eps_n
+                                     : ((m->law == FCAMD_VON_MISES_3D || split) ? kMaskedRowMaxVonMises : kMaskedRowMaxRows7);
     constants_for(m, del_t);
     a.sc = m->sc;
     a.tb = m->tb;
@@ -739,7 +744,7 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     if (!x) return fail(FCAMD_ERR_BAD_ARG, "args is NULL");
     int st = validate_call(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress,
                            reinterpret_cast<const void* const*>(x->history_prev),
-                           reinterpret_cast<const void* const*>(x->history), x->n_hist);
+                           reinterpret_cast<const void* const*>(x->history), x->n_hist, x->flags);
     if (st != FCAMD_OK) return st;
     if (x->parent_rows && m->constraint != FCAMD_FULL)
         return fail(FCAMD_ERR_UNSUPPORTED, "the indexed form exists for StressStrainConstraint.FULL only");
@@ -756,9 +761,11 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     }
     if (!aligned16(x->grad_del_u) || !aligned16(x->stress) || !aligned16(x->stress_prev) || !aligned16(x->tangent))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
-    for (int k = 0; k < m->info.n_hist; ++k)
+    for (int k = 0; k < x->n_hist; ++k)
         if (!aligned16(x->history[k]) || !aligned16(x->history_prev[k]))
             return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
+    if ((x->flags & FCAMD_EVAL_SPLIT_HISTORY) && m->constraint != FCAMD_FULL)
+        return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_SPLIT_HISTORY: 3-D laws only");
     fcamd_context* c = m->ctx;
     HIP_TRY(hipSetDevice(c->device));
     if (!aligned16(x->stress2)) return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");

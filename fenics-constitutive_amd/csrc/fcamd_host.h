@@ -129,11 +129,14 @@ constexpr size_t kCounterBytes = (size_t)kCounterSlots * 4 * sizeof(unsigned lon
 // laws whose history changes only at plastic points (elastic points keep theirs bit for bit)
 inline bool has_sparse_history(int law) { return law == FCAMD_VON_MISES_3D || law >= FCAMD_COMFE_MISES_PLASTICITY; }
 
+// laws whose reference history is one [scalar, eps_p(6)] row per point (FCAMD_EVAL_SPLIT_HISTORY)
+inline bool has_split_history(int law) { return law >= FCAMD_COMFE_MISES_PLASTICITY; }
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // the reference's argument checks (models/interfaces.py:82-101) for one call
 int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* grad, const void* stress_prev,
-                  const void* stress, const void* const* hist_prev, const void* const* hist, int n_hist);
+                  const void* stress, const void* const* hist_prev, const void* const* hist, int n_hist, int flags = 0);
 
 // one evaluate launch of `n` points on `stream` (fcamd_capi.cpp)
 int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev, double* stress,

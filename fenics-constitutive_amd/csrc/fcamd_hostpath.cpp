@@ -501,13 +501,18 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     (void)t;
     int st = validate_call(m, del_t, n, grad, stress_prev, stress,
                            reinterpret_cast<const void* const*>(hist_prev),
-                           reinterpret_cast<const void* const*>(hist), n_hist);
+                           reinterpret_cast<const void* const*>(hist), n_hist, flags);
     if (st != FCAMD_OK) return st;
     if (history_mask && !has_sparse_history(m->law))
         return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
     if (!aligned16(stress) || !aligned16(stress_prev))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
-    for (int k = 0; k < m->info.n_hist; ++k)
+    // history arrays of the state: the law's fields, or -- FCAMD_EVAL_SPLIT_HISTORY -- [scalar (n), eps_p rows (6 n)]
+    const bool split = (flags & FCAMD_EVAL_SPLIT_HISTORY) != 0;
+    const int NH = split ? 2 : m->info.n_hist;
+    size_t hdim[FCAMD_MAX_HISTORY] = {0, 0};
+    for (int k = 0; k < NH; ++k) hdim[k] = split ? (k == 0 ? 1 : 6) : (size_t)m->info.hist[k].dim;
+    for (int k = 0; k < NH; ++k)
         if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
             return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
     fcamd_context* c = m->ctx;
@@ -556,8 +561,8 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
             std::memcpy(c->bounce + o_grad, grad + GD2 * p0, np * GD2 * sizeof(double));
             const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
             double* hc[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-            for (int k = 0; k < m->info.n_hist; ++k) {
-                const size_t d = (size_t)m->info.hist[k].dim;
+            for (int k = 0; k < NH; ++k) {
+                const size_t d = hdim[k];
                 hp[k] = hist_prev[k] + d * p0;
                 hc[k] = hist[k] + d * p0;
             }
@@ -608,8 +613,8 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         // per-tile mask words line up
         const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
         double* hc[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
-        for (int k = 0; k < m->info.n_hist; ++k) {
-            const size_t d = (size_t)m->info.hist[k].dim;
+        for (int k = 0; k < NH; ++k) {
+            const size_t d = hdim[k];
             hp[k] = hist_prev[k] + d * p0;
             hc[k] = hist[k] + d * p0;
         }

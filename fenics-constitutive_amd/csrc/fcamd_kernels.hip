@@ -373,6 +373,12 @@ constexpr int kFlagSparseTangent = 1;
 // of the plastic points to the committed array (commit_delta_kernel, once per increment instead of once per
 // Newton iteration).  alpha is not affected (it enters the yield function and is read for every point anyway).
 constexpr int kFlagDeltaHistory = 2;
+// Split history of the laws whose reference layout is one [alpha, eps_p(6)] row per point (comfe-rs Mises and
+// Drucker-Prager): h0 = the scalar (n doubles), h1 = the plastic-strain rows (6 n).  eps_p is write-only for the
+// stress update (it only accumulates), the scalar is needed by every point (Mises: it enters the yield function) or
+// by the plastic ones (Drucker-Prager); in the 7-double rows every point pays 56 bytes of history reads for it.
+// A layout of device-resident states only (ResidentState), never of the interface arrays.
+constexpr int kFlagSplitHistory = 4;
 template <bool FULL>
 __device__ __forceinline__ unsigned long long sparse_tangent_need(const EvalArgs& a, unsigned long long need) {
     return (FULL && (a.flags & kFlagSparseTangent) != 0 && a.hmask != nullptr) ? need : ~0ull;
@@ -1078,6 +1084,59 @@ __device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, 
     wave_sync();
 }
 
+// Split history (kFlagSplitHistory): the scalar of every point of a touched tile and the rows `rows` of the
+// plastic-strain array, rows_out = rows_in + delta (delta = 0 at points that are not plastic: they get their committed
+// values back).  Which rows, by protocol, as in history7_store.  Row-masked access as in tile_von_mises (a 48-byte row
+// is three 16-byte chunks of the tile image).
+template <bool FULL, bool NT>
+__device__ __forceinline__ void split_history_store(const EvalArgs& a, long long p0, int npts, int lane, unsigned long long mask,
+                                                    unsigned long long touched, bool hist_in_place, double* region,
+                                                    double scalar, const double (&delta)[6]) {
+    const bool live = FULL || lane < npts;
+    const unsigned long long rows = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
+    if (rows == 0ull) return;
+    if (live) a.h0_out[p0 + lane] = scalar;  // one coalesced 512-byte store per touched tile
+    const bool masked = FULL && rows != ~0ull && (int)__popcll(rows) <= a.masked_max;
+    Chunks<6> ce;
+    bool row_live[3] = {true, true, true};
+    if (masked) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            row_live[k] = ((rows >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
+            d2 z;
+            z.x = 0.0;
+            z.y = 0.0;
+            ce.v[k] = row_live[k] ? load16<NT>(a.h1_in + p0 * 6 + 2 * (k * kWave + lane)) : z;
+        }
+    } else {
+        tile_load<6, FULL, NT>(ce, a.h1_in + p0 * 6, npts * 6, lane);
+    }
+    if (mask != 0ull) {
+        double ep[6];
+        transpose_in<6>(ce, region, lane, ep);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + delta[i];
+        if (masked) {
+            lds_put_point<6>(region, lane, ep);
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int q = k * kWave + lane;
+                if (row_live[k]) store16<NT>(a.h1_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+            }
+            wave_sync();
+        } else {
+            transpose_out<6, FULL, NT>(ep, region, lane, a.h1_out + p0 * 6, npts * 6);
+        }
+    } else if (masked) {  // only stale rows: restore the committed values
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (row_live[k]) store16<NT>(a.h1_out + p0 * 6 + 2 * (k * kWave + lane), ce.v[k]);
+    } else if (!hist_in_place) {
+        tile_store<6, FULL, NT>(ce, a.h1_out + p0 * 6, npts * 6, lane);
+    }
+}
+
 // --- comfe-rs MisesPlasticity3D: linear hardening, closed-form radial return ---------------
 // scalars: s[0]=strain factor (FRAC_1_SQRT_2), s[1]=mu, s[2]=kappa, s[3]=y_0, s[4]=h,
 //          s[5]=2*mu, s[6]=3*mu+h, s[7]=sqrt(3/2), s[8]=3*mu, s[9]=1/(1+h/(3 mu))
@@ -1089,16 +1148,27 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     Chunks<7> ch;
+    const bool split = (a.flags & kFlagSplitHistory) != 0;
+    const bool live = FULL || lane < npts;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
     sr.load(a, sb, p0, npts, lane, rows_lds);
-    tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
-    const bool live = FULL || lane < npts;
+    double alpha_n = 0.0;
+    if (split)
+        alpha_n = live ? a.h0_in[p0 + lane] : 0.0;
+    else
+        tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
     const bool hist_in_place = (a.h0_in == a.h0_out);
 
     double g[9], s[6], h[7], e[6];
     transpose_in<9>(cg, region, lane, g);
     sr.get(region, lane, s);
-    transpose_in<7>(ch, region, lane, h);
+    if (split) {  // eps_p only accumulates: start the rows at zero, what comes back is the increment
+        h[0] = alpha_n;
+#pragma unroll
+        for (int i = 1; i < 7; ++i) h[i] = 0.0;
+    } else {
+        transpose_in<7>(ch, region, lane, h);
+    }
     mandel_strain(g, a.sc.s[0], e);
 
     double B, sc2, nv[6];
@@ -1108,7 +1178,12 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
 
     sr.put(sb, region, lane, s, p0, npts);
     const unsigned long long touched = sparse_need(a, p0, mask, lane);
-    history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
+    if (split) {
+        const double d6[6] = {h[1], h[2], h[3], h[4], h[5], h[6]};
+        split_history_store<FULL, NT>(a, p0, npts, lane, mask, touched, hist_in_place, region, h[0], d6);
+    } else {
+        history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
+    }
 
     const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
     if (sb.tan && tneed != 0ull) {
@@ -1352,16 +1427,27 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     Chunks<7> ch;
+    const bool split = (a.flags & kFlagSplitHistory) != 0;
+    const bool live = FULL || lane < npts;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
     sr.load(a, sb, p0, npts, lane, rows_lds);
-    tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
-    const bool live = FULL || lane < npts;
+    double scalar_n = 0.0;
+    if (split)
+        scalar_n = live ? a.h0_in[p0 + lane] : 0.0;
+    else
+        tile_load<7, FULL, NT>(ch, a.h0_in + p0 * 7, npts * 7, lane);
     const bool hist_in_place = (a.h0_in == a.h0_out);
 
     double g9[9], sig0[6], h[7], e[6];
     transpose_in<9>(cg, region, lane, g9);
     sr.get(region, lane, sig0);
-    transpose_in<7>(ch, region, lane, h);
+    if (split) {  // the plastic strain only accumulates: start the rows at zero, what comes back is the increment
+        h[0] = scalar_n;
+#pragma unroll
+        for (int i = 1; i < 7; ++i) h[i] = 0.0;
+    } else {
+        transpose_in<7>(ch, region, lane, h);
+    }
     mandel_strain(g9, a.sc.s[0], e);
 
     DPTrial t;
@@ -1373,7 +1459,12 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
         // fully elastic tile: stress = sigma_tr, tangent = E, history untouched
         sr.put(sb, region, lane, t.sig1, p0, npts);
         const unsigned long long touched = sparse_need(a, p0, 0ull, lane);
-        history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
+        if (split) {
+            const double d6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            split_history_store<FULL, NT>(a, p0, npts, lane, 0ull, touched, hist_in_place, region, h[0], d6);
+        } else {
+            history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
+        }
         const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
         if (sb.tan && tneed != 0ull) {
             if constexpr (IDX) wave_sync();
@@ -1394,7 +1485,12 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
 
     sr.put(sb, region, lane, t.sig1, p0, npts);
     const unsigned long long touched = sparse_need(a, p0, mask, lane);
-    history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
+    if (split) {
+        const double d6[6] = {h[1], h[2], h[3], h[4], h[5], h[6]};
+        split_history_store<FULL, NT>(a, p0, npts, lane, mask, touched, hist_in_place, region, h[0], d6);
+    } else {
+        history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
+    }
 
     const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
     if (sb.tan && tneed != 0ull) {

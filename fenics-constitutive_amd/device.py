@@ -54,6 +54,24 @@ def _current_stream_ptr(device_index: int) -> int:
     return int(torch.cuda.current_stream(device_index).cuda_stream)
 
 
+#: FCAMD_EVAL_SPLIT_HISTORY: the two arrays that replace the 7-double ``history`` rows of the comfe-rs plasticity laws
+SPLIT_HISTORY_FIELDS = (("scalar", 1), ("rows", 6))
+SPLIT_HISTORY_LAWS = ("MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D")
+
+
+def split_history_rows(history7):
+    """``{"history": [7 n]}`` rows (device tensor) -> ``{"scalar": [n], "rows": [6 n]}`` (new contiguous tensors)"""
+    v = history7.view(-1, 7)
+    return {"scalar": v[:, 0].contiguous(), "rows": v[:, 1:].contiguous().view(-1)}
+
+
+def join_history_rows(split):
+    """the inverse: the reference's ``history`` array assembled from the split layout (new tensor)"""
+    import torch
+
+    return torch.cat([split["scalar"].view(-1, 1), split["rows"].view(-1, 6)], dim=1).reshape(-1)
+
+
 class DeviceLaw(IncrSmallStrainModel):
     """Base of all GPU-backed laws: owns the C model handle (created lazily, per device)
     and implements ``evaluate`` on top of the C ABI with the reference's validation."""
@@ -204,7 +222,8 @@ class DeviceLaw(IncrSmallStrainModel):
         )
 
     def evaluate_from(self, t, del_t, grad_del_u, stress_prev, stress, tangent, history_prev, history,
-                      history_mask=None, sparse_tangent: bool = False, counters=None, delta_history: bool = False) -> None:
+                      history_mask=None, sparse_tangent: bool = False, counters=None, delta_history: bool = False,
+                      split_history: bool = False) -> None:
         """Out-of-place device evaluate: read the committed state (``stress_prev``,
         ``history_prev``), write the trial state (``stress``, ``history``).  Fuses the two
         copies the reference makes before every call (solver/_lawonsubmesh.py:58-61,
@@ -215,13 +234,19 @@ class DeviceLaw(IncrSmallStrainModel):
         statistics instead of the law's own counters (``fcamd_eval_args.counters``; read it with
         ``read_counters``).  ``delta_history`` (VonMises3D, with ``history_mask``): the trial ``eps_n`` array
         receives the increment at the plastic points and the committed one is not read
-        (FCAMD_EVAL_DELTA_HISTORY; commit with ``commit_delta_history``)."""
-        hist = self._history_arrays(history)
-        hprev = self._history_arrays(history_prev)
+        (FCAMD_EVAL_DELTA_HISTORY; commit with ``commit_delta_history``).  ``split_history`` (the comfe-rs plasticity
+        laws): the histories are dicts ``{"scalar": n, "rows": 6 n}`` instead of the reference's ``{"history": 7 n}``
+        (FCAMD_EVAL_SPLIT_HISTORY: ``SPLIT_HISTORY_FIELDS``)."""
+        if split_history:
+            hist = [history[k] for k, _ in SPLIT_HISTORY_FIELDS]
+            hprev = [history_prev[k] for k, _ in SPLIT_HISTORY_FIELDS]
+        else:
+            hist = self._history_arrays(history)
+            hprev = self._history_arrays(history_prev)
         gd2, sd = self.geometric_dim**2, self.stress_strain_dim
         n = _size(grad_del_u) // gd2
         assert n == _size(stress) // sd == _size(stress_prev) // sd and (tangent is None or n == _size(tangent) // (sd * sd))
-        if history_mask is None and counters is None:
+        if history_mask is None and counters is None and not split_history:
             self._evaluate_device(t, del_t, n, grad_del_u, stress, tangent, hist, stress_prev, hprev)
             return
         # sparse trial history (fcamd_evaluate_device_from_sparse): see ResidentState
@@ -234,11 +259,13 @@ class DeviceLaw(IncrSmallStrainModel):
         dev = grad_del_u.device.index or 0
         m = self._handle(dev)
         m.ctx.set_stream(_current_stream_ptr(dev))
-        if (sparse_tangent and tangent is not None) or counters is not None or delta_history:
+        if (sparse_tangent and tangent is not None) or counters is not None or delta_history or split_history:
             flags = _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tangent is not None and history_mask is not None) else 0
             if delta_history:
                 assert history_mask is not None, "delta_history needs history_mask"
                 flags |= _capi.EVAL_DELTA_HISTORY
+            if split_history:
+                flags |= _capi.EVAL_SPLIT_HISTORY
             m.evaluate_device_ex(
                 t, del_t, n, grad_del_u.data_ptr(), stress_prev.data_ptr(), stress.data_ptr(),
                 None if tangent is None else _check_torch("tangent", tangent).data_ptr(),

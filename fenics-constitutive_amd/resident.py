@@ -39,7 +39,7 @@ class ResidentState:
 
     def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
                  reuse_constant_tangent: bool = True, sparse_tangent: bool = True, placement: str = "auto",
-                 delta_history: bool = False):
+                 delta_history: bool = False, split_history: bool = True):
         """``placement`` (device-assembler mode, large states): where the arrays the kernel streams
         live decides 10-28 % of its time on MI355X.  "vmm": on the first ``evaluate`` the state moves its arrays
         (both stress / history copies, tangent, gradient staging) into ONE working set whose 2 MiB physical
@@ -58,8 +58,15 @@ class ResidentState:
         # iterations per increment (bench.py "delta_trial_history") -- a gain for long Newton loops only, hence not the
         # default.  ``history`` (the trial view) assembles eps_n on demand.
 
+        # ``split_history`` (the comfe-rs plasticity laws, with the sparse protocol): the reference keeps one
+        # [scalar, eps_p(6)] row of 7 doubles per point (``history_dim = {"history": 7}``), so every point pays 56 bytes
+        # of history reads for the scalar; the state keeps the scalars and the eps_p rows in two arrays instead
+        # (FCAMD_EVAL_SPLIT_HISTORY: elastic points read 8 bytes and write nothing) and ``history`` /
+        # ``history_committed`` assemble the reference's rows on demand (copies -- initialise with ``set_state``).
+
         self.law, self.n = law, int(n)
         from . import _capi
+        from .device import SPLIT_HISTORY_FIELDS, SPLIT_HISTORY_LAWS
 
         self.device = torch.device("cuda", _capi.default_device()) if device is None else torch.device(device)
         gd2, sd = law.geometric_dim**2, law.stress_strain_dim
@@ -69,13 +76,17 @@ class ResidentState:
         self._grad = self._tangent = None  # device-assembler mode only; allocated on first use
         self._stress = [torch.zeros(sd * n, **f), torch.zeros(sd * n, **f)]
         hd = law.history_dim
+        self._split = bool(split_history) and bool(sparse_history) and type(law).__name__ in SPLIT_HISTORY_LAWS
+        if self._split:
+            hd = dict(SPLIT_HISTORY_FIELDS)
         self._hist = None if hd is None else [{k: torch.zeros(d * n, **f) for k, d in hd.items()} for _ in range(2)]
         self._c = 0  # index of the committed copy
         if stress0 is not None:
             self._stress[0].copy_(self._as_dev(stress0))
         if history0 is not None and self._hist is not None:
+            h0 = self._internal_history(history0)
             for k in self._hist[0]:
-                self._hist[0][k].copy_(self._as_dev(history0[k]))
+                self._hist[0][k].copy_(h0[k])
                 self._hist[1][k].copy_(self._hist[0][k])  # trial == committed (sparse-history contract)
         # Plasticity laws: sparse trial history (fcamd_evaluate_device_from_sparse).  Elastic points keep
         # their history, so only plastic / formerly plastic points are written; the mask (one word
@@ -122,6 +133,22 @@ class ResidentState:
         self._vmm = None
         self.placement = None  # what the placement step did, once it has run
 
+    def _internal_history(self, history) -> dict:
+        """The caller's history dict (NumPy arrays or device tensors, the law's ``history_dim`` fields) in the state's
+        own layout, as device tensors."""
+        if not self._split:
+            return {k: self._as_dev(v) for k, v in history.items()}
+        from .device import split_history_rows
+
+        return split_history_rows(self._as_dev(history["history"]))
+
+    def _external_history(self, internal) -> dict:
+        if not self._split:
+            return internal
+        from .device import join_history_rows
+
+        return {"history": join_history_rows(internal)}
+
     def _as_dev(self, a):
         import torch
 
@@ -158,7 +185,7 @@ class ResidentState:
         """Committed history (live tensors).  Invariant of the sparse protocol: the trial history equals
         the committed one wherever the mask is clear -- do not write initial / restart values into these
         tensors, ``set_state`` writes both copies."""
-        return None if self._hist is None else self._hist[self._c]
+        return None if self._hist is None else self._external_history(self._hist[self._c])
 
     @property
     def history(self):
@@ -168,7 +195,7 @@ class ResidentState:
             return None
         trial = self._hist[1 - self._c]
         if not self._delta:
-            return trial
+            return self._external_history(trial)
         if not self._evaluated:  # nothing evaluated in this increment yet: the trial state is the committed one
             return {**trial, "eps_n": self._hist[self._c]["eps_n"]}
         import torch
@@ -191,8 +218,9 @@ class ResidentState:
         if stress is not None:
             self.stress_committed.copy_(self._as_dev(stress))
         if history is not None and self._hist is not None:
+            h = self._internal_history(history)
             for k in self._hist[self._c]:
-                self._hist[self._c][k].copy_(self._as_dev(history[k]))
+                self._hist[self._c][k].copy_(h[k])
                 self._hist[1 - self._c][k].copy_(self._hist[self._c][k])
         if self._mask is not None:
             self._mask.zero_()
@@ -204,9 +232,10 @@ class ResidentState:
     # the Newton-iteration call --------------------------------------------------------------------
     def _launch(self, t, del_t, g, tangent, sparse_tangent=False) -> None:
         self.law.evaluate_from(t, del_t, g, self.stress_committed, self.stress, tangent,
-                               self.history_committed, None if self._hist is None else self._hist[1 - self._c],
+                               None if self._hist is None else self._hist[self._c],
+                               None if self._hist is None else self._hist[1 - self._c],
                                history_mask=self._mask, sparse_tangent=sparse_tangent, counters=self._counters,
-                               delta_history=self._delta)
+                               delta_history=self._delta, split_history=self._split)
 
     def evaluate(self, t: float, del_t: float, grad_del_u) -> None:
         """Trial state <- law(committed state, grad_del_u).  May be called any number of times per
@@ -288,9 +317,9 @@ class ResidentState:
         n, sd = self.n, self._sd
         numels = {"tangent": sd * sd * n, "stress0": sd * n, "stress1": sd * n}
         if self._hist is not None:
-            for k, d in self.law.history_dim.items():
-                numels[f"h0_{k}"] = d * n
-                numels[f"h1_{k}"] = d * n
+            for k, v in self._hist[0].items():  # the state's own layout (split or the law's fields)
+                numels[f"h0_{k}"] = v.numel()
+                numels[f"h1_{k}"] = v.numel()
         if staging or self._grad is not None:
             numels["grad"] = self._gd2 * n
         ctx = _capi.get_context(self.device.index or 0)
@@ -372,8 +401,11 @@ class ResidentState:
         import torch
 
         m.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        hp = [] if self._hist is None else [self.history_committed[k].data_ptr() for k, _ in m.history_fields]
-        hc = [] if self._hist is None else [self._hist[1 - self._c][k].data_ptr() for k, _ in m.history_fields]
+        from .device import SPLIT_HISTORY_FIELDS
+
+        fields = SPLIT_HISTORY_FIELDS if self._split else m.history_fields
+        hp = [] if self._hist is None else [self._hist[self._c][k].data_ptr() for k, _ in fields]
+        hc = [] if self._hist is None else [self._hist[1 - self._c][k].data_ptr() for k, _ in fields]
         self._evaluated = True  # the trial state is touched even if the call raises
         # sparse tangent: only into the very array that received the previous evaluate's tangent, and only
         # when the kernel writes it directly (page-locked array; the C side ignores the flag otherwise --
@@ -393,6 +425,8 @@ class ResidentState:
                                               and self._tangent_target == target) else 0
         if self._delta:
             flags |= _capi.EVAL_DELTA_HISTORY
+        if self._split:
+            flags |= _capi.EVAL_SPLIT_HISTORY
         self._tangent_target = None
         self._stats_pending = False  # synchronous: the call itself reports
         try:

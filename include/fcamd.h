@@ -241,6 +241,15 @@ typedef struct fcamd_eval_args {
    on a random 22 % mixture.  The commit of the increment is fcamd_commit_delta_history (instead of swapping the
    eps_n pointers); alpha (history[1]) keeps its usual meaning.  Every other result of the call is unchanged. */
 #define FCAMD_EVAL_DELTA_HISTORY 2
+/* Split history (the laws whose reference history is ONE [scalar, eps_p(6)] row of 7 doubles per point: comfe-rs
+   MisesPlasticity3D -- alpha --, DruckerPrager3D / DruckerPragerHyperbolic3D -- the hardening variable;
+   comfe-rs/src/plasticity/mises_plasticity.rs:58-126, general.rs:105-266).  eps_p only accumulates, the stress update
+   never reads it back, but inside the 7-double row every point pays 56 bytes of history reads for the scalar.  With this
+   flag the history of the call is TWO arrays, history[0] = the scalars (n doubles), history[1] = the eps_p rows (6 n
+   doubles), n_hist = 2: elastic points then read 8 bytes (Mises) of history and write none.  A layout for
+   device-resident states (ResidentState keeps it and assembles the reference's rows on demand), not of the interface
+   arrays; FULL 3-D only; fcamd_evaluate_device_ex and fcamd_evaluate_resident. */
+#define FCAMD_EVAL_SPLIT_HISTORY 4
 int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_t, int64_t n,
                              const fcamd_eval_args* args);
 /* history_committed0[row] += history_delta0[row] for the rows set in history_mask (the mask left by the last

@@ -104,21 +104,37 @@ def _sparse_case(law_name, n, rng):
 @pytest.mark.parametrize("law_name", ["VonMises3D", "MisesPlasticityLinearHardening3D", "DruckerPrager3D",
                                       "DruckerPragerHyperbolic3D"])
 @pytest.mark.parametrize("n", [64 * 40 + 17, 5000])
-def test_sparse_history_equals_full_history(n, law_name):
+@pytest.mark.parametrize("split", [True, False])
+def test_sparse_history_equals_full_history(n, law_name, split):
     """The sparse trial-history protocol (VonMises3D: only plastic / formerly plastic points touch
     eps_n; comfe-rs laws: only tiles with such points are written) must give the same trial state as
     the full out-of-place evaluate at every Newton iteration of every increment, with plastic sets
-    that grow, shrink and move, across pointer-swap commits."""
+    that grow, shrink and move, across pointer-swap commits.  ``split``: the comfe-rs laws with their history kept as
+    [scalar (n), eps_p rows (6 n)] inside the state (FCAMD_EVAL_SPLIT_HISTORY, the default) or as the reference's
+    7-double rows; one host-assembler pass (fcamd_evaluate_resident) in between."""
+    if law_name == "VonMises3D" and not split:
+        pytest.skip("VonMises3D has no 7-double history rows")
     rng = np.random.default_rng(n)
     law, s0, h0, grad = _sparse_case(law_name, n, rng)
-    sp = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=True)
+    sp = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=True, split_history=split)
     fu = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False)
     assert sp._mask is not None and fu._mask is None
+    assert sp._split == (split and law_name != "VonMises3D") and not fu._split
     assert sp._sparse_tangent and not fu._sparse_tangent  # sp also runs the sparse-tangent protocol
     n_plastic = []
+    sh, th = np.empty(6 * n), np.empty(36 * n)
     for inc in range(5):
         for it in range(3):
             g = grad(all_elastic=(inc == 2 and it == 1), zoned=(inc % 2 == 1))
+            if (inc, it) in ((1, 2), (3, 0)):
+                sp.evaluate_into(0.0, 1.0, g.cpu().numpy(), sh, th)
+                fu.evaluate(0.0, 1.0, g)
+                n_plastic.append(int(fu.check().n_plastic))
+                assert np.array_equal(sh, fu.stress.cpu().numpy()) and np.array_equal(th, fu.tangent.cpu().numpy()), (inc, it)
+                assert torch.equal(sp.stress, fu.stress)
+                for k in h0:
+                    assert torch.equal(sp.history[k], fu.history[k]), (inc, it, k)
+                continue
             sp.evaluate(0.0, 1.0, g)
             fu.evaluate(0.0, 1.0, g)
             n_plastic.append(int(fu.check().n_plastic))
