@@ -72,7 +72,7 @@ with open(out, "w") as f:
         f.write("Command (tools/profile_default.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py` "
                 "-- the driver's bench command, no flags: the headline workload and the five other single-GPU configurations.\n\n")
     else:
-        wl = next((workload[: -len(sfx)] for sfx in ("_full", "_delta") if workload.endswith(sfx)), workload)
+        wl = next((workload[: -len(sfx)] for sfx in ("_full", "_delta", "_rows7") if workload.endswith(sfx)), workload)
         f.write("Command (tools/profile_gpu.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
                 f"--steps 10 --warmup 2 --no-cpu-baseline --workload {wl} {extra_args}` and one `--pmc FETCH_SIZE`, one "
                 "`--pmc WRITE_SIZE` pass (`--steps 4 --warmup 2`).\n\n")
