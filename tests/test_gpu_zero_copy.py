@@ -207,12 +207,12 @@ def test_scratch_path_in_chunks():
 
 
 @pytest.mark.parametrize("cname", ["UNIAXIAL_STRESS", "PLANE_STRAIN"])
-def test_zero_copy_low_dimensional_constraints(cname):
+@pytest.mark.parametrize("n", [10_007, 150_001])
+def test_zero_copy_low_dimensional_constraints(cname, n):
     from oracle import numpy_oracle as O
     from wrappers_util import CPARAMS
 
     c = fc.StressStrainConstraint[cname]
-    n = 10_007
     rng = np.random.default_rng(5)
     gdim, sd = O.DIMS[cname]
     g = rng.normal(scale=1e-3, size=gdim * gdim * n)
@@ -229,6 +229,12 @@ def test_zero_copy_low_dimensional_constraints(cname):
     assert rel_err(s2, s_ref) <= 1e-14 and rel_err(t2, t_ref) <= 1e-14
     for k in h2:
         assert rel_err(h2[k], h_ref[k]) <= 1e-14
+    # the same call on pageable arrays (scratch or page-locked for the call, by size): bit-identical
+    s3, t3, h3 = s0.copy(), np.full(sd * sd * n, np.nan), {k: v.copy() for k, v in h0.items()}
+    law.evaluate(0.0, 0.7, g, s3, t3, h3)
+    moved = g.nbytes + s3.nbytes + t3.nbytes + sum(v.nbytes for v in h3.values())
+    assert ctx.last_host_mode() == pageable_mode(moved)
+    assert np.array_equal(s3, s2) and np.array_equal(t3, t2) and all(np.array_equal(h3[k], h2[k]) for k in h2)
 
 
 def test_nonconvergence_is_reported_on_the_zero_copy_path():
