@@ -859,7 +859,7 @@ def main():
 
     # "achievable" next to "peak" (SURVEY 8d): a plain device copy over half of the tangent array
     # (read + write counted)
-    copy_gbs = None
+    copy_gbs = stream_copy_gbs = None
     try:
         half = (wl.tangent.numel() // 2) & ~1
         cs, ce = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -872,6 +872,19 @@ def main():
             ms_ = cs.elapsed_time(ce)
             best = ms_ if best is None else min(best, ms_)
         copy_gbs = 2 * 8 * half / (best * 1e-3) / 1e9
+        # ... and the library's own copy kernel (fcamd_copy_device: the evaluate kernels' access pattern -- 16 B per lane,
+        # non-temporal -- with nothing but the copy): what this box's memory gives a kernel of this kind
+        from fenics_constitutive_amd.hostio import copy_device
+
+        best = None
+        for _ in range(5):
+            cs.record()
+            copy_device(wl.tangent[:half], wl.tangent[half : 2 * half])
+            ce.record()
+            ce.synchronize()
+            ms_ = cs.elapsed_time(ce)
+            best = ms_ if best is None else min(best, ms_)
+        stream_copy_gbs = 2 * 8 * half / (best * 1e-3) / 1e9
     except Exception:  # the probe is informational only
         copy_gbs = None
 
@@ -916,6 +929,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "traffic_GBs": None if traffic is None else round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1),
                          "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
+                         "stream_copy_GBs": None if stream_copy_gbs is None else round(stream_copy_gbs, 1),
+                         "copy_note": "device_copy_GBs: torch's device copy; stream_copy_GBs: fcamd_copy_device (16 B per lane, non-temporal, "
+                                      "the evaluate kernels' access pattern with nothing but the copy) over half of the tangent array, read + "
+                                      "write counted -- the achievable rate of this box next to the 8 TB/s peak (SURVEY 8d); traffic_GBs is the "
+                                      "evaluate kernel's PMC-measured bytes over its time",
                          "bytes_per_point": {"elastic": headline["b_el"], "plastic": headline["b_pl"]},
                          "placement_note": "frac = the timed steps, arrays placed as `placement.mode` says (the product default); "
                                            "frac_first_allocation = hipMalloc candidate 0, what a caller gets who takes the allocator's "

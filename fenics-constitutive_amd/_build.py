@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfcamd.so")
-SOURCES = ["fcamd_kernels.hip", "fcamd_capi.cpp", "fcamd_hostpath.cpp", "fcamd_multigpu.cpp", "fcamd_memory.cpp"]
+SOURCES = ["fcamd_kernels.hip", "fcamd_stream_kernels.hip", "fcamd_capi.cpp", "fcamd_hostpath.cpp", "fcamd_multigpu.cpp", "fcamd_memory.cpp"]
 HEADERS = ["fcamd_internal.h", "fcamd_host.h", os.path.join("..", "..", "include", "fcamd.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: arithmetic order is part of the parity contract (see fcamd_kernels.hip)

@@ -46,7 +46,7 @@ SYMBOLS = [
     "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex",
     "fcamd_commit_delta_history", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
     "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
-    "fcamd_context_last_host_mode", "fcamd_host_device_pointer", "fcamd_copy_to_device", "fcamd_copy_to_host",
+    "fcamd_context_last_host_mode", "fcamd_host_device_pointer", "fcamd_copy_to_device", "fcamd_copy_to_host", "fcamd_copy_device",
     "fcamd_shard_slot_points", "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_alloc", "fcamd_ipc_free",
     "fcamd_ipc_export", "fcamd_ipc_open",
     "fcamd_ipc_close", "fcamd_enable_peer_access", "fcamd_allgather_direct", "fcamd_allgather_direct_wait",
@@ -176,6 +176,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_host_device_pointer.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
         lib.fcamd_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
         lib.fcamd_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
+        lib.fcamd_copy_device.argtypes = [vp, vp, vp, C.c_size_t]
         lib.fcamd_last_error.restype = C.c_char_p
         lib.fcamd_status_string.restype = C.c_char_p
         lib.fcamd_status_string.argtypes = [C.c_int]
@@ -262,6 +263,10 @@ class Context:
         """``fcamd_copy_to_device``: synchronous, ordered after the context stream, never through the HIP
         runtime's pageable-copy path (include/fcamd.h)."""
         check(self._lib.fcamd_copy_to_device(self.handle, C.c_void_p(dst_device_ptr), C.c_void_p(src.ctypes.data), src.nbytes))
+
+    def copy_device(self, dst_device_ptr: int, src_device_ptr: int, nbytes: int) -> None:
+        """``fcamd_copy_device``: asynchronous device-to-device copy on the context stream (non-temporal, 16 B per lane)."""
+        check(self._lib.fcamd_copy_device(self.handle, C.c_void_p(dst_device_ptr), C.c_void_p(src_device_ptr), int(nbytes)))
 
     def copy_to_host(self, dst: "np.ndarray", src_device_ptr: int) -> None:
         check(self._lib.fcamd_copy_to_host(self.handle, C.c_void_p(dst.ctypes.data), C.c_void_p(src_device_ptr), dst.nbytes))

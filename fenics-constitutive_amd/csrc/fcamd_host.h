@@ -150,4 +150,7 @@ int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out);
 // release the chunk buffers and the page-locked scratch of the host entries (fcamd_hostpath.cpp)
 void free_host_staging(fcamd_context* c);
 
+// fcamd_stream_kernels.hip: dst = src over n16 16-byte chunks (non-temporal accesses, grid-stride)
+hipError_t launch_stream_copy(void* dst, const void* src, size_t n16, int grid, hipStream_t stream);
+
 }  // namespace fcamd

@@ -686,6 +686,24 @@ int host_copy(fcamd_context* c, char* dev, char* host, size_t bytes, bool to_dev
 
 extern "C" {
 
+int fcamd_copy_device(fcamd_context* c, void* dst_device, const void* src_device, size_t bytes) {
+    if (!c || (bytes && (!dst_device || !src_device))) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    if (bytes == 0) return FCAMD_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!aligned16(dst_device) || !aligned16(src_device))
+        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
+    const size_t n16 = bytes / 16;
+    // 16 KiB per workgroup and pass.  tools/stream_copy_probe.py, 8 GiB buffers, three buffer pairs: 5.0 - 5.6 TB/s with 1024
+    // workgroups, 5.5 - 5.9 with 8192, 5.8 - 6.0 with 262144 (torch's copy: 4.7 - 5.0): many short workgroups
+    const size_t tiles = (n16 + 1023) / 1024;
+    const int grid = c->grid_override > 0 ? c->grid_override : (int)std::min<size_t>(tiles, (size_t)c->num_cu * 1024);
+    if (n16) HIP_TRY(launch_stream_copy(dst_device, src_device, n16, std::max(grid, 1), c->stream));
+    if (bytes % 16)
+        HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst_device) + 16 * n16, static_cast<const char*>(src_device) + 16 * n16, bytes % 16,
+                               hipMemcpyDeviceToDevice, c->stream));
+    return FCAMD_OK;
+}
+
 int fcamd_copy_to_device(fcamd_context* c, void* dst_device, const void* src_host, size_t bytes) {
     return host_copy(c, static_cast<char*>(dst_device), static_cast<char*>(const_cast<void*>(src_host)), bytes, true);
 }

@@ -71,3 +71,16 @@ def assign(dst: np.ndarray, src) -> None:
         download(dst, src)
     else:
         dst[...] = to_host(src).reshape(dst.shape)
+
+
+def copy_device(dst, src) -> None:
+    """``dst`` <- ``src``, both contiguous device tensors of equal byte size (``fcamd_copy_device``: the access pattern of
+    the evaluate kernels; asynchronous on torch's current stream)."""
+    assert dst.is_cuda and src.is_cuda and dst.is_contiguous() and src.is_contiguous()
+    nbytes = dst.numel() * dst.element_size()
+    assert nbytes == src.numel() * src.element_size(), "copy_device: sizes differ"
+    if nbytes:
+        if dst.data_ptr() % 16 or src.data_ptr() % 16:
+            dst.copy_(src)
+        else:
+            _ctx(dst.device).copy_device(dst.data_ptr(), src.data_ptr(), nbytes)

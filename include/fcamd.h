@@ -375,6 +375,11 @@ int fcamd_host_device_pointer(fcamd_context* ctx, const void* host_ptr, size_t b
    device-resident state, one of these. */
 int fcamd_copy_to_device(fcamd_context* ctx, void* dst_device, const void* src_host, size_t bytes);
 int fcamd_copy_to_host(fcamd_context* ctx, void* dst_host, const void* src_device, size_t bytes);
+/* Device-to-device copy on the context stream (asynchronous) with the access pattern of the evaluate kernels: 16 bytes
+   per lane, non-temporal loads and stores, one contiguous KiB per wave instruction.  What a device-resident state uses
+   for "trial = committed" (solver/_history.py:64-79 on NumPy arrays) and what bench.py reports as the achievable copy
+   rate of the box next to the 8 TB/s peak.  Both pointers 16-byte aligned. */
+int fcamd_copy_device(fcamd_context* ctx, void* dst_device, const void* src_device, size_t bytes);
 
 /* ---- multi-GPU: contiguous shards + all-gather ------------------------ */
 /* The quadrature-point axis [0, n) is cut into `world` contiguous slices that start on 64-point

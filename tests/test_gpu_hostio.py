@@ -133,3 +133,22 @@ def test_resident_state_uploads_are_synchronous():
     torch.cuda.synchronize()
     assert torch.equal(a.stress, b.stress) and torch.equal(a.tangent, b.tangent)
     assert torch.equal(pa.stress_1, pb.stress_1) and torch.equal(pa.tangent, pb.tangent)
+
+
+@pytest.mark.parametrize("numel", [1, 2, 1023, 1024 * 1024 + 3, 20_000_001])
+def test_device_copy_kernel(numel):
+    """fcamd_copy_device (the evaluate kernels' access pattern with nothing but the copy): every byte, ragged tails, a
+    destination that is not 16-byte aligned (falls back to torch's copy), nothing outside the range."""
+    src = torch.arange(numel + 4, dtype=torch.float64, device="cuda")
+    dst = torch.full((numel + 4,), -1.0, dtype=torch.float64, device="cuda")
+    hostio.copy_device(dst[2 : 2 + numel], src[2 : 2 + numel])     # both 16-byte aligned (offset 16 bytes)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[2 : 2 + numel], src[2 : 2 + numel])
+    assert (dst[:2] == -1.0).all() and (dst[2 + numel :] == -1.0).all()
+    dst.fill_(-1.0)
+    hostio.copy_device(dst[1 : 1 + numel], src[2 : 2 + numel])     # destination 8 bytes off the grid
+    torch.cuda.synchronize()
+    assert torch.equal(dst[1 : 1 + numel], src[2 : 2 + numel]) and dst[0] == -1.0 and (dst[1 + numel :] == -1.0).all()
+    ctx = _capi.get_context(_capi.default_device())
+    with pytest.raises(ValueError):
+        ctx.copy_device(dst.data_ptr() + 8, src.data_ptr(), 64)
