@@ -346,8 +346,10 @@ int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
    solver/_lawonsubmesh.py:87-94): page-lock and map them once.  fcamd_evaluate_host /
    fcamd_evaluate_resident then run their kernels directly on them (zero copy; any sub-range of
    a registered range qualifies), and the staged path DMAs without the runtime's bounce
-   buffers.  The caller must unregister a buffer BEFORE freeing it: a registration that
-   outlives its memory makes later accesses at the same address go through stale pages. */
+   buffers.  The caller must unregister a buffer BEFORE freeing it: on this stack a page lock is an
+   attribute of the pages, new memory that appears at the address of a freed, still-registered buffer
+   does not carry it, and a launch on it ends in a GPU memory fault.  Registering is an optimisation
+   only: arrays that are not registered are page-locked for the duration of each call. */
 int fcamd_register_host_buffer(fcamd_context* ctx, void* ptr, size_t bytes);
 int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
 /* Data path the last fcamd_evaluate_host / fcamd_evaluate_resident call of this context took:
