@@ -680,6 +680,19 @@ def library_hash(kernels_only=False):
         return None
 
 
+def read_traffic_split(workload_key, n):
+    """(read bytes, written bytes) per launch of the same PMC measurement, or None"""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(tf) as f:
+            e = json.load(f).get(workload_key)
+        if e and int(e.get("n", 0)) == n and e.get("kernel_hash") and e.get("kernel_hash") == library_hash(kernels_only=True):
+            return int(e["read_bytes"]), int(e["write_bytes"])
+    except Exception:
+        pass
+    return None
+
+
 def read_traffic(workload_key, n):
     """PMC-measured HBM bytes per launch (profiles/traffic.json, written by tools/summarize_profile.py) --
     only if they were measured with THIS build of the kernels (same hash of the device sources) at this size; a
@@ -859,7 +872,7 @@ def main():
 
     # "achievable" next to "peak" (SURVEY 8d): a plain device copy over half of the tangent array
     # (read + write counted)
-    copy_gbs = stream_copy_gbs = None
+    copy_gbs = stream_copy_gbs = fill_gbs = read_gbs = None
     try:
         half = (wl.tangent.numel() // 2) & ~1
         cs, ce = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -885,6 +898,20 @@ def main():
             ms_ = cs.elapsed_time(ce)
             best = ms_ if best is None else min(best, ms_)
         stream_copy_gbs = 2 * 8 * half / (best * 1e-3) / 1e9
+        # ... and the two directions on their own: a pure write (fill) and a pure read (sum) of the same memory
+        rates = {}
+        for key, fn in (("fill", lambda: wl.tangent[:half].fill_(1.0)), ("read", lambda: wl.tangent[half : 2 * half].sum())):
+            fn()
+            best = None
+            for _ in range(4):
+                cs.record()
+                fn()
+                ce.record()
+                ce.synchronize()
+                ms_ = cs.elapsed_time(ce)
+                best = ms_ if best is None else min(best, ms_)
+            rates[key] = 8 * half / (best * 1e-3) / 1e9
+        fill_gbs, read_gbs = rates["fill"], rates["read"]
     except Exception:  # the probe is informational only
         copy_gbs = None
 
@@ -904,7 +931,17 @@ def main():
         value = total_pts / elapsed / 1e6
         alg_bytes = headline["alg"]
         achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9
-        traffic = read_traffic(name + ("_full" if headline["plasticity"] and not headline["sparse"] else "") + ("_delta" if wl.delta else ""), n)
+        tkey = name + ("_full" if headline["plasticity"] and not headline["sparse"] else "") + ("_delta" if wl.delta else "")
+        traffic = read_traffic(tkey, n)
+        # what this box's memory allows for THIS kernel's measured mix of reads and writes: read bytes at the pure-read rate
+        # plus written bytes at the pure-write rate, both measured above on the same array
+        streaming_model = None
+        split = read_traffic_split(tkey, n)
+        if split and fill_gbs and read_gbs:
+            model_ms = (split[0] / read_gbs + split[1] / fill_gbs) / 1e6
+            streaming_model = {"ms": round(model_ms, 3), "kernel_over_model": round(kernel_avg_ms / model_ms, 3),
+                               "note": "PMC read bytes / read_GBs + PMC written bytes / fill_GBs: the time a kernel would need that streamed "
+                                       "the same bytes at this box's pure-read and pure-write rates"}
         out = {
             "metric": METRIC,
             "value": round(value, 1),
@@ -930,7 +967,10 @@ def main():
                          "traffic_GBs": None if traffic is None else round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1),
                          "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
                          "stream_copy_GBs": None if stream_copy_gbs is None else round(stream_copy_gbs, 1),
-                         "copy_note": "device_copy_GBs: torch's device copy; stream_copy_GBs: fcamd_copy_device (16 B per lane, non-temporal, "
+                         "fill_GBs": None if fill_gbs is None else round(fill_gbs, 1),
+                         "read_GBs": None if read_gbs is None else round(read_gbs, 1),
+                         "streaming_model": streaming_model,
+                         "copy_note": "device_copy_GBs: torch's device copy; fill_GBs / read_GBs: torch fill_ / sum over one half of the tangent array; stream_copy_GBs: fcamd_copy_device (16 B per lane, non-temporal, "
                                       "the evaluate kernels' access pattern with nothing but the copy) over half of the tangent array, read + "
                                       "write counted -- the achievable rate of this box next to the 8 TB/s peak (SURVEY 8d); traffic_GBs is the "
                                       "evaluate kernel's PMC-measured bytes over its time",
@@ -1012,6 +1052,12 @@ def main():
             except Exception as e:  # one configuration failing must not lose the line
                 configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
+            # the same streaming model as for the headline, with the rates measured on this box
+            split = read_traffic_split(cname, n)
+            if split and fill_gbs and read_gbs and "kernel_ms_avg" in configs[cname]:
+                model_ms = (split[0] / read_gbs + split[1] / fill_gbs) / 1e6
+                configs[cname]["streaming_model"] = {"ms": round(model_ms, 3),
+                                                     "kernel_over_model": round(configs[cname]["kernel_ms_avg"] / model_ms, 3)}
         out["configs"] = configs
 
     if rank == 0:
