@@ -940,8 +940,9 @@ def main():
         if split and fill_gbs and read_gbs:
             model_ms = (split[0] / read_gbs + split[1] / fill_gbs) / 1e6
             streaming_model = {"ms": round(model_ms, 3), "kernel_over_model": round(kernel_avg_ms / model_ms, 3),
-                               "note": "PMC read bytes / read_GBs + PMC written bytes / fill_GBs: the time a kernel would need that streamed "
-                                       "the same bytes at this box's pure-read and pure-write rates"}
+                               "note": "PMC read bytes / read_GBs + PMC written bytes / fill_GBs: the time it takes to stream the kernel's bytes at "
+                                       "the rates torch's fill_ and sum reach on the same (placed) tangent array of this box; "
+                                       "kernel_over_model < 1: the evaluate kernel moves its bytes faster than that"}
         out = {
             "metric": METRIC,
             "value": round(value, 1),
