@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Soak run of the randomised protocol tests with seeds beyond the three the suite runs:
-   python tools/fuzz_soak.py [first seed] [last seed]      (one process; prints one line per failure)"""
+   python tests/fuzz_soak.py [first seed] [last seed]      (one process; prints one line per failure)"""
 import os
 import sys
 import traceback
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")  # as tests/conftest.py
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]  # lives under tests/: the test modules it runs import the oracle
 import test_gpu_problem_fuzz as PF  # noqa: E402
 import test_gpu_resident_fuzz as RF  # noqa: E402
 
