@@ -240,3 +240,47 @@ def test_resident_protocols_1e8():
             sp.update()
             fu.update()
     assert fractions[1] < fractions[0] < fractions[2] and fractions[0] > 0.1
+
+
+def test_split_history_1e8():
+    """comfe-rs MisesPlasticity3D at full size: the state that keeps the history as [alpha (n), eps_p rows (6 n)]
+    (FCAMD_EVAL_SPLIT_HISTORY, sparse protocol, sparse tangent) against the state that rewrites the reference's 7-double
+    rows in full, over three Newton iterates with moving plastic zones and a commit (equality of the two states)."""
+    from fenics_constitutive_amd.resident import ResidentState
+
+    need_memory(150)
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    f = dict(dtype=torch.float64, device="cuda")
+    g = torch.randn(9 * N, generator=gen, **f)
+    zone = 4096  # plastic zones in point order, as a mesh has them
+    sc = torch.where(torch.rand((N + zone - 1) // zone, generator=gen, **f) < 0.25, 1e-2, 1e-4).repeat_interleave(zone)[:N]
+    g.view(N, 9).mul_(sc[:, None])
+    del sc
+    h0 = torch.zeros(7 * N, **f)
+    h0.view(N, 7)[:, 0] = torch.rand(N, generator=gen, **f) * 0.02
+    law = fc.MisesPlasticityLinearHardening3D({k: np.array([v]) for k, v in
+                                               {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0}.items()})
+    sp = ResidentState(law, N, history0={"history": h0}, placement="torch")
+    fu = ResidentState(law, N, history0={"history": h0}, sparse_history=False, sparse_tangent=False, placement="torch")
+    del h0
+    assert sp._split and sp._mask is not None and not fu._split
+    fractions = []
+    for k, scale in enumerate((1.0, 0.4, 1.5)):
+        gk = g if scale == 1.0 else g * scale
+        sp.evaluate(0.0, 1.0, gk)
+        fu.evaluate(0.0, 1.0, gk)
+        fractions.append(fu.check().n_plastic / N)
+        sp.check()
+        assert torch.equal(sp.stress, fu.stress), k
+        assert torch.equal(sp.tangent, fu.tangent), k
+        # the reference's rows, assembled from the split layout (a 5.6 GB temporary: compare and drop)
+        a, b = sp.history["history"], fu.history["history"]
+        assert torch.equal(a, b), k
+        del a, b, gk
+        if k == 1:
+            sp.update()
+            fu.update()
+            a, b = sp.history_committed["history"], fu.history_committed["history"]
+            assert torch.equal(a, b)
+            del a, b
+    assert 0.05 < fractions[0] < 0.5 and fractions[2] >= fractions[0]
