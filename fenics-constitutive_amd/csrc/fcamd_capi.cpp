@@ -418,19 +418,26 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
 }  // namespace fcamd
 
 namespace fcamd {
-int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
-    HIP_TRY(hipMemcpyAsync(m->h_counters, m->d_counters, kCounterBytes,
-                           hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (out) {
-        out->n_nonconverged = out->n_plastic = out->n_newton_iters = out->n_domain = 0;
-        for (int s = 0; s < fcamd::kCounterSlots; ++s) {
-            out->n_nonconverged += m->h_counters[4 * s + 0];
-            out->n_plastic += m->h_counters[4 * s + 1];
-            out->n_newton_iters += m->h_counters[4 * s + 2];
-            out->n_domain += m->h_counters[4 * s + 3];
-        }
+void sum_counters(const fcamd_model* m, fcamd_stats* out) {
+    out->n_nonconverged = out->n_plastic = out->n_newton_iters = out->n_domain = 0;
+    for (int s = 0; s < fcamd::kCounterSlots; ++s) {
+        out->n_nonconverged += m->h_counters[4 * s + 0];
+        out->n_plastic += m->h_counters[4 * s + 1];
+        out->n_newton_iters += m->h_counters[4 * s + 2];
+        out->n_domain += m->h_counters[4 * s + 3];
     }
+}
+
+int enqueue_counters_download(fcamd_model* m, hipStream_t stream) {
+    HIP_TRY(hipMemcpyAsync(m->h_counters, m->d_counters, kCounterBytes, hipMemcpyDeviceToHost, stream));
+    return FCAMD_OK;
+}
+
+int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
+    int st = enqueue_counters_download(m, stream);
+    if (st != FCAMD_OK) return st;
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (out) sum_counters(m, out);
     return FCAMD_OK;
 }
 }  // namespace fcamd

@@ -144,8 +144,11 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
             const int* rows = nullptr, unsigned long long* hmask = nullptr, int flags = 0, double* stress2 = nullptr,
             unsigned long long* counters = nullptr);
 
-// download and sum the model's counters (synchronises `stream`)
+// download and sum the model's counters (synchronises `stream`); the two halves for callers that have a
+// synchronisation of their own coming: enqueue the 2 KB download behind the launches, sum after the wait
 int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out);
+int enqueue_counters_download(fcamd_model* m, hipStream_t stream);
+void sum_counters(const fcamd_model* m, fcamd_stats* out);
 
 // release the chunk buffers and the page-locked scratch of the host entries (fcamd_hostpath.cpp)
 void free_host_staging(fcamd_context* c);

@@ -61,14 +61,24 @@ int prepare_chunks(fcamd_context* c, const void* probe_host_ptr, int64_t n, int6
     return FCAMD_OK;
 }
 
-// wait for all chunk streams, read the counters, map them to the reference's error conventions
-int finish_chunks(fcamd_model* m, fcamd_stats* stats) {
+// wait for all chunk streams, read the counters, map them to the reference's error conventions.
+// `downloaded`: every launch of the call went to hstream[0] and the download of the counters is already queued
+// behind them (one wait instead of two -- 10 us of a 60 us call at 1e3 points).  Laws that count nothing (linear
+// elasticity, SLS) skip the download altogether.
+int finish_chunks(fcamd_model* m, fcamd_stats* stats, bool downloaded = false) {
     fcamd_context* c = m->ctx;
     for (int i = 0; i < fcamd_context::kSlots; ++i)
         if (c->hstream[i]) HIP_TRY(hipStreamSynchronize(c->hstream[i]));
     fcamd_stats local;
-    int st = read_stats(m, c->hstream[0], &local);
-    if (st != FCAMD_OK) return st;
+    std::memset(&local, 0, sizeof(local));
+    if (has_sparse_history(m->law)) {  // = the laws with a plastic branch: the only ones that count
+        if (downloaded) {
+            sum_counters(m, &local);
+        } else {
+            int st = read_stats(m, c->hstream[0], &local);
+            if (st != FCAMD_OK) return st;
+        }
+    }
     if (stats) *stats = local;
     if (local.n_domain > 0)
         return fail(FCAMD_ERR_DOMAIN, "non-differentiable tip of Drucker-Prager surface reached");
@@ -77,6 +87,15 @@ int finish_chunks(fcamd_model* m, fcamd_stats* stats) {
                     m->law >= FCAMD_COMFE_DRUCKER_PRAGER ? "Plasticity3D: Newton-Raphson did not converge."
                                                          : "Newton-Raphson method did not converge for plastic multiplier.");
     return FCAMD_OK;
+}
+
+// single-stream paths: queue the counters' download behind the launches on hstream[0], then finish
+int finish_single_stream(fcamd_model* m, fcamd_stats* stats) {
+    if (has_sparse_history(m->law)) {
+        int st = enqueue_counters_download(m, m->ctx->hstream[0]);
+        if (st != FCAMD_OK) return st;
+    }
+    return finish_chunks(m, stats, /*downloaded=*/true);
 }
 
 }  // namespace
@@ -369,8 +388,8 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     c->last_host_mode = 0;
     if (!c->hstream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
     if (n == 0) {
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
-        return finish_chunks(m, stats);
+        if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
+        return finish_single_stream(m, stats);
     }
     const size_t N = (size_t)n;
     size_t hist_doubles = 0;
@@ -406,7 +425,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
         st = ensure_bounce(c, lay.used);
         if (st != FCAMD_OK) return st;
         hipStream_t s = c->hstream[0];
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
+        if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         for (int64_t p0 = 0; p0 < n; p0 += chunk) {
             const size_t np = (size_t)std::min<int64_t>(chunk, n - p0);
             std::memcpy(c->bounce + o_grad, grad + GD2 * p0, np * GD2 * sizeof(double));
@@ -421,6 +440,8 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
             st = enqueue(m, del_t, (int64_t)np, reinterpret_cast<const double*>(c->bounce_dev + o_grad), d_stress, d_stress,
                          tangent ? reinterpret_cast<double*>(c->bounce_dev + o_tan) : nullptr, d_hist, d_hist, s, false);
             if (st != FCAMD_OK) return drain_and_return(c, st);
+            if (p0 + chunk >= n && has_sparse_history(m->law))  // last chunk: the counters ride on the same wait
+                HIP_TRY_DRAIN(c, hipMemcpyAsync(m->h_counters, m->d_counters, kCounterBytes, hipMemcpyDeviceToHost, s));
             HIP_TRY_DRAIN(c, hipStreamSynchronize(s));
             std::memcpy(stress + SD * p0, c->bounce + o_stress, np * SD * sizeof(double));
             if (tangent) std::memcpy(tangent + TD * p0, c->bounce + o_tan, np * TD * sizeof(double));
@@ -429,7 +450,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
                 std::memcpy(hist[k] + d * p0, c->bounce + o_hist[k], np * d * sizeof(double));
             }
         }
-        return finish_chunks(m, stats);
+        return finish_chunks(m, stats, /*downloaded=*/true);
     }
 
     if (arrays.temp_locked()) c->last_host_mode |= FCAMD_HOST_TEMP_LOCK;
@@ -442,12 +463,12 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     if (zero_copy_enabled(c) && aligned) {
         c->last_host_mode |= FCAMD_HOST_ZERO_COPY_IN | FCAMD_HOST_ZERO_COPY_OUT;
         hipStream_t s = c->hstream[0];
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
+        if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         double* zh[FCAMD_MAX_HISTORY] = {reinterpret_cast<double*>(z_hist[0]), reinterpret_cast<double*>(z_hist[1])};
         double* zs = reinterpret_cast<double*>(z_stress);
         st = enqueue(m, del_t, n, reinterpret_cast<const double*>(z_grad), zs, zs, reinterpret_cast<double*>(z_tan), zh, zh, s, false);
         if (st != FCAMD_OK) return drain_and_return(c, st);
-        return finish_chunks(m, stats);
+        return finish_single_stream(m, stats);
     }
 
     // chunked DMA pipeline between the page-locked caller arrays and device buffers
@@ -525,8 +546,8 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     c->last_host_mode = 0;
     if (!c->hstream[0]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[0], hipStreamNonBlocking));
     if (n == 0) {
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
-        return finish_chunks(m, stats);
+        if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, c->hstream[0]));
+        return finish_single_stream(m, stats);
     }
     const size_t N = (size_t)n;
     const size_t bytes_per_point = (GD2 + (stress_host ? SD : 0) + (tangent_host ? TD : 0)) * sizeof(double);
@@ -574,11 +595,13 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
             if (st != FCAMD_OK) return drain_and_return(c, st);
             if (stress_host && !second_store)
                 HIP_TRY_DRAIN(c, hipMemcpyAsync(c->bounce + o_stress, stress + SD * p0, np * SD * sizeof(double), hipMemcpyDeviceToHost, s));
+            if (p0 + chunk >= n && has_sparse_history(m->law))  // last chunk: the counters ride on the same wait
+                HIP_TRY_DRAIN(c, hipMemcpyAsync(m->h_counters, m->d_counters, kCounterBytes, hipMemcpyDeviceToHost, s));
             HIP_TRY_DRAIN(c, hipStreamSynchronize(s));
             if (stress_host) std::memcpy(stress_host + SD * p0, c->bounce + o_stress, np * SD * sizeof(double));
             if (tangent_host) std::memcpy(tangent_host + TD * p0, c->bounce + o_tan, np * TD * sizeof(double));
         }
-        return finish_chunks(m, stats);
+        return finish_chunks(m, stats, /*downloaded=*/true);
     }
     if (arrays.temp_locked()) c->last_host_mode |= FCAMD_HOST_TEMP_LOCK;
     const bool zc = zero_copy_enabled(c);
@@ -591,11 +614,11 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     double* z_stress = (zc && stress_host && m->dims.gdim == 3 && aligned16(l_stress)) ? reinterpret_cast<double*>(l_stress) : nullptr;
     if (z_grad && (z_tan || !tangent_host) && (z_stress || !stress_host) && m->dims.gdim == 3) {
         hipStream_t s = c->hstream[0];
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
+        if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         st = enqueue(m, del_t, n, z_grad, stress_prev, stress, z_tan, hist_prev, hist, s, false, nullptr,
                      reinterpret_cast<unsigned long long*>(history_mask), flags, z_stress);
         if (st != FCAMD_OK) return drain_and_return(c, st);
-        return finish_chunks(m, stats);
+        return finish_single_stream(m, stats);
     }
     int64_t chunk = 0;
     st = prepare_chunks(c, grad, n, &chunk, /*staging=*/!(z_grad && (z_tan || !tangent_host)), /*locked=*/true);
