@@ -313,3 +313,32 @@ def test_sparse_tangent_into_page_locked_host_array(law_name):
                 sp.update()
                 fu.update()
     assert 0 < law.last_stats.n_plastic < n
+
+
+@pytest.mark.parametrize("kind", ["von_mises_3d", "spring_maxwell"])
+def test_resident_scratch_path_in_chunks(kind):
+    """fcamd_evaluate_resident with host arrays that cannot be page-locked (the tangent array lies half inside a
+    registered range) and do not fit one pass through the scratch: several chunks, the sparse-history mask words and the
+    state rows of every chunk at the right offsets -- same numbers as the one-launch pass on pageable arrays."""
+    n = 200_003
+    p, g, s, h = random_case(kind, n, seed=17)
+    law = make_law(kind, p)
+    a = ResidentState(law, n, stress0=s, history0=h)
+    b = ResidentState(law, n, stress0=s, history0=h)
+    ctx = law._handle(_capi.default_device()).ctx
+    sa, ta = np.zeros(6 * n), own(np.full(36 * n, np.nan))
+    sb, tb = np.zeros(6 * n), np.full(36 * n, np.nan)
+    with Pinned(law, [ta[: 18 * n]]):
+        for it, scale in enumerate((1.0, 0.3, 1.5)):
+            gi = g * scale
+            a.evaluate_into(0.0, 1.0, gi, sa, ta)
+            if kind == "von_mises_3d" or it == 0:  # SLS: the constant tangent is written once, later calls do not pass the array
+                assert ctx.last_host_mode() == BOUNCE
+            b.evaluate_into(0.0, 1.0, gi, sb, tb)
+            assert ctx.last_host_mode() & TEMP
+            assert np.array_equal(sa, sb) and np.array_equal(ta, tb), it
+            assert torch.equal(a.stress, b.stress)
+            for k in (h or {}):
+                assert torch.equal(a.history[k], b.history[k]), (it, k)
+            if it == 1:
+                a.update(), b.update()
