@@ -342,3 +342,32 @@ def test_resident_scratch_path_in_chunks(kind):
                 assert torch.equal(a.history[k], b.history[k]), (it, k)
             if it == 1:
                 a.update(), b.update()
+
+
+@pytest.mark.parametrize("kind", ["von_mises_3d", "linear_elasticity"])
+def test_resident_chunked_dma_pipeline(kind):
+    """Option "zero_copy" = 0: fcamd_evaluate_resident page-locks the pageable host arrays and moves them chunk by chunk
+    by DMA through the four slots (here 13 chunks of 16 384 points) -- same numbers as the one-launch pass."""
+    n = 200_003
+    p, g, s, h = random_case(kind, n, seed=29)
+    law = make_law(kind, p)
+    a = ResidentState(law, n, stress0=s, history0=h)
+    b = ResidentState(law, n, stress0=s, history0=h)
+    ctx = law._handle(_capi.default_device()).ctx
+    sa, ta, sb, tb = np.zeros(6 * n), np.full(36 * n, np.nan), np.zeros(6 * n), np.full(36 * n, np.nan)
+    for it, scale in enumerate((1.0, 0.4)):
+        gi = g * scale
+        ctx.set_option("zero_copy", 0), ctx.set_option("host_chunk", 16384)
+        try:
+            a.evaluate_into(0.0, 1.0, gi, sa, ta)
+            assert ctx.last_host_mode() == TEMP
+        finally:
+            ctx.set_option("zero_copy", 1), ctx.set_option("host_chunk", 0)
+        b.evaluate_into(0.0, 1.0, gi, sb, tb)
+        # (linear elasticity: the constant tangent is written by the first call only, later ones do not pass the array)
+        assert ctx.last_host_mode() == ((ZC | TEMP) if kind == "von_mises_3d" or it == 0 else (_capi.HOST_ZERO_COPY_IN | TEMP))
+        assert np.array_equal(sa, sb), it
+        if kind == "von_mises_3d" or it == 0:
+            assert np.array_equal(ta, tb), it
+        assert torch.equal(a.stress, b.stress)
+        a.update(), b.update()
