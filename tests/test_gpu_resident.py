@@ -148,30 +148,41 @@ def test_sparse_history_equals_full_history(n, law_name, split):
     assert max(n_plastic) > 0.1 * n and min(n_plastic) < 0.5 * max(n_plastic)  # the sets really changed
 
 
-@pytest.mark.parametrize("chunk", [None, "128"])
-def test_evaluate_into_replays_golden_sequence(chunk, monkeypatch):
-    """fcamd_evaluate_resident: NumPy grad in, NumPy stress/tangent out, state on the device;
-    with a 128-point chunk the 1000+ points go through many chunks and all four slots."""
+@pytest.mark.parametrize("path", ["scratch", "lock", "chunks"])
+def test_evaluate_into_replays_golden_sequence(path):
+    """fcamd_evaluate_resident: NumPy grad in, NumPy stress/tangent out, state on the device, on each data path of the
+    pageable host arrays: through the page-locked scratch (the default at this size), page-locked for the call with one
+    launch on them ("bounce_max" = 0), and page-locked with the chunked DMA pipeline ("zero_copy" = 0, 128-point chunks:
+    the 1000+ points go through many chunks and all four slots)."""
     from fenics_constitutive_amd import _capi
 
     ctx = _capi.get_context(_capi.default_device())
-    ctx.set_option("host_chunk", int(chunk or 0))  # the FCAMD_HOST_CHUNK default is read once, at context creation
-    calls = {c.name: c for c in load_calls("von_mises_3d.npz")}
-    c0 = calls["mixed_step0_iter0"]
-    law = fc.VonMises3D(c0.params)
-    st = ResidentState(law, c0.n, stress0=c0.stress_in, history0=c0.hist_in)
-    s, t = np.empty(6 * c0.n), np.empty(36 * c0.n)
-    for k in range(4):
-        for it in (0, 1):
-            c = calls[f"mixed_step{k}_iter{it}"]
-            stats = st.evaluate_into(0.0, c.del_t, c.grad, s, t)
-            assert rel_err(s, c.stress_out) <= 1e-11 and rel_err(t, c.tangent_out) <= 1e-6
-            for key in c.hist_out:
-                assert rel_err(st.history[key].cpu().numpy(), c.hist_out[key]) <= 1e-6
-            assert np.array_equal(st.stress_committed.cpu().numpy(), c.stress_in)
-            assert stats.n_plastic > 0
-        st.update()
-    ctx.set_option("host_chunk", 0)
+    options = {"scratch": {}, "lock": {"bounce_max": 0}, "chunks": {"bounce_max": 0, "zero_copy": 0, "host_chunk": 128}}[path]
+    saved = {k: ctx.get_option(k) for k in options}
+    for k, v in options.items():
+        ctx.set_option(k, v)
+    try:
+        calls = {c.name: c for c in load_calls("von_mises_3d.npz")}
+        c0 = calls["mixed_step0_iter0"]
+        law = fc.VonMises3D(c0.params)
+        st = ResidentState(law, c0.n, stress0=c0.stress_in, history0=c0.hist_in)
+        s, t = np.empty(6 * c0.n), np.empty(36 * c0.n)
+        expected = {"scratch": _capi.HOST_BOUNCE, "lock": _capi.HOST_TEMP_LOCK | _capi.HOST_ZERO_COPY_IN | _capi.HOST_ZERO_COPY_OUT,
+                    "chunks": _capi.HOST_TEMP_LOCK}[path]
+        for k in range(4):
+            for it in (0, 1):
+                c = calls[f"mixed_step{k}_iter{it}"]
+                stats = st.evaluate_into(0.0, c.del_t, c.grad, s, t)
+                assert ctx.last_host_mode() == expected
+                assert rel_err(s, c.stress_out) <= 1e-11 and rel_err(t, c.tangent_out) <= 1e-6
+                for key in c.hist_out:
+                    assert rel_err(st.history[key].cpu().numpy(), c.hist_out[key]) <= 1e-6
+                assert np.array_equal(st.stress_committed.cpu().numpy(), c.stress_in)
+                assert stats.n_plastic > 0
+            st.update()
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
     assert st._grad is None and st._tangent is None  # no n-sized gradient / tangent on the device
 
 
