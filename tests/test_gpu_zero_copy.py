@@ -171,12 +171,14 @@ def test_fallbacks_to_the_scratch_path():
         compare((s2, t2, h2), ref, STRICT["sls"], "temporarily locked")
         # ... or, with zero copy switched off, DMA between them and the device chunk buffers
         ctx.set_option("zero_copy", 0)
-        g2, s2, t2, h2 = fresh()
-        law.evaluate(0.0, 0.5, g2, s2, t2, h2)
-        assert ctx.last_host_mode() == TEMP
-        compare((s2, t2, h2), ref, STRICT["sls"], "temporarily locked, chunked DMA")
+        for chunk in (0, 256):  # one chunk; eight chunks over the four slots
+            ctx.set_option("host_chunk", chunk)
+            g2, s2, t2, h2 = fresh()
+            law.evaluate(0.0, 0.5, g2, s2, t2, h2)
+            assert ctx.last_host_mode() == TEMP
+            compare((s2, t2, h2), ref, STRICT["sls"], f"temporarily locked, chunked DMA ({chunk})")
     finally:
-        ctx.set_option("bounce_max", BOUNCE_MAX), ctx.set_option("zero_copy", 1)
+        ctx.set_option("bounce_max", BOUNCE_MAX), ctx.set_option("zero_copy", 1), ctx.set_option("host_chunk", 0)
     # (4) after unregistering everything the same arrays are pageable again
     g2, s2, t2, h2 = fresh()
     with Pinned(law, [g2, s2, t2] + list(h2.values())):
