@@ -19,16 +19,42 @@ def own(k):
     return np.frombuffer(mmap.mmap(-1, max(8 * k, 8)), dtype=np.float64, count=k)
 
 
+def drucker_prager_case(kind, n, seed):
+    """(law, base gradient, stress0, history0) in the regime in which the reference's Newton iteration converges for every
+    scale the sequences apply (<= 1.9 x the base): compressive prestress, mostly isochoric increments up to 3e-3."""
+    import fenics_constitutive_amd as fc
+
+    rng = np.random.default_rng(seed)
+    p = {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02}
+    cls = fc.DruckerPrager3D
+    if kind.endswith("hyperbolic"):
+        p = {"mu": p["mu"], "kappa": p["kappa"], "a": p["a"], "b": p["b"], "d": 40.0, "b_flow": p["b_flow"]}
+        cls = fc.DruckerPragerHyperbolic3D
+    law = cls({k: np.array([v]) for k, v in p.items()})
+    g = (rng.normal(size=9 * n) * np.repeat(10 ** rng.uniform(-5.0, -2.52, size=n), 9)).reshape(-1, 9)
+    g[:, [0, 4, 8]] -= (0.95 * g[:, [0, 4, 8]].sum(axis=1) / 3.0)[:, None]
+    s = rng.normal(scale=30.0, size=6 * n)
+    s.reshape(-1, 6)[:, :3] -= 1000.0
+    h = rng.normal(scale=1e-3, size=7 * n)
+    h.reshape(-1, 7)[:, 0] = 0.0
+    return law, g.reshape(-1).copy(), s, {"history": h}
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
-@pytest.mark.parametrize("kind", ["von_mises_3d", "von_mises_3d+delta_history", "comfe_mises_plasticity", "linear_elasticity",
-                                  "spring_maxwell"])
+@pytest.mark.parametrize("kind", ["von_mises_3d", "von_mises_3d+delta_history", "comfe_mises_plasticity",
+                                  "comfe_mises_plasticity+rows7", "drucker_prager", "drucker_prager_hyperbolic",
+                                  "linear_elasticity", "spring_maxwell"])
 def test_random_call_sequences(kind, seed):
     n = 64 * 90 + 17
     kind, _, option = kind.partition("+")
-    p, g0, s, h = random_case(kind, n, seed=seed)
-    law = make_law(kind, p)
-    opt = ResidentState(law, n, stress0=s, history0=h, delta_history=option == "delta_history")
+    if kind.startswith("drucker_prager"):
+        law, g0, s, h = drucker_prager_case(kind, n, seed)
+    else:
+        p, g0, s, h = random_case(kind, n, seed=seed)
+        law = make_law(kind, p)
+    opt = ResidentState(law, n, stress0=s, history0=h, delta_history=option == "delta_history", split_history=option != "rows7")
     assert opt._delta == (option == "delta_history")
+    assert opt._split == (option != "rows7" and (kind == "comfe_mises_plasticity" or kind.startswith("drucker_prager")))
     ref = ResidentState(law, n, stress0=s, history0=h, sparse_history=False, sparse_tangent=False,
                         reuse_constant_tangent=False)
     rng = np.random.default_rng(100 + seed)
