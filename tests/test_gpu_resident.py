@@ -398,3 +398,39 @@ def test_delta_trial_history_equals_the_plain_protocols(n):
     with pytest.raises(ValueError, match="trial eps_n array of its own"):
         law.evaluate_from(0.0, 1.0, grad(all_elastic=False, zoned=False), f.stress_committed, f.stress, f.tangent,
                           f.history_committed, f.history_committed, history_mask=mask, delta_history=True)
+
+
+@pytest.mark.parametrize("law_name", ["MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D"])
+def test_split_history_in_place_and_out_of_place_without_mask(law_name):
+    """FCAMD_EVAL_SPLIT_HISTORY through the raw device entry (fcamd_evaluate_device_ex), without the sparse protocol: in
+    place (history == history_prev: the reference's contract on the split arrays) and out of place (every row copied)
+    against the law's plain evaluate on the reference's 7-double rows.  Also: laws without such rows refuse the flag."""
+    from fenics_constitutive_amd.device import join_history_rows, split_history_rows
+
+    n = 64 * 25 + 13
+    rng = np.random.default_rng(5)
+    law, s0, h0, grad = _sparse_case(law_name, n, rng)
+    g = grad(all_elastic=False, zoned=False)
+    f = dict(dtype=torch.float64, device="cuda")
+    s_ref, t_ref = torch.from_numpy(s0).cuda(), torch.empty(36 * n, **f)
+    h_ref = {"history": torch.from_numpy(h0["history"]).cuda()}
+    law.evaluate(0.0, 1.0, g, s_ref, t_ref, h_ref)
+    torch.cuda.synchronize()
+    assert law.device_stats().n_plastic > 0
+    # in place on the split arrays
+    s1, t1 = torch.from_numpy(s0).cuda(), torch.empty(36 * n, **f)
+    h1 = split_history_rows(torch.from_numpy(h0["history"]).cuda())
+    law.evaluate_from(0.0, 1.0, g, s1, s1, t1, h1, h1, split_history=True)
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s_ref) and torch.equal(t1, t_ref) and torch.equal(join_history_rows(h1), h_ref["history"])
+    # out of place, no mask: every row of the trial arrays is written
+    sp, hp = torch.from_numpy(s0).cuda(), split_history_rows(torch.from_numpy(h0["history"]).cuda())
+    s2, t2 = torch.full((6 * n,), float("nan"), **f), torch.empty(36 * n, **f)
+    h2 = {k: torch.full_like(v, float("nan")) for k, v in hp.items()}
+    law.evaluate_from(0.0, 1.0, g, sp, s2, t2, hp, h2, split_history=True)
+    torch.cuda.synchronize()
+    assert torch.equal(s2, s_ref) and torch.equal(t2, t_ref) and torch.equal(join_history_rows(h2), h_ref["history"])
+    vm = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
+    hv = {"scalar": torch.zeros(n, **f), "rows": torch.zeros(6 * n, **f)}
+    with pytest.raises(NotImplementedError, match="SPLIT_HISTORY"):
+        vm.evaluate_from(0.0, 1.0, g, s1, s2, t2, hv, hv, split_history=True)
