@@ -771,8 +771,11 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     for (int k = 0; k < x->n_hist; ++k)
         if (!aligned16(x->history[k]) || !aligned16(x->history_prev[k]))
             return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
-    if ((x->flags & FCAMD_EVAL_SPLIT_HISTORY) && m->constraint != FCAMD_FULL)
-        return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_SPLIT_HISTORY: 3-D laws only");
+    if (x->flags & FCAMD_EVAL_SPLIT_HISTORY) {
+        if (m->constraint != FCAMD_FULL) return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_SPLIT_HISTORY: 3-D laws only");
+        if ((x->history[0] == x->history_prev[0]) != (x->history[1] == x->history_prev[1]))
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_SPLIT_HISTORY: both history arrays in place or both out of place");
+    }
     fcamd_context* c = m->ctx;
     HIP_TRY(hipSetDevice(c->device));
     if (!aligned16(x->stress2)) return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
