@@ -291,7 +291,7 @@ void options_from_env(Options* o) {
     o->host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, geti("FCAMD_HOST_SLOTS", fcamd_context::kSlots)));
     o->zero_copy = geti("FCAMD_ZERO_COPY", 1) != 0;
     o->zero_copy_grad = geti("FCAMD_ZERO_COPY_GRAD", 1) != 0;
-    o->bounce_max = std::max<long long>(0, geti("FCAMD_BOUNCE_MAX", 2 << 20));
+    o->bounce_max = std::max<long long>(0, geti("FCAMD_BOUNCE_MAX", 256 << 10));
 }
 
 // the law's host constants, recomputed only when del_t changes (SLS) -- not once per launch

@@ -54,7 +54,7 @@ struct Options {
     int host_slots = 4;        // FCAMD_HOST_SLOTS    chunk slots in flight (1..4)
     int zero_copy = 1;         // FCAMD_ZERO_COPY     0 keeps page-locked caller arrays on the staged path
     int zero_copy_grad = 1;    // FCAMD_ZERO_COPY_GRAD 0: fcamd_evaluate_resident uploads the gradient by DMA even if page-locked
-    long long bounce_max = 2 << 20;  // FCAMD_BOUNCE_MAX  host calls that move at most this many bytes of pageable caller memory go
+    long long bounce_max = 256 << 10;  // FCAMD_BOUNCE_MAX  host calls that move at most this many bytes of pageable caller memory go
                                      // through the context's own page-locked scratch (CPU copies); larger ones page-lock the arrays
 };
 

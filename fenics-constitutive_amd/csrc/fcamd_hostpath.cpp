@@ -212,7 +212,8 @@ struct HostTimer {
 // freed and allocated again, a heap that shrank and grew -- carries no such attribute, the cache still calls it
 // locked, and the DMA engine faults ("Memory access fault by GPU node-N on address <host address>";
 // tools/hsa_lock_probe.c, tools/pageable_copy_probe.py).  Instead:
-//   * calls that move at most `bounce_max` bytes: the CPU copies inputs into / results out of the context's own
+//   * calls that move at most `bounce_max` bytes (256 KiB: where the CPU copies cost what the page locks of a call cost,
+//     tools/bounce_crossover_probe.py): the CPU copies inputs into / results out of the context's own
 //     page-locked scratch (hipHostMalloc) and the kernel runs on the scratch;
 //   * larger calls: the caller's arrays are page-locked for the duration of the call (hipHostRegister: the
 //     attribute is set on the pages that are there NOW), the kernel runs directly on them, they are unlocked on

@@ -266,7 +266,7 @@ int fcamd_commit_delta_history(fcamd_model* model, int64_t n, double* history_co
                   results over PCIe itself, both directions at once, no staging buffers;
      pageable  -- arrays the caller did not register are page-locked for the duration of the call
                   (FCAMD_HOST_TEMP_LOCK) and treated the same way; calls that move at most
-                  "bounce_max" bytes (2 MiB), and arrays that cannot be locked, go through the
+                  "bounce_max" bytes (256 KiB), and arrays that cannot be locked, go through the
                   context's own page-locked scratch with CPU copies instead (FCAMD_HOST_BOUNCE).
                   Pageable caller memory is never handed to the HIP runtime's copy path (its cache
                   of on-the-fly page locks goes stale when memory is freed and allocated again);
@@ -476,7 +476,7 @@ int fcamd_context_set_timing(fcamd_context* ctx, int enabled);
    FCAMD_* environment defaults, which are read ONCE, when the context is created:
      "tile_map" (FCAMD_TILE_MAP, 0), "masked_max" (FCAMD_MASKED_MAX, -1 = per law), "nontemporal"
      (FCAMD_NT, 1), "host_chunk" (FCAMD_HOST_CHUNK, 0 = automatic), "host_slots" (FCAMD_HOST_SLOTS, 4),
-     "bounce_max" (FCAMD_BOUNCE_MAX, 2 MiB: host calls up to this size go through the page-locked scratch),
+     "bounce_max" (FCAMD_BOUNCE_MAX, 256 KiB: host calls up to this size go through the page-locked scratch),
      "zero_copy" (FCAMD_ZERO_COPY, 1), "zero_copy_grad" (FCAMD_ZERO_COPY_GRAD, 1). */
 int fcamd_context_set_option(fcamd_context* ctx, const char* name, long long value);
 int fcamd_context_get_option(fcamd_context* ctx, const char* name, long long* value);

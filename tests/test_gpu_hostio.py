@@ -19,9 +19,9 @@ VM_P = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w
 BOUNCE, TEMP, ZC = _capi.HOST_BOUNCE, _capi.HOST_TEMP_LOCK, _capi.HOST_ZERO_COPY_IN | _capi.HOST_ZERO_COPY_OUT
 
 
-@pytest.mark.parametrize("numel", [0, 1, 1000, (2 << 20) // 8, (2 << 20) // 8 + 1, 3_000_001])
+@pytest.mark.parametrize("numel", [0, 1, 1000, (256 << 10) // 8, (256 << 10) // 8 + 1, 3_000_001])
 def test_upload_download_round_trip(numel):
-    """sizes on both sides of the scratch threshold (2 MiB), ragged, empty"""
+    """sizes on both sides of the scratch threshold (256 KiB), ragged, empty"""
     rng = np.random.default_rng(numel)
     a = rng.normal(size=numel)
     d = hostio.to_device(a, "cuda")

@@ -151,13 +151,13 @@ def test_sparse_history_equals_full_history(n, law_name, split):
 @pytest.mark.parametrize("path", ["scratch", "lock", "chunks"])
 def test_evaluate_into_replays_golden_sequence(path):
     """fcamd_evaluate_resident: NumPy grad in, NumPy stress/tangent out, state on the device, on each data path of the
-    pageable host arrays: through the page-locked scratch (the default at this size), page-locked for the call with one
+    pageable host arrays: through the page-locked scratch (the default of small calls), page-locked for the call with one
     launch on them ("bounce_max" = 0), and page-locked with the chunked DMA pipeline ("zero_copy" = 0, 128-point chunks:
     the 1000+ points go through many chunks and all four slots)."""
     from fenics_constitutive_amd import _capi
 
     ctx = _capi.get_context(_capi.default_device())
-    options = {"scratch": {}, "lock": {"bounce_max": 0}, "chunks": {"bounce_max": 0, "zero_copy": 0, "host_chunk": 128}}[path]
+    options = {"scratch": {"bounce_max": 1 << 30}, "lock": {"bounce_max": 0}, "chunks": {"bounce_max": 0, "zero_copy": 0, "host_chunk": 128}}[path]
     saved = {k: ctx.get_option(k) for k in options}
     for k, v in options.items():
         ctx.set_option(k, v)
