@@ -576,7 +576,7 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         st = ensure_bounce(c, lay.used);
         if (st != FCAMD_OK) return st;
         hipStream_t s = c->hstream[0];
-        HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
+        if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         const bool second_store = stress_host && m->dims.gdim == 3;  // the 3-D kernels can store the stress twice
         for (int64_t p0 = 0; p0 < n; p0 += chunk) {
             const size_t np = (size_t)std::min<int64_t>(chunk, n - p0);
