@@ -15,11 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfcamd.so")
-SOURCES = ["fcamd_kernels.hip", "fcamd_stream_kernels.hip", "fcamd_capi.cpp", "fcamd_hostpath.cpp", "fcamd_multigpu.cpp", "fcamd_memory.cpp"]
+SOURCES = ["fcamd_kernels.hip", "fcamd_stream_kernels.hip", "fcamd_capi.cpp", "fcamd_hostpath.cpp", "fcamd_multigpu.cpp", "fcamd_memory.cpp", "fcamd_multi.cpp"]
 HEADERS = ["fcamd_internal.h", "fcamd_host.h", os.path.join("..", "..", "include", "fcamd.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: arithmetic order is part of the parity contract (see fcamd_kernels.hip)
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 HASHFILE = os.path.join(LIBDIR, "libfcamd.srchash")

@@ -50,6 +50,11 @@ SYMBOLS = [
     "fcamd_shard_slot_points", "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_alloc", "fcamd_ipc_free",
     "fcamd_ipc_export", "fcamd_ipc_open",
     "fcamd_ipc_close", "fcamd_enable_peer_access", "fcamd_allgather_direct", "fcamd_allgather_direct_wait",
+    "fcamd_multi_create", "fcamd_multi_destroy", "fcamd_multi_device_count", "fcamd_multi_plan", "fcamd_multi_bounds",
+    "fcamd_multi_evaluate_host", "fcamd_multi_register_host_buffer", "fcamd_multi_unregister_host_buffer",
+    "fcamd_multi_last_host_mode", "fcamd_multi_set_option",
+    "fcamd_multi_state_create", "fcamd_multi_state_destroy", "fcamd_multi_state_set", "fcamd_multi_state_get",
+    "fcamd_multi_state_evaluate", "fcamd_multi_state_commit",
     "fcamd_device_alloc_set", "fcamd_device_free",
     "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
     "fcamd_context_set_option", "fcamd_context_get_option", "fcamd_context_trim",
@@ -57,6 +62,7 @@ SYMBOLS = [
 ]
 
 IPC_HANDLE_BYTES = 64
+MULTI_MAX_DEVICES, MULTI_MIN_POINTS = 64, 8192  # FCAMD_MULTI_MAX_DEVICES / FCAMD_MULTI_MIN_POINTS
 GATHER_PULL = 1
 ALLOC_SEQUENTIAL, ALLOC_INTERLEAVED = 0, 1
 
@@ -177,6 +183,23 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
         lib.fcamd_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
         lib.fcamd_copy_device.argtypes = [vp, vp, vp, C.c_size_t]
+        ip = C.POINTER(C.c_int)
+        lib.fcamd_multi_create.argtypes = [ip, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.POINTER(vp)]
+        lib.fcamd_multi_destroy.argtypes = [vp]
+        lib.fcamd_multi_device_count.argtypes = [vp, ip]
+        lib.fcamd_multi_plan.argtypes = [vp, C.c_int64, ip]
+        lib.fcamd_multi_bounds.argtypes = [vp, C.c_int64, C.c_int, i64p, i64p]
+        lib.fcamd_multi_evaluate_host.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int, C.POINTER(Stats)]
+        lib.fcamd_multi_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
+        lib.fcamd_multi_unregister_host_buffer.argtypes = [vp, vp]
+        lib.fcamd_multi_last_host_mode.argtypes = [vp, ip, ip]
+        lib.fcamd_multi_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+        lib.fcamd_multi_state_create.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(vp)]
+        lib.fcamd_multi_state_destroy.argtypes = [vp]
+        lib.fcamd_multi_state_set.argtypes = [vp, vp, C.POINTER(vp), C.c_int]
+        lib.fcamd_multi_state_get.argtypes = [vp, C.c_int, vp, C.POINTER(vp), C.c_int]
+        lib.fcamd_multi_state_evaluate.argtypes = [vp, C.c_double, C.c_double, vp, vp, vp, C.c_int, C.POINTER(Stats)]
+        lib.fcamd_multi_state_commit.argtypes = [vp]
         lib.fcamd_last_error.restype = C.c_char_p
         lib.fcamd_status_string.restype = C.c_char_p
         lib.fcamd_status_string.argtypes = [C.c_int]
@@ -399,6 +422,128 @@ def get_context(device: int = 0) -> Context:
     if ctx is None:
         ctx = ctxs[int(device)] = Context(device)
     return ctx
+
+
+def default_devices():
+    """Devices of the single-process multi-GPU host path (``fcamd_multi``): ``FCAMD_DEVICES`` = a comma-separated list
+    of device ordinals ("0,1,2,3") or "all"; unset / empty: None (the one-device path on ``default_device()``)."""
+    spec = os.environ.get("FCAMD_DEVICES", "").strip()
+    if not spec:
+        return None
+    if spec.lower() == "all":
+        import torch
+
+        return list(range(torch.cuda.device_count()))
+    return [int(x) for x in spec.split(",") if x.strip()]
+
+
+def _ptr_array(ptrs):
+    if not ptrs:
+        return None, 0
+    return (C.c_void_p * len(ptrs))(*[C.c_void_p(int(p)) for p in ptrs]), len(ptrs)
+
+
+class Multi:
+    """``fcamd_multi``: one law on several GPUs of this process -- one context, model handle and worker thread per
+    device; ``evaluate_host`` is ``fcamd_evaluate_host`` with every device working on its own slice of the caller's
+    arrays over its own PCIe link (include/fcamd.h, "one process, several GPUs")."""
+
+    def __init__(self, devices, model_id: int, constraint: int, params):
+        self._lib = load()
+        self.devices = [int(d) for d in devices]
+        assert 1 <= len(self.devices) <= MULTI_MAX_DEVICES
+        dv = (C.c_int * len(self.devices))(*self.devices)
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        h = C.c_void_p()
+        check(self._lib.fcamd_multi_create(dv, len(self.devices), int(model_id), int(constraint),
+                                           p.ctypes.data_as(C.POINTER(C.c_double)), p.size, C.byref(h)))
+        self.handle = h
+
+    def plan(self, n: int) -> int:
+        """number of devices a call over ``n`` points uses"""
+        used = C.c_int()
+        check(self._lib.fcamd_multi_plan(self.handle, int(n), C.byref(used)))
+        return int(used.value)
+
+    def bounds(self, n: int, k: int) -> tuple[int, int]:
+        lo, hi = C.c_int64(), C.c_int64()
+        check(self._lib.fcamd_multi_bounds(self.handle, int(n), int(k), C.byref(lo), C.byref(hi)))
+        return int(lo.value), int(hi.value)
+
+    def evaluate_host(self, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, hist_ptrs) -> Stats:
+        arr, nh = _ptr_array(hist_ptrs)
+        st = Stats()
+        check(self._lib.fcamd_multi_evaluate_host(self.handle, float(t), float(del_t), int(n), C.c_void_p(grad_ptr),
+                                                  C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), arr, nh, C.byref(st)))
+        return st
+
+    def register_host_buffer(self, arr: np.ndarray) -> None:
+        check(self._lib.fcamd_multi_register_host_buffer(self.handle, C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def unregister_host_buffer(self, arr: np.ndarray) -> None:
+        check(self._lib.fcamd_multi_unregister_host_buffer(self.handle, C.c_void_p(arr.ctypes.data)))
+
+    def last_host_mode(self) -> tuple[int, int]:
+        """(HOST_* flags OR-ed over the devices of the last call, number of devices it used)"""
+        mode, used = C.c_int(), C.c_int()
+        check(self._lib.fcamd_multi_last_host_mode(self.handle, C.byref(mode), C.byref(used)))
+        return int(mode.value), int(used.value)
+
+    def set_option(self, name: str, value: int) -> None:
+        check(self._lib.fcamd_multi_set_option(self.handle, name.encode(), int(value)))
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.fcamd_multi_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        if sys is None or sys.is_finalizing():  # process exit releases everything; the HIP runtime may already be going down
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiState:
+    """``fcamd_multi_state``: committed + trial stress / history of n points, sliced over the devices of a ``Multi``."""
+
+    def __init__(self, multi: Multi, n: int, flags: int = 0):
+        self.multi, self._lib, self.n = multi, multi._lib, int(n)
+        h = C.c_void_p()
+        check(self._lib.fcamd_multi_state_create(multi.handle, int(n), int(flags), C.byref(h)))
+        self.handle = h
+
+    def set(self, stress_ptr, hist_ptrs) -> None:
+        arr, nh = _ptr_array(hist_ptrs)
+        check(self._lib.fcamd_multi_state_set(self.handle, C.c_void_p(stress_ptr or 0), arr, nh))
+
+    def get(self, trial: bool, stress_ptr, hist_ptrs) -> None:
+        arr, nh = _ptr_array(hist_ptrs)
+        check(self._lib.fcamd_multi_state_get(self.handle, int(bool(trial)), C.c_void_p(stress_ptr or 0), arr, nh))
+
+    def evaluate(self, t, del_t, grad_ptr, stress_ptr, tangent_ptr, flags: int = 0) -> Stats:
+        st = Stats()
+        check(self._lib.fcamd_multi_state_evaluate(self.handle, float(t), float(del_t), C.c_void_p(grad_ptr),
+                                                   C.c_void_p(stress_ptr or 0), C.c_void_p(tangent_ptr or 0), int(flags), C.byref(st)))
+        return st
+
+    def commit(self) -> None:
+        check(self._lib.fcamd_multi_state_commit(self.handle))
+
+    def close(self) -> None:
+        if self.handle and self.multi.handle:
+            self._lib.fcamd_multi_state_destroy(self.handle)
+        self.handle = C.c_void_p()
+
+    def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Model:

@@ -544,7 +544,8 @@ int fcamd_context_destroy(fcamd_context* c) {
     (void)hipSetDevice(c->device);
     {
         std::lock_guard<std::recursive_mutex> lock(c->host_mu);
-        for (auto& kv : c->registered) (void)hipHostUnregister(kv.first);  // best effort
+        for (auto& kv : c->registered)
+            if (!kv.second.borrowed) (void)hipHostUnregister(kv.first);  // best effort
         c->registered.clear();
     }
     free_host_staging(c);

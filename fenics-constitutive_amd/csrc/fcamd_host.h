@@ -78,6 +78,7 @@ struct fcamd_context {
     struct Pinned {
         size_t bytes;
         char* dev;
+        bool borrowed = false;  // page-locked by another context of the process (fcamd_multi): never unlocked from here
     };
     std::map<char*, Pinned> registered;
     // Guards `registered` and serialises the host entries with (un)registration: Python's garbage collector
@@ -152,6 +153,15 @@ void sum_counters(const fcamd_model* m, fcamd_stats* out);
 
 // release the chunk buffers and the page-locked scratch of the host entries (fcamd_hostpath.cpp)
 void free_host_staging(fcamd_context* c);
+
+// Call-scoped page locks of caller memory, one process-wide registry with reference counts (fcamd_hostpath.cpp):
+// the host entries take them for pageable caller arrays; the coordinator of a multi-device call (fcamd_multi.cpp) takes
+// them ONCE for the whole arrays, and the per-device host entries then find their slices locked already.
+bool temp_lock_acquire(char* q, size_t bytes, char** base, char** dev);
+void temp_lock_release(char* base);
+// A range that another context of this process keeps page-locked with fcamd_register_host_buffer, entered into
+// `c`'s registry with the address c's device sees it at (never unlocked from `c`).
+int adopt_registered_range(fcamd_context* c, void* ptr, size_t bytes);
 
 // fcamd_stream_kernels.hip: dst = src over n16 16-byte chunks (non-temporal accesses, grid-stride)
 hipError_t launch_stream_copy(void* dst, const void* src, size_t n16, int grid, hipStream_t stream);

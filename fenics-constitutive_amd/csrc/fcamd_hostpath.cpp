@@ -102,6 +102,19 @@ int finish_single_stream(fcamd_model* m, fcamd_stats* stats) {
 
 namespace fcamd {
 
+int adopt_registered_range(fcamd_context* c, void* ptr, size_t bytes) {
+    if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    HIP_TRY(hipSetDevice(c->device));
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FCAMD_ERR_HIP, "device %d cannot see the page-locked range", c->device);
+    }
+    c->registered[static_cast<char*>(ptr)] = {bytes, static_cast<char*>(dev), true};
+    return FCAMD_OK;
+}
+
 // release the staging buffers of the pageable host path (up to 4 slots x 512 Ki points x 66 doubles)
 void free_host_staging(fcamd_context* c) {
     for (int i = 0; i < fcamd_context::kSlots; ++i) {
@@ -161,7 +174,7 @@ int fcamd_unregister_host_buffer(fcamd_context* c, void* ptr) {
     auto it = c->registered.find(static_cast<char*>(ptr));
     if (it == c->registered.end()) return FCAMD_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipHostUnregister(ptr));
+    if (!it->second.borrowed) HIP_TRY(hipHostUnregister(ptr));
     c->registered.erase(it);
     return FCAMD_OK;
 }
@@ -226,11 +239,91 @@ struct HostTimer {
 // ("Memobj map does not have ptr").  One registry, one mutex, reference counts.
 struct TempLock {
     size_t bytes;
-    char* dev;
     int refs;
 };
 std::mutex g_temp_mu;
 std::map<char*, TempLock> g_temp;  // host base -> lock held by one or more calls in progress
+
+// address at which the CURRENT device sees the page-locked host address q (every device of the process can reach a
+// page-locked range, each at an address of its own: one process may drive several GPUs, fcamd_multi.cpp)
+char* device_view(char* q) {
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return static_cast<char*>(d);
+}
+
+}  // namespace
+
+namespace fcamd {
+
+// Takes (or shares) the call-scoped page lock that covers [q, q + bytes).  *base = the key to hand to
+// temp_lock_release (nullptr: the range was page-locked by somebody else and is used as it is), *dev = the address the
+// current device sees q at.  false: the range cannot be locked.
+bool temp_lock_acquire(char* q, size_t bytes, char** base, char** dev) {
+    *base = *dev = nullptr;
+    std::lock_guard<std::mutex> g(g_temp_mu);
+    {   // inside a range another call in progress (or the coordinator of a multi-device call) has locked: share it
+        auto it = g_temp.upper_bound(q);
+        if (it != g_temp.begin()) {
+            --it;
+            if (q < it->first + it->second.bytes) {
+                if (q + bytes > it->first + it->second.bytes) return false;
+                char* d = device_view(q);
+                if (!d) return false;
+                ++it->second.refs;
+                *base = it->first;
+                *dev = d;
+                return true;
+            }
+        }
+    }
+    hipError_t e = hipHostRegister(q, bytes, hipHostRegisterDefault);
+    if (e == hipSuccess) {
+        char* d = device_view(q);
+        if (!d) {
+            (void)hipHostUnregister(q);
+            return false;
+        }
+        g_temp[q] = {bytes, 1};
+        *base = q;
+        *dev = d;
+        return true;
+    }
+    (void)hipGetLastError();
+    if (e == hipErrorHostMemoryAlreadyRegistered) {
+        // page-locked by somebody else (the application's own hipHostRegister / hipHostMalloc, a range registered
+        // with another context): usable, for as long as that somebody keeps it, if the whole range is one mapping
+        void *d0 = nullptr, *d1 = nullptr;
+        if (hipHostGetDevicePointer(&d0, q, 0) == hipSuccess && hipHostGetDevicePointer(&d1, q + bytes - 1, 0) == hipSuccess &&
+            static_cast<char*>(d1) - static_cast<char*>(d0) == static_cast<ptrdiff_t>(bytes - 1)) {
+            *dev = static_cast<char*>(d0);
+            return true;
+        }
+        (void)hipGetLastError();
+    }
+    return false;
+}
+
+// Drops one reference; the last one unlocks the pages.  The caller has made sure that nothing of its own is still in
+// flight on the range.
+void temp_lock_release(char* base) {
+    if (!base) return;
+    std::lock_guard<std::mutex> g(g_temp_mu);
+    auto it = g_temp.find(base);
+    if (it == g_temp.end()) return;
+    if (--it->second.refs == 0) {
+        (void)hipHostUnregister(base);
+        g_temp.erase(it);
+    }
+    (void)hipGetLastError();
+}
+
+}  // namespace fcamd
+
+namespace {
 
 class CallerArrays {
   public:
@@ -256,46 +349,10 @@ class CallerArrays {
                 }
             }
         }
-        std::lock_guard<std::mutex> g(g_temp_mu);
-        {   // inside a range another call in progress has locked: share it
-            auto it = g_temp.upper_bound(q);
-            if (it != g_temp.begin()) {
-                --it;
-                if (q < it->first + it->second.bytes) {
-                    if (q + bytes > it->first + it->second.bytes) return false;
-                    ++it->second.refs;
-                    temp_.push_back(it->first);
-                    *dev = it->second.dev + (q - it->first);
-                    return true;
-                }
-            }
-        }
-        hipError_t e = hipHostRegister(q, bytes, hipHostRegisterDefault);
-        if (e == hipSuccess) {
-            void* d = nullptr;
-            if (hipHostGetDevicePointer(&d, q, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                (void)hipHostUnregister(q);
-                return false;
-            }
-            g_temp[q] = {bytes, static_cast<char*>(d), 1};
-            temp_.push_back(q);
-            *dev = static_cast<char*>(d);
-            return true;
-        }
-        (void)hipGetLastError();
-        if (e == hipErrorHostMemoryAlreadyRegistered) {
-            // page-locked by somebody else (the application's own hipHostRegister / hipHostMalloc, a range registered
-            // with another context): usable, for as long as that somebody keeps it, if the whole range is one mapping
-            void *d0 = nullptr, *d1 = nullptr;
-            if (hipHostGetDevicePointer(&d0, q, 0) == hipSuccess && hipHostGetDevicePointer(&d1, q + bytes - 1, 0) == hipSuccess &&
-                static_cast<char*>(d1) - static_cast<char*>(d0) == static_cast<ptrdiff_t>(bytes - 1)) {
-                *dev = static_cast<char*>(d0);
-                return true;
-            }
-            (void)hipGetLastError();
-        }
-        return false;
+        char* base = nullptr;
+        if (!temp_lock_acquire(q, bytes, &base, dev)) return false;
+        if (base) temp_.push_back(base);
+        return true;
     }
 
     bool temp_locked() const { return !temp_.empty(); }
@@ -305,16 +362,7 @@ class CallerArrays {
         if (temp_.empty()) return;
         for (int i = 0; i < fcamd_context::kSlots; ++i)
             if (c_->hstream[i]) (void)hipStreamSynchronize(c_->hstream[i]);
-        std::lock_guard<std::mutex> g(g_temp_mu);
-        for (char* q : temp_) {
-            auto it = g_temp.find(q);
-            if (it == g_temp.end()) continue;
-            if (--it->second.refs == 0) {
-                (void)hipHostUnregister(q);
-                g_temp.erase(it);
-            }
-        }
-        (void)hipGetLastError();
+        for (char* q : temp_) temp_lock_release(q);
         temp_.clear();
     }
 

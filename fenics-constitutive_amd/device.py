@@ -94,6 +94,10 @@ class DeviceLaw(IncrSmallStrainModel):
         self._tls = threading.local()
         self.n_handles_created = 0
         self.last_stats = None
+        # single-process multi-GPU host path: None = one device (default_device()), else the device ordinals the
+        # ndarray path spreads every call over (use_devices; environment default FCAMD_DEVICES)
+        self._devices = _capi.default_devices()
+        self._multi_handle = None
 
     # -- interface properties --------------------------------------------------------------
     @property
@@ -111,6 +115,31 @@ class DeviceLaw(IncrSmallStrainModel):
             h = handles[device] = _capi.Model(ctx, self._model_id, self._constraint.value, self._parameter_vector)
             self.n_handles_created += 1
         return h
+
+    # -- several GPUs, one process ----------------------------------------------------------------
+    def use_devices(self, devices) -> "DeviceLaw":
+        """NumPy-array ``evaluate`` calls of this law run on these GPUs at once (list of device ordinals; ``None``:
+        back to one device): every call is cut into contiguous slices, each device evaluates its slice of the
+        caller's arrays in place over its own PCIe link (``fcamd_multi_evaluate_host``) -- the single-assembler mode
+        of a dolfinx process that drives a whole node; results are bit-identical to one device.  The environment
+        variable ``FCAMD_DEVICES`` ("0,1,2,3" / "all") sets the default for every law.  Returns ``self``."""
+        devices = None if devices is None else [int(d) for d in devices]
+        if devices != self._devices:
+            self.unpin_arrays()
+            if self._multi_handle is not None:
+                self._multi_handle.close()
+                self._multi_handle = None
+            self._devices = devices
+        return self
+
+    @property
+    def devices(self):
+        return None if self._devices is None else list(self._devices)
+
+    def _multi(self) -> "_capi.Multi":
+        if self._multi_handle is None:
+            self._multi_handle = _capi.Multi(self._devices, self._model_id, self._constraint.value, self._parameter_vector)
+        return self._multi_handle
 
     def _history_arrays(self, history):
         """Order the caller's history dict by the law's field order."""
@@ -160,9 +189,10 @@ class DeviceLaw(IncrSmallStrainModel):
             _check_numpy("tangent", tangent)
         for (name, _), h in zip(self._history_fields(), hist):
             _check_numpy(f"history['{name}']", h)
-        m = self._handle(_capi.default_device())
+        multi = self._devices is not None
+        m = self._multi() if multi else self._handle(_capi.default_device())
         if self.auto_pin:
-            self._pin(m.ctx, [grad, stress] + ([] if tangent is None else [tangent]) + list(hist))
+            self._pin(m if multi else m.ctx, [grad, stress] + ([] if tangent is None else [tangent]) + list(hist))
         self.last_stats = m.evaluate_host(
             t, del_t, n, grad.ctypes.data, stress.ctypes.data,
             None if tangent is None else tangent.ctypes.data, [h.ctypes.data for h in hist],
@@ -184,7 +214,8 @@ class DeviceLaw(IncrSmallStrainModel):
         """Page-lock caller-owned NumPy arrays that will be passed to ``evaluate`` repeatedly (the
         dolfinx ``Function.x.array`` views of one problem): the host path then DMAs directly.  The law
         keeps the arrays alive until ``unpin_arrays()``."""
-        self._pin(self._handle(_capi.default_device()).ctx, [_check_numpy("array", a) for a in arrays])
+        target = self._multi() if self._devices is not None else self._handle(_capi.default_device()).ctx
+        self._pin(target, [_check_numpy("array", a) for a in arrays])
 
     def unpin_arrays(self) -> None:
         """Undo ``auto_pin`` registrations and drop the references that kept the arrays alive."""
@@ -200,6 +231,8 @@ class DeviceLaw(IncrSmallStrainModel):
         # address go through stale pages.  Unregister first (best effort at interpreter shutdown).
         try:
             self.unpin_arrays()
+            if self._multi_handle is not None:
+                self._multi_handle.close()
         except Exception:
             pass
 

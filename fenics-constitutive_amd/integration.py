@@ -34,8 +34,12 @@ from .resident import ResidentState
 __all__ = ["use_resident_state", "use_resident_problem_state"]
 
 
-def use_resident_state(problem, sync_history: bool = True, pin: bool = True, direct_global: bool = True) -> list[ResidentState]:
+def use_resident_state(problem, sync_history: bool = True, pin: bool = True, direct_global: bool = True, devices=None) -> list:
     """Returns the created states (one per GPU-backed law of ``problem._law_on_submeshs``).
+
+    ``devices`` (list of device ordinals): the single-process multi-GPU mode -- every law's state is a
+    ``MultiDeviceResidentState`` sliced over these GPUs, each of which reads its slice of the gradient from and writes
+    its slice of stress and tangent to the problem's host arrays over its own PCIe link (no gather).
 
     ``direct_global``: a law whose submesh map is the reference's ``IdentityMap`` (one material on the
     whole mesh: ``map_to_parent`` is ``parent.x.array[:] = sub.x.array[:]``, solver/maps.py:29-47) writes
@@ -51,14 +55,21 @@ def use_resident_state(problem, sync_history: bool = True, pin: bool = True, dir
         n = los.stress.x.array.size // sd
         stress0 = los.local_stress(problem.stress).copy()  # committed stress of this law's cells
         hist0 = None if los.history is None else {k: f.x.array for k, f in los.history.history_0.items()}
-        state = ResidentState(law, n, stress0=stress0, history0=hist0)
+        if devices is not None:
+            from .multidevice import MultiDeviceResidentState
+
+            state = MultiDeviceResidentState(law, n, devices=devices, stress0=stress0,
+                                             history0=None if hist0 is None else {k: np.ascontiguousarray(v) for k, v in hist0.items()})
+        else:
+            state = ResidentState(law, n, stress0=stress0, history0=hist0)
         direct = bool(direct_global) and type(los.submesh_map).__name__ == "IdentityMap"
         if pin:
+            pinner = state if devices is not None else law  # one page lock for all devices of a multi-device state
             if direct:
-                law.pin_host_arrays(los.displacement_gradient_fn.x.array, problem.stress.current.x.array,
-                                    problem.tangent.x.array)
+                pinner.pin_host_arrays(los.displacement_gradient_fn.x.array, problem.stress.current.x.array,
+                                       problem.tangent.x.array)
             else:
-                law.pin_host_arrays(los.displacement_gradient_fn.x.array, los.stress.x.array, los.local_tangent.x.array)
+                pinner.pin_host_arrays(los.displacement_gradient_fn.x.array, los.stress.x.array, los.local_tangent.x.array)
 
         def evaluate(self, sim_time, incr_disp, global_stress, global_tangent, _state=state, _direct=direct):
             incr_disp.evaluate_local_incremental_gradient(self.cells, self.displacement_gradient_fn)
@@ -72,12 +83,16 @@ def use_resident_state(problem, sync_history: bool = True, pin: bool = True, dir
                                  self.stress.x.array, self.local_tangent.x.array)
             self.map_to_parent(global_stress, global_tangent)
 
-        def update_history(self, _state=state, _sync=sync_history):
+        def update_history(self, _state=state, _sync=sync_history, _multi=devices is not None):
             _state.update()
             if _sync and self.history is not None:
-                committed = _state.history_committed
+                if _multi:  # every device's slice straight into the problem's history_0 arrays
+                    _state.download(history={key: fn.x.array for key, fn in self.history.history_0.items()}, committed=True)
+                else:
+                    committed = _state.history_committed
+                    for key, fn in self.history.history_0.items():
+                        assign(fn.x.array, committed[key])
                 for key, fn in self.history.history_0.items():
-                    assign(fn.x.array, committed[key])
                     self.history.history_1[key].x.array[:] = fn.x.array
 
         los.evaluate = types.MethodType(evaluate, los)

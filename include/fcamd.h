@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define FCAMD_VERSION_MAJOR 0
-#define FCAMD_VERSION_MINOR 2
+#define FCAMD_VERSION_MINOR 3
 
 /* ---- status codes (mapped to Python exceptions by the ctypes shim) -------- */
 typedef enum fcamd_status {
@@ -446,6 +446,69 @@ int fcamd_enable_peer_access(fcamd_context* ctx, int peer_device);
 int fcamd_allgather_direct(fcamd_context* ctx, int world, int rank, void* const* gathered, const int* devices,
                            size_t slot_bytes, size_t offset_bytes, size_t bytes, int flags);
 int fcamd_allgather_direct_wait(fcamd_context* ctx, int host_sync);
+
+/* ---- one process, several GPUs: the single assembler's host entry (SURVEY 8b last row, 8e) ------------- */
+/* north_star's single-process mode: ONE dolfinx process assembles, its arrays are host memory (views of
+   Function.x.array, solver/_lawonsubmesh.py:87-94), several GPUs evaluate.  A gather over xGMI would end in HBM, one
+   PCIe link away from the assembler; here the gather never happens: a fcamd_multi owns one context + one model handle
+   per device and one worker thread per device; a call cuts [0, n) with fcamd_shard_bounds (world = the devices used)
+   and every device runs the host entry of the single-GPU ABI -- fcamd_evaluate_host resp. fcamd_evaluate_resident -- on
+   ITS slice of the caller's arrays, concurrently, over its own PCIe link, results straight into the assembler's
+   arrays.  The caller's arrays are page-locked once per call for all devices (ranges registered with
+   fcamd_multi_register_host_buffer: never); nothing is copied between devices; history that is resident
+   (fcamd_multi_state) never leaves its device.  Results are bit-identical to the single-GPU entries (every point is
+   independent, the slices start on tile boundaries).  `devices` may name a device more than once (two contexts on one
+   GPU: how the path is tested on a one-GPU box).  Calls of fewer than FCAMD_MULTI_MIN_POINTS points per device use
+   fewer devices (launch latency, not PCIe, bounds them).  Thread-compatible like a context: one call at a time. */
+typedef struct fcamd_multi fcamd_multi;
+#define FCAMD_MULTI_MAX_DEVICES 64
+#define FCAMD_MULTI_MIN_POINTS 8192
+int fcamd_multi_create(const int* devices, int n_devices, int model_id, int constraint, const double* params,
+                       int n_params, fcamd_multi** out);
+int fcamd_multi_destroy(fcamd_multi* mg);
+int fcamd_multi_device_count(const fcamd_multi* mg, int* n_devices);
+/* Number of devices a call over n points uses, and the slice [lo, hi) of device slot k in that call. */
+int fcamd_multi_plan(const fcamd_multi* mg, int64_t n, int* n_used);
+int fcamd_multi_bounds(const fcamd_multi* mg, int64_t n, int k, int64_t* lo, int64_t* hi);
+/* fcamd_evaluate_host over all devices: same arguments, same status codes (the first failing slice's), `stats` =
+   the sums over the slices.  In place on the caller's host arrays. */
+int fcamd_multi_evaluate_host(fcamd_multi* mg, double t, double del_t, int64_t n, const double* grad_del_u,
+                              double* stress, double* tangent, double* const* history, int n_hist,
+                              fcamd_stats* stats);
+/* Page-lock a caller range once for ALL devices of the handle (fcamd_register_host_buffer for every context, one
+   lock): calls on it skip the per-call page lock.  Unregister before freeing the memory. */
+int fcamd_multi_register_host_buffer(fcamd_multi* mg, void* ptr, size_t bytes);
+int fcamd_multi_unregister_host_buffer(fcamd_multi* mg, void* ptr);
+/* Data path every device of the last call took (FCAMD_HOST_* flags, OR-ed over the devices used), and how many
+   devices it used. */
+int fcamd_multi_last_host_mode(const fcamd_multi* mg, int* mode, int* n_used);
+/* Option of every context of the handle (fcamd_context_set_option), or the handle's own "min_points" (default
+   FCAMD_MULTI_MIN_POINTS: a call over n points uses at most n / min_points devices). */
+int fcamd_multi_set_option(fcamd_multi* mg, const char* name, long long value);
+
+/* Device-resident increment state over several GPUs (SURVEY 8f-1 for the single assembler): device slot k keeps the
+   committed and the trial copy of stress and history of ITS slice of the n points (fcamd_shard_bounds(n, devices, k))
+   in its own HBM -- allocated here, owned by the state.  Per Newton iteration only the gradient goes up and stress /
+   tangent come down, over every device's own PCIe link at once:
+     _set       committed state <- host arrays (initial conditions, restart; NULL stress / history: zeros); the trial
+                history is set equal to it and the sparse-history masks are cleared;
+     _evaluate  trial <- law(committed, grad_del_u_host), stress_host / tangent_host (nullable) receive the trial stress
+                and tangent: fcamd_evaluate_resident on every slice.  `flags`: FCAMD_EVAL_SPARSE_TANGENT as there
+                (the CALLER knows whether tangent_host still holds the previous call's tangent); the sparse trial-history
+                protocol is always on for the plasticity laws, FCAMD_EVAL_SPLIT_HISTORY is a property of the state
+                (`flags` of _create; the laws with 7-double history rows);
+     _commit    trial becomes committed (pointer swap per device; solver/_solver.py:149-159).  Refused
+                (FCAMD_ERR_NONCONVERGED / _DOMAIN / _BAD_ARG) when the last evaluate failed or none happened;
+     _get       host arrays <- committed (trial = 0) or trial (trial = 1) state, in the law's reference layout.
+   History arrays at the interface are always the law's history_dim fields (7-double rows for the comfe-rs laws). */
+typedef struct fcamd_multi_state fcamd_multi_state;
+int fcamd_multi_state_create(fcamd_multi* mg, int64_t n, int flags, fcamd_multi_state** out);
+int fcamd_multi_state_destroy(fcamd_multi_state* st);
+int fcamd_multi_state_set(fcamd_multi_state* st, const double* stress_host, const double* const* history_host, int n_hist);
+int fcamd_multi_state_get(fcamd_multi_state* st, int trial, double* stress_host, double* const* history_host, int n_hist);
+int fcamd_multi_state_evaluate(fcamd_multi_state* st, double t, double del_t, const double* grad_del_u_host,
+                               double* stress_host, double* tangent_host, int flags, fcamd_stats* stats);
+int fcamd_multi_state_commit(fcamd_multi_state* st);
 
 /* ---- device memory -------------------------------------------------------------- */
 /* A working set whose physical placement is chosen by the call: `n_arrays` address ranges of bytes[k]
