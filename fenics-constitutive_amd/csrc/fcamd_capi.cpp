@@ -544,6 +544,7 @@ int fcamd_context_destroy(fcamd_context* c) {
     (void)hipSetDevice(c->device);
     {
         std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+        forget_registered_ranges(c);
         for (auto& kv : c->registered)
             if (!kv.second.borrowed) (void)hipHostUnregister(kv.first);  // best effort
         c->registered.clear();
@@ -622,6 +623,10 @@ int fcamd_model_create(fcamd_context* c, int model_id, int constraint, const dou
         e = hipHostMalloc(reinterpret_cast<void**>(&m->h_counters), kCounterBytes,
                           hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemset(m->d_counters, 0, kCounterBytes);
+    // the fill runs on the null stream and every launch on a non-blocking stream that does not wait for it: without
+    // this wait it can land on top of the counts of the handle's first evaluate (found in round 3: 9157 instead of 9219
+    // plastic points reported by a law's very first call)
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipEventCreate(&m->ev0);
     if (e == hipSuccess) e = hipEventCreate(&m->ev1);
     if (e != hipSuccess) {

@@ -98,9 +98,40 @@ int finish_single_stream(fcamd_model* m, fcamd_stats* stats) {
     return finish_chunks(m, stats, /*downloaded=*/true);
 }
 
+// Ranges page-locked through fcamd_register_host_buffer by ANY context of the process (base -> bytes).  A host entry of
+// another context that meets such a range must use it as it is: this runtime lets a second hipHostRegister of a
+// registered address "succeed", and the hipHostUnregister that ends that call then takes the owner's lock away.
+std::mutex g_reg_mu;
+std::map<char*, size_t> g_registered;
+
+void note_registered(char* base, size_t bytes) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    g_registered[base] = bytes;
+}
+void forget_registered(char* base) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    g_registered.erase(base);
+}
+// [q, q + bytes) relative to the registered ranges of the process: 1 inside one, -1 overlaps one partly, 0 disjoint
+int in_process_registry(char* q, size_t bytes) {
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    auto it = g_registered.upper_bound(q);
+    if (it != g_registered.begin()) {
+        auto lo = std::prev(it);
+        if (q < lo->first + lo->second) return q + bytes <= lo->first + lo->second ? 1 : -1;
+    }
+    if (it != g_registered.end() && it->first < q + bytes) return -1;
+    return 0;
+}
+
 }  // namespace
 
 namespace fcamd {
+
+void forget_registered_ranges(fcamd_context* c) {
+    for (auto& kv : c->registered)
+        if (!kv.second.borrowed) forget_registered(kv.first);
+}
 
 int adopt_registered_range(fcamd_context* c, void* ptr, size_t bytes) {
     if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
@@ -139,10 +170,16 @@ int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
     if (c->registered.count(base)) {
         // Same address again: either a repeated call or a NEW buffer that landed where a freed,
         // still-registered one was.  Re-pin: a stale registration would DMA through old pages.
-        (void)hipHostUnregister(ptr);
+        if (!c->registered[base].borrowed) {
+            (void)hipHostUnregister(ptr);
+            forget_registered(base);
+        }
         c->registered.erase(base);
     }
+    if (in_process_registry(base, bytes) != 0)
+        return fail(FCAMD_ERR_BAD_ARG, "the range overlaps one that another context of this process has registered");
     HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    note_registered(base, bytes);
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -174,8 +211,12 @@ int fcamd_unregister_host_buffer(fcamd_context* c, void* ptr) {
     auto it = c->registered.find(static_cast<char*>(ptr));
     if (it == c->registered.end()) return FCAMD_OK;
     HIP_TRY(hipSetDevice(c->device));
-    if (!it->second.borrowed) HIP_TRY(hipHostUnregister(ptr));
+    const bool owner = !it->second.borrowed;
     c->registered.erase(it);
+    if (owner) {
+        forget_registered(static_cast<char*>(ptr));
+        HIP_TRY(hipHostUnregister(ptr));
+    }
     return FCAMD_OK;
 }
 
@@ -264,6 +305,11 @@ namespace fcamd {
 // current device sees q at.  false: the range cannot be locked.
 bool temp_lock_acquire(char* q, size_t bytes, char** base, char** dev) {
     *base = *dev = nullptr;
+    {   // page-locked for good by a context of this process (fcamd_register_host_buffer): use it as it is
+        const int r = in_process_registry(q, bytes);
+        if (r < 0) return false;
+        if (r > 0) return (*dev = device_view(q)) != nullptr;
+    }
     std::lock_guard<std::mutex> g(g_temp_mu);
     {   // inside a range another call in progress (or the coordinator of a multi-device call) has locked: share it
         auto it = g_temp.upper_bound(q);

@@ -414,6 +414,9 @@ int fcamd_multi_state_create(fcamd_multi* mg, int64_t n, int flags, fcamd_multi_
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sl.mask), words * sizeof(uint64_t)));
             HIP_TRY(hipMemset(sl.mask, 0, words * sizeof(uint64_t)));
         }
+        // the fills run on the null stream; everything later runs on the contexts' non-blocking streams, which do
+        // not wait for it: a fill still in flight would land on top of fcamd_multi_state_set's upload
+        HIP_TRY(hipDeviceSynchronize());
         return (int)FCAMD_OK;
     });
     if (rc != FCAMD_OK) {

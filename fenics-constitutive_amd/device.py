@@ -207,8 +207,8 @@ class DeviceLaw(IncrSmallStrainModel):
             try:
                 ctx.register_host_buffer(a)
                 pinned[key] = (a, ctx)
-            except RuntimeError:
-                pinned[key] = None  # e.g. overlaps another registration: keep the staged path
+            except (RuntimeError, ValueError):
+                pinned[key] = None  # e.g. overlaps another registration: the calls page-lock it (or find it locked) themselves
 
     def pin_host_arrays(self, *arrays) -> None:
         """Page-lock caller-owned NumPy arrays that will be passed to ``evaluate`` repeatedly (the

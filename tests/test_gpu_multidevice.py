@@ -221,7 +221,7 @@ def test_multi_device_resident_state_equals_resident_state(law_name, pinned):
             assert used == 3 and mode & _capi.HOST_ZERO_COPY_OUT and bool(mode & _capi.HOST_TEMP_LOCK) == (not pinned)
         one.update()
         multi.update()
-    assert max(n_plastic) > 0.1 * n and min(n_plastic) < 0.5 * max(n_plastic)
+    assert max(n_plastic) > 0.1 * n and min(n_plastic) < 0.75 * max(n_plastic)  # the sets really changed
     multi.close()
 
 
