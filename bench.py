@@ -207,11 +207,20 @@ class Workload:
         self._vmm, self.vmm_info = None, None
         self.n_pl_ab, self.its_ab = [0, 0], [0, 0]
 
-    def launch(self, i, tangent=None, full_history=False, sparse_tangent=None, delta_history=None):
+    def launch(self, i, tangent=None, full_history=False, sparse_tangent=None, delta_history=None, m=None):
+        """`m`: evaluate the first m points of the arrays only (the strong-scaling leg of a weak-scaling run)"""
         delta = self.delta if delta_history is None else delta_history
-        self.law.evaluate_from(0.0, self.del_t, self.grads[i & 1], self.stress_c, self.stress_t,
-                               self.tangent if tangent is None else tangent, self.hist_c, self.hist_t,
-                               history_mask=None if full_history else self.hmask,
+        tan = self.tangent if tangent is None else tangent
+        if m is None:
+            g, sc, st, hc, ht, mask = self.grads[i & 1], self.stress_c, self.stress_t, self.hist_c, self.hist_t, self.hmask
+        else:
+            dims = {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7, "scalar": 1, "rows": 6}
+            g, sc, st, tan = self.grads[i & 1][: 9 * m], self.stress_c[: 6 * m], self.stress_t[: 6 * m], tan[: 36 * m]
+            hc = None if self.hist_c is None else {k: v[: dims[k] * m] for k, v in self.hist_c.items()}
+            ht = None if self.hist_t is None else {k: v[: dims[k] * m] for k, v in self.hist_t.items()}
+            mask = None if self.hmask is None else self.hmask[: (m + 63) // 64]
+        self.law.evaluate_from(0.0, self.del_t, g, sc, st, tan, hc, ht,
+                               history_mask=None if full_history else mask,
                                sparse_tangent=self.sparse_tangent if sparse_tangent is None else sparse_tangent,
                                delta_history=bool(delta and not full_history), split_history=self.split)
 
@@ -574,7 +583,198 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
     return out
 
 
-def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent):
+def host_path_figures(devices=None, sizes=(1_000_000, 10_000_000), latency_sizes=(1_000, 10_000), reps=3, budget_s=12.0,
+                      seed=99):
+    """PCIe-inclusive figures of the HOST entries -- the call the reference times with Timer("constitutive-law-evaluation")
+    (solver/_lawonsubmesh.py:86-94: evaluate on views of Function.x.array) -- VonMises3D, mixed elastic / plastic NumPy arrays:
+      evaluate            the reference contract: law.evaluate(ndarrays) in place (fcamd_evaluate_host), 176 B/pt up, <= 392 down;
+      resident            ResidentState.evaluate_into (fcamd_evaluate_resident): state on the device, 72 B/pt up, 336 down;
+      resident_sparse     the same with the sparse tangent (the product default): only the tangent rows of plastic / formerly
+                          plastic points cross PCIe from the second call on;
+    each with pageable arrays (page-locked by the library for the duration of the call) and with arrays registered once.
+    `devices` = list of device ordinals: the single-process multi-GPU form of the same calls (fcamd_multi: every device on its
+    own slice over its own PCIe link); None: one device, the plain objects.  Never part of `value` of the default line."""
+    import numpy as np
+
+    import fenics_constitutive_amd as fc
+    from fenics_constitutive_amd import _capi
+
+    t_begin = time.perf_counter()
+    multi = devices is not None
+    n_max = max(sizes)
+    rng = np.random.default_rng(seed)
+    law = fc.VonMises3D(VM_P)
+    if multi:
+        law.use_devices(devices)
+    g = rng.standard_normal(9 * n_max)
+    g *= np.repeat(10.0 ** (rng.random(n_max) * 2.0 - 4.0), 9)
+    s0 = np.zeros(6 * n_max)
+    a0 = rng.random(n_max) * 0.02
+    s, t = np.zeros(6 * n_max), np.zeros(36 * n_max)
+    e, a = np.zeros(6 * n_max), a0.copy()
+    out = {"law": "VonMises3D, grad scale log-uniform in [1e-4, 1e-2], alpha ~ U(0, 0.02)", "devices": devices or [_capi.default_device()],
+           "bytes_per_point": {"evaluate_up": 176, "evaluate_down_max": 392, "resident_up": 72, "resident_down": 336}, "sizes": {}}
+
+    def make_state(n):
+        if multi:
+            from fenics_constitutive_amd.multidevice import MultiDeviceResidentState
+
+            return [MultiDeviceResidentState(fc.VonMises3D(VM_P), n, devices=devices, history0={"eps_n": e[: 6 * n], "alpha": a0[:n]},
+                                             sparse_tangent=sp) for sp in (False, True)]
+        from fenics_constitutive_amd.resident import ResidentState
+
+        return [ResidentState(law, n, history0={"eps_n": e[: 6 * n], "alpha": a0[:n]}, sparse_tangent=sp, placement="torch") for sp in (False, True)]
+
+    def best_of(fn, k, reset=None):
+        best = None
+        for _ in range(k):
+            if reset:
+                reset()
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best
+
+    def figures(n, k, lat=False):
+        gs, ss, ts, es, al = g[: 9 * n], s[: 6 * n], t[: 36 * n], e[: 6 * n], a[:n]
+        full, sparse = make_state(n)
+
+        def reset():
+            ss[:] = 0.0
+            es[:] = 0.0
+            al[:] = a0[:n]
+
+        row = {}
+        legs = (("evaluate", lambda: law.evaluate(0.0, 1.0, gs, ss, ts, {"eps_n": es, "alpha": al}), reset, 568),
+                ("resident", lambda: full.evaluate_into(0.0, 1.0, gs, ss, ts), None, 408),
+                ("resident_sparse", lambda: sparse.evaluate_into(0.0, 1.0, gs, ss, ts), None, 408))
+        for name, fn, rs_, bpp in legs:
+            fn()  # warm: first touch, first page lock, (sparse) the full tangent
+            dt = best_of(fn, k, rs_)
+            if lat:
+                row[name + "_us"] = round(dt * 1e6, 1)
+            else:
+                row[name] = {"ms": round(dt * 1e3, 3), "Mpts_s": round(n / dt / 1e6, 1), "interface_GBs": round(n * bpp / dt / 1e9, 2)}
+        if not lat:
+            row["plastic_fraction"] = round(law.last_stats.n_plastic / n, 4)
+        for st in (full, sparse):
+            if multi:
+                st.close()
+        return row
+
+    pin_target = None
+    try:
+        for registered in (False, True):
+            if registered:
+                if multi:
+                    pin_target = law._multi()
+                else:
+                    pin_target = law._handle(_capi.default_device()).ctx
+                for x in (g, s, t, e, a):
+                    pin_target.register_host_buffer(x)
+            key = "registered" if registered else "pageable"
+            for n in sizes:
+                if time.perf_counter() - t_begin > budget_s and n != min(sizes):
+                    out["sizes"].setdefault(str(n), {})[key] = "skipped: time budget"
+                    continue
+                out["sizes"].setdefault(str(n), {})[key] = figures(n, reps)
+            for n in latency_sizes:
+                out.setdefault("per_call_us", {}).setdefault(str(n), {})[key] = figures(n, 30, lat=True)
+        # what the link gives a plain copy between the registered tangent array and device memory
+        import torch
+
+        from fenics_constitutive_amd.hostio import download, upload
+
+        dev = torch.device("cuda", (devices or [_capi.default_device()])[0])
+        m = min(n_max, 4_000_000)
+        buf = torch.empty(36 * m, dtype=torch.float64, device=dev)
+        upload(buf, t[: 36 * m])
+        h2d = best_of(lambda: upload(buf, t[: 36 * m]), 3)
+        d2h = best_of(lambda: download(t[: 36 * m], buf), 3)
+        out["pinned_copy_GBs"] = {"h2d": round(288 * m / h2d / 1e9, 1), "d2h": round(288 * m / d2h / 1e9, 1),
+                                  "note": "fcamd_copy_to_device / _to_host of 36 doubles x %d points between the registered tangent array and one device" % m}
+        big = out["sizes"].get(str(n_max), {}).get("registered")
+        if isinstance(big, dict):
+            down = n_max * 392 / (big["evaluate"]["ms"] * 1e-3) / 1e9
+            out["evaluate_d2h_over_pinned_copy"] = round(down / (out["pinned_copy_GBs"]["d2h"] * (len(devices) if multi else 1)), 3)
+    finally:
+        if pin_target is not None:
+            for x in (g, s, t, e, a):
+                try:
+                    pin_target.unregister_host_buffer(x)
+                except Exception:
+                    pass
+    out["wall_s"] = round(time.perf_counter() - t_begin, 1)
+    return out
+
+
+def main_host(args):
+    """--mode host: the single-process multi-GPU host path (fcamd_multi).  ONE process drives --gpus devices; under
+    torch.distributed.run every rank but 0 leaves at once (nothing on this path needs a process group)."""
+    rank = int(os.environ.get("RANK", "0"))
+    if rank != 0:
+        return 0
+    import torch
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    have = torch.cuda.device_count()
+    if args.host_devices:
+        devices = [int(x) for x in args.host_devices.split(",")]
+    else:
+        devices = [k % have for k in range(args.gpus)]  # fewer GPUs than asked for: contexts share devices (rehearsal)
+    n_total = args.n * len(devices) if args.scaling == "weak" else args.n
+    t_start = time.perf_counter()
+    import numpy as np
+
+    import fenics_constitutive_amd as fc
+    from fenics_constitutive_amd import _capi
+
+    fig = host_path_figures(devices=devices, sizes=(min(1_000_000, n_total), n_total), latency_sizes=(1_000, 10_000),
+                            reps=max(2, min(args.steps, 5)), budget_s=args.wall_budget / 2)
+    # the timed steps proper: the reference contract (in-place evaluate on pageable NumPy arrays) over all devices
+    rng = np.random.default_rng(5)
+    law = fc.VonMises3D(VM_P).use_devices(devices)
+    g = rng.standard_normal(9 * n_total)
+    g *= np.repeat(10.0 ** (rng.random(n_total) * 2.0 - 4.0), 9)
+    a0 = rng.random(n_total) * 0.02
+    s, t, e, a = np.zeros(6 * n_total), np.zeros(36 * n_total), np.zeros(6 * n_total), a0.copy()
+
+    def step():
+        law.evaluate(0.0, 1.0, g, s, t, {"eps_n": e, "alpha": a})
+
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    mode, used = law._multi().last_host_mode()
+    n_pl = int(law.last_stats.n_plastic)
+    bytes_step = n_total * 176 + (n_total - n_pl) * 336 + n_pl * 392
+    out = {"metric": METRIC, "value": round(n_total * args.steps / elapsed / 1e6, 1), "unit": "Mpts/s", "n_gpus": len(devices),
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+           "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "mode": "host",
+           "config": {"workload": f"host path: VonMises3D FULL-3D, {n_total} quadrature points in ONE process's pageable NumPy arrays, in-place "
+                                  f"evaluate (the reference contract) spread over {len(devices)} device contexts by fcamd_multi_evaluate_host -- every "
+                                  f"device on its own slice over its own PCIe link, no gather; PCIe-inclusive by construction",
+                      "points_total": n_total, "devices": devices, "devices_used": used, "host_mode_flags": mode,
+                      "plastic_fraction": round(n_pl / n_total, 4), "parallelism": f"one process x {len(devices)} device contexts"},
+           "roofline": {"bound": "pcie", "achieved": round(bytes_step * args.steps / elapsed / 1e9, 2), "unit": "GB/s",
+                        "peak": None if "pinned_copy_GBs" not in fig else round((fig["pinned_copy_GBs"]["h2d"] + fig["pinned_copy_GBs"]["d2h"]) * len(set(devices)), 1),
+                        "frac": None, "traffic": None,
+                        "note": "achieved = interface bytes over PCIe per step (176 B/pt up; 336 down for elastic, 392 for plastic points) / step time, "
+                                "both directions counted; peak = measured pinned H2D + D2H copy rate of one link x distinct devices"},
+           "host_path": fig, "cpu_baseline": None, "library": {"srchash": library_hash(), "kernel_hash": library_hash(kernels_only=True)}}
+    if out["roofline"]["peak"]:
+        out["roofline"]["frac"] = round(out["roofline"]["achieved"] / out["roofline"]["peak"], 4)
+    out["wall_s"] = round(time.perf_counter() - t_start, 1)
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent, agree=None, budget_left=None):
     """The exchange step of the single-assembler mode (BASELINE config 5), timed separately
     and never part of `value`: every rank's stress slice (6/pt) in one piece and its tangent slice (36/pt)
     in chunks through two chunk buffers that are sized against the free device memory up front
@@ -632,6 +832,9 @@ def time_allgather(args, dist, torch, device, rank, world, n, stress_t, tangent)
 
     for variant in (["rccl"] if nccl else []) + ["direct"] + (["p2p"] if (nccl and args.gather_direct) else []):
         peer = variant == "direct"
+        if agree is not None and not agree(budget_left() > 75):  # every variant is a set of collectives: all ranks or none
+            result[variant + "_skipped"] = "wall budget"
+            continue
         if rank == 0:
             print(f"# allgather leg: {variant}, {ng} points per rank, budget {budget / 1e9:.1f} GB", file=sys.stderr, flush=True)
         try:  # set-up failures are raised on all ranks together (PeerBuffers exchanges the outcome of every step)
@@ -762,7 +965,21 @@ def main():
                          "with fewer GPUs than ranks (ranks then share GPUs; of the gather variants only the C ABI's "
                          "peer copies run)")
     ap.add_argument("--verbose", action="store_true", help="stage-by-stage progress lines on stderr (every rank)")
+    ap.add_argument("--mode", choices=["device", "host"], default="device",
+                    help="device (default): device-resident steps, one rank per GPU; host: the single-process multi-GPU HOST path "
+                         "(fcamd_multi: one process, --gpus device contexts, every device evaluates its slice of the process's NumPy "
+                         "arrays in place over its own PCIe link) -- PCIe-inclusive, its own line")
+    ap.add_argument("--host-devices", default="", help="--mode host: explicit device ordinals, e.g. 0,0 (two contexts on one GPU)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = --points per GPU (default; a strong-scaling leg on the first points/N of every shard is reported "
+                         "next to it under \"strong_scaling\"); strong = --points in total, cut into N contiguous shards")
+    ap.add_argument("--no-host-path", action="store_true", help="N = 1 default run: skip the host_path block (PCIe-inclusive figures of the ndarray entries)")
+    ap.add_argument("--wall-budget", type=float, default=420.0,
+                    help="seconds of wall clock after which the optional legs (strong-scaling leg, gather variants, extra configurations, host_path) "
+                         "are skipped so that the line is printed inside the driver's limit")
     args = ap.parse_args()
+    if args.mode == "host":
+        sys.exit(main_host(args))
 
     def stage(msg):
         if args.verbose:
@@ -807,6 +1024,25 @@ def main():
     name = args.workload or HEADLINE
     history = "sparse" if args.sparse_history else args.history
     n = args.n
+    if args.scaling == "strong" and world > 1:
+        # --points in total: rank r owns the contiguous, tile-aligned shard fcamd_shard_bounds(points, world, r)
+        from fenics_constitutive_amd import _capi
+
+        lo, hi = _capi.shard_bounds(args.n, world, rank)
+        n = hi - lo
+        if n <= 0:
+            sys.exit(f"--scaling strong: rank {rank} owns no point of {args.n}")
+
+    def budget_left():
+        return args.wall_budget - (time.perf_counter() - t_start)
+
+    def agree(flag):
+        """the same yes / no on every rank (a leg with collectives must be entered by all ranks or by none): the minimum over the ranks"""
+        if not (distributed and world > 1):
+            return bool(flag)
+        f = torch.tensor([1 if flag else 0], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(int(f.item()))
     wl = Workload(name, n, seed=1234 + rank, device=device, dev_index=dev_index, history=history,
                   sparse_tangent=args.sparse_tangent, grid=args.grid, delta_history=args.delta_history,
                   split_history=not args.no_split_history)
@@ -853,6 +1089,38 @@ def main():
         tk[rank] = kernel_avg_ms
         dist.all_reduce(tk, op=dist.ReduceOp.SUM)
         per_rank_ms = [round(float(x), 4) for x in tk.tolist()]
+
+    # N > 1, weak run: the strong-scaling figure next to it -- the same total as ONE GPU's shard (--points), i.e. every rank
+    # evaluates the first points/world points (tile-aligned) of its arrays; same bracket (barrier + synchronize, max over ranks)
+    strong = None
+    if distributed and world > 1 and args.scaling == "weak" and agree(budget_left() > 60):
+        m = max(64, (args.n // world // 64) * 64)
+        for i in range(max(2, args.warmup)):
+            wl.launch(i, m=m)
+        sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        dist.barrier()
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for i, (a_, b_) in enumerate(sev):
+            a_.record()
+            wl.launch(i, m=m)
+            b_.record()
+        torch.cuda.synchronize()
+        dist.barrier()
+        s_el = time.perf_counter() - ts0
+        tt = torch.tensor([s_el], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        s_el = float(tt.item())
+        tk = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        tk[rank] = sum(a_.elapsed_time(b_) for a_, b_ in sev) / len(sev)
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        wl.launch_log.append(["strong_scaling_leg", max(2, args.warmup) + args.steps])
+        strong = {"value": round(m * world * args.steps / s_el / 1e6, 1), "unit": "Mpts/s", "points_total": m * world, "points_per_gpu": m,
+                  "ms_per_step": round(s_el / args.steps * 1e3, 4), "per_rank_kernel_ms": [round(float(x), 4) for x in tk.tolist()],
+                  "note": "strong scaling: the total of ONE GPU's weak shard cut over all ranks (every rank evaluates the first points/world points "
+                          "of its arrays), same timing bracket as `value`; compare with the N = 1 line's value"}
+        for i in (0, 1):  # the sparse protocol's masks and trial rows back in step with whole-array launches
+            wl.launch(i)
 
     # next to the headline: the same step without the sparse protocol (every launch rewrites the whole trial
     # history, fcamd_evaluate_device_from) -- six extra launches after the timed region
@@ -927,7 +1195,7 @@ def main():
 
     out = None
     if rank == 0:  # the line is complete up to here; what follows only adds to it
-        total_pts = n * world * args.steps
+        total_pts = (args.n if (args.scaling == "strong" and world > 1) else n * world) * args.steps
         value = total_pts / elapsed / 1e6
         alg_bytes = headline["alg"]
         achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9
@@ -952,17 +1220,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": headline["config_text"],
                        "baseline_config": BASELINE_CONFIG.get(name),
-                       "points_per_gpu": n, "plastic_fraction": round(n_pl / n, 4),
+                       "points_per_gpu": n, "points_total": args.n if (args.scaling == "strong" and world > 1) else n * world,
+                       "plastic_fraction": round(n_pl / n, 4),
                        "mean_newton_iters": round(n_its / max(n_pl, 1), 3) if headline["kind"] in ("von_mises_3d", "comfe_drucker_prager") else None,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": None if traffic is None else f"profiles/traffic.json[{tkey}]@kernel_hash={str(library_hash(kernels_only=True))[:16]} "
+                                                                        "(stored rocprofv3 --pmc measurement of these kernels, not measured in this run)",
                          "kernel_ms_avg": round(kernel_avg_ms, 4), "kernel_ms_min": round(kernel_ms[0], 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "traffic_GBs": None if traffic is None else round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1),
@@ -1003,6 +1274,8 @@ def main():
             out["placement"]["tries"] = tries
         if per_rank_ms is not None:
             out["per_rank_kernel_ms"] = per_rank_ms
+        if strong is not None:
+            out["strong_scaling"] = strong
         out["launch_log"] = headline["launch_log"]
         out["library"] = {"srchash": library_hash(), "kernel_hash": library_hash(kernels_only=True)}
 
@@ -1011,7 +1284,12 @@ def main():
         print(json.dumps(out), flush=True)
 
     # the exchange step of config 5, timed separately (never part of `value`)
-    if distributed and world > 1 and not args.no_gather:
+    do_gather = distributed and world > 1 and not args.no_gather
+    if do_gather and not agree(budget_left() > 90):
+        do_gather = False
+        if rank == 0:
+            out["allgather"] = {"skipped": f"wall budget: {budget_left():.0f} s left of --wall-budget {args.wall_budget:.0f}"}
+    if do_gather:
         # An exchange between 8 processes can hang in ways a single GPU cannot rehearse (a peer mapping that never
         # returns, ranks leaving a collective in different places): the measured line must survive that.  If the leg
         # has not finished after --gather-timeout seconds, rank 0 prints the line with an error entry and every rank
@@ -1022,9 +1300,9 @@ def main():
             if rank == 0:
                 out["allgather"] = {"error": f"the all-gather leg did not finish within {args.gather_timeout} s; step timing above is complete"}
                 emit()
-            os._exit(0)
+            os._exit(3)  # the line is out, but a hung exchange is a FAILED leg: the driver must see it
 
-        watchdog = threading.Timer(args.gather_timeout, give_up)
+        watchdog = threading.Timer(min(args.gather_timeout, max(30.0, budget_left() - 30.0)), give_up)
         watchdog.daemon = True
         watchdog.start()
         try:
@@ -1033,7 +1311,7 @@ def main():
             keep_s, keep_t = wl.stress_t, wl.tangent
             wl.grads = wl.hist_t = wl.hmask = None  # the gather needs the room, the step timing is done
             torch.cuda.empty_cache()
-            gather = time_allgather(args, dist, torch, device, rank, world, n, keep_s, keep_t)
+            gather = time_allgather(args, dist, torch, device, rank, world, n, keep_s, keep_t, agree=agree, budget_left=budget_left)
         except Exception as e:  # e.g. no room on every rank alike: the step timing above stands
             gather = {"error": f"{type(e).__name__}: {e}"[:400]}
         watchdog.cancel()
@@ -1046,6 +1324,9 @@ def main():
     if do_configs and rank == 0:
         configs = {}
         for k, cname in enumerate(EXTRA_CONFIGS):
+            if budget_left() < 45:
+                configs[cname] = {"skipped": "wall budget"}
+                continue
             try:
                 configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
                                             min(tries, 4), history=history, placement=args.placement, cpu=not args.no_cpu_baseline,
@@ -1062,6 +1343,13 @@ def main():
         out["configs"] = configs
 
     if rank == 0:
+        if world == 1 and not args.no_host_path and args.workload is None and budget_left() > 40:
+            # the number a dolfinx user sees: the ndarray entries over PCIe ("timed separately and labelled as such")
+            try:
+                torch.cuda.empty_cache()
+                out["host_path"] = host_path_figures(devices=None, sizes=(1_000_000, min(n, 10_000_000)) if n > 1_000_000 else (n,))
+            except Exception as e:  # informational: must not lose the line
+                out["host_path"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1:
             out["cpu_baseline"] = cpu_baseline(*cpu_args) if cpu_args is not None else None
         emit()

@@ -1,0 +1,99 @@
+"""bench.py itself under test (its N > 1 path had never run outside a manual rehearsal).
+
+A one-GPU box rehearses N = 2 with both ranks on GPU 0 (``--backend gloo``: the RCCL gather variants are skipped, the C
+ABI's IPC peer copies run) -- the same control flow as the driver's 8-GPU launch: torchrun child, placement capped by
+free memory, barriers, max-over-ranks timing, the strong-scaling leg, the chunked all-gather leg.  Each run is a child
+process (bench.py initialises the GPU itself); at most three processes use the GPU at a time."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_bench(*args, timeout=420, env=None):
+    e = dict(os.environ, MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update(env or {})
+    r = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_two_ranks_weak_scaling_with_strong_leg_and_gather():
+    r, out = run_bench("--gpus", "2", "--backend", "gloo", "--points", "2000000", "--steps", "3", "--warmup", "2",
+                       "--configs", "none", "--no-cpu-baseline", "--placement-tries", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out is not None, r.stdout[-2000:]
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["unit"] == "Mpts/s"
+    assert out["config"]["points_per_gpu"] == 2_000_000 and out["config"]["points_total"] == 4_000_000
+    assert len(out["per_rank_kernel_ms"]) == 2 and all(ms > 0 for ms in out["per_rank_kernel_ms"])
+    # value = all ranks' points / max-over-ranks wall time of the timed steps
+    assert abs(out["value"] - 4_000_000 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) <= 0.01 * out["value"]
+    assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["bound"] == "hbm"
+    ss = out["strong_scaling"]
+    assert ss["points_total"] == 2 * ss["points_per_gpu"] and ss["points_per_gpu"] == (2_000_000 // 2 // 64) * 64
+    assert len(ss["per_rank_kernel_ms"]) == 2 and ss["value"] > 0
+    ag = out["allgather"]
+    assert "error" not in ag and "direct_ms" in ag and ag["direct_ms"] > 0, ag
+    assert ag["points_per_rank"] == 2_000_000 and ag["tangent_chunks"] >= 1
+    assert "rccl_ms" not in ag  # gloo rehearsal: RCCL variants are not run
+    assert out.get("cpu_baseline") is None and "configs" not in out
+
+
+def test_two_ranks_strong_scaling():
+    r, out = run_bench("--gpus", "2", "--backend", "gloo", "--points", "3000000", "--scaling", "strong", "--steps", "3", "--warmup", "1",
+                       "--configs", "none", "--no-cpu-baseline", "--no-gather", "--placement", "first")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["scaling"] == "strong" and out["config"]["points_total"] == 3_000_000
+    assert out["config"]["points_per_gpu"] == 1_500_032  # fcamd_shard_bounds(3e6, 2, 0): tile-aligned slot
+    assert abs(out["value"] - 3_000_000 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) <= 0.01 * out["value"]
+    assert "strong_scaling" not in out and "allgather" not in out
+
+
+def test_a_hung_gather_leg_is_a_failed_run():
+    """--gather-timeout fires (here at once): rank 0 still prints the line -- with the step timing and an error entry for the
+    leg -- and the processes end with a NON-ZERO exit code (a hung exchange used to be reported as rc 0)."""
+    r, out = run_bench("--gpus", "2", "--backend", "gloo", "--points", "4000000", "--steps", "2", "--warmup", "1", "--configs", "none",
+                       "--no-cpu-baseline", "--placement", "first", "--gather-timeout", "0.0", "--wall-budget", "1000")
+    assert r.returncode != 0
+    assert out is not None and out["n_gpus"] == 2 and out["value"] > 0
+    assert "did not finish" in out["allgather"]["error"]
+
+
+def test_host_mode_two_contexts():
+    r, out = run_bench("--mode", "host", "--gpus", "2", "--host-devices", "0,0", "--points", "300000", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["mode"] == "host" and out["n_gpus"] == 2 and out["config"]["devices_used"] == 2
+    assert out["config"]["points_total"] == 600_000 and out["value"] > 0
+    assert out["roofline"]["bound"] == "pcie" and out["roofline"]["achieved"] > 0
+    hp = out["host_path"]
+    big = hp["sizes"]["600000"]
+    for key in ("pageable", "registered"):
+        for leg in ("evaluate", "resident", "resident_sparse"):
+            assert big[key][leg]["Mpts_s"] > 0
+    assert set(hp["per_call_us"]) == {"1000", "10000"} and hp["pinned_copy_GBs"]["d2h"] > 0
+
+
+def test_default_line_carries_the_host_path_block():
+    """the driver's command shape at a small size: one rank, no launcher, extra configurations off"""
+    r, out = run_bench("--points", "2000000", "--steps", "3", "--warmup", "1", "--configs", "none", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak"
+    hp = out["host_path"]
+    assert "error" not in hp, hp
+    assert set(hp["sizes"]) == {"1000000", "2000000"}
+    assert hp["sizes"]["2000000"]["registered"]["resident_sparse"]["Mpts_s"] > hp["sizes"]["2000000"]["registered"]["resident"]["Mpts_s"] * 0.8
+    assert out["roofline"]["traffic"] is None or "traffic_source" in out["roofline"]
