@@ -332,6 +332,10 @@ int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* gra
     if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
     if ((flags & FCAMD_EVAL_SPLIT_HISTORY) && !has_split_history(m->law))
         return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_SPLIT_HISTORY exists for the laws with one [scalar, eps_p(6)] history row per point");
+    if (n_hist < 0 || n_hist > FCAMD_MAX_HISTORY)
+        return fail(FCAMD_ERR_SIZE, "n_hist = %d: 0 .. %d history fields exist", n_hist, FCAMD_MAX_HISTORY);
+    if (m->info.n_hist == 0 && n_hist != 0)
+        return fail(FCAMD_ERR_SIZE, "law has no history, got %d history fields", n_hist);
     if (m->info.n_hist > 0) {
         const int expected = (flags & FCAMD_EVAL_SPLIT_HISTORY) ? 2 : m->info.n_hist;  // split: [scalar (n), rows (6 n)]
         if (!hist || !hist_prev || n_hist == 0)

@@ -621,6 +621,12 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     if (st != FCAMD_OK) return st;
     if (history_mask && !has_sparse_history(m->law))
         return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
+    if (flags & FCAMD_EVAL_DELTA_HISTORY) {  // as fcamd_evaluate_device_ex: increments must never land in the committed rows
+        if (!history_mask) return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs history_mask");
+        const int kd = (flags & FCAMD_EVAL_SPLIT_HISTORY) ? 1 : 0;  // the array that accumulates plastic strain
+        if (hist && hist_prev && hist[kd] == hist_prev[kd])
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial plastic-strain array of its own");
+    }
     if (!aligned16(stress) || !aligned16(stress_prev))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
     // history arrays of the state: the law's fields, or -- FCAMD_EVAL_SPLIT_HISTORY -- [scalar (n), eps_p rows (6 n)]

@@ -69,6 +69,7 @@ class _LawState:
         self.counters = new_counters(device) if self.mask is not None or type(law).__name__ in (
             "VonMises3D", "MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D") else None
         self.stats_pending = False
+        self.failed = None  # the error of THIS law's last evaluate (cleared only when this law is evaluated again)
 
 
 class ResidentProblemState:
@@ -114,7 +115,7 @@ class ResidentProblemState:
         self._evaluated = False
         self.reuse_constant_tangent = reuse_constant_tangent
         self.sparse_tangent = sparse_tangent
-        self._failed = None  # the error of the last evaluate, if it raised: nothing to commit
+        # the error of a law's last evaluate, if it raised, lives with the law (_LawState.failed): nothing to commit
         # placement of the arrays the launches stream (see ResidentState): "auto" / "vmm" move the parent
         # stress pair, the parent tangent and every law's history pair into one interleaved VMM working set on
         # the first device-assembler evaluate; "tune" times candidate allocations of the tangent; "torch": none
@@ -175,7 +176,7 @@ class ResidentProblemState:
                 ls.tangent_target = None  # the mask no longer remembers which rows hold plastic tangents
         for ls in self._laws:
             ls.stats_pending = False
-        self._failed = None
+            ls.failed = None
 
     # the Newton-iteration call (IncrSmallStrainProblem.form, solver/_solver.py:130-147) ------------------
     def evaluate(self, grads) -> None:
@@ -190,7 +191,8 @@ class ResidentProblemState:
             self._placed = True
             if 8 * 36 * self.n >= self.AUTO_TUNE_MIN_BYTES:
                 self._place(grads)
-        self._failed = None
+        for ls in self._laws:
+            ls.failed = None
         for ls, g in zip(self._laws, grads):
             if not _is_torch(g):
                 if ls.grad is None:
@@ -275,7 +277,7 @@ class ResidentProblemState:
         hp = [] if ls.hist is None else [ls.hist[self._c][name].data_ptr() for name, _ in m.history_fields]
         hc = [] if ls.hist is None else [ls.hist[1 - self._c][name].data_ptr() for name, _ in m.history_fields]
         ls.tangent_target = None
-        self._failed = None
+        ls.failed = None  # this law's record only: another law's failure of the same iteration stays on the books
         self._evaluated = True  # the trial state is touched even if the launch fails
         m.evaluate_device_ex(self._time, self._del_t, ls.n, gptr, self.stress_0.data_ptr(), self.stress_1.data_ptr(), tptr,
                              hp, hc, None if ls.rows is None else ls.rows.data_ptr(),
@@ -300,7 +302,7 @@ class ResidentProblemState:
         hc = None if ls.hist is None else ls.hist[1 - self._c]
         ls.tangent_key = ls.host_tangent_key = None
         ls.tangent_target = None
-        self._failed = None
+        ls.failed = None
         tan = None if tangent_parent is None else self.tangent
         ls.stats_pending = ls.counters is not None
         if ls.rows is None:
@@ -438,8 +440,6 @@ class ResidentProblemState:
         # Always a synchronisation point: the host assembler reads the arrays the launches wrote (and may free
         # or unpin them) right after check() -- also when no law of the problem has counters to read.
         torch.cuda.current_stream(self.device).synchronize()
-        if self._failed is not None and not any(ls.stats_pending for ls in self._laws):
-            raise self._failed
         for ls in self._laws:
             if not ls.stats_pending:
                 continue
@@ -448,9 +448,15 @@ class ResidentProblemState:
             try:
                 ls.law.raise_for_stats(st)
             except RuntimeError as e:
-                self._failed = e
+                ls.failed = e
+        # a law whose last evaluate failed keeps the trial state uncommittable until THAT law has been evaluated again --
+        # whatever the other laws did in between (a caller that catches law k's error and carries on with law k + 1)
         if self._failed is not None:
             raise self._failed
+
+    @property
+    def _failed(self):
+        return next((ls.failed for ls in self._laws if ls.failed is not None), None)
 
     # the commit (IncrSmallStrainProblem.update, solver/_solver.py:149-159) -------------------------------
     def update(self) -> None:

@@ -129,6 +129,11 @@ class ResidentState:
         self._stats_pending = False  # a device launch whose counters have not been looked at yet
         self._failed = None          # the error of the last evaluate, if it raised: nothing to commit
         self._placement_mode = placement
+        #: Incremented whenever the state REPLACES its device arrays (the placement step of the first large device-assembler
+        #: ``evaluate`` -- or an explicit ``prepare()`` -- and ``tune_placement``): tensors obtained earlier from ``stress`` /
+        #: ``tangent`` / ``grad`` / ``history`` then alias arrays the kernel no longer writes.  A device assembler that grabs
+        #: the tensors once calls ``prepare()`` first (or compares ``generation``).
+        self.generation = 0
         self._placed = placement == "torch"  # nothing to do
         self._vmm = None
         self.placement = None  # what the placement step did, once it has run
@@ -164,6 +169,9 @@ class ResidentState:
 
     @property
     def tangent(self):
+        """The trial tangent array (allocated on first use).  With ``placement`` other than "torch" the first large
+        ``evaluate`` may move the state's arrays: take the tensor after ``prepare()`` / the first evaluate, or watch
+        ``generation``."""
         if self._tangent is None:
             import torch
 
@@ -269,6 +277,13 @@ class ResidentState:
         self._evaluated = True
         self._stats_pending = self._counts
 
+    def prepare(self, t: float, del_t: float, grad_del_u) -> None:
+        """Run the placement step NOW (it otherwise runs inside the first large device-assembler ``evaluate``) and leave a
+        valid trial state for ``grad_del_u``: after it the tensors handed out by ``stress`` / ``tangent`` / ``grad`` /
+        ``history`` stay the ones the kernel writes (``generation`` does not change any more unless ``tune_placement`` is
+        called).  For device assemblers that take the pointers once and then loop."""
+        self.evaluate(t, del_t, grad_del_u)
+
     def _place(self, t, del_t, g, staging: bool) -> None:
         """First large device-assembler evaluate: "tune" -- the fastest of a few hipMalloc candidates of the
         tangent; "vmm" -- the state's arrays in one interleaved VMM working set; "auto" -- both, timed with the
@@ -297,6 +312,7 @@ class ResidentState:
                 self._vmm = None
                 self.placement = {**(self.placement or {"mode": "torch"}), "vmm_error": f"{type(e).__name__}: {e}"[:200]}
             self._tangent_key = self._tangent_target = None  # whichever tangent array it is: written in full next
+        self.generation += 1
 
     def _time_launch(self, t, del_t, g, launches: int = 3) -> float:
         import torch
@@ -365,6 +381,7 @@ class ResidentState:
             self._sd * self._sd * self.n, lambda tan: self._launch(t, del_t, g, tan),
             tries=tries, device=self.device, first=first)
         del first
+        self.generation += 1
         self._tangent_key = None  # a constant tangent has to be written into the chosen array
         if self.placement is None:
             self.placement = {"mode": "hipmalloc_tuned", **info}

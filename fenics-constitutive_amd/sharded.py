@@ -136,15 +136,26 @@ class ShardedEvaluator:
         """Same result as :meth:`allgather` through the C ABI (``fcamd_allgather_direct``): ``peers`` holds
         every rank's ``gathered`` buffer mapped into this process (HIP IPC); this rank's slice -- or
         ``count`` values of it from ``offset`` on -- is copied into its slot of all of them by world-1
-        concurrent peer copies.  Ends with a barrier: on return every rank's buffer is complete."""
+        concurrent peer copies.  Starts with stream synchronise + barrier (nobody is still reading the previous
+        contents of a buffer that is about to be overwritten by its peers) and ends with a barrier: on return every
+        rank's buffer is complete.  Consumers of ``gathered`` must be enqueued on this rank's current stream (or be
+        finished) before the next call.  ``ChunkedGather`` with ``peer_copies`` keeps the same contract per chunk."""
         per = dim * self.plan.per_rank
         mine = gathered[per * self.rank : per * (self.rank + 1)]
         if local.data_ptr() != mine.data_ptr():
             mine[: local.numel()].copy_(local)
         count = per - offset if count is None else count
-        if pull:  # every slot must be complete before anybody reads it
-            peers.ctx.synchronize()
-            self.dist.barrier(group=self.group)
+        # Entry synchronisation, both modes.  pull: every slot must be complete before anybody reads it.  push: this rank
+        # is about to write into every PEER's gathered buffer, and a peer's consumer (assembly kernels on its own stream)
+        # may still be reading the data of the previous call -- a fast rank that has run its next evaluate already would
+        # overwrite it under the reader (write after read).  So every rank first waits for its own stream (the evaluate
+        # that produced its slot AND the consumers of its gathered buffer), then all ranks meet: after the barrier nobody
+        # reads the old contents any more.
+        import torch
+
+        torch.cuda.current_stream(gathered.device).synchronize()
+        peers.ctx.synchronize()
+        self.dist.barrier(group=self.group)
         _dbg(f"allgather_peer: {8 * count / 1e9:.2f} GB per slot, {'pull' if pull else 'push'}")
         peers.gather(8 * per, 8 * offset, 8 * count, pull=pull)
         peers.ctx.allgather_direct_wait(host_sync=True)

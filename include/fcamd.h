@@ -441,7 +441,9 @@ int fcamd_enable_peer_access(fcamd_context* ctx, int peer_device);
    blocks until THIS rank's copies have completed, (host_sync=0) makes the context's stream wait for
    them.  Completion of the peers' copies into / out of this rank's buffer is the caller's cross-rank
    barrier: after wait + barrier every rank's buffer is complete (push); before a pull every rank must
-   have passed a barrier after producing its slot. */
+   have passed a barrier after producing its slot.  Before a PUSH every rank must know that no peer is still reading
+   the previous contents of its buffer (the push overwrites them): synchronise the consumers' streams and pass a
+   barrier first, or alternate between two gathered buffers (sharded.py: allgather_peer does the former). */
 #define FCAMD_GATHER_PULL 1
 int fcamd_allgather_direct(fcamd_context* ctx, int world, int rank, void* const* gathered, const int* devices,
                            size_t slot_bytes, size_t offset_bytes, size_t bytes, int flags);
@@ -523,6 +525,9 @@ int fcamd_multi_state_commit(fcamd_multi_state* st);
 int fcamd_device_alloc_set(fcamd_context* ctx, int n_arrays, const size_t* bytes, size_t granule_bytes, int order,
                            void** ptrs);
 int fcamd_device_free(fcamd_context* ctx, void* ptr);
+/* Note: the ADDRESS RANGES of a set are never returned to the runtime (on this stack a range that is reserved again
+   and mapped to new handles serves stale data); the physical memory is.  A process that builds and frees many sets
+   consumes virtual address space only (47 bits of it are plentiful: 1e4 sets of 64 GB). */
 
 /* ---- tuning / introspection -------------------------------------------------- */
 /* Override the launch grid (number of 256-thread workgroups; 0 = automatic). */

@@ -94,6 +94,26 @@ def test_drucker_prager_messages_and_problem_state():
         dp.raise_for_stats(st)
 
 
+def test_a_caught_failure_of_one_law_is_not_forgotten_by_the_next_laws_evaluate():
+    """law 0's evaluate raises (sync=True), the caller catches it and goes on to law 1 -- update() must still
+    refuse to commit; only a clean re-evaluate of law 0 clears the record."""
+    n = 256
+    vm = fc.VonMises3D(NONCONVERGING)
+    le = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, fc.StressStrainConstraint.FULL)
+    rows = [np.arange(0, n, 2, dtype=np.int32), np.arange(1, n, 2, dtype=np.int32)]
+    ps = ResidentProblemState([(vm, rows[0]), (le, rows[1])], n)
+    g_bad, _, _, _ = nonconverging_inputs(n // 2)
+    g_le = np.full(9 * (n // 2), 1e-3)
+    sp, tp = np.zeros(6 * n), np.zeros(36 * n)
+    with pytest.raises(RuntimeError, match="did not converge"):
+        ps.evaluate_law_into(0, g_bad, sp, tp, sync=True)
+    ps.evaluate_law_into(1, g_le, sp, tp, sync=True)  # a clean law in between must not clear law 0's failure
+    with pytest.raises(RuntimeError, match="did not converge"):
+        ps.update()
+    ps.evaluate_law_into(0, 0.0 * g_bad, sp, tp, sync=True)
+    ps.update()
+
+
 def test_set_state_writes_both_history_copies():
     """a restart history must reach the trial copy too, or elastic points commit stale rows
     under the sparse protocol."""
