@@ -189,10 +189,11 @@ class Workload:
         # Newton iterations (FCAMD_EVAL_DELTA_HISTORY) and adds it to the committed array at the commit.  That moves a
         # part of the reference evaluate's work (eps_n += gamma N) out of the launch, so it is never part of the timed
         # steps of the default line -- it is measured after them and reported next to the headline, commit included.
-        self.delta = bool(delta_history and self.sparse and self.kind == "von_mises_3d")
         # comfe-rs plasticity laws under the sparse protocol: ResidentState keeps their [scalar, eps_p(6)] history rows as
         # two arrays (FCAMD_EVAL_SPLIT_HISTORY) -- an internal layout of the device-resident state, same results
         self.split = bool(split_history and self.sparse and self.kind in ("comfe_mises_plasticity", "comfe_drucker_prager"))
+        self.delta_key = "eps_n" if self.kind == "von_mises_3d" else ("rows" if self.split else None)  # the write-only plastic-strain array
+        self.delta = bool(delta_history and self.sparse and self.delta_key is not None)
         if self.split:
             from fenics_constitutive_amd.device import split_history_rows
 
@@ -242,7 +243,7 @@ class Workload:
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
         for a, b in ev:  # the commit is idempotent in cost (same mask every time); its effect on eps_n does not matter any more
             a.record()
-            self.law.commit_delta_history(self.hist_c["eps_n"], self.hist_t["eps_n"], self.hmask)
+            self.law.commit_delta_history(self.hist_c[self.delta_key], self.hist_t[self.delta_key], self.hmask)
             b.record()
         torch.cuda.synchronize()
         return sum(ms) / len(ms), min(a.elapsed_time(b) for a, b in ev[1:])
@@ -1131,7 +1132,7 @@ def main():
 
     # ... and ResidentState's delta trial history (VonMises3D): evaluate launches with the flag + the commit kernel
     delta_fig = None
-    if wl.sparse and wl.kind == "von_mises_3d" and not wl.delta:
+    if wl.sparse and wl.delta_key is not None and not wl.delta:
         try:
             d_ms, c_ms = wl.time_delta_protocol()
             delta_fig = (d_ms, c_ms)
@@ -1264,10 +1265,11 @@ def main():
                 "evaluate_kernel_ms_avg": round(d_ms, 4), "commit_kernel_ms": round(c_ms, 4),
                 "frac_equivalent": round(alg_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "break_even_newton_iterations": None if saved <= 0 else round(c_ms / saved, 2),
-                "note": "ResidentState(delta_history=True), VonMises3D (FCAMD_EVAL_DELTA_HISTORY; an option, not the default): during the Newton iterations the trial eps_n "
-                        "array receives only the increment of the plastic points and the committed rows are not read; update() adds "
-                        "the increments to the committed array (commit kernel, once per increment).  The launch then does less than "
-                        "the reference's evaluate, so it is not the timed step; frac_equivalent divides the interface's bytes by its time"}
+                "note": "ResidentState(delta_history=True / 'auto') (FCAMD_EVAL_DELTA_HISTORY; an option, not the default): during the Newton iterations the "
+                        "trial plastic-strain array receives only the increments of the plastic points, packed per tile, and the committed rows are "
+                        "not read; update() adds the increments to the committed array (commit kernel, once per increment).  The launch then does "
+                        "less than the reference's evaluate, so it is not the timed step; frac_equivalent divides the interface's bytes by its time; "
+                        "'auto' switches it on from ResidentState.DELTA_MIN_ITERATIONS evaluates per increment"}
         out["placement"] = dict(headline["vmm_info"] or {"mode": "hipmalloc_tuned" if headline["placement"] else "first"})
         if headline["placement"] is not None:
             out["placement"].update({"hipmalloc_tangent_" + k: v for k, v in headline["placement"].items()})

@@ -16,7 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfcamd.so")
 SOURCES = ["fcamd_kernels.hip", "fcamd_stream_kernels.hip", "fcamd_capi.cpp", "fcamd_hostpath.cpp", "fcamd_multigpu.cpp", "fcamd_memory.cpp", "fcamd_multi.cpp"]
-HEADERS = ["fcamd_internal.h", "fcamd_host.h", os.path.join("..", "..", "include", "fcamd.h")]
+# the device code lives in per-law headers that fcamd_kernels.hip includes
+KERNEL_HEADERS = [os.path.join("kernels", h) for h in (
+    "tile_io.h", "tangent_writers.h", "wrapped_io.h", "history_rows.h", "law_linear_elasticity.h", "law_sls.h",
+    "law_von_mises.h", "law_comfe_mises.h", "law_drucker_prager.h", "law_lowdim.h")]
+HEADERS = ["fcamd_internal.h", "fcamd_host.h", os.path.join("..", "..", "include", "fcamd.h"), *KERNEL_HEADERS]
 ARCH = "gfx950"
 # -ffp-contract=off: arithmetic order is part of the parity contract (see fcamd_kernels.hip)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -37,7 +41,9 @@ def _source_hash() -> str:
     return h.hexdigest()
 
 
-KERNEL_SOURCES = ["fcamd_kernels.hip", "fcamd_internal.h"]
+KERNEL_SOURCES = ["fcamd_kernels.hip", "fcamd_internal.h", *KERNEL_HEADERS]
+# flags that change the device code (host-only flags such as -pthread must not invalidate a PMC measurement)
+KERNEL_FLAGS = [f for f in FLAGS if f not in ("-pthread", "-fPIC", "-shared", "-Wall", "-Wno-unused-function")]
 KERNEL_HASHFILE = os.path.join(LIBDIR, "libfcamd.kernelhash")
 
 
@@ -47,7 +53,7 @@ def kernel_hash() -> str:
     invalidate a PMC measurement, a kernel change does."""
     import hashlib
 
-    h = hashlib.sha256(" ".join([ARCH, *FLAGS]).encode())
+    h = hashlib.sha256(" ".join([ARCH, *KERNEL_FLAGS]).encode())
     for f in KERNEL_SOURCES:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())

@@ -397,7 +397,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.flags = split ? FCAMD_EVAL_SPLIT_HISTORY : 0;
     if (hmask) {
         if (tangent) a.flags |= flags & FCAMD_EVAL_SPARSE_TANGENT;  // needs an array that holds the previous tangent
-        if (m->law == FCAMD_VON_MISES_3D) a.flags |= flags & FCAMD_EVAL_DELTA_HISTORY;
+        if (m->law == FCAMD_VON_MISES_3D || split) a.flags |= flags & FCAMD_EVAL_DELTA_HISTORY;  // needs plastic-strain rows of their own
     }
     a.n = n;
     a.counters = counters ? counters : m->d_counters;  // caller-owned counters are always reset here
@@ -770,11 +770,14 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     if ((x->flags & FCAMD_EVAL_SPARSE_TANGENT) && (!x->history_mask || !x->tangent))
         return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_SPARSE_TANGENT needs history_mask and tangent");
     if (x->flags & FCAMD_EVAL_DELTA_HISTORY) {
-        if (m->law != FCAMD_VON_MISES_3D)
-            return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_DELTA_HISTORY exists for VonMises3D (eps_n is write-only there)");
+        const bool split = (x->flags & FCAMD_EVAL_SPLIT_HISTORY) != 0 && has_split_history(m->law);
+        if (m->law != FCAMD_VON_MISES_3D && !split)
+            return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_DELTA_HISTORY exists for VonMises3D and, with FCAMD_EVAL_SPLIT_HISTORY, for the "
+                                               "comfe-rs plasticity laws (their plastic-strain rows are write-only)");
         if (!x->history_mask) return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs history_mask");
-        if (x->history && x->history_prev && x->history[0] == x->history_prev[0])
-            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial eps_n array of its own");
+        const int kd = split ? 1 : 0;  // the array that accumulates plastic strain
+        if (x->history && x->history_prev && x->history[kd] == x->history_prev[kd])
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial plastic-strain array of its own");
     }
     if (!aligned16(x->grad_del_u) || !aligned16(x->stress) || !aligned16(x->stress_prev) || !aligned16(x->tangent))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
@@ -800,8 +803,8 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
 int fcamd_commit_delta_history(fcamd_model* m, int64_t n, double* history_committed0, const double* history_delta0,
                                const uint64_t* history_mask) {
     if (!m) return fail(FCAMD_ERR_BAD_ARG, "model handle is NULL");
-    if (m->law != FCAMD_VON_MISES_3D)
-        return fail(FCAMD_ERR_UNSUPPORTED, "delta trial history exists for VonMises3D only");
+    if (!has_sparse_history(m->law))
+        return fail(FCAMD_ERR_UNSUPPORTED, "delta trial history exists for the plasticity laws only");
     if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
     if (n == 0) return FCAMD_OK;
     if (!history_committed0 || !history_delta0 || !history_mask) return fail(FCAMD_ERR_BAD_ARG, "NULL array");

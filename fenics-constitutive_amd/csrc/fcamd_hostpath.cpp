@@ -623,6 +623,8 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
     if (flags & FCAMD_EVAL_DELTA_HISTORY) {  // as fcamd_evaluate_device_ex: increments must never land in the committed rows
         if (!history_mask) return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs history_mask");
+        if (m->law != FCAMD_VON_MISES_3D && !((flags & FCAMD_EVAL_SPLIT_HISTORY) && has_split_history(m->law)))
+            return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_DELTA_HISTORY: VonMises3D, or a comfe-rs plasticity law with FCAMD_EVAL_SPLIT_HISTORY");
         const int kd = (flags & FCAMD_EVAL_SPLIT_HISTORY) ? 1 : 0;  // the array that accumulates plastic strain
         if (hist && hist_prev && hist[kd] == hist_prev[kd])
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial plastic-strain array of its own");

@@ -1,0 +1,144 @@
+// History write policies of the laws with one [scalar, eps_p(6)] row per point (comfe-rs Mises, Drucker-Prager): 7-double rows
+// (the reference layout) and the split layout of device-resident states.
+// Part of the device code of libfcamd (translation unit: ../fcamd_kernels.hip, which holds the kernels and launchers).
+#pragma once
+#include "tile_io.h"
+#include "tangent_writers.h"
+
+namespace fcamd {
+
+// Delta trial history (kFlagDeltaHistory; the sparse protocol of device-resident states): the plastic-strain array of a
+// law is write-only for its stress update -- VonMises3D adds gamma N to eps_n (mises_plasticity_isotropic_hardening.py:161),
+// the comfe-rs laws add to plastic_strain (mises_plasticity.rs:112, general.rs:243) and never read it back -- so during the
+// Newton iterations of an increment the TRIAL array need not hold committed + increment.  It holds the increments of the
+// points that are plastic NOW, packed: the k-th plastic point of a tile (ascending point order) owns row k of the tile's
+// slot, rows [popcount(mask), 64) of the slot are undefined.  The launch reads no plastic-strain row at all and writes
+// popcount(mask) rows as ONE contiguous run per tile -- full lines, where the unpacked form wrote isolated 48-byte rows
+// (32-byte sectors around them: profiles/r02_von_mises_mixed_rocprof.md) -- and the commit (commit_delta_kernel, once per
+// increment) reads the run back in order.  `d`: this lane's increment (only plastic lanes contribute).
+template <bool FULL, bool NT>
+__device__ __forceinline__ void delta_rows_store(double* rows_out, long long p0, int lane, unsigned long long mask,
+                                                 bool plastic, double* region, const double (&d)[6]) {
+    if (mask == 0ull) return;
+    const int cnt = (int)__popcll(mask);
+    const int rank = (int)__popcll(mask & ((1ull << lane) - 1ull));  // plastic points before this one in the tile
+    if (plastic) lds_put_point<6>(region, rank, d);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = k * kWave + lane;
+        if (q < 3 * cnt) {
+            const d2 v = reinterpret_cast<const d2*>(region)[q];
+            if constexpr (FULL) {
+                store16<NT>(rows_out + p0 * 6 + 2 * q, v);
+            } else {  // ragged last tile: its slot ends with the array, guarded 8-byte stores
+                rows_out[p0 * 6 + 2 * q] = v.x;
+                rows_out[p0 * 6 + 2 * q + 1] = v.y;
+            }
+        }
+    }
+    wave_sync();
+}
+
+// History write policy of the laws with one [alpha, eps_p(6)] row per point (comfe-rs Mises and
+// Drucker-Prager; the row is always READ: alpha enters the yield function).  Which rows change:
+//   in place                      : the plastic points of this evaluate (ballot `mask`);
+//   out of place                  : every row is copied;
+//   out of place, sparse protocol : (a.hmask != nullptr, see tile_von_mises) the trial array equals the
+//                                   committed one wherever the tile's mask word is clear, so the rows
+//                                   of the points that are plastic now (new values) or were plastic at
+//                                   the previous evaluate (stale: restore the committed values).
+// Row-masked tile store: the tile keeps its four wave-wide, address-ordered store instructions and a
+// lane skips the 16-byte chunks that lie entirely in untouched rows (chunk q holds doubles 2q and
+// 2q + 1 of the tile image, i.e. parts of rows 2q / 7 and (2q + 1) / 7; a chunk straddling a touched
+// and an untouched row rewrites 8 bytes of the latter with the value it already has).
+// plastic | formerly plastic points of the tile under the sparse protocol; records the new ballot
+__device__ __forceinline__ unsigned long long sparse_need(const EvalArgs& a, long long p0, unsigned long long mask,
+                                                          int lane) {
+    if (a.hmask == nullptr) return mask;
+    const unsigned long long m_old = a.hmask[p0 >> 6];
+    if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
+    return mask | m_old;
+}
+
+// `touched`: sparse_need() of the tile
+template <bool FULL, bool NT>
+__device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, int npts, int lane,
+                                               unsigned long long touched, bool hist_in_place, double* region,
+                                               const double (&h)[7]) {
+    const unsigned long long need = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
+    if (need == 0ull) return;
+    if (!FULL || need == ~0ull || (int)__popcll(need) > a.masked_max) {
+        transpose_out<7, FULL, NT>(h, region, lane, a.h0_out + p0 * 7, npts * 7);
+        return;
+    }
+    lds_put_point<7>(region, lane, h);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < Chunks<7>::K; ++k) {
+        const int q = k * kWave + lane;
+        const bool hit = (((need >> ((2 * q) / 7)) | (need >> ((2 * q + 1) / 7))) & 1ull) != 0ull;
+        if (chunk_live<7>(k, lane) && hit)
+            store16<NT>(a.h0_out + p0 * 7 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+    }
+    wave_sync();
+}
+
+// Split history (kFlagSplitHistory): the scalar of every point of a touched tile and the rows `rows` of the
+// plastic-strain array, rows_out = rows_in + delta (delta = 0 at points that are not plastic: they get their committed
+// values back).  Which rows, by protocol, as in history7_store.  Row-masked access as in tile_von_mises (a 48-byte row
+// is three 16-byte chunks of the tile image).
+template <bool FULL, bool NT>
+__device__ __forceinline__ void split_history_store(const EvalArgs& a, long long p0, int npts, int lane, unsigned long long mask,
+                                                    unsigned long long touched, bool hist_in_place, double* region,
+                                                    double scalar, const double (&delta)[6]) {
+    const bool live = FULL || lane < npts;
+    const unsigned long long rows = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
+    if (rows == 0ull) return;
+    if (live) a.h0_out[p0 + lane] = scalar;  // one coalesced 512-byte store per touched tile
+    if ((a.flags & kFlagDeltaHistory) != 0 && a.hmask != nullptr) {  // the increments of the plastic points, packed; nothing is read
+        delta_rows_store<FULL, NT>(a.h1_out, p0, lane, mask, live && ((mask >> lane) & 1ull) != 0ull, region, delta);
+        return;
+    }
+    const bool masked = FULL && rows != ~0ull && (int)__popcll(rows) <= a.masked_max;
+    Chunks<6> ce;
+    bool row_live[3] = {true, true, true};
+    if (masked) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            row_live[k] = ((rows >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
+            d2 z;
+            z.x = 0.0;
+            z.y = 0.0;
+            ce.v[k] = row_live[k] ? load16<NT>(a.h1_in + p0 * 6 + 2 * (k * kWave + lane)) : z;
+        }
+    } else {
+        tile_load<6, FULL, NT>(ce, a.h1_in + p0 * 6, npts * 6, lane);
+    }
+    if (mask != 0ull) {
+        double ep[6];
+        transpose_in<6>(ce, region, lane, ep);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + delta[i];
+        if (masked) {
+            lds_put_point<6>(region, lane, ep);
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int q = k * kWave + lane;
+                if (row_live[k]) store16<NT>(a.h1_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+            }
+            wave_sync();
+        } else {
+            transpose_out<6, FULL, NT>(ep, region, lane, a.h1_out + p0 * 6, npts * 6);
+        }
+    } else if (masked) {  // only stale rows: restore the committed values
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (row_live[k]) store16<NT>(a.h1_out + p0 * 6 + 2 * (k * kWave + lane), ce.v[k]);
+    } else if (!hist_in_place) {
+        tile_store<6, FULL, NT>(ce, a.h1_out + p0 * 6, npts * 6, lane);
+    }
+}
+
+}  // namespace fcamd

@@ -1,0 +1,264 @@
+// VonMises3D (models/mises_plasticity_isotropic_hardening.py:57-175): point functions, the 3-D tile, the fused wrapper tile.
+// Part of the device code of libfcamd (translation unit: ../fcamd_kernels.hip, which holds the kernels and launchers).
+#pragma once
+#include "tile_io.h"
+#include "tangent_writers.h"
+#include "wrapped_io.h"
+#include "history_rows.h"
+
+namespace fcamd {
+
+// ---------------------------------------------------------------------------------------
+// Point arithmetic of the two Mises laws, shared by the 3-D tiles and the fused 3D -> 1D/2D wrapper tiles
+// (tile_von_mises / tile_von_mises_wrapped, tile_comfe_mises / tile_comfe_mises_wrapped): every statement
+// of the reference exists once.  Everything is per lane and forced inline.
+// ---------------------------------------------------------------------------------------
+
+// VonMises3D (models/mises_plasticity_isotropic_hardening.py:75-94): trial state of one point
+struct VMTrial {
+    double dsig[6], sigtr[6];  // del_sigtr = 2 mu dev(d_eps), sigtr = dev(sigma_n) + del_sigtr
+    double tr_eps, sigtrn, phitr;
+};
+
+__device__ __forceinline__ void vm_trial(const Scalars& sc, const double (&e)[6], const double (&s)[6], double alpha_n,
+                                         VMTrial& t) {
+    const double two_mu = sc.s[2], s23 = sc.s[3], y0 = sc.s[4], dy = sc.s[5], mw = sc.s[6];
+    t.tr_eps = (e[0] + e[1]) + e[2];
+    const double tr_sig = (s[0] + s[1]) + s[2];
+    const double tr_eps3 = t.tr_eps / 3.0, tr_sig3 = tr_sig / 3.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double ed = i < 3 ? e[i] - tr_eps3 : e[i];
+        const double sd = i < 3 ? s[i] - tr_sig3 : s[i];
+        t.dsig[i] = two_mu * ed;
+        t.sigtr[i] = sd + t.dsig[i];
+    }
+    double nn = t.sigtr[0] * t.sigtr[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) nn = __builtin_fma(t.sigtr[i], t.sigtr[i], nn);  // np.dot == fma chain
+    t.sigtrn = sqrt(nn);
+    t.phitr = t.sigtrn - s23 * (y0 + dy * (1.0 - exp(mw * alpha_n)));
+}
+
+// return mapping of one plastic point (:98-151): Newton on the plastic multiplier with the reference's
+// stopping rule (it tests the residual of the PREVIOUS iterate, so one more update follows convergence)
+struct VMReturn {
+    double gamma = 0.0, xc1 = 0.0, xc2 = 0.0;
+    double N[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+};
+
+__device__ __forceinline__ void vm_return(const Scalars& sc, const VMTrial& t, double alpha_n, VMReturn& r, WaveStats& st) {
+    const double two_mu = sc.s[2], s23 = sc.s[3], y0 = sc.s[4], dy = sc.s[5], mw = sc.s[6], m2mu = sc.s[7], c23dyw = sc.s[8];
+    double g0 = 1.0, g1 = 0.0, xr = 1.0, xg;
+    int it = 0;
+    bool failed = false;
+    while (__builtin_fabs(xr) > 1e-12 && __builtin_fabs(g1 - g0) > 1e-8 * __builtin_fabs(g1)) {
+        g0 = g1;
+        ++it;
+        const double ex = exp(mw * (alpha_n + s23 * g0));
+        xr = (t.sigtrn - two_mu * g0) - s23 * (y0 + dy * (1.0 - ex));
+        xg = m2mu - c23dyw * ex;
+        g1 = g0 - xr / xg;
+        if (it > 100) {
+            failed = true;
+            break;
+        }
+    }
+    const double ex = exp(mw * (alpha_n + s23 * g1));
+    xg = m2mu - c23dyw * ex;
+    r.xc1 = -1.0 / xg;
+    r.xc2 = g1 / t.sigtrn;
+    r.gamma = g1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.N[i] = t.sigtr[i] / t.sigtrn;
+    st.iters += (unsigned long long)it;
+    st.nonconv += failed ? 1ull : 0ull;
+}
+
+// stress (:165-167): sigma += (ka tr_eps) I2 + del_sigtr - (2 mu gamma) N;  tangent coefficients (:170-175)
+__device__ __forceinline__ void vm_stress(const Scalars& sc, const VMTrial& t, const VMReturn& r, double (&s)[6]) {
+    const double kt = sc.s[1] * t.tr_eps, tmg = sc.s[2] * r.gamma;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double vol = i < 3 ? kt : kt * 0.0;
+        s[i] = s[i] + ((vol + t.dsig[i]) - tmg * r.N[i]);
+    }
+}
+__device__ __forceinline__ void vm_tangent_coefficients(const Scalars& sc, const VMReturn& r, double& B, double& C) {
+    const double two_mu = sc.s[2], four_mu2 = sc.s[9];
+    B = two_mu * (1.0 - two_mu * r.xc2);
+    C = four_mu2 * (r.xc2 - r.xc1);
+}
+
+// --- VonMises3D: J2 plasticity, saturation hardening, scalar Newton per point -----------------
+// scalars: s[0]=strain factor, s[1]=ka, s[2]=2*mu, s[3]=sqrt(2/3), s[4]=y0, s[5]=y00-y0,
+//          s[6]=-w, s[7]=(-2)*mu, s[8]=((2/3)*(y00-y0))*w, s[9]=(4*mu)*mu
+// tables:  a = ka*xioi, b = xpp
+template <bool IDX, bool SPARSE, bool FULL, bool NT>
+__device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
+                                               int* rows_lds, long long p0, int npts, int lane,
+                                               WaveStats& st) {
+    Chunks<9> cg;
+    StressRows<IDX, FULL, NT> sr;
+    tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
+    sr.load(a, sb, p0, npts, lane, rows_lds);
+    const bool live = FULL || lane < npts;
+    const double alpha_n = live ? a.h1_in[p0 + lane] : 0.0;
+    const bool hist_in_place = (a.h0_in == a.h0_out) && (a.h1_in == a.h1_out);
+
+    double g[9], s[6], e[6];
+    transpose_in<9>(cg, region, lane, g);
+    sr.get(region, lane, s);
+    mandel_strain(g, a.sc.s[0], e);
+
+    VMTrial tr;
+    vm_trial(a.sc, e, s, alpha_n, tr);
+    const bool plastic = live && (tr.phitr > 0.0);
+    const unsigned long long mask = __ballot(plastic);
+
+    // plastic-strain history: needed only by tiles with a plastic point (in place), or always
+    // when the trial history lives in a different array (out of place).
+    //
+    // Sparse trial history (a.hmask != nullptr; device-resident Newton loops): the trial arrays
+    // are kept equal to the committed ones except at the points recorded in hmask (one 64-bit
+    // word per tile = the plastic ballot of the previous evaluate).  Then only plastic points
+    // (new trial value) and stale points (plastic last time, elastic now: restore the committed
+    // value) need their 48-byte eps_n row touched; elastic points cost no history traffic at all,
+    // which is exactly the algorithmic byte count (464 B/pt elastic, 568 B/pt plastic).  The plain
+    // in-place call (the reference contract) is the same case without stale points.
+    //
+    // Row-masked tile access: a 48-byte row is exactly three 16-byte chunks of the tile's linear
+    // image (chunk q belongs to row q / 3), so the tile keeps its three wave-wide, address-ordered
+    // load and store instructions and every lane simply skips the chunks of untouched rows.  HBM
+    // sees the touched rows only (reads at the 128-byte line granularity of the memory side), the
+    // instruction count does not depend on how many rows are touched, and a fully plastic tile
+    // degenerates to the plain coalesced tile access.
+    Chunks<6> ce;
+    constexpr bool sparse = SPARSE;
+    unsigned long long m_old = 0ull;
+    if constexpr (sparse) m_old = a.hmask[p0 >> 6];
+    const unsigned long long need_mask = mask | m_old;
+    // delta trial history: only the rows of points that are plastic NOW are written (their increment), nothing is read
+    const bool delta = sparse && (a.flags & kFlagDeltaHistory) != 0;
+    const unsigned long long eps_mask = delta ? mask : need_mask;
+    const bool masked = FULL && (sparse || hist_in_place) && ((int)__popcll(eps_mask) <= a.masked_max);
+    const bool touch_eps = masked ? (eps_mask != 0ull)
+                                  : (sparse ? (eps_mask != 0ull) : ((mask != 0ull) || !hist_in_place));
+    const bool touch_alpha = delta ? (need_mask != 0ull) : touch_eps;  // stale points get their committed alpha back
+    bool row_live[3] = {true, true, true};  // per chunk of this lane: its row is touched
+    if (masked) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) row_live[k] = ((eps_mask >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
+    }
+    if (!delta && touch_eps) {
+        if (masked) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d2 z;
+                z.x = 0.0;
+                z.y = 0.0;
+                ce.v[k] = row_live[k] ? load16<NT>(a.h0_in + p0 * 6 + 2 * (k * kWave + lane)) : z;
+            }
+        } else {
+            tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
+        }
+    }
+
+    VMReturn rm;
+    if (mask != 0ull) {
+        if (plastic) vm_return(a.sc, tr, alpha_n, rm, st);
+        st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
+    }
+
+    vm_stress(a.sc, tr, rm, s);
+    sr.put(sb, region, lane, s, p0, npts);
+
+    // history: eps_n += gamma N ; alpha += sqrt(2/3) gamma
+    if (delta) {  // the increment of the plastic points, packed at the head of the tile's slot (delta_rows_store)
+        double ep[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ep[i] = 0.0 + rm.gamma * rm.N[i];
+        delta_rows_store<FULL, NT>(a.h0_out, p0, lane, mask, plastic, region, ep);
+    } else if (touch_eps) {
+        if (mask != 0ull) {
+            double ep[6];
+            transpose_in<6>(ce, region, lane, ep);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ep[i] = ep[i] + rm.gamma * rm.N[i];
+            if (masked) {
+                lds_put_point<6>(region, lane, ep);
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int q = k * kWave + lane;
+                    if (row_live[k]) store16<NT>(a.h0_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+                }
+                wave_sync();
+            } else {
+                transpose_out<6, FULL, NT>(ep, region, lane, a.h0_out + p0 * 6, npts * 6);
+            }
+        } else if (masked) {  // only stale rows: restore the committed values
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (row_live[k]) store16<NT>(a.h0_out + p0 * 6 + 2 * (k * kWave + lane), ce.v[k]);
+        } else {
+            tile_store<6, FULL, NT>(ce, a.h0_out + p0 * 6, npts * 6, lane);
+        }
+    }
+    // alpha: one coalesced 512-byte store per touched tile
+    if (touch_alpha && live) a.h1_out[p0 + lane] = alpha_n + a.sc.s[3] * rm.gamma;
+    if constexpr (sparse) {
+        if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
+    }
+
+    // tangent: ka xioi + 2 mu (1 - 2 mu xc2) xpp + 4 mu^2 (xc2 - xc1) N (x) N
+    const unsigned long long tneed = sparse_tangent_need<FULL>(a, need_mask);
+    if (sb.tan && tneed != 0ull) {
+        double B, C;
+        vm_tangent_coefficients(a.sc, rm, B, C);
+        publish_tangent_params(region, lane, B, C, rm.N);
+        wave_sync();
+        tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed);
+        wave_sync();
+    }
+}
+
+template <int WRAP, bool FULL, bool NT>
+__device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const Tables* T, double* region,
+                                                       long long p0, int npts, int lane, WaveStats& st) {
+    const bool live = FULL || lane < npts;
+    double g[9], s[6], e[6];
+    const double alpha_n = live ? a.h1_in[p0 + lane] : 0.0;
+    wrapped_load<WRAP, FULL, NT>(a, region, p0, npts, lane, g, s);
+    mandel_strain(g, a.sc.s[0], e);
+
+    VMTrial tr;
+    vm_trial(a.sc, e, s, alpha_n, tr);
+    const bool plastic = live && (tr.phitr > 0.0);
+    const unsigned long long mask = __ballot(plastic);
+
+    Chunks<6> ce;
+    if (mask != 0ull) tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
+    VMReturn rm;
+    if (mask != 0ull) {
+        if (plastic) vm_return(a.sc, tr, alpha_n, rm, st);
+        st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
+    }
+    vm_stress(a.sc, tr, rm, s);
+    wrapped_store_stress<WRAP, FULL, NT>(a, region, p0, npts, lane, s);
+    if (mask != 0ull) {
+        double ep[6];
+        transpose_in<6>(ce, region, lane, ep);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + rm.gamma * rm.N[i];
+        transpose_out<6, FULL, NT>(ep, region, lane, a.h0_out + p0 * 6, npts * 6);
+        if (live) a.h1_out[p0 + lane] = alpha_n + a.sc.s[3] * rm.gamma;
+    }
+    if (a.tangent) {
+        double B, C;
+        vm_tangent_coefficients(a.sc, rm, B, C);
+        wrapped_tangent_mises<false, WRAP, FULL, NT>(a, T, region, p0, npts, lane, B, C, rm.N);
+    }
+}
+
+}  // namespace fcamd

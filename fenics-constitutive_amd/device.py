@@ -352,8 +352,9 @@ class DeviceLaw(IncrSmallStrainModel):
             counters_ptr=_counters_ptr(counters))
 
     def commit_delta_history(self, committed, delta, history_mask) -> None:
-        """``committed[row] += delta[row]`` for the rows of ``history_mask`` (``fcamd_commit_delta_history``): the
-        commit of a trial ``eps_n`` array written with ``delta_history=True``.  Asynchronous on torch's current stream."""
+        """``committed[row] += increment`` for the points of ``history_mask`` (``fcamd_commit_delta_history``): the commit of
+        a trial plastic-strain array written with ``delta_history=True`` (increments packed per tile).  Asynchronous on
+        torch's current stream."""
         _check_torch("committed", committed), _check_torch("delta", delta)
         n = committed.numel() // 6
         assert delta.numel() == committed.numel() and history_mask.numel() >= (n + 63) // 64

@@ -36,6 +36,10 @@ class ResidentState:
     #: device-assembler mode: place the state's arrays on the first ``evaluate`` when the tangent is at
     #: least this large (below, launches are latency-bound and the placement does not show)
     AUTO_TUNE_MIN_BYTES = 256 << 20
+    #: ``delta_history="auto"``: switch the delta trial history on when the running mean of the evaluates per increment
+    #: reaches this (the measured break-even, bench.py "delta_trial_history"), off again below ``DELTA_OFF_ITERATIONS``
+    DELTA_MIN_ITERATIONS = 3.0
+    DELTA_OFF_ITERATIONS = 2.5
 
     def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
                  reuse_constant_tangent: bool = True, sparse_tangent: bool = True, placement: str = "auto",
@@ -50,13 +54,16 @@ class ResidentState:
         import torch
 
         assert placement in ("auto", "vmm", "tune", "torch")
-        # ``delta_history`` (opt-in; VonMises3D with the sparse protocol): ``eps_n`` is write-only for the stress update
-        # (mises_plasticity_isotropic_hardening.py:161 only adds gamma N to it), so the trial array can hold the INCREMENT
-        # of the plastic points during the Newton iterations: the committed rows are then never read by ``evaluate``
-        # (-0.5 ms of 8.5 ms per launch at 1e8 points, 22-31 % plastic) and ``update()`` adds the increments of the plastic
-        # points to the committed array (one scattered pass, 2.0 ms at 1e8 points).  Measured break-even: 4 Newton
-        # iterations per increment (bench.py "delta_trial_history") -- a gain for long Newton loops only, hence not the
-        # default.  ``history`` (the trial view) assembles eps_n on demand.
+        # ``delta_history`` (VonMises3D and -- with ``split_history`` -- the comfe-rs plasticity laws, under the sparse
+        # protocol): the plastic-strain array is write-only for the stress update (mises_plasticity_isotropic_hardening.py:161,
+        # mises_plasticity.rs:112, general.rs:243 only accumulate it), so the trial array can hold the INCREMENTS of the
+        # plastic points during the Newton iterations, packed per tile: ``evaluate`` then reads no plastic-strain row and
+        # writes contiguous runs, and ``update()`` adds the increments to the committed rows (one pass per increment, the
+        # commit kernel).  It moves work from every Newton iteration to the commit, so it pays from ``DELTA_MIN_ITERATIONS``
+        # iterations per increment on (bench.py "delta_trial_history": evaluate / commit kernel times, break-even).
+        # True: always; "auto": the state watches how many evaluates its increments take and switches the protocol at
+        # increment boundaries (one full-history evaluate when it goes back to the plain protocol); False (default): never.
+        # ``history`` (the trial view) assembles the rows on demand.
 
         # ``split_history`` (the comfe-rs plasticity laws, with the sparse protocol): the reference keeps one
         # [scalar, eps_p(6)] row of 7 doubles per point (``history_dim = {"history": 7}``), so every point pays 56 bytes
@@ -95,7 +102,14 @@ class ResidentState:
         if sparse_history and type(law).__name__ in ("VonMises3D", "MisesPlasticityLinearHardening3D",
                                                      "DruckerPrager3D", "DruckerPragerHyperbolic3D"):
             self._mask = torch.zeros((self.n + 63) // 64, dtype=torch.int64, device=self.device)
-        self._delta = bool(delta_history) and self._mask is not None and type(law).__name__ == "VonMises3D"
+        # Delta trial history needs a plastic-strain array of its own: VonMises3D's eps_n, the split laws' eps_p rows.
+        self._delta_key = "eps_n" if type(law).__name__ == "VonMises3D" else ("rows" if self._split else None)
+        capable = self._mask is not None and self._delta_key is not None
+        assert delta_history in (False, True, "auto"), "delta_history: False, True or 'auto'"
+        self._delta_auto = capable and delta_history == "auto"
+        self._delta = capable and delta_history is True
+        self._n_eval = 0          # evaluates of the increment in progress (Newton iterations)
+        self._iters_ema = None    # running mean of the Newton iterations per increment ("auto")
         self._evaluated = False
         # Linear elasticity and the SLS laws have one tangent for all points, a function of the
         # parameters (and del_t) only -- the reference tiles it into the array on every call
@@ -197,25 +211,29 @@ class ResidentState:
 
     @property
     def history(self):
-        """Trial history.  Under the delta protocol (VonMises3D) ``eps_n`` is assembled here from the committed
+        """Trial history.  Under the delta protocol the plastic-strain array is assembled here from the committed
         array and the increments of the currently plastic points (a copy: the state keeps the increments)."""
         if self._hist is None:
             return None
         trial = self._hist[1 - self._c]
         if not self._delta:
             return self._external_history(trial)
+        key = self._delta_key
         if not self._evaluated:  # nothing evaluated in this increment yet: the trial state is the committed one
-            return {**trial, "eps_n": self._hist[self._c]["eps_n"]}
+            return self._external_history({**trial, key: self._hist[self._c][key]})
         import torch
 
+        # committed rows + the increments of the currently plastic points, which lie packed at the head of every tile's
+        # slot of the trial array (include/fcamd.h, FCAMD_EVAL_DELTA_HISTORY): the k-th set bit of a tile's mask word
+        # owns row 64 tile + k
         n = self.n
         shifts = torch.arange(64, device=self.device, dtype=torch.int64)
-        bits = ((self._mask[:, None] >> shifts[None, :]) & 1).reshape(-1)[:n].to(torch.float64)
-        eps = self._hist[self._c]["eps_n"].view(n, 6) + trial["eps_n"].view(n, 6) * bits[:, None]
-        # rows of elastic points hold whatever the array held before: multiplied by an exact 0.0 they could still
-        # inject NaN / inf -- mask them out explicitly
-        eps = torch.where(bits[:, None] != 0, eps, self._hist[self._c]["eps_n"].view(n, 6))
-        return {**trial, "eps_n": eps.reshape(-1)}
+        bits = (self._mask[:, None] >> shifts[None, :]) & 1  # [tiles, 64]
+        src = (torch.arange(bits.shape[0], device=self.device)[:, None] * 64 + torch.cumsum(bits, dim=1) - 1).reshape(-1)[:n]
+        sel = bits.reshape(-1)[:n].bool()
+        rows = self._hist[self._c][key].view(n, 6).clone()
+        rows[sel] = rows[sel] + trial[key].view(n, 6)[src[sel]]
+        return self._external_history({**trial, key: rows.reshape(-1)})
 
     def set_state(self, stress=None, history=None) -> None:
         """(Re)initialise the committed state -- initial conditions, a restart -- from NumPy arrays or device
@@ -275,6 +293,7 @@ class ResidentState:
         self._tangent_key = key
         self._tangent_target = "dev"
         self._evaluated = True
+        self._n_eval += 1
         self._stats_pending = self._counts
 
     def prepare(self, t: float, del_t: float, grad_del_u) -> None:
@@ -424,6 +443,7 @@ class ResidentState:
         hp = [] if self._hist is None else [self._hist[self._c][k].data_ptr() for k, _ in fields]
         hc = [] if self._hist is None else [self._hist[1 - self._c][k].data_ptr() for k, _ in fields]
         self._evaluated = True  # the trial state is touched even if the call raises
+        self._n_eval += 1
         # sparse tangent: only into the very array that received the previous evaluate's tangent, and only
         # when the kernel writes it directly (page-locked array; the C side ignores the flag otherwise --
         # then every row is downloaded and the array is current as well)
@@ -474,13 +494,31 @@ class ResidentState:
             raise RuntimeError(f"the last evaluate failed, nothing to commit: {self._failed}")
         self.check()
         if self._delta:
-            # eps_n: add the increments of the plastic points to the committed array (it stays the committed one: the two
-            # dicts exchange their eps_n tensors, so that the flip below leaves it on the committed side)
+            # plastic strain: add the increments of the plastic points to the committed array (it stays the committed one:
+            # the two dicts exchange the tensors, so that the flip below leaves it on the committed side)
+            key = self._delta_key
             c, t = self._hist[self._c], self._hist[1 - self._c]
-            self.law.commit_delta_history(c["eps_n"], t["eps_n"], self._mask)
-            c["eps_n"], t["eps_n"] = t["eps_n"], c["eps_n"]
+            self.law.commit_delta_history(c[key], t[key], self._mask)
+            c[key], t[key] = t[key], c[key]
         self._c = 1 - self._c
         self._evaluated = False
+        if self._delta_auto:
+            self._adapt_delta()
+        self._n_eval = 0
+
+    def _adapt_delta(self) -> None:
+        """``delta_history="auto"``, at an increment boundary: the delta protocol pays when the commit kernel is spread over
+        enough Newton iterations; the state has just seen how many this increment took."""
+        it = float(self._n_eval)
+        self._iters_ema = it if self._iters_ema is None else 0.5 * self._iters_ema + 0.5 * it
+        if not self._delta and self._iters_ema >= self.DELTA_MIN_ITERATIONS:
+            self._delta = True  # the trial rows become the packed increments; nothing of them is read
+        elif self._delta and self._iters_ema < self.DELTA_OFF_ITERATIONS:
+            # back to the plain sparse protocol, whose contract is "trial == committed wherever the mask is clear": the trial
+            # rows hold increments now, so every row is declared stale -- the next evaluate rewrites the whole trial history
+            # (and tangent) once
+            self._delta = False
+            self._mask.fill_(-1)
 
     # host access ------------------------------------------------------------------------------------
     def download(self, stress: np.ndarray | None = None, tangent: np.ndarray | None = None,

@@ -233,13 +233,17 @@ typedef struct fcamd_eval_args {
    evaluate are written; rows of points that stay elastic -- 288 of their 464 bytes -- are not touched.
    Same array contents as without the flag (tests/test_gpu_resident.py). */
 #define FCAMD_EVAL_SPARSE_TANGENT 1
-/* Delta trial history (VonMises3D, needs history_mask and a trial eps_n array of its own): `eps_n` is write-only
-   with respect to the stress update (models/mises_plasticity_isotropic_hardening.py:161 only accumulates it), so
-   during the Newton iterations of a device-resident increment the trial array need not hold eps_n + gamma N: with
-   this flag history[0] receives the INCREMENT gamma N at the points of the mask written by the call (the plastic
-   points) and is not defined elsewhere, and history_prev[0] is not read at all -- 28 of the 156 bytes read per point
-   on a random 22 % mixture.  The commit of the increment is fcamd_commit_delta_history (instead of swapping the
-   eps_n pointers); alpha (history[1]) keeps its usual meaning.  Every other result of the call is unchanged. */
+/* Delta trial history (needs history_mask and a trial plastic-strain array of its own; VonMises3D: history[0] = eps_n;
+   the comfe-rs plasticity laws with FCAMD_EVAL_SPLIT_HISTORY: history[1] = the eps_p rows).  The plastic-strain array of
+   these laws is write-only with respect to the stress update (models/mises_plasticity_isotropic_hardening.py:161,
+   comfe-rs/src/mises_plasticity.rs:112, plasticity/general.rs:243 only accumulate it), so during the Newton iterations
+   of a device-resident increment the trial array need not hold committed + increment: with this flag it receives the
+   INCREMENTS of the points that are plastic in this call, PACKED per 64-point tile -- the k-th plastic point of tile t
+   (ascending point order, bit k-th set in history_mask[t] after the call) owns doubles [6 (64 t + k), 6 (64 t + k) + 6);
+   the other rows of the tile's slot are undefined -- and the committed rows are not read at all: 28 of the 156 bytes
+   read per point on a random 22 % mixture, and the written rows leave as one contiguous run per tile instead of isolated
+   48-byte rows.  The commit of the increment is fcamd_commit_delta_history (instead of swapping the plastic-strain
+   pointers); the scalar history (alpha / kappa) keeps its usual meaning.  Every other result of the call is unchanged. */
 #define FCAMD_EVAL_DELTA_HISTORY 2
 /* Split history (the laws whose reference history is ONE [scalar, eps_p(6)] row of 7 doubles per point: comfe-rs
    MisesPlasticity3D -- alpha --, DruckerPrager3D / DruckerPragerHyperbolic3D -- the hardening variable;
@@ -252,10 +256,10 @@ typedef struct fcamd_eval_args {
 #define FCAMD_EVAL_SPLIT_HISTORY 4
 int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_t, int64_t n,
                              const fcamd_eval_args* args);
-/* history_committed0[row] += history_delta0[row] for the rows set in history_mask (the mask left by the last
-   evaluate with FCAMD_EVAL_DELTA_HISTORY): the commit of a delta trial history.  Asynchronous on the context's
-   stream.  The mask is not modified. */
-int fcamd_commit_delta_history(fcamd_model* model, int64_t n, double* history_committed0, const double* history_delta0,
+/* The commit of a delta trial history: committed_rows[6 p .. 6 p + 6) += the increment of point p, for the points set in
+   history_mask (the mask left by the last evaluate with FCAMD_EVAL_DELTA_HISTORY), read from the packed layout that
+   evaluate wrote into `delta_rows`.  Asynchronous on the context's stream.  The mask is not modified. */
+int fcamd_commit_delta_history(fcamd_model* model, int64_t n, double* committed_rows, const double* delta_rows,
                                const uint64_t* history_mask);
 
 /* Host evaluate: the ndarray entry.  Pointers are host arrays laid out as above; results are
@@ -300,7 +304,7 @@ int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
    fcamd_evaluate_device_from_sparse (plasticity laws).  `flags`: FCAMD_EVAL_SPARSE_TANGENT applies the
    sparse-tangent protocol to `tangent_host` when the kernel writes it directly: only the rows of
    plastic / formerly plastic points cross PCIe (the caller's array must still hold the previous
-   call's tangent); ignored on the chunked and scratch paths, which write every row.  FCAMD_EVAL_DELTA_HISTORY (VonMises3D, with history_mask) as in fcamd_evaluate_device_ex.  Synchronous; waits for work queued on the
+   call's tangent); ignored on the chunked and scratch paths, which write every row.  FCAMD_EVAL_DELTA_HISTORY (with history_mask) as in fcamd_evaluate_device_ex.  Synchronous; waits for work queued on the
    context stream before touching the state arrays.  Status and `stats` as fcamd_evaluate_host. */
 int fcamd_evaluate_resident(fcamd_model* model, double t, double del_t, int64_t n,
                             const double* grad_del_u_host, const double* stress_prev,

@@ -351,20 +351,23 @@ def test_vmm_placement_moves_the_state_and_keeps_results(numpy_grad):
     assert torch.equal(keep, ref)  # the view keeps the working set's memory alive
 
 
+@pytest.mark.parametrize("law_name", ["VonMises3D", "MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D"])
 @pytest.mark.parametrize("n", [64 * 30 + 11, 4000])
-def test_delta_trial_history_equals_the_plain_protocols(n):
-    """Delta trial history (FCAMD_EVAL_DELTA_HISTORY, ResidentState(delta_history=True), VonMises3D): during the Newton
-    iterations the trial eps_n array holds only the increments of the plastic points and the committed rows are never
-    read; update() adds them to the committed array.  Stress, tangent, alpha, the assembled trial eps_n and every
-    committed state must equal the sparse protocol without it and the full protocol bit for bit, over growing,
-    shrinking and vanishing plastic sets, device and host-assembler calls."""
+def test_delta_trial_history_equals_the_plain_protocols(n, law_name):
+    """Delta trial history (FCAMD_EVAL_DELTA_HISTORY, ResidentState(delta_history=True); VonMises3D's eps_n and the eps_p rows
+    of the comfe-rs laws under the split layout): during the Newton iterations the trial plastic-strain array holds only
+    the increments of the plastic points, packed per tile, and the committed rows are never read; update() adds them to
+    the committed array.  Stress, tangent, the scalar history, the assembled trial plastic strain and every committed state
+    must equal the sparse protocol without it and the full protocol bit for bit, over growing, shrinking and vanishing
+    plastic sets, device and host-assembler calls."""
     rng = np.random.default_rng(n)
-    law, s0, h0, grad = _sparse_case("VonMises3D", n, rng)
-    d = ResidentState(law, n, stress0=s0, history0=h0, delta_history=True)           # increments in the trial eps_n array
-    p = ResidentState(law, n, stress0=s0, history0=h0)                               # sparse (default), eps_n + gamma N in the trial array
+    law, s0, h0, grad = _sparse_case(law_name, n, rng)
+    d = ResidentState(law, n, stress0=s0, history0=h0, delta_history=True)           # packed increments in the trial array
+    p = ResidentState(law, n, stress0=s0, history0=h0)                               # sparse (default), committed + increment in the trial array
     f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False)
     assert d._delta and not p._delta and not f._delta
     sh, th = np.empty(6 * n), np.empty(36 * n)
+    n_plastic = []
     for inc in range(5):
         for it in range(3):
             g = grad(all_elastic=(inc == 2 and it == 1), zoned=(inc % 2 == 1))
@@ -374,6 +377,7 @@ def test_delta_trial_history_equals_the_plain_protocols(n):
                 d.evaluate(0.0, 1.0, g)
             p.evaluate(0.0, 1.0, g)
             f.evaluate(0.0, 1.0, g)
+            n_plastic.append(int(f.check().n_plastic))
             assert torch.equal(d.stress, f.stress) and torch.equal(p.stress, f.stress), (inc, it)
             if (inc, it) == (3, 1):
                 assert np.array_equal(th, f.tangent.cpu().numpy()) and np.array_equal(sh, f.stress.cpu().numpy())
@@ -385,19 +389,49 @@ def test_delta_trial_history_equals_the_plain_protocols(n):
         d.update(), p.update(), f.update()
         for k in h0:
             assert torch.equal(d.history_committed[k], f.history_committed[k]), (inc, k)
-            assert torch.equal(d.history[k], f.history_committed[k]) or k != "eps_n"  # nothing evaluated yet: trial == committed
-    # the flag is VonMises3D's: other laws refuse it, and it needs a trial array of its own
-    rs, s1, h1, grad1 = _sparse_case("MisesPlasticityLinearHardening3D", n, rng)
-    st = ResidentState(rs, n, stress0=s1, history0=h1, delta_history=True)
-    assert not st._delta
+            # nothing evaluated yet: the assembled trial plastic strain is the committed one (the scalar history of stale
+            # points is restored by the next evaluate, as under the plain sparse protocol)
+            assert torch.equal(d.history[k], f.history_committed[k]) or k != "eps_n"
+    assert max(n_plastic) > 0.1 * n
     mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
-    g = grad1(all_elastic=False, zoned=False)
-    with pytest.raises(NotImplementedError, match="DELTA_HISTORY"):
-        rs.evaluate_from(0.0, 1.0, g, st.stress_committed, st.stress, st.tangent, st.history_committed, st.history,
-                         history_mask=mask, delta_history=True)
-    with pytest.raises(ValueError, match="trial eps_n array of its own"):
-        law.evaluate_from(0.0, 1.0, grad(all_elastic=False, zoned=False), f.stress_committed, f.stress, f.tangent,
-                          f.history_committed, f.history_committed, history_mask=mask, delta_history=True)
+    if law_name == "VonMises3D":
+        with pytest.raises(ValueError, match="plastic-strain array of its own"):
+            law.evaluate_from(0.0, 1.0, grad(all_elastic=False, zoned=False), f.stress_committed, f.stress, f.tangent,
+                              f.history_committed, f.history_committed, history_mask=mask, delta_history=True)
+    else:
+        # 7-double rows (no split layout): the scalar sits inside the row, there is no write-only array -- refused
+        st = ResidentState(law, n, stress0=s0, history0=h0, delta_history=True, split_history=False)
+        assert not st._delta
+        with pytest.raises(NotImplementedError, match="DELTA_HISTORY"):
+            law.evaluate_from(0.0, 1.0, grad(all_elastic=False, zoned=False), st.stress_committed, st.stress, st.tangent,
+                              st.history_committed, st.history, history_mask=mask, delta_history=True)
+
+
+@pytest.mark.parametrize("law_name", ["VonMises3D", "DruckerPrager3D"])
+def test_delta_trial_history_switches_itself_on_and_off(law_name):
+    """``delta_history="auto"``: increments of four Newton iterations switch the delta protocol on at the next increment
+    boundary, increments of one iteration switch it off again (one full-history evaluate restores the plain protocol's
+    contract) -- and through all of it the state equals the full protocol bit for bit."""
+    n = 64 * 50 + 3
+    rng = np.random.default_rng(17)
+    law, s0, h0, grad = _sparse_case(law_name, n, rng)
+    a = ResidentState(law, n, stress0=s0, history0=h0, delta_history="auto")
+    f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False)
+    assert a._delta_auto and not a._delta
+    modes = []
+    for inc, iters in enumerate([4, 4, 4, 1, 1, 1, 1, 5, 2]):
+        for it in range(iters):
+            g = grad(all_elastic=False, zoned=(inc % 2 == 1))
+            a.evaluate(0.0, 1.0, g)
+            f.evaluate(0.0, 1.0, g)
+            assert torch.equal(a.stress, f.stress) and torch.equal(a.tangent, f.tangent), (inc, it)
+            for k in h0:
+                assert torch.equal(a.history[k], f.history[k]), (inc, it, k)
+        a.update(), f.update()
+        modes.append(a._delta)
+        for k in h0:
+            assert torch.equal(a.history_committed[k], f.history_committed[k]), (inc, k)
+    assert modes[0] and modes[2] and not modes[5] and not modes[6] and modes[7], modes  # on after 4, 4, 4; off after the 1s; on after 5
 
 
 @pytest.mark.parametrize("law_name", ["MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D"])

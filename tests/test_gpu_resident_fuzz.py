@@ -41,8 +41,9 @@ def drucker_prager_case(kind, n, seed):
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
-@pytest.mark.parametrize("kind", ["von_mises_3d", "von_mises_3d+delta_history", "comfe_mises_plasticity",
-                                  "comfe_mises_plasticity+rows7", "drucker_prager", "drucker_prager_hyperbolic",
+@pytest.mark.parametrize("kind", ["von_mises_3d", "von_mises_3d+delta_history", "von_mises_3d+delta_auto", "comfe_mises_plasticity",
+                                  "comfe_mises_plasticity+rows7", "comfe_mises_plasticity+delta_history", "drucker_prager",
+                                  "drucker_prager+delta_history", "drucker_prager_hyperbolic+delta_auto", "drucker_prager_hyperbolic",
                                   "linear_elasticity", "spring_maxwell"])
 def test_random_call_sequences(kind, seed):
     n = 64 * 90 + 17
@@ -52,7 +53,10 @@ def test_random_call_sequences(kind, seed):
     else:
         p, g0, s, h = random_case(kind, n, seed=seed)
         law = make_law(kind, p)
-    opt = ResidentState(law, n, stress0=s, history0=h, delta_history=option == "delta_history", split_history=option != "rows7")
+    opt = ResidentState(law, n, stress0=s, history0=h, delta_history={"delta_history": True, "delta_auto": "auto"}.get(option, False),
+                        split_history=option != "rows7")
+    if option == "delta_auto":
+        opt.DELTA_MIN_ITERATIONS, opt.DELTA_OFF_ITERATIONS = 2.0, 1.5  # the random sequences commit after 1 - 4 evaluates: both switches happen
     assert opt._delta == (option == "delta_history")
     assert opt._split == (option != "rows7" and (kind == "comfe_mises_plasticity" or kind.startswith("drucker_prager")))
     ref = ResidentState(law, n, stress0=s, history0=h, sparse_history=False, sparse_tangent=False,
