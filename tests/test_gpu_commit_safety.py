@@ -107,8 +107,11 @@ def test_a_caught_failure_of_one_law_is_not_forgotten_by_the_next_laws_evaluate(
     sp, tp = np.zeros(6 * n), np.zeros(36 * n)
     with pytest.raises(RuntimeError, match="did not converge"):
         ps.evaluate_law_into(0, g_bad, sp, tp, sync=True)
-    ps.evaluate_law_into(1, g_le, sp, tp, sync=True)  # a clean law in between must not clear law 0's failure
+    # a clean law in between must not clear law 0's failure: its own synchronising check still reports it ...
     with pytest.raises(RuntimeError, match="did not converge"):
+        ps.evaluate_law_into(1, g_le, sp, tp, sync=True)
+    assert ps._laws[0].failed is not None and ps._laws[1].failed is None
+    with pytest.raises(RuntimeError, match="did not converge"):  # ... and nothing can be committed
         ps.update()
     ps.evaluate_law_into(0, 0.0 * g_bad, sp, tp, sync=True)
     ps.update()
