@@ -43,7 +43,7 @@ class ResidentState:
 
     def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
                  reuse_constant_tangent: bool = True, sparse_tangent: bool = True, placement: str = "auto",
-                 delta_history: bool = False, split_history: bool = True):
+                 delta_history="auto", split_history: bool = True):
         """``placement`` (device-assembler mode, large states): where the arrays the kernel streams
         live decides 10-28 % of its time on MI355X.  "vmm": on the first ``evaluate`` the state moves its arrays
         (both stress / history copies, tangent, gradient staging) into ONE working set whose 2 MiB physical
@@ -61,8 +61,8 @@ class ResidentState:
         # writes contiguous runs, and ``update()`` adds the increments to the committed rows (one pass per increment, the
         # commit kernel).  It moves work from every Newton iteration to the commit, so it pays from ``DELTA_MIN_ITERATIONS``
         # iterations per increment on (bench.py "delta_trial_history": evaluate / commit kernel times, break-even).
-        # True: always; "auto": the state watches how many evaluates its increments take and switches the protocol at
-        # increment boundaries (one full-history evaluate when it goes back to the plain protocol); False (default): never.
+        # True: always; "auto" (default): the state watches how many evaluates its increments take and switches the protocol
+        # at increment boundaries (one full-history evaluate when it goes back to the plain protocol); False: never.
         # ``history`` (the trial view) assembles the rows on demand.
 
         # ``split_history`` (the comfe-rs plasticity laws, with the sparse protocol): the reference keeps one
@@ -108,6 +108,10 @@ class ResidentState:
         assert delta_history in (False, True, "auto"), "delta_history: False, True or 'auto'"
         self._delta_auto = capable and delta_history == "auto"
         self._delta = capable and delta_history is True
+        if type(law).__name__.startswith("DruckerPrager"):
+            # more of the launch is the return mapping itself: measured break-even 3.7 iterations at 56 % plastic points
+            # (VonMises3D 1.7 at 22 %, comfe-rs Mises 2.1 at 40 %; bench.py "delta_trial_history", 1e8 points)
+            self.DELTA_MIN_ITERATIONS, self.DELTA_OFF_ITERATIONS = 4.0, 3.0
         self._n_eval = 0          # evaluates of the increment in progress (Newton iterations)
         self._iters_ema = None    # running mean of the Newton iterations per increment ("auto")
         self._evaluated = False

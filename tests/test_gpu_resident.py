@@ -363,7 +363,7 @@ def test_delta_trial_history_equals_the_plain_protocols(n, law_name):
     rng = np.random.default_rng(n)
     law, s0, h0, grad = _sparse_case(law_name, n, rng)
     d = ResidentState(law, n, stress0=s0, history0=h0, delta_history=True)           # packed increments in the trial array
-    p = ResidentState(law, n, stress0=s0, history0=h0)                               # sparse (default), committed + increment in the trial array
+    p = ResidentState(law, n, stress0=s0, history0=h0, delta_history=False)          # plain sparse protocol: committed + increment in the trial array
     f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False)
     assert d._delta and not p._delta and not f._delta
     sh, th = np.empty(6 * n), np.empty(36 * n)
@@ -418,6 +418,7 @@ def test_delta_trial_history_switches_itself_on_and_off(law_name):
     a = ResidentState(law, n, stress0=s0, history0=h0, delta_history="auto")
     f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False)
     assert a._delta_auto and not a._delta
+    a.DELTA_MIN_ITERATIONS, a.DELTA_OFF_ITERATIONS = 3.0, 2.5  # (the Drucker-Prager laws ship with 4.0 / 3.0)
     modes = []
     for inc, iters in enumerate([4, 4, 4, 1, 1, 1, 1, 5, 2]):
         for it in range(iters):
