@@ -326,3 +326,64 @@ def test_drucker_prager_tip_assertion():
         O.comfe_drucker_prager(DP_P, 0, 1, g, s, np.zeros(360), h)
     # the hyperbolic surface has no tip assertion
     O.comfe_drucker_prager(DP_H, 0, 1, g, s, np.zeros(360), h, hyperbolic=True)
+
+
+# ---- self-derived 50-digit vectors for the comfe-rs plasticity updates (oracle/mp_pins.py) --------------------------
+# NOT reference-held: a third, independent transcription of the Rust text (full 8 x 8 Newton system, mpmath) against
+# which both oracles are bounded at rounding level -- it separates transcription errors from rounding, it does not lift
+# "parity unpinned" (only a Rust build or vectors held by the reference would).
+
+SELFDERIVED = [("comfe_selfderived_mises.npz", "mises", False), ("comfe_selfderived_drucker_prager_classic.npz", "dp", False),
+               ("comfe_selfderived_drucker_prager_hyperbolic.npz", "dp", True)]
+
+
+def _selfderived(fname):
+    import os
+
+    from golden_util import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, fname))
+    return z, dict(zip([str(k) for k in z["param_keys"]], [float(v) for v in z["param_vals"]]))
+
+
+def _worst_point(a, b, d):
+    """largest per-point relative error: max_i ( max|a_i - b_i| / max|b_i| )"""
+    a, b = a.reshape(-1, d), b.reshape(-1, d)
+    return float((np.abs(a - b).max(axis=1) / np.abs(b).max(axis=1)).max())
+
+
+@pytest.mark.parametrize("which", ["numpy", "c"])
+@pytest.mark.parametrize("fname,kind,hyper", SELFDERIVED)
+def test_oracles_against_the_50_digit_transcription(fname, kind, hyper, which):
+    from oracle import c_oracle as CO
+
+    z, p = _selfderived(fname)
+    mod = O if which == "numpy" else CO
+    s, t, h = z["stress_in"].copy(), np.full(z["tangent_out"].size, np.nan), {"history": z["hist_in"].copy()}
+    if kind == "mises":
+        mod.comfe_mises_plasticity(p, 0.0, 1.0, z["grad"], s, t, h)
+    else:
+        mod.comfe_drucker_prager(p, 0.0, 1.0, z["grad"], s, t, h, hyperbolic=hyper)
+    pl = z["plastic"]
+    assert 0.2 * pl.size < pl.sum() < 0.8 * pl.size  # both branches are in the sample
+    hv, ho = h["history"].reshape(-1, 7), z["hist_out"].reshape(-1, 7)
+    assert np.array_equal(hv[:, 0] != z["hist_in"].reshape(-1, 7)[:, 0], pl)  # the same points yield
+    # PER POINT, relative to the point's own largest entry: rounding level (measured 2e-16 .. 1e-14), bound 1e-13
+    assert _worst_point(s, z["stress_out"], 6) <= 1e-13
+    assert _worst_point(t, z["tangent_out"], 36) <= 1e-13
+    assert np.abs(hv[:, 0] - ho[:, 0]).max() <= 1e-13 * np.abs(ho[:, 0]).max()
+    assert _worst_point(hv[:, 1:].copy(), ho[:, 1:].copy(), 6) <= 1e-13
+
+
+def test_selfderived_fixtures_reproduce():
+    """the committed vectors are what oracle/mp_pins.py computes (first points of every file; needs mpmath)"""
+    pytest.importorskip("mpmath")
+    from oracle import mp_pins
+
+    for fname, kind, hyper in SELFDERIVED:
+        z, p = _selfderived(fname)
+        k = 6
+        g, s, h = z["grad"][: 9 * k], z["stress_in"][: 6 * k], z["hist_in"][: 7 * k]
+        out = mp_pins.run_mises(g, s, h, p) if kind == "mises" else mp_pins.run_dp(g, s, h, p, hyper)
+        assert np.array_equal(out[0], z["stress_out"][: 6 * k]) and np.array_equal(out[1], z["tangent_out"][: 36 * k])
+        assert np.array_equal(out[2], z["hist_out"][: 7 * k]) and np.array_equal(out[3], z["plastic"][:k])
