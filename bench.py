@@ -312,7 +312,7 @@ class Workload:
             self.torch.cuda.synchronize()
         except Exception as e:
             # no room for the second copy of the working set (e.g. under rocprofv3, which keeps released VMM memory
-            # alive: tools/vmm_leak_probe.py): "auto" stays on the tuned hipMalloc arrays, "vmm" has nothing to run on
+            # alive: round-2 probe vmm_leak_probe.py (git history)): "auto" stays on the tuned hipMalloc arrays, "vmm" has nothing to run on
             for k, v in old.items():
                 setattr(self, k, v)
             if keep_if_faster_than is None:

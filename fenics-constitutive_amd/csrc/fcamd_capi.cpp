@@ -44,7 +44,7 @@ namespace {
 // Row-masked history access (fcamd_kernels.hip: tile_von_mises, history7_store) pays off while few rows
 // of a tile are touched: every skipped row saves its bytes, but holes turn full-line writes into partial
 // ones.  Tiles with more touched rows than this take the dense tile path.  Measured at 5e7 points
-// (tools/masked_threshold_probe.py, random mixtures, sparse protocol; dense = 5.55 ms for VonMises3D):
+// (round-2 probe masked_threshold_probe.py (git history), random mixtures, sparse protocol; dense = 5.55 ms for VonMises3D):
 // 5 % plastic 4.75 ms, 10 % 4.93, 19 % 5.23, 33 % 5.52 with thresholds 16-24, while "always masked" loses
 // 4-6 % from 47 % plastic on; the 56-byte rows of the comfe-rs laws straddle chunks and turn earlier.
 constexpr int kMaskedRowMaxVonMises = 20;

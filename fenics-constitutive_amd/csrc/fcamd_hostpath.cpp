@@ -267,12 +267,12 @@ struct HostTimer {
 // locked, and the DMA engine faults ("Memory access fault by GPU node-N on address <host address>";
 // tools/hsa_lock_probe.c, tools/pageable_copy_probe.py).  Instead:
 //   * calls that move at most `bounce_max` bytes (256 KiB: where the CPU copies cost what the page locks of a call cost,
-//     tools/bounce_crossover_probe.py): the CPU copies inputs into / results out of the context's own
+//     round-2 probe bounce_crossover_probe.py (git history)): the CPU copies inputs into / results out of the context's own
 //     page-locked scratch (hipHostMalloc) and the kernel runs on the scratch;
 //   * larger calls: the caller's arrays are page-locked for the duration of the call (hipHostRegister: the
 //     attribute is set on the pages that are there NOW), the kernel runs directly on them, they are unlocked on
 //     return.  Measured against the runtime's pageable path, VonMises3D, 1e7 points: 254 instead of 270 ms on
-//     arrays never seen before, 80.7 instead of 103.9 ms on arrays used before (tools/temp_register_probe.py);
+//     arrays never seen before, 80.7 instead of 103.9 ms on arrays used before (round-2 probe temp_register_probe.py (git history));
 //   * arrays that cannot be locked (a range that overlaps somebody else's registration): the scratch again, in chunks.
 // Page locks taken for the duration of a call are shared by all contexts of the process: two threads (each with a
 // context of its own) may pass the SAME read-only array -- the gradient -- at the same time, and two concurrent
@@ -553,7 +553,7 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     for (int k = 0; k < NH; ++k) aligned = aligned && aligned16(z_hist[k]);
     // Zero copy: one launch directly on the (page-locked) caller arrays -- the GPU reads the inputs and writes the
     // results over PCIe itself, both directions at once, no staging buffers.  Measured on MI355X / PCIe gen5
-    // (tools/zero_copy_probe.py, VonMises3D): 140 instead of 117 Mpts/s at 1e7 points (55 GB/s of device-to-host
+    // (round-2 probe zero_copy_probe.py (git history), VonMises3D): 140 instead of 117 Mpts/s at 1e7 points (55 GB/s of device-to-host
     // traffic), 40 instead of 145 us per call at 1e3 points.
     if (zero_copy_enabled(c) && aligned) {
         c->last_host_mode |= FCAMD_HOST_ZERO_COPY_IN | FCAMD_HOST_ZERO_COPY_OUT;
@@ -819,7 +819,7 @@ int fcamd_copy_device(fcamd_context* c, void* dst_device, const void* src_device
     if (!aligned16(dst_device) || !aligned16(src_device))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
     const size_t n16 = bytes / 16;
-    // 16 KiB per workgroup and pass.  tools/stream_copy_probe.py, 8 GiB buffers, three buffer pairs: 5.0 - 5.6 TB/s with 1024
+    // 16 KiB per workgroup and pass.  round-2 probe stream_copy_probe.py (git history), 8 GiB buffers, three buffer pairs: 5.0 - 5.6 TB/s with 1024
     // workgroups, 5.5 - 5.9 with 8192, 5.8 - 6.0 with 262144 (torch's copy: 4.7 - 5.0): many short workgroups
     const size_t tiles = (n16 + 1023) / 1024;
     const int grid = c->grid_override > 0 ? c->grid_override : (int)std::min<size_t>(tiles, (size_t)c->num_cu * 1024);

@@ -442,7 +442,7 @@ hipError_t launch_evaluate_wrapped(int law, int wrap, const EvalArgs& args, int 
 }
 
 int default_grid(int law, int num_cu) {
-    // Measured on MI355X (VonMises3D, 1e8 points, tools/variance_probe2.py): the more workgroups
+    // Measured on MI355X (VonMises3D, 1e8 points, round-2 probe variance_probe2.py (git history)): the more workgroups
     // the better, monotonically -- 512: 9.5-10.3 ms, 1024 (= resident set): 9.3-10.0, 4096:
     // 9.0-9.6, 16384: 9.0-9.4 -- short queues of workgroups rebalance CUs and HBM channels.
     (void)law;

@@ -7,7 +7,7 @@
 // API instead: one address range per array, backed by physical handles of `granule` bytes that are
 // created in an interleaved order over all arrays of the set (proportionally to their sizes), so that the
 // physical placement of the arrays relative to each other is a property of the call, not of the
-// allocator's history.  Whether that removes the lottery is an experiment (tools/vmm_placement_probe.py,
+// allocator's history.  Whether that removes the lottery is an experiment (round-2 probe vmm_placement_probe.py (git history),
 // profiles/r02_placement_vmm.md), not a promise.
 #include <algorithm>
 #include <cstring>
@@ -44,7 +44,7 @@ hipError_t release(void* base, VmmArray& a) {
     }
     // The address range is NOT returned (hipMemAddressFree): on this stack a range that is reserved again at
     // the same address and mapped to new handles serves stale data -- the second of two identical sets built
-    // after freeing the first read back wrong values in every trial (tools/vmm_placement_probe.py --selftest
+    // after freeing the first read back wrong values in every trial (round-2 probe vmm_placement_probe.py (git history) --selftest
     // reproduces it with the free enabled).  Address space is plentiful (the physical memory IS released);
     // a range is simply never reused.
     a.handles.clear();
@@ -139,7 +139,7 @@ int fcamd_device_alloc_set(fcamd_context* c, int n_arrays, const size_t* bytes, 
         // Access is granted per mapped handle.  One hipMemSetAccess over a range of several handles is
         // accepted by this runtime but maps the range as if its handles had been created back to back:
         // with an interleaved creation order the arrays of the set then alias each other's physical memory
-        // (found with distinct fill patterns, tools/vmm_placement_probe.py --selftest).
+        // (found with distinct fill patterns, round-2 probe vmm_placement_probe.py (git history) --selftest).
         VMM_TRY(hipMemSetAccess(va, granule, &acc, 1));
         ++done[k];
     }

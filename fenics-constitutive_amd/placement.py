@@ -3,9 +3,9 @@
 On MI355X the time of the evaluate kernels depends on WHICH device memory the driver hands out for
 the arrays the kernel writes -- above all the tangent, 51-63 % of the traffic: with everything else
 fixed, candidate allocations of the tangent alone move the kernel between 4.49 and 5.49 ms at 5e7
-points (tools/tangent_placement_probe.py), reproducibly for a given allocation and invisible to
+points (round-2 probe tangent_placement_probe.py (git history)), reproducibly for a given allocation and invisible to
 plain fill / read bandwidth tests of the same memory.  Virtual offsets inside an allocation do not
-matter (tools/offset_probe.py), so there is nothing to align: the remedy is to allocate a few
+matter (round-2 probe offset_probe.py (git history)), so there is nothing to align: the remedy is to allocate a few
 candidates while the earlier ones are still alive (the driver then has to hand out different
 memory), time the real kernel on each and keep the fastest.  For a simulation that evaluates the
 same arrays for thousands of Newton iterations this costs a few launches once.
