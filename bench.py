@@ -1344,6 +1344,38 @@ def main():
                                                      "kernel_over_model": round(configs[cname]["kernel_ms_avg"] / model_ms, 3)}
         out["configs"] = configs
 
+    # N > 1: the single-process form of the host path on THIS node's GPUs (fcamd_multi) -- rank 0 alone drives all
+    # of them over their own PCIe links while the other ranks wait on the CPU (a key in the process group's store, not a
+    # collective: an RCCL barrier would keep their GPUs busy with a spinning kernel)
+    if distributed and world > 1 and not args.no_host_path:
+        import datetime
+
+        store = None
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            pass
+        if rank == 0:
+            try:
+                if budget_left() > 75 and store is not None:
+                    have = torch.cuda.device_count()
+                    devs = [k % have for k in range(world)]  # fewer GPUs than ranks (gloo rehearsal): contexts share devices
+                    torch.cuda.empty_cache()
+                    per_dev = min(n, 2_500_000)
+                    out["host_path_multi"] = host_path_figures(devices=devs, sizes=(min(1_000_000, per_dev * world), per_dev * world),
+                                                               latency_sizes=(), reps=2, budget_s=40.0)
+                else:
+                    out["host_path_multi"] = {"skipped": "wall budget" if store is not None else "no process-group store to wait on"}
+            except Exception as e:  # informational: must not lose the line
+                out["host_path_multi"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if store is not None:
+                store.set("fcamd_host_multi_done", "1")
+        elif store is not None:
+            try:
+                store.wait(["fcamd_host_multi_done"], datetime.timedelta(seconds=max(60.0, budget_left())))
+            except Exception:
+                pass  # rank 0 is late or gone: the closing barrier below decides
+
     if rank == 0:
         if world == 1 and not args.no_host_path and args.workload is None and budget_left() > 40:
             # the number a dolfinx user sees: the ndarray entries over PCIe ("timed separately and labelled as such")

@@ -51,6 +51,9 @@ def test_two_ranks_weak_scaling_with_strong_leg_and_gather():
     assert ag["points_per_rank"] == 2_000_000 and ag["tangent_chunks"] >= 1
     assert "rccl_ms" not in ag  # gloo rehearsal: RCCL variants are not run
     assert out.get("cpu_baseline") is None and "configs" not in out
+    hm = out["host_path_multi"]  # rank 0 alone drives one context per rank's device over the host path
+    assert "error" not in hm and hm["devices"] == [0, 0], hm
+    assert hm["sizes"]["4000000"]["registered"]["resident_sparse"]["Mpts_s"] > 0 and "per_call_us" not in hm
 
 
 def test_two_ranks_strong_scaling():

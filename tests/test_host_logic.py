@@ -165,6 +165,43 @@ def test_default_device_selection(monkeypatch):
     assert _capi.default_device() == 2
 
 
+def test_devices_of_the_single_process_multi_gpu_path(monkeypatch):
+    """FCAMD_DEVICES is the environment default of every law's use_devices (an unchanged dolfinx script on a whole node);
+    the multi handle itself is created lazily, at the first ndarray evaluate."""
+    import fenics_constitutive_amd as fc
+    from fenics_constitutive_amd import _capi
+
+    monkeypatch.delenv("FCAMD_DEVICES", raising=False)
+    assert _capi.default_devices() is None
+    law = fc.LinearElasticityModel({"E": 1.0, "nu": 0.3}, fc.StressStrainConstraint.FULL)
+    assert law.devices is None and law._multi_handle is None
+    assert law.use_devices([2, 0]) is law and law.devices == [2, 0] and law._multi_handle is None
+    assert law.use_devices(None).devices is None
+    monkeypatch.setenv("FCAMD_DEVICES", "0, 3,1")
+    assert _capi.default_devices() == [0, 3, 1]
+    assert fc.VonMises3D({"p_ka": 1.0, "p_mu": 1.0, "p_y0": 1.0, "p_y00": 2.0, "p_w": 1.0}).devices == [0, 3, 1]
+    monkeypatch.setenv("FCAMD_DEVICES", "")
+    assert _capi.default_devices() is None
+
+
+def test_multi_handle_rejects_bad_arguments_without_touching_a_device():
+    import ctypes as C
+
+    from fenics_constitutive_amd import _capi
+
+    lib = _capi.load()
+    h = C.c_void_p()
+    p = (C.c_double * 2)(1.0, 0.3)
+    assert lib.fcamd_multi_create(None, 2, _capi.LINEAR_ELASTICITY, 5, p, 2, C.byref(h)) == _capi.ERR_BAD_ARG
+    dv = (C.c_int * 1)(0)
+    assert lib.fcamd_multi_create(dv, 0, _capi.LINEAR_ELASTICITY, 5, p, 2, C.byref(h)) == _capi.ERR_BAD_ARG
+    assert lib.fcamd_multi_create(dv, _capi.MULTI_MAX_DEVICES + 1, _capi.LINEAR_ELASTICITY, 5, p, 2, C.byref(h)) == _capi.ERR_BAD_ARG
+    assert not h.value
+    assert lib.fcamd_multi_destroy(None) == _capi.OK and lib.fcamd_multi_state_destroy(None) == _capi.OK
+    assert lib.fcamd_multi_evaluate_host(None, 0.0, 1.0, 0, None, None, None, None, 0, None) == _capi.ERR_BAD_ARG
+    assert lib.fcamd_multi_state_commit(None) == _capi.ERR_BAD_ARG
+
+
 def test_rows_of_cells_matches_quadrature_numbering():
     """Quadrature dofs are numbered cell by cell (solver/maps.py:43-79): cell c, point q -> c*Q + q."""
     from fenics_constitutive_amd.problem import rows_of_cells
@@ -203,7 +240,8 @@ def test_header_constants_match_the_ctypes_module():
              "FCAMD_COUNTER_SLOTS": _capi.COUNTER_SLOTS,
              "FCAMD_MAX_HISTORY": _capi.MAX_HISTORY, "FCAMD_IPC_HANDLE_BYTES": _capi.IPC_HANDLE_BYTES,
              "FCAMD_GATHER_PULL": _capi.GATHER_PULL, "FCAMD_ALLOC_SEQUENTIAL": _capi.ALLOC_SEQUENTIAL,
-             "FCAMD_ALLOC_INTERLEAVED": _capi.ALLOC_INTERLEAVED}
+             "FCAMD_ALLOC_INTERLEAVED": _capi.ALLOC_INTERLEAVED, "FCAMD_EVAL_SPLIT_HISTORY": _capi.EVAL_SPLIT_HISTORY,
+             "FCAMD_MULTI_MAX_DEVICES": _capi.MULTI_MAX_DEVICES, "FCAMD_MULTI_MIN_POINTS": _capi.MULTI_MIN_POINTS}
     for name, value in pairs.items():
         assert defines[name] == value, name
     assert _capi.COUNTER_WORDS == 4 * defines["FCAMD_COUNTER_SLOTS"]  # FCAMD_COUNTER_WORDS is an expression in the header
