@@ -129,6 +129,30 @@ class ResidentAdapter:
         return self.rs.history_committed[key].cpu().numpy()
 
 
+class MultiResidentAdapter:
+    """The single-process multi-GPU resident state (fcamd_multi_state) behind the same four calls: the state of the n
+    bodies sliced over several device contexts, stress / tangent straight into this process's NumPy arrays."""
+
+    def __init__(self, law, n, devices=(0, 0, 0)):
+        from fenics_constitutive_amd.multidevice import MultiDeviceResidentState
+
+        self.rs, self.n = MultiDeviceResidentState(law, n, devices=list(devices)), n
+        self.sd = law.stress_strain_dim
+        self._s, self._t = np.zeros(self.sd * n), np.zeros(self.sd * self.sd * n)
+
+    def evaluate(self, t, del_t, grad):
+        self.rs.evaluate_into(t, del_t, np.ascontiguousarray(grad, dtype=np.float64), self._s, self._t)
+
+    def update(self):
+        self.rs.update()
+
+    def fetch(self):
+        return self._s.reshape(self.n, self.sd), self._t.reshape(self.n, self.sd, self.sd)
+
+    def history_of(self, key):
+        return self.rs.history_committed[key]
+
+
 class MaterialPoints:
     """``n`` homogeneous bodies.  ``increment`` prescribes the Mandel strain increment of the
     controlled components and solves for the free ones so that ``stress[free] == target``."""

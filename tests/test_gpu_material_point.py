@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import material_point_cases as cases
-from material_point import HostState, MaterialPoints, ResidentAdapter
+from material_point import HostState, MaterialPoints, MultiResidentAdapter, ResidentAdapter
 
 pytestmark = pytest.mark.gpu
 
@@ -37,13 +37,19 @@ def make_law(kind, params, constraint):
 def builder(mode):
     def build(kind, params, constraint, n):
         law = make_law(kind, params, constraint)
-        state = HostState(law, n) if mode == "host" else ResidentAdapter(law, n, host_assembler=(mode == "resident_host"))
+        if mode == "multi_host":  # the in-place ndarray evaluate spread over three device contexts, one tile per context at least
+            law.use_devices([0, 0, 0])
+            law._multi().set_option("min_points", 32)
+        if mode == "multi_resident":
+            state = MultiResidentAdapter(law, n)
+        else:
+            state = HostState(law, n) if mode.endswith("host") and mode != "resident_host" else ResidentAdapter(law, n, host_assembler=(mode == "resident_host"))
         return MaterialPoints(state, constraint, tol=1e-11)
 
     return build
 
 
-MODES = ["host", "resident", "resident_host"]
+MODES = ["host", "resident", "resident_host", "multi_host", "multi_resident"]
 
 
 @pytest.mark.parametrize("mode", MODES)
