@@ -47,16 +47,30 @@ KERNEL_FLAGS = [f for f in FLAGS if f not in ("-pthread", "-fPIC", "-shared", "-
 KERNEL_HASHFILE = os.path.join(LIBDIR, "libfcamd.kernelhash")
 
 
-def kernel_hash() -> str:
-    """Content hash of the DEVICE code alone (kernels, their internal header, arch and flags): what measured
-    HBM traffic depends on.  profiles/traffic.json is keyed by it, so host-side changes of the C ABI layer do not
-    invalidate a PMC measurement, a kernel change does."""
+def _code_only(text: str) -> str:
+    """C / C++ source without comments and with whitespace collapsed: what the compiler's output depends on"""
+    import re
+
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return " ".join(text.split())
+
+
+def kernel_hash(read=None) -> str:
+    """Content hash of the DEVICE code alone (kernels, their headers, arch and codegen flags; comments and whitespace
+    do not count): what measured HBM traffic depends on.  profiles/traffic.json is keyed by it, so host-side changes
+    of the C ABI layer and comment edits do not invalidate a PMC measurement, a kernel change does.  `read(relative
+    path) -> text` substitutes another source tree (tools: the hash of an earlier commit)."""
     import hashlib
+
+    if read is None:
+        def read(f):
+            with open(os.path.join(CSRC, f)) as fh:
+                return fh.read()
 
     h = hashlib.sha256(" ".join([ARCH, *KERNEL_FLAGS]).encode())
     for f in KERNEL_SOURCES:
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(fh.read())
+        h.update(f.encode() + b"\0" + _code_only(read(f)).encode() + b"\0")
     return h.hexdigest()
 
 
