@@ -307,3 +307,22 @@ def test_parent_rows_of_a_subspace_map():
     b = np.zeros(10)
     b[rows] = sub_array
     assert np.array_equal(a, b) and rows.tolist() == [3, 0, 7, 9]
+
+
+def test_kernel_hash_ignores_comments_but_not_code():
+    """profiles/traffic.json is keyed by the hash of the device code: a comment or whitespace edit must not invalidate a
+    stored PMC measurement, any change of the code must."""
+    from fenics_constitutive_amd import _build
+
+    def tree(patch):
+        def read(f):
+            with open(os.path.join(_build.CSRC, f)) as fh:
+                text = fh.read()
+            return patch(text) if f == "fcamd_kernels.hip" else text
+        return read
+
+    base = _build.kernel_hash()
+    assert _build.kernel_hash(tree(lambda t: t)) == base
+    assert _build.kernel_hash(tree(lambda t: t.replace("namespace fcamd {", "namespace fcamd {  // a remark\n\n   /* and\n another */", 1))) == base
+    assert _build.kernel_hash(tree(lambda t: t.replace("return 64 * num_cu;", "return 32 * num_cu;", 1))) != base
+    assert "-pthread" not in _build.KERNEL_FLAGS and "-ffp-contract=off" in _build.KERNEL_FLAGS
