@@ -50,7 +50,12 @@ struct Worker {
                 j = std::move(job);
                 has_job = false;
             }
-            const int st = j();
+            int st;
+            try {
+                st = j();
+            } catch (const std::exception& e) {  // e.g. std::bad_alloc of a host temporary: a status, not std::terminate
+                st = fail(FCAMD_ERR_BAD_ARG, "device slot job failed: %s", e.what());
+            }
             std::string msg = st == FCAMD_OK ? std::string() : std::string(fcamd_last_error());
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -100,6 +105,7 @@ struct fcamd_multi {
     int last_mode = 0, last_used = 0;
     int64_t min_points = FCAMD_MULTI_MIN_POINTS;  // option "min_points": a call uses at most n / min_points devices
     std::mutex call_mu;  // one call at a time
+    std::vector<fcamd_multi_state*> states;  // live resident states (destroyed with the handle if the caller did not)
 
     // number of devices a call over n points uses
     int used_for(int64_t n) const {
@@ -209,6 +215,7 @@ int fcamd_multi_create(const int* devices, int n_devices, int model_id, int cons
 
 int fcamd_multi_destroy(fcamd_multi* mg) {
     if (!mg) return FCAMD_OK;
+    while (!mg->states.empty()) fcamd_multi_state_destroy(mg->states.back());  // their arrays live in this handle's contexts
     for (auto& w : mg->w) {
         if (!w->th.joinable()) continue;
         Worker* wp = w.get();
@@ -435,6 +442,7 @@ int fcamd_multi_state_create(fcamd_multi* mg, int64_t n, int flags, fcamd_multi_
         });
         return fail(rc, "%s", msg.c_str());
     }
+    mg->states.push_back(st.get());
     *out = st.release();
     return FCAMD_OK;
 }
@@ -444,6 +452,7 @@ int fcamd_multi_state_destroy(fcamd_multi_state* st) {
     fcamd_multi* mg = st->mg;
     {
         std::lock_guard<std::mutex> call(mg->call_mu);
+        mg->states.erase(std::remove(mg->states.begin(), mg->states.end(), st), mg->states.end());
         (void)mg->run((int)mg->w.size(), [&](int k) {
             auto& sl = st->s[(size_t)k];
             (void)hipSetDevice(mg->w[k]->device);

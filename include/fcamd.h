@@ -471,7 +471,7 @@ typedef struct fcamd_multi fcamd_multi;
 #define FCAMD_MULTI_MIN_POINTS 8192
 int fcamd_multi_create(const int* devices, int n_devices, int model_id, int constraint, const double* params,
                        int n_params, fcamd_multi** out);
-int fcamd_multi_destroy(fcamd_multi* mg);
+int fcamd_multi_destroy(fcamd_multi* mg);  /* also destroys the fcamd_multi_state objects still alive on it */
 int fcamd_multi_device_count(const fcamd_multi* mg, int* n_devices);
 /* Number of devices a call over n points uses, and the slice [lo, hi) of device slot k in that call. */
 int fcamd_multi_plan(const fcamd_multi* mg, int64_t n, int* n_used);

@@ -107,6 +107,24 @@ def test_c_program_runs(tmp_path, lib):
     assert "max error" in r.stdout
 
 
+def test_c_program_drives_several_device_contexts(tmp_path, lib):
+    """examples/c_caller_multi.c: a plain-C host runs the single-process multi-GPU entry (three contexts) and the
+    multi-device resident state; its own checks compare with the single-device entry bit for bit."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(LIB)
+    exe = tmp_path / "c_caller_multi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_caller_multi.c"),
+                    "-o", str(exe), "-L", libdir, "-lfcamd", "-lm", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"], check=True)
+    r = subprocess.run([str(exe), "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "3 device contexts (3 used" in r.stdout and "bit for bit" in r.stdout
+
+
 def test_host_mapping_and_flag_errors(lib):
     """fcamd_host_device_pointer / FCAMD_EVAL_SPARSE_TANGENT argument checks, raw."""
     import mmap
