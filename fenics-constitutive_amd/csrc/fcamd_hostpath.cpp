@@ -176,8 +176,12 @@ int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
         }
         c->registered.erase(base);
     }
-    if (in_process_registry(base, bytes) != 0)
-        return fail(FCAMD_ERR_BAD_ARG, "the range overlaps one that another context of this process has registered");
+    {   // page-locked already by another context of this process (one process driving several GPUs, several threads with a
+        // context each): this context enters the range with its own device's view of it and leaves the lock to its owner
+        const int r = in_process_registry(base, bytes);
+        if (r > 0) return adopt_registered_range(c, ptr, bytes);
+        if (r < 0) return fail(FCAMD_ERR_BAD_ARG, "the range overlaps one that another context of this process has registered");
+    }
     HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     note_registered(base, bytes);
     void* dev = nullptr;

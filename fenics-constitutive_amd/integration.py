@@ -114,7 +114,7 @@ def _parent_rows(los, n_local: int):
     return rows
 
 
-def use_resident_problem_state(problem, sync_history: bool = True, pin: bool = True) -> ResidentProblemState:
+def use_resident_problem_state(problem, sync_history: bool = True, pin: bool = True, devices=None):
     """Multi-material form of ``use_resident_state``: ONE ``ResidentProblemState`` for all GPU-backed (FULL
     3-D) laws of ``problem`` -- the committed / trial stress of the whole mesh and every law's history on the
     GPU -- and every ``LawOnSubMesh.evaluate`` replaced by: incremental gradient (unchanged dolfinx call) ->
@@ -124,7 +124,11 @@ def use_resident_problem_state(problem, sync_history: bool = True, pin: bool = T
     ``map_to_sub``; ``map_to_parent``: fancy-indexed host copies of 48 + 336 bytes per point,
     solver/maps.py:82-123) and the per-law local stress / tangent arrays.  The laws of one iteration are
     launched back to back and synchronised once, after the last one.  ``update_history`` of the first law
-    commits the shared state (pointer swap); laws that are not GPU-backed keep the reference's path."""
+    commits the shared state (pointer swap); laws that are not GPU-backed keep the reference's path.
+
+    ``devices`` (list of device ordinals): the same flow with ONE process driving several GPUs -- every law's points are
+    cut into one contiguous slice per device (``multidevice.MultiDeviceProblemState``), each device writes its rows of
+    the global host arrays over its own PCIe link."""
     gpu = [(i, los) for i, los in enumerate(problem._law_on_submeshs) if isinstance(los.law, DeviceLaw)]
     assert gpu, "no GPU-backed law in this problem"
     assert all(los.law.constraint.name == "FULL" for _, los in gpu), "use_resident_problem_state: FULL 3-D laws only"
@@ -134,11 +138,19 @@ def use_resident_problem_state(problem, sync_history: bool = True, pin: bool = T
         n_k = los.displacement_gradient_fn.x.array.size // 9
         laws.append((los.law, _parent_rows(los, n_k)))
     single_identity = len(laws) == 1 and laws[0][1] is None
-    state = ResidentProblemState(laws[0][0] if single_identity else laws, n, del_t=problem.sim_time.dt)
+    if devices is not None:
+        from .multidevice import MultiDeviceProblemState
+
+        state = MultiDeviceProblemState(laws, n, devices, del_t=problem.sim_time.dt)
+    else:
+        state = ResidentProblemState(laws[0][0] if single_identity else laws, n, del_t=problem.sim_time.dt)
     state.set_state(problem.stress.previous.x.array,
                     [None if los.history is None else {k: f.x.array for k, f in los.history.history_0.items()}
                      for _, los in gpu])
-    if pin:
+    if pin and devices is not None:  # one page lock, entered by every device's context
+        state.pin_host_arrays(problem.stress.current.x.array, problem.tangent.x.array,
+                              *[los.displacement_gradient_fn.x.array for _, los in gpu])
+    elif pin:
         first = gpu[0][1].law
         first.pin_host_arrays(problem.stress.current.x.array, problem.tangent.x.array)
         for _, los in gpu:
@@ -159,9 +171,13 @@ def use_resident_problem_state(problem, sync_history: bool = True, pin: bool = T
             if _k == 0:
                 state.update()
             if sync_history and self.history is not None:
-                committed = state._history_0[_k]
+                if devices is not None:  # every device's slice straight into the problem's history_0 arrays
+                    state.download_history(_k, {key: fn.x.array for key, fn in self.history.history_0.items()})
+                else:
+                    committed = state._history_0[_k]
+                    for key, fn in self.history.history_0.items():
+                        assign(fn.x.array, committed[key])
                 for key, fn in self.history.history_0.items():
-                    assign(fn.x.array, committed[key])
                     self.history.history_1[key].x.array[:] = fn.x.array
 
         los.evaluate = types.MethodType(evaluate, los)

@@ -12,7 +12,9 @@ xGMI, the history never leaves its device, the commit is a pointer swap per devi
 The ndarray ``evaluate`` of every law has the same spread without resident state: ``law.use_devices([0, 1, ...])``
 (``fcamd_multi_evaluate_host``), or ``FCAMD_DEVICES=all`` in the environment of an unchanged dolfinx script.
 
-PyTorch is not involved: the state's device arrays are owned by the C library.
+``MultiDeviceResidentState`` does not involve PyTorch (its device arrays are owned by the C library);
+``MultiDeviceProblemState`` -- the fused multi-material host flow over several GPUs -- is built from one
+``ResidentProblemState`` (torch tensors) per device.
 """
 
 from __future__ import annotations
@@ -22,7 +24,7 @@ import numpy as np
 from . import _capi
 from .device import SPLIT_HISTORY_LAWS, DeviceLaw, _check_numpy
 
-__all__ = ["MultiDeviceResidentState"]
+__all__ = ["MultiDeviceResidentState", "MultiDeviceProblemState"]
 
 _PLASTICITY = ("VonMises3D", "MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D")
 _CONST_TANGENT = ("LinearElasticityModel", "LinearElasticity3D", "SpringMaxwellModel", "SpringKelvinModel")
@@ -203,6 +205,143 @@ class MultiDeviceResidentState:
         self.unpin_arrays()
         self._state.close()
         self._multi.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiDeviceProblemState:
+    """Several laws on one mesh, one assembling process, several GPUs: ``ResidentProblemState`` (the fused multi-material
+    host flow: every law's kernel reads its local gradient from and writes its rows of the problem's GLOBAL stress /
+    tangent host arrays itself -- no ``map_to_sub`` / ``map_to_parent``, solver/maps.py:82-123) with every law's points cut
+    into contiguous slices, one per device.  Device d keeps the committed / trial parent stress rows and the history of
+    ITS slices and launches its laws on its own stream; one Python thread enqueues the launches of all devices (they are
+    asynchronous: the devices work concurrently, each over its own PCIe link) and synchronises once.
+
+    ``laws``: a list of ``(law, rows)`` as for ``ResidentProblemState`` (``rows`` = parent rows of the law's local points;
+    one law with ``rows=None`` covers all points).  The global host arrays must be page-locked for every device:
+    ``pin_host_arrays`` does it (one page lock, every device context enters the range).  Results are bit-identical to
+    the one-device state (``tests/test_gpu_multidevice.py``)."""
+
+    def __init__(self, laws, n_points: int, devices, del_t: float = 1.0, **kw):
+        from .problem import ResidentProblemState
+
+        if isinstance(laws, DeviceLaw):
+            laws = [(laws, None)]
+        self.devices = [int(d) for d in devices]
+        assert self.devices, "no GPU to run on"
+        self.n, world = int(n_points), len(self.devices)
+        self._law_objs = [law for law, _ in laws]
+        self._rows = [np.arange(self.n, dtype=np.int32) if rows is None else np.ascontiguousarray(rows, dtype=np.int32) for _, rows in laws]
+        # slice [lo, hi) of every law's LOCAL points per device (tile-aligned: the rule of fcamd_shard_bounds)
+        self._bounds = [[_capi.shard_bounds(r.size, world, d) for r in self._rows] for d in range(world)]
+        kw.setdefault("placement", "torch")  # the tangent lives on the host: nothing to place
+        self.states = [ResidentProblemState([(law, self._rows[k][lo:hi]) for k, (law, (lo, hi)) in enumerate(zip(self._law_objs, self._bounds[d]))],
+                                            self.n, del_t=del_t, device=f"cuda:{dev}", **kw)
+                       for d, dev in enumerate(self.devices)]
+        self._pinned = []
+
+    # -- the reference's names (solver/_solver.py:165-219), forwarded to every device's state -----------------
+    @property
+    def _time(self):
+        return self.states[0]._time
+
+    @_time.setter
+    def _time(self, v):
+        for s in self.states:
+            s._time = v
+
+    @property
+    def _del_t(self):
+        return self.states[0]._del_t
+
+    @_del_t.setter
+    def _del_t(self, v):
+        for s in self.states:
+            s._del_t = v
+
+    def set_state(self, stress=None, history=None) -> None:
+        """Committed state: parent stress (6 n, host) and one history dict per law (the law's LOCAL arrays)."""
+        for d, s in enumerate(self.states):
+            h = None
+            if history is not None:
+                h = []
+                for k, hk in enumerate(history):
+                    lo, hi = self._bounds[d][k]
+                    dims = self._law_objs[k].history_dim
+                    h.append(None if hk is None else {key: np.ascontiguousarray(hk[key][dims[key] * lo: dims[key] * hi]) for key in hk})
+            s.set_state(stress, h)
+
+    def pin_host_arrays(self, *arrays) -> None:
+        """Page-lock the problem's global stress / tangent arrays and the laws' gradient arrays once, for every device."""
+        seen = set()
+        for dev in self.devices:
+            if dev in seen:
+                continue
+            seen.add(dev)
+            ctx = _capi.get_context(dev)
+            for a in arrays:
+                _check_numpy("array", a)
+                ctx.register_host_buffer(a)  # the first context takes the page lock, the others enter the range
+                self._pinned.append((ctx, a))
+
+    def unpin_arrays(self) -> None:
+        pinned, self._pinned = self._pinned, []
+        for ctx, a in reversed(pinned):  # the owner of the page lock (first to register) last
+            ctx.unregister_host_buffer(a)
+
+    def evaluate_law_into(self, k: int, grad_del_u: np.ndarray, stress_parent: np.ndarray, tangent_parent, sync: bool = True) -> None:
+        """Law ``k`` on every device: each device's slice of the law's local gradient in, its rows of the global arrays
+        out.  ``sync=False`` returns after the launches (several laws in flight); the last call of a Newton iteration
+        synchronises (``check``)."""
+        _check_numpy("grad_del_u", grad_del_u)
+        assert grad_del_u.size == 9 * self._rows[k].size, "grad_del_u has the wrong length"
+        for d, s in enumerate(self.states):
+            lo, hi = self._bounds[d][k]
+            if hi > lo:
+                s.evaluate_law_into(k, grad_del_u[9 * lo: 9 * hi], stress_parent, tangent_parent, sync=False)
+        if sync:
+            self.check()
+
+    def check(self) -> None:
+        """Synchronise every device and look at every law's counters; raises the reference's exceptions."""
+        first = None
+        for s in self.states:
+            try:
+                s.check()
+            except RuntimeError as e:  # every device is synchronised before the first error is passed on
+                first = first or e
+        if first is not None:
+            raise first
+
+    def update(self) -> None:
+        """Commit (``IncrSmallStrainProblem.update``): refused as a whole if any device's trial state is not fit."""
+        self.check()
+        for s in self.states:
+            if s._evaluated:
+                s.update()
+            else:  # a device whose slices are all empty never evaluates: keep its clock in step
+                s._time += s._del_t
+
+    def download_history(self, k: int, history: dict, committed: bool = True) -> None:
+        """Law ``k``'s history (its LOCAL arrays) -> the caller's NumPy arrays."""
+        from .hostio import download
+
+        dims = self._law_objs[k].history_dim
+        for d, s in enumerate(self.states):
+            lo, hi = self._bounds[d][k]
+            if hi == lo:
+                continue
+            src = (s._history_0 if committed else s._history_1)[k]
+            for key, arr in history.items():
+                download(arr[dims[key] * lo: dims[key] * hi], src[key])
+
+    def close(self) -> None:
+        self.unpin_arrays()
+        self.states = []
 
     def __del__(self):
         try:

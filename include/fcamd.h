@@ -353,7 +353,9 @@ int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
    buffers.  The caller must unregister a buffer BEFORE freeing it: on this stack a page lock is an
    attribute of the pages, new memory that appears at the address of a freed, still-registered buffer
    does not carry it, and a launch on it ends in a GPU memory fault.  Registering is an optimisation
-   only: arrays that are not registered are page-locked for the duration of each call. */
+   only: arrays that are not registered are page-locked for the duration of each call.  A range that ANOTHER context of
+   the process has registered already (several GPUs or threads, one array) is entered into this context's registry with
+   its own device's view of it; the page lock stays with the first context -- unregister it there last. */
 int fcamd_register_host_buffer(fcamd_context* ctx, void* ptr, size_t bytes);
 int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
 /* Data path the last fcamd_evaluate_host / fcamd_evaluate_resident call of this context took:

@@ -309,3 +309,123 @@ def test_use_resident_state_with_devices_equals_the_unpatched_problem():
     assert states[0].last_host_mode()[1] == 2
     for s in states:
         s.close()
+
+
+@pytest.mark.parametrize("permuted", [False, True])
+def test_fused_problem_state_over_device_contexts_equals_unpatched(permuted):
+    """use_resident_problem_state(problem, devices=[0, 0, 0]): the fused multi-material host flow (kernels write their rows of
+    the GLOBAL stress / tangent host arrays, no submesh maps) with every law's points cut into three device slices --
+    bit-identical global arrays and histories against the unpatched reference protocol (stand-ins of test_gpu_integration)."""
+    import test_gpu_integration as TI
+    from fenics_constitutive_amd.integration import use_resident_problem_state
+    from fenics_constitutive_amd.multidevice import MultiDeviceProblemState
+
+    n_cells, q = 1500, 4
+    a, b = TI.build(n_cells, q, 13), TI.build(n_cells, q, 13)
+    if permuted:
+        rng_p = np.random.default_rng(1)
+        for pa, pb in zip(a._law_on_submeshs, b._law_on_submeshs):
+            perm = rng_p.permutation(pa.submesh_map.parent.size)
+            pa.submesh_map.sub, pb.submesh_map.sub = perm, perm.copy()
+            for k, f in pa.history.history_0.items():
+                d = f.x.array.size // perm.size
+                v = f.x.array.reshape(-1, d).copy()
+                f.x.array.reshape(-1, d)[perm] = v
+                pb.history.history_0[k].x.array[:] = f.x.array
+    for los in b._law_on_submeshs:  # no map call may survive the patch
+        los.submesh_map.map_to_sub = los.submesh_map.map_to_parent = None
+    state = use_resident_problem_state(b, devices=[0, 0, 0])
+    assert isinstance(state, MultiDeviceProblemState) and len(state.states) == 3
+    rng = np.random.default_rng(8)
+    try:
+        for inc in range(3):
+            for it in range(3):
+                for los_a, los_b in zip(a._law_on_submeshs, b._law_on_submeshs):
+                    m = los_a.stress.x.array.size // 6
+                    g = rng.normal(size=9 * m) * np.repeat(10 ** rng.uniform(-4, -1.8 if it else -3.5, size=m), 9)
+                    a.incr_disp.grads[los_a.cells.tobytes()] = g
+                    b.incr_disp.grads[los_b.cells.tobytes()] = g
+                a.form()
+                b.form()
+                assert np.array_equal(a.stress.current.x.array, b.stress.current.x.array), (inc, it)
+                assert np.array_equal(a.tangent.x.array, b.tangent.x.array), (inc, it)
+            a.update()
+            b.update()
+            for los_a, los_b in zip(a._law_on_submeshs, b._law_on_submeshs):
+                for k in los_a.history.history_0:
+                    assert np.array_equal(los_a.history.history_0[k].x.array, los_b.history.history_0[k].x.array), (inc, k)
+        assert all(s._tangent is None for s in state.states)  # the parent tangent never existed on a device
+    finally:
+        state.close()
+
+
+def test_multi_device_problem_state_never_commits_a_failed_law():
+    from fenics_constitutive_amd.multidevice import MultiDeviceProblemState
+    from test_oracle_c import NONCONVERGING, nonconverging_inputs
+
+    n = 4096
+    vm = fc.VonMises3D(NONCONVERGING)
+    le = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, FULL)
+    rows = [np.arange(0, n, 2, dtype=np.int32), np.arange(1, n, 2, dtype=np.int32)]
+    ps = MultiDeviceProblemState([(vm, rows[0]), (le, rows[1])], n, devices=[0, 0])
+    g_bad, _, _, _ = nonconverging_inputs(n // 2)
+    g_bad[: 9 * (n // 2 - 5)] = 0.0  # the failing points lie in the second device's slice only
+    g_le = np.full(9 * (n // 2), 1e-3)
+    sp, tp, g_ok = np.zeros(6 * n), np.zeros(36 * n), 0.0 * g_bad
+    ps.pin_host_arrays(sp, tp, g_bad, g_le, g_ok)  # page-locked: the asynchronous launches of the fused flow
+    ps.evaluate_law_into(0, g_bad, sp, tp, sync=False)
+    with pytest.raises(RuntimeError, match="did not converge"):
+        ps.evaluate_law_into(1, g_le, sp, tp, sync=True)
+    with pytest.raises(RuntimeError, match="did not converge"):
+        ps.update()
+    ps.evaluate_law_into(0, g_ok, sp, tp, sync=True)
+    ps.update()
+    assert ps._time == 1.0 and all(s._time == 1.0 for s in ps.states)
+    ps.close()
+
+
+def test_a_range_registered_by_one_context_is_entered_by_another():
+    """Two threads, a context each (one process driving several GPUs looks the same to the library): the second
+    registration of one array enters the first one's page lock instead of locking again (a second hipHostRegister of a
+    registered address 'succeeds' on this runtime and its unregister would take the owner's lock away)."""
+    import threading
+
+    n = 40_000
+    law = LAWS["vm"]()
+    g, s, h = inputs(law, n, np.random.default_rng(9), "vm")
+    ref = evaluate_copy(LAWS["vm"](), 1.0, g, s, h)
+    arrays = {"s": s.copy(), "t": np.full(36 * n, np.nan), "e": h["eps_n"].copy(), "a": h["alpha"].copy()}
+    main_ctx = _capi.get_context(0)
+    for x in (g, *arrays.values()):
+        main_ctx.register_host_buffer(x)
+    result = {}
+
+    def other_thread():
+        try:
+            ctx = _capi.get_context(0)  # thread-local: a context of its own
+            assert ctx is not main_ctx
+            for x in (g, *arrays.values()):
+                ctx.register_host_buffer(x)  # enters the main thread's registration
+            law.evaluate(0.0, 1.0, g, arrays["s"], arrays["t"], {"eps_n": arrays["e"], "alpha": arrays["a"]})
+            result["mode"] = ctx.last_host_mode()
+            for x in (g, *arrays.values()):
+                ctx.unregister_host_buffer(x)  # the borrower leaves; the page lock stays
+        except Exception as e:  # noqa: BLE001
+            result["error"] = e
+
+    t = threading.Thread(target=other_thread)
+    t.start()
+    t.join()
+    assert "error" not in result, result
+    assert result["mode"] == (_capi.HOST_ZERO_COPY_IN | _capi.HOST_ZERO_COPY_OUT)  # no per-call lock: the range was registered
+    assert_same((arrays["s"], arrays["t"], {"eps_n": arrays["e"], "alpha": arrays["a"]}), ref)
+    # the owner's registration is intact: another zero-copy call from this thread, then the real unlock
+    s2, t2, h2 = s.copy(), arrays["t"], {"eps_n": h["eps_n"].copy(), "alpha": h["alpha"].copy()}
+    arrays["s"][:] = s
+    arrays["e"][:], arrays["a"][:] = h["eps_n"], h["alpha"]
+    law.evaluate(0.0, 1.0, g, arrays["s"], arrays["t"], {"eps_n": arrays["e"], "alpha": arrays["a"]})
+    assert main_ctx.last_host_mode() == (_capi.HOST_ZERO_COPY_IN | _capi.HOST_ZERO_COPY_OUT)
+    assert_same((arrays["s"], arrays["t"], {"eps_n": arrays["e"], "alpha": arrays["a"]}), ref)
+    for x in (g, *arrays.values()):
+        main_ctx.unregister_host_buffer(x)
+    del s2, t2, h2
