@@ -165,7 +165,7 @@ int adopt_registered_range(fcamd_context* c, void* ptr, size_t bytes);
 // drop c's own registrations from the process-wide registry of registered ranges (context destruction)
 void forget_registered_ranges(fcamd_context* c);
 
-// fcamd_stream_kernels.hip: dst = src over n16 16-byte chunks (non-temporal accesses, grid-stride)
+// fcamd_aux_kernels.hip: dst = src over n16 16-byte chunks (non-temporal accesses, grid-stride)
 hipError_t launch_stream_copy(void* dst, const void* src, size_t n16, int grid, hipStream_t stream);
 
 }  // namespace fcamd

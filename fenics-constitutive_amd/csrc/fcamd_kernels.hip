@@ -249,96 +249,6 @@ __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) 
     flush_stats<LAW>(a, st, lane);
 }
 
-// Commit of a delta trial history (kFlagDeltaHistory): committed[row] += increment for the rows whose bit is set in the
-// tile's mask word (the plastic set of the last evaluate); the increments lie PACKED at the head of the tile's slot of
-// `delta` (kernels/history_rows.h: delta_rows_store), so they are read as one contiguous run per tile -- only the
-// committed rows are scattered accesses.  One wave per 64-point tile, 16-byte chunks: chunk q of the tile belongs to row
-// q / 3; the ragged last tile with guarded 8-byte accesses.
-__global__ void __launch_bounds__(kBlock)
-    commit_delta_kernel(double* committed, const double* delta, const unsigned long long* hmask, long long n) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const long long ntiles = (n + kWave - 1) / kWave;
-    const long long nfull = n / kWave;
-    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
-    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
-        const unsigned long long m = hmask[tile];
-        if (m == 0ull) continue;
-        const long long base = tile * kWave * 6;
-        if (tile < nfull) {
-            d2 c[3], d[3];
-            bool hit[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {  // all loads of the tile first, then the stores
-                const int q = k * kWave + lane;
-                const int p = q / 3;
-                hit[k] = ((m >> p) & 1ull) != 0ull;
-                if (hit[k]) {
-                    const int rank = (int)__popcll(m & ((1ull << p) - 1ull));
-                    c[k] = load16<true>(committed + base + 2 * q);
-                    d[k] = load16<true>(delta + base + 2 * (3 * rank + (q - 3 * p)));
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (hit[k]) {
-                    d2 r;
-                    r.x = c[k].x + d[k].x;
-                    r.y = c[k].y + d[k].y;
-                    store16<true>(committed + base + 2 * (k * kWave + lane), r);
-                }
-            }
-        } else {
-            const int npts = (int)(n - tile * kWave);
-            if (lane < npts && ((m >> lane) & 1ull)) {
-                const int rank = (int)__popcll(m & ((1ull << lane) - 1ull));
-#pragma unroll
-                for (int i = 0; i < 6; ++i) committed[base + 6 * lane + i] = committed[base + 6 * lane + i] + delta[base + 6 * rank + i];
-            }
-        }
-    }
-}
-
-hipError_t launch_commit_delta(double* committed, const double* delta, const unsigned long long* hmask, long long n, int grid,
-                               hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(commit_delta_kernel, dim3(grid), dim3(kBlock), 0, stream, committed, delta, hmask, n);
-    return hipGetLastError();
-}
-
-// strain_from_grad_u (FULL): [9n] -> [6n]
-template <bool NT>
-__global__ void __launch_bounds__(kBlock)
-    strain_kernel(const double* grad, double* strain, long long n, double factor) {
-    __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
-    const int lane = threadIdx.x & (kWave - 1);
-    // wave index as a scalar: tile index, p0 and every array's tile base pointer then live in SGPRs and
-    // the per-lane part of an address is a small 32-bit offset (saddr addressing)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    double* region = scratch[wave];
-    const long long ntiles = (n + kWave - 1) / kWave;
-    const long long nfull = n / kWave;
-    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
-    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
-         tile += wstride) {
-        const long long p0 = tile * kWave;
-        Chunks<9> cg;
-        double g[9], e[6];
-        if (tile < nfull) {
-            tile_load<9, true, NT>(cg, grad + p0 * 9, kWave * 9, lane);
-            transpose_in<9>(cg, region, lane, g);
-            mandel_strain(g, factor, e);
-            transpose_out<6, true, NT>(e, region, lane, strain + p0 * 6, kWave * 6);
-        } else {
-            const int npts = (int)(n - p0);
-            tile_load<9, false, NT>(cg, grad + p0 * 9, npts * 9, lane);
-            transpose_in<9>(cg, region, lane, g);
-            mandel_strain(g, factor, e);
-            transpose_out<6, false, NT>(e, region, lane, strain + p0 * 6, npts * 6);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------
@@ -447,74 +357,6 @@ int default_grid(int law, int num_cu) {
     // 9.0-9.6, 16384: 9.0-9.4 -- short queues of workgroups rebalance CUs and HBM channels.
     (void)law;
     return 64 * num_cu;
-}
-
-// Component maps of the 3D<->1D/2D wrappers: a pure strided copy, one thread per moved double.
-__global__ void __launch_bounds__(kBlock)
-    strided_copy_kernel(const double* in, double* out, long long n, const CopyMap m) {
-    const long long total = n * m.K;
-    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
-         e += (long long)gridDim.x * kBlock) {
-        const long long i = e / m.K;
-        const int k = (int)(e - i * m.K);
-        out[i * m.out_stride + m.omap[k]] = in[i * m.in_stride + m.imap[k]];
-    }
-}
-
-hipError_t launch_strided_copy(const double* in, double* out, long long n, const CopyMap& m,
-                               hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    const long long total = n * m.K;
-    long long blocks = (total + kBlock - 1) / kBlock;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(strided_copy_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, in, out, n, m);
-    return hipGetLastError();
-}
-
-// Row gather/scatter (submesh <-> parent maps).  One thread per 16-byte chunk when rows are an
-// even number of doubles (6, 36, 16, 4: consecutive lanes walk along a row, so each row is moved
-// by full-width contiguous accesses), one per double otherwise.
-template <int W>  // doubles per thread: 2 or 1
-__global__ void __launch_bounds__(kBlock)
-    map_rows_kernel(const double* src, const int* src_idx, double* dst, const int* dst_idx,
-                    long long n_rows, int row_size) {
-    const int per_row = row_size / W;
-    const long long total = n_rows * per_row;
-    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
-         e += (long long)gridDim.x * kBlock) {
-        const long long r = e / per_row;
-        const int c = (int)(e - r * per_row);
-        const long long sr = src_idx ? (long long)src_idx[r] : r;
-        const long long dr = dst_idx ? (long long)dst_idx[r] : r;
-        if constexpr (W == 2) {
-            *reinterpret_cast<d2*>(dst + dr * row_size + 2 * c) =
-                *reinterpret_cast<const d2*>(src + sr * row_size + 2 * c);
-        } else {
-            dst[dr * row_size + c] = src[sr * row_size + c];
-        }
-    }
-}
-
-hipError_t launch_map_rows(const double* src, const int* src_idx, double* dst, const int* dst_idx,
-                           long long n_rows, int row_size, hipStream_t stream) {
-    if (n_rows <= 0 || row_size <= 0) return hipSuccess;
-    const bool wide = (row_size % 2 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
-    const long long total = n_rows * (wide ? row_size / 2 : row_size);
-    long long blocks = (total + kBlock - 1) / kBlock;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    if (wide)
-        hipLaunchKernelGGL(map_rows_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, src, src_idx, dst, dst_idx, n_rows, row_size);
-    else
-        hipLaunchKernelGGL(map_rows_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, src, src_idx, dst, dst_idx, n_rows, row_size);
-    return hipGetLastError();
-}
-
-hipError_t launch_strain(const double* grad, double* strain, long long n, double factor, int grid,
-                         hipStream_t stream) {
-    hipLaunchKernelGGL((strain_kernel<kNT>), dim3(grid), dim3(kBlock), 0, stream, grad, strain, n,
-                       factor);
-    return hipGetLastError();
 }
 
 }  // namespace fcamd
