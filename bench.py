@@ -922,8 +922,9 @@ def main():
     ap.add_argument("--configs", choices=["auto", "all", "none"], default="auto",
                     help="the other single-GPU BASELINE configurations after the headline: auto = when no --workload is given and N = 1")
     ap.add_argument("--config-steps", type=int, default=6, help="timed launches per extra configuration (>= 5)")
-    ap.add_argument("--n", "--points", dest="n", type=int, default=100_000_000,
-                    help="quadrature points per GPU (use --points under torch.distributed.run, whose parser claims --n)")
+    ap.add_argument("--n", "--points", dest="n", type=int, default=None,
+                    help="quadrature points per GPU (use --points under torch.distributed.run, whose parser claims --n); default 1e8, "
+                         "--mode host: 1e7 (the arrays are host memory: 568 B per point)")
     ap.add_argument("--grid", type=int, default=0, help="override the launch grid (workgroups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--history", choices=["sparse", "full"], default="sparse",
@@ -979,6 +980,8 @@ def main():
                     help="seconds of wall clock after which the optional legs (strong-scaling leg, gather variants, extra configurations, host_path) "
                          "are skipped so that the line is printed inside the driver's limit")
     args = ap.parse_args()
+    if args.n is None:
+        args.n = 10_000_000 if args.mode == "host" else 100_000_000
     if args.mode == "host":
         sys.exit(main_host(args))
 
