@@ -114,3 +114,18 @@ def test_default_line_carries_the_host_path_block():
     assert set(hp["sizes"]) == {"1000000", "2000000"}
     assert hp["sizes"]["2000000"]["registered"]["resident_sparse"]["Mpts_s"] > hp["sizes"]["2000000"]["registered"]["resident"]["Mpts_s"] * 0.8
     assert out["roofline"]["traffic"] is None or "traffic_source" in out["roofline"]
+
+
+def test_one_rank_under_the_launcher_with_rccl():
+    """The driver's launch shape (python -m torch.distributed.run ... bench.py --gpus N) with N = 1: the process group is
+    RCCL, the barriers / all-reduces of the timed region and of the per-rank kernel times run on the device."""
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), BENCH, "--gpus", "1", "--steps", "3", "--warmup", "1", "--points", "2000000",
+           "--configs", "none", "--no-cpu-baseline", "--no-host-path", "--placement-tries", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["per_rank_kernel_ms"] and len(out["per_rank_kernel_ms"]) == 1
+    assert "allgather" not in out and "strong_scaling" not in out and "host_path" not in out and "host_path_multi" not in out
+    assert abs(out["value"] - 2_000_000 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) <= 0.01 * out["value"]
