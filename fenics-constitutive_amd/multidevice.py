@@ -217,9 +217,11 @@ class MultiDeviceProblemState:
     """Several laws on one mesh, one assembling process, several GPUs: ``ResidentProblemState`` (the fused multi-material
     host flow: every law's kernel reads its local gradient from and writes its rows of the problem's GLOBAL stress /
     tangent host arrays itself -- no ``map_to_sub`` / ``map_to_parent``, solver/maps.py:82-123) with every law's points cut
-    into contiguous slices, one per device.  Device d keeps the committed / trial parent stress rows and the history of
-    ITS slices and launches its laws on its own stream; one Python thread enqueues the launches of all devices (they are
-    asynchronous: the devices work concurrently, each over its own PCIe link) and synchronises once.
+    into contiguous slices, one per device.  Device d keeps the history of ITS slices and a parent-sized committed / trial
+    stress pair of which it only ever touches the rows of its slices (2 x 48 bytes per PARENT point and device: the indexed
+    kernel addresses all stress arrays of a launch by parent row) and launches its laws on its own stream; one Python
+    thread enqueues the launches of all devices (they are asynchronous: the devices work concurrently, each over its own
+    PCIe link) and synchronises once.
 
     ``laws``: a list of ``(law, rows)`` as for ``ResidentProblemState`` (``rows`` = parent rows of the law's local points;
     one law with ``rows=None`` covers all points).  The global host arrays must be page-locked for every device:
