@@ -440,6 +440,7 @@ def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="
         # PMC-measured HBM bytes of this configuration's launch (profiles/traffic.json: its own rocprofv3 passes, same kernels)
         key = name + ("_full" if wl.plasticity and not wl.sparse else "") + ("_delta" if wl.delta else "")
         out["traffic"] = read_traffic(key, n)
+        out["traffic_source"] = None if not out["traffic"] else f"profiles/traffic.json[{key}] (stored rocprofv3 --pmc measurement of these kernels)"
         out["traffic_over_algorithmic"] = None if not out["traffic"] else round(out["traffic"] / alg, 4)
         out["placement_mode"] = (wl.vmm_info or {}).get("mode", "hipmalloc_tuned" if wl.placement else "first")
         if wl.vmm_info and "vmm_ms" in wl.vmm_info:
