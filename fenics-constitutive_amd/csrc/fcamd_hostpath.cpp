@@ -29,7 +29,7 @@ bool zero_copy_enabled(const fcamd_context* c) { return c->opt.zero_copy != 0; }
 
 // chunk slots of the host-staged entries: sizes the slots, creates the streams, returns the chunk
 // length.  Enough chunks in flight to keep both DMA directions busy.  Measured on MI355X / PCIe
-// gen5 (tools/host_path_bench.py): page-locked caller arrays like many small chunks in flight
+// gen5 (bench.py (host_path_figures)): page-locked caller arrays like many small chunks in flight
 // (4 x 128 Ki points: 116 Mpts/s); pageable arrays are staged by the runtime and prefer large
 // chunks (512 Ki points: 93 Mpts/s).  FCAMD_HOST_CHUNK / FCAMD_HOST_SLOTS override (experiments).
 // `staging` = false: every per-chunk array is read / written by the kernel in the caller's page-locked
