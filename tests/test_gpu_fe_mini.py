@@ -78,3 +78,106 @@ def test_cube_under_tension(kind, mode):
         assert norms[-1][-1] > 1e-3 * norms[-1][0]             # ... which has not converged after 8 iterations
     else:
         assert all(len(h) <= 2 for h in norms)                 # linear viscoelastic step: one solve
+
+
+# ---- two materials on one mesh: the fused multi-material host flow inside the Newton loop -------------------------------
+class TwoLawOracleState(FE.CopyProtocolState):
+    """the reference's protocol with two laws on disjoint cell sets: every law sees the rows of its cells (what
+    LawOnSubMesh + SubSpaceMap do, solver/_lawonsubmesh.py:47-110), evaluated by the CPU oracle laws"""
+
+    def __init__(self, laws_rows, n):
+        self.laws_rows, self.n = laws_rows, n
+        self.stress_c, self.stress, self.tangent = np.zeros(6 * n), np.zeros(6 * n), np.zeros(36 * n)
+        self.hist_c = [None if law.history_dim is None else {k: np.zeros(d * rows.size) for k, d in law.history_dim.items()} for law, rows in laws_rows]
+
+    def evaluate(self, t, del_t, grad):
+        self.trial = []
+        for (law, rows), hc in zip(self.laws_rows, self.hist_c):
+            s = self.stress_c.reshape(-1, 6)[rows].reshape(-1).copy()
+            tan = np.zeros(36 * rows.size)
+            h = None if hc is None else {k: v.copy() for k, v in hc.items()}
+            law.evaluate(t, del_t, grad.reshape(-1, 9)[rows].reshape(-1).copy(), s, tan, h)
+            self.stress.reshape(-1, 6)[rows] = s.reshape(-1, 6)
+            self.tangent.reshape(-1, 36)[rows] = tan.reshape(-1, 36)
+            self.trial.append(h)
+
+    def commit(self):
+        self.stress_c[:] = self.stress
+        self.hist_c = self.trial
+
+
+class FusedProblemProtocolState:
+    """ResidentProblemState / MultiDeviceProblemState behind the same two calls: every law's kernel writes its rows of the
+    GLOBAL stress / tangent arrays of the solver itself (no per-law arrays, no map_to_parent)."""
+
+    def __init__(self, ps, rows, n):
+        self.ps, self.rows, self.n = ps, rows, n
+        self.stress, self.tangent = np.zeros(6 * n), np.zeros(36 * n)
+        self.grads = [np.zeros(9 * r.size) for r in rows]
+
+    def pin(self, pinner):
+        pinner(self.stress, self.tangent, *self.grads)
+
+    def evaluate(self, t, del_t, grad):
+        self.ps._time, self.ps._del_t = t, del_t
+        for k, r in enumerate(self.rows):
+            self.grads[k][:] = grad.reshape(-1, 9)[r].reshape(-1)  # the per-law gradient array of the reference (incr_disp.evaluate_local_incremental_gradient)
+            self.ps.evaluate_law_into(k, self.grads[k], self.stress, self.tangent, sync=(k == len(self.rows) - 1))
+
+    def commit(self):
+        self.ps.update()
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_two_material_cube(devices):
+    """A cube whose lower layers are VonMises3D and upper layers LinearElasticityModel (a stiff elastic cap), pulled until the
+    lower part yields: the fused multi-material flow (one device, and every law's points over three device contexts)
+    against the reference protocol with the oracle laws -- and an all-elastic two-material bar against its closed form
+    (tests/models/test_elasticity.py:90-154: two springs in series)."""
+    from fenics_constitutive_amd.multidevice import MultiDeviceProblemState
+    from fenics_constitutive_amd.problem import ResidentProblemState, rows_of_cells
+
+    mesh = FE.Cube(4, 4, 6)
+    zc = mesh.nodes[mesh.cells].mean(axis=1)[:, 2]
+    cells = [np.flatnonzero(zc < 0.5), np.flatnonzero(zc >= 0.5)]
+    rows = [rows_of_cells(c, 8) for c in cells]
+    le_p = {"E": 210000.0, "nu": 0.3}
+
+    def gpu_state(laws):
+        ps = (ResidentProblemState(list(zip(laws, rows)), mesh.n_points, placement="torch") if devices is None
+              else MultiDeviceProblemState(list(zip(laws, rows)), mesh.n_points, devices))
+        st = FusedProblemProtocolState(ps, rows, mesh.n_points)
+        if devices is None:
+            st.pin(laws[0].pin_host_arrays)
+        else:
+            st.pin(ps.pin_host_arrays)
+        return st, ps
+
+    # (1) plastic bottom, elastic top
+    ref = TwoLawOracleState([(FE.OracleLaw(O.von_mises_3d, VM_P, {"eps_n": 6, "alpha": 1}), rows[0]),
+                             (FE.OracleLaw(O.linear_elasticity, le_p, None), rows[1])], mesh.n_points)
+    r_ref, n_ref, u_ref = FE.tension_test(mesh, ref, steps=5, top_displacement=0.008)
+    laws = [fc.VonMises3D(VM_P), fc.LinearElasticityModel(le_p, fc.StressStrainConstraint.FULL)]
+    st, ps = gpu_state(laws)
+    try:
+        r, norms, u = FE.tension_test(mesh, st, steps=5, top_displacement=0.008)
+        assert np.max(np.abs(r - r_ref)) <= 1e-8 * np.max(np.abs(r_ref))
+        assert np.max(np.abs(u - u_ref)) <= 1e-7 * np.max(np.abs(u_ref))
+        assert [len(h) for h in norms] == [len(h) for h in n_ref] and max(len(h) for h in norms) >= 4
+        assert max(FE.convergence_orders(norms)) >= 1.7  # quadratic once the plastic zone has settled
+    finally:
+        laws[0].unpin_arrays()
+        if devices is not None:
+            ps.close()
+    # (2) two elastic materials in series, nu = 0, uniform pull: reaction = d / (0.5 / E_a + 0.5 / E_b)
+    Ea, Eb, d = 42.0, 10.0, 0.01
+    laws = [fc.LinearElasticityModel({"E": Ea, "nu": 0.0}, fc.StressStrainConstraint.FULL),
+            fc.LinearElasticityModel({"E": Eb, "nu": 0.0}, fc.StressStrainConstraint.FULL)]
+    st, ps = gpu_state(laws)
+    try:
+        r, norms, u = FE.tension_test(mesh, st, steps=2, top_displacement=d, tilt=0.0)
+        assert abs(r[-1] - d / (0.5 / Ea + 0.5 / Eb)) <= 1e-11 * abs(r[-1])
+    finally:
+        laws[0].unpin_arrays()
+        if devices is not None:
+            ps.close()
