@@ -429,3 +429,30 @@ def test_a_range_registered_by_one_context_is_entered_by_another():
     for x in (g, *arrays.values()):
         main_ctx.unregister_host_buffer(x)
     del s2, t2, h2
+
+
+@pytest.mark.parametrize("kind,constraint", [("kelvin", "PLANE_STRESS"), ("maxwell", "UNIAXIAL_STRESS"), ("le", "PLANE_STRAIN"), ("kelvin", "UNIAXIAL_STRAIN")])
+def test_multi_device_resident_state_low_dimensional_constraints(kind, constraint):
+    """the laws the reference implements for all constraints, resident over three device contexts (the chunked pass of
+    fcamd_evaluate_resident: 1 / 4 doubles per point instead of 6 / 9) against the single-device resident state"""
+    c = fc.StressStrainConstraint[constraint]
+    n = 64 * 300 + 11
+    law = LAWS[kind](c)
+    rng = np.random.default_rng(21)
+    gd2, sd = law.geometric_dim**2, law.stress_strain_dim
+    one = ResidentState(law, n, placement="torch")
+    multi = MultiDeviceResidentState(LAWS[kind](c), n, devices=[0, 0, 0])
+    sa, ta, sb, tb = np.zeros(sd * n), np.full(sd * sd * n, np.nan), np.zeros(sd * n), np.full(sd * sd * n, np.nan)
+    for inc in range(3):
+        for it in range(2):
+            g = rng.normal(scale=1e-3, size=gd2 * n)
+            one.evaluate_into(float(inc), 0.5, g, sa, ta)
+            multi.evaluate_into(float(inc), 0.5, g, sb, tb)
+            assert np.array_equal(sa, sb) and np.array_equal(ta, tb), (inc, it)
+        one.update()
+        multi.update()
+        if law.history_dim is not None:
+            hc = multi.history_committed
+            for k in law.history_dim:
+                assert np.array_equal(hc[k], one.history_committed[k].cpu().numpy()), (inc, k)
+    multi.close()
