@@ -456,3 +456,31 @@ def test_multi_device_resident_state_low_dimensional_constraints(kind, constrain
             for k in law.history_dim:
                 assert np.array_equal(hc[k], one.history_committed[k].cpu().numpy()), (inc, k)
     multi.close()
+
+
+def test_multi_handle_error_paths():
+    """a device that does not exist, flags of the wrong law, wrong history counts: statuses with messages, no leaks of
+    half-built handles (the worker threads of a failed create are joined)"""
+    import threading
+
+    before = threading.active_count()  # Python threads only; the C workers are not counted, a hang would be
+    with pytest.raises(ValueError, match="out of range"):
+        _capi.Multi([0, 99], _capi.VON_MISES_3D, 5, [175000.0, 80769.0, 1200.0, 2500.0, 200.0])
+    with pytest.raises(ValueError):
+        _capi.Multi([0], _capi.VON_MISES_3D, 5, [1.0, 2.0])  # wrong parameter count
+    with pytest.raises(NotImplementedError):
+        _capi.Multi([0, 0], _capi.VON_MISES_3D, 3, [175000.0, 80769.0, 1200.0, 2500.0, 200.0])  # PLANE_STRAIN: FULL only
+    m = _capi.Multi([0, 0], _capi.VON_MISES_3D, 5, [175000.0, 80769.0, 1200.0, 2500.0, 200.0])
+    with pytest.raises(NotImplementedError, match="SPLIT_HISTORY"):
+        _capi.MultiState(m, 1000, _capi.EVAL_SPLIT_HISTORY)  # VonMises3D has no 7-double rows
+    st = _capi.MultiState(m, 1000)
+    a = np.zeros(6000)
+    with pytest.raises(AssertionError, match="history fields"):
+        st.set(a.ctypes.data, [a.ctypes.data])  # one history array for a law with two fields
+    with pytest.raises(ValueError, match="commit before any evaluate"):
+        st.commit()
+    with pytest.raises(ValueError, match="SPARSE_TANGENT or 0"):
+        st.evaluate(0.0, 1.0, np.zeros(9000).ctypes.data, None, None, flags=_capi.EVAL_DELTA_HISTORY)
+    m.close()  # destroys the state that is still alive on it
+    st.close()  # ... so this is a no-op
+    assert threading.active_count() == before
