@@ -98,6 +98,7 @@ class DeviceLaw(IncrSmallStrainModel):
         # ndarray path spreads every call over (use_devices; environment default FCAMD_DEVICES)
         self._devices = _capi.default_devices()
         self._multi_handle = None
+        self._multi_lock = threading.Lock()  # two threads' first calls must not build two handles (the handle itself serialises calls)
 
     # -- interface properties --------------------------------------------------------------
     @property
@@ -137,9 +138,10 @@ class DeviceLaw(IncrSmallStrainModel):
         return None if self._devices is None else list(self._devices)
 
     def _multi(self) -> "_capi.Multi":
-        if self._multi_handle is None:
-            self._multi_handle = _capi.Multi(self._devices, self._model_id, self._constraint.value, self._parameter_vector)
-        return self._multi_handle
+        with self._multi_lock:
+            if self._multi_handle is None:
+                self._multi_handle = _capi.Multi(self._devices, self._model_id, self._constraint.value, self._parameter_vector)
+            return self._multi_handle
 
     def _history_arrays(self, history):
         """Order the caller's history dict by the law's field order."""
