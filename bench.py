@@ -1360,6 +1360,16 @@ def main():
         except Exception:
             pass
         if rank == 0:
+            import threading
+
+            def give_up_host():  # as for the gather leg: a leg that hangs on hardware nobody could rehearse must not cost the line
+                out["host_path_multi"] = {"error": "the single-process multi-GPU host leg did not finish within its time limit; everything above is complete"}
+                emit()
+                os._exit(3)
+
+            host_watchdog = threading.Timer(max(45.0, min(150.0, budget_left() - 20.0)), give_up_host)
+            host_watchdog.daemon = True
+            host_watchdog.start()
             try:
                 if budget_left() > 75 and store is not None:
                     have = torch.cuda.device_count()
@@ -1372,6 +1382,7 @@ def main():
                     out["host_path_multi"] = {"skipped": "wall budget" if store is not None else "no process-group store to wait on"}
             except Exception as e:  # informational: must not lose the line
                 out["host_path_multi"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            host_watchdog.cancel()
             if store is not None:
                 store.set("fcamd_host_multi_done", "1")
         elif store is not None:
