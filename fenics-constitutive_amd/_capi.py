@@ -58,7 +58,7 @@ SYMBOLS = [
     "fcamd_device_alloc_set", "fcamd_device_free",
     "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
     "fcamd_context_set_option", "fcamd_context_get_option", "fcamd_context_trim",
-    "fcamd_last_error", "fcamd_status_string", "fcamd_version",
+    "fcamd_last_error", "fcamd_status_string", "fcamd_version", "fcamd_device_count",
 ]
 
 IPC_HANDLE_BYTES = 64
@@ -200,6 +200,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_multi_state_get.argtypes = [vp, C.c_int, vp, C.POINTER(vp), C.c_int]
         lib.fcamd_multi_state_evaluate.argtypes = [vp, C.c_double, C.c_double, vp, vp, vp, C.c_int, C.POINTER(Stats)]
         lib.fcamd_multi_state_commit.argtypes = [vp]
+        lib.fcamd_device_count.argtypes = [C.POINTER(C.c_int)]
         lib.fcamd_last_error.restype = C.c_char_p
         lib.fcamd_status_string.restype = C.c_char_p
         lib.fcamd_status_string.argtypes = [C.c_int]
@@ -393,21 +394,31 @@ def gather_chunk_plan(slot_points: int, world: int, values_per_point: int, budge
     return int(c.value), int(k.value)
 
 
+def device_count() -> int:
+    """visible HIP devices (``fcamd_device_count``; 0 without a GPU)"""
+    n = C.c_int()
+    return int(n.value) if load().fcamd_device_count(C.byref(n)) == OK else 0
+
+
 def default_device() -> int:
-    """GPU used by the NumPy (host) path of this process: ``FCAMD_DEVICE`` if set, else torch's
-    current device when torch has been imported, else the node-local rank of the usual launchers
-    (one MPI rank / one torchrun worker per GPU, as dolfinx runs), else 0."""
+    """GPU used by the NumPy (host) path of this process: ``FCAMD_DEVICE`` if set; else a device the application has
+    selected itself (``torch.cuda.set_device(k)``, k != 0); else the node-local rank of the usual launchers MODULO the
+    number of visible GPUs -- dolfinx under MPI runs one rank per GPU, or several ranks per GPU when there are more ranks
+    than GPUs; else torch's current device / 0."""
     import sys
 
     if "FCAMD_DEVICE" in os.environ:
         return int(os.environ["FCAMD_DEVICE"])
     torch = sys.modules.get("torch")
-    if torch is not None and torch.cuda.is_available():
-        return int(torch.cuda.current_device())
+    cur = int(torch.cuda.current_device()) if torch is not None and torch.cuda.is_available() else None
+    if cur:  # selected explicitly: the application's choice wins over the launcher's numbering
+        return cur
     for var in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"):
         if var in os.environ:
-            return int(os.environ[var])
-    return 0
+            rank = int(os.environ[var])
+            count = int(torch.cuda.device_count()) if cur is not None else device_count()
+            return rank % count if count > 0 else rank
+    return cur or 0
 
 
 # Thread-local: a context (4 chunk streams, up to ~1.1 GB of staging buffers, the registry of page-locked

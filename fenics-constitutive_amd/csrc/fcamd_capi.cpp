@@ -450,6 +450,16 @@ extern "C" {
 
 int fcamd_version(void) { return FCAMD_VERSION_MAJOR * 1000 + FCAMD_VERSION_MINOR; }
 
+int fcamd_device_count(int* count) {
+    if (!count) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    *count = 0;
+    if (hipGetDeviceCount(count) != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+    }
+    return FCAMD_OK;
+}
+
 const char* fcamd_last_error(void) { return g_last_error.c_str(); }
 
 const char* fcamd_status_string(int status) {

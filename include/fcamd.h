@@ -557,6 +557,8 @@ int fcamd_context_get_option(fcamd_context* ctx, const char* name, long long* va
 /* Release the staging buffers the pageable host path keeps between calls (up to ~1.1 GB). */
 int fcamd_context_trim(fcamd_context* ctx);
 
+/* Number of HIP devices visible to the process (0 and FCAMD_OK when there is none). */
+int fcamd_device_count(int* count);
 const char* fcamd_last_error(void);
 const char* fcamd_status_string(int status);
 int fcamd_version(void);

@@ -155,8 +155,12 @@ def test_default_device_selection(monkeypatch):
 
     if torch.cuda.is_available():
         assert _capi.default_device() == torch.cuda.current_device()
+        # a launcher's local rank maps onto the visible GPUs modulo their number (more ranks than GPUs share them) ...
+        monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", str(torch.cuda.device_count() + 1))
+        if torch.cuda.current_device() == 0:
+            assert _capi.default_device() == 1 % torch.cuda.device_count()
     else:
-        assert _capi.default_device() == 0
+        assert _capi.default_device() == 0 and _capi.device_count() == 0
         monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_RANK", "3")
         assert _capi.default_device() == 3
         monkeypatch.setenv("LOCAL_RANK", "5")
