@@ -71,6 +71,53 @@ BASELINE_CONFIG = {"linear_elasticity": "configs[1]", "von_mises_mixed": "config
 PLASTICITY = ("von_mises_3d", "comfe_mises_plasticity", "comfe_drucker_prager")
 
 
+class LineGuard:
+    """The ONE JSON line survives the death of the process that measured it.
+
+    The timed steps are over long before the optional legs (all-gather variants, extra configurations, host path, CPU
+    baselines) are; a leg that takes the process down on hardware nobody could rehearse (a fault in a peer mapping, the
+    launcher terminating rank 0 because another rank died) must not cost the measured line.  A small child process
+    (started BEFORE anything touches the GPU, no GPU use of its own, a session of its own) reads lines from a pipe and
+    prints the LAST one it received when the pipe closes: rank 0 sends the line as it stands before every optional leg
+    (marked "incomplete": the leg it was about to enter) and the complete line at the end.  Exactly one line reaches
+    stdout either way; the exit code of the job still says that a leg failed."""
+
+    CHILD = ("import sys\nlast = None\nfor line in sys.stdin:\n    if line.strip():\n        last = line\n"
+             "if last is not None:\n    sys.stdout.write(last if last.endswith('\\n') else last + '\\n')\n    sys.stdout.flush()\n")
+
+    def __init__(self):
+        import subprocess
+
+        self.proc = None
+        try:
+            self.proc = subprocess.Popen([sys.executable, "-c", self.CHILD], stdin=subprocess.PIPE, text=True, start_new_session=True)
+        except OSError:
+            pass  # no guard: the line is printed directly at the end
+
+    def _send(self, line):
+        self.proc.stdin.write(line + "\n")
+        self.proc.stdin.flush()
+
+    def provisional(self, out, leg):
+        if self.proc is None:
+            return
+        try:
+            self._send(json.dumps(dict(out, incomplete=f"the process ended in the optional leg '{leg}'; everything in this line was measured before it")))
+        except (OSError, ValueError):
+            self.proc = None
+
+    def final(self, line):
+        if self.proc is not None:
+            try:
+                self._send(line)
+                self.proc.stdin.close()
+                self.proc.wait(timeout=30)
+                return
+            except Exception:
+                pass
+        print(line, flush=True)
+
+
 def make_law(kind):
     import numpy as np
 
@@ -1009,6 +1056,7 @@ def main():
                    os.path.abspath(__file__)] + [a if a != "--n" else "--points" for a in sys.argv[1:]]
             sys.exit(subprocess.run(cmd).returncode)
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    guard = LineGuard() if rank == 0 else None  # before the first call that initialises the GPU
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     dev_index = local_rank % torch.cuda.device_count()  # identity on a node with one GPU per rank
@@ -1287,7 +1335,13 @@ def main():
 
     def emit():
         out["wall_s"] = round(time.perf_counter() - t_start, 1)
-        print(json.dumps(out), flush=True)
+        guard.final(json.dumps(out))
+
+    def checkpoint(leg):  # the line as it stands, in case the process does not survive `leg`
+        if rank == 0:
+            guard.provisional(dict(out, wall_s=round(time.perf_counter() - t_start, 1)), leg)
+            if os.environ.get("BENCH_DIE_IN") == leg.split(":")[0]:  # knob: fault injection (tests/test_gpu_bench_cli.py)
+                os.kill(os.getpid(), 9)
 
     # the exchange step of config 5, timed separately (never part of `value`)
     do_gather = distributed and world > 1 and not args.no_gather
@@ -1296,6 +1350,7 @@ def main():
         if rank == 0:
             out["allgather"] = {"skipped": f"wall budget: {budget_left():.0f} s left of --wall-budget {args.wall_budget:.0f}"}
     if do_gather:
+        checkpoint("allgather")
         # An exchange between 8 processes can hang in ways a single GPU cannot rehearse (a peer mapping that never
         # returns, ranks leaving a collective in different places): the measured line must survive that.  If the leg
         # has not finished after --gather-timeout seconds, rank 0 prints the line with an error entry and every rank
@@ -1330,6 +1385,8 @@ def main():
     if do_configs and rank == 0:
         configs = {}
         for k, cname in enumerate(EXTRA_CONFIGS):
+            out["configs"] = configs
+            checkpoint(f"configs: {cname}")
             if budget_left() < 45:
                 configs[cname] = {"skipped": "wall budget"}
                 continue
@@ -1361,6 +1418,8 @@ def main():
             pass
         if rank == 0:
             import threading
+
+            checkpoint("host_path_multi")
 
             def give_up_host():  # as for the gather leg: a leg that hangs on hardware nobody could rehearse must not cost the line
                 out["host_path_multi"] = {"error": "the single-process multi-GPU host leg did not finish within its time limit; everything above is complete"}
@@ -1394,12 +1453,14 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_host_path and args.workload is None and budget_left() > 40:
             # the number a dolfinx user sees: the ndarray entries over PCIe ("timed separately and labelled as such")
+            checkpoint("host_path")
             try:
                 torch.cuda.empty_cache()
                 out["host_path"] = host_path_figures(devices=None, sizes=(1_000_000, min(n, 10_000_000)) if n > 1_000_000 else (n,))
             except Exception as e:  # informational: must not lose the line
                 out["host_path"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1:
+            checkpoint("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(*cpu_args) if cpu_args is not None else None
         emit()
     if distributed:

@@ -330,3 +330,33 @@ def test_kernel_hash_ignores_comments_but_not_code():
     assert _build.kernel_hash(tree(lambda t: t.replace("namespace fcamd {", "namespace fcamd {  // a remark\n\n   /* and\n another */", 1))) == base
     assert _build.kernel_hash(tree(lambda t: t.replace("return 64 * num_cu;", "return 32 * num_cu;", 1))) != base
     assert "-pthread" not in _build.KERNEL_FLAGS and "-ffp-contract=off" in _build.KERNEL_FLAGS
+
+
+@pytest.mark.parametrize("die", [True, False])
+def test_bench_line_guard_prints_exactly_one_line(die):
+    """bench.py's measured line survives the death of the process in an optional leg: the guard child prints the last
+    line it was handed (provisional, marked incomplete) -- or the final one, and never both."""
+    import json
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent(f"""
+        import json, os, sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        g = bench.LineGuard()
+        g.provisional({{"value": 1}}, "leg a")
+        g.provisional({{"value": 2}}, "leg b")
+        if {die!r}:
+            os.kill(os.getpid(), 9)
+        g.final(json.dumps({{"value": 3}}))
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    got = json.loads(lines[0])
+    if die:
+        assert r.returncode != 0 and got["value"] == 2 and "leg b" in got["incomplete"]
+    else:
+        assert r.returncode == 0 and got == {"value": 3}
