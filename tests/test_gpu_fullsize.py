@@ -303,3 +303,48 @@ def test_split_history_1e8(law_name):
             assert torch.equal(a, b)
             del a, b
     assert 0.05 < fractions[0] < 0.5 and fractions[2] >= fractions[0]
+
+
+def _host_memory_gb():
+    with open("/proc/meminfo") as f:
+        for line in f:
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    return 0.0
+
+
+@pytest.mark.parametrize("contexts", [1, 2])
+def test_host_path_arrays_beyond_4GiB(contexts):
+    """The ndarray ``evaluate`` (zero-copy host path: the kernel works on the caller's page-locked arrays over PCIe) with a
+    tangent array of 5.2 GB -- byte offsets beyond 2^32 inside one array, page locks of several GiB -- on one context and
+    cut over two device contexts (``use_devices``); bit for bit the device path's result, whole arrays compared."""
+    n = 18_000_000  # tangent 5.18 GB, gradient 1.30 GB
+    if _host_memory_gb() < 40:
+        pytest.skip("needs 40 GB of host memory")
+    need_memory(20)
+    rng = np.random.default_rng(41)
+    g = rng.standard_normal(9 * n)
+    g.reshape(n, 9)[:] *= np.power(10.0, rng.random(n) * 2 - 4)[:, None]
+    s0 = rng.standard_normal(6 * n) * 50.0
+    a0 = rng.random(n) * 0.02
+    law = fc.VonMises3D(VM_P)
+    # device path: the reference result for this test (itself checked against the oracle at 1e8 points above)
+    gd, sd, td = torch.from_numpy(g).cuda(), torch.from_numpy(s0).cuda(), torch.empty(36 * n, dtype=torch.float64, device="cuda")
+    hd = {"eps_n": torch.zeros(6 * n, dtype=torch.float64, device="cuda"), "alpha": torch.from_numpy(a0).cuda()}
+    law.evaluate(0.0, 1.0, gd, sd, td, hd)
+    n_plastic = law.device_stats().n_plastic
+    assert 0.1 * n < n_plastic < 0.5 * n
+    host_law = fc.VonMises3D(VM_P)
+    if contexts > 1:
+        host_law.use_devices([0] * contexts)
+    s, t = s0.copy(), np.full(36 * n, np.nan)
+    h = {"eps_n": np.zeros(6 * n), "alpha": a0.copy()}
+    host_law.evaluate(0.0, 1.0, g, s, t, h)
+    assert host_law.last_stats.n_plastic == n_plastic
+    assert np.array_equal(s, sd.cpu().numpy())
+    assert np.array_equal(h["alpha"], hd["alpha"].cpu().numpy()) and np.array_equal(h["eps_n"], hd["eps_n"].cpu().numpy())
+    del sd, hd, gd
+    tv = t.reshape(n, 36)
+    step = 3_000_000  # compare the tangent in pieces: no second 5 GB host copy
+    for lo in range(0, n, step):
+        assert np.array_equal(tv[lo: lo + step], td.view(n, 36)[lo: lo + step].cpu().numpy()), lo
