@@ -8,6 +8,7 @@ import traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")  # as tests/conftest.py
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]  # lives under tests/: the test modules it runs import the oracle
+import test_gpu_multidevice_fuzz as MF  # noqa: E402
 import test_gpu_problem_fuzz as PF  # noqa: E402
 import test_gpu_resident_fuzz as RF  # noqa: E402
 
@@ -18,6 +19,9 @@ kinds = ["von_mises_3d", "von_mises_3d+delta_history", "von_mises_3d+delta_auto"
 bad = 0
 for seed in range(lo, hi + 1):
     cases = [(RF.test_random_call_sequences, (k, seed)) for k in kinds] + [(PF.test_random_call_sequences, (seed,))]
+    cases += [(MF.test_random_call_sequences, (k, [0] * (2 + (seed + i) % 3), seed)) for i, k in enumerate(
+        ["von_mises_3d", "comfe_mises_plasticity", "comfe_mises_plasticity+rows7", "drucker_prager", "drucker_prager_hyperbolic",
+         "linear_elasticity", "spring_maxwell", "spring_kelvin"])]
     for fn, args in cases:
         try:
             fn(*args)
