@@ -360,3 +360,27 @@ def test_bench_line_guard_prints_exactly_one_line(die):
         assert r.returncode != 0 and got["value"] == 2 and "leg b" in got["incomplete"]
     else:
         assert r.returncode == 0 and got == {"value": 3}
+
+
+def test_reference_import_paths_resolve():
+    """every name of the reference's ``fenics_constitutive.models`` package and of its submodules (models/__init__.py:7-23,
+    models/utils.py:8-15, models/interfaces.py:8-11, models/rust_models.py:85-145) is importable from the same path under
+    ``fenics_constitutive_amd.models``"""
+    import importlib
+
+    paths = {
+        "": ["LinearElasticityModel", "MisesPlasticityLinearHardening3D", "SpringKelvinModel", "SpringMaxwellModel", "VonMises3D",
+             "IncrSmallStrainModel", "StressStrainConstraint", "lame_parameters", "get_elastic_tangent", "get_identity",
+             "strain_from_grad_u", "UniaxialStrainFrom3D", "PlaneStrainFrom3D"],
+        ".interfaces": ["IncrSmallStrainModel", "StressStrainConstraint"],
+        ".utils": ["lame_parameters", "get_elastic_tangent", "get_identity", "strain_from_grad_u", "UniaxialStrainFrom3D", "PlaneStrainFrom3D"],
+        ".linear_elasticity_model": ["LinearElasticityModel"],
+        ".mises_plasticity_isotropic_hardening": ["VonMises3D"],
+        ".spring_maxwell_model": ["SpringMaxwellModel"],
+        ".spring_kelvin_model": ["SpringKelvinModel"],
+        ".rust_models": ["LinearElasticity3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D", "MisesPlasticityLinearHardening3D"],
+    }
+    for sub, names in paths.items():
+        mod = importlib.import_module("fenics_constitutive_amd.models" + sub)
+        for name in names:
+            assert getattr(mod, name) is getattr(fc, name), (sub, name)
