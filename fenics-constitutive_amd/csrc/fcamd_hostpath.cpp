@@ -101,20 +101,41 @@ int finish_single_stream(fcamd_model* m, fcamd_stats* stats) {
 // Ranges page-locked through fcamd_register_host_buffer by ANY context of the process (base -> bytes).  A host entry of
 // another context that meets such a range must use it as it is: this runtime lets a second hipHostRegister of a
 // registered address "succeed", and the hipHostUnregister that ends that call then takes the owner's lock away.
-std::mutex g_reg_mu;
+//
+// g_pages_mu guards BOTH process-wide tables of page locks -- the registered ranges here and the call-scoped locks
+// (g_temp, below) -- and is held across "look the range up in both, then hipHostRegister / hipHostUnregister": a thread
+// that registers an array while a host entry of another thread holds a call-scoped lock on it would otherwise lock it a
+// second time, and the end of that call would take the lock away.  Order: a context's host_mu first, g_pages_mu second.
+std::recursive_mutex g_pages_mu;
 std::map<char*, size_t> g_registered;
 
+struct TempLock {
+    size_t bytes;
+    int refs;
+};
+std::map<char*, TempLock> g_temp;  // host base -> page lock held by one or more calls in progress
+
 void note_registered(char* base, size_t bytes) {
-    std::lock_guard<std::mutex> g(g_reg_mu);
+    std::lock_guard<std::recursive_mutex> g(g_pages_mu);
     g_registered[base] = bytes;
 }
 void forget_registered(char* base) {
-    std::lock_guard<std::mutex> g(g_reg_mu);
+    std::lock_guard<std::recursive_mutex> g(g_pages_mu);
     g_registered.erase(base);
+}
+// does [q, q + bytes) touch a call-scoped page lock of a host entry in progress?
+bool overlaps_call_scoped_lock(char* q, size_t bytes) {
+    std::lock_guard<std::recursive_mutex> g(g_pages_mu);
+    auto it = g_temp.upper_bound(q);
+    if (it != g_temp.begin()) {
+        auto lo = std::prev(it);
+        if (q < lo->first + lo->second.bytes) return true;
+    }
+    return it != g_temp.end() && it->first < q + bytes;
 }
 // [q, q + bytes) relative to the registered ranges of the process: 1 inside one, -1 overlaps one partly, 0 disjoint
 int in_process_registry(char* q, size_t bytes) {
-    std::lock_guard<std::mutex> g(g_reg_mu);
+    std::lock_guard<std::recursive_mutex> g(g_pages_mu);
     auto it = g_registered.upper_bound(q);
     if (it != g_registered.begin()) {
         auto lo = std::prev(it);
@@ -165,8 +186,11 @@ extern "C" {
 int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
     if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    std::lock_guard<std::recursive_mutex> pages(g_pages_mu);
     HIP_TRY(hipSetDevice(c->device));
     char* base = static_cast<char*>(ptr);
+    if (overlaps_call_scoped_lock(base, bytes))
+        return fail(FCAMD_ERR_BAD_ARG, "a host call in progress on another thread holds a page lock on this range: register it when no evaluate runs on it");
     if (c->registered.count(base)) {
         // Same address again: either a repeated call or a NEW buffer that landed where a freed,
         // still-registered one was.  Re-pin: a stale registration would DMA through old pages.
@@ -212,6 +236,7 @@ int fcamd_unregister_host_buffer(fcamd_context* c, void* ptr) {
     if (!c || !ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     // waits for a host entry in progress on another thread (it holds host_mu for the whole synchronous call)
     std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    std::lock_guard<std::recursive_mutex> pages(g_pages_mu);
     auto it = c->registered.find(static_cast<char*>(ptr));
     if (it == c->registered.end()) return FCAMD_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -281,13 +306,7 @@ struct HostTimer {
 // Page locks taken for the duration of a call are shared by all contexts of the process: two threads (each with a
 // context of its own) may pass the SAME read-only array -- the gradient -- at the same time, and two concurrent
 // hipHostRegister calls on one address both "succeed" in this runtime, the second hipHostUnregister then aborts
-// ("Memobj map does not have ptr").  One registry, one mutex, reference counts.
-struct TempLock {
-    size_t bytes;
-    int refs;
-};
-std::mutex g_temp_mu;
-std::map<char*, TempLock> g_temp;  // host base -> lock held by one or more calls in progress
+// ("Memobj map does not have ptr").  One registry (g_temp, above), one mutex (g_pages_mu), reference counts.
 
 // address at which the CURRENT device sees the page-locked host address q (every device of the process can reach a
 // page-locked range, each at an address of its own: one process may drive several GPUs, fcamd_multi.cpp)
@@ -309,12 +328,12 @@ namespace fcamd {
 // current device sees q at.  false: the range cannot be locked.
 bool temp_lock_acquire(char* q, size_t bytes, char** base, char** dev) {
     *base = *dev = nullptr;
+    std::lock_guard<std::recursive_mutex> g(g_pages_mu);
     {   // page-locked for good by a context of this process (fcamd_register_host_buffer): use it as it is
         const int r = in_process_registry(q, bytes);
         if (r < 0) return false;
         if (r > 0) return (*dev = device_view(q)) != nullptr;
     }
-    std::lock_guard<std::mutex> g(g_temp_mu);
     {   // inside a range another call in progress (or the coordinator of a multi-device call) has locked: share it
         auto it = g_temp.upper_bound(q);
         if (it != g_temp.begin()) {
@@ -361,7 +380,7 @@ bool temp_lock_acquire(char* q, size_t bytes, char** base, char** dev) {
 // flight on the range.
 void temp_lock_release(char* base) {
     if (!base) return;
-    std::lock_guard<std::mutex> g(g_temp_mu);
+    std::lock_guard<std::recursive_mutex> g(g_pages_mu);
     auto it = g_temp.find(base);
     if (it == g_temp.end()) return;
     if (--it->second.refs == 0) {

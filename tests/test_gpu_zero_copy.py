@@ -374,3 +374,62 @@ def test_resident_chunked_dma_pipeline(kind):
             assert np.array_equal(ta, tb), it
         assert torch.equal(a.stress, b.stress)
         a.update(), b.update()
+
+
+def test_registering_an_array_while_another_thread_evaluates_on_it():
+    """Two threads, a context each.  One evaluates in place on pageable arrays again and again (every call page-locks them
+    for its duration); the other registers the very same tangent array with ITS context in the middle of that.  The
+    registration is either refused (a call holds a call-scoped lock on the range right now) or lands between two calls, in
+    which case the evaluating thread's later calls use the registered range as it is -- never a second page lock on a locked
+    range, whose release would pull the pages from under the other holder (this runtime: abort in hipHostUnregister)."""
+    import threading
+    import time
+
+    import fenics_constitutive_amd as fc
+    from fenics_constitutive_amd import _capi
+
+    n = 1_500_000
+    rng = np.random.default_rng(12)
+    g = rng.standard_normal(9 * n) * 1e-3
+    law = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, fc.StressStrainConstraint.FULL)
+    s_ref, t_ref = np.zeros(6 * n), np.zeros(36 * n)
+    law.evaluate(0.0, 1.0, g, s_ref, t_ref, None)
+    t = np.full(36 * n, np.nan)
+    stop, errors, calls = threading.Event(), [], [0]
+
+    def work():
+        try:
+            while not stop.is_set():
+                s = np.zeros(6 * n)
+                law.evaluate(0.0, 1.0, g, s, t, None)
+                assert np.array_equal(s, s_ref)
+                calls[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = threading.Thread(target=work)
+    th.start()
+    ctx = _capi.get_context(_capi.default_device())
+    refused, registered = 0, False
+    t_end = time.time() + 20.0
+    while calls[0] < 2 and time.time() < t_end:
+        time.sleep(0.001)
+    while not registered and time.time() < t_end:
+        try:
+            ctx.register_host_buffer(t)
+            registered = True
+        except (ValueError, RuntimeError) as e:
+            assert "in progress" in str(e), e
+            refused += 1
+    before = calls[0]
+    while calls[0] < before + 3 and time.time() < t_end and not errors:
+        time.sleep(0.005)
+    stop.set()
+    th.join()
+    assert not errors, errors
+    assert registered and calls[0] >= before + 3
+    assert np.array_equal(t, t_ref)
+    ctx.unregister_host_buffer(t)
+    law.evaluate(0.0, 1.0, g, np.zeros(6 * n), t, None)  # pageable again
+    assert np.array_equal(t, t_ref)
+    print(f"registration refused {refused} times while a call was in progress, {calls[0]} calls")
