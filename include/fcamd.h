@@ -355,7 +355,10 @@ int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
    does not carry it, and a launch on it ends in a GPU memory fault.  Registering is an optimisation
    only: arrays that are not registered are page-locked for the duration of each call.  A range that ANOTHER context of
    the process has registered already (several GPUs or threads, one array) is entered into this context's registry with
-   its own device's view of it; the page lock stays with the first context -- unregister it there last. */
+   its own device's view of it; the page lock stays with the first context -- unregister it there last.  Threads: a range
+   on which a host entry of another thread is running right now (it holds a call-scoped page lock) is refused with
+   FCAMD_ERR_BAD_ARG -- register between calls; unregistering a range while another thread's call uses it is the
+   caller's error, like freeing it. */
 int fcamd_register_host_buffer(fcamd_context* ctx, void* ptr, size_t bytes);
 int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
 /* Data path the last fcamd_evaluate_host / fcamd_evaluate_resident call of this context took:
