@@ -256,6 +256,7 @@ class ResidentState:
             self._mask.zero_()
         self._tangent_target = self._tangent_key = self._host_tangent_key = None
         self._evaluated = False
+        self._n_eval = 0
         self._stats_pending = False
         self._failed = None
 
@@ -533,8 +534,9 @@ class ResidentState:
         if tangent is not None:
             assign(tangent, self.tangent)
         if history is not None and self._hist is not None:
+            trial = self.history  # once: under the delta protocol the view is assembled on demand
             for k in history:
-                assign(history[k], self.history[k])
+                assign(history[k], trial[k])
 
     def check(self):
         """Synchronise with this state's last device evaluate and return its counters; raises the
