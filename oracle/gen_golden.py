@@ -292,8 +292,74 @@ def main_material_point():
     print("material_point.npz", len(d), "curves (every scenario's assertions also held for the reference classes)")
 
 
+def main_random_parameters():
+    """Random MATERIAL PARAMETERS (the other fixtures vary the inputs around two or three parameter sets): eight sets per
+    law over many decades, random prestress / history, two increments with a discarded Newton iterate each -- pins the
+    oracles' and the kernels' dependence on the parameters (host constants, del_t / tau ratios, hardening laws) to the
+    imported reference itself.  Files random_parameters_<law>.npz, a generator of their own: the fixtures above are
+    unchanged."""
+    m = import_reference()
+    FULL = m.StressStrainConstraint.FULL
+    rng = np.random.default_rng(20261004)
+    n, sets = 32, 8
+
+    def logu(lo, hi):
+        return float(10 ** rng.uniform(np.log10(lo), np.log10(hi)))
+
+    # LinearElasticityModel
+    r = Recorder()
+    for k in range(sets):
+        p = {"E": logu(1.0, 1e12), "nu": float(rng.uniform(-0.3, 0.49))}
+        law = m.LinearElasticityModel(p, FULL)
+        r.call(f"set{k}", law, p, 1.0, rng.normal(scale=logu(1e-6, 1e-1), size=9 * n), rng.normal(scale=1e-3 * p["E"], size=6 * n), None)
+    r.save("random_parameters_linear_elasticity.npz")
+
+    # VonMises3D: mixed elastic / plastic points around each set's own yield strain
+    r = Recorder()
+    k = 0
+    while k < sets:
+        mu = logu(1e3, 1e11)
+        y0 = mu * logu(1e-4, 1e-2)
+        p = {"p_ka": mu * float(rng.uniform(0.7, 5.0)), "p_mu": mu, "p_y0": y0, "p_y00": y0 * float(rng.uniform(1.0, 3.0)),
+             "p_w": float(rng.uniform(1.0, 500.0))}
+        law = m.VonMises3D(p)
+        scale = np.repeat((y0 / mu) * 10 ** rng.uniform(-1.5, 1.0, size=n), 9)
+        s, h = np.zeros(6 * n), {"eps_n": np.zeros(6 * n), "alpha": rng.uniform(0.0, 0.02, size=n)}
+        mark = (len(r.calls), dict(r.d))
+        try:
+            for step in range(2):
+                gk = rng.normal(size=9 * n) * scale
+                r.call(f"set{k}_step{step}_iter0", law, p, 1.0, 0.85 * gk, s, h)
+                s, h = r.call(f"set{k}_step{step}_iter1", law, p, 1.0, gk, s, h)
+        except RuntimeError:  # the reference's Newton iteration gave up on this set: draw another one
+            del r.calls[mark[0]:]
+            r.d = mark[1]
+            continue
+        k += 1
+    r.save("random_parameters_von_mises_3d.npz")
+
+    # SLS Maxwell / Kelvin: del_t / tau over six decades
+    for cls, fname in ((m.SpringMaxwellModel, "random_parameters_spring_maxwell.npz"), (m.SpringKelvinModel, "random_parameters_spring_kelvin.npz")):
+        r = Recorder()
+        for k in range(sets):
+            E0 = logu(1.0, 1e11)
+            p = {"E0": E0, "E1": E0 * float(rng.uniform(0.05, 2.0)), "tau": logu(1e-3, 1e3), "nu": float(rng.uniform(0.0, 0.45))}
+            law = cls(p, FULL)
+            eps = logu(1e-5, 1e-2)
+            s = rng.normal(scale=eps * E0, size=6 * n)
+            h = {"strain_visco": rng.normal(scale=0.3 * eps, size=6 * n), "strain": rng.normal(scale=eps, size=6 * n)}
+            for step in range(2):
+                dt = p["tau"] * logu(1e-3, 1e3)
+                gk = rng.normal(scale=eps, size=9 * n)
+                r.call(f"set{k}_step{step}_iter0", law, p, dt, 1.2 * gk, s, h)
+                s, h = r.call(f"set{k}_step{step}_iter1", law, p, dt, gk, s, h)
+        r.save(fname)
+
+
 if __name__ == "__main__":
-    if "--material-point" in sys.argv:
+    if "--random-parameters" in sys.argv:
+        main_random_parameters()
+    elif "--material-point" in sys.argv:
         main_material_point()
     elif "--constraints" in sys.argv:
         main_constraints()
@@ -304,3 +370,4 @@ if __name__ == "__main__":
         main_wrappers()
         main_constraints()
         main_material_point()
+        main_random_parameters()

@@ -79,7 +79,11 @@ def compare(got, ref, tol, what=""):
 # golden vectors captured from the reference
 # ---------------------------------------------------------------------------------------
 GOLDEN = [(f, k, c) for f, k in [("linear_elasticity.npz", "linear_elasticity"), ("von_mises_3d.npz", "von_mises_3d"),
-                                 ("spring_maxwell.npz", "spring_maxwell"), ("spring_kelvin.npz", "spring_kelvin")]
+                                 ("spring_maxwell.npz", "spring_maxwell"), ("spring_kelvin.npz", "spring_kelvin"),
+                                 ("random_parameters_linear_elasticity.npz", "linear_elasticity"),
+                                 ("random_parameters_von_mises_3d.npz", "von_mises_3d"),
+                                 ("random_parameters_spring_maxwell.npz", "spring_maxwell"),
+                                 ("random_parameters_spring_kelvin.npz", "spring_kelvin")]
           for c in load_calls(f)]
 
 

@@ -13,6 +13,10 @@ FIXTURES = [
     ("spring_maxwell.npz", "spring_maxwell", 1e-13),
     ("spring_kelvin.npz", "spring_kelvin", 1e-13),
     ("von_mises_3d.npz", "von_mises_3d", 1e-11),
+    ("random_parameters_linear_elasticity.npz", "linear_elasticity", 1e-13),
+    ("random_parameters_spring_maxwell.npz", "spring_maxwell", 1e-13),
+    ("random_parameters_spring_kelvin.npz", "spring_kelvin", 1e-13),
+    ("random_parameters_von_mises_3d.npz", "von_mises_3d", 1e-11),
 ]
 CASES = [(f, m, tol, c) for f, m, tol in FIXTURES for c in load_calls(f)]
 

@@ -88,6 +88,17 @@ def test_comfe_tangent_known_answer():
 # ---- golden vectors from the imported reference ----------------------------
 
 
+RANDOM_PARAMETERS = [(kind, c) for kind in ("linear_elasticity", "von_mises_3d", "spring_maxwell", "spring_kelvin")
+                     for c in load_calls(f"random_parameters_{kind}.npz")]
+
+
+@pytest.mark.parametrize("kind,c", RANDOM_PARAMETERS, ids=[f"{k}-{c.name}" for k, c in RANDOM_PARAMETERS])
+def test_random_parameters_golden(kind, c):
+    """eight random parameter sets per law over many decades (oracle/gen_golden.py: main_random_parameters), outputs of the
+    imported reference"""
+    _check(c, *_run(getattr(O, kind), c), TOL_PL if kind == "von_mises_3d" else TOL_LE)
+
+
 @pytest.mark.parametrize("c", load_calls("linear_elasticity.npz"), ids=lambda c: c.name)
 def test_linear_elasticity_golden(c):
     _check(c, *_run(O.linear_elasticity, c), TOL_LE)
