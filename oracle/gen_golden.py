@@ -355,6 +355,42 @@ def main_random_parameters():
                 s, h = r.call(f"set{k}_step{step}_iter1", law, p, dt, gk, s, h)
         r.save(fname)
 
+    # the same three laws under the four non-FULL constraints, four random parameter sets each (format of constraints.npz
+    # plus the parameters of every call)
+    C = m.StressStrainConstraint
+    d, idx = {}, 0
+    for c in (C.UNIAXIAL_STRAIN, C.UNIAXIAL_STRESS, C.PLANE_STRAIN, C.PLANE_STRESS):
+        for lname in ("le", "maxwell", "kelvin"):
+            for k in range(4):
+                if lname == "le":
+                    p = {"E": logu(1.0, 1e12), "nu": float(rng.uniform(-0.3, 0.49))}
+                    law, E = m.LinearElasticityModel(p, c), p["E"]
+                else:
+                    E = logu(1.0, 1e11)
+                    p = {"E0": E, "E1": E * float(rng.uniform(0.05, 2.0)), "tau": logu(1e-3, 1e3), "nu": float(rng.uniform(0.0, 0.45))}
+                    law = (m.SpringMaxwellModel if lname == "maxwell" else m.SpringKelvinModel)(p, c)
+                gd2, sd = law.geometric_dim**2, law.stress_strain_dim
+                eps = logu(1e-5, 1e-2)
+                s = rng.normal(scale=eps * E, size=sd * n)
+                h = None if lname == "le" else {"strain_visco": rng.normal(scale=0.3 * eps, size=sd * n), "strain": rng.normal(scale=eps, size=sd * n)}
+                for step in range(2):
+                    dt = 1.0 if lname == "le" else p["tau"] * logu(1e-3, 1e3)
+                    g = rng.normal(scale=eps, size=gd2 * n)
+                    s_in, h_in = s.copy(), None if h is None else {kk: v.copy() for kk, v in h.items()}
+                    tan = np.full(sd * sd * n, np.nan)
+                    law.evaluate(0.0, dt, g, s, tan, h)
+                    q = f"c{idx}."
+                    d[q + "constraint"], d[q + "law"], d[q + "del_t"] = np.array(c.name), np.array(lname), np.float64(dt)
+                    d[q + "param_keys"], d[q + "param_vals"] = np.array(list(p)), np.array([float(v) for v in p.values()])
+                    d[q + "grad"], d[q + "stress_in"], d[q + "stress_out"], d[q + "tangent_out"] = g, s_in, s.copy(), tan
+                    if h is not None:
+                        for kk in h:
+                            d[q + "hist_in." + kk], d[q + "hist_out." + kk] = h_in[kk], h[kk].copy()
+                    idx += 1
+    d["n_calls"] = np.int64(idx)
+    np.savez_compressed(os.path.join(OUT, "random_parameters_constraints.npz"), **d)
+    print("random_parameters_constraints.npz", idx, "calls")
+
 
 if __name__ == "__main__":
     if "--random-parameters" in sys.argv:

@@ -17,19 +17,19 @@ from oracle import numpy_oracle as O  # noqa: E402
 C = fc.StressStrainConstraint
 
 
-def make(law, cname):
+def make(law, cname, params=None):
     c = C[cname]
-    return {"le": lambda: fc.LinearElasticityModel(CPARAMS["le"], c), "maxwell": lambda: fc.SpringMaxwellModel(CPARAMS["maxwell"], c),
-            "kelvin": lambda: fc.SpringKelvinModel(CPARAMS["kelvin"], c)}[law]()
+    p = CPARAMS[law] if params is None else params
+    return {"le": fc.LinearElasticityModel, "maxwell": fc.SpringMaxwellModel, "kelvin": fc.SpringKelvinModel}[law](p, c)
 
 
-CALLS = load_constraint_calls()
+CALLS = load_constraint_calls() + load_constraint_calls("random_parameters_constraints.npz")
 
 
 @pytest.mark.parametrize("path", ["host", "device"])
 @pytest.mark.parametrize("c", CALLS, ids=[f"{c['law']}-{c['constraint']}-{i}" for i, c in enumerate(CALLS)])
 def test_constraint_golden(c, path):
-    law = make(c["law"], c["constraint"])
+    law = make(c["law"], c["constraint"], c["params"])
     s, t = c["stress_in"].copy(), np.full_like(c["tangent_out"], np.nan)
     h = None if c["hist_in"] is None else {k: v.copy() for k, v in c["hist_in"].items()}
     if path == "host":

@@ -252,12 +252,12 @@ def test_wrappers_golden():
 
 def test_constraints_golden():
     """LE / Maxwell / Kelvin under the four non-FULL constraints, against the reference."""
-    from wrappers_util import CPARAMS, load_constraint_calls
+    from wrappers_util import load_constraint_calls
 
-    for c in load_constraint_calls():
+    for c in load_constraint_calls() + load_constraint_calls("random_parameters_constraints.npz"):
         s, t = c["stress_in"].copy(), np.full_like(c["tangent_out"], np.nan)
         h = None if c["hist_in"] is None else {k: v.copy() for k, v in c["hist_in"].items()}
-        O.MODELS_C[c["law"]](CPARAMS[c["law"]], c["constraint"], 0.0, c["del_t"], c["grad"], s, t, h)
+        O.MODELS_C[c["law"]](c["params"], c["constraint"], 0.0, c["del_t"], c["grad"], s, t, h)
         assert rel_err(s, c["stress_out"]) <= 1e-13 and rel_err(t, c["tangent_out"]) <= 1e-13, (c["law"], c["constraint"])
         if h is not None:
             for k in h:

@@ -27,13 +27,17 @@ def load_sequences():
     return [(k[0], k[1], v) for k, v in seqs.items()]
 
 
-def load_constraint_calls():
-    """tests/golden/constraints.npz -> list of call dicts (sequences are in file order)."""
-    z = np.load(os.path.join(GOLDEN, "constraints.npz"))
+def load_constraint_calls(fname="constraints.npz"):
+    """tests/golden/constraints.npz (or random_parameters_constraints.npz: every call with parameters of its own) -> list
+    of call dicts (sequences are in file order)."""
+    z = np.load(os.path.join(GOLDEN, fname))
     out = []
     for i in range(int(z["n_calls"])):
         p = f"c{i}."
-        c = {"constraint": str(z[p + "constraint"]), "law": str(z[p + "law"]), "del_t": float(z[p + "del_t"]),
+        law = str(z[p + "law"])
+        params = dict(zip([str(k) for k in z[p + "param_keys"]], [float(v) for v in z[p + "param_vals"]])) if p + "param_keys" in z \
+            else {"le": LE_P, "maxwell": SLS_P, "kelvin": SLS_P}[law]
+        c = {"constraint": str(z[p + "constraint"]), "law": law, "del_t": float(z[p + "del_t"]), "params": params,
              "grad": z[p + "grad"], "stress_in": z[p + "stress_in"], "stress_out": z[p + "stress_out"],
              "tangent_out": z[p + "tangent_out"], "hist_in": None, "hist_out": None}
         if p + "hist_in.strain" in z:
