@@ -392,8 +392,35 @@ def main_random_parameters():
     print("random_parameters_constraints.npz", idx, "calls")
 
 
+def main_mises_limit():
+    """A pin from the imported reference for the PLASTIC branch of comfe-rs MisesPlasticity3D (which has no test of its own
+    in the reference): the Python VonMises3D with saturation hardening sigma_y = y0 + (y00 - y0)(1 - exp(-w alpha))
+    (mises_plasticity_isotropic_hardening.py:92-95) tends to LINEAR hardening sigma_y = y0 + h alpha, h = (y00 - y0) w, for
+    w alpha -> 0 -- the hardening law of the Rust class (mises_plasticity.rs:98-107).  With w = 1e-6 the two yield stresses
+    differ by less than 1e-8 h alpha (truncation w alpha / 2 and the cancellation in 1 - exp), so stress and alpha of the Rust
+    law must reproduce these outputs to ~1e-9; its plastic strain is sqrt(2/3) times the Python one and its tangent differs
+    by a rank-one term (the non-unit flow direction and the sign of the Rust text) -- tests/test_oracle_golden.py states
+    both relations.  File mises_linear_hardening_limit.npz."""
+    m = import_reference()
+    rng = np.random.default_rng(777)
+    r = Recorder()
+    n = 96
+    for k, (mu, ka, y0, h) in enumerate([(80769.0, 175000.0, 1200.0, 200.0), (80769.0, 175000.0, 1200.0, 20000.0), (2.6e10, 5.5e10, 2.4e8, 1.5e9)]):
+        w = 1e-6
+        p = {"p_ka": ka, "p_mu": mu, "p_y0": y0, "p_y00": y0 + h / w, "p_w": w}
+        law = m.VonMises3D(p)
+        scale = np.repeat((y0 / mu) * 10 ** rng.uniform(-1.0, 1.0, size=n), 9)
+        s, hist = np.zeros(6 * n), {"eps_n": np.zeros(6 * n), "alpha": rng.uniform(0.0, 0.02, size=n)}
+        for step in range(3):
+            gk = rng.normal(size=9 * n) * scale
+            s, hist = r.call(f"set{k}_step{step}", law, p, 1.0, gk, s, hist)
+    r.save("mises_linear_hardening_limit.npz")
+
+
 if __name__ == "__main__":
-    if "--random-parameters" in sys.argv:
+    if "--mises-limit" in sys.argv:
+        main_mises_limit()
+    elif "--random-parameters" in sys.argv:
         main_random_parameters()
     elif "--material-point" in sys.argv:
         main_material_point()
@@ -407,3 +434,4 @@ if __name__ == "__main__":
         main_constraints()
         main_material_point()
         main_random_parameters()
+        main_mises_limit()

@@ -59,3 +59,55 @@ def rel_err(a, b):
     if scale == 0.0:
         return float(np.max(np.abs(a - b))) if a.size else 0.0
     return float(np.max(np.abs(a - b)) / scale)
+
+
+def mises_limit_cases():
+    """tests/golden/mises_linear_hardening_limit.npz (oracle/gen_golden.py: main_mises_limit) -> for every call the inputs of
+    comfe-rs MisesPlasticity3D and what it must return, derived from the outputs of the IMPORTED Python VonMises3D in its
+    linear-hardening limit (w = 1e-6, h = (y00 - y0) w):
+
+    * stress and alpha: the same numbers (both laws are radial return with sigma_y = y0 + h alpha in this limit);
+    * plastic strain: the Rust text adds del_gamma * s_tr / s_tr_eq (mises_plasticity.rs:110-112, a flow direction of length
+      sqrt(2/3)), the Python one gamma * s_tr / |s_tr| (mises_plasticity_isotropic_hardening.py:161) -> a factor sqrt(2/3);
+    * tangent: kappa I x I + 2 mu theta P_dev is common; the last term is -2 mu theta_bar n n^T with a unit n in Python
+      (:172-176) and +2 mu theta_bar (2/3) n n^T in Rust (mises_plasticity.rs:117-121) -> the Rust tangent is the Python one
+      plus (10/3) mu theta_bar n n^T at plastic points.
+
+    ``tol``: the limit's own error (truncation w alpha / 2 and the cancellation in 1 - exp(-w alpha), both ~1e-8 of the
+    hardening term h alpha) relative to the stress, with a margin."""
+    out = []
+    for c in load_calls("mises_linear_hardening_limit.npz"):
+        p, n = c.params, c.n
+        mu, h = p["p_mu"], (p["p_y00"] - p["p_y0"]) * p["p_w"]
+        rs = {"mu": mu, "kappa": p["p_ka"], "y_0": p["p_y0"], "h": h}
+        f = np.sqrt(2.0 / 3.0)
+        a_in, a_out = c.hist_in["alpha"], c.hist_out["alpha"]
+        e_in, e_out = c.hist_in["eps_n"].reshape(n, 6), c.hist_out["eps_n"].reshape(n, 6)
+        h_in = np.concatenate([a_in[:, None], f * e_in], axis=1).reshape(-1)
+        gamma = (a_out - a_in) / f
+        pl = gamma > 0
+        xn = (e_out - e_in)[pl] / gamma[pl, None]
+        s_out = c.stress_out.reshape(n, 6)
+        dev = s_out.copy()
+        dev[:, :3] -= s_out[:, :3].mean(axis=1, keepdims=True)
+        norm_tr = np.linalg.norm(dev[pl], axis=1) + 2.0 * mu * gamma[pl]   # s_out_dev = theta s_tr = s_tr - 2 mu gamma n
+        theta = 1.0 - 2.0 * mu * gamma[pl] / norm_tr
+        theta_bar = 1.0 / (1.0 + h / (3.0 * mu)) - (1.0 - theta)
+        T = c.tangent_out.reshape(n, 6, 6).copy()
+        T[pl] += (10.0 / 3.0) * mu * theta_bar[:, None, None] * xn[:, :, None] * xn[:, None, :]
+        expected = {"stress": c.stress_out, "alpha": a_out, "eps_p": f * e_out, "tangent": T.reshape(-1)}
+        tol = 2e-9 if h / p["p_y0"] < 1.0 else 2e-7
+        out.append({"name": c.name, "params": rs, "grad": c.grad, "stress_in": c.stress_in, "history_in": h_in, "expected": expected,
+                    "plastic": pl, "tol": tol})
+    return out
+
+
+def check_mises_limit(case, stress, tangent, history):
+    n = case["grad"].size // 9
+    e, tol = case["expected"], case["tol"]
+    h = np.asarray(history).reshape(n, 7)
+    assert rel_err(stress, e["stress"]) <= tol, (case["name"], "stress", rel_err(stress, e["stress"]))
+    assert rel_err(h[:, 0], e["alpha"]) <= tol, (case["name"], "alpha", rel_err(h[:, 0], e["alpha"]))
+    assert rel_err(h[:, 1:], e["eps_p"].reshape(n, 6)) <= 4 * tol, (case["name"], "eps_p", rel_err(h[:, 1:], e["eps_p"].reshape(n, 6)))
+    assert rel_err(tangent, e["tangent"]) <= 4 * tol, (case["name"], "tangent", rel_err(tangent, e["tangent"]))
+    assert 0.5 < case["plastic"].mean() < 1.0  # the branch under test, with elastic points next to it

@@ -39,3 +39,33 @@ def test_hip_kernels_against_the_50_digit_transcription(fname, cls, tol_s, tol_t
     print(fname, errs)
     assert max(errs.values()) <= 1e-6, errs  # the contract
     assert errs["stress"] <= tol_s and errs["alpha"] <= tol_s and errs["eps_p"] <= 10 * tol_s and errs["tangent"] <= tol_t, errs
+
+
+from golden_util import check_mises_limit, mises_limit_cases  # noqa: E402
+
+MISES_LIMIT = mises_limit_cases()
+
+
+@pytest.mark.parametrize("path", ["host", "device", "resident"])
+@pytest.mark.parametrize("case", MISES_LIMIT, ids=[c["name"] for c in MISES_LIMIT])
+def test_comfe_mises_kernel_against_the_imported_reference_in_the_linear_hardening_limit(case, path):
+    """The one pin the reference itself gives for the plastic branch of comfe-rs MisesPlasticity3D: its Python VonMises3D for
+    w -> 0 is the same radial return with linear hardening (golden_util.mises_limit_cases: stress, alpha, plastic strain x
+    sqrt(2/3), tangent + the rank-one term of the Rust text; tolerance = the limit's own error)."""
+    law = fc.MisesPlasticityLinearHardening3D({k: np.array([v]) for k, v in case["params"].items()})
+    n = case["grad"].size // 9
+    s, t, h = case["stress_in"].copy(), np.full(36 * n, np.nan), {"history": case["history_in"].copy()}
+    if path == "host":
+        law.evaluate(0.0, 1.0, case["grad"].copy(), s, t, h)
+    elif path == "device":
+        sd, td = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+        hd = {"history": torch.from_numpy(h["history"]).cuda()}
+        law.evaluate(0.0, 1.0, torch.from_numpy(case["grad"]).cuda(), sd, td, hd)
+        s, t, h = sd.cpu().numpy(), td.cpu().numpy(), {"history": hd["history"].cpu().numpy()}
+    else:  # the device-resident state: split history, sparse protocols
+        from fenics_constitutive_amd.resident import ResidentState
+
+        rs = ResidentState(law, n, stress0=s, history0=h)
+        rs.evaluate_into(0.0, 1.0, case["grad"].copy(), s, t)
+        h = {"history": rs.history["history"].cpu().numpy()}
+    check_mises_limit(case, s, t, h["history"])

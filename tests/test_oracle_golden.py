@@ -398,3 +398,25 @@ def test_selfderived_fixtures_reproduce():
         out = mp_pins.run_mises(g, s, h, p) if kind == "mises" else mp_pins.run_dp(g, s, h, p, hyper)
         assert np.array_equal(out[0], z["stress_out"][: 6 * k]) and np.array_equal(out[1], z["tangent_out"][: 36 * k])
         assert np.array_equal(out[2], z["hist_out"][: 7 * k]) and np.array_equal(out[3], z["plastic"][:k])
+
+
+# ---- a8: the plastic branch of comfe-rs MisesPlasticity3D against the IMPORTED Python reference in its linear-hardening limit ----
+
+from golden_util import check_mises_limit, mises_limit_cases  # noqa: E402
+
+MISES_LIMIT = mises_limit_cases()
+
+
+@pytest.mark.parametrize("oracle", ["numpy", "c"])
+@pytest.mark.parametrize("case", MISES_LIMIT, ids=[c["name"] for c in MISES_LIMIT])
+def test_comfe_mises_reproduces_the_reference_von_mises_in_the_linear_hardening_limit(case, oracle):
+    """The reference holds no vector for the Rust law's plastic branch, but its Python VonMises3D tends to the same law for
+    w -> 0: outputs of the imported reference pin stress, alpha, plastic strain (x sqrt(2/3)) and the tangent (+ the
+    rank-one term of the Rust text) of both restatements (golden_util.mises_limit_cases)."""
+    from oracle import c_oracle as CO
+
+    fn = O.comfe_mises_plasticity if oracle == "numpy" else CO.comfe_mises_plasticity
+    n = case["grad"].size // 9
+    s, t, h = case["stress_in"].copy(), np.full(36 * n, np.nan), {"history": case["history_in"].copy()}
+    fn(case["params"], 0.0, 1.0, case["grad"].copy(), s, t, h)
+    check_mises_limit(case, s, t, h["history"])
