@@ -416,6 +416,21 @@ def main_mises_limit():
             s, hist = r.call(f"set{k}_step{step}", law, p, 1.0, gk, s, hist)
     r.save("mises_linear_hardening_limit.npz")
 
+    # ... and for the general return mapping (plasticity/general.rs:105-266) with the Drucker-Prager surfaces: for b = b_flow = 0
+    # they are J2 cylinders without hardening (drucker_prager_classic.rs:88: f = sqrt(J2) - a; hyperbolic.rs:87:
+    # f = sqrt(J2 + d^2) - a) with a flow direction along s, i.e. the closest-point projection IS the radial return of the
+    # Python VonMises3D with y00 = y0 = sqrt(3) a (hyperbolic: sqrt(3 (a^2 - d^2))).  Three increments, mixed points.
+    r = Recorder()
+    for k, (mu, ka, y0) in enumerate([(80769.0, 175000.0, 1200.0), (2.6e10, 5.5e10, 2.4e8)]):
+        p = {"p_ka": ka, "p_mu": mu, "p_y0": y0, "p_y00": y0, "p_w": 200.0}
+        law = m.VonMises3D(p)
+        scale = np.repeat((y0 / mu) * 10 ** rng.uniform(-1.0, 0.7, size=n), 9)
+        s, hist = np.zeros(6 * n), {"eps_n": np.zeros(6 * n), "alpha": np.zeros(n)}
+        for step in range(3):
+            gk = rng.normal(size=9 * n) * scale
+            s, hist = r.call(f"set{k}_step{step}", law, p, 1.0, gk, s, hist)
+    r.save("von_mises_perfect_plasticity.npz")
+
 
 if __name__ == "__main__":
     if "--mises-limit" in sys.argv:

@@ -69,3 +69,36 @@ def test_comfe_mises_kernel_against_the_imported_reference_in_the_linear_hardeni
         rs.evaluate_into(0.0, 1.0, case["grad"].copy(), s, t)
         h = {"history": rs.history["history"].cpu().numpy()}
     check_mises_limit(case, s, t, h["history"])
+
+
+from golden_util import check_dp_j2, dp_j2_cases  # noqa: E402
+
+DP_J2 = dp_j2_cases()
+
+
+@pytest.mark.parametrize("path", ["host", "device", "resident"])
+@pytest.mark.parametrize("case", DP_J2, ids=[c["name"] for c in DP_J2])
+def test_drucker_prager_kernels_against_the_imported_reference_for_b_zero(case, path):
+    """The general return mapping on its J2 sub-family (b = b_flow = 0): the closest-point projection is the radial return of
+    the Python VonMises3D without hardening -- stress, plastic strain and consistent tangent from the imported reference
+    (golden_util.dp_j2_cases).  The kernels iterate in invariant coordinates with a closed-form inverse; the pin is on the
+    result."""
+    cls = fc.DruckerPragerHyperbolic3D if case["hyperbolic"] else fc.DruckerPrager3D
+    law = cls({k: np.array([v]) for k, v in case["params"].items()})
+    n = case["grad"].size // 9
+    s, t, h = case["stress_in"].copy(), np.full(36 * n, np.nan), {"history": case["history_in"].copy()}
+    if path == "host":
+        law.evaluate(0.0, 1.0, case["grad"].copy(), s, t, h)
+    elif path == "device":
+        sd, td = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+        hd = {"history": torch.from_numpy(h["history"]).cuda()}
+        law.evaluate(0.0, 1.0, torch.from_numpy(case["grad"]).cuda(), sd, td, hd)
+        law.device_stats()
+        s, t, h = sd.cpu().numpy(), td.cpu().numpy(), {"history": hd["history"].cpu().numpy()}
+    else:
+        from fenics_constitutive_amd.resident import ResidentState
+
+        rs = ResidentState(law, n, stress0=s, history0=h)
+        rs.evaluate_into(0.0, 1.0, case["grad"].copy(), s, t)
+        h = {"history": rs.history["history"].cpu().numpy()}
+    check_dp_j2(case, s, t, h["history"])

@@ -420,3 +420,27 @@ def test_comfe_mises_reproduces_the_reference_von_mises_in_the_linear_hardening_
     s, t, h = case["stress_in"].copy(), np.full(36 * n, np.nan), {"history": case["history_in"].copy()}
     fn(case["params"], 0.0, 1.0, case["grad"].copy(), s, t, h)
     check_mises_limit(case, s, t, h["history"])
+
+
+# ---- f4: the general return mapping against the IMPORTED Python reference on the J2 sub-family (b = b_flow = 0) ----
+
+from golden_util import check_dp_j2, dp_j2_cases  # noqa: E402
+
+DP_J2 = dp_j2_cases()
+
+
+@pytest.mark.parametrize("oracle", ["numpy", "c"])
+@pytest.mark.parametrize("case", DP_J2, ids=[c["name"] for c in DP_J2])
+def test_general_return_mapping_reproduces_the_reference_von_mises_for_b_zero(case, oracle):
+    """No reference test touches plasticity/general.rs, but for b = b_flow = 0 its closest-point projection onto the
+    Drucker-Prager surfaces is the radial return of the Python VonMises3D without hardening: outputs of the imported
+    reference pin stress, plastic strain and the consistent tangent of the 8 x 8 Newton machinery
+    (golden_util.dp_j2_cases).  The pressure-dependent terms (b, b_flow != 0) stay with the identities and the 50-digit
+    transcription above."""
+    from oracle import c_oracle as CO
+
+    fn = O.comfe_drucker_prager if oracle == "numpy" else CO.comfe_drucker_prager
+    n = case["grad"].size // 9
+    s, t, h = case["stress_in"].copy(), np.full(36 * n, np.nan), {"history": case["history_in"].copy()}
+    fn(case["params"], 0.0, 1.0, case["grad"].copy(), s, t, h, hyperbolic=case["hyperbolic"])
+    check_dp_j2(case, s, t, h["history"])
