@@ -1288,6 +1288,7 @@ def main():
                          "traffic_source": None if traffic is None else f"profiles/traffic.json[{tkey}]@kernel_hash={str(library_hash(kernels_only=True))[:16]} "
                                                                         "(stored rocprofv3 --pmc measurement of these kernels, not measured in this run)",
                          "kernel_ms_avg": round(kernel_avg_ms, 4), "kernel_ms_min": round(kernel_ms[0], 4),
+                         "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "traffic_GBs": None if traffic is None else round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1),
                          "device_copy_GBs": None if copy_gbs is None else round(copy_gbs, 1),
