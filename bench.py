@@ -89,8 +89,11 @@ class LineGuard:
         import subprocess
 
         self.proc = None
+        # a plain interpreter: under rocprofv3 the parent's environment preloads the profiler, which would initialise the GPU
+        # (and claim counters) in the guard as well
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS"))}
         try:
-            self.proc = subprocess.Popen([sys.executable, "-c", self.CHILD], stdin=subprocess.PIPE, text=True, start_new_session=True)
+            self.proc = subprocess.Popen([sys.executable, "-c", self.CHILD], stdin=subprocess.PIPE, text=True, start_new_session=True, env=env)
         except OSError:
             pass  # no guard: the line is printed directly at the end
 
