@@ -431,6 +431,47 @@ def main_mises_limit():
             s, hist = r.call(f"set{k}_step{step}", law, p, 1.0, gk, s, hist)
     r.save("von_mises_perfect_plasticity.npz")
 
+    # ... and the PRESSURE DEPENDENCE of the yield functions: with b != 0 but b_flow = 0 (non-associated, purely deviatoric flow,
+    # drucker_prager_classic.rs:96-103) the return leaves the pressure at its trial value, so every point returns radially onto a
+    # J2 cylinder of ITS OWN radius sqrt(J2) = a - b I1_trial (hyperbolic: sqrt((a - b I1_trial)^2 - d^2)).  The Python
+    # VonMises3D, called point by point with y00 = y0 = sqrt(3) x that radius, returns the same stress and plastic strain; its
+    # tangent lacks only the derivative of the radius with respect to the strain (tests/golden_util.py: dp_pressure_cases).
+    d, idx = {}, 0
+    mu, ka = 80769.0, 175000.0
+    sid = np.array([1.0, 1.0, 1.0, 0.0, 0.0, 0.0])
+    for name, a, b, dd in (("classic", 100.0, 0.05, 0.0), ("classic_steep", 40.0, 0.2, 0.0), ("hyperbolic", 100.0, 0.05, 40.0)):
+        nn = 64
+        s = rng.normal(scale=30.0, size=(nn, 6))
+        s[:, :3] -= rng.uniform(300.0, 1500.0, size=nn)[:, None]
+        eps_p = np.zeros((nn, 6))
+        for step in range(2):
+            g = rng.normal(size=(nn, 9)) * (10 ** rng.uniform(-4.0, -2.3, size=nn))[:, None]
+            g[:, [0, 4, 8]] -= (0.9 * g[:, [0, 4, 8]].sum(axis=1) / 3.0)[:, None]  # mostly isochoric: the trial pressure stays below the tip
+            strain = m.strain_from_grad_u(g.reshape(-1), m.StressStrainConstraint.FULL).reshape(nn, 6)
+            i1_tr = s[:, :3].sum(axis=1) + 3.0 * ka * strain[:, :3].sum(axis=1)
+            big = a - b * i1_tr
+            radius = np.sqrt(big * big - dd * dd)
+            s_out, t_out, e_out = np.empty((nn, 6)), np.empty((nn, 36)), np.empty((nn, 6))
+            for i in range(nn):  # one reference call per point: its own yield stress
+                y = float(np.sqrt(3.0) * radius[i])
+                law = m.VonMises3D({"p_ka": ka, "p_mu": mu, "p_y0": y, "p_y00": y, "p_w": 1.0})
+                si, ti = s[i].copy(), np.full(36, np.nan)
+                hi = {"eps_n": eps_p[i].copy(), "alpha": np.zeros(1)}
+                law.evaluate(0.0, 1.0, g[i].copy(), si, ti, hi)
+                s_out[i], t_out[i], e_out[i] = si, ti, hi["eps_n"]
+            q = f"c{idx}."
+            d[q + "name"] = np.array(f"{name}_step{step}")
+            d[q + "param_keys"] = np.array(["mu", "kappa", "a", "b", "d", "b_flow"])
+            d[q + "param_vals"] = np.array([mu, ka, a, b, dd, 0.0])
+            d[q + "grad"], d[q + "stress_in"], d[q + "eps_p_in"] = g.reshape(-1), s.reshape(-1).copy(), eps_p.reshape(-1).copy()
+            d[q + "stress_out"], d[q + "tangent_py"], d[q + "eps_p_out"] = s_out.reshape(-1), t_out.reshape(-1), e_out.reshape(-1)
+            d[q + "radius"], d[q + "a_minus_b_i1"] = radius, big
+            s, eps_p = s_out, e_out
+            idx += 1
+    d["n_calls"] = np.int64(idx)
+    np.savez_compressed(os.path.join(OUT, "drucker_prager_deviatoric_flow.npz"), **d)
+    print("drucker_prager_deviatoric_flow.npz", idx, "calls")
+
 
 if __name__ == "__main__":
     if "--mises-limit" in sys.argv:

@@ -157,4 +157,46 @@ def check_dp_j2(case, stress, tangent, history, tol=1e-11):
     # the hardening variable follows the state of the LAST BUT ONE iterate (its row of the Newton system is linearised): with the
     # hyperbolic surface, whose |g| depends on J2, it carries the size of the last step, bounded by the iteration's 1e-8
     assert rel_err(h[:, 0], e["kappa"]) <= (1e-7 if case["hyperbolic"] else tol), (case["name"], "kappa", rel_err(h[:, 0], e["kappa"]))
-    assert 0.5 < case["plastic"].mean() < 1.0
+    assert 0.15 < case["plastic"].mean() < 1.0  # the branch under test, with elastic points next to it
+
+
+def dp_pressure_cases():
+    """tests/golden/drucker_prager_deviatoric_flow.npz (oracle/gen_golden.py: main_mises_limit) -> inputs of the comfe-rs
+    Drucker-Prager laws with b != 0, b_flow = 0 and what the general return mapping must return, from POINT-BY-POINT calls
+    of the imported Python VonMises3D:
+
+    * b_flow = 0 makes the flow direction purely deviatoric (drucker_prager_classic.rs:96-103): the pressure stays at its trial
+      value and every point returns radially onto sqrt(J2) = R with R = a - b I1_trial (classic, :88) resp.
+      sqrt((a - b I1_trial)^2 - d^2) (hyperbolic.rs:87) -- the radial return of VonMises3D with y00 = y0 = sqrt(3) R of that
+      point: same stress, same plastic strain;
+    * the tangent d sigma / d eps of the Rust law additionally carries the derivative of R: with sigma_dev = sqrt(2) R n,
+      d R / d eps = -3 kappa b (A / R) I2 (A = a - b I1_trial; A / R = 1 for the classic surface) -> the Python tangent
+      - 3 sqrt(2) kappa b (A / R) n (x) I2 at plastic points, rows = n, columns = I2: a NON-SYMMETRIC term, which also pins the
+      orientation of the stored 6 x 6 block (general.rs:244-253 transposes before the column-major store);
+    * hardening variable: + sqrt(2/3) |g| with |g| = R / (sqrt(2) A) (general.rs:208: no del_lambda)."""
+    z = np.load(os.path.join(GOLDEN, "drucker_prager_deviatoric_flow.npz"))
+    i2 = np.array([1.0, 1.0, 1.0, 0.0, 0.0, 0.0])
+    out = []
+    for i in range(int(z["n_calls"])):
+        q = f"c{i}."
+        p = dict(zip([str(k) for k in z[q + "param_keys"]], [float(v) for v in z[q + "param_vals"]]))
+        hyper = p["d"] != 0.0
+        if not hyper:
+            del p["d"]
+        n = z[q + "grad"].size // 9
+        e_in, e_out = z[q + "eps_p_in"].reshape(n, 6), z[q + "eps_p_out"].reshape(n, 6)
+        pl = np.abs(e_out - e_in).max(axis=1) > 0.0
+        s_out = z[q + "stress_out"].reshape(n, 6)
+        dev = s_out.copy()
+        dev[:, :3] -= s_out[:, :3].mean(axis=1, keepdims=True)
+        nvec = dev[pl] / np.linalg.norm(dev[pl], axis=1, keepdims=True)
+        R, A = z[q + "radius"][pl], z[q + "a_minus_b_i1"][pl]
+        T = z[q + "tangent_py"].reshape(n, 6, 6).copy()
+        T[pl] -= (3.0 * np.sqrt(2.0) * p["kappa"] * p["b"] * (A / R))[:, None, None] * nvec[:, :, None] * i2[None, None, :]
+        kappa = np.zeros(n)
+        kappa[pl] = np.sqrt(2.0 / 3.0) * R / (np.sqrt(2.0) * A)
+        h_in = np.concatenate([np.zeros((n, 1)), e_in], axis=1).reshape(-1)
+        out.append({"name": str(z[q + "name"]), "hyperbolic": hyper, "params": p, "grad": z[q + "grad"], "stress_in": z[q + "stress_in"],
+                    "history_in": h_in, "plastic": pl,
+                    "expected": {"stress": z[q + "stress_out"], "eps_p": z[q + "eps_p_out"], "tangent": T.reshape(-1), "kappa": kappa}})
+    return out

@@ -71,18 +71,19 @@ def test_comfe_mises_kernel_against_the_imported_reference_in_the_linear_hardeni
     check_mises_limit(case, s, t, h["history"])
 
 
-from golden_util import check_dp_j2, dp_j2_cases  # noqa: E402
+from golden_util import check_dp_j2, dp_j2_cases, dp_pressure_cases  # noqa: E402
 
-DP_J2 = dp_j2_cases()
+DP_J2 = dp_j2_cases() + dp_pressure_cases()  # b = b_flow = 0, and b != 0 with b_flow = 0 (point-by-point reference calls)
 
 
 @pytest.mark.parametrize("path", ["host", "device", "resident"])
 @pytest.mark.parametrize("case", DP_J2, ids=[c["name"] for c in DP_J2])
 def test_drucker_prager_kernels_against_the_imported_reference_for_b_zero(case, path):
-    """The general return mapping on its J2 sub-family (b = b_flow = 0): the closest-point projection is the radial return of
-    the Python VonMises3D without hardening -- stress, plastic strain and consistent tangent from the imported reference
-    (golden_util.dp_j2_cases).  The kernels iterate in invariant coordinates with a closed-form inverse; the pin is on the
-    result."""
+    """The general return mapping where it coincides with the Python VonMises3D without hardening: b = b_flow = 0 (J2
+    sub-family: stress, plastic strain, consistent tangent from the imported reference, golden_util.dp_j2_cases) and b != 0
+    with b_flow = 0 (every point returns onto a cylinder whose radius follows from its trial pressure: point-by-point
+    reference calls, tangent + a non-symmetric rank-one term, golden_util.dp_pressure_cases).  The kernels iterate in
+    invariant coordinates with a closed-form inverse; the pin is on the result."""
     cls = fc.DruckerPragerHyperbolic3D if case["hyperbolic"] else fc.DruckerPrager3D
     law = cls({k: np.array([v]) for k, v in case["params"].items()})
     n = case["grad"].size // 9

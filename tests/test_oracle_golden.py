@@ -424,9 +424,28 @@ def test_comfe_mises_reproduces_the_reference_von_mises_in_the_linear_hardening_
 
 # ---- f4: the general return mapping against the IMPORTED Python reference on the J2 sub-family (b = b_flow = 0) ----
 
-from golden_util import check_dp_j2, dp_j2_cases  # noqa: E402
+from golden_util import check_dp_j2, dp_j2_cases, dp_pressure_cases  # noqa: E402
 
 DP_J2 = dp_j2_cases()
+DP_PRESSURE = dp_pressure_cases()
+
+
+@pytest.mark.parametrize("oracle", ["numpy", "c"])
+@pytest.mark.parametrize("case", DP_PRESSURE, ids=[c["name"] for c in DP_PRESSURE])
+def test_general_return_mapping_pressure_dependence_against_pointwise_reference_calls(case, oracle):
+    """b != 0, b_flow = 0: every point returns radially onto a J2 cylinder whose radius follows from ITS trial pressure --
+    stress and plastic strain are those of the imported Python VonMises3D called point by point with that yield stress, the
+    tangent is the Python one plus a non-symmetric rank-one term (golden_util.dp_pressure_cases), which also pins the
+    orientation of the stored tangent.  Still without a Python counterpart: b_flow != 0 (volumetric plastic flow)."""
+    from oracle import c_oracle as CO
+
+    fn = O.comfe_drucker_prager if oracle == "numpy" else CO.comfe_drucker_prager
+    n = case["grad"].size // 9
+    s, t, h = case["stress_in"].copy(), np.full(36 * n, np.nan), {"history": case["history_in"].copy()}
+    fn(case["params"], 0.0, 1.0, case["grad"].copy(), s, t, h, hyperbolic=case["hyperbolic"])
+    check_dp_j2(case, s, t, h["history"])
+    transposed = case["expected"]["tangent"].reshape(n, 6, 6).transpose(0, 2, 1).reshape(-1)
+    assert rel_err(t, transposed) > 0.1  # the term is not symmetric: the other orientation is far off
 
 
 @pytest.mark.parametrize("oracle", ["numpy", "c"])
