@@ -472,6 +472,52 @@ def main_mises_limit():
     np.savez_compressed(os.path.join(OUT, "drucker_prager_deviatoric_flow.npz"), **d)
     print("drucker_prager_deviatoric_flow.npz", idx, "calls")
 
+    # ... and b_flow != 0 (classic surface; associated flow b_flow = b included): the deviatoric part of the return is still
+    # radial -- onto sqrt(J2) = R = sqrt(J2_trial) - mu del_lambda --, the flow's volumetric part b_flow I2 moves the pressure.
+    # The radius handed to the reference (point by point, as above) is the one at which the RETURNED state -- the reference's
+    # deviatoric stress, the pressure moved by what the Rust flow rule says for the reference's own plastic multiplier --
+    # satisfies the Rust yield function; tests/golden_util.py: dp_volumetric_cases checks that and states the relations.
+    d, idx = {}, 0
+    for name, a, b, bf in (("nonassociated", 100.0, 0.05, 0.02), ("associated", 100.0, 0.05, 0.05), ("steep", 40.0, 0.2, 0.1)):
+        nn = 64
+        s = rng.normal(scale=30.0, size=(nn, 6))
+        s[:, :3] -= rng.uniform(300.0, 1500.0, size=nn)[:, None]
+        eps_p = np.zeros((nn, 6))
+        for step in range(2):
+            g = rng.normal(size=(nn, 9)) * (10 ** rng.uniform(-4.0, -2.3, size=nn))[:, None]
+            g[:, [0, 4, 8]] -= (0.9 * g[:, [0, 4, 8]].sum(axis=1) / 3.0)[:, None]
+            strain = m.strain_from_grad_u(g.reshape(-1), m.StressStrainConstraint.FULL).reshape(nn, 6)
+            i1_tr = s[:, :3].sum(axis=1) + 3.0 * ka * strain[:, :3].sum(axis=1)
+            dev = s.copy()
+            dev[:, :3] -= s[:, :3].mean(axis=1, keepdims=True)
+            e_dev = strain.copy()
+            e_dev[:, :3] -= strain[:, :3].mean(axis=1, keepdims=True)
+            rj2_tr = np.sqrt(0.5 * ((dev + 2.0 * mu * e_dev) ** 2).sum(axis=1))
+            f_tr = rj2_tr + b * i1_tr - a
+            radius = np.where(f_tr > 0.0, rj2_tr - mu * f_tr / (mu + 9.0 * ka * b * bf), a - b * i1_tr)
+            s_out, t_out, e_out, al = np.empty((nn, 6)), np.empty((nn, 36)), np.empty((nn, 6)), np.empty(nn)
+            for i in range(nn):
+                y = float(np.sqrt(3.0) * radius[i])
+                law = m.VonMises3D({"p_ka": ka, "p_mu": mu, "p_y0": y, "p_y00": y, "p_w": 1.0})
+                si, ti = s[i].copy(), np.full(36, np.nan)
+                hi = {"eps_n": np.zeros(6), "alpha": np.zeros(1)}
+                law.evaluate(0.0, 1.0, g[i].copy(), si, ti, hi)
+                s_out[i], t_out[i], e_out[i], al[i] = si, ti, hi["eps_n"], hi["alpha"][0]
+            q = f"c{idx}."
+            d[q + "name"] = np.array(f"{name}_step{step}")
+            d[q + "param_keys"] = np.array(["mu", "kappa", "a", "b", "b_flow"])
+            d[q + "param_vals"] = np.array([mu, ka, a, b, bf])
+            d[q + "grad"], d[q + "stress_in"], d[q + "eps_p_in"] = g.reshape(-1), s.reshape(-1).copy(), eps_p.reshape(-1).copy()
+            d[q + "stress_py"], d[q + "tangent_py"], d[q + "deps_py"], d[q + "alpha_py"] = s_out.reshape(-1), t_out.reshape(-1), e_out.reshape(-1), al
+            # carried state for the next increment: what the Rust law returns according to the relations of dp_volumetric_cases
+            dl = np.sqrt(3.0) * al
+            s = s_out - (3.0 * ka * bf * dl)[:, None] * sid[None, :]
+            eps_p = eps_p + e_out + (bf * dl)[:, None] * sid[None, :]
+            idx += 1
+    d["n_calls"] = np.int64(idx)
+    np.savez_compressed(os.path.join(OUT, "drucker_prager_volumetric_flow.npz"), **d)
+    print("drucker_prager_volumetric_flow.npz", idx, "calls")
+
 
 if __name__ == "__main__":
     if "--mises-limit" in sys.argv:

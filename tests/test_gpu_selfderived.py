@@ -71,9 +71,10 @@ def test_comfe_mises_kernel_against_the_imported_reference_in_the_linear_hardeni
     check_mises_limit(case, s, t, h["history"])
 
 
-from golden_util import check_dp_j2, dp_j2_cases, dp_pressure_cases  # noqa: E402
+from golden_util import check_dp_j2, dp_j2_cases, dp_pressure_cases, dp_volumetric_cases  # noqa: E402
 
-DP_J2 = dp_j2_cases() + dp_pressure_cases()  # b = b_flow = 0, and b != 0 with b_flow = 0 (point-by-point reference calls)
+# b = b_flow = 0; b != 0 with b_flow = 0; b_flow != 0 on the classic surface (point-by-point reference calls)
+DP_J2 = dp_j2_cases() + dp_pressure_cases() + dp_volumetric_cases()
 
 
 @pytest.mark.parametrize("path", ["host", "device", "resident"])
@@ -82,7 +83,9 @@ def test_drucker_prager_kernels_against_the_imported_reference_for_b_zero(case, 
     """The general return mapping where it coincides with the Python VonMises3D without hardening: b = b_flow = 0 (J2
     sub-family: stress, plastic strain, consistent tangent from the imported reference, golden_util.dp_j2_cases) and b != 0
     with b_flow = 0 (every point returns onto a cylinder whose radius follows from its trial pressure: point-by-point
-    reference calls, tangent + a non-symmetric rank-one term, golden_util.dp_pressure_cases).  The kernels iterate in
+    reference calls, tangent + a non-symmetric rank-one term, golden_util.dp_pressure_cases), and the classic surface with
+    b_flow != 0 (the reference's deviatoric return + the volumetric part of the Rust flow rule for the reference's own plastic
+    multiplier, verified to lie on the Rust yield surface, golden_util.dp_volumetric_cases).  The kernels iterate in
     invariant coordinates with a closed-form inverse; the pin is on the result."""
     cls = fc.DruckerPragerHyperbolic3D if case["hyperbolic"] else fc.DruckerPrager3D
     law = cls({k: np.array([v]) for k, v in case["params"].items()})

@@ -424,10 +424,27 @@ def test_comfe_mises_reproduces_the_reference_von_mises_in_the_linear_hardening_
 
 # ---- f4: the general return mapping against the IMPORTED Python reference on the J2 sub-family (b = b_flow = 0) ----
 
-from golden_util import check_dp_j2, dp_j2_cases, dp_pressure_cases  # noqa: E402
+from golden_util import check_dp_j2, dp_j2_cases, dp_pressure_cases, dp_volumetric_cases  # noqa: E402
 
 DP_J2 = dp_j2_cases()
 DP_PRESSURE = dp_pressure_cases()
+DP_VOLUMETRIC = dp_volumetric_cases()
+
+
+@pytest.mark.parametrize("oracle", ["numpy", "c"])
+@pytest.mark.parametrize("case", DP_VOLUMETRIC, ids=[c["name"] for c in DP_VOLUMETRIC])
+def test_general_return_mapping_with_volumetric_flow_against_pointwise_reference_calls(case, oracle):
+    """b_flow != 0 (non-associated, associated, a steep surface): the deviatoric part of the return is the reference's radial
+    return, the volumetric part follows from the reference's own plastic multiplier through the Rust flow rule, and the
+    assembled state is verified to lie on the Rust yield surface (golden_util.dp_volumetric_cases) -- stress, plastic strain
+    and the full consistent tangent of the 8 x 8 Newton machinery for the whole classic Drucker-Prager family."""
+    from oracle import c_oracle as CO
+
+    fn = O.comfe_drucker_prager if oracle == "numpy" else CO.comfe_drucker_prager
+    n = case["grad"].size // 9
+    s, t, h = case["stress_in"].copy(), np.full(36 * n, np.nan), {"history": case["history_in"].copy()}
+    fn(case["params"], 0.0, 1.0, case["grad"].copy(), s, t, h, hyperbolic=False)
+    check_dp_j2(case, s, t, h["history"])
 
 
 @pytest.mark.parametrize("oracle", ["numpy", "c"])
