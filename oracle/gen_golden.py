@@ -514,6 +514,58 @@ def main_mises_limit():
             s = s_out - (3.0 * ka * bf * dl)[:, None] * sid[None, :]
             eps_p = eps_p + e_out + (bf * dl)[:, None] * sid[None, :]
             idx += 1
+    # the hyperbolic surface with b_flow != 0, same idea: s_1 (1 + mu del_lambda / Q) = s_trial with Q = sqrt(J2_1 + d^2) =
+    # a - b (I1_trial - 9 kappa b_flow del_lambda) is one scalar equation for del_lambda, solved here by bisection ONLY to choose the
+    # radius handed to the reference; the checks of dp_volumetric_cases are on the returned state
+    for name, a, b, bf, dd in (("hyperbolic_nonassociated", 100.0, 0.05, 0.02, 40.0), ("hyperbolic_associated", 100.0, 0.05, 0.05, 40.0)):
+        nn = 64
+        s = rng.normal(scale=30.0, size=(nn, 6))
+        s[:, :3] -= rng.uniform(300.0, 1500.0, size=nn)[:, None]
+        eps_p = np.zeros((nn, 6))
+        for step in range(2):
+            g = rng.normal(size=(nn, 9)) * (10 ** rng.uniform(-4.0, -2.3, size=nn))[:, None]
+            g[:, [0, 4, 8]] -= (0.9 * g[:, [0, 4, 8]].sum(axis=1) / 3.0)[:, None]
+            strain = m.strain_from_grad_u(g.reshape(-1), m.StressStrainConstraint.FULL).reshape(nn, 6)
+            i1_tr = s[:, :3].sum(axis=1) + 3.0 * ka * strain[:, :3].sum(axis=1)
+            dev = s.copy()
+            dev[:, :3] -= s[:, :3].mean(axis=1, keepdims=True)
+            e_dev = strain.copy()
+            e_dev[:, :3] -= strain[:, :3].mean(axis=1, keepdims=True)
+            rj2_tr = np.sqrt(0.5 * ((dev + 2.0 * mu * e_dev) ** 2).sum(axis=1))
+            big = a - b * i1_tr
+            f_tr = np.sqrt(rj2_tr**2 + dd * dd) - big
+            radius = np.sqrt(big * big - dd * dd)  # elastic points: any radius they stay inside of
+            for i in np.flatnonzero(f_tr > 0.0):
+                def h(dl):
+                    q_ = big[i] + 9.0 * ka * b * bf * dl
+                    return np.sqrt(max(q_ * q_ - dd * dd, 0.0)) * (1.0 + mu * dl / q_) - rj2_tr[i]
+                lo, hi = 0.0, rj2_tr[i] / mu
+                for _ in range(200):
+                    mid = 0.5 * (lo + hi)
+                    lo, hi = (mid, hi) if h(mid) < 0.0 else (lo, mid)
+                q_ = big[i] + 9.0 * ka * b * bf * 0.5 * (lo + hi)
+                radius[i] = np.sqrt(q_ * q_ - dd * dd)
+            s_out, t_out, e_out, al = np.empty((nn, 6)), np.empty((nn, 36)), np.empty((nn, 6)), np.empty(nn)
+            for i in range(nn):
+                y = float(np.sqrt(3.0) * radius[i])
+                law = m.VonMises3D({"p_ka": ka, "p_mu": mu, "p_y0": y, "p_y00": y, "p_w": 1.0})
+                si, ti = s[i].copy(), np.full(36, np.nan)
+                hi_ = {"eps_n": np.zeros(6), "alpha": np.zeros(1)}
+                law.evaluate(0.0, 1.0, g[i].copy(), si, ti, hi_)
+                s_out[i], t_out[i], e_out[i], al[i] = si, ti, hi_["eps_n"], hi_["alpha"][0]
+            q = f"c{idx}."
+            d[q + "name"] = np.array(f"{name}_step{step}")
+            d[q + "param_keys"] = np.array(["mu", "kappa", "a", "b", "d", "b_flow"])
+            d[q + "param_vals"] = np.array([mu, ka, a, b, dd, bf])
+            d[q + "grad"], d[q + "stress_in"], d[q + "eps_p_in"] = g.reshape(-1), s.reshape(-1).copy(), eps_p.reshape(-1).copy()
+            d[q + "stress_py"], d[q + "tangent_py"], d[q + "deps_py"], d[q + "alpha_py"] = s_out.reshape(-1), t_out.reshape(-1), e_out.reshape(-1), al
+            dev1 = s_out.copy()
+            dev1[:, :3] -= s_out[:, :3].mean(axis=1, keepdims=True)
+            j2_1 = 0.5 * (dev1**2).sum(axis=1)
+            dl = np.sqrt(3.0) * al * np.sqrt(j2_1 + dd * dd) / np.sqrt(np.where(j2_1 > 0.0, j2_1, 1.0))
+            s = s_out - (3.0 * ka * bf * dl)[:, None] * sid[None, :]
+            eps_p = eps_p + e_out + (bf * dl)[:, None] * sid[None, :]
+            idx += 1
     d["n_calls"] = np.int64(idx)
     np.savez_compressed(os.path.join(OUT, "drucker_prager_volumetric_flow.npz"), **d)
     print("drucker_prager_volumetric_flow.npz", idx, "calls")
