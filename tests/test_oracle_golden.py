@@ -437,13 +437,14 @@ def test_general_return_mapping_with_volumetric_flow_against_pointwise_reference
     """b_flow != 0 (non-associated, associated, a steep surface): the deviatoric part of the return is the reference's radial
     return, the volumetric part follows from the reference's own plastic multiplier through the Rust flow rule, and the
     assembled state is verified to lie on the Rust yield surface (golden_util.dp_volumetric_cases) -- stress, plastic strain
-    and the full consistent tangent of the 8 x 8 Newton machinery for the whole classic Drucker-Prager family."""
+    and the full consistent tangent of the 8 x 8 Newton machinery for the whole classic Drucker-Prager family; stress, plastic
+    strain and hardening variable for the hyperbolic surface."""
     from oracle import c_oracle as CO
 
     fn = O.comfe_drucker_prager if oracle == "numpy" else CO.comfe_drucker_prager
     n = case["grad"].size // 9
     s, t, h = case["stress_in"].copy(), np.full(36 * n, np.nan), {"history": case["history_in"].copy()}
-    fn(case["params"], 0.0, 1.0, case["grad"].copy(), s, t, h, hyperbolic=False)
+    fn(case["params"], 0.0, 1.0, case["grad"].copy(), s, t, h, hyperbolic=case["hyperbolic"])
     check_dp_j2(case, s, t, h["history"])
 
 
