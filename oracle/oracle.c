@@ -9,9 +9,9 @@
  * Parity pin: tests/test_oracle_c.py checks every function against the golden vectors
  * captured from the imported reference (tests/golden/, oracle/gen_golden.py) and against
  * oracle/numpy_oracle.py.  The plastic values of the comfe-rs laws are not pinned by any
- * reference test of their own; they are pinned indirectly through the imported Python VonMises3D
- * where the laws coincide, the pressure-dependent Drucker-Prager terms stay "parity unpinned"
- * (see numpy_oracle.py).
+ * reference test of their own; they are pinned indirectly through outputs of the imported Python
+ * VonMises3D; the tangent of the hyperbolic Drucker-Prager surface with b_flow != 0 stays "parity
+ * unpinned" (see numpy_oracle.py).
  *
  * Serial loops over points mirror the reference's own structure:
  *   Python per-point loop   models/mises_plasticity_isotropic_hardening.py:74-175
@@ -322,9 +322,10 @@ long long oracle_comfe_mises(double mu, double kappa, double y_0, double h, long
    drucker_prager_hyperbolic.rs:64-114; driven by interfaces.rs:441-455).  8 unknowns
    [sigma(6), del_lambda, alpha]; nalgebra's LU with partial pivoting is restated as Doolittle LU with
    row pivoting on the 8x8 matrix; the consistent tangent is (dres^-1)[0:6,0:6] . E, transposed and then
-   stored column-major (= row-major of the product).  Pinned by the imported Python VonMises3D on the J2 sub-family
-   b = b_flow = 0; PARITY UNPINNED for the terms in b and b_flow (see numpy_oracle.py): this is a second, independent
-   restatement; tests compare the two.
+   stored column-major (= row-major of the product).  Pinned indirectly by outputs of the imported Python VonMises3D
+   (tests/golden_util.py: dp_j2_cases, dp_pressure_cases, dp_volumetric_cases); PARITY UNPINNED only for the tangent of
+   the hyperbolic surface with b_flow != 0 (see numpy_oracle.py): this is a second, independent restatement; tests
+   compare the two.
    status (return value): number of plastic points; *flags |= 1 tip of the classic surface reached,
    |= 2 Newton did not converge, |= 4 singular system. */
 typedef struct {
