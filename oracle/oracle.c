@@ -10,8 +10,8 @@
  * captured from the imported reference (tests/golden/, oracle/gen_golden.py) and against
  * oracle/numpy_oracle.py.  The plastic values of the comfe-rs laws are not pinned by any
  * reference test of their own; they are pinned indirectly through outputs of the imported Python
- * VonMises3D; the tangent of the hyperbolic Drucker-Prager surface with b_flow != 0 stays "parity
- * unpinned" (see numpy_oracle.py).
+ * VonMises3D; no output of the crate itself exists ("parity unpinned" in the literal sense; see
+ * numpy_oracle.py).
  *
  * Serial loops over points mirror the reference's own structure:
  *   Python per-point loop   models/mises_plasticity_isotropic_hardening.py:74-175
@@ -323,9 +323,8 @@ long long oracle_comfe_mises(double mu, double kappa, double y_0, double h, long
    [sigma(6), del_lambda, alpha]; nalgebra's LU with partial pivoting is restated as Doolittle LU with
    row pivoting on the 8x8 matrix; the consistent tangent is (dres^-1)[0:6,0:6] . E, transposed and then
    stored column-major (= row-major of the product).  Pinned indirectly by outputs of the imported Python VonMises3D
-   (tests/golden_util.py: dp_j2_cases, dp_pressure_cases, dp_volumetric_cases); PARITY UNPINNED only for the tangent of
-   the hyperbolic surface with b_flow != 0 (see numpy_oracle.py): this is a second, independent restatement; tests
-   compare the two.
+   (tests/golden_util.py: dp_j2_cases, dp_pressure_cases, dp_volumetric_cases); PARITY UNPINNED in the literal sense (no
+   output of the crate itself; see numpy_oracle.py): this is a second, independent restatement; tests compare the two.
    status (return value): number of plastic points; *flags |= 1 tip of the classic surface reached,
    |= 2 Newton did not converge, |= 4 singular system. */
 typedef struct {

@@ -153,8 +153,7 @@ def check_dp_j2(case, stress, tangent, history, tol=1e-11):
     h = np.asarray(history).reshape(n, 7)
     assert rel_err(stress, e["stress"]) <= tol, (case["name"], "stress", rel_err(stress, e["stress"]))
     assert rel_err(h[:, 1:], e["eps_p"].reshape(n, 6)) <= tol, (case["name"], "eps_p")
-    if e["tangent"] is not None:  # (hyperbolic surface with b_flow != 0: no closed form stated -- stress and plastic strain only)
-        assert rel_err(tangent, e["tangent"]) <= tol, (case["name"], "tangent", rel_err(tangent, e["tangent"]))
+    assert rel_err(tangent, e["tangent"]) <= tol, (case["name"], "tangent", rel_err(tangent, e["tangent"]))
     # the hardening variable follows the state of the LAST BUT ONE iterate (its row of the Newton system is linearised): with the
     # hyperbolic surface, whose |g| depends on J2, it carries the size of the last step, bounded by the iteration's 1e-8
     assert rel_err(h[:, 0], e["kappa"]) <= (1e-7 if case["hyperbolic"] else tol), (case["name"], "kappa", rel_err(h[:, 0], e["kappa"]))
@@ -215,8 +214,9 @@ def dp_volumetric_cases():
     * plastic strain: the Python one + b_flow del_lambda I2;
     * THE CHECK THAT THE RADIUS WAS THE RIGHT ONE: the state so assembled satisfies the Rust yield function
       sqrt(J2) + b I1 - a = 0 (:88) at every plastic point -- asserted here, to 1e-12 a;
-    * tangent: Python's + 2 mu n (x) n - (3 kappa b_flow I2 + sqrt(2) mu n) (x) (sqrt(2) mu n + 3 kappa b I2) / (mu + 9 kappa b b_flow)
-      (the derivative of del_lambda = f_trial / (mu + 9 kappa b b_flow) replaces the one of the fixed-radius return);
+    * tangent: classic surface: Python's + 2 mu n (x) n - (3 kappa b_flow I2 + sqrt(2) mu n) (x) (sqrt(2) mu n + 3 kappa b I2) / (mu + 9 kappa b b_flow)
+      (the derivative of del_lambda = f_trial / (mu + 9 kappa b b_flow) replaces the one of the fixed-radius return); both surfaces in
+      the general form stated next to the code below;
     * hardening variable: + sqrt(2/3) |g| = sqrt(2/3) sqrt(3 b_flow^2 + 1/2) (general.rs:208: no del_lambda)."""
     z = np.load(os.path.join(GOLDEN, "drucker_prager_volumetric_flow.npz"))
     i2 = np.array([1.0, 1.0, 1.0, 0.0, 0.0, 0.0])
@@ -244,13 +244,20 @@ def dp_volumetric_cases():
         f_new = np.sqrt(0.5 * (dev[pl] ** 2).sum(axis=1) + dd * dd) + b * stress[pl, :3].sum(axis=1) - a
         assert np.abs(f_new).max() <= 1e-11 * a, np.abs(f_new).max()   # the assembled state lies ON the Rust yield surface
         nvec = dev[pl] / np.linalg.norm(dev[pl], axis=1, keepdims=True)
-        T = None
-        if not hyper:
-            T = z[q + "tangent_py"].reshape(n, 6, 6).copy()
-            left = 3.0 * ka * bf * i2[None, :] + np.sqrt(2.0) * mu * nvec
-            right = np.sqrt(2.0) * mu * nvec + 3.0 * ka * b * i2[None, :]
-            T[pl] += 2.0 * mu * nvec[:, :, None] * nvec[:, None, :] - left[:, :, None] * right[:, None, :] / (mu + 9.0 * ka * b * bf)
-            T = T.reshape(-1)
+        # tangent, both surfaces: sigma_1 = (p_trial - 3 kappa b_flow del_lambda) I2 + sqrt(2) r n with r = sqrt(J2_1), Q = sqrt(r^2 + d^2)
+        # = A + c del_lambda (A = a - b I1_trial, c = 9 kappa b b_flow) and r (1 + mu del_lambda / Q) = sqrt(J2_trial); the Python
+        # tangent is the derivative at FIXED r, so T = T_py - 3 kappa b_flow I2 (x) w + sqrt(2) (Q / r) n (x) (c w - 3 kappa b I2) with
+        # w = d del_lambda / d eps = (sqrt(2) mu n + 3 kappa b G I2) / (c G + mu r / Q), G = (Q / r)(1 + mu del_lambda / Q) - mu del_lambda r / Q^2
+        # (classic surface, d = 0: Q = r, G = 1 -- the closed form in the docstring)
+        r_ = np.sqrt(j2_1[pl])
+        Q = np.sqrt(j2_1[pl] + dd * dd)
+        c = 9.0 * ka * b * bf
+        G = (Q / r_) * (1.0 + mu * dl[pl] / Q) - mu * dl[pl] * r_ / (Q * Q)
+        w = (np.sqrt(2.0) * mu * nvec + (3.0 * ka * b * G)[:, None] * i2[None, :]) / (c * G + mu * r_ / Q)[:, None]
+        T = z[q + "tangent_py"].reshape(n, 6, 6).copy()
+        T[pl] += -3.0 * ka * bf * i2[None, :, None] * w[:, None, :] \
+            + (np.sqrt(2.0) * Q / r_)[:, None, None] * nvec[:, :, None] * (c * w - 3.0 * ka * b * i2[None, :])[:, None, :]
+        T = T.reshape(-1)
         # |g|^2 = 3 b_flow^2 + J2 / (2 Q^2)
         g_norm = np.sqrt(3.0 * bf * bf + 0.5 * j2_1 / (j2_1 + dd * dd)) if hyper else np.sqrt(3.0 * bf * bf + 0.5)
         kappa = np.where(pl, np.sqrt(2.0 / 3.0) * g_norm, 0.0)

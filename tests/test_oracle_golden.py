@@ -437,8 +437,7 @@ def test_general_return_mapping_with_volumetric_flow_against_pointwise_reference
     """b_flow != 0 (non-associated, associated, a steep surface): the deviatoric part of the return is the reference's radial
     return, the volumetric part follows from the reference's own plastic multiplier through the Rust flow rule, and the
     assembled state is verified to lie on the Rust yield surface (golden_util.dp_volumetric_cases) -- stress, plastic strain
-    and the full consistent tangent of the 8 x 8 Newton machinery for the whole classic Drucker-Prager family; stress, plastic
-    strain and hardening variable for the hyperbolic surface."""
+    and the full consistent tangent of the 8 x 8 Newton machinery, both surfaces."""
     from oracle import c_oracle as CO
 
     fn = O.comfe_drucker_prager if oracle == "numpy" else CO.comfe_drucker_prager
