@@ -1,7 +1,8 @@
 """the comfe-rs general return mapping with the two Drucker-Prager surfaces on the GPU,
 against the NumPy restatement of comfe-rs/src/plasticity/general.rs (oracle/numpy_oracle.py).
-PARITY UNPINNED by the reference (no test exercises these laws, no Rust toolchain): the oracle itself
-is pinned by identities only (tests/test_oracle_golden.py::test_drucker_prager_identities)."""
+No output of the crate exists (no reference test exercises these laws, no Rust toolchain -- literally PARITY UNPINNED): the
+oracle is pinned by identities, a 50-digit transcription and, indirectly, by point-by-point outputs of the imported Python
+VonMises3D (tests/test_oracle_golden.py; the kernels against the same vectors: tests/test_gpu_selfderived.py)."""
 
 import numpy as np
 import pytest
