@@ -469,3 +469,46 @@ def test_split_history_in_place_and_out_of_place_without_mask(law_name):
     hv = {"scalar": torch.zeros(n, **f), "rows": torch.zeros(6 * n, **f)}
     with pytest.raises(NotImplementedError, match="SPLIT_HISTORY"):
         vm.evaluate_from(0.0, 1.0, g, s1, s2, t2, hv, hv, split_history=True)
+
+
+@pytest.mark.parametrize("kind,split", [("von_mises_3d", True), ("comfe_mises_plasticity", True), ("comfe_mises_plasticity", False)])
+def test_row_fill_granules_leave_identical_bits(kind, split):
+    """Row-masked history access in aligned granules of 16 << row_fill bytes (context option ``row_fill``, default 2 = 64
+    bytes; csrc/kernels/history_rows.h: granule_touched): the chunks filled in next to a touched row carry the values the
+    array holds already, so every setting leaves the same BITS in every array -- in place (the reference contract) and under
+    the sparse protocol of a resident state, with plastic sets that shrink and grow."""
+    from fenics_constitutive_amd import _capi
+    from test_gpu_parity import make_law, random_case
+
+    n = 64 * 40 + 13
+    p, g0, s0, h0 = random_case(kind, n, seed=21)
+    law = make_law(kind, p)
+    ctx = law._handle(_capi.default_device()).ctx
+    results = {}
+    try:
+        for fill in (0, 1, 2, 3):
+            ctx.set_option("row_fill", fill)
+            out = []
+            # in place, device tensors: two calls, the second with a smaller plastic set
+            s, t = torch.from_numpy(s0).cuda(), torch.full((36 * n,), float("nan"), dtype=torch.float64, device="cuda")
+            h = {k: torch.from_numpy(v).cuda() for k, v in h0.items()}
+            for scale in (1.0, 0.3):
+                law.evaluate(0.0, 1.0, torch.from_numpy(g0 * scale).cuda(), s, t, h)
+                law.device_stats()
+                out += [s.clone(), t.clone()] + [v.clone() for v in h.values()]
+            # sparse protocol: resident state, plastic set shrinks, grows, commit, shrinks
+            rs = ResidentState(law, n, stress0=s0, history0=h0, split_history=split, delta_history=False, placement="torch")
+            for k, scale in enumerate((1.0, 0.2, 1.5, 0.4)):
+                rs.evaluate(0.0, 1.0, g0 * scale)
+                rs.check()
+                out += [rs.stress.clone(), rs.tangent.clone()] + [v.clone() for v in rs.history.values()]
+                if k == 2:
+                    rs.update()
+                    out += [v.clone() for v in rs.history_committed.values()]
+            results[fill] = out
+    finally:
+        ctx.set_option("row_fill", 2)
+    for fill in (1, 2, 3):
+        assert len(results[fill]) == len(results[0])
+        for a, b in zip(results[fill], results[0]):
+            assert torch.equal(a.view(torch.int64), b.view(torch.int64)), fill

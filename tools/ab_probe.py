@@ -22,14 +22,14 @@ mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
 e1.copy_(e0), a1.copy_(a0)  # sparse contract: trial == committed
 # launch knobs are context options (fcamd_context_set_option); the FCAMD_* environment names select them here
 variants = [v.split("=") for v in sys.argv[1:]] or [["FCAMD_TILE_MAP", "0"], ["FCAMD_TILE_MAP", "1"]]
-OPTION = {"FCAMD_TILE_MAP": "tile_map", "FCAMD_NT": "nontemporal", "FCAMD_MASKED_MAX": "masked_max"}
+OPTION = {"FCAMD_TILE_MAP": "tile_map", "FCAMD_NT": "nontemporal", "FCAMD_MASKED_MAX": "masked_max", "FCAMD_ROW_FILL": "row_fill"}
 ctx = law._handle(0).ctx
 res = {tuple(v): [] for v in variants}
 for rnd in range(6):
     for k, v in variants:
         if k in OPTION:
             ctx.set_option(OPTION[k], int(v))
-        hm = mask if (k == "SPARSE" and v == "1") else None
+        hm = mask if ((k == "SPARSE" and v == "1") or os.environ.get("AB_SPARSE") == "1") else None
         for _ in range(2):
             law.evaluate_from(0, 1, g, s0, s1, t, h0, h1, history_mask=hm)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
