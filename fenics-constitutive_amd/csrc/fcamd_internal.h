@@ -53,7 +53,6 @@ struct EvalArgs {
     int tile_map;              // 0: tiles dealt round-robin to all waves; 1: one contiguous region per XCD
     int nontemporal;           // main kernel of the plain (non-indexed, non-sparse) form: non-temporal global accesses (default) or plain ones
     int masked_max;            // row-masked history access for tiles with at most this many touched rows (else dense)
-    int row_fill;              // row-masked access in aligned granules of 16 << row_fill bytes (history_rows.h: granule_touched)
     int flags;                 // bit 0: sparse-tangent protocol (fcamd_kernels.hip: sparse_tangent_need); bit 1: delta trial history
     Scalars sc;
     Tables tb;

@@ -49,11 +49,14 @@ __device__ __forceinline__ void delta_rows_store(double* rows_out, long long p0,
 // holds already (in place) resp. the committed values, which the trial array holds wherever the mask is clear (sparse
 // protocol) -- every chunk is still moved by exactly one lane.  Measured on the headline workload (VonMises3D mixed, 1e8
 // points, same buffers, interleaved): fill 0 / 1 / 2 / 3 = 8.42 / 8.39 / 8.34 / 8.41 ms -> 64-byte granules (fill = 2).
+// Used by VonMises3D's eps_n rows (law_von_mises.h); the comfe-rs laws' stores below keep the bare rule: their mixed workloads
+// take the dense path for most tiles (no measurable difference) and the Drucker-Prager kernels have no register to spare.
+constexpr int kRowFill = 2;  // compile-time: as a launch argument the shifts cost more than the granules gain
 template <int ROW>
-__device__ __forceinline__ bool granule_touched(unsigned long long touched, int q, int fill) {
-    const int c0 = (q >> fill) << fill;              // first chunk of the granule
+__device__ __forceinline__ bool granule_touched(unsigned long long touched, int q) {
+    const int c0 = (q >> kRowFill) << kRowFill;       // first chunk of the granule
     const int rlo = (2 * c0) / ROW;                   // rows of its first and last double
-    const int rhi = (2 * (c0 + (1 << fill)) - 1) / ROW;
+    const int rhi = (2 * (c0 + (1 << kRowFill)) - 1) / ROW;
     return ((touched >> rlo) & ((2ull << (rhi - rlo)) - 1ull)) != 0ull;
 }
 
@@ -94,7 +97,8 @@ __device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, 
 #pragma unroll
     for (int k = 0; k < Chunks<7>::K; ++k) {
         const int q = k * kWave + lane;
-        if (chunk_live<7>(k, lane) && granule_touched<7>(need, q, a.row_fill))
+        const bool hit = (((need >> ((2 * q) / 7)) | (need >> ((2 * q + 1) / 7))) & 1ull) != 0ull;
+        if (chunk_live<7>(k, lane) && hit)
             store16<NT>(a.h0_out + p0 * 7 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
     }
     wave_sync();
@@ -122,7 +126,7 @@ __device__ __forceinline__ void split_history_store(const EvalArgs& a, long long
     if (masked) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            row_live[k] = granule_touched<6>(rows, k * kWave + lane, a.row_fill);
+            row_live[k] = ((rows >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
             d2 z;
             z.x = 0.0;
             z.y = 0.0;

@@ -149,7 +149,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     bool row_live[3] = {true, true, true};  // per chunk of this lane: its row is touched
     if (masked) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) row_live[k] = granule_touched<6>(eps_mask, k * kWave + lane, a.row_fill);
+        for (int k = 0; k < 3; ++k) row_live[k] = granule_touched<6>(eps_mask, k * kWave + lane);
     }
     if (!delta && touch_eps) {
         if (masked) {

@@ -472,11 +472,12 @@ def test_split_history_in_place_and_out_of_place_without_mask(law_name):
 
 
 @pytest.mark.parametrize("kind,split", [("von_mises_3d", True), ("comfe_mises_plasticity", True), ("comfe_mises_plasticity", False)])
-def test_row_fill_granules_leave_identical_bits(kind, split):
-    """Row-masked history access in aligned granules of 16 << row_fill bytes (context option ``row_fill``, default 2 = 64
-    bytes; csrc/kernels/history_rows.h: granule_touched): the chunks filled in next to a touched row carry the values the
-    array holds already, so every setting leaves the same BITS in every array -- in place (the reference contract) and under
-    the sparse protocol of a resident state, with plastic sets that shrink and grow."""
+def test_row_masked_access_leaves_identical_bits(kind, split):
+    """Row-masked history access (tiles with at most ``masked_max`` touched rows; VonMises3D moves its rows in aligned
+    64-byte granules, csrc/kernels/history_rows.h: granule_touched -- the chunks filled in next to a touched row carry the
+    values the array holds already) against the dense tile access (``masked_max`` = 0) and the always-masked one (64): the
+    same BITS in every array -- in place (the reference contract) and under the sparse protocol of a resident state, with
+    plastic sets that shrink and grow."""
     from fenics_constitutive_amd import _capi
     from test_gpu_parity import make_law, random_case
 
@@ -486,8 +487,8 @@ def test_row_fill_granules_leave_identical_bits(kind, split):
     ctx = law._handle(_capi.default_device()).ctx
     results = {}
     try:
-        for fill in (0, 1, 2, 3):
-            ctx.set_option("row_fill", fill)
+        for fill in (0, 20, 64):
+            ctx.set_option("masked_max", fill)
             out = []
             # in place, device tensors: two calls, the second with a smaller plastic set
             s, t = torch.from_numpy(s0).cuda(), torch.full((36 * n,), float("nan"), dtype=torch.float64, device="cuda")
@@ -507,8 +508,8 @@ def test_row_fill_granules_leave_identical_bits(kind, split):
                     out += [v.clone() for v in rs.history_committed.values()]
             results[fill] = out
     finally:
-        ctx.set_option("row_fill", 2)
-    for fill in (1, 2, 3):
+        ctx.set_option("masked_max", -1)
+    for fill in (20, 64):
         assert len(results[fill]) == len(results[0])
         for a, b in zip(results[fill], results[0]):
             assert torch.equal(a.view(torch.int64), b.view(torch.int64)), fill
