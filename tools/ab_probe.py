@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""In-process A/B of launch knobs (env re-read per call) on identical buffers: interleaved rounds."""
+"""In-process A/B of launch knobs (context options) on identical buffers: interleaved rounds.
+    python tools/ab_probe.py FCAMD_MASKED_MAX=0 FCAMD_MASKED_MAX=20 ...      (AB_SPARSE=1: every variant with the sparse trial-history mask)"""
 import os
 import sys
 
