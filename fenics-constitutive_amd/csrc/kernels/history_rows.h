@@ -40,26 +40,6 @@ __device__ __forceinline__ void delta_rows_store(double* rows_out, long long p0,
     wave_sync();
 }
 
-// Row-masked access in aligned granules.  A tile's array image is a run of 16-byte chunks (chunk q = doubles 2q, 2q + 1 of
-// rows of ROW doubles); a lane moves chunk q if ANY row that has a byte in the aligned granule of (1 << fill) chunks around
-// q is touched.  fill = 0 is the bare rule "the chunks of touched rows".  With isolated 48- or 56-byte rows that rule issues
-// 16-byte accesses that split 32-byte sectors and 64-byte memory transfers: the bytes next to a touched row are fetched with
-// it anyway (reads arrive in 128-byte lines) but a partial write of a transfer unit is not free.  Completing the granule
-// costs no extra HBM read and turns the partial writes into whole ones: the filled-in chunks carry the values the array
-// holds already (in place) resp. the committed values, which the trial array holds wherever the mask is clear (sparse
-// protocol) -- every chunk is still moved by exactly one lane.  Measured on the headline workload (VonMises3D mixed, 1e8
-// points, same buffers, interleaved): fill 0 / 1 / 2 / 3 = 8.42 / 8.39 / 8.34 / 8.41 ms -> 64-byte granules (fill = 2).
-// Used by VonMises3D's eps_n rows (law_von_mises.h); the comfe-rs laws' stores below keep the bare rule: their mixed workloads
-// take the dense path for most tiles (no measurable difference) and the Drucker-Prager kernels have no register to spare.
-constexpr int kRowFill = 2;  // compile-time: as a launch argument the shifts cost more than the granules gain
-template <int ROW>
-__device__ __forceinline__ bool granule_touched(unsigned long long touched, int q) {
-    const int c0 = (q >> kRowFill) << kRowFill;       // first chunk of the granule
-    const int rlo = (2 * c0) / ROW;                   // rows of its first and last double
-    const int rhi = (2 * (c0 + (1 << kRowFill)) - 1) / ROW;
-    return ((touched >> rlo) & ((2ull << (rhi - rlo)) - 1ull)) != 0ull;
-}
-
 // History write policy of the laws with one [alpha, eps_p(6)] row per point (comfe-rs Mises and
 // Drucker-Prager; the row is always READ: alpha enters the yield function).  Which rows change:
 //   in place                      : the plastic points of this evaluate (ballot `mask`);
@@ -139,7 +119,7 @@ __device__ __forceinline__ void split_history_store(const EvalArgs& a, long long
         double ep[6];
         transpose_in<6>(ce, region, lane, ep);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + delta[i];  // (delta = 0.0 where the point is not plastic)
+        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + delta[i];
         if (masked) {
             lds_put_point<6>(region, lane, ep);
             wave_sync();

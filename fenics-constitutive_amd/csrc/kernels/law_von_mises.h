@@ -132,8 +132,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     // load and store instructions and every lane simply skips the chunks of untouched rows.  HBM
     // sees the touched rows only (reads at the 128-byte line granularity of the memory side), the
     // instruction count does not depend on how many rows are touched, and a fully plastic tile
-    // degenerates to the plain coalesced tile access.  The chunks are taken in aligned 64-byte granules
-    // (granule_touched, history_rows.h): whole memory-side transfers instead of partial ones.
+    // degenerates to the plain coalesced tile access.
     Chunks<6> ce;
     constexpr bool sparse = SPARSE;
     unsigned long long m_old = 0ull;
@@ -149,7 +148,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     bool row_live[3] = {true, true, true};  // per chunk of this lane: its row is touched
     if (masked) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) row_live[k] = granule_touched<6>(eps_mask, k * kWave + lane);
+        for (int k = 0; k < 3; ++k) row_live[k] = ((eps_mask >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
     }
     if (!delta && touch_eps) {
         if (masked) {
@@ -185,7 +184,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
             double ep[6];
             transpose_in<6>(ce, region, lane, ep);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ep[i] = plastic ? ep[i] + rm.gamma * rm.N[i] : ep[i];  // (rows passing through keep their bits)
+            for (int i = 0; i < 6; ++i) ep[i] = ep[i] + rm.gamma * rm.N[i];
             if (masked) {
                 lds_put_point<6>(region, lane, ep);
                 wave_sync();

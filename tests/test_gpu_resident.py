@@ -473,11 +473,9 @@ def test_split_history_in_place_and_out_of_place_without_mask(law_name):
 
 @pytest.mark.parametrize("kind,split", [("von_mises_3d", True), ("comfe_mises_plasticity", True), ("comfe_mises_plasticity", False)])
 def test_row_masked_access_leaves_identical_bits(kind, split):
-    """Row-masked history access (tiles with at most ``masked_max`` touched rows; VonMises3D moves its rows in aligned
-    64-byte granules, csrc/kernels/history_rows.h: granule_touched -- the chunks filled in next to a touched row carry the
-    values the array holds already) against the dense tile access (``masked_max`` = 0) and the always-masked one (64): the
-    same BITS in every array -- in place (the reference contract) and under the sparse protocol of a resident state, with
-    plastic sets that shrink and grow."""
+    """Row-masked history access (tiles with at most ``masked_max`` touched rows move only the chunks of those rows) against
+    the dense tile access (``masked_max`` = 0) and the always-masked one (64): the same BITS in every array -- in place (the
+    reference contract) and under the sparse protocol of a resident state, with plastic sets that shrink and grow."""
     from fenics_constitutive_amd import _capi
     from test_gpu_parity import make_law, random_case
 

@@ -3,7 +3,7 @@
     python tools/ab_lib.py libA.so libB.so [n ...]
 VonMises3D mixed workload, committed->trial evaluate.  AB_SPARSE=1: sparse trial-history protocol
 (fcamd_evaluate_device_from_sparse, VonMises3D only); AB_ZONED=1: plastic points in contiguous
-4096-point zones instead of a random mixture."""
+4096-point zones instead of a random mixture; AB_SCALE=1e-2 / 1e-4: uniform strain scale (all plastic / all elastic)."""
 import ctypes as C
 import sys
 
@@ -59,6 +59,8 @@ for n in sizes:
     if ZONED:
         pl = torch.rand((n + 4095) // 4096, generator=gen, **f) < 0.22
         g.view(n, 9).mul_(torch.where(pl, 1e-2, 1e-4).to(torch.float64).repeat_interleave(4096)[:n][:, None])
+    elif os.environ.get("AB_SCALE"):  # uniform strain scale: 1e-2 all plastic, 1e-4 all elastic
+        g.mul_(float(os.environ["AB_SCALE"]))
     else:
         g.view(n, 9).mul_(torch.pow(10.0, torch.rand(n, generator=gen, **f) * 2 - 4)[:, None])
     s0, s1 = torch.zeros(6 * n, **f), torch.empty(6 * n, **f)
