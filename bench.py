@@ -963,6 +963,64 @@ def read_traffic(workload_key, n):
     return None
 
 
+def under_profiler():
+    """is THIS process running under rocprofv3 (a nested profiler must not be started)"""
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def live_traffic(name, n, history, extra, budget_s):
+    """HBM bytes per timed launch of this workload, measured NOW as MI355X_MICROARCH.md ("HBM", rocprofv3) prescribes: two
+    child runs of this file (4 timed steps each, first-allocation placement -- the traffic of a launch does not depend on
+    where its arrays lie) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes; no trace domain next
+    to --pmc), the evaluate dispatches of the TIMED phase picked out with the child's own launch_log.  Corrections: both
+    counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide (16 B per lane) streaming read -> x 2.
+    None if rocprofv3 is not there, the budget is short or anything goes wrong (the stored figure is reported then)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None or under_profiler():
+        return None
+    t_end = time.perf_counter() + budget_s
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        left = t_end - time.perf_counter()
+        if left < 25:
+            return None
+        d = tempfile.mkdtemp(prefix="fcamd_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", name, "--points", str(n), "--history", history, "--steps", "4", "--warmup", "2", "--configs", "none",
+                   "--no-host-path", "--no-cpu-baseline", "--placement", "first", "--no-live-traffic"] + list(extra)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=left)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            if r.returncode != 0 or not lines:
+                return None
+            child = json.loads(lines[-1])
+            files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+            if not files:
+                return None
+            with open(files[-1]) as f:
+                rows = [x for x in csv.DictReader(f) if "fcamd::evaluate" in x["Kernel_Name"] and x.get("Counter_Name", counter) == counter]
+            rows.sort(key=lambda x: int(x["Dispatch_Id"]))
+            vals, i, timed = [float(x["Counter_Value"]) for x in rows], 0, []
+            for phase, k in child.get("launch_log", []):
+                if phase == "timed":
+                    timed = vals[i: i + k]
+                i += k
+            if len(timed) != 4 or i > len(vals):
+                return None
+            got[counter] = sum(timed) / len(timed)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    read_b, write_b = 2.0 * 1024.0 * got["FETCH_SIZE"], 1024.0 * got["WRITE_SIZE"]
+    return {"hbm_bytes_per_launch": int(read_b + write_b), "read_bytes": int(read_b), "write_bytes": int(write_b)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1027,6 +1085,9 @@ def main():
                     help="N > 1: weak = --points per GPU (default; a strong-scaling leg on the first points/N of every shard is reported "
                          "next to it under \"strong_scaling\"); strong = --points in total, cut into N contiguous shards")
     ap.add_argument("--no-host-path", action="store_true", help="N = 1 default run: skip the host_path block (PCIe-inclusive figures of the ndarray entries)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: do not measure roofline.traffic in this run (two child passes under rocprofv3 --pmc, about 40 s); the "
+                         "stored figure of profiles/traffic.json is reported instead (labelled as stored)")
     ap.add_argument("--wall-budget", type=float, default=420.0,
                     help="seconds of wall clock after which the optional legs (strong-scaling leg, gather variants, extra configurations, host_path) "
                          "are skipped so that the line is printed inside the driver's limit")
@@ -1463,6 +1524,21 @@ def main():
                 out["host_path"] = host_path_figures(devices=None, sizes=(1_000_000, min(n, 10_000_000)) if n > 1_000_000 else (n,))
             except Exception as e:  # informational: must not lose the line
                 out["host_path"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if world == 1 and not args.no_live_traffic and budget_left() > 100:
+            # roofline.traffic measured in THIS run (the kernels' memory is free by now); the stored figure stays next to it
+            checkpoint("live_traffic")
+            extra = (["--delta-history"] if args.delta_history else []) + (["--no-split-history"] if args.no_split_history else []) \
+                + (["--sparse-tangent"] if args.sparse_tangent else [])
+            torch.cuda.empty_cache()
+            lt = live_traffic(name, n, history, extra, min(120.0, budget_left() - 45.0))
+            if lt is not None:
+                rf = out["roofline"]
+                rf["traffic_stored"] = rf["traffic"]
+                rf["traffic"] = lt["hbm_bytes_per_launch"]
+                rf["traffic_read_write"] = [lt["read_bytes"], lt["write_bytes"]]
+                rf["traffic_GBs"] = round(lt["hbm_bytes_per_launch"] / (kernel_avg_ms * 1e-3) / 1e9, 1)
+                rf["traffic_source"] = ("measured in this run: two child passes of this workload under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                                        "(4 timed launches each; KiB x 1024, FETCH_SIZE x 2 on gfx950); traffic_stored = profiles/traffic.json")
         if world == 1:
             checkpoint("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(*cpu_args) if cpu_args is not None else None

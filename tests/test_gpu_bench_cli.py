@@ -24,9 +24,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_bench(*args, timeout=420, env=None):
+def run_bench(*args, timeout=420, env=None, live_traffic=False):
     e = dict(os.environ, MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     e.update(env or {})
+    if not live_traffic and "--mode" not in args:
+        args = (*args, "--no-live-traffic")  # (two more child processes under rocprofv3 --pmc: one test below runs them)
     r = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) <= 1, r.stdout[-3000:]  # ONE JSON line, whatever happened
@@ -119,9 +121,17 @@ def test_host_mode_two_contexts():
 
 def test_default_line_carries_the_host_path_block():
     """the driver's command shape at a small size: one rank, no launcher, extra configurations off"""
-    r, out = run_bench("--points", "2000000", "--steps", "3", "--warmup", "1", "--configs", "none", "--no-cpu-baseline")
+    r, out = run_bench("--points", "2000000", "--steps", "3", "--warmup", "1", "--configs", "none", "--no-cpu-baseline", live_traffic=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert out["n_gpus"] == 1 and out["scaling"] == "weak"
+    import shutil
+
+    rf = out["roofline"]
+    if shutil.which("rocprofv3"):
+        # roofline.traffic measured in this very run (rocprofv3 --pmc child passes): between the algorithmic bytes and 1.25 x them
+        assert "measured in this run" in rf["traffic_source"], rf.get("traffic_source")
+        assert rf["algorithmic_bytes_per_launch"] * 0.99 <= rf["traffic"] <= rf["algorithmic_bytes_per_launch"] * 1.25, rf
+        assert sum(rf["traffic_read_write"]) == rf["traffic"]
     hp = out["host_path"]
     assert "error" not in hp, hp
     assert set(hp["sizes"]) == {"1000000", "2000000"}
