@@ -994,9 +994,19 @@ def live_traffic(name, n, history, extra, budget_s):
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--workload", name, "--points", str(n), "--history", history, "--steps", "4", "--warmup", "2", "--configs", "none",
                    "--no-host-path", "--no-cpu-baseline", "--placement", "first", "--no-live-traffic"] + list(extra)
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=left)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-            if r.returncode != 0 or not lines:
+            # a process group of its own: on a timeout the whole pass (profiler + the profiled child) is ended, nothing else
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 text=True, start_new_session=True)
+            try:
+                stdout, _ = p.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                os.killpg(p.pid, signal.SIGKILL)
+                p.communicate()
+                return None
+            lines = [ln for ln in stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            if p.returncode != 0 or not lines:
                 return None
             child = json.loads(lines[-1])
             files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
