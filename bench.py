@@ -22,7 +22,9 @@ stress/tangent all-gather of the single-assembler mode (config 5) is timed separ
 shard -- stress in one piece, tangent in chunks that fit next to the working set -- and reported under
 "allgather", never inside `value`.
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `roofline.traffic` (HBM bytes per launch by the PMC counters) is
+measured at the end of an N = 1 run by two child passes of this file under `rocprofv3 --pmc` (--no-live-traffic: the stored
+figure of profiles/traffic.json instead).
 """
 
 from __future__ import annotations
