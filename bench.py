@@ -1551,6 +1551,16 @@ def main():
                 rf["traffic_GBs"] = round(lt["hbm_bytes_per_launch"] / (kernel_avg_ms * 1e-3) / 1e9, 1)
                 rf["traffic_source"] = ("measured in this run: two child passes of this workload under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                                         "(4 timed launches each; KiB x 1024, FETCH_SIZE x 2 on gfx950); traffic_stored = profiles/traffic.json")
+                # ... and the other configurations of the line, the same way, while the budget lasts
+                for cname, c in (out.get("configs") or {}).items():
+                    if "kernel_ms_avg" not in c or budget_left() < 110:
+                        continue
+                    checkpoint(f"live_traffic: {cname}")
+                    lc = live_traffic(cname, n, history, extra, min(60.0, budget_left() - 60.0))
+                    if lc is not None:
+                        c["traffic_stored"], c["traffic"] = c.get("traffic"), lc["hbm_bytes_per_launch"]
+                        c["traffic_source"] = "measured in this run (rocprofv3 --pmc child passes, as roofline.traffic)"
+                        c["traffic_over_algorithmic"] = round(lc["hbm_bytes_per_launch"] / c["algorithmic_bytes_per_launch"], 4)
         if world == 1:
             checkpoint("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(*cpu_args) if cpu_args is not None else None
