@@ -93,13 +93,13 @@ def test_a_hung_gather_leg_is_a_failed_run():
     assert "did not finish" in out["allgather"]["error"]
 
 
-@pytest.mark.parametrize("leg,gpus", [("host_path_multi", 2), ("allgather", 2), ("host_path", 1)])
+@pytest.mark.parametrize("leg,gpus", [("host_path_multi", 2), ("allgather", 2), ("host_path", 1), ("live_traffic", 1)])
 def test_the_line_survives_the_death_of_rank0_in_an_optional_leg(leg, gpus):
     """rank 0 is killed (SIGKILL, fault injection) when it enters an optional leg: the measured line still comes out, once,
     marked incomplete, and the job fails"""
     extra = ["--backend", "gloo"] if gpus > 1 else []
     r, out = run_bench("--gpus", str(gpus), *extra, "--points", "1000000", "--steps", "2", "--warmup", "1", "--configs", "none",
-                       "--no-cpu-baseline", "--placement", "first", env={"BENCH_DIE_IN": leg})
+                       "--no-cpu-baseline", "--placement", "first", env={"BENCH_DIE_IN": leg}, live_traffic=leg == "live_traffic")
     assert r.returncode != 0
     assert out is not None and out["n_gpus"] == gpus and out["value"] > 0 and out["roofline"]["frac"] > 0
     assert leg in out["incomplete"] and leg not in out
