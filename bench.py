@@ -1468,8 +1468,11 @@ def main():
                 configs[cname] = {"skipped": "wall budget"}
                 continue
             try:
+                # (under rocprofv3 released VMM memory stays alive: five more working sets would not fit -- hipMalloc candidates only)
                 configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
-                                            min(tries, 4), history=history, placement=args.placement, cpu=not args.no_cpu_baseline,
+                                            min(tries, 4), history=history,
+                                            placement="tune" if (args.placement == "auto" and under_profiler()) else args.placement,
+                                            cpu=not args.no_cpu_baseline,
                                             delta_history=args.delta_history)
             except Exception as e:  # one configuration failing must not lose the line
                 configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
