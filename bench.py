@@ -206,7 +206,7 @@ class Workload:
     """One law on n synthetic device-resident points: the committed state, two Newton iterates of the
     gradient, the trial arrays, and the launch every timed step issues."""
 
-    def __init__(self, name, n, seed, device, dev_index, history="sparse", sparse_tangent=False, grid=0, delta_history=False,
+    def __init__(self, name, n, seed, device, dev_index, history="packed", sparse_tangent=False, grid=0, delta_history=False,
                  split_history=True):
         import torch
 
@@ -235,7 +235,7 @@ class Workload:
         if grid:
             self.law._handle(dev_index).ctx.set_grid(grid)
         self.plasticity = self.kind in PLASTICITY
-        self.sparse = self.plasticity and history == "sparse"
+        self.sparse = self.plasticity and history in ("sparse", "packed")
         self.sparse_tangent = bool(sparse_tangent and self.sparse)
         # VonMises3D under the sparse protocol: ResidentState keeps the INCREMENT of eps_n in the trial array during the
         # Newton iterations (FCAMD_EVAL_DELTA_HISTORY) and adds it to the committed array at the commit.  That moves a
@@ -251,6 +251,18 @@ class Workload:
 
             self.hist_c = split_history_rows(self.hist_c["history"])
             self.hist_t = {k: torch.empty_like(v) for k, v in self.hist_c.items()}
+        # Packed plastic-strain history (FCAMD_EVAL_PACKED_HISTORY; ResidentState's default layout of the array that only
+        # accumulates): committed and trial copy hold the rows of the ever-plastic points of every tile as one contiguous run,
+        # one EVER-mask word per tile next to each; the commit stays a pointer swap.  Same values, same launch, same bytes
+        # asked of the interface -- only the rows move as full lines instead of isolated 48-byte pieces.
+        self.packed = bool(self.sparse and history == "packed" and self.delta_key is not None and not self.delta)
+        self.ever_c = self.ever_t = None
+        self._plain = None  # unpacked twin of the history arrays for the legs that run another protocol (full / delta)
+        if self.packed:
+            from fenics_constitutive_amd.device import pack_rows
+
+            self.hist_c[self.delta_key], self.ever_c = pack_rows(self.hist_c[self.delta_key])
+            self.ever_t = self.ever_c.clone()
         self.hmask = None
         if self.sparse:
             for k in self.hist_c:
@@ -260,30 +272,56 @@ class Workload:
         self._vmm, self.vmm_info = None, None
         self.n_pl_ab, self.its_ab = [0, 0], [0, 0]
 
-    def launch(self, i, tangent=None, full_history=False, sparse_tangent=None, delta_history=None, m=None):
+    def launch(self, i, tangent=None, full_history=False, sparse_tangent=None, delta_history=None, m=None, unpacked=False):
         """`m`: evaluate the first m points of the arrays only (the strong-scaling leg of a weak-scaling run)"""
         delta = self.delta if delta_history is None else delta_history
         tan = self.tangent if tangent is None else tangent
+        packed = self.packed and not full_history and not delta and not unpacked
+        hist_c, hist_t, hmask = self.hist_c, self.hist_t, self.hmask
+        if self.packed and not packed:  # another protocol on this workload: it needs the plain layout of the same state
+            hist_c, hist_t, hmask = self.plain_twin()
+        pm = None
         if m is None:
-            g, sc, st, hc, ht, mask = self.grads[i & 1], self.stress_c, self.stress_t, self.hist_c, self.hist_t, self.hmask
+            g, sc, st, hc, ht, mask = self.grads[i & 1], self.stress_c, self.stress_t, hist_c, hist_t, hmask
+            if packed:
+                pm = (self.ever_c, self.ever_t)
         else:
             dims = {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7, "scalar": 1, "rows": 6}
             g, sc, st, tan = self.grads[i & 1][: 9 * m], self.stress_c[: 6 * m], self.stress_t[: 6 * m], tan[: 36 * m]
-            hc = None if self.hist_c is None else {k: v[: dims[k] * m] for k, v in self.hist_c.items()}
-            ht = None if self.hist_t is None else {k: v[: dims[k] * m] for k, v in self.hist_t.items()}
-            mask = None if self.hmask is None else self.hmask[: (m + 63) // 64]
+            hc = None if hist_c is None else {k: v[: dims[k] * m] for k, v in hist_c.items()}
+            ht = None if hist_t is None else {k: v[: dims[k] * m] for k, v in hist_t.items()}
+            mask = None if hmask is None else hmask[: (m + 63) // 64]
+            if packed:
+                pm = (self.ever_c[: (m + 63) // 64], self.ever_t[: (m + 63) // 64])
         self.law.evaluate_from(0.0, self.del_t, g, sc, st, tan, hc, ht,
                                history_mask=None if full_history else mask,
                                sparse_tangent=self.sparse_tangent if sparse_tangent is None else sparse_tangent,
-                               delta_history=bool(delta and not full_history), split_history=self.split)
+                               delta_history=bool(delta and not full_history), split_history=self.split, packed_masks=pm)
+
+    def plain_twin(self):
+        """(committed history, trial history, mask) of this packed workload in the PLAIN layout -- built on first use, for the
+        legs that time another protocol on the same state (full trial history, delta trial history)"""
+        if self._plain is None:
+            from fenics_constitutive_amd.device import unpack_rows
+
+            hc = dict(self.hist_c)
+            hc[self.delta_key] = unpack_rows(self.hist_c[self.delta_key], self.ever_c, self.n)
+            ht = {k: v.clone() for k, v in hc.items()}
+            self._plain = (hc, ht, self.torch.zeros_like(self.hmask))
+        return self._plain
+
+    def drop_plain_twin(self):
+        self._plain = None
+        self.torch.cuda.empty_cache()
 
     def reference_history(self):
-        """the committed history in the reference's layout (the split layout joined back into 7-double rows)"""
+        """the committed history in the reference's layout (packed rows unpacked, the split layout joined back into 7-double rows)"""
+        hist_c = self.plain_twin()[0] if self.packed else self.hist_c
         if not self.split:
-            return self.hist_c
+            return hist_c
         from fenics_constitutive_amd.device import join_history_rows
 
-        return {"history": join_history_rows(self.hist_c)}
+        return {"history": join_history_rows(hist_c)}
 
     def time_delta_protocol(self, launches=6):
         """ResidentState's delta trial history on this workload: the evaluate launches with the flag (two alternating
@@ -295,7 +333,8 @@ class Workload:
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
         for a, b in ev:  # the commit is idempotent in cost (same mask every time); its effect on eps_n does not matter any more
             a.record()
-            self.law.commit_delta_history(self.hist_c[self.delta_key], self.hist_t[self.delta_key], self.hmask)
+            hc, ht, hm = self.plain_twin() if self.packed else (self.hist_c, self.hist_t, self.hmask)
+            self.law.commit_delta_history(hc[self.delta_key], ht[self.delta_key], hm)
             b.record()
         torch.cuda.synchronize()
         return sum(ms) / len(ms), min(a.elapsed_time(b) for a, b in ev[1:])
@@ -443,14 +482,21 @@ class Workload:
         return (f"{self.name}: {self.kind} FULL-3D, {self.n} quadrature points per GPU, device-resident AoS, "
                 f"committed->trial evaluate of two alternating Newton iterates"
                 f"{', sparse trial history (ResidentState protocol)' if self.sparse else (', full trial history' if self.plasticity else '')}"
+                f"{', plastic-strain rows of both state copies packed per tile (ResidentState default; commit = pointer swap)' if self.packed else ''}"
                 f"{', eps_n kept as increment during the iterations (delta trial history)' if self.delta else ''}"
                 f"{', history kept as [scalar, eps_p rows] in the state (split history)' if self.split else ''}"
                 f"{', sparse tangent (rows of points that stay elastic are not rewritten)' if self.sparse_tangent else ''}")
 
     def free(self):
-        for k in ("grads", "stress_c", "stress_t", "hist_c", "hist_t", "tangent", "hmask", "_vmm"):
+        for k in ("grads", "stress_c", "stress_t", "hist_c", "hist_t", "tangent", "hmask", "_vmm", "_plain", "ever_c", "ever_t"):
             setattr(self, k, None)  # a VMM working set is released with its last view
         self.torch.cuda.empty_cache()
+
+
+def traffic_key(wl):
+    """key of a workload's PMC measurement in profiles/traffic.json: the packed layout is the default of every law that has it"""
+    unpacked = wl.sparse and wl.delta_key is not None and not wl.packed and not wl.delta
+    return wl.name + ("_full" if wl.plasticity and not wl.sparse else "") + ("_delta" if wl.delta else "") + ("_unpacked" if unpacked else "")
 
 
 def placement_fracs(wl, alg0):
@@ -468,7 +514,7 @@ def placement_fracs(wl, alg0):
     return out
 
 
-def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="sparse", placement="auto", cpu=True, delta_history=False):
+def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="packed", placement="auto", cpu=True, delta_history=False):
     """One extra configuration, same method as the headline: placement, warm up, count, >= 5 event-timed launches."""
     wl = Workload(name, n, seed, device, dev_index, history=history, delta_history=delta_history)
     try:
@@ -490,7 +536,7 @@ def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="
         if wl.placement:
             out["placement_candidate_ms"] = wl.placement["candidate_ms"]
         # PMC-measured HBM bytes of this configuration's launch (profiles/traffic.json: its own rocprofv3 passes, same kernels)
-        key = name + ("_full" if wl.plasticity and not wl.sparse else "") + ("_delta" if wl.delta else "")
+        key = traffic_key(wl)
         out["traffic"] = read_traffic(key, n)
         out["traffic_source"] = None if not out["traffic"] else f"profiles/traffic.json[{key}] (stored rocprofv3 --pmc measurement of these kernels)"
         out["traffic_over_algorithmic"] = None if not out["traffic"] else round(out["traffic"] / alg, 4)
@@ -1048,11 +1094,13 @@ def main():
                          "--mode host: 1e7 (the arrays are host memory: 568 B per point)")
     ap.add_argument("--grid", type=int, default=0, help="override the launch grid (workgroups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--history", choices=["sparse", "full"], default="sparse",
-                    help="plasticity laws: how the trial history is written.  sparse (default) = the protocol of the "
-                         "product's device-resident Newton loop (ResidentState, fcamd_evaluate_device_from_sparse): trial "
-                         "== committed except at plastic / formerly plastic points, so elastic points cost no history "
-                         "traffic; full = every launch rewrites the whole trial history (fcamd_evaluate_device_from)")
+    ap.add_argument("--history", choices=["packed", "sparse", "full"], default="packed",
+                    help="plasticity laws: how the trial history is written.  packed (default) = the protocol of the "
+                         "product's device-resident Newton loop (ResidentState): trial == committed except at plastic / "
+                         "formerly plastic points, so elastic points cost no history traffic, and both copies of the "
+                         "plastic-strain array keep the rows of the ever-plastic points packed per tile (FCAMD_EVAL_PACKED_HISTORY; "
+                         "the commit stays a pointer swap); sparse = the same protocol on the reference's array layout "
+                         "(ResidentState(packed_history=False)); full = every launch rewrites the whole trial history")
     ap.add_argument("--sparse-history", action="store_true", help="same as --history sparse (kept for old command lines)")
     ap.add_argument("--delta-history", action="store_true",
                     help="VonMises3D, --history sparse: run the TIMED steps with ResidentState's delta trial history (the trial eps_n "
@@ -1258,6 +1306,14 @@ def main():
         ms = wl.timed_events(6, phase="full_trial_history", full_history=True, sparse_tangent=False)
         full_ms = sum(ms[1:]) / (len(ms) - 1)
 
+    # ... the sparse protocol on the reference's array layout (ResidentState(packed_history=False); the headline of rounds 1-3)
+    unpacked_ms = None
+    if wl.packed:
+        wl.launch(0, unpacked=True), wl.launch(1, unpacked=True)
+        wl.launch_log.append(["sparse_unpacked_history_warm", 2])
+        ms = wl.timed_events(6, phase="sparse_unpacked_history", unpacked=True, sparse_tangent=False)
+        unpacked_ms = sum(ms) / len(ms)
+
     # ... and ResidentState's delta trial history (VonMises3D): evaluate launches with the flag + the commit kernel
     delta_fig = None
     if wl.sparse and wl.delta_key is not None and not wl.delta:
@@ -1320,7 +1376,8 @@ def main():
                                                     for k, v in wl.reference_history().items()}, wl.del_t)
     headline = {"placement": wl.placement, "vmm_info": wl.vmm_info, "launch_log": list(wl.launch_log), "config_text": wl.config_text(), "kind": wl.kind,
                 "b_el": wl.b_el, "b_pl": wl.b_pl, "alg": wl.alg_bytes(n_pl), "alg0": wl.alg_bytes(wl.n_pl_ab[0]),
-                "fracs": placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])), "sparse": wl.sparse, "plasticity": wl.plasticity}
+                "fracs": placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])), "sparse": wl.sparse, "plasticity": wl.plasticity,
+                "tkey": traffic_key(wl), "packed": wl.packed}
 
     out = None
     if rank == 0:  # the line is complete up to here; what follows only adds to it
@@ -1328,7 +1385,7 @@ def main():
         value = total_pts / elapsed / 1e6
         alg_bytes = headline["alg"]
         achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9
-        tkey = name + ("_full" if headline["plasticity"] and not headline["sparse"] else "") + ("_delta" if wl.delta else "")
+        tkey = headline["tkey"]
         traffic = read_traffic(tkey, n)
         # what this box's memory allows for THIS kernel's measured mix of reads and writes: read bytes at the pure-read rate
         # plus written bytes at the pure-write rate, both measured above on the same array
@@ -1387,6 +1444,11 @@ def main():
             out["full_trial_history"] = {"kernel_ms_avg": round(full_ms, 4),
                                          "frac": round(alg_bytes / (full_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          "note": "same step, whole trial history rewritten by every launch (--history full)"}
+        if unpacked_ms is not None:
+            out["sparse_unpacked_history"] = {"kernel_ms_avg": round(unpacked_ms, 4),
+                                              "frac": round(alg_bytes / (unpacked_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                              "note": "same step, same sparse protocol, plastic-strain arrays in the reference's layout "
+                                                      "(--history sparse; isolated 48-byte rows instead of one run per tile)"}
         if delta_fig is not None:
             d_ms, c_ms = delta_fig
             saved = kernel_avg_ms - d_ms

@@ -29,6 +29,7 @@ COUNTER_SLOTS, COUNTER_WORDS = 64, 256  # FCAMD_COUNTER_SLOTS / FCAMD_COUNTER_WO
 EVAL_SPARSE_TANGENT = 1
 EVAL_DELTA_HISTORY = 2
 EVAL_SPLIT_HISTORY = 4
+EVAL_PACKED_HISTORY = 8
 
 # fcamd_context_last_host_mode flags (include/fcamd.h)
 HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT, HOST_TEMP_LOCK, HOST_BOUNCE = 1, 2, 4, 8
@@ -73,7 +74,7 @@ class EvalArgs(C.Structure):
     _fields_ = [("grad_del_u", C.c_void_p), ("stress_prev", C.c_void_p), ("stress", C.c_void_p),
                 ("tangent", C.c_void_p), ("history_prev", C.POINTER(C.c_void_p)), ("history", C.POINTER(C.c_void_p)),
                 ("n_hist", C.c_int), ("parent_rows", C.c_void_p), ("history_mask", C.c_void_p), ("flags", C.c_int), ("stress2", C.c_void_p),
-                ("counters", C.c_void_p)]
+                ("counters", C.c_void_p), ("packed_mask_prev", C.c_void_p), ("packed_mask", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -169,8 +170,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_commit_delta_history.argtypes = [vp, C.c_int64, vp, vp, vp]
         lib.fcamd_evaluate_device_wrapped.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp,
                                                       C.POINTER(vp), C.c_int]
-        lib.fcamd_evaluate_resident.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.POINTER(vp),
-                                                C.c_int, vp, C.c_int, vp, vp, C.POINTER(Stats)]
+        lib.fcamd_evaluate_resident.argtypes = [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs), vp, vp, C.POINTER(Stats)]
         lib.fcamd_strain_from_grad_u_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int]
         lib.fcamd_convert_device.argtypes = [vp, C.c_int, C.c_int64, vp, vp]
         lib.fcamd_map_rows_device.argtypes = [vp, C.c_int64, C.c_int, vp, vp, vp, vp]
@@ -621,11 +621,12 @@ class Model:
 
     def evaluate_device_ex(self, t, del_t, n, grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr, hist_prev_ptrs,
                            hist_ptrs, rows_ptr=None, mask_ptr=None, flags: int = 0, stress2_ptr=None,
-                           counters_ptr=None) -> None:
+                           counters_ptr=None, packed_mask_ptrs=None) -> None:
         arr, nh = self._ptr_array(hist_ptrs)
         parr, _ = self._ptr_array(hist_prev_ptrs)
+        pm_prev, pm = packed_mask_ptrs or (None, None)
         x = EvalArgs(grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr or None, parr, arr, nh, rows_ptr or None,
-                     mask_ptr or None, int(flags), stress2_ptr or None, counters_ptr or None)
+                     mask_ptr or None, int(flags), stress2_ptr or None, counters_ptr or None, pm_prev or None, pm or None)
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
 
     def commit_delta_history(self, n, committed_ptr, delta_ptr, mask_ptr) -> None:
@@ -640,14 +641,15 @@ class Model:
             C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), C.c_void_p(stress3d_ptr), arr, nh))
 
     def evaluate_resident(self, t, del_t, n, grad_host_ptr, stress_prev_ptr, stress_ptr, hist_prev_ptrs, hist_ptrs,
-                          mask_ptr, stress_host_ptr, tangent_host_ptr, flags: int = 0) -> Stats:
+                          mask_ptr, stress_host_ptr, tangent_host_ptr, flags: int = 0, packed_mask_ptrs=None) -> Stats:
         arr, nh = self._ptr_array(hist_ptrs)
         parr, _ = self._ptr_array(hist_prev_ptrs)
+        pm_prev, pm = packed_mask_ptrs or (None, None)
+        x = EvalArgs(grad_host_ptr, stress_prev_ptr, stress_ptr, None, parr, arr, nh, None, mask_ptr or None, int(flags), None, None,
+                     pm_prev or None, pm or None)
         st = Stats()
-        status = self._lib.fcamd_evaluate_resident(self.handle, float(t), float(del_t), int(n), C.c_void_p(grad_host_ptr),
-                                                   C.c_void_p(stress_prev_ptr), C.c_void_p(stress_ptr), parr, arr, nh,
-                                                   C.c_void_p(mask_ptr or 0), int(flags), C.c_void_p(stress_host_ptr or 0),
-                                                   C.c_void_p(tangent_host_ptr or 0), C.byref(st))
+        status = self._lib.fcamd_evaluate_resident(self.handle, float(t), float(del_t), int(n), C.byref(x),
+                                                   C.c_void_p(stress_host_ptr or 0), C.c_void_p(tangent_host_ptr or 0), C.byref(st))
         check(status)
         return st
 

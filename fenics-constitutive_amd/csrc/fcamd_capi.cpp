@@ -378,7 +378,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
             double* stress, double* tangent, const double* const* hprev, double* const* hcur,
             hipStream_t stream, bool reset_counters, const int* rows,
             unsigned long long* hmask, int flags, double* stress2,
-            unsigned long long* counters) {
+            unsigned long long* counters, const unsigned long long* emask_prev, unsigned long long* emask) {
     EvalArgs a;
     a.grad = grad;
     a.stress_in = stress_prev;
@@ -398,7 +398,11 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     if (hmask) {
         if (tangent) a.flags |= flags & FCAMD_EVAL_SPARSE_TANGENT;  // needs an array that holds the previous tangent
         if (m->law == FCAMD_VON_MISES_3D || split) a.flags |= flags & FCAMD_EVAL_DELTA_HISTORY;  // needs plastic-strain rows of their own
+        if ((m->law == FCAMD_VON_MISES_3D || split) && emask_prev && emask && !rows) a.flags |= flags & FCAMD_EVAL_PACKED_HISTORY;
+        if (a.flags & FCAMD_EVAL_PACKED_HISTORY) a.flags &= ~FCAMD_EVAL_DELTA_HISTORY;  // the packed layout replaces it
     }
+    a.emask_in = emask_prev;
+    a.emask_out = emask;
     a.n = n;
     a.counters = counters ? counters : m->d_counters;  // caller-owned counters are always reset here
     const Options& o = m->ctx->opt;
@@ -789,6 +793,20 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
         if (x->history && x->history_prev && x->history[kd] == x->history_prev[kd])
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial plastic-strain array of its own");
     }
+    if (x->flags & FCAMD_EVAL_PACKED_HISTORY) {
+        const bool split = (x->flags & FCAMD_EVAL_SPLIT_HISTORY) != 0 && has_split_history(m->law);
+        if (m->law != FCAMD_VON_MISES_3D && !split)
+            return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_PACKED_HISTORY exists for VonMises3D and, with FCAMD_EVAL_SPLIT_HISTORY, for the "
+                                               "comfe-rs plasticity laws");
+        if (!x->history_mask || !x->packed_mask_prev || !x->packed_mask)
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs history_mask, packed_mask_prev and packed_mask");
+        if (x->parent_rows) return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_PACKED_HISTORY: not with parent_rows");
+        if (x->flags & FCAMD_EVAL_DELTA_HISTORY)
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY and FCAMD_EVAL_DELTA_HISTORY exclude each other");
+        const int kd = split ? 1 : 0;
+        if (x->history[kd] == x->history_prev[kd] || x->packed_mask == x->packed_mask_prev)
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs trial plastic-strain and mask arrays of their own");
+    }
     if (!aligned16(x->grad_del_u) || !aligned16(x->stress) || !aligned16(x->stress_prev) || !aligned16(x->tangent))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
     for (int k = 0; k < x->n_hist; ++k)
@@ -805,7 +823,9 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     if ((st = timing_begin(m)) != FCAMD_OK) return st;
     st = enqueue(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history,
                  c->stream, !m->timed, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask), x->flags,
-                 x->stress2, reinterpret_cast<unsigned long long*>(x->counters));
+                 x->stress2, reinterpret_cast<unsigned long long*>(x->counters),
+                 (x->flags & FCAMD_EVAL_PACKED_HISTORY) ? reinterpret_cast<const unsigned long long*>(x->packed_mask_prev) : nullptr,
+                 (x->flags & FCAMD_EVAL_PACKED_HISTORY) ? reinterpret_cast<unsigned long long*>(x->packed_mask) : nullptr);
     if (st != FCAMD_OK) return st;
     return timing_end(m);
 }

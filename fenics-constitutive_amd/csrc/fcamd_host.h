@@ -143,7 +143,8 @@ int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* gra
 int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev, double* stress,
             double* tangent, const double* const* hprev, double* const* hcur, hipStream_t stream, bool reset_counters,
             const int* rows = nullptr, unsigned long long* hmask = nullptr, int flags = 0, double* stress2 = nullptr,
-            unsigned long long* counters = nullptr);
+            unsigned long long* counters = nullptr, const unsigned long long* emask_prev = nullptr,
+            unsigned long long* emask = nullptr);
 
 // download and sum the model's counters (synchronises `stream`); the two halves for callers that have a
 // synchronisation of their own coming: enqueue the 2 KB download behind the launches, sum after the wait

@@ -633,11 +633,22 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     return finish_chunks(m, stats);
 }
 
-int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
-                            const double* stress_prev, double* stress, const double* const* hist_prev,
-                            double* const* hist, int n_hist, uint64_t* history_mask, int flags,
+int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, const fcamd_eval_args* x,
                             double* stress_host, double* tangent_host, fcamd_stats* stats) {
     (void)t;
+    if (!x) return fail(FCAMD_ERR_BAD_ARG, "state is NULL");
+    if (x->parent_rows || x->stress2 || x->tangent)
+        return fail(FCAMD_ERR_UNSUPPORTED, "fcamd_evaluate_resident: parent_rows / stress2 / a device tangent are options of fcamd_evaluate_device_ex");
+    const double* grad = x->grad_del_u;  // HOST array
+    const double* stress_prev = x->stress_prev;
+    double* stress = x->stress;
+    const double* const* hist_prev = x->history_prev;
+    double* const* hist = x->history;
+    const int n_hist = x->n_hist, flags = x->flags;
+    uint64_t* history_mask = x->history_mask;
+    const bool packed = (flags & FCAMD_EVAL_PACKED_HISTORY) != 0;
+    const unsigned long long* emask_prev = packed ? reinterpret_cast<const unsigned long long*>(x->packed_mask_prev) : nullptr;
+    unsigned long long* emask = packed ? reinterpret_cast<unsigned long long*>(x->packed_mask) : nullptr;
     int st = validate_call(m, del_t, n, grad, stress_prev, stress,
                            reinterpret_cast<const void* const*>(hist_prev),
                            reinterpret_cast<const void* const*>(hist), n_hist, flags);
@@ -651,6 +662,17 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         const int kd = (flags & FCAMD_EVAL_SPLIT_HISTORY) ? 1 : 0;  // the array that accumulates plastic strain
         if (hist && hist_prev && hist[kd] == hist_prev[kd])
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial plastic-strain array of its own");
+    }
+    if (packed) {  // as fcamd_evaluate_device_ex
+        if (!history_mask || !emask_prev || !emask || emask == emask_prev)
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs history_mask and two mask arrays, packed_mask_prev and packed_mask");
+        if (m->law != FCAMD_VON_MISES_3D && !((flags & FCAMD_EVAL_SPLIT_HISTORY) && has_split_history(m->law)))
+            return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_PACKED_HISTORY: VonMises3D, or a comfe-rs plasticity law with FCAMD_EVAL_SPLIT_HISTORY");
+        if (flags & FCAMD_EVAL_DELTA_HISTORY)
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY and FCAMD_EVAL_DELTA_HISTORY exclude each other");
+        const int kd = (flags & FCAMD_EVAL_SPLIT_HISTORY) ? 1 : 0;
+        if (hist && hist_prev && hist[kd] == hist_prev[kd])
+            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs a trial plastic-strain array of its own");
     }
     if (!aligned16(stress) || !aligned16(stress_prev))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
@@ -717,7 +739,8 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
             st = enqueue(m, del_t, (int64_t)np, reinterpret_cast<const double*>(c->bounce_dev + o_grad), stress_prev + SD * p0,
                          stress + SD * p0, tangent_host ? reinterpret_cast<double*>(c->bounce_dev + o_tan) : nullptr, hp, hc, s, false,
                          nullptr, history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
-                         flags & ~FCAMD_EVAL_SPARSE_TANGENT, second_store ? reinterpret_cast<double*>(c->bounce_dev + o_stress) : nullptr);
+                         flags & ~FCAMD_EVAL_SPARSE_TANGENT, second_store ? reinterpret_cast<double*>(c->bounce_dev + o_stress) : nullptr,
+                         nullptr, emask_prev ? emask_prev + p0 / 64 : nullptr, emask ? emask + p0 / 64 : nullptr);
             if (st != FCAMD_OK) return drain_and_return(c, st);
             if (stress_host && !second_store)
                 HIP_TRY_DRAIN(c, hipMemcpyAsync(c->bounce + o_stress, stress + SD * p0, np * SD * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -742,7 +765,7 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         hipStream_t s = c->hstream[0];
         if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         st = enqueue(m, del_t, n, z_grad, stress_prev, stress, z_tan, hist_prev, hist, s, false, nullptr,
-                     reinterpret_cast<unsigned long long*>(history_mask), flags, z_stress);
+                     reinterpret_cast<unsigned long long*>(history_mask), flags, z_stress, nullptr, emask_prev, emask);
         if (st != FCAMD_OK) return drain_and_return(c, st);
         return finish_single_stream(m, stats);
     }
@@ -775,7 +798,8 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         st = enqueue(m, del_t, np, k_grad, stress_prev + SD * p0, stress + SD * p0, k_tan,
                      hp, hc, s, false, nullptr,
                      history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
-                     z_tan ? flags : (flags & ~FCAMD_EVAL_SPARSE_TANGENT));  // the staging buffer of a chunk holds no previous tangent: full rows
+                     z_tan ? flags : (flags & ~FCAMD_EVAL_SPARSE_TANGENT),  // the staging buffer of a chunk holds no previous tangent: full rows
+                     nullptr, nullptr, emask_prev ? emask_prev + p0 / 64 : nullptr, emask ? emask + p0 / 64 : nullptr);
         if (st != FCAMD_OK) return drain_and_return(c, st);
         if (stress_host)
             HIP_TRY_DRAIN(c, hipMemcpyAsync(stress_host + SD * p0, stress + SD * p0, (size_t)np * SD * sizeof(double),

@@ -46,6 +46,8 @@ struct EvalArgs {
     const double* h1_in;       // second history field or nullptr
     double* h1_out;
     unsigned long long* hmask; // nullptr, or sparse-trial-history mask, one word per 64-point tile (VonMises3D)
+    const unsigned long long* emask_in;  // packed plastic-strain history (flags bit 3): EVER mask of the committed array, one word per tile
+    unsigned long long* emask_out;       // ... of the trial array (written for touched tiles)
     const int* rows;           // nullptr, or parent row of every point: stress/tangent are parent arrays
     double* cache3d;           // fused 3D->1D/2D wrappers only: the wrapper's cached 3-D stress [6n], in place
     long long n;               // quadrature points
@@ -53,7 +55,7 @@ struct EvalArgs {
     int tile_map;              // 0: tiles dealt round-robin to all waves; 1: one contiguous region per XCD
     int nontemporal;           // main kernel of the plain (non-indexed, non-sparse) form: non-temporal global accesses (default) or plain ones
     int masked_max;            // row-masked history access for tiles with at most this many touched rows (else dense)
-    int flags;                 // bit 0: sparse-tangent protocol (fcamd_kernels.hip: sparse_tangent_need); bit 1: delta trial history
+    int flags;                 // bit 0: sparse-tangent protocol (fcamd_kernels.hip: sparse_tangent_need); bit 1: delta trial history; bit 2: split history; bit 3: packed plastic-strain history
     Scalars sc;
     Tables tb;
 };

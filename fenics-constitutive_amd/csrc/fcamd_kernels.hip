@@ -48,7 +48,7 @@ namespace fcamd {
 // ---------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------
-template <int LAW, bool IDX, bool FULL, bool NT, bool SPARSE = false>
+template <int LAW, bool IDX, bool FULL, bool NT, int SPARSE = 0>
 __device__ __forceinline__ void run_tile(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                          int* rows_lds, long long p0, int npts, int lane, int r0,
                                          WaveStats& st) {
@@ -80,7 +80,7 @@ __device__ __forceinline__ void run_tile(const EvalArgs& a, const StressBases& s
 // One full tile of the main kernel.  Indexed kernel: when the 64 parent rows of the tile are
 // consecutive (cells of a material are mostly numbered in runs) the coalesced tile body runs on
 // shifted base pointers; only tiles with scattered rows pay the per-lane row accesses.
-template <int LAW, bool IDX, bool NT, bool SPARSE>
+template <int LAW, bool IDX, bool NT, int SPARSE>
 __device__ __forceinline__ void run_full_tile(const EvalArgs& a, const Tables* T, double* region,
                                               int* rows_lds, long long p0, int lane, int r0, WaveStats& st) {
     const StressBases sb{a.stress_in, a.stress_out, a.tangent, a.stress_out2};
@@ -128,8 +128,14 @@ __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& 
 
 // Main kernel: all full 64-point tiles.  Persistent: wave w of the grid takes tiles
 // w, w + W, w + 2W, ...
-template <int LAW, bool NT, bool IDX, bool SPARSE = false>
-__global__ void __launch_bounds__(kBlock, (LAW >= LAW_COMFE_DP ? 3 : 4)) evaluate_kernel(const EvalArgs a) {
+// SPARSE (VonMises3D): 0 plain, 1 sparse trial history, 2 sparse on the packed plastic-strain layout (tile_von_mises: HIST)
+// Waves per SIMD the register budget is cut for: 4 (128 VGPRs), 3 for the Drucker-Prager laws (their return mapping) and for
+// the indexed Maxwell kernel (four loaded arrays plus the per-chunk row look-ups of its tangent spilled 5 VGPRs at 128).
+template <int LAW, bool IDX>
+constexpr int kMinBlocks = (LAW >= LAW_COMFE_DP || (LAW == LAW_MAXWELL && IDX)) ? 3 : 4;
+
+template <int LAW, bool NT, bool IDX, int SPARSE = 0>
+__global__ void __launch_bounds__(kBlock, (kMinBlocks<LAW, IDX>)) evaluate_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     __shared__ int rows_all[IDX ? kWavesPerBlock : 1][kWave];
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(kWave) evaluate_wrapped_tail_kernel(const Eval
 }
 
 // Tail kernel: the last, ragged tile (n % 64 points), one wavefront, guarded 8-byte accesses.
-template <int LAW, bool IDX, bool SPARSE = false>
+template <int LAW, bool IDX, int SPARSE = 0>
 __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
@@ -259,16 +265,23 @@ static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream)
     if constexpr (LAW == LAW_VM3D) {
         if (args.hmask && args.rows) {  // sparse trial history on a submesh (history is local, stress/tangent indexed)
             if (args.n >= kWave)
-                hipLaunchKernelGGL((evaluate_kernel<LAW, true, true, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+                hipLaunchKernelGGL((evaluate_kernel<LAW, true, true, 1>), dim3(grid), dim3(kBlock), 0, stream, args);
             if (args.n % kWave != 0)
-                hipLaunchKernelGGL((evaluate_tail_kernel<LAW, true, true>), dim3(1), dim3(kWave), 0, stream, args);
+                hipLaunchKernelGGL((evaluate_tail_kernel<LAW, true, 1>), dim3(1), dim3(kWave), 0, stream, args);
+            return hipGetLastError();
+        }
+        if (args.hmask && (args.flags & kFlagPackedHistory)) {  // sparse protocol on the packed plastic-strain layout
+            if (args.n >= kWave)
+                hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, 2>), dim3(grid), dim3(kBlock), 0, stream, args);
+            if (args.n % kWave != 0)
+                hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false, 2>), dim3(1), dim3(kWave), 0, stream, args);
             return hipGetLastError();
         }
         if (args.hmask) {  // sparse trial history
             if (args.n >= kWave)
-                hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+                hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, 1>), dim3(grid), dim3(kBlock), 0, stream, args);
             if (args.n % kWave != 0)
-                hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false, true>), dim3(1), dim3(kWave), 0, stream, args);
+                hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false, 1>), dim3(1), dim3(kWave), 0, stream, args);
             return hipGetLastError();
         }
     }

@@ -625,9 +625,16 @@ int fcamd_multi_state_evaluate(fcamd_multi_state* st, double t, double del_t, co
         const double* hp[FCAMD_MAX_HISTORY] = {sl.hist[c][0], sl.hist[c][1]};
         double* hc[FCAMD_MAX_HISTORY] = {sl.hist[1 - c][0], sl.hist[1 - c][1]};
         const size_t lo = (size_t)sl.lo;
-        const int s = fcamd_evaluate_resident(w->model, t, del_t, nk, grad + GD2 * lo, sl.stress[c], sl.stress[1 - c],
-                                              st->nh ? hp : nullptr, st->nh ? hc : nullptr, st->nh, sl.mask, eflags,
-                                              stress_host ? stress_host + SD * lo : nullptr,
+        fcamd_eval_args x{};
+        x.grad_del_u = grad + GD2 * lo;  // host array
+        x.stress_prev = sl.stress[c];
+        x.stress = sl.stress[1 - c];
+        x.history_prev = st->nh ? hp : nullptr;
+        x.history = st->nh ? hc : nullptr;
+        x.n_hist = st->nh;
+        x.history_mask = sl.mask;
+        x.flags = eflags;
+        const int s = fcamd_evaluate_resident(w->model, t, del_t, nk, &x, stress_host ? stress_host + SD * lo : nullptr,
                                               tangent_host ? tangent_host + TD * lo : nullptr, &part[(size_t)k]);
         modes[(size_t)k] = w->ctx->last_host_mode;
         return s;

@@ -40,6 +40,75 @@ __device__ __forceinline__ void delta_rows_store(double* rows_out, long long p0,
     wave_sync();
 }
 
+// Packed plastic-strain history (kFlagPackedHistory; a layout of device-resident states, committed AND trial array).
+// The plastic-strain array of a law only accumulates (mises_plasticity_isotropic_hardening.py:161, mises_plasticity.rs:112,
+// general.rs:243) and is +0.0 at every point that has never been plastic.  A state therefore keeps, per 64-point tile, the
+// rows of the points whose row is not all +0.0 -- the tile's EVER mask, one word per tile next to the array -- packed at the
+// head of the tile's slot: the k-th set bit of the mask (ascending point order) owns row k of the slot, rows
+// [popcount(ever), 64) are undefined.  One evaluate of a touched tile (a point plastic now, or plastic at the previous
+// evaluate: the sparse protocol's `need`) reads the committed run and writes the trial run, ever_trial = ever_committed |
+// plastic-now, each as ONE contiguous stream of full lines -- where the unpacked layout moves isolated 48-byte rows (reads
+// arrive in 128-byte lines, writes leave in partial 32-byte sectors: profiles/r03_von_mises_mixed_rocprof.md).  Untouched
+// tiles keep trial == committed (run and mask word), so the commit stays a pointer swap of arrays and mask arrays.
+// Values are bit for bit those of the plain protocol: a row outside ever_committed is the +0.0 row the plain array holds.
+//
+// load(): issues the global loads of the committed run (before the law's arithmetic, so that they are in flight with it);
+// update(): rows_out run <- rows_in run + d (d = 0 at points that are not plastic now), records ever_trial.
+template <bool NT>
+struct PackedRows {
+    Chunks<6> c;
+    unsigned long long ever_in = 0ull;
+
+    __device__ __forceinline__ void load(const EvalArgs& a, const double* rows_in, long long p0, int lane, bool touch) {
+        ever_in = a.emask_in[p0 >> 6];
+        const int nq = 3 * (int)__popcll(ever_in);
+        if (touch) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int q = k * kWave + lane;
+                d2 z;
+                z.x = 0.0;
+                z.y = 0.0;
+                c.v[k] = q < nq ? load16<NT>(rows_in + p0 * 6 + 2 * q) : z;
+            }
+        }
+    }
+    // `mask`: the points that are plastic in this evaluate; only called for touched tiles
+    __device__ __forceinline__ void update(const EvalArgs& a, double* rows_out, long long p0, int lane, unsigned long long mask,
+                                           double* region, const double (&d)[6]) {
+        const unsigned long long ever_out = ever_in | mask;
+        const int nq_in = 3 * (int)__popcll(ever_in), nq_out = 3 * (int)__popcll(ever_out);
+        const unsigned lo_in = (unsigned)ever_in, hi_in = (unsigned)(ever_in >> 32);
+        const unsigned lo_out = (unsigned)ever_out, hi_out = (unsigned)(ever_out >> 32);
+        const int rank_in = (int)__builtin_amdgcn_mbcnt_hi(hi_in, __builtin_amdgcn_mbcnt_lo(lo_in, 0u));     // set bits below this lane
+        const int rank_out = (int)__builtin_amdgcn_mbcnt_hi(hi_out, __builtin_amdgcn_mbcnt_lo(lo_out, 0u));
+        const bool in_c = ((ever_in >> lane) & 1ull) != 0ull, in_t = ((ever_out >> lane) & 1ull) != 0ull;
+        double ep[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (ever_in != 0ull) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int q = k * kWave + lane;
+                if (q < nq_in) reinterpret_cast<d2*>(region)[q] = c.v[k];
+            }
+            wave_sync();
+            if (in_c) lds_get_point<6>(region, rank_in, ep);
+            wave_sync();
+        }
+        const bool plastic = ((mask >> lane) & 1ull) != 0ull;  // the others keep their bits (the plain protocol does not touch them)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ep[i] = plastic ? ep[i] + d[i] : ep[i];
+        if (in_t) lds_put_point<6>(region, rank_out, ep);
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int q = k * kWave + lane;
+            if (q < nq_out) store16<NT>(rows_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+        }
+        wave_sync();
+        if (lane == 0) a.emask_out[p0 >> 6] = ever_out;
+    }
+};
+
 // History write policy of the laws with one [alpha, eps_p(6)] row per point (comfe-rs Mises and
 // Drucker-Prager; the row is always READ: alpha enters the yield function).  Which rows change:
 //   in place                      : the plastic points of this evaluate (ballot `mask`);
@@ -96,6 +165,12 @@ __device__ __forceinline__ void split_history_store(const EvalArgs& a, long long
     const unsigned long long rows = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
     if (rows == 0ull) return;
     if (live) a.h0_out[p0 + lane] = scalar;  // one coalesced 512-byte store per touched tile
+    if ((a.flags & kFlagPackedHistory) != 0 && a.hmask != nullptr) {  // committed run in, trial run out (PackedRows)
+        PackedRows<NT> pk;
+        pk.load(a, a.h1_in, p0, lane, true);
+        pk.update(a, a.h1_out, p0, lane, mask, region, delta);
+        return;
+    }
     if ((a.flags & kFlagDeltaHistory) != 0 && a.hmask != nullptr) {  // the increments of the plastic points, packed; nothing is read
         delta_rows_store<FULL, NT>(a.h1_out, p0, lane, mask, live && ((mask >> lane) & 1ull) != 0ull, region, delta);
         return;

@@ -94,7 +94,9 @@ __device__ __forceinline__ void vm_tangent_coefficients(const Scalars& sc, const
 // scalars: s[0]=strain factor, s[1]=ka, s[2]=2*mu, s[3]=sqrt(2/3), s[4]=y0, s[5]=y00-y0,
 //          s[6]=-w, s[7]=(-2)*mu, s[8]=((2/3)*(y00-y0))*w, s[9]=(4*mu)*mu
 // tables:  a = ka*xioi, b = xpp
-template <bool IDX, bool SPARSE, bool FULL, bool NT>
+// HIST: 0 = the caller's arrays as they are (in place or out of place), 1 = sparse trial history (a.hmask; + delta by flag),
+//       2 = sparse protocol on the packed plastic-strain layout (history_rows.h: PackedRows)
+template <bool IDX, int HIST, bool FULL, bool NT>
 __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                                int* rows_lds, long long p0, int npts, int lane,
                                                WaveStats& st) {
@@ -134,14 +136,16 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     // instruction count does not depend on how many rows are touched, and a fully plastic tile
     // degenerates to the plain coalesced tile access.
     Chunks<6> ce;
-    constexpr bool sparse = SPARSE;
+    constexpr bool sparse = HIST != 0;
+    constexpr bool packed = HIST == 2;
+    PackedRows<NT> pk;
     unsigned long long m_old = 0ull;
     if constexpr (sparse) m_old = a.hmask[p0 >> 6];
     const unsigned long long need_mask = mask | m_old;
     // delta trial history: only the rows of points that are plastic NOW are written (their increment), nothing is read
-    const bool delta = sparse && (a.flags & kFlagDeltaHistory) != 0;
+    const bool delta = sparse && !packed && (a.flags & kFlagDeltaHistory) != 0;
     const unsigned long long eps_mask = delta ? mask : need_mask;
-    const bool masked = FULL && (sparse || hist_in_place) && ((int)__popcll(eps_mask) <= a.masked_max);
+    const bool masked = !packed && FULL && (sparse || hist_in_place) && ((int)__popcll(eps_mask) <= a.masked_max);
     const bool touch_eps = masked ? (eps_mask != 0ull)
                                   : (sparse ? (eps_mask != 0ull) : ((mask != 0ull) || !hist_in_place));
     const bool touch_alpha = delta ? (need_mask != 0ull) : touch_eps;  // stale points get their committed alpha back
@@ -150,7 +154,9 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
 #pragma unroll
         for (int k = 0; k < 3; ++k) row_live[k] = ((eps_mask >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
     }
-    if (!delta && touch_eps) {
+    if constexpr (packed) {
+        pk.load(a, a.h0_in, p0, lane, touch_eps);
+    } else if (!delta && touch_eps) {
         if (masked) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -174,7 +180,14 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     sr.put(sb, region, lane, s, p0, npts);
 
     // history: eps_n += gamma N ; alpha += sqrt(2/3) gamma
-    if (delta) {  // the increment of the plastic points, packed at the head of the tile's slot (delta_rows_store)
+    if constexpr (packed) {
+        if (touch_eps) {
+            double dep[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dep[i] = rm.gamma * rm.N[i];
+            pk.update(a, a.h0_out, p0, lane, mask, region, dep);
+        }
+    } else if (delta) {  // the increment of the plastic points, packed at the head of the tile's slot (delta_rows_store)
         double ep[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) ep[i] = 0.0 + rm.gamma * rm.N[i];

@@ -63,6 +63,9 @@ constexpr int kFlagDeltaHistory = 2;
 // by the plastic ones (Drucker-Prager); in the 7-double rows every point pays 56 bytes of history reads for it.
 // A layout of device-resident states only (ResidentState), never of the interface arrays.
 constexpr int kFlagSplitHistory = 4;
+// Packed plastic-strain history (kernels/history_rows.h: PackedRows): committed and trial plastic-strain arrays hold, per tile,
+// the rows of the ever-plastic points as one contiguous run; EvalArgs::emask_in / emask_out are the tiles' EVER masks.
+constexpr int kFlagPackedHistory = 8;
 template <bool FULL>
 __device__ __forceinline__ unsigned long long sparse_tangent_need(const EvalArgs& a, unsigned long long need) {
     return (FULL && (a.flags & kFlagSparseTangent) != 0 && a.hmask != nullptr) ? need : ~0ull;

@@ -72,6 +72,49 @@ def join_history_rows(split):
     return torch.cat([split["scalar"].view(-1, 1), split["rows"].view(-1, 6)], dim=1).reshape(-1)
 
 
+def _tile_bits(mask, n):
+    """[tiles, 64] 0/1 matrix of the bits of one int64 word per 64-point tile"""
+    import torch
+
+    shifts = torch.arange(64, device=mask.device, dtype=torch.int64)
+    return (mask[: (n + 63) // 64, None] >> shifts[None, :]) & 1
+
+
+def pack_rows(rows):
+    """The packed layout of a plastic-strain array (FCAMD_EVAL_PACKED_HISTORY, include/fcamd.h): ``rows`` is the reference's
+    ``[6 n]`` array (device tensor); returns ``(packed [6 n], ever [tiles] int64)`` -- per 64-point tile the rows that are
+    not all +0.0 (bitwise) at the head of the tile's slot in ascending point order, and the tile's EVER mask.  The rest of
+    a slot is zero-filled here (undefined by contract)."""
+    import torch
+
+    n = rows.numel() // 6
+    tiles = (n + 63) // 64
+    r = rows.view(n, 6)
+    nz = (r.view(torch.int64) != 0).any(dim=1)  # bitwise: a -0.0 component keeps its row
+    bits = torch.zeros(tiles * 64, dtype=torch.int64, device=rows.device)
+    bits[:n] = nz
+    bits = bits.view(tiles, 64)
+    shifts = torch.arange(64, device=rows.device, dtype=torch.int64)
+    ever = (bits << shifts[None, :]).sum(dim=1)  # distinct bits: the sum is the OR (bit 63 wraps to the sign bit)
+    dst = (torch.arange(tiles, device=rows.device)[:, None] * 64 + torch.cumsum(bits, dim=1) - 1).reshape(-1)[:n]
+    packed = torch.zeros_like(rows)
+    packed.view(n, 6)[dst[nz]] = r[nz]
+    return packed, ever
+
+
+def unpack_rows(packed, ever, n=None):
+    """The inverse of ``pack_rows``: the reference's ``[6 n]`` array (new tensor) from the packed layout."""
+    import torch
+
+    n = packed.numel() // 6 if n is None else n
+    bits = _tile_bits(ever, n)
+    src = (torch.arange(bits.shape[0], device=packed.device)[:, None] * 64 + torch.cumsum(bits, dim=1) - 1).reshape(-1)[:n]
+    sel = bits.reshape(-1)[:n].bool()
+    rows = torch.zeros(6 * n, dtype=packed.dtype, device=packed.device)
+    rows.view(n, 6)[sel] = packed.view(-1, 6)[src[sel]]
+    return rows
+
+
 class DeviceLaw(IncrSmallStrainModel):
     """Base of all GPU-backed laws: owns the C model handle (created lazily, per device)
     and implements ``evaluate`` on top of the C ABI with the reference's validation."""
@@ -258,7 +301,7 @@ class DeviceLaw(IncrSmallStrainModel):
 
     def evaluate_from(self, t, del_t, grad_del_u, stress_prev, stress, tangent, history_prev, history,
                       history_mask=None, sparse_tangent: bool = False, counters=None, delta_history: bool = False,
-                      split_history: bool = False) -> None:
+                      split_history: bool = False, packed_masks=None) -> None:
         """Out-of-place device evaluate: read the committed state (``stress_prev``,
         ``history_prev``), write the trial state (``stress``, ``history``).  Fuses the two
         copies the reference makes before every call (solver/_lawonsubmesh.py:58-61,
@@ -271,7 +314,9 @@ class DeviceLaw(IncrSmallStrainModel):
         receives the increment at the plastic points and the committed one is not read
         (FCAMD_EVAL_DELTA_HISTORY; commit with ``commit_delta_history``).  ``split_history`` (the comfe-rs plasticity
         laws): the histories are dicts ``{"scalar": n, "rows": 6 n}`` instead of the reference's ``{"history": 7 n}``
-        (FCAMD_EVAL_SPLIT_HISTORY: ``SPLIT_HISTORY_FIELDS``)."""
+        (FCAMD_EVAL_SPLIT_HISTORY: ``SPLIT_HISTORY_FIELDS``).  ``packed_masks = (ever_prev, ever)`` (with ``history_mask``;
+        int64 device tensors, one word per 64-point tile): the plastic-strain arrays of ``history_prev`` / ``history``
+        (``eps_n`` resp. the split ``rows``) are in the packed layout of ``pack_rows`` (FCAMD_EVAL_PACKED_HISTORY)."""
         if split_history:
             hist = [history[k] for k, _ in SPLIT_HISTORY_FIELDS]
             hprev = [history_prev[k] for k, _ in SPLIT_HISTORY_FIELDS]
@@ -294,8 +339,15 @@ class DeviceLaw(IncrSmallStrainModel):
         dev = grad_del_u.device.index or 0
         m = self._handle(dev)
         m.ctx.set_stream(_current_stream_ptr(dev))
-        if (sparse_tangent and tangent is not None) or counters is not None or delta_history or split_history:
+        if (sparse_tangent and tangent is not None) or counters is not None or delta_history or split_history or packed_masks is not None:
             flags = _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tangent is not None and history_mask is not None) else 0
+            pm = None
+            if packed_masks is not None:
+                assert history_mask is not None and not delta_history, "packed history: with history_mask, without delta_history"
+                for mk in packed_masks:
+                    assert mk.dtype == torch.int64 and mk.is_cuda and mk.numel() >= (n + 63) // 64
+                flags |= _capi.EVAL_PACKED_HISTORY
+                pm = (packed_masks[0].data_ptr(), packed_masks[1].data_ptr())
             if delta_history:
                 assert history_mask is not None, "delta_history needs history_mask"
                 flags |= _capi.EVAL_DELTA_HISTORY
@@ -306,7 +358,7 @@ class DeviceLaw(IncrSmallStrainModel):
                 None if tangent is None else _check_torch("tangent", tangent).data_ptr(),
                 [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist],
                 None, None if history_mask is None else history_mask.data_ptr(), flags,
-                counters_ptr=_counters_ptr(counters))
+                counters_ptr=_counters_ptr(counters), packed_mask_ptrs=pm)
             return
         m.evaluate_device_from_sparse(
             t, del_t, n, grad_del_u.data_ptr(), stress_prev.data_ptr(), stress.data_ptr(),

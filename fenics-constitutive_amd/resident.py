@@ -43,7 +43,7 @@ class ResidentState:
 
     def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
                  reuse_constant_tangent: bool = True, sparse_tangent: bool = True, placement: str = "auto",
-                 delta_history="auto", split_history: bool = True):
+                 delta_history=False, split_history: bool = True, packed_history="auto"):
         """``placement`` (device-assembler mode, large states): where the arrays the kernel streams
         live decides 10-28 % of its time on MI355X.  "vmm": on the first ``evaluate`` the state moves its arrays
         (both stress / history copies, tangent, gradient staging) into ONE working set whose 2 MiB physical
@@ -61,9 +61,18 @@ class ResidentState:
         # writes contiguous runs, and ``update()`` adds the increments to the committed rows (one pass per increment, the
         # commit kernel).  It moves work from every Newton iteration to the commit, so it pays from ``DELTA_MIN_ITERATIONS``
         # iterations per increment on (bench.py "delta_trial_history": evaluate / commit kernel times, break-even).
-        # True: always; "auto" (default): the state watches how many evaluates its increments take and switches the protocol
-        # at increment boundaries (one full-history evaluate when it goes back to the plain protocol); False: never.
-        # ``history`` (the trial view) assembles the rows on demand.
+        # True: always; "auto": the state watches how many evaluates its increments take and switches the protocol
+        # at increment boundaries (one full-history evaluate when it goes back to the plain protocol; ``generation`` is
+        # incremented at every switch, because the MEANING of the trial plastic-strain tensor changes with it); False
+        # (default): never.  ``history`` (the trial view) assembles the rows on demand.
+
+        # ``packed_history`` (same laws, sparse protocol; "auto" = on unless ``delta_history`` was asked for): BOTH copies of
+        # the plastic-strain array are kept packed per 64-point tile -- the rows that are not all +0.0, i.e. the points that
+        # have ever been plastic, as one contiguous run at the head of the tile's slot, plus one EVER-mask word per tile
+        # (FCAMD_EVAL_PACKED_HISTORY, include/fcamd.h; ``device.pack_rows``).  A launch reads and writes contiguous runs
+        # instead of isolated 48-byte rows, and ``update()`` stays a pointer swap (no commit kernel).  ``history`` /
+        # ``history_committed`` hand out the plastic-strain array in the reference's layout as a COPY (always, from the first
+        # call on -- nothing changes meaning mid-run); initialise with ``set_state``.
 
         # ``split_history`` (the comfe-rs plasticity laws, with the sparse protocol): the reference keeps one
         # [scalar, eps_p(6)] row of 7 doubles per point (``history_dim = {"history": 7}``), so every point pays 56 bytes
@@ -106,8 +115,14 @@ class ResidentState:
         self._delta_key = "eps_n" if type(law).__name__ == "VonMises3D" else ("rows" if self._split else None)
         capable = self._mask is not None and self._delta_key is not None
         assert delta_history in (False, True, "auto"), "delta_history: False, True or 'auto'"
-        self._delta_auto = capable and delta_history == "auto"
-        self._delta = capable and delta_history is True
+        assert packed_history in (False, True, "auto"), "packed_history: False, True or 'auto'"
+        self._packed = capable and (packed_history is True or (packed_history == "auto" and delta_history is False))
+        self._delta_auto = capable and delta_history == "auto" and not self._packed
+        self._delta = capable and delta_history is True and not self._packed
+        # EVER masks of the two copies of the packed plastic-strain array (one word per tile), swapped with them
+        self._ever = [torch.zeros_like(self._mask), torch.zeros_like(self._mask)] if self._packed else None
+        if self._packed and history0 is not None:
+            self._pack_into_both(self._hist[0][self._delta_key].clone())
         if type(law).__name__.startswith("DruckerPrager"):
             # more of the launch is the return mapping itself: measured break-even 3.7 iterations at 56 % plastic points
             # (VonMises3D 1.7 at 22 %, comfe-rs Mises 2.1 at 40 %; bench.py "delta_trial_history", 1e8 points)
@@ -165,6 +180,22 @@ class ResidentState:
 
         return split_history_rows(self._as_dev(history["history"]))
 
+    def _pack_into_both(self, rows) -> None:
+        """both copies of the plastic-strain array <- ``rows`` (reference layout) in the packed layout, both EVER masks"""
+        from .device import pack_rows
+
+        packed, ever = pack_rows(rows)
+        for i in (0, 1):
+            self._hist[i][self._delta_key].copy_(packed)
+            self._ever[i].copy_(ever)
+
+    def _unpacked(self, copy: int) -> dict:
+        """internal history dict of one copy with the plastic-strain array in the reference's layout (a new tensor)"""
+        from .device import unpack_rows
+
+        h = self._hist[copy]
+        return {**h, self._delta_key: unpack_rows(h[self._delta_key], self._ever[copy], self.n)}
+
     def _external_history(self, internal) -> dict:
         if not self._split:
             return internal
@@ -208,17 +239,23 @@ class ResidentState:
 
     @property
     def history_committed(self):
-        """Committed history (live tensors).  Invariant of the sparse protocol: the trial history equals
+        """Committed history (live tensors; the plastic-strain array of a packed state -- ``packed_history`` -- is a copy in
+        the reference's layout).  Invariant of the sparse protocol: the trial history equals
         the committed one wherever the mask is clear -- do not write initial / restart values into these
         tensors, ``set_state`` writes both copies."""
-        return None if self._hist is None else self._external_history(self._hist[self._c])
+        if self._hist is None:
+            return None
+        return self._external_history(self._unpacked(self._c) if self._packed else self._hist[self._c])
 
     @property
     def history(self):
-        """Trial history.  Under the delta protocol the plastic-strain array is assembled here from the committed
-        array and the increments of the currently plastic points (a copy: the state keeps the increments)."""
+        """Trial history.  The plastic-strain array of a packed state is a copy in the reference's layout; under the delta
+        protocol it is assembled here from the committed array and the increments of the currently plastic points (a copy:
+        the state keeps the increments).  Every other tensor is the live one the kernel writes."""
         if self._hist is None:
             return None
+        if self._packed:  # nothing evaluated in this increment yet: the trial state is the committed one
+            return self._external_history(self._unpacked(1 - self._c if self._evaluated else self._c))
         trial = self._hist[1 - self._c]
         if not self._delta:
             return self._external_history(trial)
@@ -250,6 +287,9 @@ class ResidentState:
         if history is not None and self._hist is not None:
             h = self._internal_history(history)
             for k in self._hist[self._c]:
+                if self._packed and k == self._delta_key:
+                    self._pack_into_both(h[k])
+                    continue
                 self._hist[self._c][k].copy_(h[k])
                 self._hist[1 - self._c][k].copy_(self._hist[self._c][k])
         if self._mask is not None:
@@ -266,7 +306,8 @@ class ResidentState:
                                None if self._hist is None else self._hist[self._c],
                                None if self._hist is None else self._hist[1 - self._c],
                                history_mask=self._mask, sparse_tangent=sparse_tangent, counters=self._counters,
-                               delta_history=self._delta, split_history=self._split)
+                               delta_history=self._delta, split_history=self._split,
+                               packed_masks=(self._ever[self._c], self._ever[1 - self._c]) if self._packed else None)
 
     def evaluate(self, t: float, del_t: float, grad_del_u) -> None:
         """Trial state <- law(committed state, grad_del_u).  May be called any number of times per
@@ -303,9 +344,11 @@ class ResidentState:
 
     def prepare(self, t: float, del_t: float, grad_del_u) -> None:
         """Run the placement step NOW (it otherwise runs inside the first large device-assembler ``evaluate``) and leave a
-        valid trial state for ``grad_del_u``: after it the tensors handed out by ``stress`` / ``tangent`` / ``grad`` /
-        ``history`` stay the ones the kernel writes (``generation`` does not change any more unless ``tune_placement`` is
-        called).  For device assemblers that take the pointers once and then loop."""
+        valid trial state for ``grad_del_u``: after it the tensors handed out by ``stress`` / ``tangent`` / ``grad`` and the
+        live tensors of ``history`` stay the ones the kernel writes (``generation`` does not change any more unless
+        ``tune_placement`` is called or ``delta_history="auto"`` switches the protocol).  The plastic-strain array of
+        ``history`` is NOT such a tensor under ``packed_history`` (always a copy) or ``delta_history`` (its meaning follows the
+        protocol): read it through ``history`` when needed.  For device assemblers that take the pointers once and then loop."""
         self.evaluate(t, del_t, grad_del_u)
 
     def _place(self, t, del_t, g, staging: bool) -> None:
@@ -469,13 +512,16 @@ class ResidentState:
             flags |= _capi.EVAL_DELTA_HISTORY
         if self._split:
             flags |= _capi.EVAL_SPLIT_HISTORY
+        if self._packed:
+            flags |= _capi.EVAL_PACKED_HISTORY
         self._tangent_target = None
         self._stats_pending = False  # synchronous: the call itself reports
         try:
             self.law.last_stats = m.evaluate_resident(
                 t, del_t, self.n, grad_del_u.ctypes.data, self.stress_committed.data_ptr(), self.stress.data_ptr(),
                 hp, hc, None if self._mask is None else self._mask.data_ptr(),
-                None if stress is None else stress.ctypes.data, None if tangent is None else tangent.ctypes.data, flags)
+                None if stress is None else stress.ctypes.data, None if tangent is None else tangent.ctypes.data, flags,
+                packed_mask_ptrs=(self._ever[self._c].data_ptr(), self._ever[1 - self._c].data_ptr()) if self._packed else None)
         except Exception as e:
             self._failed = e  # the trial state is not fit to be committed: update() raises until a clean evaluate
             raise
@@ -518,12 +564,14 @@ class ResidentState:
         self._iters_ema = it if self._iters_ema is None else 0.5 * self._iters_ema + 0.5 * it
         if not self._delta and self._iters_ema >= self.DELTA_MIN_ITERATIONS:
             self._delta = True  # the trial rows become the packed increments; nothing of them is read
+            self.generation += 1  # a tensor taken from ``history`` earlier no longer means what it meant
         elif self._delta and self._iters_ema < self.DELTA_OFF_ITERATIONS:
             # back to the plain sparse protocol, whose contract is "trial == committed wherever the mask is clear": the trial
             # rows hold increments now, so every row is declared stale -- the next evaluate rewrites the whole trial history
             # (and tangent) once
             self._delta = False
             self._mask.fill_(-1)
+            self.generation += 1
 
     # host access ------------------------------------------------------------------------------------
     def download(self, stress: np.ndarray | None = None, tangent: np.ndarray | None = None,

@@ -220,6 +220,8 @@ typedef struct fcamd_eval_args {
                                            model's own (FCAMD_COUNTER_WORDS words, reset by the call) -- every
                                            resident state keeps its own, so that states sharing one model
                                            handle cannot read each other's non-convergence */
+    const uint64_t* packed_mask_prev;   /* FCAMD_EVAL_PACKED_HISTORY: the EVER mask of the committed plastic-strain array, */
+    uint64_t* packed_mask;              /* ... of the trial array (written); one word per 64-point tile each */
 } fcamd_eval_args;
 /* Layout of a counter buffer: FCAMD_COUNTER_SLOTS slots of 4 words {non-converged points, plastic
    points, Newton iterations, points outside the law's domain}; the totals (fcamd_stats) are the sums
@@ -254,6 +256,17 @@ typedef struct fcamd_eval_args {
    device-resident states (ResidentState keeps it and assembles the reference's rows on demand), not of the interface
    arrays; FULL 3-D only; fcamd_evaluate_device_ex and fcamd_evaluate_resident. */
 #define FCAMD_EVAL_SPLIT_HISTORY 4
+/* Packed plastic-strain history (with history_mask; VonMises3D: history[0] = eps_n; the comfe-rs plasticity laws with
+   FCAMD_EVAL_SPLIT_HISTORY: history[1] = the eps_p rows; not with parent_rows).  The plastic-strain array only accumulates
+   and is +0.0 wherever a point has never been plastic, so a device-resident state keeps BOTH its copies packed per
+   64-point tile: the rows of the points whose row is not all +0.0 -- the tile's EVER mask, `packed_mask_prev[tile]` for the
+   committed copy, `packed_mask[tile]` for the trial copy -- lie at the head of the tile's slot, the k-th set bit (ascending
+   point order) owning doubles [6 (64 tile + k), 6 (64 tile + k) + 6); the other rows of the slot are undefined.  A touched
+   tile (sparse protocol: a point plastic now or at the previous evaluate) reads the committed run and writes the trial run
+   (ever_trial = ever_committed | plastic now) as one contiguous stream each; untouched tiles keep trial == committed (run
+   and mask word), so the commit is still a swap of pointers -- arrays and mask arrays.  Same values, bit for bit, as the
+   unpacked sparse protocol; the scalar history keeps its layout.  ResidentState packs / unpacks at set_state / history. */
+#define FCAMD_EVAL_PACKED_HISTORY 8
 int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_t, int64_t n,
                              const fcamd_eval_args* args);
 /* The commit of a delta trial history: committed_rows[6 p .. 6 p + 6) += the increment of point p, for the points set in
@@ -300,16 +313,16 @@ int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
    instead of passing through the chunk buffers; when all host arrays of the call are page-locked
    (3-D laws) the whole pass is one launch that writes the stress both to the device-resident trial
    array and to `stress_host`.
-   `history_mask` (nullable) selects the sparse trial-history protocol of
-   fcamd_evaluate_device_from_sparse (plasticity laws).  `flags`: FCAMD_EVAL_SPARSE_TANGENT applies the
+   `state` describes the device-resident arrays exactly as for fcamd_evaluate_device_ex -- stress_prev / stress,
+   history_prev / history, n_hist, history_mask, flags, packed_mask_prev / packed_mask -- with ONE difference:
+   `state->grad_del_u` is the HOST gradient array; `tangent`, `parent_rows`, `stress2` must be NULL and `counters` is
+   ignored (the call is synchronous and reports through `stats`).
+   `history_mask` (nullable) selects the sparse trial-history protocol (plasticity laws).  `flags`: FCAMD_EVAL_SPARSE_TANGENT applies the
    sparse-tangent protocol to `tangent_host` when the kernel writes it directly: only the rows of
    plastic / formerly plastic points cross PCIe (the caller's array must still hold the previous
-   call's tangent); ignored on the chunked and scratch paths, which write every row.  FCAMD_EVAL_DELTA_HISTORY (with history_mask) as in fcamd_evaluate_device_ex.  Synchronous; waits for work queued on the
+   call's tangent); ignored on the chunked and scratch paths, which write every row.  FCAMD_EVAL_DELTA_HISTORY / FCAMD_EVAL_SPLIT_HISTORY / FCAMD_EVAL_PACKED_HISTORY as in fcamd_evaluate_device_ex.  Synchronous; waits for work queued on the
    context stream before touching the state arrays.  Status and `stats` as fcamd_evaluate_host. */
-int fcamd_evaluate_resident(fcamd_model* model, double t, double del_t, int64_t n,
-                            const double* grad_del_u_host, const double* stress_prev,
-                            double* stress, const double* const* history_prev,
-                            double* const* history, int n_hist, uint64_t* history_mask, int flags,
+int fcamd_evaluate_resident(fcamd_model* model, double t, double del_t, int64_t n, const fcamd_eval_args* state,
                             double* stress_host, double* tangent_host, fcamd_stats* stats);
 
 /* Mandel strain from displacement gradient, FULL (utils.py:132-151,187-208).

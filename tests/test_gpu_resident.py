@@ -85,6 +85,13 @@ def _sparse_case(law_name, n, rng):
             s0 = rng.normal(scale=30.0, size=6 * n)
             s0.reshape(-1, 6)[:, :3] -= 1000.0  # compressive prestress keeps the classic surface off its tip
 
+    # plastic-strain rows: zones of 200 points that have never been plastic (+0.0 rows: what the packed layout of a resident
+    # state leaves out), zones in which every point has been, and mixed zones -- EVER masks from empty to full
+    zone = (np.arange(n) // 200) % 4
+    virgin = (zone == 0) | ((zone >= 2) & (rng.random(n) < 0.5))
+    key, w = ("eps_n", 6) if law_name == "VonMises3D" else ("history", 7)
+    h0[key].reshape(-1, w)[virgin, w - 6:] = 0.0
+
     hi = -2.3 if law_name.startswith("Drucker") else -1.6  # log10 of the largest strain scale
 
     def grad(all_elastic, zoned):
@@ -363,32 +370,43 @@ def test_delta_trial_history_equals_the_plain_protocols(n, law_name):
     rng = np.random.default_rng(n)
     law, s0, h0, grad = _sparse_case(law_name, n, rng)
     d = ResidentState(law, n, stress0=s0, history0=h0, delta_history=True)           # packed increments in the trial array
-    p = ResidentState(law, n, stress0=s0, history0=h0, delta_history=False)          # plain sparse protocol: committed + increment in the trial array
+    p = ResidentState(law, n, stress0=s0, history0=h0)                               # the default: packed plastic-strain arrays, commit = pointer swap
+    u = ResidentState(law, n, stress0=s0, history0=h0, packed_history=False)         # plain sparse protocol: committed + increment in the trial array
     f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False)
-    assert d._delta and not p._delta and not f._delta
+    assert d._delta and not p._delta and not f._delta and not u._delta
+    assert p._packed and not (d._packed or u._packed or f._packed)
     sh, th = np.empty(6 * n), np.empty(36 * n)
+    shp, thp = np.empty(6 * n), np.empty(36 * n)
     n_plastic = []
     for inc in range(5):
         for it in range(3):
             g = grad(all_elastic=(inc == 2 and it == 1), zoned=(inc % 2 == 1))
             if (inc, it) == (3, 1):  # one host-assembler pass in between (fcamd_evaluate_resident with the flag)
                 d.evaluate_into(0.0, 1.0, g.cpu().numpy(), sh, th)
+                p.evaluate_into(0.0, 1.0, g.cpu().numpy(), shp, thp)
             else:
                 d.evaluate(0.0, 1.0, g)
-            p.evaluate(0.0, 1.0, g)
+                p.evaluate(0.0, 1.0, g)
+            u.evaluate(0.0, 1.0, g)
             f.evaluate(0.0, 1.0, g)
             n_plastic.append(int(f.check().n_plastic))
-            assert torch.equal(d.stress, f.stress) and torch.equal(p.stress, f.stress), (inc, it)
+            assert int(p.check().n_plastic) == n_plastic[-1] and int(u.check().n_plastic) == n_plastic[-1]
+            assert torch.equal(d.stress, f.stress) and torch.equal(p.stress, f.stress) and torch.equal(u.stress, f.stress), (inc, it)
             if (inc, it) == (3, 1):
                 assert np.array_equal(th, f.tangent.cpu().numpy()) and np.array_equal(sh, f.stress.cpu().numpy())
+                assert np.array_equal(thp, th) and np.array_equal(shp, sh)
             else:
-                assert torch.equal(d.tangent, f.tangent), (inc, it)
+                assert torch.equal(d.tangent, f.tangent) and torch.equal(p.tangent, f.tangent), (inc, it)
+            assert torch.equal(u.tangent, f.tangent), (inc, it)
             for k in h0:
-                assert torch.equal(d.history[k], f.history[k]), (inc, it, k)
-                assert torch.equal(d.history_committed[k], f.history_committed[k]), (inc, it, k)
-        d.update(), p.update(), f.update()
+                for st in (d, p, u):
+                    assert torch.equal(st.history[k], f.history[k]), (inc, it, k, st._packed, st._delta)
+                    assert torch.equal(st.history_committed[k], f.history_committed[k]), (inc, it, k, st._packed, st._delta)
+        d.update(), p.update(), u.update(), f.update()
         for k in h0:
             assert torch.equal(d.history_committed[k], f.history_committed[k]), (inc, k)
+            assert torch.equal(p.history_committed[k], f.history_committed[k]), (inc, k)
+            assert torch.equal(u.history_committed[k], f.history_committed[k]), (inc, k)
             # nothing evaluated yet: the assembled trial plastic strain is the committed one (the scalar history of stale
             # points is restored by the next evaluate, as under the plain sparse protocol)
             assert torch.equal(d.history[k], f.history_committed[k]) or k != "eps_n"

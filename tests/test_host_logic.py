@@ -216,7 +216,7 @@ def test_rows_of_cells_matches_quadrature_numbering():
 
 
 def test_eval_args_struct_layout_matches_header():
-    """ctypes mirror of fcamd_eval_args: twelve fields in the header's order, pointer-sized except n_hist / flags."""
+    """ctypes mirror of fcamd_eval_args: fourteen fields in the header's order, pointer-sized except n_hist / flags."""
     import ctypes as C
     import re
 
@@ -226,7 +226,7 @@ def test_eval_args_struct_layout_matches_header():
     body = re.search(r"typedef struct fcamd_eval_args \{(.*?)\} fcamd_eval_args;", hdr, re.S).group(1)
     names = re.findall(r"(\w+);", body)
     assert names == [f[0] for f in _capi.EvalArgs._fields_]
-    assert C.sizeof(_capi.EvalArgs) == 12 * C.sizeof(C.c_void_p)  # n_hist and flags each padded to pointer size
+    assert C.sizeof(_capi.EvalArgs) == 14 * C.sizeof(C.c_void_p)  # n_hist and flags each padded to pointer size
     assert _capi.EvalArgs.flags.offset == 9 * C.sizeof(C.c_void_p)
 
 
@@ -245,6 +245,7 @@ def test_header_constants_match_the_ctypes_module():
              "FCAMD_MAX_HISTORY": _capi.MAX_HISTORY, "FCAMD_IPC_HANDLE_BYTES": _capi.IPC_HANDLE_BYTES,
              "FCAMD_GATHER_PULL": _capi.GATHER_PULL, "FCAMD_ALLOC_SEQUENTIAL": _capi.ALLOC_SEQUENTIAL,
              "FCAMD_ALLOC_INTERLEAVED": _capi.ALLOC_INTERLEAVED, "FCAMD_EVAL_SPLIT_HISTORY": _capi.EVAL_SPLIT_HISTORY,
+             "FCAMD_EVAL_PACKED_HISTORY": _capi.EVAL_PACKED_HISTORY,
              "FCAMD_MULTI_MAX_DEVICES": _capi.MULTI_MAX_DEVICES, "FCAMD_MULTI_MIN_POINTS": _capi.MULTI_MIN_POINTS}
     for name, value in pairs.items():
         assert defines[name] == value, name

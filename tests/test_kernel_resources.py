@@ -1,0 +1,46 @@
+"""Every kernel of the library, as the compiler reports it for gfx950 (no GPU needed): no scratch -- a spilled VGPR is
+HBM traffic on a path whose bound is HBM -- and at least 3 waves per SIMD.  Round 3 shipped one spilling instantiation
+(the indexed Maxwell kernel, 5 VGPRs / 16 B per lane) that no profile covered; this guards every instantiation."""
+
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def rows():
+    import kernel_resources
+
+    return kernel_resources.kernel_resources()
+
+
+def test_all_kernels_reported(rows):
+    names = [r["name"] for r in rows]
+    assert len(rows) >= 70, names
+    for must in ("evaluate_kernel<2, true, false, 2>", "evaluate_kernel<3, true, true, 0>", "commit_delta_kernel", "strain_kernel"):
+        assert any(must in n for n in names), must
+    for r in rows:
+        for key in ("vgpr", "scratch", "occupancy", "vgpr_spill"):
+            assert isinstance(r.get(key), int), (r["name"], key)
+
+
+def test_no_scratch_no_vgpr_spills(rows):
+    bad = [(r["name"], r["scratch"], r["vgpr_spill"]) for r in rows if r["scratch"] != 0 or r["vgpr_spill"] != 0]
+    assert not bad, bad
+
+
+def test_occupancy_at_least_three_waves_per_simd(rows):
+    bad = [(r["name"], r["vgpr"], r["occupancy"]) for r in rows if r["occupancy"] < 3]
+    assert not bad, bad
+
+
+def test_headline_kernels_keep_four_waves(rows):
+    """the streaming kernels of the BASELINE configurations are cut for 4 waves per SIMD (128 VGPRs)"""
+    for law in (1, 2, 3, 4):
+        for r in rows:
+            if r["name"].startswith(f"void evaluate_kernel<{law}, true, false"):
+                assert r["occupancy"] >= 4 and r["vgpr"] <= 128, r

@@ -1,28 +1,80 @@
-#!/usr/bin/env python3
-"""Per-kernel resource usage of fcamd_kernels.hip (hipcc -Rpass-analysis=kernel-resource-usage), one line per
-kernel: VGPRs, AGPRs, SGPR / VGPR spills, scratch, occupancy, LDS.   python tools/kernel_resources.py [out.tsv]"""
+"""Register / scratch / occupancy table of every kernel of libfcamd, from the compiler's own remarks.
+
+``python tools/kernel_resources.py [--md]`` compiles the device code of the two .hip translation units for gfx950
+(device only, nothing is linked or run; works without a GPU) with ``-Rpass-analysis=kernel-resource-usage`` and prints
+one row per kernel.  ``tests/test_kernel_resources.py`` fails on any kernel with scratch (a spilled VGPR costs HBM
+traffic on a path whose bound is HBM) or fewer than 3 waves per SIMD.
+"""
+
+from __future__ import annotations
+
 import os
 import re
+import shutil
 import subprocess
 import sys
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "fenics-constitutive_amd", "csrc", "fcamd_kernels.hip")
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c", src,
-                    "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
-cur, rows = None, {}
-for line in r.stderr.splitlines():
-    m = re.search(r"remark: .*?:\d+:\d+: +(Function Name|Name): (\S+)", line) or re.search(r"(Function Name|Name): (\S+)", line)
-    if m:
-        cur = subprocess.run(["c++filt", m.group(2)], capture_output=True, text=True).stdout.strip()
-        cur = cur.replace("fcamd::", "").split("(")[0]
-        rows[cur] = {}
-        continue
-    m = re.search(r"(VGPRs|AGPRs|SGPRs Spill|VGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
-    if m and cur:
-        rows[cur][m.group(1)] = int(m.group(2))
-cols = ["VGPRs", "AGPRs", "SGPRs Spill", "VGPRs Spill", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]"]
-out = open(sys.argv[1], "w") if len(sys.argv) > 1 else sys.stdout
-out.write("kernel\t" + "\t".join(cols) + "\n")
-for k in sorted(rows):
-    out.write(k + "\t" + "\t".join(str(rows[k].get(c, "")) for c in cols) + "\n")
+sys.path.insert(0, ROOT)
+
+FIELDS = {"TotalSGPRs": "sgpr", "VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch",
+          "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
+          "LDS Size [bytes/block]": "lds"}
+
+
+def demangle(names):
+    filt = shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    try:
+        out = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True, check=True).stdout.split("\n")
+        return [o.replace("fcamd::", "").replace("(fcamd::EvalArgs)", "").replace("(anonymous namespace)::", "") for o in out[: len(names)]]
+    except Exception:
+        return list(names)
+
+
+def kernel_resources(sources=None):
+    """[{name, mangled, vgpr, sgpr, scratch, occupancy, vgpr_spill, sgpr_spill, lds, source}] for every kernel"""
+    from fenics_constitutive_amd import _build
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    flags = [f for f in _build.FLAGS if f not in ("-shared", "-fPIC", "-pthread")]
+    rows = []
+    for src in sources or [s for s in _build.SOURCES if s.endswith(".hip")]:
+        with tempfile.TemporaryDirectory() as tmp:
+            cmd = [hipcc, f"--offload-arch={_build.ARCH}", *flags, "--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage",
+                   "-o", os.path.join(tmp, "k.o"), os.path.join(_build.CSRC, src)]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-2000:]}")
+        cur = None
+        for line in r.stderr.splitlines():
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                cur = {"mangled": m.group(1), "source": src}
+                rows.append(cur)
+                continue
+            m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\S+) \[-Rpass", line)
+            if m and cur is not None and m.group(1).strip() in FIELDS:
+                v = m.group(2)
+                cur[FIELDS[m.group(1).strip()]] = int(v) if v.lstrip("-").isdigit() else v
+    for row, name in zip(rows, demangle([r["mangled"] for r in rows])):
+        row["name"] = name
+    return rows
+
+
+def main():
+    rows = kernel_resources()
+    md = "--md" in sys.argv
+    hdr = ["kernel", "VGPR", "SGPR", "scratch B/lane", "VGPR spill", "SGPR spill", "LDS B/block", "waves/SIMD"]
+    if md:
+        print("| " + " | ".join(hdr) + " |\n|" + "---|" * len(hdr))
+    for r in sorted(rows, key=lambda r: r["name"]):
+        vals = [r["name"], r.get("vgpr"), r.get("sgpr"), r.get("scratch"), r.get("vgpr_spill"), r.get("sgpr_spill"), r.get("lds"), r.get("occupancy")]
+        print(("| " + " | ".join(str(v) for v in vals) + " |") if md else "  ".join(f"{str(v):>6}" if i else f"{str(v):<78}" for i, v in enumerate(vals)))
+    bad = [r["name"] for r in rows if r.get("scratch", 0) or r.get("occupancy", 8) < 3]
+    print(f"{len(rows)} kernels; with scratch or occupancy < 3: {bad or 'none'}", file=sys.stderr)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
