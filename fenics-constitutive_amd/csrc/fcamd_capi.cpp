@@ -793,7 +793,7 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
         if (x->history && x->history_prev && x->history[kd] == x->history_prev[kd])
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial plastic-strain array of its own");
     }
-    if (x->flags & FCAMD_EVAL_PACKED_HISTORY) {
+    if ((x->flags & FCAMD_EVAL_PACKED_HISTORY) && n > 0) {
         const bool split = (x->flags & FCAMD_EVAL_SPLIT_HISTORY) != 0 && has_split_history(m->law);
         if (m->law != FCAMD_VON_MISES_3D && !split)
             return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_PACKED_HISTORY exists for VonMises3D and, with FCAMD_EVAL_SPLIT_HISTORY, for the "

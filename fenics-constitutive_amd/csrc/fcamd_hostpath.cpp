@@ -663,7 +663,7 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         if (hist && hist_prev && hist[kd] == hist_prev[kd])
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial plastic-strain array of its own");
     }
-    if (packed) {  // as fcamd_evaluate_device_ex
+    if (packed && n > 0) {  // as fcamd_evaluate_device_ex
         if (!history_mask || !emask_prev || !emask || emask == emask_prev)
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs history_mask and two mask arrays, packed_mask_prev and packed_mask");
         if (m->law != FCAMD_VON_MISES_3D && !((flags & FCAMD_EVAL_SPLIT_HISTORY) && has_split_history(m->law)))

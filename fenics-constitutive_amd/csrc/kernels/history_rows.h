@@ -52,52 +52,67 @@ __device__ __forceinline__ void delta_rows_store(double* rows_out, long long p0,
 // tiles keep trial == committed (run and mask word), so the commit stays a pointer swap of arrays and mask arrays.
 // Values are bit for bit those of the plain protocol: a row outside ever_committed is the +0.0 row the plain array holds.
 //
-// load(): issues the global loads of the committed run (before the law's arithmetic, so that they are in flight with it);
-// update(): rows_out run <- rows_in run + d (d = 0 at points that are not plastic now), records ever_trial.
-template <bool NT>
+// load(): requests the committed run (as early as the tile knows that it is touched, so that the request is in flight with the
+// law's arithmetic); gather(): the committed row of every lane's point, BEFORE the tile issues its first store; scatter():
+// rows_out run <- rows + d at the plastic points, records ever_trial.
+template <bool FULL, bool NT>
 struct PackedRows {
     Chunks<6> c;
     unsigned long long ever_in = 0ull;
 
-    __device__ __forceinline__ void load(const EvalArgs& a, const double* rows_in, long long p0, int lane, bool touch) {
-        ever_in = a.emask_in[p0 >> 6];
-        const int nq = 3 * (int)__popcll(ever_in);
-        if (touch) {
+    // 16-byte chunks of a run of `rows` rows, rounded up to whole 128-byte lines (a slot is 24 lines; the ragged last tile,
+    // whose slot ends with the array: the exact run; FCAMD_PACKED_LINE=0: always exact, the experiment knob)
+#ifndef FCAMD_PACKED_LINE
+#define FCAMD_PACKED_LINE 1
+#endif
+    static __device__ __forceinline__ int run_chunks(int rows) {
+#if FCAMD_PACKED_LINE
+        return FULL ? ((3 * rows + 7) & ~7) : 3 * rows;  // <= 192
+#else
+        return 3 * rows;
+#endif
+    }
+
+    // requests the committed run (ever_in must be set: the tile's EVER word, a.emask_in[tile])
+    __device__ __forceinline__ void load(const double* rows_in, long long p0, int lane) {
+        const int nq = run_chunks((int)__popcll(ever_in));
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int q = k * kWave + lane;
-                d2 z;
-                z.x = 0.0;
-                z.y = 0.0;
-                c.v[k] = q < nq ? load16<NT>(rows_in + p0 * 6 + 2 * q) : z;
-            }
+        for (int k = 0; k < 3; ++k) {
+            const int q = k * kWave + lane;
+            d2 z;
+            z.x = 0.0;
+            z.y = 0.0;
+            c.v[k] = q < nq ? load16<NT>(rows_in + p0 * 6 + 2 * q) : z;
         }
     }
-    // `mask`: the points that are plastic in this evaluate; only called for touched tiles
-    __device__ __forceinline__ void update(const EvalArgs& a, double* rows_out, long long p0, int lane, unsigned long long mask,
-                                           double* region, const double (&d)[6]) {
-        const unsigned long long ever_out = ever_in | mask;
-        const int nq_in = 3 * (int)__popcll(ever_in), nq_out = 3 * (int)__popcll(ever_out);
-        const unsigned lo_in = (unsigned)ever_in, hi_in = (unsigned)(ever_in >> 32);
-        const unsigned lo_out = (unsigned)ever_out, hi_out = (unsigned)(ever_out >> 32);
-        const int rank_in = (int)__builtin_amdgcn_mbcnt_hi(hi_in, __builtin_amdgcn_mbcnt_lo(lo_in, 0u));     // set bits below this lane
-        const int rank_out = (int)__builtin_amdgcn_mbcnt_hi(hi_out, __builtin_amdgcn_mbcnt_lo(lo_out, 0u));
-        const bool in_c = ((ever_in >> lane) & 1ull) != 0ull, in_t = ((ever_out >> lane) & 1ull) != 0ull;
-        double ep[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (ever_in != 0ull) {
+    // ep <- the committed row of this lane's point (+0.0 row for a point outside ever_in), through the wave's LDS region
+    __device__ __forceinline__ void gather(double* region, int lane, double (&ep)[6]) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int q = k * kWave + lane;
-                if (q < nq_in) reinterpret_cast<d2*>(region)[q] = c.v[k];
-            }
-            wave_sync();
-            if (in_c) lds_get_point<6>(region, rank_in, ep);
-            wave_sync();
+        for (int i = 0; i < 6; ++i) ep[i] = 0.0;
+        if (ever_in == 0ull) return;
+        const int nq_in = 3 * (int)__popcll(ever_in);
+        const int rank_in = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ever_in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ever_in, 0u));  // set bits below this lane
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int q = k * kWave + lane;
+            if (q < nq_in) reinterpret_cast<d2*>(region)[q] = c.v[k];
         }
-        const bool plastic = ((mask >> lane) & 1ull) != 0ull;  // the others keep their bits (the plain protocol does not touch them)
+        wave_sync();
+        if (((ever_in >> lane) & 1ull) != 0ull) lds_get_point<6>(region, rank_in, ep);
+        wave_sync();
+    }
+    // trial run <- ep + d at the points of `mask` (plastic now), ep at the others (their bits, as the plain protocol leaves
+    // them); records ever_trial = ever_in | mask
+    __device__ __forceinline__ void scatter(const EvalArgs& a, double* rows_out, long long p0, int lane, unsigned long long mask,
+                                            double* region, double (&ep)[6], const double (&d)[6]) {
+        const unsigned long long ever_out = ever_in | mask;
+        // the run that is written ends on a 128-byte line (the rest of the slot is undefined by contract): no partial line leaves
+        const int nq_out = run_chunks((int)__popcll(ever_out));
+        const int rank_out = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ever_out >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ever_out, 0u));
+        const bool plastic = ((mask >> lane) & 1ull) != 0ull;
 #pragma unroll
         for (int i = 0; i < 6; ++i) ep[i] = plastic ? ep[i] + d[i] : ep[i];
-        if (in_t) lds_put_point<6>(region, rank_out, ep);
+        if (((ever_out >> lane) & 1ull) != 0ull) lds_put_point<6>(region, rank_out, ep);
         wave_sync();
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -166,9 +181,12 @@ __device__ __forceinline__ void split_history_store(const EvalArgs& a, long long
     if (rows == 0ull) return;
     if (live) a.h0_out[p0 + lane] = scalar;  // one coalesced 512-byte store per touched tile
     if ((a.flags & kFlagPackedHistory) != 0 && a.hmask != nullptr) {  // committed run in, trial run out (PackedRows)
-        PackedRows<NT> pk;
-        pk.load(a, a.h1_in, p0, lane, true);
-        pk.update(a, a.h1_out, p0, lane, mask, region, delta);
+        PackedRows<FULL, NT> pk;
+        pk.ever_in = a.emask_in[p0 >> 6];
+        pk.load(a.h1_in, p0, lane);
+        double ep[6];
+        pk.gather(region, lane, ep);
+        pk.scatter(a, a.h1_out, p0, lane, mask, region, ep, delta);
         return;
     }
     if ((a.flags & kFlagDeltaHistory) != 0 && a.hmask != nullptr) {  // the increments of the plastic points, packed; nothing is read
