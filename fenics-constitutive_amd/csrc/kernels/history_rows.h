@@ -79,10 +79,11 @@ struct PackedRows {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int q = k * kWave + lane;
-            d2 z;
-            z.x = 0.0;
-            z.y = 0.0;
-            c.v[k] = q < nq ? load16<NT>(rows_in + p0 * 6 + 2 * q) : z;
+            d2 v;
+            v.x = 0.0;
+            v.y = 0.0;
+            if (q < nq) v = load16<NT>(rows_in + p0 * 6 + 2 * q);
+            c.v[k] = v;
         }
     }
     // ep <- the committed row of this lane's point (+0.0 row for a point outside ever_in), through the wave's LDS region
@@ -101,18 +102,15 @@ struct PackedRows {
         if (((ever_in >> lane) & 1ull) != 0ull) lds_get_point<6>(region, rank_in, ep);
         wave_sync();
     }
-    // trial run <- ep + d at the points of `mask` (plastic now), ep at the others (their bits, as the plain protocol leaves
-    // them); records ever_trial = ever_in | mask
+    // trial run <- `row` (the final row of this lane's point: committed row + increment where it is plastic now, the committed
+    // row's bits elsewhere, as the plain protocol leaves them); records ever_trial = ever_in | mask
     __device__ __forceinline__ void scatter(const EvalArgs& a, double* rows_out, long long p0, int lane, unsigned long long mask,
-                                            double* region, double (&ep)[6], const double (&d)[6]) {
+                                            double* region, const double (&row)[6]) {
         const unsigned long long ever_out = ever_in | mask;
         // the run that is written ends on a 128-byte line (the rest of the slot is undefined by contract): no partial line leaves
         const int nq_out = run_chunks((int)__popcll(ever_out));
         const int rank_out = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ever_out >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ever_out, 0u));
-        const bool plastic = ((mask >> lane) & 1ull) != 0ull;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) ep[i] = plastic ? ep[i] + d[i] : ep[i];
-        if (((ever_out >> lane) & 1ull) != 0ull) lds_put_point<6>(region, rank_out, ep);
+        if (((ever_out >> lane) & 1ull) != 0ull) lds_put_point<6>(region, rank_out, row);
         wave_sync();
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -136,16 +134,39 @@ struct PackedRows {
 // lane skips the 16-byte chunks that lie entirely in untouched rows (chunk q holds doubles 2q and
 // 2q + 1 of the tile image, i.e. parts of rows 2q / 7 and (2q + 1) / 7; a chunk straddling a touched
 // and an untouched row rewrites 8 bytes of the latter with the value it already has).
-// plastic | formerly plastic points of the tile under the sparse protocol; records the new ballot
-__device__ __forceinline__ unsigned long long sparse_need(const EvalArgs& a, long long p0, unsigned long long mask,
-                                                          int lane) {
-    if (a.hmask == nullptr) return mask;
-    const unsigned long long m_old = a.hmask[p0 >> 6];
-    if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
-    return mask | m_old;
+// The per-tile words of the sparse protocol -- the previous plastic ballot and, for a packed state, the EVER mask of the committed
+// run.  A tile loads them FIRST, with its gradient: they arrive with it instead of costing a dependent memory round trip after the
+// ballot.  The new ballot is recorded at the END of the tile (sparse_record): a store issued earlier would sit, in the wave's one
+// vmcnt, in front of the row loads that follow it.
+struct SparseWords {
+    unsigned long long m_old = 0ull, ever = 0ull;
+};
+__device__ __forceinline__ SparseWords sparse_words(const EvalArgs& a, long long p0) {
+    SparseWords w;
+    if (a.hmask != nullptr) {
+        w.m_old = a.hmask[p0 >> 6];
+        if ((a.flags & kFlagPackedHistory) != 0) w.ever = a.emask_in[p0 >> 6];
+    }
+    return w;
+}
+// the words as scalars (they are wave-uniform): call once the tile's first loads have been waited for
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void sparse_words_uniform(SparseWords& w) {
+    w.m_old = uniform64(w.m_old);
+    w.ever = uniform64(w.ever);
+}
+// plastic | formerly plastic points of the tile under the sparse protocol
+__device__ __forceinline__ unsigned long long sparse_touched(const EvalArgs& a, const SparseWords& w, unsigned long long mask) {
+    return a.hmask == nullptr ? mask : (mask | w.m_old);
+}
+__device__ __forceinline__ void sparse_record(const EvalArgs& a, const SparseWords& w, long long p0, unsigned long long mask, int lane) {
+    if (a.hmask != nullptr && lane == 0 && mask != w.m_old) a.hmask[p0 >> 6] = mask;
 }
 
-// `touched`: sparse_need() of the tile
+// `touched`: sparse_touched() of the tile
 template <bool FULL, bool NT>
 __device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, int npts, int lane,
                                                unsigned long long touched, bool hist_in_place, double* region,
@@ -171,67 +192,95 @@ __device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, 
 // Split history (kFlagSplitHistory): the scalar of every point of a touched tile and the rows `rows` of the
 // plastic-strain array, rows_out = rows_in + delta (delta = 0 at points that are not plastic: they get their committed
 // values back).  Which rows, by protocol, as in history7_store.  Row-masked access as in tile_von_mises (a 48-byte row
-// is three 16-byte chunks of the tile image).
+// is three 16-byte chunks of the tile image).  Three phases, placed by the tile so that no load is consumed after a younger
+// store (one vmcnt counts both: the wave would wait for the store to complete):
+//   request()  after the ballot, before the return mapping: the committed rows this tile needs are requested;
+//   gather()   before the tile's first store: the rows of this lane's point, ep;
+//   store()    after the stress store: the scalar of a touched tile and the rows out.
 template <bool FULL, bool NT>
-__device__ __forceinline__ void split_history_store(const EvalArgs& a, long long p0, int npts, int lane, unsigned long long mask,
-                                                    unsigned long long touched, bool hist_in_place, double* region,
-                                                    double scalar, const double (&delta)[6]) {
-    const bool live = FULL || lane < npts;
-    const unsigned long long rows = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
-    if (rows == 0ull) return;
-    if (live) a.h0_out[p0 + lane] = scalar;  // one coalesced 512-byte store per touched tile
-    if ((a.flags & kFlagPackedHistory) != 0 && a.hmask != nullptr) {  // committed run in, trial run out (PackedRows)
-        PackedRows<FULL, NT> pk;
-        pk.ever_in = a.emask_in[p0 >> 6];
-        pk.load(a.h1_in, p0, lane);
-        double ep[6];
-        pk.gather(region, lane, ep);
-        pk.scatter(a, a.h1_out, p0, lane, mask, region, ep, delta);
-        return;
-    }
-    if ((a.flags & kFlagDeltaHistory) != 0 && a.hmask != nullptr) {  // the increments of the plastic points, packed; nothing is read
-        delta_rows_store<FULL, NT>(a.h1_out, p0, lane, mask, live && ((mask >> lane) & 1ull) != 0ull, region, delta);
-        return;
-    }
-    const bool masked = FULL && rows != ~0ull && (int)__popcll(rows) <= a.masked_max;
-    Chunks<6> ce;
+struct SplitRows {
+    PackedRows<FULL, NT> pk;  // its chunk registers pk.c also hold the rows of the unpacked layouts (one array: stays in VGPRs)
+    unsigned long long rows = 0ull;
+    bool delta = false, packed = false, masked = false;
     bool row_live[3] = {true, true, true};
-    if (masked) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            row_live[k] = ((rows >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
-            d2 z;
-            z.x = 0.0;
-            z.y = 0.0;
-            ce.v[k] = row_live[k] ? load16<NT>(a.h1_in + p0 * 6 + 2 * (k * kWave + lane)) : z;
+
+    __device__ __forceinline__ void request(const EvalArgs& a, const SparseWords& w, long long p0, int npts, int lane,
+                                            unsigned long long touched, bool hist_in_place) {
+        rows = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
+        if (rows == 0ull) return;
+        delta = (a.flags & kFlagDeltaHistory) != 0 && a.hmask != nullptr;  // increments of the plastic points, packed; nothing is read
+        packed = (a.flags & kFlagPackedHistory) != 0 && a.hmask != nullptr;  // committed run in, trial run out (PackedRows)
+        if (delta) return;
+        if (packed) {
+            pk.ever_in = w.ever;
+            pk.load(a.h1_in, p0, lane);
+            return;
         }
-    } else {
-        tile_load<6, FULL, NT>(ce, a.h1_in + p0 * 6, npts * 6, lane);
-    }
-    if (mask != 0ull) {
-        double ep[6];
-        transpose_in<6>(ce, region, lane, ep);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + delta[i];
+        masked = FULL && rows != ~0ull && (int)__popcll(rows) <= a.masked_max;
         if (masked) {
-            lds_put_point<6>(region, lane, ep);
-            wave_sync();
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int q = k * kWave + lane;
-                if (row_live[k]) store16<NT>(a.h1_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+                row_live[k] = ((rows >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
+                d2 v;
+                v.x = 0.0;
+                v.y = 0.0;
+                if (row_live[k]) v = load16<NT>(a.h1_in + p0 * 6 + 2 * (k * kWave + lane));
+                pk.c.v[k] = v;
             }
-            wave_sync();
         } else {
-            transpose_out<6, FULL, NT>(ep, region, lane, a.h1_out + p0 * 6, npts * 6);
+            tile_load<6, FULL, NT>(pk.c, a.h1_in + p0 * 6, npts * 6, lane);
         }
-    } else if (masked) {  // only stale rows: restore the committed values
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (row_live[k]) store16<NT>(a.h1_out + p0 * 6 + 2 * (k * kWave + lane), ce.v[k]);
-    } else if (!hist_in_place) {
-        tile_store<6, FULL, NT>(ce, a.h1_out + p0 * 6, npts * 6, lane);
     }
-}
+    // d: in, the increment of this lane's point (zero unless it is plastic now); out, the row to be written -- committed row +
+    // increment at the plastic points, the committed row (its bits) elsewhere.  Summed here, at once: the committed rows do not
+    // stay in registers across the stress store.  (Delta protocol: d stays the increment.)
+    __device__ __forceinline__ void gather(double* region, int lane, unsigned long long mask, double (&d)[6]) {
+        if (rows == 0ull || delta) return;
+        double ep[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (packed)
+            pk.gather(region, lane, ep);
+        else if (mask != 0ull)
+            transpose_in<6>(pk.c, region, lane, ep);
+        else
+            return;  // only stale rows: they leave as the chunks they came as
+        const bool plastic = ((mask >> lane) & 1ull) != 0ull;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = (plastic || !packed) ? ep[i] + d[i] : ep[i];
+    }
+    __device__ __forceinline__ void store(const EvalArgs& a, long long p0, int npts, int lane, unsigned long long mask,
+                                          bool hist_in_place, double* region, double scalar, const double (&d)[6]) {
+        const bool live = FULL || lane < npts;
+        if (rows == 0ull) return;
+        if (live) a.h0_out[p0 + lane] = scalar;  // one coalesced 512-byte store per touched tile
+        if (delta) {
+            delta_rows_store<FULL, NT>(a.h1_out, p0, lane, mask, live && ((mask >> lane) & 1ull) != 0ull, region, d);
+            return;
+        }
+        if (packed) {
+            pk.scatter(a, a.h1_out, p0, lane, mask, region, d);
+            return;
+        }
+        if (mask != 0ull) {
+            if (masked) {
+                lds_put_point<6>(region, lane, d);
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int q = k * kWave + lane;
+                    if (row_live[k]) store16<NT>(a.h1_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+                }
+                wave_sync();
+            } else {
+                transpose_out<6, FULL, NT>(d, region, lane, a.h1_out + p0 * 6, npts * 6);
+            }
+        } else if (masked) {  // only stale rows: restore the committed values
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (row_live[k]) store16<NT>(a.h1_out + p0 * 6 + 2 * (k * kWave + lane), pk.c.v[k]);
+        } else if (!hist_in_place) {
+            tile_store<6, FULL, NT>(pk.c, a.h1_out + p0 * 6, npts * 6, lane);
+        }
+    }
+};
 
 }  // namespace fcamd

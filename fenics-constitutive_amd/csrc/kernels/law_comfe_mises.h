@@ -75,6 +75,7 @@ template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                                  int* rows_lds, long long p0, int npts, int lane,
                                                  WaveStats& st) {
+    const SparseWords w = sparse_words(a, p0);  // first: they arrive with the gradient
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     Chunks<7> ch;
@@ -105,15 +106,23 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
     const bool plastic = cm_point(a.sc, live, e, s, h, B, sc2, nv);
     const unsigned long long mask = __ballot(plastic);
     st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
+    const unsigned long long touched = sparse_touched(a, w, mask);
 
-    sr.put(sb, region, lane, s, p0, npts);
-    const unsigned long long touched = sparse_need(a, p0, mask, lane);
+    // split layout: the committed eps_p rows are requested and taken into the lanes BEFORE the stress store is issued
+    // (history_rows.h: SplitRows)
+    SplitRows<FULL, NT> hr;
+    double d6[6] = {h[1], h[2], h[3], h[4], h[5], h[6]};
     if (split) {
-        const double d6[6] = {h[1], h[2], h[3], h[4], h[5], h[6]};
-        split_history_store<FULL, NT>(a, p0, npts, lane, mask, touched, hist_in_place, region, h[0], d6);
+        hr.request(a, w, p0, npts, lane, touched, hist_in_place);
+        hr.gather(region, lane, mask, d6);
+    }
+    sr.put(sb, region, lane, s, p0, npts);
+    if (split) {
+        hr.store(a, p0, npts, lane, mask, hist_in_place, region, h[0], d6);
     } else {
         history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
     }
+    sparse_record(a, w, p0, mask, lane);
 
     const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
     if (sb.tan && tneed != 0ull) {

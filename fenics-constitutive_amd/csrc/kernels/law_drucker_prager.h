@@ -237,6 +237,7 @@ template <bool HYPER, bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBases& sb, const Tables* T,
                                               double* region, int* rows_lds, long long p0, int npts, int lane,
                                               int r0, WaveStats& st) {
+    SparseWords w = sparse_words(a, p0);  // first: they arrive with the gradient
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     Chunks<7> ch;
@@ -253,6 +254,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
 
     double g9[9], sig0[6], h[7], e[6];
     transpose_in<9>(cg, region, lane, g9);
+    sparse_words_uniform(w);  // arrived with the gradient: two SGPR pairs through the return mapping instead of VGPRs
     sr.get(region, lane, sig0);
     if (split) {  // the plastic strain only accumulates: start the rows at zero, what comes back is the increment
         h[0] = scalar_n;
@@ -268,16 +270,22 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     const bool plastic = live && (t.m.f > 0.0);
     const unsigned long long mask = __ballot(plastic);
 
+    const unsigned long long touched = sparse_touched(a, w, mask);
+    SplitRows<FULL, NT> hr;
     if (mask == 0ull) {
-        // fully elastic tile: stress = sigma_tr, tangent = E, history untouched
-        sr.put(sb, region, lane, t.sig1, p0, npts);
-        const unsigned long long touched = sparse_need(a, p0, 0ull, lane);
+        // fully elastic tile: stress = sigma_tr, tangent = E, history untouched (sparse protocol: stale rows restored)
+        double d6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (split) {
-            const double d6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            split_history_store<FULL, NT>(a, p0, npts, lane, 0ull, touched, hist_in_place, region, h[0], d6);
+            hr.request(a, w, p0, npts, lane, touched, hist_in_place);
+            hr.gather(region, lane, 0ull, d6);
+        }
+        sr.put(sb, region, lane, t.sig1, p0, npts);
+        if (split) {
+            hr.store(a, p0, npts, lane, 0ull, hist_in_place, region, h[0], d6);
         } else {
             history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
         }
+        sparse_record(a, w, p0, 0ull, lane);
         const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
         if (sb.tan && tneed != 0ull) {
             if constexpr (IDX) wave_sync();
@@ -296,14 +304,20 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
     st.domain += (live && t.tip) ? 1ull : 0ull;  // tip of the classic surface reached (reference: assert!)
 
-    sr.put(sb, region, lane, t.sig1, p0, npts);
-    const unsigned long long touched = sparse_need(a, p0, mask, lane);
+    // the committed rows: requested after the return mapping (whose registers they would otherwise share: spills at the
+    // 168-VGPR cap of the indexed kernels) and taken into the lanes before the first store of the tile
+    double d6[6] = {h[1], h[2], h[3], h[4], h[5], h[6]};
     if (split) {
-        const double d6[6] = {h[1], h[2], h[3], h[4], h[5], h[6]};
-        split_history_store<FULL, NT>(a, p0, npts, lane, mask, touched, hist_in_place, region, h[0], d6);
+        hr.request(a, w, p0, npts, lane, touched, hist_in_place);
+        hr.gather(region, lane, mask, d6);
+    }
+    sr.put(sb, region, lane, t.sig1, p0, npts);
+    if (split) {
+        hr.store(a, p0, npts, lane, mask, hist_in_place, region, h[0], d6);
     } else {
         history7_store<FULL, NT>(a, p0, npts, lane, touched, hist_in_place, region, h);
     }
+    sparse_record(a, w, p0, mask, lane);
 
     const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
     if (sb.tan && tneed != 0ull) {

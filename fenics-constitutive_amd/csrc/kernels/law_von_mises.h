@@ -202,10 +202,9 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     // history: eps_n += gamma N ; alpha += sqrt(2/3) gamma
     if constexpr (packed) {
         if (touch_eps) {
-            double dep[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) dep[i] = rm.gamma * rm.N[i];
-            pk.scatter(a, a.h0_out, p0, lane, mask, region, ep, dep);
+            for (int i = 0; i < 6; ++i) ep[i] = plastic ? ep[i] + rm.gamma * rm.N[i] : ep[i];  // the others keep their bits
+            pk.scatter(a, a.h0_out, p0, lane, mask, region, ep);
         }
     } else if (delta) {  // the increment of the plastic points, packed at the head of the tile's slot (delta_rows_store)
         double dp[6];
@@ -236,7 +235,8 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
             tile_store<6, FULL, NT>(ce, a.h0_out + p0 * 6, npts * 6, lane);
         }
     }
-    // alpha: one coalesced 512-byte store per touched tile
+    // alpha: one coalesced 512-byte store per touched tile (round 4: storing only the 32-byte sectors that hold a plastic or
+    // stale point saves 3 B/pt and costs 1 % -- partial lines; 64- / 128-byte granules neither gain nor lose)
     if (touch_alpha && live) a.h1_out[p0 + lane] = alpha_n + a.sc.s[3] * rm.gamma;
     if constexpr (sparse) {
         if (lane == 0 && mask != m_old) a.hmask[p0 >> 6] = mask;
