@@ -206,8 +206,7 @@ class Workload:
     """One law on n synthetic device-resident points: the committed state, two Newton iterates of the
     gradient, the trial arrays, and the launch every timed step issues."""
 
-    def __init__(self, name, n, seed, device, dev_index, history="packed", sparse_tangent=False, grid=0, delta_history=False,
-                 split_history=True):
+    def __init__(self, name, n, seed, device, dev_index, history="packed", sparse_tangent=False, grid=0, split_history=True):
         import torch
 
         self.torch = torch
@@ -237,15 +236,10 @@ class Workload:
         self.plasticity = self.kind in PLASTICITY
         self.sparse = self.plasticity and history in ("sparse", "packed")
         self.sparse_tangent = bool(sparse_tangent and self.sparse)
-        # VonMises3D under the sparse protocol: ResidentState keeps the INCREMENT of eps_n in the trial array during the
-        # Newton iterations (FCAMD_EVAL_DELTA_HISTORY) and adds it to the committed array at the commit.  That moves a
-        # part of the reference evaluate's work (eps_n += gamma N) out of the launch, so it is never part of the timed
-        # steps of the default line -- it is measured after them and reported next to the headline, commit included.
         # comfe-rs plasticity laws under the sparse protocol: ResidentState keeps their [scalar, eps_p(6)] history rows as
         # two arrays (FCAMD_EVAL_SPLIT_HISTORY) -- an internal layout of the device-resident state, same results
         self.split = bool(split_history and self.sparse and self.kind in ("comfe_mises_plasticity", "comfe_drucker_prager"))
-        self.delta_key = "eps_n" if self.kind == "von_mises_3d" else ("rows" if self.split else None)  # the write-only plastic-strain array
-        self.delta = bool(delta_history and self.sparse and self.delta_key is not None)
+        self.rows_key = "eps_n" if self.kind == "von_mises_3d" else ("rows" if self.split else None)  # the array that only accumulates plastic strain
         if self.split:
             from fenics_constitutive_amd.device import split_history_rows
 
@@ -255,13 +249,13 @@ class Workload:
         # accumulates): committed and trial copy hold the rows of the ever-plastic points of every tile as one contiguous run,
         # one EVER-mask word per tile next to each; the commit stays a pointer swap.  Same values, same launch, same bytes
         # asked of the interface -- only the rows move as full lines instead of isolated 48-byte pieces.
-        self.packed = bool(self.sparse and history == "packed" and self.delta_key is not None and not self.delta)
+        self.packed = bool(self.sparse and history == "packed" and self.rows_key is not None)
         self.ever_c = self.ever_t = None
-        self._plain = None  # unpacked twin of the history arrays for the legs that run another protocol (full / delta)
+        self._plain = None  # unpacked twin of the history arrays for the legs that run another protocol (full / unpacked sparse)
         if self.packed:
             from fenics_constitutive_amd.device import pack_rows
 
-            self.hist_c[self.delta_key], self.ever_c = pack_rows(self.hist_c[self.delta_key])
+            self.hist_c[self.rows_key], self.ever_c = pack_rows(self.hist_c[self.rows_key])
             self.ever_t = self.ever_c.clone()
         self.hmask = None
         if self.sparse:
@@ -272,11 +266,10 @@ class Workload:
         self._vmm, self.vmm_info = None, None
         self.n_pl_ab, self.its_ab = [0, 0], [0, 0]
 
-    def launch(self, i, tangent=None, full_history=False, sparse_tangent=None, delta_history=None, m=None, unpacked=False):
+    def launch(self, i, tangent=None, full_history=False, sparse_tangent=None, m=None, unpacked=False):
         """`m`: evaluate the first m points of the arrays only (the strong-scaling leg of a weak-scaling run)"""
-        delta = self.delta if delta_history is None else delta_history
         tan = self.tangent if tangent is None else tangent
-        packed = self.packed and not full_history and not delta and not unpacked
+        packed = self.packed and not full_history and not unpacked
         hist_c, hist_t, hmask = self.hist_c, self.hist_t, self.hmask
         if self.packed and not packed:  # another protocol on this workload: it needs the plain layout of the same state
             hist_c, hist_t, hmask = self.plain_twin()
@@ -296,16 +289,16 @@ class Workload:
         self.law.evaluate_from(0.0, self.del_t, g, sc, st, tan, hc, ht,
                                history_mask=None if full_history else mask,
                                sparse_tangent=self.sparse_tangent if sparse_tangent is None else sparse_tangent,
-                               delta_history=bool(delta and not full_history), split_history=self.split, packed_masks=pm)
+                               split_history=self.split, packed_masks=pm)
 
     def plain_twin(self):
         """(committed history, trial history, mask) of this packed workload in the PLAIN layout -- built on first use, for the
-        legs that time another protocol on the same state (full trial history, delta trial history)"""
+        legs that time another protocol on the same state (full trial history, the sparse protocol on the reference's layout)"""
         if self._plain is None:
             from fenics_constitutive_amd.device import unpack_rows
 
             hc = dict(self.hist_c)
-            hc[self.delta_key] = unpack_rows(self.hist_c[self.delta_key], self.ever_c, self.n)
+            hc[self.rows_key] = unpack_rows(self.hist_c[self.rows_key], self.ever_c, self.n)
             ht = {k: v.clone() for k, v in hc.items()}
             self._plain = (hc, ht, self.torch.zeros_like(self.hmask))
         return self._plain
@@ -322,22 +315,6 @@ class Workload:
         from fenics_constitutive_amd.device import join_history_rows
 
         return {"history": join_history_rows(hist_c)}
-
-    def time_delta_protocol(self, launches=6):
-        """ResidentState's delta trial history on this workload: the evaluate launches with the flag (two alternating
-        iterates) and the commit kernel that adds the increments of the plastic points to the committed eps_n."""
-        torch = self.torch
-        self.launch(0, delta_history=True), self.launch(1, delta_history=True)
-        self.launch_log.append(["delta_trial_history_warm", 2])
-        ms = self.timed_events(launches, phase="delta_trial_history", delta_history=True)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
-        for a, b in ev:  # the commit is idempotent in cost (same mask every time); its effect on eps_n does not matter any more
-            a.record()
-            hc, ht, hm = self.plain_twin() if self.packed else (self.hist_c, self.hist_t, self.hmask)
-            self.law.commit_delta_history(hc[self.delta_key], ht[self.delta_key], hm)
-            b.record()
-        torch.cuda.synchronize()
-        return sum(ms) / len(ms), min(a.elapsed_time(b) for a, b in ev[1:])
 
     def tune_placement(self, tries):
         """hipMalloc placements of the tangent (the dominant write stream): a few candidate allocations, the
@@ -483,7 +460,6 @@ class Workload:
                 f"committed->trial evaluate of two alternating Newton iterates"
                 f"{', sparse trial history (ResidentState protocol)' if self.sparse else (', full trial history' if self.plasticity else '')}"
                 f"{', plastic-strain rows of both state copies packed per tile (ResidentState default; commit = pointer swap)' if self.packed else ''}"
-                f"{', eps_n kept as increment during the iterations (delta trial history)' if self.delta else ''}"
                 f"{', history kept as [scalar, eps_p rows] in the state (split history)' if self.split else ''}"
                 f"{', sparse tangent (rows of points that stay elastic are not rewritten)' if self.sparse_tangent else ''}")
 
@@ -495,8 +471,8 @@ class Workload:
 
 def traffic_key(wl):
     """key of a workload's PMC measurement in profiles/traffic.json: the packed layout is the default of every law that has it"""
-    unpacked = wl.sparse and wl.delta_key is not None and not wl.packed and not wl.delta
-    return wl.name + ("_full" if wl.plasticity and not wl.sparse else "") + ("_delta" if wl.delta else "") + ("_unpacked" if unpacked else "")
+    unpacked = wl.sparse and wl.rows_key is not None and not wl.packed
+    return wl.name + ("_full" if wl.plasticity and not wl.sparse else "") + ("_unpacked" if unpacked else "")
 
 
 def placement_fracs(wl, alg0):
@@ -514,9 +490,9 @@ def placement_fracs(wl, alg0):
     return out
 
 
-def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="packed", placement="auto", cpu=True, delta_history=False):
+def run_config(name, n, seed, device, dev_index, steps, warmup, tries, history="packed", placement="auto", cpu=True):
     """One extra configuration, same method as the headline: placement, warm up, count, >= 5 event-timed launches."""
-    wl = Workload(name, n, seed, device, dev_index, history=history, delta_history=delta_history)
+    wl = Workload(name, n, seed, device, dev_index, history=history)
     try:
         wl.place(placement, tries)
         wl.warmup(warmup)
@@ -1102,11 +1078,6 @@ def main():
                          "the commit stays a pointer swap); sparse = the same protocol on the reference's array layout "
                          "(ResidentState(packed_history=False)); full = every launch rewrites the whole trial history")
     ap.add_argument("--sparse-history", action="store_true", help="same as --history sparse (kept for old command lines)")
-    ap.add_argument("--delta-history", action="store_true",
-                    help="VonMises3D, --history sparse: run the TIMED steps with ResidentState's delta trial history (the trial eps_n "
-                         "array receives the increment, the committed rows are not read; the accumulation happens at the commit).  Not "
-                         "the reference's evaluate -- never the default line; the default run measures it after the timed steps and "
-                         "reports it under \"delta_trial_history\" with the commit kernel's time")
     ap.add_argument("--no-split-history", action="store_true",
                     help="comfe-rs plasticity workloads: keep the reference's 7-double history rows in the state instead of "
                          "ResidentState's [scalar, eps_p rows] layout (FCAMD_EVAL_SPLIT_HISTORY)")
@@ -1221,7 +1192,7 @@ def main():
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         return bool(int(f.item()))
     wl = Workload(name, n, seed=1234 + rank, device=device, dev_index=dev_index, history=history,
-                  sparse_tangent=args.sparse_tangent, grid=args.grid, delta_history=args.delta_history,
+                  sparse_tangent=args.sparse_tangent, grid=args.grid,
                   split_history=not args.no_split_history)
     tries = args.placement_tries
     if world > 1 and tries > 1:
@@ -1313,15 +1284,6 @@ def main():
         wl.launch_log.append(["sparse_unpacked_history_warm", 2])
         ms = wl.timed_events(6, phase="sparse_unpacked_history", unpacked=True, sparse_tangent=False)
         unpacked_ms = sum(ms) / len(ms)
-
-    # ... and ResidentState's delta trial history (VonMises3D): evaluate launches with the flag + the commit kernel
-    delta_fig = None
-    if wl.sparse and wl.delta_key is not None and not wl.delta:
-        try:
-            d_ms, c_ms = wl.time_delta_protocol()
-            delta_fig = (d_ms, c_ms)
-        except Exception:  # informational
-            delta_fig = None
 
     # "achievable" next to "peak" (SURVEY 8d): a plain device copy over half of the tangent array
     # (read + write counted)
@@ -1449,18 +1411,6 @@ def main():
                                               "frac": round(alg_bytes / (unpacked_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                               "note": "same step, same sparse protocol, plastic-strain arrays in the reference's layout "
                                                       "(--history sparse; isolated 48-byte rows instead of one run per tile)"}
-        if delta_fig is not None:
-            d_ms, c_ms = delta_fig
-            saved = kernel_avg_ms - d_ms
-            out["delta_trial_history"] = {
-                "evaluate_kernel_ms_avg": round(d_ms, 4), "commit_kernel_ms": round(c_ms, 4),
-                "frac_equivalent": round(alg_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "break_even_newton_iterations": None if saved <= 0 else round(c_ms / saved, 2),
-                "note": "ResidentState(delta_history=True / 'auto') (FCAMD_EVAL_DELTA_HISTORY; an option, not the default): during the Newton iterations the "
-                        "trial plastic-strain array receives only the increments of the plastic points, packed per tile, and the committed rows are "
-                        "not read; update() adds the increments to the committed array (commit kernel, once per increment).  The launch then does "
-                        "less than the reference's evaluate, so it is not the timed step; frac_equivalent divides the interface's bytes by its time; "
-                        "'auto' switches it on from ResidentState.DELTA_MIN_ITERATIONS evaluates per increment"}
         out["placement"] = dict(headline["vmm_info"] or {"mode": "hipmalloc_tuned" if headline["placement"] else "first"})
         if headline["placement"] is not None:
             out["placement"].update({"hipmalloc_tangent_" + k: v for k, v in headline["placement"].items()})
@@ -1534,8 +1484,7 @@ def main():
                 configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
                                             min(tries, 4), history=history,
                                             placement="tune" if (args.placement == "auto" and under_profiler()) else args.placement,
-                                            cpu=not args.no_cpu_baseline,
-                                            delta_history=args.delta_history)
+                                            cpu=not args.no_cpu_baseline)
             except Exception as e:  # one configuration failing must not lose the line
                 configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
@@ -1604,7 +1553,7 @@ def main():
         if world == 1 and not args.no_live_traffic and budget_left() > 100:
             # roofline.traffic measured in THIS run (the kernels' memory is free by now); the stored figure stays next to it
             checkpoint("live_traffic")
-            extra = (["--delta-history"] if args.delta_history else []) + (["--no-split-history"] if args.no_split_history else []) \
+            extra = (["--no-split-history"] if args.no_split_history else []) \
                 + (["--sparse-tangent"] if args.sparse_tangent else [])
             torch.cuda.empty_cache()
             lt = live_traffic(name, n, history, extra, min(120.0, budget_left() - 45.0))

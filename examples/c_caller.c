@@ -48,7 +48,7 @@ int main(void) {
     /* contiguous 64-aligned slices of the point axis for 8 ranks (multi-GPU: every rank evaluates its own slice) */
     int64_t lo = 0, hi = 0, covered = 0;
     for (int r = 0; r < 8; ++r) {
-        CHECK(fcamd_shard_bounds(N, 8, r, &lo, &hi));
+        CHECK(fcamd_shard_bounds(N, 8, r, &lo, &hi, NULL));
         covered += hi - lo;
     }
     if (covered != N) return 4;

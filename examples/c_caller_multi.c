@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     fcamd_multi* mg = NULL;
     CHECK(fcamd_multi_create(devices, n_ctx, FCAMD_VON_MISES_3D, FCAMD_FULL, params, 5, &mg));
     int used = 0, mode = 0;
-    CHECK(fcamd_multi_plan(mg, N, &used));
+    CHECK(fcamd_multi_plan(mg, N, 0, &used, NULL, NULL));
     double* h2[2] = {e2, a2};
     CHECK(fcamd_multi_evaluate_host(mg, 0.0, 1.0, N, grad, s2, t2, h2, 2, &st2));
     CHECK(fcamd_multi_last_host_mode(mg, &mode, &used));

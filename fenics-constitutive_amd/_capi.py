@@ -27,45 +27,38 @@ COUNTER_SLOTS, COUNTER_WORDS = 64, 256  # FCAMD_COUNTER_SLOTS / FCAMD_COUNTER_WO
 
 # fcamd_eval_args.flags / fcamd_evaluate_resident flags (include/fcamd.h)
 EVAL_SPARSE_TANGENT = 1
-EVAL_DELTA_HISTORY = 2
 EVAL_SPLIT_HISTORY = 4
 EVAL_PACKED_HISTORY = 8
 
-# fcamd_context_last_host_mode flags (include/fcamd.h)
+# context option "last_host_mode": FCAMD_HOST_* flags (include/fcamd.h)
 HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT, HOST_TEMP_LOCK, HOST_BOUNCE = 1, 2, 4, 8
 
 # conversion kinds (include/fcamd.h)
 (GRAD_1D_TO_3D, STRESS_1D_TO_3D, STRESS_3D_TO_1D, TANGENT_3D_TO_1D,
  GRAD_2D_TO_3D, STRESS_2D_TO_3D, STRESS_3D_TO_2D, TANGENT_3D_TO_2D) = range(1, 9)
 
-#: every symbol include/fcamd.h declares (checked by tests/test_host_logic.py::test_library_exports_every_declared_symbol)
+#: every symbol include/fcamd.h exports (FCAMD_API; checked by tests/test_host_logic.py::test_library_exports_every_declared_symbol)
 SYMBOLS = [
-    "fcamd_context_create", "fcamd_context_destroy", "fcamd_context_set_stream",
-    "fcamd_context_synchronize", "fcamd_model_create", "fcamd_model_destroy",
-    "fcamd_model_history_count", "fcamd_model_history_field", "fcamd_model_constraint", "fcamd_model_dims",
-    "fcamd_evaluate_device",
-    "fcamd_evaluate_device_from", "fcamd_evaluate_device_from_sparse", "fcamd_evaluate_device_indexed", "fcamd_evaluate_device_ex",
-    "fcamd_commit_delta_history", "fcamd_evaluate_device_wrapped", "fcamd_evaluate_host", "fcamd_evaluate_resident", "fcamd_strain_from_grad_u_device",
-    "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats", "fcamd_register_host_buffer", "fcamd_unregister_host_buffer",
-    "fcamd_context_last_host_mode", "fcamd_host_device_pointer", "fcamd_copy_to_device", "fcamd_copy_to_host", "fcamd_copy_device",
-    "fcamd_shard_slot_points", "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_alloc", "fcamd_ipc_free",
-    "fcamd_ipc_export", "fcamd_ipc_open",
-    "fcamd_ipc_close", "fcamd_enable_peer_access", "fcamd_allgather_direct", "fcamd_allgather_direct_wait",
-    "fcamd_multi_create", "fcamd_multi_destroy", "fcamd_multi_device_count", "fcamd_multi_plan", "fcamd_multi_bounds",
-    "fcamd_multi_evaluate_host", "fcamd_multi_register_host_buffer", "fcamd_multi_unregister_host_buffer",
-    "fcamd_multi_last_host_mode", "fcamd_multi_set_option",
+    "fcamd_context_create", "fcamd_context_destroy", "fcamd_context_set_stream", "fcamd_context_synchronize",
+    "fcamd_model_create", "fcamd_model_destroy", "fcamd_model_get_info",
+    "fcamd_evaluate_host", "fcamd_evaluate_device_ex", "fcamd_evaluate_resident",
+    "fcamd_strain_from_grad_u_device", "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats",
+    "fcamd_register_host_buffer", "fcamd_unregister_host_buffer", "fcamd_host_device_pointer", "fcamd_copy",
+    "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_export", "fcamd_ipc_open", "fcamd_ipc_close",
+    "fcamd_allgather_direct", "fcamd_allgather_direct_wait",
+    "fcamd_multi_create", "fcamd_multi_destroy", "fcamd_multi_plan", "fcamd_multi_evaluate_host",
+    "fcamd_multi_register_host_buffer", "fcamd_multi_set_option", "fcamd_multi_get_option",
     "fcamd_multi_state_create", "fcamd_multi_state_destroy", "fcamd_multi_state_set", "fcamd_multi_state_get",
     "fcamd_multi_state_evaluate", "fcamd_multi_state_commit",
-    "fcamd_device_alloc_set", "fcamd_device_free",
-    "fcamd_context_set_grid", "fcamd_model_last_kernel_ms", "fcamd_context_set_timing",
-    "fcamd_context_set_option", "fcamd_context_get_option", "fcamd_context_trim",
-    "fcamd_last_error", "fcamd_status_string", "fcamd_version", "fcamd_device_count",
+    "fcamd_device_alloc_set", "fcamd_device_free", "fcamd_context_set_option", "fcamd_context_get_option",
+    "fcamd_device_count", "fcamd_last_error", "fcamd_version",
 ]
 
 IPC_HANDLE_BYTES = 64
 MULTI_MAX_DEVICES, MULTI_MIN_POINTS = 64, 8192  # FCAMD_MULTI_MAX_DEVICES / FCAMD_MULTI_MIN_POINTS
 GATHER_PULL = 1
-ALLOC_SEQUENTIAL, ALLOC_INTERLEAVED = 0, 1
+ALLOC_SEQUENTIAL, ALLOC_INTERLEAVED, ALLOC_IPC = 0, 1, 2
+COPY_TO_DEVICE, COPY_TO_HOST, COPY_DEVICE = 1, 2, 3
 
 
 class EvalArgs(C.Structure):
@@ -74,7 +67,15 @@ class EvalArgs(C.Structure):
     _fields_ = [("grad_del_u", C.c_void_p), ("stress_prev", C.c_void_p), ("stress", C.c_void_p),
                 ("tangent", C.c_void_p), ("history_prev", C.POINTER(C.c_void_p)), ("history", C.POINTER(C.c_void_p)),
                 ("n_hist", C.c_int), ("parent_rows", C.c_void_p), ("history_mask", C.c_void_p), ("flags", C.c_int), ("stress2", C.c_void_p),
-                ("counters", C.c_void_p), ("packed_mask_prev", C.c_void_p), ("packed_mask", C.c_void_p)]
+                ("counters", C.c_void_p), ("packed_mask_prev", C.c_void_p), ("packed_mask", C.c_void_p),
+                ("wrapper_constraint", C.c_int), ("stress_3d", C.c_void_p)]
+
+
+class ModelInfo(C.Structure):
+    """``fcamd_model_info``."""
+
+    _fields_ = [("model_id", C.c_int), ("constraint", C.c_int), ("stress_strain_dim", C.c_int), ("geometric_dim", C.c_int),
+                ("n_history", C.c_int), ("history_name", C.c_char_p * MAX_HISTORY), ("history_dim", C.c_int * MAX_HISTORY)]
 
 
 class Stats(C.Structure):
@@ -83,6 +84,7 @@ class Stats(C.Structure):
         ("n_plastic", C.c_uint64),
         ("n_newton_iters", C.c_uint64),
         ("n_domain", C.c_uint64),
+        ("kernel_ms", C.c_double),
     ]
 
 
@@ -135,24 +137,15 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_context_destroy.argtypes = [vp]
         lib.fcamd_context_set_stream.argtypes = [vp, vp]
         lib.fcamd_context_synchronize.argtypes = [vp]
-        lib.fcamd_context_set_grid.argtypes = [vp, C.c_int]
-        lib.fcamd_context_set_timing.argtypes = [vp, C.c_int]
         lib.fcamd_model_create.argtypes = [vp, C.c_int, C.c_int, dp, C.c_int, C.POINTER(vp)]
         lib.fcamd_model_destroy.argtypes = [vp]
-        lib.fcamd_model_history_count.argtypes = [vp, C.POINTER(C.c_int)]
-        lib.fcamd_model_history_field.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
-        lib.fcamd_model_constraint.argtypes = [vp, C.POINTER(C.c_int)]
-        lib.fcamd_model_dims.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.fcamd_model_get_info.argtypes = [vp, C.POINTER(ModelInfo)]
         i64p = C.POINTER(C.c_int64)
-        lib.fcamd_shard_slot_points.argtypes = [C.c_int64, C.c_int, i64p]
-        lib.fcamd_shard_bounds.argtypes = [C.c_int64, C.c_int, C.c_int, i64p, i64p]
+        lib.fcamd_shard_bounds.argtypes = [C.c_int64, C.c_int, C.c_int, i64p, i64p, i64p]
         lib.fcamd_gather_chunk_plan.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_size_t, C.c_int, i64p, i64p]
-        lib.fcamd_ipc_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
-        lib.fcamd_ipc_free.argtypes = [vp, vp]
         lib.fcamd_ipc_export.argtypes = [vp, vp, C.c_char_p, C.POINTER(C.c_size_t)]
         lib.fcamd_ipc_open.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp)]
         lib.fcamd_ipc_close.argtypes = [vp, vp, C.c_size_t]
-        lib.fcamd_enable_peer_access.argtypes = [vp, C.c_int]
         lib.fcamd_allgather_direct.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.c_size_t,
                                                C.c_size_t, C.c_size_t, C.c_int]
         lib.fcamd_allgather_direct_wait.argtypes = [vp, C.c_int]
@@ -160,40 +153,25 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_device_free.argtypes = [vp, vp]
         lib.fcamd_context_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
         lib.fcamd_context_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
-        lib.fcamd_context_trim.argtypes = [vp]
-        lib.fcamd_evaluate_device.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int]
-        lib.fcamd_evaluate_device_from.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int]
-        lib.fcamd_evaluate_device_from_sparse.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int, vp]
-        lib.fcamd_evaluate_device_indexed.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_host.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int, C.POINTER(Stats)]
         lib.fcamd_evaluate_device_ex.argtypes = [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs)]
-        lib.fcamd_commit_delta_history.argtypes = [vp, C.c_int64, vp, vp, vp]
-        lib.fcamd_evaluate_device_wrapped.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int64, vp, vp, vp, vp,
-                                                      C.POINTER(vp), C.c_int]
         lib.fcamd_evaluate_resident.argtypes = [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs), vp, vp, C.POINTER(Stats)]
         lib.fcamd_strain_from_grad_u_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int]
         lib.fcamd_convert_device.argtypes = [vp, C.c_int, C.c_int64, vp, vp]
         lib.fcamd_map_rows_device.argtypes = [vp, C.c_int64, C.c_int, vp, vp, vp, vp]
         lib.fcamd_model_last_stats.argtypes = [vp, C.POINTER(Stats)]
-        lib.fcamd_model_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         lib.fcamd_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
         lib.fcamd_unregister_host_buffer.argtypes = [vp, vp]
-        lib.fcamd_context_last_host_mode.argtypes = [vp, C.POINTER(C.c_int)]
         lib.fcamd_host_device_pointer.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
-        lib.fcamd_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
-        lib.fcamd_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
-        lib.fcamd_copy_device.argtypes = [vp, vp, vp, C.c_size_t]
+        lib.fcamd_copy.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
         ip = C.POINTER(C.c_int)
         lib.fcamd_multi_create.argtypes = [ip, C.c_int, C.c_int, C.c_int, dp, C.c_int, C.POINTER(vp)]
         lib.fcamd_multi_destroy.argtypes = [vp]
-        lib.fcamd_multi_device_count.argtypes = [vp, ip]
-        lib.fcamd_multi_plan.argtypes = [vp, C.c_int64, ip]
-        lib.fcamd_multi_bounds.argtypes = [vp, C.c_int64, C.c_int, i64p, i64p]
+        lib.fcamd_multi_plan.argtypes = [vp, C.c_int64, C.c_int, ip, i64p, i64p]
         lib.fcamd_multi_evaluate_host.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int, C.POINTER(Stats)]
         lib.fcamd_multi_register_host_buffer.argtypes = [vp, vp, C.c_size_t]
-        lib.fcamd_multi_unregister_host_buffer.argtypes = [vp, vp]
-        lib.fcamd_multi_last_host_mode.argtypes = [vp, ip, ip]
         lib.fcamd_multi_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+        lib.fcamd_multi_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
         lib.fcamd_multi_state_create.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(vp)]
         lib.fcamd_multi_state_destroy.argtypes = [vp]
         lib.fcamd_multi_state_set.argtypes = [vp, vp, C.POINTER(vp), C.c_int]
@@ -202,14 +180,26 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_multi_state_commit.argtypes = [vp]
         lib.fcamd_device_count.argtypes = [C.POINTER(C.c_int)]
         lib.fcamd_last_error.restype = C.c_char_p
-        lib.fcamd_status_string.restype = C.c_char_p
-        lib.fcamd_status_string.argtypes = [C.c_int]
         for name in SYMBOLS:
             f = getattr(lib, name)
-            if name not in ("fcamd_last_error", "fcamd_status_string"):
+            if name != "fcamd_last_error":
                 f.restype = C.c_int
         _lib = lib
         return lib
+
+
+#: the header's fcamd_status_string (a static inline there: no symbol to call)
+STATUS_STRINGS = {
+    OK: "ok", ERR_SIZE: "Stress, strain, and tangent lengths do not match", ERR_NULL_HISTORY: "history must not be None",
+    ERR_DEL_T: "Time step must be defined and positive.",
+    ERR_NONCONVERGED: "Newton-Raphson method did not converge for plastic multiplier.", ERR_HIP: "HIP runtime error",
+    ERR_BAD_ARG: "bad argument", ERR_ALIGN: "device arrays must be 16-byte aligned",
+    ERR_UNSUPPORTED: "constraint / layout not implemented", ERR_DOMAIN: "non-differentiable tip of Drucker-Prager surface reached",
+}
+
+
+def status_string(status: int) -> str:
+    return STATUS_STRINGS.get(int(status), "unknown status")
 
 
 def check(status: int) -> None:
@@ -218,7 +208,7 @@ def check(status: int) -> None:
     if status == OK:
         return
     lib = load()
-    detail = (lib.fcamd_last_error() or b"").decode() or lib.fcamd_status_string(status).decode()
+    detail = (lib.fcamd_last_error() or b"").decode() or status_string(status)
     if status in (ERR_SIZE, ERR_DEL_T):
         raise AssertionError(detail)
     if status == ERR_NULL_HISTORY:
@@ -251,10 +241,10 @@ class Context:
         check(self._lib.fcamd_context_synchronize(self.handle))
 
     def set_grid(self, n_workgroups: int) -> None:
-        check(self._lib.fcamd_context_set_grid(self.handle, int(n_workgroups)))
+        self.set_option("grid", int(n_workgroups))
 
     def set_timing(self, enabled: bool) -> None:
-        check(self._lib.fcamd_context_set_timing(self.handle, int(bool(enabled))))
+        self.set_option("timing", int(bool(enabled)))
 
     def set_option(self, name: str, value: int) -> None:
         """Launch / data-path knob (``fcamd_context_set_option``; the FCAMD_* environment variables are only
@@ -268,7 +258,7 @@ class Context:
 
     def trim(self) -> None:
         """Release the staging buffers of the pageable host path."""
-        check(self._lib.fcamd_context_trim(self.handle))
+        self.set_option("trim", 1)
 
     def register_host_buffer(self, arr: np.ndarray) -> None:
         check(self._lib.fcamd_register_host_buffer(self.handle, C.c_void_p(arr.ctypes.data), arr.nbytes))
@@ -286,32 +276,30 @@ class Context:
     def copy_to_device(self, dst_device_ptr: int, src: "np.ndarray") -> None:
         """``fcamd_copy_to_device``: synchronous, ordered after the context stream, never through the HIP
         runtime's pageable-copy path (include/fcamd.h)."""
-        check(self._lib.fcamd_copy_to_device(self.handle, C.c_void_p(dst_device_ptr), C.c_void_p(src.ctypes.data), src.nbytes))
+        check(self._lib.fcamd_copy(self.handle, C.c_void_p(dst_device_ptr), C.c_void_p(src.ctypes.data), src.nbytes, COPY_TO_DEVICE))
 
     def copy_device(self, dst_device_ptr: int, src_device_ptr: int, nbytes: int) -> None:
         """``fcamd_copy_device``: asynchronous device-to-device copy on the context stream (non-temporal, 16 B per lane)."""
-        check(self._lib.fcamd_copy_device(self.handle, C.c_void_p(dst_device_ptr), C.c_void_p(src_device_ptr), int(nbytes)))
+        check(self._lib.fcamd_copy(self.handle, C.c_void_p(dst_device_ptr), C.c_void_p(src_device_ptr), int(nbytes), COPY_DEVICE))
 
     def copy_to_host(self, dst: "np.ndarray", src_device_ptr: int) -> None:
-        check(self._lib.fcamd_copy_to_host(self.handle, C.c_void_p(dst.ctypes.data), C.c_void_p(src_device_ptr), dst.nbytes))
+        check(self._lib.fcamd_copy(self.handle, C.c_void_p(dst.ctypes.data), C.c_void_p(src_device_ptr), dst.nbytes, COPY_TO_HOST))
 
     def last_host_mode(self) -> int:
         """Data path of the last host-entry call (HOST_* flags): bit 0 = inputs, bit 1 = results moved by the kernel
         itself (zero copy on page-locked caller arrays), bit 2 = pageable caller arrays were page-locked for the call,
         bit 3 = moved by the CPU through the context's page-locked scratch; 0 = staged through device buffers."""
-        mode = C.c_int()
-        check(self._lib.fcamd_context_last_host_mode(self.handle, C.byref(mode)))
-        return int(mode.value)
+        return self.get_option("last_host_mode")
 
     # -- multi-GPU ----------------------------------------------------------------------------
     def ipc_alloc(self, nbytes: int) -> int:
-        """``fcamd_ipc_alloc``: device buffer whose size hipIpcOpenMemHandle can map (see include/fcamd.h)."""
-        out = C.c_void_p()
-        check(self._lib.fcamd_ipc_alloc(self.handle, int(nbytes), C.byref(out)))
-        return int(out.value)
+        """``fcamd_device_alloc_set(FCAMD_ALLOC_IPC)``: device buffer whose size hipIpcOpenMemHandle can map (see include/fcamd.h)."""
+        size, out = (C.c_size_t * 1)(int(nbytes)), (C.c_void_p * 1)()
+        check(self._lib.fcamd_device_alloc_set(self.handle, 1, size, 0, ALLOC_IPC, out))
+        return int(out[0])
 
     def ipc_free(self, device_ptr: int) -> None:
-        check(self._lib.fcamd_ipc_free(self.handle, C.c_void_p(device_ptr)))
+        check(self._lib.fcamd_device_free(self.handle, C.c_void_p(device_ptr)))
 
     def ipc_export(self, device_ptr: int) -> tuple[bytes, int]:
         """(64-byte handle of the allocation ``device_ptr`` lies in, offset of the pointer inside it)."""
@@ -329,7 +317,7 @@ class Context:
         check(self._lib.fcamd_ipc_close(self.handle, C.c_void_p(device_ptr), int(offset)))
 
     def enable_peer_access(self, peer_device: int) -> None:
-        check(self._lib.fcamd_enable_peer_access(self.handle, int(peer_device)))
+        self.set_option("peer_access", int(peer_device))
 
     def allgather_direct(self, world: int, rank: int, gathered_ptrs, slot_bytes: int, offset_bytes: int = 0,
                          nbytes: int | None = None, devices=None, pull: bool = False) -> None:
@@ -376,13 +364,13 @@ class Context:
 def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
     """``fcamd_shard_bounds``: [lo, hi) of rank's contiguous, 64-aligned slice of [0, n)."""
     lo, hi = C.c_int64(), C.c_int64()
-    check(load().fcamd_shard_bounds(int(n), int(world), int(rank), C.byref(lo), C.byref(hi)))
+    check(load().fcamd_shard_bounds(int(n), int(world), int(rank), C.byref(lo), C.byref(hi), None))
     return int(lo.value), int(hi.value)
 
 
 def shard_slot_points(n: int, world: int) -> int:
-    per = C.c_int64()
-    check(load().fcamd_shard_slot_points(int(n), int(world), C.byref(per)))
+    lo, hi, per = C.c_int64(), C.c_int64(), C.c_int64()
+    check(load().fcamd_shard_bounds(int(n), int(world), 0, C.byref(lo), C.byref(hi), C.byref(per)))
     return int(per.value)
 
 
@@ -473,12 +461,12 @@ class Multi:
     def plan(self, n: int) -> int:
         """number of devices a call over ``n`` points uses"""
         used = C.c_int()
-        check(self._lib.fcamd_multi_plan(self.handle, int(n), C.byref(used)))
+        check(self._lib.fcamd_multi_plan(self.handle, int(n), 0, C.byref(used), None, None))
         return int(used.value)
 
     def bounds(self, n: int, k: int) -> tuple[int, int]:
         lo, hi = C.c_int64(), C.c_int64()
-        check(self._lib.fcamd_multi_bounds(self.handle, int(n), int(k), C.byref(lo), C.byref(hi)))
+        check(self._lib.fcamd_multi_plan(self.handle, int(n), int(k), None, C.byref(lo), C.byref(hi)))
         return int(lo.value), int(hi.value)
 
     def evaluate_host(self, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, hist_ptrs) -> Stats:
@@ -492,13 +480,16 @@ class Multi:
         check(self._lib.fcamd_multi_register_host_buffer(self.handle, C.c_void_p(arr.ctypes.data), arr.nbytes))
 
     def unregister_host_buffer(self, arr: np.ndarray) -> None:
-        check(self._lib.fcamd_multi_unregister_host_buffer(self.handle, C.c_void_p(arr.ctypes.data)))
+        check(self._lib.fcamd_multi_register_host_buffer(self.handle, C.c_void_p(arr.ctypes.data), 0))  # bytes = 0: unregister
 
     def last_host_mode(self) -> tuple[int, int]:
         """(HOST_* flags OR-ed over the devices of the last call, number of devices it used)"""
-        mode, used = C.c_int(), C.c_int()
-        check(self._lib.fcamd_multi_last_host_mode(self.handle, C.byref(mode), C.byref(used)))
-        return int(mode.value), int(used.value)
+        return self.get_option("last_host_mode"), self.get_option("last_n_used")
+
+    def get_option(self, name: str) -> int:
+        v = C.c_longlong()
+        check(self._lib.fcamd_multi_get_option(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def set_option(self, name: str, value: int) -> None:
         check(self._lib.fcamd_multi_set_option(self.handle, name.encode(), int(value)))
@@ -568,27 +559,26 @@ class Model:
         check(self._lib.fcamd_model_create(ctx.handle, int(model_id), int(constraint),
                                            p.ctypes.data_as(C.POINTER(C.c_double)), p.size, C.byref(h)))
         self.handle = h
-        n = C.c_int()
-        check(self._lib.fcamd_model_history_count(h, C.byref(n)))
-        self.history_fields: list[tuple[str, int]] = []
-        for k in range(n.value):
-            name, dim = C.c_char_p(), C.c_int()
-            check(self._lib.fcamd_model_history_field(h, k, C.byref(name), C.byref(dim)))
-            self.history_fields.append((name.value.decode(), dim.value))
+        info = self.info()
+        self.history_fields: list[tuple[str, int]] = [(info.history_name[k].decode(), int(info.history_dim[k]))
+                                                      for k in range(info.n_history)]
+
+    def info(self) -> ModelInfo:
+        """``fcamd_model_get_info``: constraint, array widths per point, history fields."""
+        info = ModelInfo()
+        check(self._lib.fcamd_model_get_info(self.handle, C.byref(info)))
+        return info
 
     @property
     def constraint(self) -> int:
-        """``fcamd_model_constraint``: the StressStrainConstraint value of the handle."""
-        v = C.c_int()
-        check(self._lib.fcamd_model_constraint(self.handle, C.byref(v)))
-        return int(v.value)
+        """the StressStrainConstraint value of the handle"""
+        return int(self.info().constraint)
 
     @property
     def dims(self) -> tuple[int, int]:
-        """``fcamd_model_dims``: (stress_strain_dim, geometric_dim)."""
-        sd, gd = C.c_int(), C.c_int()
-        check(self._lib.fcamd_model_dims(self.handle, C.byref(sd), C.byref(gd)))
-        return int(sd.value), int(gd.value)
+        """(stress_strain_dim, geometric_dim)"""
+        i = self.info()
+        return int(i.stress_strain_dim), int(i.geometric_dim)
 
     def _ptr_array(self, ptrs):
         if not ptrs:
@@ -607,38 +597,32 @@ class Model:
 
     def evaluate_device(self, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, hist_ptrs,
                         stress_prev_ptr=None, hist_prev_ptrs=None) -> None:
-        arr, nh = self._ptr_array(hist_ptrs)
-        if stress_prev_ptr is None and hist_prev_ptrs is None:
-            check(self._lib.fcamd_evaluate_device(self.handle, float(t), float(del_t), int(n),
-                                                  C.c_void_p(grad_ptr), C.c_void_p(stress_ptr),
-                                                  C.c_void_p(tangent_ptr or 0), arr, nh))
-            return
-        parr, _ = self._ptr_array(hist_prev_ptrs if hist_prev_ptrs is not None else hist_ptrs)
-        check(self._lib.fcamd_evaluate_device_from(
-            self.handle, float(t), float(del_t), int(n), C.c_void_p(grad_ptr),
-            C.c_void_p(stress_prev_ptr if stress_prev_ptr is not None else stress_ptr),
-            C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), parr, arr, nh))
+        """in place, or -- with ``stress_prev_ptr`` / ``hist_prev_ptrs`` -- committed -> trial (the header's
+        fcamd_evaluate_device / fcamd_evaluate_device_from shorthands)"""
+        self.evaluate_device_ex(t, del_t, n, grad_ptr, stress_ptr if stress_prev_ptr is None else stress_prev_ptr, stress_ptr,
+                                tangent_ptr, hist_ptrs if hist_prev_ptrs is None else hist_prev_ptrs, hist_ptrs)
 
     def evaluate_device_ex(self, t, del_t, n, grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr, hist_prev_ptrs,
                            hist_ptrs, rows_ptr=None, mask_ptr=None, flags: int = 0, stress2_ptr=None,
-                           counters_ptr=None, packed_mask_ptrs=None) -> None:
+                           counters_ptr=None, packed_mask_ptrs=None, wrapper_constraint: int = 0, stress3d_ptr=None) -> None:
+        """``fcamd_evaluate_device_ex``: THE device entry, every form of the call in one argument struct"""
         arr, nh = self._ptr_array(hist_ptrs)
         parr, _ = self._ptr_array(hist_prev_ptrs)
         pm_prev, pm = packed_mask_ptrs or (None, None)
         x = EvalArgs(grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr or None, parr, arr, nh, rows_ptr or None,
-                     mask_ptr or None, int(flags), stress2_ptr or None, counters_ptr or None, pm_prev or None, pm or None)
+                     mask_ptr or None, int(flags), stress2_ptr or None, counters_ptr or None, pm_prev or None, pm or None,
+                     int(wrapper_constraint), stress3d_ptr or None)
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
-
-    def commit_delta_history(self, n, committed_ptr, delta_ptr, mask_ptr) -> None:
-        check(self._lib.fcamd_commit_delta_history(self.handle, int(n), C.c_void_p(committed_ptr), C.c_void_p(delta_ptr),
-                                                   C.c_void_p(mask_ptr)))
 
     def evaluate_device_wrapped(self, wrapper_constraint, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, stress3d_ptr,
                                 hist_ptrs) -> None:
+        """the fused 3D -> 1D/2D wrapper form (``wrapper_constraint`` + ``stress_3d`` of fcamd_eval_args), in place"""
+        if n > 0 and not stress3d_ptr:
+            raise ValueError("stress_3d is NULL")
         arr, nh = self._ptr_array(hist_ptrs)
-        check(self._lib.fcamd_evaluate_device_wrapped(
-            self.handle, int(wrapper_constraint), float(t), float(del_t), int(n), C.c_void_p(grad_ptr),
-            C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), C.c_void_p(stress3d_ptr), arr, nh))
+        x = EvalArgs(grad_ptr, stress_ptr, stress_ptr, tangent_ptr or None, arr, arr, nh, None, None, 0, None, None, None, None,
+                     int(wrapper_constraint) or -1, stress3d_ptr or None)
+        check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
 
     def evaluate_resident(self, t, del_t, n, grad_host_ptr, stress_prev_ptr, stress_ptr, hist_prev_ptrs, hist_ptrs,
                           mask_ptr, stress_host_ptr, tangent_host_ptr, flags: int = 0, packed_mask_ptrs=None) -> Stats:
@@ -646,7 +630,7 @@ class Model:
         parr, _ = self._ptr_array(hist_prev_ptrs)
         pm_prev, pm = packed_mask_ptrs or (None, None)
         x = EvalArgs(grad_host_ptr, stress_prev_ptr, stress_ptr, None, parr, arr, nh, None, mask_ptr or None, int(flags), None, None,
-                     pm_prev or None, pm or None)
+                     pm_prev or None, pm or None, 0, None)
         st = Stats()
         status = self._lib.fcamd_evaluate_resident(self.handle, float(t), float(del_t), int(n), C.byref(x),
                                                    C.c_void_p(stress_host_ptr or 0), C.c_void_p(tangent_host_ptr or 0), C.byref(st))
@@ -655,19 +639,17 @@ class Model:
 
     def evaluate_device_from_sparse(self, t, del_t, n, grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr,
                                     hist_prev_ptrs, hist_ptrs, mask_ptr) -> None:
-        arr, nh = self._ptr_array(hist_ptrs)
-        parr, _ = self._ptr_array(hist_prev_ptrs)
-        check(self._lib.fcamd_evaluate_device_from_sparse(
-            self.handle, float(t), float(del_t), int(n), C.c_void_p(grad_ptr), C.c_void_p(stress_prev_ptr),
-            C.c_void_p(stress_ptr), C.c_void_p(tangent_ptr or 0), parr, arr, nh, C.c_void_p(mask_ptr)))
+        if n > 0 and not mask_ptr:
+            raise ValueError("history_mask is NULL")
+        self.evaluate_device_ex(t, del_t, n, grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr, hist_prev_ptrs, hist_ptrs,
+                                mask_ptr=mask_ptr)
 
     def evaluate_device_indexed(self, t, del_t, n, grad_ptr, stress_prev_parent_ptr, stress_parent_ptr,
                                 tangent_parent_ptr, rows_ptr, hist_prev_ptrs, hist_ptrs) -> None:
-        arr, nh = self._ptr_array(hist_ptrs)
-        parr, _ = self._ptr_array(hist_prev_ptrs)
-        check(self._lib.fcamd_evaluate_device_indexed(
-            self.handle, float(t), float(del_t), int(n), C.c_void_p(grad_ptr), C.c_void_p(stress_prev_parent_ptr),
-            C.c_void_p(stress_parent_ptr), C.c_void_p(tangent_parent_ptr or 0), C.c_void_p(rows_ptr), parr, arr, nh))
+        if n > 0 and not rows_ptr:
+            raise ValueError("parent_rows is NULL")
+        self.evaluate_device_ex(t, del_t, n, grad_ptr, stress_prev_parent_ptr, stress_parent_ptr, tangent_parent_ptr,
+                                hist_prev_ptrs, hist_ptrs, rows_ptr=rows_ptr)
 
     def last_stats(self) -> Stats:
         st = Stats()
@@ -675,9 +657,11 @@ class Model:
         return st
 
     def last_kernel_ms(self) -> float:
-        ms = C.c_float()
-        check(self._lib.fcamd_model_last_kernel_ms(self.handle, C.byref(ms)))
-        return float(ms.value)
+        """time of the model's last entry (context option "timing"): ``fcamd_stats.kernel_ms`` of ``fcamd_model_last_stats``"""
+        ms = float(self.last_stats().kernel_ms)
+        if ms < 0.0:
+            raise ValueError("timing was not enabled for the last launch")
+        return ms
 
     def close(self) -> None:
         if self.handle:

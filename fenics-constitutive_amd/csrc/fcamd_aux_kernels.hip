@@ -1,5 +1,5 @@
 // Auxiliary kernels of libfcamd, everything that is not the constitutive update itself: the device copy behind
-// fcamd_copy_device, the commit of a delta trial history, strain_from_grad_u, the component maps of the 3D <-> 1D/2D
+// fcamd_copy_device, strain_from_grad_u, the component maps of the 3D <-> 1D/2D
 // wrappers, the row gather / scatter of the submesh maps.  Kept out of fcamd_kernels.hip so that the hash that ties PMC
 // traffic figures to the EVALUATE kernels (_build.kernel_hash) does not move with them.
 #include <hip/hip_runtime.h>
@@ -39,71 +39,6 @@ __global__ void __launch_bounds__(kCopyBlock) stream_copy_kernel(const d2* __res
 hipError_t launch_stream_copy(void* dst, const void* src, size_t n16, int grid, hipStream_t stream) {
     if (n16 == 0) return hipSuccess;
     hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(kCopyBlock), 0, stream, static_cast<const d2*>(src), static_cast<d2*>(dst), n16);
-    return hipGetLastError();
-}
-
-// Commit of a delta trial history (kFlagDeltaHistory): committed[row] += increment for the rows whose bit is set in the
-// tile's mask word (the plastic set of the last evaluate); the increments lie PACKED at the head of the tile's slot of
-// `delta` (kernels/history_rows.h: delta_rows_store), so they are read as one contiguous run per tile -- only the
-// committed rows are scattered accesses.  One wave per 64-point tile, 16-byte chunks: chunk q of the tile belongs to row
-// q / 3; the ragged last tile with guarded 8-byte accesses.
-constexpr int kCommitDenseMin = 20;
-
-__global__ void __launch_bounds__(kBlock)
-    commit_delta_kernel(double* committed, const double* delta, const unsigned long long* hmask, long long n) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const long long ntiles = (n + kWave - 1) / kWave;
-    const long long nfull = n / kWave;
-    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
-    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += wstride) {
-        const unsigned long long m = hmask[tile];
-        if (m == 0ull) continue;
-        const long long base = tile * kWave * 6;
-        if (tile < nfull) {
-            // Tiles with many plastic rows rewrite the whole 3 KiB slot of the committed array (untouched rows with the values
-            // they have): holes turn full-line writes into partial ones, the same trade as the row-masked history access of
-            // the evaluate kernels (kCommitDenseMin = their threshold).
-            const bool dense = (int)__popcll(m) > kCommitDenseMin;
-            d2 c[3], d[3];
-            bool hit[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {  // all loads of the tile first, then the stores
-                const int q = k * kWave + lane;
-                const int p = q / 3;
-                hit[k] = ((m >> p) & 1ull) != 0ull;
-                if (dense || hit[k]) c[k] = load16<true>(committed + base + 2 * q);
-                if (hit[k]) {
-                    const int rank = (int)__popcll(m & ((1ull << p) - 1ull));
-                    d[k] = load16<true>(delta + base + 2 * (3 * rank + (q - 3 * p)));
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (dense || hit[k]) {
-                    d2 r = c[k];
-                    if (hit[k]) {
-                        r.x = c[k].x + d[k].x;
-                        r.y = c[k].y + d[k].y;
-                    }
-                    store16<true>(committed + base + 2 * (k * kWave + lane), r);
-                }
-            }
-        } else {
-            const int npts = (int)(n - tile * kWave);
-            if (lane < npts && ((m >> lane) & 1ull)) {
-                const int rank = (int)__popcll(m & ((1ull << lane) - 1ull));
-#pragma unroll
-                for (int i = 0; i < 6; ++i) committed[base + 6 * lane + i] = committed[base + 6 * lane + i] + delta[base + 6 * rank + i];
-            }
-        }
-    }
-}
-
-hipError_t launch_commit_delta(double* committed, const double* delta, const unsigned long long* hmask, long long n, int grid,
-                               hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(commit_delta_kernel, dim3(grid), dim3(kBlock), 0, stream, committed, delta, hmask, n);
     return hipGetLastError();
 }
 

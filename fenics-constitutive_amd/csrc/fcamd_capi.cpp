@@ -397,9 +397,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.flags = split ? FCAMD_EVAL_SPLIT_HISTORY : 0;
     if (hmask) {
         if (tangent) a.flags |= flags & FCAMD_EVAL_SPARSE_TANGENT;  // needs an array that holds the previous tangent
-        if (m->law == FCAMD_VON_MISES_3D || split) a.flags |= flags & FCAMD_EVAL_DELTA_HISTORY;  // needs plastic-strain rows of their own
         if ((m->law == FCAMD_VON_MISES_3D || split) && emask_prev && emask && !rows) a.flags |= flags & FCAMD_EVAL_PACKED_HISTORY;
-        if (a.flags & FCAMD_EVAL_PACKED_HISTORY) a.flags &= ~FCAMD_EVAL_DELTA_HISTORY;  // the packed layout replaces it
     }
     a.emask_in = emask_prev;
     a.emask_out = emask;
@@ -428,6 +426,7 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
 namespace fcamd {
 void sum_counters(const fcamd_model* m, fcamd_stats* out) {
     out->n_nonconverged = out->n_plastic = out->n_newton_iters = out->n_domain = 0;
+    out->kernel_ms = -1.0;  // fcamd_model_last_stats fills it
     for (int s = 0; s < fcamd::kCounterSlots; ++s) {
         out->n_nonconverged += m->h_counters[4 * s + 0];
         out->n_plastic += m->h_counters[4 * s + 1];
@@ -450,6 +449,9 @@ int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out) {
 }
 }  // namespace fcamd
 
+static int evaluate_wrapped(fcamd_model* m, int wrapper_constraint, double del_t, int64_t n, const double* grad_lo, double* stress_lo,
+                            double* tangent_lo, double* stress_3d, double* const* hist, int n_hist);
+
 extern "C" {
 
 int fcamd_version(void) { return FCAMD_VERSION_MAJOR * 1000 + FCAMD_VERSION_MINOR; }
@@ -465,22 +467,6 @@ int fcamd_device_count(int* count) {
 }
 
 const char* fcamd_last_error(void) { return g_last_error.c_str(); }
-
-const char* fcamd_status_string(int status) {
-    switch (status) {
-        case FCAMD_OK: return "ok";
-        case FCAMD_ERR_SIZE: return "inconsistent array sizes";
-        case FCAMD_ERR_NULL_HISTORY: return "history must not be None";
-        case FCAMD_ERR_DEL_T: return "Time step must be defined and positive.";
-        case FCAMD_ERR_NONCONVERGED: return "Newton-Raphson method did not converge for plastic multiplier.";
-        case FCAMD_ERR_HIP: return "HIP runtime error";
-        case FCAMD_ERR_BAD_ARG: return "bad argument";
-        case FCAMD_ERR_ALIGN: return "device pointer not 16-byte aligned";
-        case FCAMD_ERR_UNSUPPORTED: return "not implemented";
-        case FCAMD_ERR_DOMAIN: return "non-differentiable tip of Drucker-Prager surface reached";
-        default: return "unknown status";
-    }
-}
 
 int fcamd_context_create(int device, void* stream, fcamd_context** out) {
     if (!out) return fail(FCAMD_ERR_BAD_ARG, "out is NULL");
@@ -514,7 +500,7 @@ int fcamd_context_create(int device, void* stream, fcamd_context** out) {
     return FCAMD_OK;
 }
 
-int fcamd_context_trim(fcamd_context* c) {
+static int context_trim(fcamd_context* c) {
     if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
     std::lock_guard<std::recursive_mutex> lock(c->host_mu);
     HIP_TRY(hipSetDevice(c->device));
@@ -537,6 +523,10 @@ int fcamd_context_set_option(fcamd_context* c, const char* name, long long value
     else if (k == "zero_copy") o.zero_copy = value != 0;
     else if (k == "zero_copy_grad") o.zero_copy_grad = value != 0;
     else if (k == "bounce_max") o.bounce_max = std::max<long long>(0, value);
+    else if (k == "grid") c->grid_override = value > 0 ? (int)value : 0;
+    else if (k == "timing") c->timing = value != 0;
+    else if (k == "trim") return context_trim(c);
+    else if (k == "peer_access") return fcamd::enable_peer_access(c, (int)value);
     else return fail(FCAMD_ERR_BAD_ARG, "unknown option '%s'", name);
     return FCAMD_OK;
 }
@@ -553,6 +543,9 @@ int fcamd_context_get_option(fcamd_context* c, const char* name, long long* valu
     else if (k == "zero_copy") *value = o.zero_copy;
     else if (k == "zero_copy_grad") *value = o.zero_copy_grad;
     else if (k == "bounce_max") *value = o.bounce_max;
+    else if (k == "grid") *value = c->grid_override;
+    else if (k == "timing") *value = c->timing ? 1 : 0;
+    else if (k == "last_host_mode") *value = c->last_host_mode;
     else return fail(FCAMD_ERR_BAD_ARG, "unknown option '%s'", name);
     return FCAMD_OK;
 }
@@ -562,10 +555,7 @@ int fcamd_context_destroy(fcamd_context* c) {
     (void)hipSetDevice(c->device);
     {
         std::lock_guard<std::recursive_mutex> lock(c->host_mu);
-        forget_registered_ranges(c);
-        for (auto& kv : c->registered)
-            if (!kv.second.borrowed) (void)hipHostUnregister(kv.first);  // best effort
-        c->registered.clear();
+        release_registered_ranges(c);  // the page locks it shares: the last context to leave unlocks the pages
     }
     free_host_staging(c);
     for (int i = 0; i < fcamd_context::kSlots; ++i)
@@ -593,18 +583,6 @@ int fcamd_context_set_stream(fcamd_context* c, void* stream) {
 int fcamd_context_synchronize(fcamd_context* c) {
     if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return FCAMD_OK;
-}
-
-int fcamd_context_set_grid(fcamd_context* c, int n_workgroups) {
-    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
-    c->grid_override = n_workgroups > 0 ? n_workgroups : 0;
-    return FCAMD_OK;
-}
-
-int fcamd_context_set_timing(fcamd_context* c, int enabled) {
-    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
-    c->timing = enabled != 0;
     return FCAMD_OK;
 }
 
@@ -667,132 +645,43 @@ int fcamd_model_destroy(fcamd_model* m) {
     return FCAMD_OK;
 }
 
-int fcamd_model_history_count(const fcamd_model* m, int* n_fields) {
-    if (!m || !n_fields) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    *n_fields = m->info.n_hist;
+int fcamd_model_get_info(const fcamd_model* m, fcamd_model_info* info) {
+    if (!m || !info) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    std::memset(info, 0, sizeof(*info));
+    info->model_id = m->law;
+    info->constraint = m->constraint;
+    info->stress_strain_dim = m->dims.sd;
+    info->geometric_dim = m->dims.gdim;
+    info->n_history = m->info.n_hist;
+    for (int k = 0; k < m->info.n_hist && k < FCAMD_MAX_HISTORY; ++k) {
+        info->history_name[k] = m->info.hist[k].name;
+        info->history_dim[k] = m->info.hist[k].dim;
+    }
     return FCAMD_OK;
-}
-
-int fcamd_model_history_field(const fcamd_model* m, int k, const char** name, int* dim) {
-    if (!m || !name || !dim) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    if (k < 0 || k >= m->info.n_hist) return fail(FCAMD_ERR_BAD_ARG, "history field %d out of range", k);
-    *name = m->info.hist[k].name;
-    *dim = m->info.hist[k].dim;
-    return FCAMD_OK;
-}
-
-int fcamd_model_constraint(const fcamd_model* m, int* constraint) {
-    if (!m || !constraint) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    *constraint = m->constraint;
-    return FCAMD_OK;
-}
-
-int fcamd_model_dims(const fcamd_model* m, int* stress_strain_dim, int* geometric_dim) {
-    if (!m || !stress_strain_dim || !geometric_dim) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    *stress_strain_dim = m->dims.sd;
-    *geometric_dim = m->dims.gdim;
-    return FCAMD_OK;
-}
-
-int fcamd_evaluate_device_from(fcamd_model* m, double t, double del_t, int64_t n,
-                               const double* grad, const double* stress_prev, double* stress,
-                               double* tangent, const double* const* hist_prev,
-                               double* const* hist, int n_hist) {
-    (void)t;
-    int st = validate_call(m, del_t, n, grad, stress_prev, stress,
-                           reinterpret_cast<const void* const*>(hist_prev),
-                           reinterpret_cast<const void* const*>(hist), n_hist);
-    if (st != FCAMD_OK) return st;
-    if (!aligned16(grad) || !aligned16(stress) || !aligned16(stress_prev) || !aligned16(tangent))
-        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
-    for (int k = 0; k < m->info.n_hist; ++k)
-        if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
-            return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
-    fcamd_context* c = m->ctx;
-    HIP_TRY(hipSetDevice(c->device));
-    if ((st = timing_begin(m)) != FCAMD_OK) return st;
-    st = enqueue(m, del_t, n, grad, stress_prev, stress, tangent, hist_prev, hist, c->stream,
-                 !m->timed);
-    if (st != FCAMD_OK) return st;
-    return timing_end(m);
-}
-
-int fcamd_evaluate_device_indexed(fcamd_model* m, double t, double del_t, int64_t n,
-                                  const double* grad, const double* stress_prev_parent,
-                                  double* stress_parent, double* tangent_parent,
-                                  const int32_t* parent_rows, const double* const* hist_prev,
-                                  double* const* hist, int n_hist) {
-    (void)t;
-    int st = validate_call(m, del_t, n, grad, stress_prev_parent, stress_parent,
-                           reinterpret_cast<const void* const*>(hist_prev),
-                           reinterpret_cast<const void* const*>(hist), n_hist);
-    if (st != FCAMD_OK) return st;
-    if (m->constraint != FCAMD_FULL)
-        return fail(FCAMD_ERR_UNSUPPORTED, "the indexed form exists for StressStrainConstraint.FULL only");
-    if (n > 0 && !parent_rows) return fail(FCAMD_ERR_BAD_ARG, "parent_rows is NULL");
-    if (!aligned16(grad) || !aligned16(stress_parent) || !aligned16(stress_prev_parent) || !aligned16(tangent_parent))
-        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
-    for (int k = 0; k < m->info.n_hist; ++k)
-        if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
-            return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
-    fcamd_context* c = m->ctx;
-    HIP_TRY(hipSetDevice(c->device));
-    if ((st = timing_begin(m)) != FCAMD_OK) return st;
-    st = enqueue(m, del_t, n, grad, stress_prev_parent, stress_parent, tangent_parent, hist_prev, hist,
-                 c->stream, !m->timed, parent_rows);
-    if (st != FCAMD_OK) return st;
-    return timing_end(m);
-}
-
-int fcamd_evaluate_device_from_sparse(fcamd_model* m, double t, double del_t, int64_t n,
-                                      const double* grad, const double* stress_prev, double* stress,
-                                      double* tangent, const double* const* hist_prev,
-                                      double* const* hist, int n_hist, uint64_t* history_mask) {
-    (void)t;
-    int st = validate_call(m, del_t, n, grad, stress_prev, stress,
-                           reinterpret_cast<const void* const*>(hist_prev),
-                           reinterpret_cast<const void* const*>(hist), n_hist);
-    if (st != FCAMD_OK) return st;
-    if (!has_sparse_history(m->law))
-        return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
-    if (n > 0 && !history_mask) return fail(FCAMD_ERR_BAD_ARG, "history_mask is NULL");
-    if (!aligned16(grad) || !aligned16(stress) || !aligned16(stress_prev) || !aligned16(tangent))
-        return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
-    for (int k = 0; k < m->info.n_hist; ++k)
-        if (!aligned16(hist[k]) || !aligned16(hist_prev[k]))
-            return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
-    fcamd_context* c = m->ctx;
-    HIP_TRY(hipSetDevice(c->device));
-    if ((st = timing_begin(m)) != FCAMD_OK) return st;
-    st = enqueue(m, del_t, n, grad, stress_prev, stress, tangent, hist_prev, hist, c->stream, !m->timed, nullptr,
-                 reinterpret_cast<unsigned long long*>(history_mask));
-    if (st != FCAMD_OK) return st;
-    return timing_end(m);
 }
 
 int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, const fcamd_eval_args* x) {
     (void)t;
     if (!x) return fail(FCAMD_ERR_BAD_ARG, "args is NULL");
+    if (x->wrapper_constraint != 0) {  // the fused 3D -> 1D/2D wrapper form
+        if (x->parent_rows || x->history_mask || x->stress2 || x->counters || x->flags != 0)
+            return fail(FCAMD_ERR_UNSUPPORTED, "the fused wrapper form takes no parent_rows / history_mask / stress2 / counters / flags");
+        if (x->stress_prev != x->stress || (x->n_hist > 0 && x->history_prev != const_cast<const double* const*>(x->history)))
+            return fail(FCAMD_ERR_BAD_ARG, "the fused wrapper form is in place: stress_prev == stress, history_prev == history");
+        return evaluate_wrapped(m, x->wrapper_constraint, del_t, n, x->grad_del_u, x->stress, x->tangent, x->stress_3d, x->history, x->n_hist);
+    }
     int st = validate_call(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress,
                            reinterpret_cast<const void* const*>(x->history_prev),
                            reinterpret_cast<const void* const*>(x->history), x->n_hist, x->flags);
     if (st != FCAMD_OK) return st;
+    if (x->flags & ~(FCAMD_EVAL_SPARSE_TANGENT | FCAMD_EVAL_SPLIT_HISTORY | FCAMD_EVAL_PACKED_HISTORY))
+        return fail(FCAMD_ERR_UNSUPPORTED, "unknown FCAMD_EVAL_* flag in 0x%x (2, FCAMD_EVAL_DELTA_HISTORY of ABI 0.3, was removed in 0.4)", x->flags);
     if (x->parent_rows && m->constraint != FCAMD_FULL)
         return fail(FCAMD_ERR_UNSUPPORTED, "the indexed form exists for StressStrainConstraint.FULL only");
     if (x->history_mask && !has_sparse_history(m->law))
         return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
     if ((x->flags & FCAMD_EVAL_SPARSE_TANGENT) && (!x->history_mask || !x->tangent))
         return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_SPARSE_TANGENT needs history_mask and tangent");
-    if (x->flags & FCAMD_EVAL_DELTA_HISTORY) {
-        const bool split = (x->flags & FCAMD_EVAL_SPLIT_HISTORY) != 0 && has_split_history(m->law);
-        if (m->law != FCAMD_VON_MISES_3D && !split)
-            return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_DELTA_HISTORY exists for VonMises3D and, with FCAMD_EVAL_SPLIT_HISTORY, for the "
-                                               "comfe-rs plasticity laws (their plastic-strain rows are write-only)");
-        if (!x->history_mask) return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs history_mask");
-        const int kd = split ? 1 : 0;  // the array that accumulates plastic strain
-        if (x->history && x->history_prev && x->history[kd] == x->history_prev[kd])
-            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial plastic-strain array of its own");
-    }
     if ((x->flags & FCAMD_EVAL_PACKED_HISTORY) && n > 0) {
         const bool split = (x->flags & FCAMD_EVAL_SPLIT_HISTORY) != 0 && has_split_history(m->law);
         if (m->law != FCAMD_VON_MISES_3D && !split)
@@ -801,8 +690,6 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
         if (!x->history_mask || !x->packed_mask_prev || !x->packed_mask)
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs history_mask, packed_mask_prev and packed_mask");
         if (x->parent_rows) return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_PACKED_HISTORY: not with parent_rows");
-        if (x->flags & FCAMD_EVAL_DELTA_HISTORY)
-            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY and FCAMD_EVAL_DELTA_HISTORY exclude each other");
         const int kd = split ? 1 : 0;
         if (x->history[kd] == x->history_prev[kd] || x->packed_mask == x->packed_mask_prev)
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs trial plastic-strain and mask arrays of their own");
@@ -830,31 +717,10 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     return timing_end(m);
 }
 
-int fcamd_commit_delta_history(fcamd_model* m, int64_t n, double* history_committed0, const double* history_delta0,
-                               const uint64_t* history_mask) {
-    if (!m) return fail(FCAMD_ERR_BAD_ARG, "model handle is NULL");
-    if (!has_sparse_history(m->law))
-        return fail(FCAMD_ERR_UNSUPPORTED, "delta trial history exists for the plasticity laws only");
-    if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
-    if (n == 0) return FCAMD_OK;
-    if (!history_committed0 || !history_delta0 || !history_mask) return fail(FCAMD_ERR_BAD_ARG, "NULL array");
-    if (!aligned16(history_committed0) || !aligned16(history_delta0))
-        return fail(FCAMD_ERR_ALIGN, "device history arrays must be 16-byte aligned");
-    fcamd_context* c = m->ctx;
-    HIP_TRY(hipSetDevice(c->device));
-    int grid = c->grid_override > 0 ? c->grid_override : c->num_cu * 16;
-    const int64_t need = ((n + 63) / 64 + 3) / 4;
-    if (need < grid) grid = (int)std::max<int64_t>(need, 1);
-    (void)hipGetLastError();  // as in enqueue()
-    HIP_TRY(launch_commit_delta(history_committed0, history_delta0, reinterpret_cast<const unsigned long long*>(history_mask), n,
-                                grid, c->stream));
-    return FCAMD_OK;
-}
+}  // extern "C"
 
-int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double t, double del_t, int64_t n,
-                                  const double* grad_lo, double* stress_lo, double* tangent_lo,
-                                  double* stress_3d, double* const* hist, int n_hist) {
-    (void)t;
+static int evaluate_wrapped(fcamd_model* m, int wrapper_constraint, double del_t, int64_t n, const double* grad_lo, double* stress_lo,
+                            double* tangent_lo, double* stress_3d, double* const* hist, int n_hist) {
     int st = validate_call(m, del_t, n, grad_lo, stress_lo, stress_lo,
                            reinterpret_cast<const void* const*>(hist),
                            reinterpret_cast<const void* const*>(hist), n_hist);
@@ -901,28 +767,22 @@ int fcamd_evaluate_device_wrapped(fcamd_model* m, int wrapper_constraint, double
     return timing_end(m);
 }
 
-int fcamd_evaluate_device(fcamd_model* m, double t, double del_t, int64_t n, const double* grad,
-                          double* stress, double* tangent, double* const* hist, int n_hist) {
-    return fcamd_evaluate_device_from(m, t, del_t, n, grad, stress, stress, tangent,
-                                      const_cast<const double* const*>(hist), hist, n_hist);
-}
+extern "C" {
 
 int fcamd_model_last_stats(fcamd_model* m, fcamd_stats* stats) {
     if (!m || !stats) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(m->ctx->device));
-    return read_stats(m, m->ctx->stream, stats);
-}
-
-int fcamd_model_last_kernel_ms(fcamd_model* m, float* ms) {
-    if (!m || !ms) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    const int st = read_stats(m, m->ctx->stream, stats);
+    if (st != FCAMD_OK) return st;
+    stats->kernel_ms = -1.0;
     if (m->host_ms >= 0.0f) {  // the last entry was a (synchronous) host entry: its wall-clock
-        *ms = m->host_ms;
-        return FCAMD_OK;
+        stats->kernel_ms = m->host_ms;
+    } else if (m->timed) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventSynchronize(m->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+        stats->kernel_ms = ms;
     }
-    if (!m->timed) return fail(FCAMD_ERR_BAD_ARG, "timing was not enabled for the last launch");
-    HIP_TRY(hipSetDevice(m->ctx->device));
-    HIP_TRY(hipEventSynchronize(m->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, m->ev0, m->ev1));
     return FCAMD_OK;
 }
 

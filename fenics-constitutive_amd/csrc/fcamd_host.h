@@ -78,7 +78,8 @@ struct fcamd_context {
     struct Pinned {
         size_t bytes;
         char* dev;
-        bool borrowed = false;  // page-locked by another context of the process (fcamd_multi): never unlocked from here
+        bool borrowed = false;  // entered after another context of the process had page-locked it (the lock itself is shared)
+        char* lock_base = nullptr;  // base of the process-wide page lock this entry holds a reference to (g_registered)
     };
     std::map<char*, Pinned> registered;
     // Guards `registered` and serialises the host entries with (un)registration: Python's garbage collector
@@ -139,6 +140,10 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 int validate_call(const fcamd_model* m, double del_t, int64_t n, const void* grad, const void* stress_prev,
                   const void* stress, const void* const* hist_prev, const void* const* hist, int n_hist, int flags = 0);
 
+// context option "peer_access" (fcamd_multigpu.cpp); rounded size of a buffer peers can map (hipIpcOpenMemHandle, see include/fcamd.h)
+int enable_peer_access(fcamd_context* c, int peer_device);
+size_t ipc_safe_alloc_size(size_t bytes);
+
 // one evaluate launch of `n` points on `stream` (fcamd_capi.cpp)
 int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev, double* stress,
             double* tangent, const double* const* hprev, double* const* hcur, hipStream_t stream, bool reset_counters,
@@ -164,7 +169,7 @@ void temp_lock_release(char* base);
 // `c`'s registry with the address c's device sees it at (never unlocked from `c`).
 int adopt_registered_range(fcamd_context* c, void* ptr, size_t bytes);
 // drop c's own registrations from the process-wide registry of registered ranges (context destruction)
-void forget_registered_ranges(fcamd_context* c);
+void release_registered_ranges(fcamd_context* c);
 
 // fcamd_aux_kernels.hip: dst = src over n16 16-byte chunks (non-temporal accesses, grid-stride)
 hipError_t launch_stream_copy(void* dst, const void* src, size_t n16, int grid, hipStream_t stream);

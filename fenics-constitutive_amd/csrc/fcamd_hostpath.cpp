@@ -106,8 +106,15 @@ int finish_single_stream(fcamd_model* m, fcamd_stats* stats) {
 // (g_temp, below) -- and is held across "look the range up in both, then hipHostRegister / hipHostUnregister": a thread
 // that registers an array while a host entry of another thread holds a call-scoped lock on it would otherwise lock it a
 // second time, and the end of that call would take the lock away.  Order: a context's host_mu first, g_pages_mu second.
+// A registered range is ONE page lock shared by every context that has entered it (round 4, ADVICE r3: the first context
+// used to own the lock and the others kept dangling entries when it let go): reference-counted, released by hipHostUnregister
+// when the last context leaves -- unregister, context destroy -- in any order.
 std::recursive_mutex g_pages_mu;
-std::map<char*, size_t> g_registered;
+struct SharedLock {
+    size_t bytes;
+    int refs;
+};
+std::map<char*, SharedLock> g_registered;
 
 struct TempLock {
     size_t bytes;
@@ -117,11 +124,26 @@ std::map<char*, TempLock> g_temp;  // host base -> page lock held by one or more
 
 void note_registered(char* base, size_t bytes) {
     std::lock_guard<std::recursive_mutex> g(g_pages_mu);
-    g_registered[base] = bytes;
+    g_registered[base] = {bytes, 1};
 }
-void forget_registered(char* base) {
+// one context leaves the shared page lock that starts at `base`; the last one unlocks the pages
+void release_registered(char* base) {
     std::lock_guard<std::recursive_mutex> g(g_pages_mu);
-    g_registered.erase(base);
+    auto it = g_registered.find(base);
+    if (it == g_registered.end()) return;
+    if (--it->second.refs > 0) return;
+    g_registered.erase(it);
+    if (hipHostUnregister(base) != hipSuccess) (void)hipGetLastError();  // best effort: the memory may be gone already
+}
+// base of the registered range that contains [q, q + bytes), taking a reference to it; nullptr if there is none
+char* share_registered(char* q, size_t bytes) {
+    std::lock_guard<std::recursive_mutex> g(g_pages_mu);
+    auto it = g_registered.upper_bound(q);
+    if (it == g_registered.begin()) return nullptr;
+    auto lo = std::prev(it);
+    if (q + bytes > lo->first + lo->second.bytes) return nullptr;
+    ++lo->second.refs;
+    return lo->first;
 }
 // does [q, q + bytes) touch a call-scoped page lock of a host entry in progress?
 bool overlaps_call_scoped_lock(char* q, size_t bytes) {
@@ -139,7 +161,7 @@ int in_process_registry(char* q, size_t bytes) {
     auto it = g_registered.upper_bound(q);
     if (it != g_registered.begin()) {
         auto lo = std::prev(it);
-        if (q < lo->first + lo->second) return q + bytes <= lo->first + lo->second ? 1 : -1;
+        if (q < lo->first + lo->second.bytes) return q + bytes <= lo->first + lo->second.bytes ? 1 : -1;
     }
     if (it != g_registered.end() && it->first < q + bytes) return -1;
     return 0;
@@ -149,21 +171,33 @@ int in_process_registry(char* q, size_t bytes) {
 
 namespace fcamd {
 
-void forget_registered_ranges(fcamd_context* c) {
+// a context is going away: it leaves every page lock it holds a reference to
+void release_registered_ranges(fcamd_context* c) {
     for (auto& kv : c->registered)
-        if (!kv.second.borrowed) forget_registered(kv.first);
+        if (kv.second.lock_base) release_registered(kv.second.lock_base);
+    c->registered.clear();
 }
 
 int adopt_registered_range(fcamd_context* c, void* ptr, size_t bytes) {
     if (!c || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     std::lock_guard<std::recursive_mutex> lock(c->host_mu);
     HIP_TRY(hipSetDevice(c->device));
+    {   // entered already (a repeated call): the old entry's reference goes back first
+        auto old = c->registered.find(static_cast<char*>(ptr));
+        if (old != c->registered.end()) {
+            if (old->second.lock_base) release_registered(old->second.lock_base);
+            c->registered.erase(old);
+        }
+    }
+    char* lock_base = share_registered(static_cast<char*>(ptr), bytes);
+    if (!lock_base) return fail(FCAMD_ERR_BAD_ARG, "the range is not inside one that a context of this process has registered");
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess) {
         (void)hipGetLastError();
+        release_registered(lock_base);
         return fail(FCAMD_ERR_HIP, "device %d cannot see the page-locked range", c->device);
     }
-    c->registered[static_cast<char*>(ptr)] = {bytes, static_cast<char*>(dev), true};
+    c->registered[static_cast<char*>(ptr)] = {bytes, static_cast<char*>(dev), true, lock_base};
     return FCAMD_OK;
 }
 
@@ -193,15 +227,13 @@ int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
         return fail(FCAMD_ERR_BAD_ARG, "a host call in progress on another thread holds a page lock on this range: register it when no evaluate runs on it");
     if (c->registered.count(base)) {
         // Same address again: either a repeated call or a NEW buffer that landed where a freed,
-        // still-registered one was.  Re-pin: a stale registration would DMA through old pages.
-        if (!c->registered[base].borrowed) {
-            (void)hipHostUnregister(ptr);
-            forget_registered(base);
-        }
+        // still-registered one was.  Leave the old lock (the last holder unlocks it) and pin again: a stale
+        // registration would DMA through old pages.
+        if (c->registered[base].lock_base) release_registered(c->registered[base].lock_base);
         c->registered.erase(base);
     }
     {   // page-locked already by another context of this process (one process driving several GPUs, several threads with a
-        // context each): this context enters the range with its own device's view of it and leaves the lock to its owner
+        // context each): this context enters the range with its own device's view of it and shares the page lock
         const int r = in_process_registry(base, bytes);
         if (r > 0) return adopt_registered_range(c, ptr, bytes);
         if (r < 0) return fail(FCAMD_ERR_BAD_ARG, "the range overlaps one that another context of this process has registered");
@@ -213,13 +245,7 @@ int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
         (void)hipGetLastError();
         dev = nullptr;  // page-locked but not mapped: DMA path only
     }
-    c->registered[base] = {dev ? bytes : 0, static_cast<char*>(dev)};
-    return FCAMD_OK;
-}
-
-int fcamd_context_last_host_mode(fcamd_context* c, int* mode) {
-    if (!c || !mode) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    *mode = c->last_host_mode;
+    c->registered[base] = {dev ? bytes : 0, static_cast<char*>(dev), false, base};
     return FCAMD_OK;
 }
 
@@ -240,12 +266,9 @@ int fcamd_unregister_host_buffer(fcamd_context* c, void* ptr) {
     auto it = c->registered.find(static_cast<char*>(ptr));
     if (it == c->registered.end()) return FCAMD_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const bool owner = !it->second.borrowed;
+    char* lock_base = it->second.lock_base;
     c->registered.erase(it);
-    if (owner) {
-        forget_registered(static_cast<char*>(ptr));
-        HIP_TRY(hipHostUnregister(ptr));
-    }
+    if (lock_base) release_registered(lock_base);  // the last context to leave unlocks the pages
     return FCAMD_OK;
 }
 
@@ -637,8 +660,8 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
                             double* stress_host, double* tangent_host, fcamd_stats* stats) {
     (void)t;
     if (!x) return fail(FCAMD_ERR_BAD_ARG, "state is NULL");
-    if (x->parent_rows || x->stress2 || x->tangent)
-        return fail(FCAMD_ERR_UNSUPPORTED, "fcamd_evaluate_resident: parent_rows / stress2 / a device tangent are options of fcamd_evaluate_device_ex");
+    if (x->parent_rows || x->stress2 || x->tangent || x->wrapper_constraint)
+        return fail(FCAMD_ERR_UNSUPPORTED, "fcamd_evaluate_resident: parent_rows / stress2 / a device tangent / the wrapper form are options of fcamd_evaluate_device_ex");
     const double* grad = x->grad_del_u;  // HOST array
     const double* stress_prev = x->stress_prev;
     double* stress = x->stress;
@@ -655,21 +678,13 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     if (st != FCAMD_OK) return st;
     if (history_mask && !has_sparse_history(m->law))
         return fail(FCAMD_ERR_UNSUPPORTED, "sparse trial history exists for the plasticity laws only");
-    if (flags & FCAMD_EVAL_DELTA_HISTORY) {  // as fcamd_evaluate_device_ex: increments must never land in the committed rows
-        if (!history_mask) return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs history_mask");
-        if (m->law != FCAMD_VON_MISES_3D && !((flags & FCAMD_EVAL_SPLIT_HISTORY) && has_split_history(m->law)))
-            return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_DELTA_HISTORY: VonMises3D, or a comfe-rs plasticity law with FCAMD_EVAL_SPLIT_HISTORY");
-        const int kd = (flags & FCAMD_EVAL_SPLIT_HISTORY) ? 1 : 0;  // the array that accumulates plastic strain
-        if (hist && hist_prev && hist[kd] == hist_prev[kd])
-            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_DELTA_HISTORY needs a trial plastic-strain array of its own");
-    }
+    if (flags & ~(FCAMD_EVAL_SPARSE_TANGENT | FCAMD_EVAL_SPLIT_HISTORY | FCAMD_EVAL_PACKED_HISTORY))
+        return fail(FCAMD_ERR_UNSUPPORTED, "unknown FCAMD_EVAL_* flag in 0x%x (2, FCAMD_EVAL_DELTA_HISTORY of ABI 0.3, was removed in 0.4)", flags);
     if (packed && n > 0) {  // as fcamd_evaluate_device_ex
         if (!history_mask || !emask_prev || !emask || emask == emask_prev)
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs history_mask and two mask arrays, packed_mask_prev and packed_mask");
         if (m->law != FCAMD_VON_MISES_3D && !((flags & FCAMD_EVAL_SPLIT_HISTORY) && has_split_history(m->law)))
             return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_PACKED_HISTORY: VonMises3D, or a comfe-rs plasticity law with FCAMD_EVAL_SPLIT_HISTORY");
-        if (flags & FCAMD_EVAL_DELTA_HISTORY)
-            return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY and FCAMD_EVAL_DELTA_HISTORY exclude each other");
         const int kd = (flags & FCAMD_EVAL_SPLIT_HISTORY) ? 1 : 0;
         if (hist && hist_prev && hist[kd] == hist_prev[kd])
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs a trial plastic-strain array of its own");
@@ -859,7 +874,7 @@ int host_copy(fcamd_context* c, char* dev, char* host, size_t bytes, bool to_dev
 
 extern "C" {
 
-int fcamd_copy_device(fcamd_context* c, void* dst_device, const void* src_device, size_t bytes) {
+static int copy_device(fcamd_context* c, void* dst_device, const void* src_device, size_t bytes) {
     if (!c || (bytes && (!dst_device || !src_device))) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     if (bytes == 0) return FCAMD_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -877,12 +892,13 @@ int fcamd_copy_device(fcamd_context* c, void* dst_device, const void* src_device
     return FCAMD_OK;
 }
 
-int fcamd_copy_to_device(fcamd_context* c, void* dst_device, const void* src_host, size_t bytes) {
-    return host_copy(c, static_cast<char*>(dst_device), static_cast<char*>(const_cast<void*>(src_host)), bytes, true);
-}
-
-int fcamd_copy_to_host(fcamd_context* c, void* dst_host, const void* src_device, size_t bytes) {
-    return host_copy(c, static_cast<char*>(const_cast<void*>(src_device)), static_cast<char*>(dst_host), bytes, false);
+int fcamd_copy(fcamd_context* c, void* dst, const void* src, size_t bytes, int kind) {
+    switch (kind) {
+        case FCAMD_COPY_TO_DEVICE: return host_copy(c, static_cast<char*>(dst), static_cast<char*>(const_cast<void*>(src)), bytes, true);
+        case FCAMD_COPY_TO_HOST: return host_copy(c, static_cast<char*>(const_cast<void*>(src)), static_cast<char*>(dst), bytes, false);
+        case FCAMD_COPY_DEVICE: return copy_device(c, dst, src, bytes);
+        default: return fail(FCAMD_ERR_BAD_ARG, "unknown copy kind %d", kind);
+    }
 }
 
 }  // extern "C"

@@ -55,7 +55,7 @@ struct EvalArgs {
     int tile_map;              // 0: tiles dealt round-robin to all waves; 1: one contiguous region per XCD
     int nontemporal;           // main kernel of the plain (non-indexed, non-sparse) form: non-temporal global accesses (default) or plain ones
     int masked_max;            // row-masked history access for tiles with at most this many touched rows (else dense)
-    int flags;                 // bit 0: sparse-tangent protocol (fcamd_kernels.hip: sparse_tangent_need); bit 1: delta trial history; bit 2: split history; bit 3: packed plastic-strain history
+    int flags;                 // bit 0: sparse-tangent protocol (fcamd_kernels.hip: sparse_tangent_need); bit 2: split history; bit 3: packed plastic-strain history
     Scalars sc;
     Tables tb;
 };
@@ -80,10 +80,6 @@ struct CopyMap {
     int imap[16], omap[16];
 };
 hipError_t launch_strided_copy(const double* in, double* out, long long n, const CopyMap& m,
-                               hipStream_t stream);
-
-// committed[row] += delta[row] for the rows of the mask (commit of a delta trial history, VonMises3D eps_n)
-hipError_t launch_commit_delta(double* committed, const double* delta, const unsigned long long* hmask, long long n, int grid,
                                hipStream_t stream);
 
 hipError_t launch_map_rows(const double* src, const int* src_idx, double* dst, const int* dst_idx,

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "fcamd_host.h"
@@ -30,6 +31,7 @@ struct VmmArray {
 
 std::mutex g_vmm_mu;
 std::unordered_map<void*, VmmArray> g_vmm;  // base address -> its mapping
+std::unordered_set<void*> g_plain;        // FCAMD_ALLOC_IPC blocks (plain hipMalloc)
 
 // returns the first HIP error met (everything is attempted regardless)
 hipError_t release(void* base, VmmArray& a) {
@@ -60,6 +62,22 @@ int fcamd_device_alloc_set(fcamd_context* c, int n_arrays, const size_t* bytes, 
                            void** ptrs) {
     if (!c || !bytes || !ptrs || n_arrays <= 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (order == FCAMD_ALLOC_IPC) {  // plain hipMalloc blocks that peers can map (fcamd_ipc_export)
+        for (int k = 0; k < n_arrays; ++k) ptrs[k] = nullptr;
+        for (int k = 0; k < n_arrays; ++k) {
+            if (bytes[k] == 0) continue;
+            const hipError_t e = hipMalloc(&ptrs[k], ipc_safe_alloc_size(bytes[k]));
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                for (int j = 0; j < k; ++j)
+                    if (ptrs[j]) (void)hipFree(ptrs[j]);
+                return fail(FCAMD_ERR_HIP, "hipMalloc of an IPC buffer of %zu bytes failed: %s", bytes[k], hipGetErrorString(e));
+            }
+            std::lock_guard<std::mutex> lock(g_vmm_mu);
+            g_plain.insert(ptrs[k]);
+        }
+        return FCAMD_OK;
+    }
     hipMemAllocationProp prop;
     std::memset(&prop, 0, sizeof(prop));
     prop.type = hipMemAllocationTypePinned;
@@ -160,6 +178,11 @@ int fcamd_device_free(fcamd_context* c, void* ptr) {
     VmmArray a;
     {
         std::lock_guard<std::mutex> lock(g_vmm_mu);
+        if (g_plain.erase(ptr)) {  // an FCAMD_ALLOC_IPC block
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipFree(ptr));  // waits for the device
+            return FCAMD_OK;
+        }
         auto it = g_vmm.find(ptr);
         if (it == g_vmm.end()) return fail(FCAMD_ERR_BAD_ARG, "pointer was not returned by fcamd_device_alloc_set");
         a = std::move(it->second);

@@ -238,23 +238,13 @@ int fcamd_multi_destroy(fcamd_multi* mg) {
     return FCAMD_OK;
 }
 
-int fcamd_multi_device_count(const fcamd_multi* mg, int* n_devices) {
-    if (!mg || !n_devices) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    *n_devices = (int)mg->w.size();
-    return FCAMD_OK;
-}
-
-int fcamd_multi_plan(const fcamd_multi* mg, int64_t n, int* n_used) {
-    if (!mg || !n_used) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
-    *n_used = mg->used_for(n);
-    return FCAMD_OK;
-}
-
-int fcamd_multi_bounds(const fcamd_multi* mg, int64_t n, int k, int64_t* lo, int64_t* hi) {
-    if (!mg || !lo || !hi) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+int fcamd_multi_plan(const fcamd_multi* mg, int64_t n, int k, int* n_used, int64_t* lo, int64_t* hi) {
+    if (!mg) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     if (n < 0) return fail(FCAMD_ERR_SIZE, "negative number of quadrature points");
     const int used = mg->used_for(n);
+    if (n_used) *n_used = used;
+    if (!lo && !hi) return FCAMD_OK;
+    if (!lo || !hi) return fail(FCAMD_ERR_BAD_ARG, "lo and hi: both or none");
     if (k < 0 || k >= (int)mg->w.size()) return fail(FCAMD_ERR_BAD_ARG, "device slot %d out of range", k);
     if (k >= used) {
         *lo = *hi = n;
@@ -320,8 +310,11 @@ int fcamd_multi_evaluate_host(fcamd_multi* mg, double t, double del_t, int64_t n
     return st;
 }
 
+static int multi_unregister_host_buffer(fcamd_multi* mg, void* ptr);
+
 int fcamd_multi_register_host_buffer(fcamd_multi* mg, void* ptr, size_t bytes) {
-    if (!mg || !ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    if (!mg || !ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    if (bytes == 0) return multi_unregister_host_buffer(mg, ptr);
     std::lock_guard<std::mutex> call(mg->call_mu);
     // slot 0 takes the page lock, the other contexts enter the range with their own device's view of it
     int st = mg->run(1, [&](int) { return fcamd_register_host_buffer(mg->w[0]->ctx, ptr, bytes); });
@@ -344,8 +337,7 @@ int fcamd_multi_register_host_buffer(fcamd_multi* mg, void* ptr, size_t bytes) {
     return FCAMD_OK;
 }
 
-int fcamd_multi_unregister_host_buffer(fcamd_multi* mg, void* ptr) {
-    if (!mg || !ptr) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+static int multi_unregister_host_buffer(fcamd_multi* mg, void* ptr) {
     std::lock_guard<std::mutex> call(mg->call_mu);
     int first = FCAMD_OK;
     for (size_t k = mg->w.size(); k-- > 0;) {  // the borrowers first, the owner of the lock (slot 0) last
@@ -357,10 +349,13 @@ int fcamd_multi_unregister_host_buffer(fcamd_multi* mg, void* ptr) {
     return first;
 }
 
-int fcamd_multi_last_host_mode(const fcamd_multi* mg, int* mode, int* n_used) {
-    if (!mg || !mode || !n_used) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    *mode = mg->last_mode;
-    *n_used = mg->last_used;
+int fcamd_multi_get_option(const fcamd_multi* mg, const char* name, long long* value) {
+    if (!mg || !name || !value) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    if (std::strcmp(name, "n_devices") == 0) *value = (long long)mg->w.size();
+    else if (std::strcmp(name, "last_host_mode") == 0) *value = mg->last_mode;
+    else if (std::strcmp(name, "last_n_used") == 0) *value = mg->last_used;
+    else if (std::strcmp(name, "min_points") == 0) *value = mg->min_points;
+    else return fail(FCAMD_ERR_BAD_ARG, "unknown option '%s'", name);
     return FCAMD_OK;
 }
 
@@ -513,6 +508,20 @@ int move_history(fcamd_multi_state* st, int k, int c, double* const* host, bool 
     return FCAMD_OK;
 }
 
+// the coordinator's call-scoped page locks on the caller's whole state arrays (several devices, arrays beyond the scratch path)
+void lock_state_arrays(fcamd_multi_state* st, LockSet& locks, const double* stress_host, const double* const* history_host) {
+    fcamd_multi* mg = st->mg;
+    if (mg->w.size() < 2) return;
+    const fcamd_context* c0 = mg->w[0]->ctx;
+    const size_t N = (size_t)st->n;
+    auto want = [&](const void* p, size_t bytes) {
+        if (p && bytes > (size_t)c0->opt.bounce_max && !inside_registered(c0, p, bytes)) locks.add(p, bytes);
+    };
+    want(stress_host, N * (size_t)mg->dims.sd * sizeof(double));
+    if (history_host)
+        for (int f = 0; f < mg->info.n_hist; ++f) want(history_host[f], N * (size_t)mg->info.hist[f].dim * sizeof(double));
+}
+
 }  // namespace
 
 extern "C" {
@@ -528,6 +537,10 @@ int fcamd_multi_state_set(fcamd_multi_state* st, const double* stress_host, cons
     std::lock_guard<std::mutex> call(mg->call_mu);
     const size_t SD = (size_t)mg->dims.sd;
     const int c = st->committed;
+    // As in _evaluate: the coordinator page-locks every WHOLE caller array once; the workers then find their slices
+    // locked.  (Slices are tile-aligned, not page-aligned: per-worker locks would share boundary pages.)
+    LockSet locks;
+    lock_state_arrays(st, locks, stress_host, history_host);
     const int rc = mg->run((int)mg->w.size(), [&](int k) {
         auto& sl = st->s[(size_t)k];
         const size_t nk = (size_t)(sl.hi - sl.lo);
@@ -570,6 +583,8 @@ int fcamd_multi_state_get(fcamd_multi_state* st, int trial, double* stress_host,
     const size_t SD = (size_t)mg->dims.sd;
     // before the first evaluate of an increment the trial state IS the committed one
     const int c = (trial && st->evaluated) ? 1 - st->committed : st->committed;
+    LockSet locks;
+    lock_state_arrays(st, locks, stress_host, history_host);
     return mg->run((int)mg->w.size(), [&](int k) {
         auto& sl = st->s[(size_t)k];
         const size_t nk = (size_t)(sl.hi - sl.lo);

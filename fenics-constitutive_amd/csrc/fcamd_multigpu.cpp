@@ -46,20 +46,14 @@ int ensure_peer_streams(fcamd_context* c, int world) {
 
 extern "C" {
 
-int fcamd_shard_slot_points(int64_t n, int world, int64_t* per_rank) {
-    if (!per_rank) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    if (n < 0 || world <= 0) return fail(FCAMD_ERR_BAD_ARG, "n >= 0 and world > 0 expected");
-    *per_rank = slot_points(n, world);
-    return FCAMD_OK;
-}
-
-int fcamd_shard_bounds(int64_t n, int world, int rank, int64_t* lo, int64_t* hi) {
+int fcamd_shard_bounds(int64_t n, int world, int rank, int64_t* lo, int64_t* hi, int64_t* slot) {
     if (!lo || !hi) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     if (n < 0 || world <= 0 || rank < 0 || rank >= world)
         return fail(FCAMD_ERR_BAD_ARG, "n >= 0, world > 0 and 0 <= rank < world expected");
     const int64_t per = slot_points(n, world);
     *lo = std::min<int64_t>((int64_t)rank * per, n);
     *hi = std::min<int64_t>(*lo + per, n);
+    if (slot) *slot = per;
     return FCAMD_OK;
 }
 
@@ -101,27 +95,12 @@ int fcamd_ipc_export(fcamd_context* c, const void* device_ptr, unsigned char han
     if (!ipc_size_is_safe(size))
         return fail(FCAMD_ERR_UNSUPPORTED,
                     "the allocation behind this pointer has %zu bytes: (size mod 4 GiB) >= 2 GiB, which hipIpcOpenMemHandle of this "
-                    "ROCm stack cannot map (it never returns); allocate shared buffers with fcamd_ipc_alloc", size);
+                    "ROCm stack cannot map (it never returns); allocate shared buffers with fcamd_device_alloc_set(FCAMD_ALLOC_IPC)", size);
     hipIpcMemHandle_t h;
     HIP_TRY(hipIpcGetMemHandle(&h, base));
     std::memset(handle, 0, FCAMD_IPC_HANDLE_BYTES);
     std::memcpy(handle, &h, sizeof(h));
     *offset_bytes = (size_t)(static_cast<const char*>(device_ptr) - static_cast<const char*>(base));
-    return FCAMD_OK;
-}
-
-int fcamd_ipc_alloc(fcamd_context* c, size_t bytes, void** device_ptr) {
-    if (!c || !device_ptr || bytes == 0) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMalloc(device_ptr, ipc_safe_size(bytes)));
-    return FCAMD_OK;
-}
-
-int fcamd_ipc_free(fcamd_context* c, void* device_ptr) {
-    if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
-    if (!device_ptr) return FCAMD_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipFree(device_ptr));  // waits for the device
     return FCAMD_OK;
 }
 
@@ -160,7 +139,12 @@ int fcamd_ipc_close(fcamd_context* c, void* device_ptr, size_t offset_bytes) {
     return fail(FCAMD_ERR_BAD_ARG, "pointer was not returned by fcamd_ipc_open of this context");
 }
 
-int fcamd_enable_peer_access(fcamd_context* c, int peer_device) {
+}  // extern "C"
+
+namespace fcamd {
+size_t ipc_safe_alloc_size(size_t bytes) { return ipc_safe_size(bytes); }
+
+int enable_peer_access(fcamd_context* c, int peer_device) {
     if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
     if (peer_device == c->device) return FCAMD_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -175,6 +159,9 @@ int fcamd_enable_peer_access(fcamd_context* c, int peer_device) {
     (void)hipGetLastError();
     return FCAMD_OK;
 }
+}  // namespace fcamd
+
+extern "C" {
 
 int fcamd_allgather_direct(fcamd_context* c, int world, int rank, void* const* gathered, const int* devices,
                            size_t slot_bytes, size_t offset_bytes, size_t bytes, int flags) {

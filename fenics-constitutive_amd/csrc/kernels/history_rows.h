@@ -7,39 +7,6 @@
 
 namespace fcamd {
 
-// Delta trial history (kFlagDeltaHistory; the sparse protocol of device-resident states): the plastic-strain array of a
-// law is write-only for its stress update -- VonMises3D adds gamma N to eps_n (mises_plasticity_isotropic_hardening.py:161),
-// the comfe-rs laws add to plastic_strain (mises_plasticity.rs:112, general.rs:243) and never read it back -- so during the
-// Newton iterations of an increment the TRIAL array need not hold committed + increment.  It holds the increments of the
-// points that are plastic NOW, packed: the k-th plastic point of a tile (ascending point order) owns row k of the tile's
-// slot, rows [popcount(mask), 64) of the slot are undefined.  The launch reads no plastic-strain row at all and writes
-// popcount(mask) rows as ONE contiguous run per tile -- full lines, where the unpacked form wrote isolated 48-byte rows
-// (32-byte sectors around them: profiles/r02_von_mises_mixed_rocprof.md) -- and the commit (commit_delta_kernel, once per
-// increment) reads the run back in order.  `d`: this lane's increment (only plastic lanes contribute).
-template <bool FULL, bool NT>
-__device__ __forceinline__ void delta_rows_store(double* rows_out, long long p0, int lane, unsigned long long mask,
-                                                 bool plastic, double* region, const double (&d)[6]) {
-    if (mask == 0ull) return;
-    const int cnt = (int)__popcll(mask);
-    const int rank = (int)__popcll(mask & ((1ull << lane) - 1ull));  // plastic points before this one in the tile
-    if (plastic) lds_put_point<6>(region, rank, d);
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int q = k * kWave + lane;
-        if (q < 3 * cnt) {
-            const d2 v = reinterpret_cast<const d2*>(region)[q];
-            if constexpr (FULL) {
-                store16<NT>(rows_out + p0 * 6 + 2 * q, v);
-            } else {  // ragged last tile: its slot ends with the array, guarded 8-byte stores
-                rows_out[p0 * 6 + 2 * q] = v.x;
-                rows_out[p0 * 6 + 2 * q + 1] = v.y;
-            }
-        }
-    }
-    wave_sync();
-}
-
 // Packed plastic-strain history (kFlagPackedHistory; a layout of device-resident states, committed AND trial array).
 // The plastic-strain array of a law only accumulates (mises_plasticity_isotropic_hardening.py:161, mises_plasticity.rs:112,
 // general.rs:243) and is +0.0 at every point that has never been plastic.  A state therefore keeps, per 64-point tile, the
@@ -201,16 +168,14 @@ template <bool FULL, bool NT>
 struct SplitRows {
     PackedRows<FULL, NT> pk;  // its chunk registers pk.c also hold the rows of the unpacked layouts (one array: stays in VGPRs)
     unsigned long long rows = 0ull;
-    bool delta = false, packed = false, masked = false;
+    bool packed = false, masked = false;
     bool row_live[3] = {true, true, true};
 
     __device__ __forceinline__ void request(const EvalArgs& a, const SparseWords& w, long long p0, int npts, int lane,
                                             unsigned long long touched, bool hist_in_place) {
         rows = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
         if (rows == 0ull) return;
-        delta = (a.flags & kFlagDeltaHistory) != 0 && a.hmask != nullptr;  // increments of the plastic points, packed; nothing is read
         packed = (a.flags & kFlagPackedHistory) != 0 && a.hmask != nullptr;  // committed run in, trial run out (PackedRows)
-        if (delta) return;
         if (packed) {
             pk.ever_in = w.ever;
             pk.load(a.h1_in, p0, lane);
@@ -233,9 +198,9 @@ struct SplitRows {
     }
     // d: in, the increment of this lane's point (zero unless it is plastic now); out, the row to be written -- committed row +
     // increment at the plastic points, the committed row (its bits) elsewhere.  Summed here, at once: the committed rows do not
-    // stay in registers across the stress store.  (Delta protocol: d stays the increment.)
+    // stay in registers across the stress store.
     __device__ __forceinline__ void gather(double* region, int lane, unsigned long long mask, double (&d)[6]) {
-        if (rows == 0ull || delta) return;
+        if (rows == 0ull) return;
         double ep[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (packed)
             pk.gather(region, lane, ep);
@@ -252,10 +217,6 @@ struct SplitRows {
         const bool live = FULL || lane < npts;
         if (rows == 0ull) return;
         if (live) a.h0_out[p0 + lane] = scalar;  // one coalesced 512-byte store per touched tile
-        if (delta) {
-            delta_rows_store<FULL, NT>(a.h1_out, p0, lane, mask, live && ((mask >> lane) & 1ull) != 0ull, region, d);
-            return;
-        }
         if (packed) {
             pk.scatter(a, a.h1_out, p0, lane, mask, region, d);
             return;

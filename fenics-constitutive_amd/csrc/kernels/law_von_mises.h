@@ -94,7 +94,7 @@ __device__ __forceinline__ void vm_tangent_coefficients(const Scalars& sc, const
 // scalars: s[0]=strain factor, s[1]=ka, s[2]=2*mu, s[3]=sqrt(2/3), s[4]=y0, s[5]=y00-y0,
 //          s[6]=-w, s[7]=(-2)*mu, s[8]=((2/3)*(y00-y0))*w, s[9]=(4*mu)*mu
 // tables:  a = ka*xioi, b = xpp
-// HIST: 0 = the caller's arrays as they are (in place or out of place), 1 = sparse trial history (a.hmask; + delta by flag),
+// HIST: 0 = the caller's arrays as they are (in place or out of place), 1 = sparse trial history (a.hmask),
 //       2 = sparse protocol on the packed plastic-strain layout (history_rows.h: PackedRows)
 template <bool IDX, int HIST, bool FULL, bool NT>
 __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
@@ -151,13 +151,11 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     // degenerates to the plain coalesced tile access.
     Chunks<6> ce;
     const unsigned long long need_mask = mask | m_old;
-    // delta trial history: only the rows of points that are plastic NOW are written (their increment), nothing is read
-    const bool delta = sparse && !packed && (a.flags & kFlagDeltaHistory) != 0;
-    const unsigned long long eps_mask = delta ? mask : need_mask;
+    const unsigned long long eps_mask = need_mask;
     const bool masked = !packed && FULL && (sparse || hist_in_place) && ((int)__popcll(eps_mask) <= a.masked_max);
     const bool touch_eps = masked ? (eps_mask != 0ull)
                                   : (sparse ? (eps_mask != 0ull) : ((mask != 0ull) || !hist_in_place));
-    const bool touch_alpha = delta ? (need_mask != 0ull) : touch_eps;  // stale points get their committed alpha back
+    const bool touch_alpha = touch_eps;  // stale points get their committed alpha back
     bool row_live[3] = {true, true, true};  // per chunk of this lane: its row is touched
     if (masked) {
 #pragma unroll
@@ -165,7 +163,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     }
     if constexpr (packed) {
         if (!early && touch_eps) pk.load(a.h0_in, p0, lane);  // a tile that turns plastic now: the one late request
-    } else if (!delta && touch_eps) {
+    } else if (touch_eps) {
         if (masked) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -189,7 +187,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     // load consumed after younger stores makes the wave wait for those stores to complete (one vmcnt for both; measured in
     // round 4: 0.7 ms of 8.4 at 1e8 points with the rows consumed after the stress store).
     double ep[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const bool ep_in_lanes = !packed && !delta && touch_eps && mask != 0ull;
+    const bool ep_in_lanes = !packed && touch_eps && mask != 0ull;
     if constexpr (packed) {
         if (touch_eps) pk.gather(region, lane, ep);
     } else {
@@ -206,11 +204,6 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
             for (int i = 0; i < 6; ++i) ep[i] = plastic ? ep[i] + rm.gamma * rm.N[i] : ep[i];  // the others keep their bits
             pk.scatter(a, a.h0_out, p0, lane, mask, region, ep);
         }
-    } else if (delta) {  // the increment of the plastic points, packed at the head of the tile's slot (delta_rows_store)
-        double dp[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dp[i] = 0.0 + rm.gamma * rm.N[i];
-        delta_rows_store<FULL, NT>(a.h0_out, p0, lane, mask, plastic, region, dp);
     } else if (touch_eps) {
         if (mask != 0ull) {
 #pragma unroll

@@ -50,13 +50,6 @@ __device__ __forceinline__ void tangent_const_masked(const double* tab, double* 
 // (back to the elastic tangent) -- the same `mask | m_old` set as the history rows.  Rows of points that
 // stay elastic, 288 of their 464 bytes, are not touched.  Ragged last tiles are written in full.
 constexpr int kFlagSparseTangent = 1;
-// Delta trial history (FCAMD_EVAL_DELTA_HISTORY; VonMises3D under the sparse protocol): eps_n is write-only with
-// respect to the stress update, so the trial array need not hold eps_n + gamma N -- it receives the INCREMENT
-// gamma N at the plastic points (and is not defined elsewhere), the committed rows are not read at all
-// (28 of the 156 bytes read per point on the 22 % mixture: -3.5 % kernel time), and the commit adds the increments
-// of the plastic points to the committed array (commit_delta_kernel, once per increment instead of once per
-// Newton iteration).  alpha is not affected (it enters the yield function and is read for every point anyway).
-constexpr int kFlagDeltaHistory = 2;
 // Split history of the laws whose reference layout is one [alpha, eps_p(6)] row per point (comfe-rs Mises and
 // Drucker-Prager): h0 = the scalar (n doubles), h1 = the plastic-strain rows (6 n).  eps_p is write-only for the
 // stress update (it only accumulates), the scalar is needed by every point (Mises: it enters the yield function) or

@@ -300,7 +300,7 @@ class DeviceLaw(IncrSmallStrainModel):
         )
 
     def evaluate_from(self, t, del_t, grad_del_u, stress_prev, stress, tangent, history_prev, history,
-                      history_mask=None, sparse_tangent: bool = False, counters=None, delta_history: bool = False,
+                      history_mask=None, sparse_tangent: bool = False, counters=None,
                       split_history: bool = False, packed_masks=None) -> None:
         """Out-of-place device evaluate: read the committed state (``stress_prev``,
         ``history_prev``), write the trial state (``stress``, ``history``).  Fuses the two
@@ -310,9 +310,7 @@ class DeviceLaw(IncrSmallStrainModel):
         formerly plastic points are rewritten (FCAMD_EVAL_SPARSE_TANGENT, include/fcamd.h).  ``counters``:
         caller-owned int64 device tensor of ``_capi.COUNTER_WORDS`` words that receives this launch's
         statistics instead of the law's own counters (``fcamd_eval_args.counters``; read it with
-        ``read_counters``).  ``delta_history`` (VonMises3D, with ``history_mask``): the trial ``eps_n`` array
-        receives the increment at the plastic points and the committed one is not read
-        (FCAMD_EVAL_DELTA_HISTORY; commit with ``commit_delta_history``).  ``split_history`` (the comfe-rs plasticity
+        ``read_counters``).  ``split_history`` (the comfe-rs plasticity
         laws): the histories are dicts ``{"scalar": n, "rows": 6 n}`` instead of the reference's ``{"history": 7 n}``
         (FCAMD_EVAL_SPLIT_HISTORY: ``SPLIT_HISTORY_FIELDS``).  ``packed_masks = (ever_prev, ever)`` (with ``history_mask``;
         int64 device tensors, one word per 64-point tile): the plastic-strain arrays of ``history_prev`` / ``history``
@@ -339,18 +337,15 @@ class DeviceLaw(IncrSmallStrainModel):
         dev = grad_del_u.device.index or 0
         m = self._handle(dev)
         m.ctx.set_stream(_current_stream_ptr(dev))
-        if (sparse_tangent and tangent is not None) or counters is not None or delta_history or split_history or packed_masks is not None:
+        if (sparse_tangent and tangent is not None) or counters is not None or split_history or packed_masks is not None:
             flags = _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tangent is not None and history_mask is not None) else 0
             pm = None
             if packed_masks is not None:
-                assert history_mask is not None and not delta_history, "packed history: with history_mask, without delta_history"
+                assert history_mask is not None, "packed history: with history_mask"
                 for mk in packed_masks:
                     assert mk.dtype == torch.int64 and mk.is_cuda and mk.numel() >= (n + 63) // 64
                 flags |= _capi.EVAL_PACKED_HISTORY
                 pm = (packed_masks[0].data_ptr(), packed_masks[1].data_ptr())
-            if delta_history:
-                assert history_mask is not None, "delta_history needs history_mask"
-                flags |= _capi.EVAL_DELTA_HISTORY
             if split_history:
                 flags |= _capi.EVAL_SPLIT_HISTORY
             m.evaluate_device_ex(
@@ -404,18 +399,6 @@ class DeviceLaw(IncrSmallStrainModel):
             None if history_mask is None else history_mask.data_ptr(),
             _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tan_ptr is not None and history_mask is not None) else 0,
             counters_ptr=_counters_ptr(counters))
-
-    def commit_delta_history(self, committed, delta, history_mask) -> None:
-        """``committed[row] += increment`` for the points of ``history_mask`` (``fcamd_commit_delta_history``): the commit of
-        a trial plastic-strain array written with ``delta_history=True`` (increments packed per tile).  Asynchronous on
-        torch's current stream."""
-        _check_torch("committed", committed), _check_torch("delta", delta)
-        n = committed.numel() // 6
-        assert delta.numel() == committed.numel() and history_mask.numel() >= (n + 63) // 64
-        dev = committed.device.index or 0
-        m = self._handle(dev)
-        m.ctx.set_stream(_current_stream_ptr(dev))
-        m.commit_delta_history(n, committed.data_ptr(), delta.data_ptr(), history_mask.data_ptr())
 
     def raise_for_stats(self, st) -> None:
         """The reference's errors for the counters of a finished launch: the Drucker-Prager tip

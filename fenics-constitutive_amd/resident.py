@@ -36,14 +36,10 @@ class ResidentState:
     #: device-assembler mode: place the state's arrays on the first ``evaluate`` when the tangent is at
     #: least this large (below, launches are latency-bound and the placement does not show)
     AUTO_TUNE_MIN_BYTES = 256 << 20
-    #: ``delta_history="auto"``: switch the delta trial history on when the running mean of the evaluates per increment
-    #: reaches this (the measured break-even, bench.py "delta_trial_history"), off again below ``DELTA_OFF_ITERATIONS``
-    DELTA_MIN_ITERATIONS = 3.0
-    DELTA_OFF_ITERATIONS = 2.5
 
     def __init__(self, law: DeviceLaw, n: int, device=None, stress0=None, history0=None, sparse_history: bool = True,
                  reuse_constant_tangent: bool = True, sparse_tangent: bool = True, placement: str = "auto",
-                 delta_history=False, split_history: bool = True, packed_history="auto"):
+                 split_history: bool = True, packed_history: bool = True):
         """``placement`` (device-assembler mode, large states): where the arrays the kernel streams
         live decides 10-28 % of its time on MI355X.  "vmm": on the first ``evaluate`` the state moves its arrays
         (both stress / history copies, tangent, gradient staging) into ONE working set whose 2 MiB physical
@@ -54,25 +50,16 @@ class ResidentState:
         import torch
 
         assert placement in ("auto", "vmm", "tune", "torch")
-        # ``delta_history`` (VonMises3D and -- with ``split_history`` -- the comfe-rs plasticity laws, under the sparse
-        # protocol): the plastic-strain array is write-only for the stress update (mises_plasticity_isotropic_hardening.py:161,
-        # mises_plasticity.rs:112, general.rs:243 only accumulate it), so the trial array can hold the INCREMENTS of the
-        # plastic points during the Newton iterations, packed per tile: ``evaluate`` then reads no plastic-strain row and
-        # writes contiguous runs, and ``update()`` adds the increments to the committed rows (one pass per increment, the
-        # commit kernel).  It moves work from every Newton iteration to the commit, so it pays from ``DELTA_MIN_ITERATIONS``
-        # iterations per increment on (bench.py "delta_trial_history": evaluate / commit kernel times, break-even).
-        # True: always; "auto": the state watches how many evaluates its increments take and switches the protocol
-        # at increment boundaries (one full-history evaluate when it goes back to the plain protocol; ``generation`` is
-        # incremented at every switch, because the MEANING of the trial plastic-strain tensor changes with it); False
-        # (default): never.  ``history`` (the trial view) assembles the rows on demand.
-
-        # ``packed_history`` (same laws, sparse protocol; "auto" = on unless ``delta_history`` was asked for): BOTH copies of
-        # the plastic-strain array are kept packed per 64-point tile -- the rows that are not all +0.0, i.e. the points that
-        # have ever been plastic, as one contiguous run at the head of the tile's slot, plus one EVER-mask word per tile
-        # (FCAMD_EVAL_PACKED_HISTORY, include/fcamd.h; ``device.pack_rows``).  A launch reads and writes contiguous runs
-        # instead of isolated 48-byte rows, and ``update()`` stays a pointer swap (no commit kernel).  ``history`` /
-        # ``history_committed`` hand out the plastic-strain array in the reference's layout as a COPY (always, from the first
-        # call on -- nothing changes meaning mid-run); initialise with ``set_state``.
+        # ``packed_history`` (VonMises3D and -- with ``split_history`` -- the comfe-rs plasticity laws, under the sparse
+        # protocol): the plastic-strain array only accumulates (mises_plasticity_isotropic_hardening.py:161,
+        # mises_plasticity.rs:112, general.rs:243) and is +0.0 wherever a point has never been plastic, so BOTH copies of it
+        # are kept packed per 64-point tile -- the rows that are not all +0.0 as one contiguous run at the head of the
+        # tile's slot, plus one EVER-mask word per tile (FCAMD_EVAL_PACKED_HISTORY, include/fcamd.h; ``device.pack_rows``).
+        # A launch reads and writes contiguous runs instead of isolated 48-byte rows, and ``update()`` stays a pointer swap.
+        # ``history`` / ``history_committed`` hand out the plastic-strain array in the reference's layout as a COPY (always,
+        # from the first call on -- nothing changes meaning mid-run); initialise with ``set_state``.  (Round 3 had a
+        # "delta" protocol here -- increments in the trial array plus a commit kernel per increment; the packed layout
+        # reaches the same byte rate without the commit kernel and replaced it.)
 
         # ``split_history`` (the comfe-rs plasticity laws, with the sparse protocol): the reference keeps one
         # [scalar, eps_p(6)] row of 7 doubles per point (``history_dim = {"history": 7}``), so every point pays 56 bytes
@@ -111,24 +98,14 @@ class ResidentState:
         if sparse_history and type(law).__name__ in ("VonMises3D", "MisesPlasticityLinearHardening3D",
                                                      "DruckerPrager3D", "DruckerPragerHyperbolic3D"):
             self._mask = torch.zeros((self.n + 63) // 64, dtype=torch.int64, device=self.device)
-        # Delta trial history needs a plastic-strain array of its own: VonMises3D's eps_n, the split laws' eps_p rows.
-        self._delta_key = "eps_n" if type(law).__name__ == "VonMises3D" else ("rows" if self._split else None)
-        capable = self._mask is not None and self._delta_key is not None
-        assert delta_history in (False, True, "auto"), "delta_history: False, True or 'auto'"
-        assert packed_history in (False, True, "auto"), "packed_history: False, True or 'auto'"
-        self._packed = capable and (packed_history is True or (packed_history == "auto" and delta_history is False))
-        self._delta_auto = capable and delta_history == "auto" and not self._packed
-        self._delta = capable and delta_history is True and not self._packed
+        # The packed layout needs a plastic-strain array of its own: VonMises3D's eps_n, the split laws' eps_p rows.
+        self._rows_key = "eps_n" if type(law).__name__ == "VonMises3D" else ("rows" if self._split else None)
+        self._packed = bool(packed_history) and self._mask is not None and self._rows_key is not None
         # EVER masks of the two copies of the packed plastic-strain array (one word per tile), swapped with them
         self._ever = [torch.zeros_like(self._mask), torch.zeros_like(self._mask)] if self._packed else None
         if self._packed and history0 is not None:
-            self._pack_into_both(self._hist[0][self._delta_key].clone())
-        if type(law).__name__.startswith("DruckerPrager"):
-            # more of the launch is the return mapping itself: measured break-even 3.7 iterations at 56 % plastic points
-            # (VonMises3D 1.7 at 22 %, comfe-rs Mises 2.1 at 40 %; bench.py "delta_trial_history", 1e8 points)
-            self.DELTA_MIN_ITERATIONS, self.DELTA_OFF_ITERATIONS = 4.0, 3.0
+            self._pack_into_both(self._hist[0][self._rows_key].clone())
         self._n_eval = 0          # evaluates of the increment in progress (Newton iterations)
-        self._iters_ema = None    # running mean of the Newton iterations per increment ("auto")
         self._evaluated = False
         # Linear elasticity and the SLS laws have one tangent for all points, a function of the
         # parameters (and del_t) only -- the reference tiles it into the array on every call
@@ -186,7 +163,7 @@ class ResidentState:
 
         packed, ever = pack_rows(rows)
         for i in (0, 1):
-            self._hist[i][self._delta_key].copy_(packed)
+            self._hist[i][self._rows_key].copy_(packed)
             self._ever[i].copy_(ever)
 
     def _unpacked(self, copy: int) -> dict:
@@ -194,7 +171,7 @@ class ResidentState:
         from .device import unpack_rows
 
         h = self._hist[copy]
-        return {**h, self._delta_key: unpack_rows(h[self._delta_key], self._ever[copy], self.n)}
+        return {**h, self._rows_key: unpack_rows(h[self._rows_key], self._ever[copy], self.n)}
 
     def _external_history(self, internal) -> dict:
         if not self._split:
@@ -249,32 +226,13 @@ class ResidentState:
 
     @property
     def history(self):
-        """Trial history.  The plastic-strain array of a packed state is a copy in the reference's layout; under the delta
-        protocol it is assembled here from the committed array and the increments of the currently plastic points (a copy:
-        the state keeps the increments).  Every other tensor is the live one the kernel writes."""
+        """Trial history.  The plastic-strain array of a packed state is a copy in the reference's layout; every other tensor
+        is the live one the kernel writes."""
         if self._hist is None:
             return None
         if self._packed:  # nothing evaluated in this increment yet: the trial state is the committed one
             return self._external_history(self._unpacked(1 - self._c if self._evaluated else self._c))
-        trial = self._hist[1 - self._c]
-        if not self._delta:
-            return self._external_history(trial)
-        key = self._delta_key
-        if not self._evaluated:  # nothing evaluated in this increment yet: the trial state is the committed one
-            return self._external_history({**trial, key: self._hist[self._c][key]})
-        import torch
-
-        # committed rows + the increments of the currently plastic points, which lie packed at the head of every tile's
-        # slot of the trial array (include/fcamd.h, FCAMD_EVAL_DELTA_HISTORY): the k-th set bit of a tile's mask word
-        # owns row 64 tile + k
-        n = self.n
-        shifts = torch.arange(64, device=self.device, dtype=torch.int64)
-        bits = (self._mask[:, None] >> shifts[None, :]) & 1  # [tiles, 64]
-        src = (torch.arange(bits.shape[0], device=self.device)[:, None] * 64 + torch.cumsum(bits, dim=1) - 1).reshape(-1)[:n]
-        sel = bits.reshape(-1)[:n].bool()
-        rows = self._hist[self._c][key].view(n, 6).clone()
-        rows[sel] = rows[sel] + trial[key].view(n, 6)[src[sel]]
-        return self._external_history({**trial, key: rows.reshape(-1)})
+        return self._external_history(self._hist[1 - self._c])
 
     def set_state(self, stress=None, history=None) -> None:
         """(Re)initialise the committed state -- initial conditions, a restart -- from NumPy arrays or device
@@ -287,7 +245,7 @@ class ResidentState:
         if history is not None and self._hist is not None:
             h = self._internal_history(history)
             for k in self._hist[self._c]:
-                if self._packed and k == self._delta_key:
+                if self._packed and k == self._rows_key:
                     self._pack_into_both(h[k])
                     continue
                 self._hist[self._c][k].copy_(h[k])
@@ -306,7 +264,7 @@ class ResidentState:
                                None if self._hist is None else self._hist[self._c],
                                None if self._hist is None else self._hist[1 - self._c],
                                history_mask=self._mask, sparse_tangent=sparse_tangent, counters=self._counters,
-                               delta_history=self._delta, split_history=self._split,
+                               split_history=self._split,
                                packed_masks=(self._ever[self._c], self._ever[1 - self._c]) if self._packed else None)
 
     def evaluate(self, t: float, del_t: float, grad_del_u) -> None:
@@ -346,9 +304,8 @@ class ResidentState:
         """Run the placement step NOW (it otherwise runs inside the first large device-assembler ``evaluate``) and leave a
         valid trial state for ``grad_del_u``: after it the tensors handed out by ``stress`` / ``tangent`` / ``grad`` and the
         live tensors of ``history`` stay the ones the kernel writes (``generation`` does not change any more unless
-        ``tune_placement`` is called or ``delta_history="auto"`` switches the protocol).  The plastic-strain array of
-        ``history`` is NOT such a tensor under ``packed_history`` (always a copy) or ``delta_history`` (its meaning follows the
-        protocol): read it through ``history`` when needed.  For device assemblers that take the pointers once and then loop."""
+        ``tune_placement`` is called).  The plastic-strain array of ``history`` is NOT such a tensor under ``packed_history``
+        (always a copy): read it through ``history`` when needed.  For device assemblers that take the pointers once and then loop."""
         self.evaluate(t, del_t, grad_del_u)
 
     def _place(self, t, del_t, g, staging: bool) -> None:
@@ -508,8 +465,6 @@ class ResidentState:
         target = None if tangent is None else ("host", tangent.ctypes.data, tangent.nbytes)
         flags = _capi.EVAL_SPARSE_TANGENT if (self._sparse_tangent and target is not None
                                               and self._tangent_target == target) else 0
-        if self._delta:
-            flags |= _capi.EVAL_DELTA_HISTORY
         if self._split:
             flags |= _capi.EVAL_SPLIT_HISTORY
         if self._packed:
@@ -544,34 +499,9 @@ class ResidentState:
         if self._failed is not None:
             raise RuntimeError(f"the last evaluate failed, nothing to commit: {self._failed}")
         self.check()
-        if self._delta:
-            # plastic strain: add the increments of the plastic points to the committed array (it stays the committed one:
-            # the two dicts exchange the tensors, so that the flip below leaves it on the committed side)
-            key = self._delta_key
-            c, t = self._hist[self._c], self._hist[1 - self._c]
-            self.law.commit_delta_history(c[key], t[key], self._mask)
-            c[key], t[key] = t[key], c[key]
         self._c = 1 - self._c
         self._evaluated = False
-        if self._delta_auto:
-            self._adapt_delta()
         self._n_eval = 0
-
-    def _adapt_delta(self) -> None:
-        """``delta_history="auto"``, at an increment boundary: the delta protocol pays when the commit kernel is spread over
-        enough Newton iterations; the state has just seen how many this increment took."""
-        it = float(self._n_eval)
-        self._iters_ema = it if self._iters_ema is None else 0.5 * self._iters_ema + 0.5 * it
-        if not self._delta and self._iters_ema >= self.DELTA_MIN_ITERATIONS:
-            self._delta = True  # the trial rows become the packed increments; nothing of them is read
-            self.generation += 1  # a tensor taken from ``history`` earlier no longer means what it meant
-        elif self._delta and self._iters_ema < self.DELTA_OFF_ITERATIONS:
-            # back to the plain sparse protocol, whose contract is "trial == committed wherever the mask is clear": the trial
-            # rows hold increments now, so every row is declared stale -- the next evaluate rewrites the whole trial history
-            # (and tangent) once
-            self._delta = False
-            self._mask.fill_(-1)
-            self.generation += 1
 
     # host access ------------------------------------------------------------------------------------
     def download(self, stress: np.ndarray | None = None, tangent: np.ndarray | None = None,
@@ -582,7 +512,7 @@ class ResidentState:
         if tangent is not None:
             assign(tangent, self.tangent)
         if history is not None and self._hist is not None:
-            trial = self.history  # once: under the delta protocol the view is assembled on demand
+            trial = self.history  # once: the plastic-strain array of a packed state is assembled on demand
             for k in history:
                 assign(history[k], trial[k])
 

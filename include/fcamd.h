@@ -20,6 +20,12 @@
  *   - a context is bound to one device and one stream; use one context per thread.
  *
  * Plain pointers and sizes only; nothing from torch or numpy appears here.
+ *
+ * Version 0.4 (round 4): the boundary is THREE evaluate entries -- fcamd_evaluate_host (the ndarray call),
+ * fcamd_evaluate_device_ex (device arrays, every option in one argument struct), fcamd_evaluate_resident (host
+ * assembler on a device-resident state) -- 45 exported symbols in all (0.3: 69).  The narrower forms of 0.3
+ * (fcamd_evaluate_device, _from, _from_sparse, _indexed, _wrapped, the single-value getters and setters) are
+ * `static inline` shorthands at the end of this header: same names, same arguments, no symbols.
  */
 #ifndef FCAMD_H
 #define FCAMD_H
@@ -31,8 +37,13 @@
 extern "C" {
 #endif
 
+/* Every EXPORTED entry point of libfcamd.so carries FCAMD_API. */
+#ifndef FCAMD_API
+#define FCAMD_API
+#endif
+
 #define FCAMD_VERSION_MAJOR 0
-#define FCAMD_VERSION_MINOR 3
+#define FCAMD_VERSION_MINOR 4
 
 /* ---- status codes (mapped to Python exceptions by the ctypes shim) -------- */
 typedef enum fcamd_status {
@@ -101,107 +112,100 @@ typedef struct fcamd_stats {
     uint64_t n_plastic;      /* points that took the plastic branch */
     uint64_t n_newton_iters; /* total Newton iterations over all plastic points */
     uint64_t n_domain;       /* points that left the law's domain (Drucker-Prager tip) */
+    double kernel_ms;        /* filled by fcamd_model_last_stats only: time of the model's last entry with the context
+                                option "timing" on (HIP events around the kernel(s) of a device entry; wall-clock of a
+                                synchronous host entry, copies included); -1 when it was not timed */
 } fcamd_stats;
 
 /* ---- lifecycle --------------------------------------------------------------- */
 
 /* Create a context on HIP device `device`.  `stream` is a hipStream_t to launch on
    (e.g. torch's current stream), or NULL to let the context own a private stream. */
-int fcamd_context_create(int device, void* stream, fcamd_context** out);
-int fcamd_context_destroy(fcamd_context* ctx);
+FCAMD_API int fcamd_context_create(int device, void* stream, fcamd_context** out);
+FCAMD_API int fcamd_context_destroy(fcamd_context* ctx);
 /* Re-bind the launch stream (borrowed; not destroyed with the context). */
-int fcamd_context_set_stream(fcamd_context* ctx, void* stream);
-int fcamd_context_synchronize(fcamd_context* ctx);
+FCAMD_API int fcamd_context_set_stream(fcamd_context* ctx, void* stream);
+FCAMD_API int fcamd_context_synchronize(fcamd_context* ctx);
 
 /* Model handle = law id + constraint + host-precomputed constants.
    Replaces the PyO3 constructor `Py*::new(parameters)` (bindings/src/lib.rs:60-75).
    `params` holds the law's parameters in the order documented at fcamd_model_id. */
-int fcamd_model_create(fcamd_context* ctx, int model_id, int constraint,
-                       const double* params, int n_params, fcamd_model** out);
-int fcamd_model_destroy(fcamd_model* model);
+FCAMD_API int fcamd_model_create(fcamd_context* ctx, int model_id, int constraint,
+                                 const double* params, int n_params, fcamd_model** out);
+FCAMD_API int fcamd_model_destroy(fcamd_model* model);
 
-/* history_dim of the law (models/interfaces.py:133-143; bindings/src/lib.rs:131-136):
-   number of fields, and per field its name and per-point dimension. */
-int fcamd_model_history_count(const fcamd_model* model, int* n_fields);
-int fcamd_model_history_field(const fcamd_model* model, int k, const char** name, int* dim);
-
-/* The other getters of the reference's native model classes (bindings/src/lib.rs:137-148:
-   `constraint`, `stress_strain_dim`, `geometric_dim` next to `history_dim`; models/interfaces.py:103-131).
-   `constraint` receives an fcamd_constraint value (= StressStrainConstraint value). */
-int fcamd_model_constraint(const fcamd_model* model, int* constraint);
-int fcamd_model_dims(const fcamd_model* model, int* stress_strain_dim, int* geometric_dim);
+/* The getters of the reference's native model classes in one call (bindings/src/lib.rs:131-148: `history_dim`,
+   `constraint`, `stress_strain_dim`, `geometric_dim`; models/interfaces.py:103-143): the StressStrainConstraint value,
+   the array widths per point, and the law's history fields (name and per-point dimension, in the order every entry
+   takes the history pointers).  The names point into the library (valid for its lifetime). */
+typedef struct fcamd_model_info {
+    int model_id;
+    int constraint; /* fcamd_constraint = StressStrainConstraint value */
+    int stress_strain_dim;
+    int geometric_dim;
+    int n_history;
+    const char* history_name[FCAMD_MAX_HISTORY];
+    int history_dim[FCAMD_MAX_HISTORY];
+} fcamd_model_info;
+FCAMD_API int fcamd_model_get_info(const fcamd_model* model, fcamd_model_info* info);
 
 /* ---- the hot path ------------------------------------------------------------- */
 
-/* Device-resident evaluate (roofline path): all pointers are device pointers, 16-byte
-   aligned.  Asynchronous on the context's stream.  `tangent` may be NULL (the Rust
-   entry allows it, comfe-rs/src/interfaces.rs:383-394).  `history` has n_hist device
-   pointers in history-field order, or NULL/0 for laws without history.
-   In place: stress and history are read and overwritten. */
-int fcamd_evaluate_device(fcamd_model* model, double t, double del_t, int64_t n,
-                          const double* grad_del_u, double* stress, double* tangent,
-                          double* const* history, int n_hist);
+/* Host evaluate: the ndarray entry.  Pointers are host arrays laid out as above; results are
+   written back in place.  Two data paths, chosen per call:
+     zero copy -- every array of the call lies inside ranges page-locked with
+                  fcamd_register_host_buffer (and is 16-byte aligned): ONE kernel launch runs
+                  directly on the caller's arrays; the GPU reads the inputs and writes the
+                  results over PCIe itself, both directions at once, no staging buffers;
+     pageable  -- arrays the caller did not register are page-locked for the duration of the call
+                  (FCAMD_HOST_TEMP_LOCK) and treated the same way; calls that move at most
+                  "bounce_max" bytes (256 KiB), and arrays that cannot be locked, go through the
+                  context's own page-locked scratch with CPU copies instead (FCAMD_HOST_BOUNCE).
+                  Pageable caller memory is never handed to the HIP runtime's copy path (its cache
+                  of on-the-fly page locks goes stale when memory is freed and allocated again);
+     staged    -- option "zero_copy" = 0, or an array off the 16-byte grid: chunk by chunk through
+                  device buffers (four chunk slots on four streams: H2D / kernel / D2H of one chunk
+                  overlap the others'), DMA from / into the page-locked arrays.
+   Both produce bit-identical results.  Synchronous.  Validates like the reference and returns
+   the matching status; on FCAMD_ERR_NONCONVERGED the outputs hold the values the kernel
+   produced (the reference raises mid-loop). `stats` may be NULL.  `tangent` may be NULL (the Rust
+   entry allows it, comfe-rs/src/interfaces.rs:383-394). */
+FCAMD_API int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
+                                  const double* grad_del_u, double* stress, double* tangent,
+                                  double* const* history, int n_hist, fcamd_stats* stats);
 
-/* Out-of-place form: reads the committed state (stress_prev, history_prev) and writes
-   the trial state (stress, history).  Fuses the copies the reference performs before
-   every call (solver/_lawonsubmesh.py:58-61 stress_local <- stress.previous;
-   solver/_history.py:64-79 history_1 <- history_0).  prev pointers may alias the
-   outputs, which is then exactly fcamd_evaluate_device. */
-int fcamd_evaluate_device_from(fcamd_model* model, double t, double del_t, int64_t n,
-                               const double* grad_del_u, const double* stress_prev,
-                               double* stress, double* tangent,
-                               const double* const* history_prev, double* const* history,
-                               int n_hist);
-
-/* Sparse-trial-history form of fcamd_evaluate_device_from for device-resident Newton loops
-   (the plasticity laws; history rows are touched per point -- tiles in which more than 20 (VonMises3D)
-   / 16 (comfe-rs laws) rows are touched are written as a whole, which restores stale rows as well).
-   Contract: on entry the trial history arrays equal the committed ones except at
-   the points whose bit is set in `history_mask` (one uint64 per 64-point tile, bit l = point
-   64*tile + l; all zero initially).  On return the trial history is exactly what
-   fcamd_evaluate_device_from would have written -- but only plastic points (new value) and
-   points that were plastic at the previous call and are elastic now (restored to the committed
-   value) are touched, and `history_mask` holds the new plastic set.  Elastic points cost no
-   history traffic: HBM traffic equals the algorithmic 464 / 568 bytes per point.  A commit by
-   swapping the committed and trial pointers keeps the contract (the mask then marks the points
-   where the new trial array is stale). */
-int fcamd_evaluate_device_from_sparse(fcamd_model* model, double t, double del_t, int64_t n,
-                                      const double* grad_del_u, const double* stress_prev,
-                                      double* stress, double* tangent,
-                                      const double* const* history_prev, double* const* history,
-                                      int n_hist, uint64_t* history_mask);
-
-/* Submesh-indexed form (multi-material problems, FULL laws): the gather of the committed
-   stress and the scatter of stress and tangent that the reference performs around evaluate
-   (solver/_lawonsubmesh.py:58-70 with SubSpaceMap, solver/maps.py:82-123) are folded into the
-   kernel's addressing.  `grad_del_u` and the history arrays are local to the n points of this
-   law (as in the reference); `stress_prev_parent`, `stress_parent` and `tangent_parent` are
-   the PARENT arrays and point i of this law uses their row `parent_rows[i]` (int32 device
-   array, every row at most once).  Rows of other laws are not touched. */
-int fcamd_evaluate_device_indexed(fcamd_model* model, double t, double del_t, int64_t n,
-                                  const double* grad_del_u, const double* stress_prev_parent,
-                                  double* stress_parent, double* tangent_parent,
-                                  const int32_t* parent_rows,
-                                  const double* const* history_prev, double* const* history,
-                                  int n_hist);
-
-/* Fused form of the reference's 3D -> 1D/2D wrappers around LinearElasticityModel and the plasticity laws (UniaxialStrainFrom3D /
-   PlaneStrainFrom3D, models/utils.py:211-412): `grad_lo`, `stress_lo`, `tangent_lo` are the
-   low-dimensional arrays (1 / 1 / 1 doubles per point for FCAMD_UNIAXIAL_STRAIN, 4 / 4 / 16 for
-   FCAMD_PLANE_STRAIN), `stress_3d` (6 n) is the wrapper's cached 3-D stress whose unmapped
-   components persist from call to call (utils.py:253-266; zero-initialised by the caller), the
-   history is the 3-D law's, everything in place.  One kernel replaces map -> evaluate -> map;
-   no 3-D gradient or tangent array exists.  Other laws: FCAMD_ERR_UNSUPPORTED (use
-   fcamd_convert_device around fcamd_evaluate_device). */
-int fcamd_evaluate_device_wrapped(fcamd_model* model, int wrapper_constraint, double t, double del_t,
-                                  int64_t n, const double* grad_lo, double* stress_lo,
-                                  double* tangent_lo, double* stress_3d, double* const* history,
-                                  int n_hist);
-
-/* General device entry: every option of the forms above in one call.  `parent_rows` (nullable)
-   selects the submesh-indexed addressing of stress / tangent, `history_mask` (nullable) the sparse
-   trial-history protocol (plasticity laws; the mask and the history arrays are local to the
-   law's n points also when parent_rows is given); prev pointers may alias the outputs. */
+/* Device evaluate (roofline path): all pointers are device pointers, 16-byte aligned; asynchronous on the
+   context's stream.  One argument struct carries every form of the call:
+     in place        stress_prev == stress, history_prev == history: the reference's contract;
+     out of place    reads the committed state (stress_prev, history_prev), writes the trial state (stress,
+                     history): fuses the copies the reference performs before every call
+                     (solver/_lawonsubmesh.py:58-61 stress_local <- stress.previous; solver/_history.py:64-79
+                     history_1 <- history_0);
+     parent_rows     submesh-indexed form (multi-material problems, FULL laws): the gather of the committed stress
+                     and the scatter of stress and tangent that the reference performs around evaluate
+                     (solver/_lawonsubmesh.py:58-70 with SubSpaceMap, solver/maps.py:82-123) are folded into the
+                     kernel's addressing.  `grad_del_u` and the history arrays are local to the n points of this
+                     law (as in the reference); stress_prev, stress (stress2) and tangent are the PARENT arrays and
+                     point i uses their row parent_rows[i] (int32 device array, every row at most once);
+     history_mask    sparse trial-history protocol for device-resident Newton loops (plasticity laws).  Contract: on
+                     entry the trial history arrays equal the committed ones except at the points whose bit is set
+                     in history_mask (one uint64 per 64-point tile, bit l = point 64*tile + l; all zero initially).
+                     On return the trial history is exactly what the plain out-of-place call would have written --
+                     but only plastic points (new value) and points that were plastic at the previous call and are
+                     elastic now (restored to the committed value) are touched, and history_mask holds the new plastic
+                     set.  Elastic points cost no history traffic.  A commit by swapping the committed and trial
+                     pointers keeps the contract (the mask then marks the points where the new trial array is stale);
+     wrapper_constraint, stress_3d
+                     fused form of the reference's 3D -> 1D/2D wrappers around LinearElasticityModel and the
+                     plasticity laws (UniaxialStrainFrom3D / PlaneStrainFrom3D, models/utils.py:211-412):
+                     grad_del_u, stress, tangent are the LOW-dimensional arrays (1 / 1 / 1 doubles per point for
+                     FCAMD_UNIAXIAL_STRAIN, 4 / 4 / 16 for FCAMD_PLANE_STRAIN), stress_3d (6 n) is the wrapper's
+                     cached 3-D stress whose unmapped components persist from call to call (utils.py:253-266;
+                     zero-initialised by the caller), the history is the 3-D law's, everything in place
+                     (stress_prev == stress, history_prev == history).  One kernel replaces map -> evaluate -> map;
+                     no 3-D gradient or tangent array exists.  Other laws: FCAMD_ERR_UNSUPPORTED (use
+                     fcamd_convert_device around the plain call);
+     flags           FCAMD_EVAL_* below. */
 typedef struct fcamd_eval_args {
     const double* grad_del_u;
     const double* stress_prev;
@@ -222,6 +226,8 @@ typedef struct fcamd_eval_args {
                                            handle cannot read each other's non-convergence */
     const uint64_t* packed_mask_prev;   /* FCAMD_EVAL_PACKED_HISTORY: the EVER mask of the committed plastic-strain array, */
     uint64_t* packed_mask;              /* ... of the trial array (written); one word per 64-point tile each */
+    int wrapper_constraint;             /* 0, or FCAMD_UNIAXIAL_STRAIN / FCAMD_PLANE_STRAIN: the fused 3D wrapper form */
+    double* stress_3d;                  /* the wrapper's cached 3-D stress (6 n), with wrapper_constraint */
 } fcamd_eval_args;
 /* Layout of a counter buffer: FCAMD_COUNTER_SLOTS slots of 4 words {non-converged points, plastic
    points, Newton iterations, points outside the law's domain}; the totals (fcamd_stats) are the sums
@@ -235,18 +241,8 @@ typedef struct fcamd_eval_args {
    evaluate are written; rows of points that stay elastic -- 288 of their 464 bytes -- are not touched.
    Same array contents as without the flag (tests/test_gpu_resident.py). */
 #define FCAMD_EVAL_SPARSE_TANGENT 1
-/* Delta trial history (needs history_mask and a trial plastic-strain array of its own; VonMises3D: history[0] = eps_n;
-   the comfe-rs plasticity laws with FCAMD_EVAL_SPLIT_HISTORY: history[1] = the eps_p rows).  The plastic-strain array of
-   these laws is write-only with respect to the stress update (models/mises_plasticity_isotropic_hardening.py:161,
-   comfe-rs/src/mises_plasticity.rs:112, plasticity/general.rs:243 only accumulate it), so during the Newton iterations
-   of a device-resident increment the trial array need not hold committed + increment: with this flag it receives the
-   INCREMENTS of the points that are plastic in this call, PACKED per 64-point tile -- the k-th plastic point of tile t
-   (ascending point order, bit k-th set in history_mask[t] after the call) owns doubles [6 (64 t + k), 6 (64 t + k) + 6);
-   the other rows of the tile's slot are undefined -- and the committed rows are not read at all: 28 of the 156 bytes
-   read per point on a random 22 % mixture, and the written rows leave as one contiguous run per tile instead of isolated
-   48-byte rows.  The commit of the increment is fcamd_commit_delta_history (instead of swapping the plastic-strain
-   pointers); the scalar history (alpha / kappa) keeps its usual meaning.  Every other result of the call is unchanged. */
-#define FCAMD_EVAL_DELTA_HISTORY 2
+/* (2 was FCAMD_EVAL_DELTA_HISTORY in 0.3: increments in the trial array plus a commit kernel.  Removed in 0.4 --
+   FCAMD_EVAL_PACKED_HISTORY gives the same contiguous accesses with a pointer-swap commit.) */
 /* Split history (the laws whose reference history is ONE [scalar, eps_p(6)] row of 7 doubles per point: comfe-rs
    MisesPlasticity3D -- alpha --, DruckerPrager3D / DruckerPragerHyperbolic3D -- the hardening variable;
    comfe-rs/src/plasticity/mises_plasticity.rs:58-126, general.rs:105-266).  eps_p only accumulates, the stress update
@@ -254,10 +250,11 @@ typedef struct fcamd_eval_args {
    flag the history of the call is TWO arrays, history[0] = the scalars (n doubles), history[1] = the eps_p rows (6 n
    doubles), n_hist = 2: elastic points then read 8 bytes (Mises) of history and write none.  A layout for
    device-resident states (ResidentState keeps it and assembles the reference's rows on demand), not of the interface
-   arrays; FULL 3-D only; fcamd_evaluate_device_ex and fcamd_evaluate_resident. */
+   arrays; FULL 3-D only. */
 #define FCAMD_EVAL_SPLIT_HISTORY 4
 /* Packed plastic-strain history (with history_mask; VonMises3D: history[0] = eps_n; the comfe-rs plasticity laws with
    FCAMD_EVAL_SPLIT_HISTORY: history[1] = the eps_p rows; not with parent_rows).  The plastic-strain array only accumulates
+   (models/mises_plasticity_isotropic_hardening.py:161, comfe-rs/src/mises_plasticity.rs:112, plasticity/general.rs:243)
    and is +0.0 wherever a point has never been plastic, so a device-resident state keeps BOTH its copies packed per
    64-point tile: the rows of the points whose row is not all +0.0 -- the tile's EVER mask, `packed_mask_prev[tile]` for the
    committed copy, `packed_mask[tile]` for the trial copy -- lie at the head of the tile's slot, the k-th set bit (ascending
@@ -267,68 +264,39 @@ typedef struct fcamd_eval_args {
    and mask word), so the commit is still a swap of pointers -- arrays and mask arrays.  Same values, bit for bit, as the
    unpacked sparse protocol; the scalar history keeps its layout.  ResidentState packs / unpacks at set_state / history. */
 #define FCAMD_EVAL_PACKED_HISTORY 8
-int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_t, int64_t n,
-                             const fcamd_eval_args* args);
-/* The commit of a delta trial history: committed_rows[6 p .. 6 p + 6) += the increment of point p, for the points set in
-   history_mask (the mask left by the last evaluate with FCAMD_EVAL_DELTA_HISTORY), read from the packed layout that
-   evaluate wrote into `delta_rows`.  Asynchronous on the context's stream.  The mask is not modified. */
-int fcamd_commit_delta_history(fcamd_model* model, int64_t n, double* committed_rows, const double* delta_rows,
-                               const uint64_t* history_mask);
-
-/* Host evaluate: the ndarray entry.  Pointers are host arrays laid out as above; results are
-   written back in place.  Two data paths, chosen per call:
-     zero copy -- every array of the call lies inside ranges page-locked with
-                  fcamd_register_host_buffer (and is 16-byte aligned): ONE kernel launch runs
-                  directly on the caller's arrays; the GPU reads the inputs and writes the
-                  results over PCIe itself, both directions at once, no staging buffers;
-     pageable  -- arrays the caller did not register are page-locked for the duration of the call
-                  (FCAMD_HOST_TEMP_LOCK) and treated the same way; calls that move at most
-                  "bounce_max" bytes (256 KiB), and arrays that cannot be locked, go through the
-                  context's own page-locked scratch with CPU copies instead (FCAMD_HOST_BOUNCE).
-                  Pageable caller memory is never handed to the HIP runtime's copy path (its cache
-                  of on-the-fly page locks goes stale when memory is freed and allocated again);
-     staged    -- option "zero_copy" = 0, or an array off the 16-byte grid: chunk by chunk through
-                  device buffers (four chunk slots on four streams: H2D / kernel / D2H of one chunk
-                  overlap the others'), DMA from / into the page-locked arrays.
-   Both produce bit-identical results.  Synchronous.  Validates like the reference and returns
-   the matching status; on FCAMD_ERR_NONCONVERGED the outputs hold the values the kernel
-   produced (the reference raises mid-loop). `stats` may be NULL. */
-int fcamd_evaluate_host(fcamd_model* model, double t, double del_t, int64_t n,
-                        const double* grad_del_u, double* stress, double* tangent,
-                        double* const* history, int n_hist, fcamd_stats* stats);
+FCAMD_API int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_t, int64_t n,
+                                       const fcamd_eval_args* args);
 
 /* Resident-state evaluate for a host assembler (replaces the per-iteration copies of
    solver/_lawonsubmesh.py:58-61,84-95 and solver/_history.py:64-79): the committed and trial
-   copies of stress and history are DEVICE arrays of n points (as in fcamd_evaluate_device_from,
-   committed is read, trial is written), while what must cross PCIe in every Newton iteration
-   stays on the host: `grad_del_u_host` (gd2*n) is uploaded chunk by chunk, each chunk is
+   copies of stress and history are DEVICE arrays of n points (committed is read, trial is written), while what must
+   cross PCIe in every Newton iteration stays on the host: the gradient (gd2*n) is uploaded chunk by chunk, each chunk is
    evaluated on the device-resident state, and the chunk's trial stress and tangent are
    downloaded into `stress_host` (sd*n) / `tangent_host` (sd*sd*n) while the next chunks are in
    flight (either may be NULL).  The tangent never exists as an n-sized device array.  72 B/pt
    up and 336 B/pt down instead of 176 + 392, and no host-side state copies.
+   `state` describes the device-resident arrays exactly as for fcamd_evaluate_device_ex -- stress_prev / stress,
+   history_prev / history, n_hist, history_mask, flags, packed_mask_prev / packed_mask -- with ONE difference:
+   `state->grad_del_u` is the HOST gradient array; tangent, parent_rows, stress2, wrapper_constraint must be NULL / 0 and
+   `counters` is ignored (the call is synchronous and reports through `stats`).
    The host arrays are handled as in fcamd_evaluate_host: ranges registered with
    fcamd_register_host_buffer as they are, pageable arrays page-locked for the duration of the call
    (passes that move at most "bounce_max" bytes: through the context's page-locked scratch).  A
-   page-locked `grad_del_u_host` / `tangent_host` is read / written by the kernel itself (zero copy)
+   page-locked gradient / `tangent_host` is read / written by the kernel itself (zero copy)
    instead of passing through the chunk buffers; when all host arrays of the call are page-locked
    (3-D laws) the whole pass is one launch that writes the stress both to the device-resident trial
    array and to `stress_host`.
-   `state` describes the device-resident arrays exactly as for fcamd_evaluate_device_ex -- stress_prev / stress,
-   history_prev / history, n_hist, history_mask, flags, packed_mask_prev / packed_mask -- with ONE difference:
-   `state->grad_del_u` is the HOST gradient array; `tangent`, `parent_rows`, `stress2` must be NULL and `counters` is
-   ignored (the call is synchronous and reports through `stats`).
-   `history_mask` (nullable) selects the sparse trial-history protocol (plasticity laws).  `flags`: FCAMD_EVAL_SPARSE_TANGENT applies the
-   sparse-tangent protocol to `tangent_host` when the kernel writes it directly: only the rows of
-   plastic / formerly plastic points cross PCIe (the caller's array must still hold the previous
-   call's tangent); ignored on the chunked and scratch paths, which write every row.  FCAMD_EVAL_DELTA_HISTORY / FCAMD_EVAL_SPLIT_HISTORY / FCAMD_EVAL_PACKED_HISTORY as in fcamd_evaluate_device_ex.  Synchronous; waits for work queued on the
-   context stream before touching the state arrays.  Status and `stats` as fcamd_evaluate_host. */
-int fcamd_evaluate_resident(fcamd_model* model, double t, double del_t, int64_t n, const fcamd_eval_args* state,
-                            double* stress_host, double* tangent_host, fcamd_stats* stats);
+   FCAMD_EVAL_SPARSE_TANGENT applies the sparse-tangent protocol to `tangent_host` when the kernel writes it directly:
+   only the rows of plastic / formerly plastic points cross PCIe (the caller's array must still hold the previous
+   call's tangent); ignored on the chunked and scratch paths, which write every row.  Synchronous; waits for work queued
+   on the context stream before touching the state arrays.  Status and `stats` as fcamd_evaluate_host. */
+FCAMD_API int fcamd_evaluate_resident(fcamd_model* model, double t, double del_t, int64_t n, const fcamd_eval_args* state,
+                                      double* stress_host, double* tangent_host, fcamd_stats* stats);
 
 /* Mandel strain from displacement gradient, FULL (utils.py:132-151,187-208).
    rust_factor = 0: factor 1/2**0.5 (Python); 1: FRAC_1_SQRT_2 (mandel.rs:147). */
-int fcamd_strain_from_grad_u_device(fcamd_context* ctx, int64_t n, const double* grad_u,
-                                    double* strain, int rust_factor);
+FCAMD_API int fcamd_strain_from_grad_u_device(fcamd_context* ctx, int64_t n, const double* grad_u,
+                                              double* strain, int rust_factor);
 
 /* Component maps of the reference's 3D->1D/2D wrappers (models/utils.py:276-297, 362-412):
    strided copies between a low-dimensional AoS array and its 3-D counterpart.  "TO_3D" kinds
@@ -344,7 +312,7 @@ typedef enum fcamd_convert_kind {
     FCAMD_STRESS_3D_TO_2D = 7,   /* stress2d[4i+0..3]   <- stress3d[6i+0..3]    utils.py:385-388 */
     FCAMD_TANGENT_3D_TO_2D = 8   /* tangent2d[16i+4r+c] <- tangent3d[36i+6r+c], r,c<4  utils.py:390-412 */
 } fcamd_convert_kind;
-int fcamd_convert_device(fcamd_context* ctx, int kind, int64_t n, const double* src, double* dst);
+FCAMD_API int fcamd_convert_device(fcamd_context* ctx, int kind, int64_t n, const double* src, double* dst);
 
 /* Row gather/scatter between a parent quadrature array and a per-material submesh array:
        dst[row_size*dst_idx[r] + k] = src[row_size*src_idx[r] + k],  r < n_rows, k < row_size
@@ -352,12 +320,13 @@ int fcamd_convert_device(fcamd_context* ctx, int kind, int64_t n, const double* 
    "parent_array[self.parent] = sub_array[self.sub]" with rows of 6 (stress) or 36 (tangent)
    doubles).  Index arrays are int32 device arrays (dolfinx dof indices are int32); NULL means
    the identity (IdentityMap, solver/maps.py:29-59). */
-int fcamd_map_rows_device(fcamd_context* ctx, int64_t n_rows, int row_size, const double* src,
-                          const int32_t* src_idx, double* dst, const int32_t* dst_idx);
+FCAMD_API int fcamd_map_rows_device(fcamd_context* ctx, int64_t n_rows, int row_size, const double* src,
+                                    const int32_t* src_idx, double* dst, const int32_t* dst_idx);
 
-/* Synchronise the stream and read the counters accumulated by the last
-   evaluate_device* launch of this model. */
-int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
+/* Synchronise the stream and read the counters accumulated by the last fcamd_evaluate_device_ex launch of this model
+   (and `kernel_ms`, see fcamd_stats: the counterpart of the reference's Timer("constitutive-law-evaluation") around
+   evaluate, solver/_lawonsubmesh.py:86). */
+FCAMD_API int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
 
 /* Caller arrays are stable across Newton iterations (views of Function.x.array,
    solver/_lawonsubmesh.py:87-94): page-lock and map them once.  fcamd_evaluate_host /
@@ -368,46 +337,47 @@ int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
    does not carry it, and a launch on it ends in a GPU memory fault.  Registering is an optimisation
    only: arrays that are not registered are page-locked for the duration of each call.  A range that ANOTHER context of
    the process has registered already (several GPUs or threads, one array) is entered into this context's registry with
-   its own device's view of it; the page lock stays with the first context -- unregister it there last.  Threads: a range
+   its own device's view of it; the page lock is shared and reference-counted -- it is released when the LAST of the
+   contexts unregisters the range (or is destroyed), in any order.  Threads: a range
    on which a host entry of another thread is running right now (it holds a call-scoped page lock) is refused with
    FCAMD_ERR_BAD_ARG -- register between calls; unregistering a range while another thread's call uses it is the
    caller's error, like freeing it. */
-int fcamd_register_host_buffer(fcamd_context* ctx, void* ptr, size_t bytes);
-int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
-/* Data path the last fcamd_evaluate_host / fcamd_evaluate_resident call of this context took:
-   a bit mask of the flags below (0 = everything staged). */
+FCAMD_API int fcamd_register_host_buffer(fcamd_context* ctx, void* ptr, size_t bytes);
+FCAMD_API int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
+/* Data path of the last fcamd_evaluate_host / fcamd_evaluate_resident call of a context (context option
+   "last_host_mode", read-only): a bit mask of the flags below (0 = everything staged). */
 #define FCAMD_HOST_ZERO_COPY_IN 1  /* inputs read by the kernel from the caller's host arrays */
 #define FCAMD_HOST_ZERO_COPY_OUT 2 /* results written by the kernel into the caller's host arrays */
 #define FCAMD_HOST_TEMP_LOCK 4     /* pageable caller arrays were page-locked for the duration of the call */
 #define FCAMD_HOST_BOUNCE 8        /* pageable caller arrays were moved by the CPU through the context's page-locked scratch */
-int fcamd_context_last_host_mode(fcamd_context* ctx, int* mode);
-/* Address at which the device entries (fcamd_evaluate_device*) can read / write the host range
+/* Address at which fcamd_evaluate_device_ex can read / write the host range
    [host_ptr, host_ptr + bytes): it must lie inside one range registered with
    fcamd_register_host_buffer and be 16-byte aligned (FCAMD_ERR_BAD_ARG otherwise).  With it a device
    launch can take the host assembler's arrays as operands -- e.g. the PARENT stress / tangent arrays
-   of a multi-material problem as `stress2` / `tangent` of fcamd_evaluate_device_ex with `parent_rows`:
+   of a multi-material problem as `stress2` / `tangent` with `parent_rows`:
    the reference's map_to_parent copies (solver/maps.py:82-101) then happen inside the kernel, over
    PCIe.  The caller synchronises (fcamd_context_synchronize) before the host reads the results. */
-int fcamd_host_device_pointer(fcamd_context* ctx, const void* host_ptr, size_t bytes, void** device_ptr);
+FCAMD_API int fcamd_host_device_pointer(fcamd_context* ctx, const void* host_ptr, size_t bytes, void** device_ptr);
 
-/* Synchronous copies between the caller's HOST memory and device memory, ordered after the work queued on the
-   context stream.  Like the host entries they never hand pageable memory to the HIP runtime's copy path (whose cache
-   of on-the-fly page locks is keyed by address and goes stale when memory is freed and allocated again -- a GPU
-   memory fault on this stack): up to "bounce_max" bytes go through the context's own page-locked
-   scratch, larger ranges are page-locked for the duration of the copy, registered ranges are used as they are.
-   What the reference does with `array[:] = other` between NumPy arrays (solver/_history.py:64-79) is, for a
-   device-resident state, one of these. */
-int fcamd_copy_to_device(fcamd_context* ctx, void* dst_device, const void* src_host, size_t bytes);
-int fcamd_copy_to_host(fcamd_context* ctx, void* dst_host, const void* src_device, size_t bytes);
-/* Device-to-device copy on the context stream (asynchronous) with the access pattern of the evaluate kernels: 16 bytes
-   per lane, non-temporal loads and stores, one contiguous KiB per wave instruction.  What a device-resident state uses
-   for "trial = committed" (solver/_history.py:64-79 on NumPy arrays) and what bench.py reports as the achievable copy
-   rate of the box next to the 8 TB/s peak.  Both pointers 16-byte aligned. */
-int fcamd_copy_device(fcamd_context* ctx, void* dst_device, const void* src_device, size_t bytes);
+/* Copies, ordered after the work queued on the context stream.
+     FCAMD_COPY_TO_DEVICE / FCAMD_COPY_TO_HOST   synchronous, between the caller's HOST memory and device memory.  Like the
+         host entries they never hand pageable memory to the HIP runtime's copy path (whose cache of on-the-fly page locks is
+         keyed by address and goes stale when memory is freed and allocated again -- a GPU memory fault on this stack,
+         DESIGN.md 6): up to "bounce_max" bytes go through the context's own page-locked scratch, larger ranges are
+         page-locked for the duration of the copy, registered ranges are used as they are.  What the reference does with
+         `array[:] = other` between NumPy arrays (solver/_history.py:64-79) is, for a device-resident state, one of these;
+     FCAMD_COPY_DEVICE   device to device, asynchronous, with the access pattern of the evaluate kernels: 16 bytes per lane,
+         non-temporal loads and stores, one contiguous KiB per wave instruction -- "trial = committed" of a device-resident
+         state, and what bench.py reports as the achievable copy rate of the box next to the 8 TB/s peak.
+         Both pointers 16-byte aligned. */
+#define FCAMD_COPY_TO_DEVICE 1
+#define FCAMD_COPY_TO_HOST 2
+#define FCAMD_COPY_DEVICE 3
+FCAMD_API int fcamd_copy(fcamd_context* ctx, void* dst, const void* src, size_t bytes, int kind);
 
 /* ---- multi-GPU: contiguous shards + all-gather ------------------------ */
 /* The quadrature-point axis [0, n) is cut into `world` contiguous slices that start on 64-point
-   (wavefront-tile) boundaries and are padded to one common length, the SLOT (fcamd_shard_slot_points):
+   (wavefront-tile) boundaries and are padded to one common length, the SLOT (`slot_points`, nullable):
    rank r owns [lo, hi) = [min(r*slot, n), min(r*slot + slot, n)); trailing ranks may be empty.  Every
    array slices by dim*lo.  Evaluation needs no collective and the history stays sharded; the only
    exchange is the optional all-gather of stress (6/pt) and tangent (36/pt) for ONE assembling process
@@ -415,8 +385,7 @@ int fcamd_copy_device(fcamd_context* ctx, void* dst_device, const void* src_devi
    forwarding, solver/_solver.py:146-147).  A gathered buffer has world*slot*dim doubles, rank r's slice
    in slot r; because every rank before the last non-empty one is full, its first dim*n doubles are the
    global array. */
-int fcamd_shard_slot_points(int64_t n, int world, int64_t* per_rank);
-int fcamd_shard_bounds(int64_t n, int world, int rank, int64_t* lo, int64_t* hi);
+FCAMD_API int fcamd_shard_bounds(int64_t n, int world, int rank, int64_t* lo, int64_t* hi, int64_t* slot_points);
 
 /* Chunked gather for shards whose gathered tangent does not fit next to the working set (config 5:
    8 x 1e8 points = 230 GB of gathered tangent per GPU): the assembler consumes the gathered array chunk
@@ -425,33 +394,30 @@ int fcamd_shard_bounds(int64_t n, int world, int rank, int64_t* lo, int64_t* hi)
    tile-aligned chunk length whose buffers fit into `budget_bytes` (then equalised over the chunks) and
    the number of chunks; FCAMD_ERR_SIZE if not even one tile per rank fits -- the budget is checked up
    front, before anything is allocated. */
-int fcamd_gather_chunk_plan(int64_t slot_points, int world, int values_per_point, size_t budget_bytes,
-                            int n_buffers, int64_t* chunk_points, int64_t* n_chunks);
+FCAMD_API int fcamd_gather_chunk_plan(int64_t slot_points, int world, int values_per_point, size_t budget_bytes,
+                                      int n_buffers, int64_t* chunk_points, int64_t* n_chunks);
 
 /* One rank per process: a peer's gathered buffer is mapped through HIP IPC.  fcamd_ipc_export gives
    the handle of the ALLOCATION `device_ptr` lies in plus its offset inside it (the pointer may be a
    sub-block of a caching allocator, e.g. a torch tensor); the 64 bytes + offset travel to the peers by
    any host channel (torch.distributed.all_gather_object, MPI); fcamd_ipc_open maps it there.  A mapping
-   is closed with the same offset it was opened with, before the owner frees the memory. */
-#define FCAMD_IPC_HANDLE_BYTES 64
-/* Device buffer meant to be mapped by peers.  Plain hipMalloc, with one precaution: on this ROCm stack
+   is closed with the same offset it was opened with, before the owner frees the memory.
+   Buffers meant to be mapped by peers come from fcamd_device_alloc_set(order = FCAMD_ALLOC_IPC): on this ROCm stack
    hipIpcOpenMemHandle never returns for an allocation whose size has bit 31 set ((size mod 4 GiB) >= 2 GiB;
-   measured, tools/ipc_open_probe.py), so such a request is rounded up to the next multiple of 4 GiB.
+   measured, tools/ipc_open_probe.py), so such a request is rounded up to the next multiple of 4 GiB there, and
    fcamd_ipc_export refuses (FCAMD_ERR_UNSUPPORTED) a pointer whose allocation has such a size instead of
    letting the peers hang. */
-int fcamd_ipc_alloc(fcamd_context* ctx, size_t bytes, void** device_ptr);
-int fcamd_ipc_free(fcamd_context* ctx, void* device_ptr);
-int fcamd_ipc_export(fcamd_context* ctx, const void* device_ptr, unsigned char handle[FCAMD_IPC_HANDLE_BYTES],
-                     size_t* offset_bytes);
-int fcamd_ipc_open(fcamd_context* ctx, const unsigned char handle[FCAMD_IPC_HANDLE_BYTES], size_t offset_bytes,
-                   void** device_ptr);
-int fcamd_ipc_close(fcamd_context* ctx, void* device_ptr, size_t offset_bytes);
-/* One process driving several GPUs: let the context's device access `peer_device`'s memory directly. */
-int fcamd_enable_peer_access(fcamd_context* ctx, int peer_device);
+#define FCAMD_IPC_HANDLE_BYTES 64
+FCAMD_API int fcamd_ipc_export(fcamd_context* ctx, const void* device_ptr, unsigned char handle[FCAMD_IPC_HANDLE_BYTES],
+                               size_t* offset_bytes);
+FCAMD_API int fcamd_ipc_open(fcamd_context* ctx, const unsigned char handle[FCAMD_IPC_HANDLE_BYTES], size_t offset_bytes,
+                             void** device_ptr);
+FCAMD_API int fcamd_ipc_close(fcamd_context* ctx, void* device_ptr, size_t offset_bytes);
 
 /* Direct (one-hop) all-gather, in place: `gathered[p]` is the address, in THIS process, of rank p's
    gathered buffer (own allocation for p == rank; an IPC mapping or an allocation on another device of
-   this process otherwise), `devices[p]` its HIP device ordinal (NULL: all on the context's device or
+   this process otherwise -- context option "peer_access" = that device lets the context's device reach it), `devices[p]`
+   its HIP device ordinal (NULL: all on the context's device or
    reachable by unified addressing).  Bytes [offset_bytes, offset_bytes + bytes) of a slot of slot_bytes
    are exchanged (offset / bytes select one chunk of a chunked gather).
      push (default):    this rank's slot is copied into the same slot of every peer's buffer;
@@ -467,9 +433,9 @@ int fcamd_enable_peer_access(fcamd_context* ctx, int peer_device);
    the previous contents of its buffer (the push overwrites them): synchronise the consumers' streams and pass a
    barrier first, or alternate between two gathered buffers (sharded.py: allgather_peer does the former). */
 #define FCAMD_GATHER_PULL 1
-int fcamd_allgather_direct(fcamd_context* ctx, int world, int rank, void* const* gathered, const int* devices,
-                           size_t slot_bytes, size_t offset_bytes, size_t bytes, int flags);
-int fcamd_allgather_direct_wait(fcamd_context* ctx, int host_sync);
+FCAMD_API int fcamd_allgather_direct(fcamd_context* ctx, int world, int rank, void* const* gathered, const int* devices,
+                                     size_t slot_bytes, size_t offset_bytes, size_t bytes, int flags);
+FCAMD_API int fcamd_allgather_direct_wait(fcamd_context* ctx, int host_sync);
 
 /* ---- one process, several GPUs: the single assembler's host entry (SURVEY 8b last row, 8e) ------------- */
 /* north_star's single-process mode: ONE dolfinx process assembles, its arrays are host memory (views of
@@ -487,28 +453,26 @@ int fcamd_allgather_direct_wait(fcamd_context* ctx, int host_sync);
 typedef struct fcamd_multi fcamd_multi;
 #define FCAMD_MULTI_MAX_DEVICES 64
 #define FCAMD_MULTI_MIN_POINTS 8192
-int fcamd_multi_create(const int* devices, int n_devices, int model_id, int constraint, const double* params,
-                       int n_params, fcamd_multi** out);
-int fcamd_multi_destroy(fcamd_multi* mg);  /* also destroys the fcamd_multi_state objects still alive on it */
-int fcamd_multi_device_count(const fcamd_multi* mg, int* n_devices);
-/* Number of devices a call over n points uses, and the slice [lo, hi) of device slot k in that call. */
-int fcamd_multi_plan(const fcamd_multi* mg, int64_t n, int* n_used);
-int fcamd_multi_bounds(const fcamd_multi* mg, int64_t n, int k, int64_t* lo, int64_t* hi);
+FCAMD_API int fcamd_multi_create(const int* devices, int n_devices, int model_id, int constraint, const double* params,
+                                 int n_params, fcamd_multi** out);
+FCAMD_API int fcamd_multi_destroy(fcamd_multi* mg);  /* also destroys the fcamd_multi_state objects still alive on it */
+/* How a call over n points is spread: the number of devices it uses and the slice [lo, hi) of device slot k in that
+   call (every output nullable; k is ignored when lo and hi are NULL). */
+FCAMD_API int fcamd_multi_plan(const fcamd_multi* mg, int64_t n, int k, int* n_used, int64_t* lo, int64_t* hi);
 /* fcamd_evaluate_host over all devices: same arguments, same status codes (the first failing slice's), `stats` =
    the sums over the slices.  In place on the caller's host arrays. */
-int fcamd_multi_evaluate_host(fcamd_multi* mg, double t, double del_t, int64_t n, const double* grad_del_u,
-                              double* stress, double* tangent, double* const* history, int n_hist,
-                              fcamd_stats* stats);
+FCAMD_API int fcamd_multi_evaluate_host(fcamd_multi* mg, double t, double del_t, int64_t n, const double* grad_del_u,
+                                        double* stress, double* tangent, double* const* history, int n_hist,
+                                        fcamd_stats* stats);
 /* Page-lock a caller range once for ALL devices of the handle (fcamd_register_host_buffer for every context, one
-   lock): calls on it skip the per-call page lock.  Unregister before freeing the memory. */
-int fcamd_multi_register_host_buffer(fcamd_multi* mg, void* ptr, size_t bytes);
-int fcamd_multi_unregister_host_buffer(fcamd_multi* mg, void* ptr);
-/* Data path every device of the last call took (FCAMD_HOST_* flags, OR-ed over the devices used), and how many
-   devices it used. */
-int fcamd_multi_last_host_mode(const fcamd_multi* mg, int* mode, int* n_used);
-/* Option of every context of the handle (fcamd_context_set_option), or the handle's own "min_points" (default
-   FCAMD_MULTI_MIN_POINTS: a call over n points uses at most n / min_points devices). */
-int fcamd_multi_set_option(fcamd_multi* mg, const char* name, long long value);
+   lock): calls on it skip the per-call page lock.  bytes = 0 UNREGISTERS the range that starts at ptr -- do it before
+   freeing the memory. */
+FCAMD_API int fcamd_multi_register_host_buffer(fcamd_multi* mg, void* ptr, size_t bytes);
+/* Options.  set: an option of every context of the handle (fcamd_context_set_option), or the handle's own "min_points"
+   (default FCAMD_MULTI_MIN_POINTS: a call over n points uses at most n / min_points devices).  get (read-only):
+   "n_devices"; "last_host_mode" (FCAMD_HOST_* flags of the last call, OR-ed over the devices used), "last_n_used". */
+FCAMD_API int fcamd_multi_set_option(fcamd_multi* mg, const char* name, long long value);
+FCAMD_API int fcamd_multi_get_option(const fcamd_multi* mg, const char* name, long long* value);
 
 /* Device-resident increment state over several GPUs (SURVEY 8f-1 for the single assembler): device slot k keeps the
    committed and the trial copy of stress and history of ITS slice of the n points (fcamd_shard_bounds(n, devices, k))
@@ -526,13 +490,13 @@ int fcamd_multi_set_option(fcamd_multi* mg, const char* name, long long value);
      _get       host arrays <- committed (trial = 0) or trial (trial = 1) state, in the law's reference layout.
    History arrays at the interface are always the law's history_dim fields (7-double rows for the comfe-rs laws). */
 typedef struct fcamd_multi_state fcamd_multi_state;
-int fcamd_multi_state_create(fcamd_multi* mg, int64_t n, int flags, fcamd_multi_state** out);
-int fcamd_multi_state_destroy(fcamd_multi_state* st);
-int fcamd_multi_state_set(fcamd_multi_state* st, const double* stress_host, const double* const* history_host, int n_hist);
-int fcamd_multi_state_get(fcamd_multi_state* st, int trial, double* stress_host, double* const* history_host, int n_hist);
-int fcamd_multi_state_evaluate(fcamd_multi_state* st, double t, double del_t, const double* grad_del_u_host,
-                               double* stress_host, double* tangent_host, int flags, fcamd_stats* stats);
-int fcamd_multi_state_commit(fcamd_multi_state* st);
+FCAMD_API int fcamd_multi_state_create(fcamd_multi* mg, int64_t n, int flags, fcamd_multi_state** out);
+FCAMD_API int fcamd_multi_state_destroy(fcamd_multi_state* st);
+FCAMD_API int fcamd_multi_state_set(fcamd_multi_state* st, const double* stress_host, const double* const* history_host, int n_hist);
+FCAMD_API int fcamd_multi_state_get(fcamd_multi_state* st, int trial, double* stress_host, double* const* history_host, int n_hist);
+FCAMD_API int fcamd_multi_state_evaluate(fcamd_multi_state* st, double t, double del_t, const double* grad_del_u_host,
+                                         double* stress_host, double* tangent_host, int flags, fcamd_stats* stats);
+FCAMD_API int fcamd_multi_state_commit(fcamd_multi_state* st);
 
 /* ---- device memory -------------------------------------------------------------- */
 /* A working set whose physical placement is chosen by the call: `n_arrays` address ranges of bytes[k]
@@ -540,44 +504,215 @@ int fcamd_multi_state_commit(fcamd_multi_state* st);
    to the device's allocation granularity) created either array after array (FCAMD_ALLOC_SEQUENTIAL) or
    interleaved over all arrays in proportion to their sizes (FCAMD_ALLOC_INTERLEAVED) through
    hipMemAddressReserve / hipMemCreate / hipMemMap.  Background: on MI355X the kernel time follows where
-   the written arrays live.  ptrs[k] receives the base of array k; each array is released
-   on its own with fcamd_device_free (which synchronises the device). */
+   the written arrays live.  FCAMD_ALLOC_IPC: plain hipMalloc blocks that peers can map
+   (fcamd_ipc_export; sizes rounded as described there, granule_bytes ignored).  ptrs[k] receives the base of array k;
+   each array is released on its own with fcamd_device_free (which synchronises the device). */
 #define FCAMD_ALLOC_SEQUENTIAL 0
 #define FCAMD_ALLOC_INTERLEAVED 1
-int fcamd_device_alloc_set(fcamd_context* ctx, int n_arrays, const size_t* bytes, size_t granule_bytes, int order,
-                           void** ptrs);
-int fcamd_device_free(fcamd_context* ctx, void* ptr);
-/* Note: the ADDRESS RANGES of a set are never returned to the runtime (on this stack a range that is reserved again
+#define FCAMD_ALLOC_IPC 2
+FCAMD_API int fcamd_device_alloc_set(fcamd_context* ctx, int n_arrays, const size_t* bytes, size_t granule_bytes, int order,
+                                     void** ptrs);
+FCAMD_API int fcamd_device_free(fcamd_context* ctx, void* ptr);
+/* Note: the ADDRESS RANGES of a VMM set are never returned to the runtime (on this stack a range that is reserved again
    and mapped to new handles serves stale data); the physical memory is.  A process that builds and frees many sets
    consumes virtual address space only (47 bits of it are plentiful: 1e4 sets of 64 GB). */
 
 /* ---- tuning / introspection -------------------------------------------------- */
-/* Override the launch grid (number of 256-thread workgroups; 0 = automatic). */
-int fcamd_context_set_grid(fcamd_context* ctx, int n_workgroups);
-/* Timing of the hot call -- the counterpart of the reference's Timer("constitutive-law-evaluation")
-   around evaluate (solver/_lawonsubmesh.py:86).  With timing enabled (default off) EVERY device entry
-   (fcamd_evaluate_device, _from, _from_sparse, _indexed, _ex, _wrapped) is bracketed by HIP events on
-   the context's stream and fcamd_model_last_kernel_ms returns the kernel time of the model's last
-   entry (synchronises); after a host entry (fcamd_evaluate_host, fcamd_evaluate_resident -- they are
-   synchronous) it returns the wall-clock of that call, copies included. */
-int fcamd_model_last_kernel_ms(fcamd_model* model, float* ms);
-int fcamd_context_set_timing(fcamd_context* ctx, int enabled);
-/* Launch / data-path knobs (experiments; the defaults are the measured optimum).  Names and their
-   FCAMD_* environment defaults, which are read ONCE, when the context is created:
+/* Context options (name, value).  Launch / data-path knobs (experiments; the defaults are the measured optimum) and
+   their FCAMD_* environment defaults, which are read ONCE, when the context is created:
      "tile_map" (FCAMD_TILE_MAP, 0), "masked_max" (FCAMD_MASKED_MAX, -1 = per law), "nontemporal"
      (FCAMD_NT, 1), "host_chunk" (FCAMD_HOST_CHUNK, 0 = automatic), "host_slots" (FCAMD_HOST_SLOTS, 4),
      "bounce_max" (FCAMD_BOUNCE_MAX, 256 KiB: host calls up to this size go through the page-locked scratch),
-     "zero_copy" (FCAMD_ZERO_COPY, 1), "zero_copy_grad" (FCAMD_ZERO_COPY_GRAD, 1). */
-int fcamd_context_set_option(fcamd_context* ctx, const char* name, long long value);
-int fcamd_context_get_option(fcamd_context* ctx, const char* name, long long* value);
-/* Release the staging buffers the pageable host path keeps between calls (up to ~1.1 GB). */
-int fcamd_context_trim(fcamd_context* ctx);
+     "zero_copy" (FCAMD_ZERO_COPY, 1), "zero_copy_grad" (FCAMD_ZERO_COPY_GRAD, 1);
+   "grid": the launch grid (number of 256-thread workgroups; 0 = automatic);
+   "timing": 1 = every fcamd_evaluate_device_ex is bracketed by HIP events on the context's stream and every host entry
+       by a wall clock; fcamd_model_last_stats reports the time (fcamd_stats.kernel_ms) -- the counterpart of the
+       reference's Timer("constitutive-law-evaluation") around evaluate (solver/_lawonsubmesh.py:86); default 0;
+   "peer_access" (set only): value = a HIP device ordinal whose memory the context's device may access directly from
+       now on (one process driving several GPUs: fcamd_allgather_direct);
+   "trim" (set only): release the staging buffers the pageable host path keeps between calls (up to ~1.1 GB);
+   "last_host_mode" (get only): FCAMD_HOST_* flags of the context's last host entry. */
+FCAMD_API int fcamd_context_set_option(fcamd_context* ctx, const char* name, long long value);
+FCAMD_API int fcamd_context_get_option(fcamd_context* ctx, const char* name, long long* value);
 
 /* Number of HIP devices visible to the process (0 and FCAMD_OK when there is none). */
-int fcamd_device_count(int* count);
-const char* fcamd_last_error(void);
-const char* fcamd_status_string(int status);
-int fcamd_version(void);
+FCAMD_API int fcamd_device_count(int* count);
+FCAMD_API const char* fcamd_last_error(void);
+FCAMD_API int fcamd_version(void);
+
+/* ================================================================================================================
+ * Conveniences: `static inline` shorthands of the entries above (the names and arguments of ABI 0.3).  No symbols.
+ * ================================================================================================================ */
+#if defined(__GNUC__) || defined(__clang__)
+#define FCAMD_INLINE static inline __attribute__((unused))
+#else
+#define FCAMD_INLINE static inline
+#endif
+
+FCAMD_INLINE const char* fcamd_status_string(int status) {
+    switch (status) {
+        case FCAMD_OK: return "ok";
+        case FCAMD_ERR_SIZE: return "Stress, strain, and tangent lengths do not match";
+        case FCAMD_ERR_NULL_HISTORY: return "history must not be None";
+        case FCAMD_ERR_DEL_T: return "Time step must be defined and positive.";
+        case FCAMD_ERR_NONCONVERGED: return "Newton-Raphson method did not converge for plastic multiplier.";
+        case FCAMD_ERR_HIP: return "HIP runtime error";
+        case FCAMD_ERR_BAD_ARG: return "bad argument";
+        case FCAMD_ERR_ALIGN: return "device arrays must be 16-byte aligned";
+        case FCAMD_ERR_UNSUPPORTED: return "constraint / layout not implemented";
+        case FCAMD_ERR_DOMAIN: return "non-differentiable tip of Drucker-Prager surface reached";
+        default: return "unknown status";
+    }
+}
+
+/* history_dim and the other getters, one value at a time (models/interfaces.py:103-143; bindings/src/lib.rs:131-148) */
+FCAMD_INLINE int fcamd_model_history_count(const fcamd_model* model, int* n_fields) {
+    fcamd_model_info i;
+    const int st = fcamd_model_get_info(model, &i);
+    if (st != FCAMD_OK) return st;
+    if (!n_fields) return FCAMD_ERR_BAD_ARG;
+    *n_fields = i.n_history;
+    return FCAMD_OK;
+}
+FCAMD_INLINE int fcamd_model_history_field(const fcamd_model* model, int k, const char** name, int* dim) {
+    fcamd_model_info i;
+    const int st = fcamd_model_get_info(model, &i);
+    if (st != FCAMD_OK) return st;
+    if (!name || !dim || k < 0 || k >= i.n_history) return FCAMD_ERR_BAD_ARG;
+    *name = i.history_name[k];
+    *dim = i.history_dim[k];
+    return FCAMD_OK;
+}
+FCAMD_INLINE int fcamd_model_constraint(const fcamd_model* model, int* constraint) {
+    fcamd_model_info i;
+    const int st = fcamd_model_get_info(model, &i);
+    if (st != FCAMD_OK) return st;
+    if (!constraint) return FCAMD_ERR_BAD_ARG;
+    *constraint = i.constraint;
+    return FCAMD_OK;
+}
+FCAMD_INLINE int fcamd_model_dims(const fcamd_model* model, int* stress_strain_dim, int* geometric_dim) {
+    fcamd_model_info i;
+    const int st = fcamd_model_get_info(model, &i);
+    if (st != FCAMD_OK) return st;
+    if (!stress_strain_dim || !geometric_dim) return FCAMD_ERR_BAD_ARG;
+    *stress_strain_dim = i.stress_strain_dim;
+    *geometric_dim = i.geometric_dim;
+    return FCAMD_OK;
+}
+
+/* the narrower device forms: out of place; in place; sparse trial history; submesh-indexed; fused 3D wrapper */
+FCAMD_INLINE int fcamd_evaluate_device_from(fcamd_model* model, double t, double del_t, int64_t n,
+                                            const double* grad_del_u, const double* stress_prev,
+                                            double* stress, double* tangent,
+                                            const double* const* history_prev, double* const* history, int n_hist) {
+    fcamd_eval_args x = {0};
+    x.grad_del_u = grad_del_u, x.stress_prev = stress_prev, x.stress = stress, x.tangent = tangent;
+    x.history_prev = history_prev, x.history = history, x.n_hist = n_hist;
+    return fcamd_evaluate_device_ex(model, t, del_t, n, &x);
+}
+FCAMD_INLINE int fcamd_evaluate_device(fcamd_model* model, double t, double del_t, int64_t n,
+                                       const double* grad_del_u, double* stress, double* tangent,
+                                       double* const* history, int n_hist) {
+    return fcamd_evaluate_device_from(model, t, del_t, n, grad_del_u, stress, stress, tangent,
+                                      (const double* const*)history, history, n_hist);
+}
+FCAMD_INLINE int fcamd_evaluate_device_from_sparse(fcamd_model* model, double t, double del_t, int64_t n,
+                                                   const double* grad_del_u, const double* stress_prev,
+                                                   double* stress, double* tangent,
+                                                   const double* const* history_prev, double* const* history,
+                                                   int n_hist, uint64_t* history_mask) {
+    fcamd_eval_args x = {0};
+    if (n > 0 && !history_mask) return FCAMD_ERR_BAD_ARG;
+    x.grad_del_u = grad_del_u, x.stress_prev = stress_prev, x.stress = stress, x.tangent = tangent;
+    x.history_prev = history_prev, x.history = history, x.n_hist = n_hist, x.history_mask = history_mask;
+    return fcamd_evaluate_device_ex(model, t, del_t, n, &x);
+}
+FCAMD_INLINE int fcamd_evaluate_device_indexed(fcamd_model* model, double t, double del_t, int64_t n,
+                                               const double* grad_del_u, const double* stress_prev_parent,
+                                               double* stress_parent, double* tangent_parent,
+                                               const int32_t* parent_rows,
+                                               const double* const* history_prev, double* const* history, int n_hist) {
+    fcamd_eval_args x = {0};
+    if (n > 0 && !parent_rows) return FCAMD_ERR_BAD_ARG;
+    x.grad_del_u = grad_del_u, x.stress_prev = stress_prev_parent, x.stress = stress_parent, x.tangent = tangent_parent;
+    x.history_prev = history_prev, x.history = history, x.n_hist = n_hist, x.parent_rows = parent_rows;
+    return fcamd_evaluate_device_ex(model, t, del_t, n, &x);
+}
+FCAMD_INLINE int fcamd_evaluate_device_wrapped(fcamd_model* model, int wrapper_constraint, double t, double del_t,
+                                               int64_t n, const double* grad_lo, double* stress_lo,
+                                               double* tangent_lo, double* stress_3d, double* const* history, int n_hist) {
+    fcamd_eval_args x = {0};
+    x.grad_del_u = grad_lo, x.stress_prev = stress_lo, x.stress = stress_lo, x.tangent = tangent_lo;
+    x.history_prev = (const double* const*)history, x.history = history, x.n_hist = n_hist;
+    x.wrapper_constraint = wrapper_constraint ? wrapper_constraint : -1, x.stress_3d = stress_3d;
+    return fcamd_evaluate_device_ex(model, t, del_t, n, &x);
+}
+
+/* copies, one direction per name */
+FCAMD_INLINE int fcamd_copy_to_device(fcamd_context* ctx, void* dst_device, const void* src_host, size_t bytes) {
+    return fcamd_copy(ctx, dst_device, src_host, bytes, FCAMD_COPY_TO_DEVICE);
+}
+FCAMD_INLINE int fcamd_copy_to_host(fcamd_context* ctx, void* dst_host, const void* src_device, size_t bytes) {
+    return fcamd_copy(ctx, dst_host, src_device, bytes, FCAMD_COPY_TO_HOST);
+}
+FCAMD_INLINE int fcamd_copy_device(fcamd_context* ctx, void* dst_device, const void* src_device, size_t bytes) {
+    return fcamd_copy(ctx, dst_device, src_device, bytes, FCAMD_COPY_DEVICE);
+}
+
+/* options by name */
+FCAMD_INLINE int fcamd_context_set_grid(fcamd_context* ctx, int n_workgroups) { return fcamd_context_set_option(ctx, "grid", n_workgroups); }
+FCAMD_INLINE int fcamd_context_set_timing(fcamd_context* ctx, int enabled) { return fcamd_context_set_option(ctx, "timing", enabled); }
+FCAMD_INLINE int fcamd_context_trim(fcamd_context* ctx) { return fcamd_context_set_option(ctx, "trim", 1); }
+FCAMD_INLINE int fcamd_enable_peer_access(fcamd_context* ctx, int peer_device) { return fcamd_context_set_option(ctx, "peer_access", peer_device); }
+FCAMD_INLINE int fcamd_context_last_host_mode(fcamd_context* ctx, int* mode) {
+    long long v = 0;
+    const int st = fcamd_context_get_option(ctx, "last_host_mode", &v);
+    if (st != FCAMD_OK) return st;
+    if (!mode) return FCAMD_ERR_BAD_ARG;
+    *mode = (int)v;
+    return FCAMD_OK;
+}
+/* kernel time of the model's last entry (context option "timing"); FCAMD_ERR_BAD_ARG when it was not timed */
+FCAMD_INLINE int fcamd_model_last_kernel_ms(fcamd_model* model, float* ms) {
+    fcamd_stats s;
+    const int st = fcamd_model_last_stats(model, &s);
+    if (st != FCAMD_OK) return st;
+    if (!ms || s.kernel_ms < 0.0) return FCAMD_ERR_BAD_ARG;
+    *ms = (float)s.kernel_ms;
+    return FCAMD_OK;
+}
+
+/* shards, IPC buffers, the multi handle */
+FCAMD_INLINE int fcamd_shard_slot_points(int64_t n, int world, int64_t* per_rank) {
+    int64_t lo, hi;
+    return fcamd_shard_bounds(n, world, 0, &lo, &hi, per_rank);
+}
+FCAMD_INLINE int fcamd_ipc_alloc(fcamd_context* ctx, size_t bytes, void** device_ptr) {
+    return fcamd_device_alloc_set(ctx, 1, &bytes, 0, FCAMD_ALLOC_IPC, device_ptr);
+}
+FCAMD_INLINE int fcamd_ipc_free(fcamd_context* ctx, void* device_ptr) { return fcamd_device_free(ctx, device_ptr); }
+FCAMD_INLINE int fcamd_multi_unregister_host_buffer(fcamd_multi* mg, void* ptr) { return fcamd_multi_register_host_buffer(mg, ptr, 0); }
+FCAMD_INLINE int fcamd_multi_device_count(const fcamd_multi* mg, int* n_devices) {
+    long long v = 0;
+    const int st = fcamd_multi_get_option(mg, "n_devices", &v);
+    if (st != FCAMD_OK) return st;
+    if (!n_devices) return FCAMD_ERR_BAD_ARG;
+    *n_devices = (int)v;
+    return FCAMD_OK;
+}
+FCAMD_INLINE int fcamd_multi_bounds(const fcamd_multi* mg, int64_t n, int k, int64_t* lo, int64_t* hi) {
+    return (lo && hi) ? fcamd_multi_plan(mg, n, k, (int*)0, lo, hi) : FCAMD_ERR_BAD_ARG;
+}
+FCAMD_INLINE int fcamd_multi_last_host_mode(const fcamd_multi* mg, int* mode, int* n_used) {
+    long long m = 0, u = 0;
+    int st = fcamd_multi_get_option(mg, "last_host_mode", &m);
+    if (st == FCAMD_OK) st = fcamd_multi_get_option(mg, "last_n_used", &u);
+    if (st != FCAMD_OK) return st;
+    if (mode) *mode = (int)m;
+    if (n_used) *n_used = (int)u;
+    return FCAMD_OK;
+}
 
 #ifdef __cplusplus
 }

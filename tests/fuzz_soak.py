@@ -13,10 +13,9 @@ import test_gpu_problem_fuzz as PF  # noqa: E402
 import test_gpu_resident_fuzz as RF  # noqa: E402
 
 lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3, 40)
-kinds = ["von_mises_3d", "von_mises_3d+unpacked", "von_mises_3d+dense_rows", "von_mises_3d+delta_history", "von_mises_3d+delta_auto",
-         "comfe_mises_plasticity", "comfe_mises_plasticity+unpacked", "comfe_mises_plasticity+rows7",
-         "comfe_mises_plasticity+delta_history", "drucker_prager", "drucker_prager+unpacked", "drucker_prager+delta_history",
-         "drucker_prager_hyperbolic+delta_auto", "drucker_prager_hyperbolic", "linear_elasticity", "spring_maxwell"]
+kinds = ["von_mises_3d", "von_mises_3d+unpacked", "von_mises_3d+dense_rows", "comfe_mises_plasticity", "comfe_mises_plasticity+unpacked",
+         "comfe_mises_plasticity+rows7", "drucker_prager", "drucker_prager+unpacked", "drucker_prager_hyperbolic",
+         "drucker_prager_hyperbolic+unpacked", "linear_elasticity", "spring_maxwell"]
 bad = 0
 for seed in range(lo, hi + 1):
     cases = [(RF.test_random_call_sequences, (k, seed)) for k in kinds] + [(PF.test_random_call_sequences, (seed,))]

@@ -164,10 +164,14 @@ def test_vmm_working_set_is_usable_memory(interleaved):
 def test_raw_ctypes_new_entries():
     lib = _capi.load()
     lo, hi = C.c_int64(), C.c_int64()
-    assert lib.fcamd_shard_bounds(10**8 * 8, 8, 7, C.byref(lo), C.byref(hi)) == 0
-    assert (lo.value, hi.value) == (7 * 10**8, 8 * 10**8)
-    assert lib.fcamd_shard_bounds(10, 0, 0, C.byref(lo), C.byref(hi)) == _capi.ERR_BAD_ARG
+    slot = C.c_int64()
+    assert lib.fcamd_shard_bounds(10**8 * 8, 8, 7, C.byref(lo), C.byref(hi), C.byref(slot)) == 0
+    assert (lo.value, hi.value, slot.value) == (7 * 10**8, 8 * 10**8, 10**8)
+    assert lib.fcamd_shard_bounds(10, 0, 0, C.byref(lo), C.byref(hi), None) == _capi.ERR_BAD_ARG
     ctx = _capi.get_context(0)
     v = C.c_longlong()
     assert lib.fcamd_context_get_option(ctx.handle, b"host_slots", C.byref(v)) == 0 and v.value == 4
-    assert lib.fcamd_model_dims(None, None, None) == _capi.ERR_BAD_ARG
+    assert lib.fcamd_model_get_info(None, None) == _capi.ERR_BAD_ARG
+    assert lib.fcamd_context_get_option(ctx.handle, b"last_host_mode", C.byref(v)) == 0
+    assert lib.fcamd_context_set_option(ctx.handle, b"last_host_mode", 1) == _capi.ERR_BAD_ARG  # read-only
+    assert lib.fcamd_copy(ctx.handle, None, None, 8, 99) == _capi.ERR_BAD_ARG

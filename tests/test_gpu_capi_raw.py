@@ -22,7 +22,6 @@ def lib():
     _build.build_library()
     l = C.CDLL(LIB)
     l.fcamd_last_error.restype = C.c_char_p
-    l.fcamd_status_string.restype = C.c_char_p
     return l
 
 
@@ -31,17 +30,18 @@ def test_integration_stub_von_mises(lib):
     assert lib.fcamd_context_create(0, None, C.byref(ctx)) == 0
     p = (C.c_double * 5)(175000.0, 80769.0, 1200.0, 2500.0, 200.0)
     assert lib.fcamd_model_create(ctx, 2, 5, p, 5, C.byref(mdl)) == 0  # FCAMD_VON_MISES_3D, FCAMD_FULL
-    nh = C.c_int()
-    assert lib.fcamd_model_history_count(mdl, C.byref(nh)) == 0 and nh.value == 2
-    names = []
-    for k in range(2):
-        name, dim = C.c_char_p(), C.c_int()
-        assert lib.fcamd_model_history_field(mdl, k, C.byref(name), C.byref(dim)) == 0
-        names.append((name.value.decode(), dim.value))
-    assert names == [("eps_n", 6), ("alpha", 1)]  # history_dim of the reference (:184-186)
+    class Info(C.Structure):  # fcamd_model_info
+        _fields_ = [("model_id", C.c_int), ("constraint", C.c_int), ("stress_strain_dim", C.c_int), ("geometric_dim", C.c_int),
+                    ("n_history", C.c_int), ("history_name", C.c_char_p * 2), ("history_dim", C.c_int * 2)]
 
-    class Stats(C.Structure):
-        _fields_ = [("nonconv", C.c_uint64), ("plastic", C.c_uint64), ("iters", C.c_uint64), ("reserved", C.c_uint64)]
+    info = Info()
+    assert lib.fcamd_model_get_info(mdl, C.byref(info)) == 0 and info.n_history == 2
+    names = [(info.history_name[k].decode(), info.history_dim[k]) for k in range(2)]
+    assert names == [("eps_n", 6), ("alpha", 1)]  # history_dim of the reference (:184-186)
+    assert (info.model_id, info.constraint, info.stress_strain_dim, info.geometric_dim) == (2, 5, 6, 3)
+
+    class Stats(C.Structure):  # fcamd_stats
+        _fields_ = [("nonconv", C.c_uint64), ("plastic", C.c_uint64), ("iters", C.c_uint64), ("domain", C.c_uint64), ("kernel_ms", C.c_double)]
 
     for c in load_calls("von_mises_3d.npz")[:6]:
         s, t, h = c.fresh()
@@ -77,14 +77,22 @@ def test_status_codes(lib):
     assert lib.fcamd_evaluate_host(mdl, C.c_double(0), C.c_double(1.0), *args, hp, 1, None) == 1  # SIZE
     assert lib.fcamd_evaluate_host(mdl, C.c_double(0), C.c_double(1.0), *args, hp, 2, None) == 0
     assert lib.fcamd_evaluate_host(mdl, C.c_double(0), C.c_double(1.0), C.c_int64(0), None, None, None, hp, 2, None) == 0  # n = 0
-    assert lib.fcamd_status_string(4).startswith(b"Newton-Raphson")
-    # device entry rejects misaligned pointers
+    # the device entry (fcamd_evaluate_device_ex; in place: prev == out) rejects misaligned pointers
+    from fenics_constitutive_amd._capi import EvalArgs
+
     d = torch.zeros(64 * 60, dtype=torch.float64, device="cuda")
     base = d.data_ptr()
-    lib.fcamd_evaluate_device.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int]
+    lib.fcamd_evaluate_device_ex.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs)]
     hd = (C.c_void_p * 2)(base + 8 * 1024, base + 8 * 2048)
-    assert lib.fcamd_evaluate_device(mdl, 0.0, 1.0, 8, base + 8, base + 8 * 512, None, hd, 2) == 7  # ALIGN
-    assert lib.fcamd_evaluate_device(mdl, 0.0, 1.0, 8, base, base + 8 * 512, None, hd, 2) == 0
+
+    def in_place(grad, stress):
+        return EvalArgs(grad, stress, stress, None, hd, hd, 2, None, None, 0, None, None, None, None, 0, None)
+
+    assert lib.fcamd_evaluate_device_ex(mdl, 0.0, 1.0, 8, C.byref(in_place(base + 8, base + 8 * 512))) == 7  # ALIGN
+    assert lib.fcamd_evaluate_device_ex(mdl, 0.0, 1.0, 8, C.byref(in_place(base, base + 8 * 512))) == 0
+    bad = in_place(base, base + 8 * 512)
+    bad.flags = 2  # FCAMD_EVAL_DELTA_HISTORY of ABI 0.3: removed
+    assert lib.fcamd_evaluate_device_ex(mdl, 0.0, 1.0, 8, C.byref(bad)) == 8  # UNSUPPORTED
     assert lib.fcamd_context_synchronize(ctx) == 0
     lib.fcamd_model_destroy(mdl)
     lib.fcamd_context_destroy(ctx)

@@ -209,10 +209,10 @@ def test_cfg1_linear_elasticity_1e5_ndarray_path():
     assert np.array_equal(s, s_ref) and np.array_equal(t, t_ref)
 
 
-@pytest.mark.parametrize("delta", [False, True])
-def test_resident_protocols_1e8(delta):
+@pytest.mark.parametrize("packed", [True, False])
+def test_resident_protocols_1e8(packed):
     """bench.py's default step at full size: the sparse trial-history and sparse-tangent protocols of
-    ResidentState -- and (``delta``) the packed delta trial history with its commit kernel -- over three Newton
+    ResidentState -- on the packed plastic-strain layout (the default) and on the reference's layout -- over three Newton
     iterates with moving plastic sets must leave exactly the arrays that rewriting everything leaves
     (size-independent property: equality of the two states)."""
     from fenics_constitutive_amd.resident import ResidentState
@@ -224,9 +224,9 @@ def test_resident_protocols_1e8(delta):
     a0 = torch.rand(N, dtype=torch.float64, device="cuda", generator=gen) * 0.02
     h0 = {"eps_n": torch.zeros(6 * N, dtype=torch.float64, device="cuda"), "alpha": a0}
     law = fc.VonMises3D(VM_P)
-    sp = ResidentState(law, N, history0=h0, delta_history=delta)
+    sp = ResidentState(law, N, history0=h0, packed_history=packed)
     fu = ResidentState(law, N, history0=h0, sparse_history=False, sparse_tangent=False)
-    assert sp._sparse_tangent and sp._mask is not None and fu._mask is None and sp._delta == delta
+    assert sp._sparse_tangent and sp._mask is not None and fu._mask is None and sp._packed == packed
     fractions = []
     for k, scale in enumerate((1.0, 0.5, 1.6)):   # plastic set shrinks, then grows beyond the first one
         gk = g if scale == 1.0 else g * scale

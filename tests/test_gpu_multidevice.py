@@ -431,6 +431,58 @@ def test_a_range_registered_by_one_context_is_entered_by_another():
     del s2, t2, h2
 
 
+def test_shared_page_lock_outlives_the_context_that_took_it():
+    """a range entered by a second context must stay page-locked when the FIRST registrant unregisters it (or
+    is destroyed) -- the lock is shared and reference-counted, the last holder unlocks the pages.  Before round 4 the
+    second context kept an entry that still claimed 'page-locked, zero copy' and the next launch DMA'd into unpinned memory."""
+    import threading
+
+    n = 30_000
+    law = LAWS["vm"]()
+    g, s, h = inputs(law, n, np.random.default_rng(11), "vm")
+    ref = evaluate_copy(LAWS["vm"](), 1.0, g, s, h)
+    arrays = {"s": s.copy(), "t": np.full(36 * n, np.nan), "e": h["eps_n"].copy(), "a": h["alpha"].copy()}
+    everything = (g, *arrays.values())
+    main_ctx = _capi.get_context(0)
+    ready, go, result = threading.Event(), threading.Event(), {}
+
+    def first_registrant():  # a context of its own (thread-local), which takes the page locks and then goes away
+        try:
+            ctx = _capi.get_context(0)
+            for x in everything:
+                ctx.register_host_buffer(x)
+            ready.set()
+            go.wait(30)
+            for x in everything[:2]:
+                ctx.unregister_host_buffer(x)  # two ranges left explicitly ...
+            ctx.close()                         # ... the others with the context's destruction
+        except Exception as e:  # noqa: BLE001
+            result["error"] = e
+            ready.set()
+
+    t = threading.Thread(target=first_registrant)
+    t.start()
+    assert ready.wait(60) and "error" not in result, result
+    for x in everything:
+        main_ctx.register_host_buffer(x)  # enters the other context's locks
+    go.set()
+    t.join()
+    assert "error" not in result, result
+    # the first registrant is gone; this context's ranges are still page-locked: zero copy, right results, twice
+    for _ in range(2):
+        arrays["s"][:], arrays["e"][:], arrays["a"][:] = s, h["eps_n"], h["alpha"]
+        law.evaluate(0.0, 1.0, g, arrays["s"], arrays["t"], {"eps_n": arrays["e"], "alpha": arrays["a"]})
+        assert main_ctx.last_host_mode() == (_capi.HOST_ZERO_COPY_IN | _capi.HOST_ZERO_COPY_OUT)
+        assert_same((arrays["s"], arrays["t"], {"eps_n": arrays["e"], "alpha": arrays["a"]}), ref)
+    for x in everything:
+        main_ctx.unregister_host_buffer(x)  # the last holder: the pages are unlocked here
+    # unlocked for real: the same call now takes a call-scoped lock (or the scratch path) again
+    arrays["s"][:], arrays["e"][:], arrays["a"][:] = s, h["eps_n"], h["alpha"]
+    law.evaluate(0.0, 1.0, g, arrays["s"], arrays["t"], {"eps_n": arrays["e"], "alpha": arrays["a"]})
+    assert main_ctx.last_host_mode() & (_capi.HOST_TEMP_LOCK | _capi.HOST_BOUNCE)
+    assert_same((arrays["s"], arrays["t"], {"eps_n": arrays["e"], "alpha": arrays["a"]}), ref)
+
+
 @pytest.mark.parametrize("kind,constraint", [("kelvin", "PLANE_STRESS"), ("maxwell", "UNIAXIAL_STRESS"), ("le", "PLANE_STRAIN"), ("kelvin", "UNIAXIAL_STRAIN")])
 def test_multi_device_resident_state_low_dimensional_constraints(kind, constraint):
     """the laws the reference implements for all constraints, resident over three device contexts (the chunked pass of

@@ -360,98 +360,104 @@ def test_vmm_placement_moves_the_state_and_keeps_results(numpy_grad):
 
 @pytest.mark.parametrize("law_name", ["VonMises3D", "MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D"])
 @pytest.mark.parametrize("n", [64 * 30 + 11, 4000])
-def test_delta_trial_history_equals_the_plain_protocols(n, law_name):
-    """Delta trial history (FCAMD_EVAL_DELTA_HISTORY, ResidentState(delta_history=True); VonMises3D's eps_n and the eps_p rows
-    of the comfe-rs laws under the split layout): during the Newton iterations the trial plastic-strain array holds only
-    the increments of the plastic points, packed per tile, and the committed rows are never read; update() adds them to
-    the committed array.  Stress, tangent, the scalar history, the assembled trial plastic strain and every committed state
-    must equal the sparse protocol without it and the full protocol bit for bit, over growing, shrinking and vanishing
-    plastic sets, device and host-assembler calls."""
+def test_packed_history_equals_the_plain_protocols(n, law_name):
+    """Packed plastic-strain history (FCAMD_EVAL_PACKED_HISTORY, the default of ResidentState; VonMises3D's eps_n and the
+    eps_p rows of the comfe-rs laws under the split layout): both copies of the array hold the rows of the ever-plastic
+    points of every tile as one run, the commit stays a pointer swap.  Stress, tangent, the scalar history, the unpacked
+    trial plastic strain and every committed state must equal the sparse protocol on the reference's layout and the
+    full protocol bit for bit, over growing, shrinking and vanishing plastic sets, EVER masks from empty to full, device
+    and host-assembler calls."""
     rng = np.random.default_rng(n)
     law, s0, h0, grad = _sparse_case(law_name, n, rng)
-    d = ResidentState(law, n, stress0=s0, history0=h0, delta_history=True)           # packed increments in the trial array
     p = ResidentState(law, n, stress0=s0, history0=h0)                               # the default: packed plastic-strain arrays, commit = pointer swap
-    u = ResidentState(law, n, stress0=s0, history0=h0, packed_history=False)         # plain sparse protocol: committed + increment in the trial array
+    u = ResidentState(law, n, stress0=s0, history0=h0, packed_history=False)         # sparse protocol on the reference's layout
     f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False)
-    assert d._delta and not p._delta and not f._delta and not u._delta
-    assert p._packed and not (d._packed or u._packed or f._packed)
-    sh, th = np.empty(6 * n), np.empty(36 * n)
+    assert p._packed and not (u._packed or f._packed)
+    key = "eps_n" if law_name == "VonMises3D" else "history"
+    for st in (p, u):  # what went in comes out, before anything is evaluated
+        assert torch.equal(st.history_committed[key], f.history_committed[key]) and torch.equal(st.history[key], f.history[key])
     shp, thp = np.empty(6 * n), np.empty(36 * n)
-    n_plastic = []
+    n_plastic, ever_counts = [], []
     for inc in range(5):
         for it in range(3):
             g = grad(all_elastic=(inc == 2 and it == 1), zoned=(inc % 2 == 1))
-            if (inc, it) == (3, 1):  # one host-assembler pass in between (fcamd_evaluate_resident with the flag)
-                d.evaluate_into(0.0, 1.0, g.cpu().numpy(), sh, th)
+            host_pass = (inc, it) == (3, 1)  # one host-assembler pass in between (fcamd_evaluate_resident with the flag)
+            if host_pass:
                 p.evaluate_into(0.0, 1.0, g.cpu().numpy(), shp, thp)
             else:
-                d.evaluate(0.0, 1.0, g)
                 p.evaluate(0.0, 1.0, g)
             u.evaluate(0.0, 1.0, g)
             f.evaluate(0.0, 1.0, g)
             n_plastic.append(int(f.check().n_plastic))
-            if (inc, it) != (3, 1):  # (the synchronous host pass reports through its return value)
-                assert int(p.check().n_plastic) == n_plastic[-1] and int(u.check().n_plastic) == n_plastic[-1]
-            assert torch.equal(d.stress, f.stress) and torch.equal(p.stress, f.stress) and torch.equal(u.stress, f.stress), (inc, it)
-            if (inc, it) == (3, 1):
-                assert np.array_equal(th, f.tangent.cpu().numpy()) and np.array_equal(sh, f.stress.cpu().numpy())
-                assert np.array_equal(thp, th) and np.array_equal(shp, sh)
+            assert int(u.check().n_plastic) == n_plastic[-1]
+            if not host_pass:  # (the synchronous host pass reports through its return value)
+                assert int(p.check().n_plastic) == n_plastic[-1]
+            assert torch.equal(p.stress, f.stress) and torch.equal(u.stress, f.stress), (inc, it)
+            if host_pass:
+                assert np.array_equal(thp, f.tangent.cpu().numpy()) and np.array_equal(shp, f.stress.cpu().numpy())
             else:
-                assert torch.equal(d.tangent, f.tangent) and torch.equal(p.tangent, f.tangent), (inc, it)
+                assert torch.equal(p.tangent, f.tangent), (inc, it)
             assert torch.equal(u.tangent, f.tangent), (inc, it)
             for k in h0:
-                for st in (d, p, u):
-                    assert torch.equal(st.history[k], f.history[k]), (inc, it, k, st._packed, st._delta)
-                    assert torch.equal(st.history_committed[k], f.history_committed[k]), (inc, it, k, st._packed, st._delta)
-        d.update(), p.update(), u.update(), f.update()
+                for st in (p, u):
+                    assert torch.equal(st.history[k], f.history[k]), (inc, it, k, st._packed)
+                    assert torch.equal(st.history_committed[k], f.history_committed[k]), (inc, it, k, st._packed)
+        p.update(), u.update(), f.update()
+        ever_counts.append(int(sum(bin(w & 0xFFFFFFFFFFFFFFFF).count("1") for w in p._ever[p._c].tolist())))
         for k in h0:
-            assert torch.equal(d.history_committed[k], f.history_committed[k]), (inc, k)
             assert torch.equal(p.history_committed[k], f.history_committed[k]), (inc, k)
             assert torch.equal(u.history_committed[k], f.history_committed[k]), (inc, k)
-            # nothing evaluated yet: the assembled trial plastic strain is the committed one (the scalar history of stale
-            # points is restored by the next evaluate, as under the plain sparse protocol)
-            assert torch.equal(d.history[k], f.history_committed[k]) or k != "eps_n"
+            assert torch.equal(p.history[k], f.history_committed[k]) or k != key  # nothing evaluated yet: trial view = committed
     assert max(n_plastic) > 0.1 * n
+    # the EVER masks are exactly the rows that are not all +0.0, and they only grow
+    rows = f.history_committed[key].view(n, -1)[:, -6:]
+    assert ever_counts[-1] == int((rows.contiguous().view(torch.int64) != 0).any(dim=1).sum()) and ever_counts == sorted(ever_counts)
+    # raw entry: the flag needs the sparse protocol's mask, both EVER-mask arrays and trial arrays of its own; 0.3's delta flag is gone
     mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    g = grad(all_elastic=False, zoned=False)
+    m = law._handle(0)
+    hp = [f.history_committed[k].data_ptr() for k in h0]
+    with pytest.raises(NotImplementedError, match="removed in 0.4"):
+        m.evaluate_device_ex(0.0, 1.0, n, g.data_ptr(), f.stress_committed.data_ptr(), f.stress.data_ptr(), None, hp, hp, mask_ptr=mask.data_ptr(), flags=2)
     if law_name == "VonMises3D":
-        with pytest.raises(ValueError, match="plastic-strain array of its own"):
-            law.evaluate_from(0.0, 1.0, grad(all_elastic=False, zoned=False), f.stress_committed, f.stress, f.tangent,
-                              f.history_committed, f.history_committed, history_mask=mask, delta_history=True)
+        ht = [f.history[k].data_ptr() for k in h0]
+        with pytest.raises(ValueError, match="packed_mask_prev and packed_mask"):
+            m.evaluate_device_ex(0.0, 1.0, n, g.data_ptr(), f.stress_committed.data_ptr(), f.stress.data_ptr(), None, hp, ht,
+                                 mask_ptr=mask.data_ptr(), flags=8)
+        with pytest.raises(ValueError, match="of their own"):
+            m.evaluate_device_ex(0.0, 1.0, n, g.data_ptr(), f.stress_committed.data_ptr(), f.stress.data_ptr(), None, hp, hp,
+                                 mask_ptr=mask.data_ptr(), flags=8, packed_mask_ptrs=(mask.data_ptr(), mask.data_ptr()))
     else:
-        # 7-double rows (no split layout): the scalar sits inside the row, there is no write-only array -- refused
-        st = ResidentState(law, n, stress0=s0, history0=h0, delta_history=True, split_history=False)
-        assert not st._delta
-        with pytest.raises(NotImplementedError, match="DELTA_HISTORY"):
-            law.evaluate_from(0.0, 1.0, grad(all_elastic=False, zoned=False), st.stress_committed, st.stress, st.tangent,
-                              st.history_committed, st.history, history_mask=mask, delta_history=True)
+        # 7-double rows (no split layout): the scalar sits inside the row, there is no array that only accumulates -- refused
+        st = ResidentState(law, n, stress0=s0, history0=h0, split_history=False)
+        assert not st._packed
+        with pytest.raises(NotImplementedError, match="PACKED_HISTORY"):
+            m.evaluate_device_ex(0.0, 1.0, n, g.data_ptr(), st.stress_committed.data_ptr(), st.stress.data_ptr(), None,
+                                 [st.history_committed["history"].data_ptr()], [st.history["history"].data_ptr()],
+                                 mask_ptr=mask.data_ptr(), flags=8, packed_mask_ptrs=(mask.data_ptr(), mask.clone().data_ptr()))
 
 
-@pytest.mark.parametrize("law_name", ["VonMises3D", "DruckerPrager3D"])
-def test_delta_trial_history_switches_itself_on_and_off(law_name):
-    """``delta_history="auto"``: increments of four Newton iterations switch the delta protocol on at the next increment
-    boundary, increments of one iteration switch it off again (one full-history evaluate restores the plain protocol's
-    contract) -- and through all of it the state equals the full protocol bit for bit."""
-    n = 64 * 50 + 3
-    rng = np.random.default_rng(17)
-    law, s0, h0, grad = _sparse_case(law_name, n, rng)
-    a = ResidentState(law, n, stress0=s0, history0=h0, delta_history="auto")
-    f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False)
-    assert a._delta_auto and not a._delta
-    a.DELTA_MIN_ITERATIONS, a.DELTA_OFF_ITERATIONS = 3.0, 2.5  # (the Drucker-Prager laws ship with 4.0 / 3.0)
-    modes = []
-    for inc, iters in enumerate([4, 4, 4, 1, 1, 1, 1, 5, 2]):
-        for it in range(iters):
-            g = grad(all_elastic=False, zoned=(inc % 2 == 1))
-            a.evaluate(0.0, 1.0, g)
-            f.evaluate(0.0, 1.0, g)
-            assert torch.equal(a.stress, f.stress) and torch.equal(a.tangent, f.tangent), (inc, it)
-            for k in h0:
-                assert torch.equal(a.history[k], f.history[k]), (inc, it, k)
-        a.update(), f.update()
-        modes.append(a._delta)
-        for k in h0:
-            assert torch.equal(a.history_committed[k], f.history_committed[k]), (inc, k)
-    assert modes[0] and modes[2] and not modes[5] and not modes[6] and modes[7], modes  # on after 4, 4, 4; off after the 1s; on after 5
+def test_packed_history_views_do_not_change_meaning():
+    """a tensor taken from ``history`` must mean the same thing for the whole run.  Under the packed layout the
+    plastic-strain array of ``history`` / ``history_committed`` is a COPY in the reference's layout from the first call on
+    (nothing switches mid-run, ``generation`` stays put); the scalar history is the live tensor."""
+    n = 64 * 20 + 5
+    rng = np.random.default_rng(3)
+    law, s0, h0, grad = _sparse_case("VonMises3D", n, rng)
+    st = ResidentState(law, n, stress0=s0, history0=h0, placement="torch")
+    f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False, placement="torch")
+    gen0 = st.generation
+    held_eps, held_alpha = st.history["eps_n"], st.history["alpha"]
+    before = held_eps.clone()
+    for inc in range(3):
+        for it in range(4):
+            g = grad(all_elastic=False, zoned=False)
+            st.evaluate(0.0, 1.0, g), f.evaluate(0.0, 1.0, g)
+        assert torch.equal(held_eps, before)                      # a copy: never written behind the holder's back
+        assert torch.equal(st.history["eps_n"], f.history["eps_n"])  # the view, asked again, is current
+        st.update(), f.update()
+    assert st.generation == gen0
+    assert held_alpha.data_ptr() in (st._hist[0]["alpha"].data_ptr(), st._hist[1]["alpha"].data_ptr())  # a live tensor of the state
 
 
 @pytest.mark.parametrize("law_name", ["MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D"])
@@ -515,7 +521,7 @@ def test_row_masked_access_leaves_identical_bits(kind, split):
                 law.device_stats()
                 out += [s.clone(), t.clone()] + [v.clone() for v in h.values()]
             # sparse protocol: resident state, plastic set shrinks, grows, commit, shrinks
-            rs = ResidentState(law, n, stress0=s0, history0=h0, split_history=split, delta_history=False, placement="torch")
+            rs = ResidentState(law, n, stress0=s0, history0=h0, split_history=split, placement="torch")
             for k, scale in enumerate((1.0, 0.2, 1.5, 0.4)):
                 rs.evaluate(0.0, 1.0, g0 * scale)
                 rs.check()

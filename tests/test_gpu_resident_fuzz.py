@@ -41,11 +41,10 @@ def drucker_prager_case(kind, n, seed):
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
-@pytest.mark.parametrize("kind", ["von_mises_3d", "von_mises_3d+unpacked", "von_mises_3d+dense_rows", "von_mises_3d+delta_history",
-                                  "von_mises_3d+delta_auto", "comfe_mises_plasticity", "comfe_mises_plasticity+unpacked",
-                                  "comfe_mises_plasticity+rows7", "comfe_mises_plasticity+delta_history", "drucker_prager",
-                                  "drucker_prager+unpacked", "drucker_prager+delta_history", "drucker_prager_hyperbolic+delta_auto",
-                                  "drucker_prager_hyperbolic", "linear_elasticity", "spring_maxwell"])
+@pytest.mark.parametrize("kind", ["von_mises_3d", "von_mises_3d+unpacked", "von_mises_3d+dense_rows", "comfe_mises_plasticity",
+                                  "comfe_mises_plasticity+unpacked", "comfe_mises_plasticity+rows7", "drucker_prager",
+                                  "drucker_prager+unpacked", "drucker_prager_hyperbolic", "drucker_prager_hyperbolic+unpacked",
+                                  "linear_elasticity", "spring_maxwell"])
 def test_random_call_sequences(kind, seed):
     n = 64 * 90 + 17
     kind, _, option = kind.partition("+")
@@ -60,11 +59,7 @@ def test_random_call_sequences(kind, seed):
         key, w = ("eps_n", 6) if kind == "von_mises_3d" else ("history", 7)
         virgin = np.random.default_rng(7 + seed).random(n) < 0.6
         h[key].reshape(-1, w)[virgin, w - 6:] = 0.0
-    opt = ResidentState(law, n, stress0=s, history0=h, delta_history={"delta_history": True, "delta_auto": "auto"}.get(option, False),
-                        split_history=option != "rows7", packed_history=False if option == "unpacked" else "auto")
-    if option == "delta_auto":
-        opt.DELTA_MIN_ITERATIONS, opt.DELTA_OFF_ITERATIONS = 2.0, 1.5  # the random sequences commit after 1 - 4 evaluates: both switches happen
-    assert opt._delta == (option == "delta_history")
+    opt = ResidentState(law, n, stress0=s, history0=h, split_history=option != "rows7", packed_history=option != "unpacked")
     # the packed plastic-strain layout is the default wherever a law has a plastic-strain array of its own
     assert opt._packed == (plasticity and option in ("", "dense_rows"))
     assert opt._split == (option != "rows7" and (kind == "comfe_mises_plasticity" or kind.startswith("drucker_prager")))

@@ -77,15 +77,32 @@ def test_strain_from_grad_u_needs_the_gpu_for_every_constraint():
 
 
 def test_library_exports_every_declared_symbol():
+    import subprocess
+
     hdr = open(os.path.join(ROOT, "include", "fcamd.h")).read()
-    declared = sorted(set(re.findall(r"\b(fcamd_[a-z_0-9]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"^FCAMD_API [a-z_ *]*?\b(fcamd_[a-z_0-9]+)\s*\(", hdr, re.M)))
     assert declared == sorted(_capi.SYMBOLS)
+    assert len(declared) <= 45  # the boundary stays small: one evaluate per data path (bindings/src/lib.rs:76-129 has one per model)
     lib = ctypes.CDLL(_capi.library_path()) if os.path.exists(_capi.library_path()) else _capi.load()
     for name in declared:
         assert hasattr(lib, name), name
+    # ... and nothing else: the library's dynamic symbol table holds exactly the declared entries
+    nm = subprocess.run(["nm", "-D", "--defined-only", _capi.library_path()], capture_output=True, text=True)
+    if nm.returncode == 0:
+        exported = sorted(ln.split()[-1] for ln in nm.stdout.splitlines() if " T fcamd_" in ln)
+        assert exported == declared
+    # the header's static inline shorthands (ABI 0.3 names) are not symbols
+    inline = set(re.findall(r"^FCAMD_INLINE [a-z_ *]*?\b(fcamd_[a-z_0-9]+)\s*\(", hdr, re.M))
+    assert {"fcamd_evaluate_device", "fcamd_evaluate_device_from", "fcamd_evaluate_device_indexed", "fcamd_status_string"} <= inline
+    assert not (inline & set(declared))
     major, minor = (int(re.search(rf"#define FCAMD_VERSION_{k} (\d+)", hdr).group(1)) for k in ("MAJOR", "MINOR"))
     assert _capi.load().fcamd_version() == 1000 * major + minor
-    assert _capi.load().fcamd_status_string(4).decode().startswith("Newton-Raphson")
+    assert _capi.status_string(4).startswith("Newton-Raphson")
+    # the ctypes module's table of status texts is the header's fcamd_status_string, case by case
+    body = hdr[hdr.index("FCAMD_INLINE const char* fcamd_status_string"):]
+    for code, text in re.findall(r'case (FCAMD_[A-Z_]+): return "([^"]+)";', body[: body.index("default:")]):
+        value = int(re.search(rf"{code} = (\d+)", hdr).group(1))
+        assert _capi.STATUS_STRINGS[value] == text, code
 
 
 def test_no_cpu_fallback():
@@ -216,7 +233,7 @@ def test_rows_of_cells_matches_quadrature_numbering():
 
 
 def test_eval_args_struct_layout_matches_header():
-    """ctypes mirror of fcamd_eval_args: fourteen fields in the header's order, pointer-sized except n_hist / flags."""
+    """ctypes mirror of fcamd_eval_args: sixteen fields in the header's order, pointer-sized except n_hist / flags / wrapper_constraint."""
     import ctypes as C
     import re
 
@@ -226,7 +243,11 @@ def test_eval_args_struct_layout_matches_header():
     body = re.search(r"typedef struct fcamd_eval_args \{(.*?)\} fcamd_eval_args;", hdr, re.S).group(1)
     names = re.findall(r"(\w+);", body)
     assert names == [f[0] for f in _capi.EvalArgs._fields_]
-    assert C.sizeof(_capi.EvalArgs) == 14 * C.sizeof(C.c_void_p)  # n_hist and flags each padded to pointer size
+    assert C.sizeof(_capi.EvalArgs) == 16 * C.sizeof(C.c_void_p)  # the three ints each padded to pointer size
+    info = re.search(r"typedef struct fcamd_model_info \{(.*?)\} fcamd_model_info;", hdr, re.S).group(1)
+    assert re.findall(r"(\w+)(?:\[\w+\])?;", info) == [f[0] for f in _capi.ModelInfo._fields_]
+    stats = re.search(r"typedef struct fcamd_stats \{(.*?)\} fcamd_stats;", hdr, re.S).group(1)
+    assert re.findall(r"^\s*\w+ (\w+);", stats, re.M) == [f[0] for f in _capi.Stats._fields_] and C.sizeof(_capi.Stats) == 40
     assert _capi.EvalArgs.flags.offset == 9 * C.sizeof(C.c_void_p)
 
 
@@ -238,13 +259,14 @@ def test_header_constants_match_the_ctypes_module():
 
     hdr = open(os.path.join(ROOT, "include", "fcamd.h")).read()
     defines = {k: int(v, 0) for k, v in re.findall(r"#define (FCAMD_[A-Z_0-9]+) (\d+|0x[0-9a-fA-F]+)\b", hdr)}
-    pairs = {"FCAMD_EVAL_SPARSE_TANGENT": _capi.EVAL_SPARSE_TANGENT, "FCAMD_EVAL_DELTA_HISTORY": _capi.EVAL_DELTA_HISTORY,
+    pairs = {"FCAMD_EVAL_SPARSE_TANGENT": _capi.EVAL_SPARSE_TANGENT,
              "FCAMD_HOST_ZERO_COPY_IN": _capi.HOST_ZERO_COPY_IN, "FCAMD_HOST_ZERO_COPY_OUT": _capi.HOST_ZERO_COPY_OUT,
              "FCAMD_HOST_TEMP_LOCK": _capi.HOST_TEMP_LOCK, "FCAMD_HOST_BOUNCE": _capi.HOST_BOUNCE,
              "FCAMD_COUNTER_SLOTS": _capi.COUNTER_SLOTS,
              "FCAMD_MAX_HISTORY": _capi.MAX_HISTORY, "FCAMD_IPC_HANDLE_BYTES": _capi.IPC_HANDLE_BYTES,
              "FCAMD_GATHER_PULL": _capi.GATHER_PULL, "FCAMD_ALLOC_SEQUENTIAL": _capi.ALLOC_SEQUENTIAL,
-             "FCAMD_ALLOC_INTERLEAVED": _capi.ALLOC_INTERLEAVED, "FCAMD_EVAL_SPLIT_HISTORY": _capi.EVAL_SPLIT_HISTORY,
+             "FCAMD_ALLOC_INTERLEAVED": _capi.ALLOC_INTERLEAVED, "FCAMD_ALLOC_IPC": _capi.ALLOC_IPC,
+             "FCAMD_COPY_TO_DEVICE": _capi.COPY_TO_DEVICE, "FCAMD_COPY_TO_HOST": _capi.COPY_TO_HOST, "FCAMD_COPY_DEVICE": _capi.COPY_DEVICE, "FCAMD_EVAL_SPLIT_HISTORY": _capi.EVAL_SPLIT_HISTORY,
              "FCAMD_EVAL_PACKED_HISTORY": _capi.EVAL_PACKED_HISTORY,
              "FCAMD_MULTI_MAX_DEVICES": _capi.MULTI_MAX_DEVICES, "FCAMD_MULTI_MIN_POINTS": _capi.MULTI_MIN_POINTS}
     for name, value in pairs.items():

@@ -13,7 +13,7 @@ try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r = d["roofline"]
     print(f"{sys.argv[2]:>16}: kernel {r['kernel_ms_avg']:.3f} ms (min {r['kernel_ms_min']:.3f}) frac {r['frac']:.4f}  first {r.get('frac_first_allocation')} worst {r.get('frac_worst_candidate')}  "
-          f"unpacked {d.get('sparse_unpacked_history', {}).get('kernel_ms_avg')} delta {d.get('delta_trial_history', {}).get('evaluate_kernel_ms_avg')} full {d.get('full_trial_history', {}).get('kernel_ms_avg')}")
+          f"unpacked {d.get('sparse_unpacked_history', {}).get('kernel_ms_avg')} full {d.get('full_trial_history', {}).get('kernel_ms_avg')}")
 except Exception as e:
     print(sys.argv[2], "failed:", e)
 PY

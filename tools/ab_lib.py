@@ -2,14 +2,17 @@
 """A/B two builds of libfcamd.so in ONE process on identical buffers (interleaved rounds):
     python tools/ab_lib.py libA.so libB.so [n ...]
 VonMises3D mixed workload, committed->trial evaluate.  AB_SPARSE=1: sparse trial-history protocol
-(fcamd_evaluate_device_from_sparse, VonMises3D only); AB_ZONED=1: plastic points in contiguous
+(fcamd_evaluate_device_ex with history_mask, VonMises3D only); AB_ZONED=1: plastic points in contiguous
 4096-point zones instead of a random mixture; AB_SCALE=1e-2 / 1e-4: uniform strain scale (all plastic / all elastic)."""
 import ctypes as C
 import sys
 
+import os
+
 import torch
 
-import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fenics_constitutive_amd._capi import EvalArgs  # noqa: E402  (the struct only; the libraries are loaded by path below)
 libs = [a for a in sys.argv[1:] if a.endswith('.so')]
 sizes = [int(float(x)) for x in sys.argv[1:] if not x.endswith('.so')] or [1_000_000, 10_000_000, 100_000_000]
 LAW = os.environ.get("AB_LAW", "vm")  # vm | le | maxwell
@@ -30,9 +33,7 @@ class Lib:
         # torch's default stream has handle 0 = "own a private stream" for create(); bind it explicitly
         assert self.l.fcamd_context_set_stream(self.ctx, stream) == 0
         assert self.l.fcamd_model_create(self.ctx, MODEL[0], 5, P, len(MODEL[1]), C.byref(self.m)) == 0
-        self.l.fcamd_evaluate_device_from.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64] + [C.c_void_p] * 4 + [C.POINTER(C.c_void_p)] * 2 + [C.c_int]
-
-        self.l.fcamd_evaluate_device_from_sparse.argtypes = self.l.fcamd_evaluate_device_from.argtypes + [C.c_void_p]
+        self.l.fcamd_evaluate_device_ex.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs)]
         self.mask = None
 
     def run(self, n, g, s0, s1, t, h0, h1):
@@ -43,11 +44,13 @@ class Lib:
                 # protocol: trial == committed wherever the mask is clear
                 h1[0].copy_(h0[0]), h1[1].copy_(h0[1])
                 self.mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
-            rc = self.l.fcamd_evaluate_device_from_sparse(self.m, 0.0, 1.0, n, g.data_ptr(), s0.data_ptr(), s1.data_ptr(),
-                                                          t.data_ptr(), a0, a1, MODEL[2], self.mask.data_ptr())
+            x = EvalArgs(g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, MODEL[2], None, self.mask.data_ptr(), 0,
+                         None, None, None, None, 0, None)
+            rc = self.l.fcamd_evaluate_device_ex(self.m, 0.0, 1.0, n, C.byref(x))
             assert rc == 0, rc
             return
-        rc = self.l.fcamd_evaluate_device_from(self.m, 0.0, 1.0, n, g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, MODEL[2])
+        x = EvalArgs(g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, MODEL[2], None, None, 0, None, None, None, None, 0, None)
+        rc = self.l.fcamd_evaluate_device_ex(self.m, 0.0, 1.0, n, C.byref(x))
         assert rc == 0, rc
 
 

@@ -8,7 +8,7 @@ strip = lambda x: {k: v for k, v in (x or {}).items() if k not in ("note", "laun
 print("value", d["value"], "frac", r["frac"], "kernel_ms", r["kernel_ms_avg"], "alg", r["algorithmic_bytes_per_launch"], "traffic", r.get("traffic"),
       "ratio", None if not r.get("traffic") else round(r["traffic"] / r["algorithmic_bytes_per_launch"], 4), r.get("traffic_read_write"))
 print({k: v for k, v in r.items() if k.startswith("frac_")}, d["placement"].get("mode"))
-for k in ("full_trial_history", "sparse_unpacked_history", "delta_trial_history", "strong_scaling"):
+for k in ("full_trial_history", "sparse_unpacked_history", "strong_scaling"):
     if k in d:
         print(k, strip(d[k]))
 for k, c in (d.get("configs") or {}).items():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box: tools/profile_gpu.sh for a list of "tag|bench args" entries (one rocprofv3 kernel-trace pass and two
-# PMC passes each).  Usage: tools/profile_round.sh "von_mises_mixed|--workload von_mises_mixed" "von_mises_mixed_delta|--workload von_mises_mixed --delta-history" ...
+# PMC passes each).  Usage: tools/profile_round.sh "von_mises_mixed|--workload von_mises_mixed" "von_mises_mixed_unpacked|--workload von_mises_mixed --history sparse" ...
 # Summarise afterwards, per tag:  python tools/summarize_profile.py gpurun_out/prof/<tag> <round> <tag> ["extra bench args"]
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

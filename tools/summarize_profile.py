@@ -72,7 +72,7 @@ with open(out, "w") as f:
         f.write("Command (tools/profile_default.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py` "
                 "-- the driver's bench command, no flags: the headline workload and the five other single-GPU configurations.\n\n")
     else:
-        wl = next((workload[: -len(sfx)] for sfx in ("_full", "_delta", "_rows7") if workload.endswith(sfx)), workload)
+        wl = next((workload[: -len(sfx)] for sfx in ("_full", "_unpacked", "_rows7") if workload.endswith(sfx)), workload)
         f.write("Command (tools/profile_gpu.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
                 f"--steps 10 --warmup 2 --no-cpu-baseline --workload {wl} {extra_args}` and one `--pmc FETCH_SIZE`, one "
                 "`--pmc WRITE_SIZE` pass (`--steps 4 --warmup 2`).\n\n")
@@ -80,8 +80,8 @@ with open(out, "w") as f:
             "sliced with it.  Phases of one workload: 1 in-place warm step, the hipMalloc tangent candidates x 4 launches, the VMM "
             "working set x 4 launches (`--placement auto`), the warm-up steps, 2 launches that read the plastic counts of the two "
             "Newton iterates, the TIMED steps, and (sparse protocol only) six launches of the mask-less kernel variant for the "
-            "`full_trial_history` figure and 2 + 6 launches with FCAMD_EVAL_DELTA_HISTORY for the `delta_trial_history` figure "
-            f"(VonMises3D).  {len(dur)} evaluate dispatches in the trace, {used} accounted for by the log.\n\n")
+            "`full_trial_history` figure and 2 + 6 launches of the sparse protocol on the reference's array layout for the "
+            f"`sparse_unpacked_history` figure.  {len(dur)} evaluate dispatches in the trace, {used} accounted for by the log.\n\n")
     f.write("## kernel stats (`*_kernel_stats.csv`, top rows; averages over ALL phases of all workloads that use the kernel)\n\n"
             "| kernel | calls | total ms | avg ms | % | min ms | max ms |\n|---|---|---|---|---|---|---|\n")
     for r in stats[:8]:
