@@ -532,7 +532,7 @@ def test_multi_handle_error_paths():
     with pytest.raises(ValueError, match="commit before any evaluate"):
         st.commit()
     with pytest.raises(ValueError, match="SPARSE_TANGENT or 0"):
-        st.evaluate(0.0, 1.0, np.zeros(9000).ctypes.data, None, None, flags=_capi.EVAL_DELTA_HISTORY)
+        st.evaluate(0.0, 1.0, np.zeros(9000).ctypes.data, None, None, flags=_capi.EVAL_PACKED_HISTORY)
     m.close()  # destroys the state that is still alive on it
     st.close()  # ... so this is a no-op
     assert threading.active_count() == before
