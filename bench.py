@@ -992,7 +992,7 @@ def under_profiler():
     return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def live_traffic(name, n, history, extra, budget_s):
+def live_traffic(name, n, history, extra, budget_s, frow=False):
     """HBM bytes per timed launch of this workload, measured NOW as MI355X_MICROARCH.md ("HBM", rocprofv3) prescribes: two
     child runs of this file (4 timed steps each, first-allocation placement -- the traffic of a launch does not depend on
     where its arrays lie) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes; no trace domain next
@@ -1015,9 +1015,12 @@ def live_traffic(name, n, history, extra, budget_s):
             return None
         d = tempfile.mkdtemp(prefix="fcamd_pmc_", dir="/tmp")
         try:
-            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--workload", name, "--points", str(n), "--history", history, "--steps", "4", "--warmup", "2", "--configs", "none",
-                   "--no-host-path", "--no-cpu-baseline", "--placement", "first", "--no-live-traffic"] + list(extra)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)]
+            if frow:  # one row of SURVEY 8(f) alone (bench_frows.py)
+                cmd += ["--frow", name, "--points", str(n), "--steps", "4", "--warmup", "2"]
+            else:
+                cmd += ["--workload", name, "--points", str(n), "--history", history, "--steps", "4", "--warmup", "2", "--configs", "none",
+                        "--no-host-path", "--no-cpu-baseline", "--placement", "first", "--no-live-traffic"] + list(extra)
             # a process group of its own: on a timeout the whole pass (profiler + the profiled child) is ended, nothing else
             p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                                  text=True, start_new_session=True)
@@ -1055,6 +1058,23 @@ def live_traffic(name, n, history, extra, budget_s):
     return {"hbm_bytes_per_launch": int(read_b + write_b), "read_bytes": int(read_b), "write_bytes": int(write_b)}
 
 
+def main_frow(args):
+    """`--frow NAME`: one SURVEY 8(f) row alone; prints one JSON line (with the launch_log the PMC slicing needs)"""
+    import torch
+
+    import bench_frows
+
+    if args.frow not in bench_frows.FROWS:
+        sys.exit(f"--frow: one of {sorted(bench_frows.FROWS)}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    out = bench_frows.run_frow(args.frow, args.n, device, launches=max(1, args.steps), warm=max(1, args.warmup), peak_gbs=HBM_PEAK_GBS)
+    print(json.dumps({"metric": METRIC, "frow": args.frow, **out}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1062,6 +1082,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help=f"time this workload only (default: {HEADLINE}, followed at N = 1 by the other BASELINE configurations)")
+    ap.add_argument("--frow", default=None,
+                    help="run ONE row of SURVEY 8(f) alone (bench_frows.FROWS: indexed evaluate, fused wrapper, low-dimensional kernels, "
+                         "resident sparse-tangent iteration) and print its figures -- the child of the default run's PMC passes")
+    ap.add_argument("--no-frows", action="store_true", help="N = 1 default run: skip the SURVEY 8(f) rows after the BASELINE configurations")
     ap.add_argument("--configs", choices=["auto", "all", "none"], default="auto",
                     help="the other single-GPU BASELINE configurations after the headline: auto = when no --workload is given and N = 1")
     ap.add_argument("--config-steps", type=int, default=6, help="timed launches per extra configuration (>= 5)")
@@ -1127,6 +1151,8 @@ def main():
         args.n = 10_000_000 if args.mode == "host" else 100_000_000
     if args.mode == "host":
         sys.exit(main_host(args))
+    if args.frow is not None:
+        sys.exit(main_frow(args))
 
     def stage(msg):
         if args.verbose:
@@ -1496,6 +1522,24 @@ def main():
                                                      "kernel_over_model": round(configs[cname]["kernel_ms_avg"] / model_ms, 3)}
         out["configs"] = configs
 
+    # the "next" rows of SURVEY 8(f) on the roofline: indexed evaluate (f2), fused wrapper and low-dimensional kernels (f3), the
+    # resident state's sparse-tangent Newton iteration (f1) -- same method as the configurations, appended to `configs`
+    frow_names = []
+    if do_configs and rank == 0 and not args.no_frows:
+        import bench_frows
+
+        for fname in bench_frows.FROWS:
+            checkpoint(f"frows: {fname}")
+            if budget_left() < 60:
+                out["configs"][fname] = {"skipped": "wall budget"}
+                continue
+            try:
+                out["configs"][fname] = bench_frows.run_frow(fname, n, device, launches=max(5, args.config_steps), peak_gbs=HBM_PEAK_GBS)
+                frow_names.append(fname)
+            except Exception as e:  # one row failing must not lose the line
+                out["configs"][fname] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+
     # N > 1: the single-process form of the host path on THIS node's GPUs (fcamd_multi) -- rank 0 alone drives all
     # of them over their own PCIe links while the other ranks wait on the CPU (a key in the process group's store, not a
     # collective: an RCCL barrier would keep their GPUs busy with a spinning kernel)
@@ -1570,7 +1614,7 @@ def main():
                     if "kernel_ms_avg" not in c or budget_left() < 110:
                         continue
                     checkpoint(f"live_traffic: {cname}")
-                    lc = live_traffic(cname, n, history, extra, min(60.0, budget_left() - 60.0))
+                    lc = live_traffic(cname, n, history, extra, min(60.0, budget_left() - 60.0), frow=cname in frow_names)
                     if lc is not None:
                         c["traffic_stored"], c["traffic"] = c.get("traffic"), lc["hbm_bytes_per_launch"]
                         c["traffic_source"] = "measured in this run (rocprofv3 --pmc child passes, as roofline.traffic)"
