@@ -1058,6 +1058,15 @@ def live_traffic(name, n, history, extra, budget_s, frow=False):
     return {"hbm_bytes_per_launch": int(read_b + write_b), "read_bytes": int(read_b), "write_bytes": int(write_b)}
 
 
+def all_agree(flag, dist, device):
+    """the same yes / no on every rank (a leg with collectives must be entered by all ranks or by none): the minimum over the ranks"""
+    import torch
+
+    f = torch.tensor([1 if flag else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(f, op=dist.ReduceOp.MIN)
+    return bool(int(f.item()))
+
+
 def main_frow(args):
     """`--frow NAME`: one SURVEY 8(f) row alone; prints one JSON line (with the launch_log the PMC slicing needs)"""
     import torch
@@ -1211,12 +1220,9 @@ def main():
         return args.wall_budget - (time.perf_counter() - t_start)
 
     def agree(flag):
-        """the same yes / no on every rank (a leg with collectives must be entered by all ranks or by none): the minimum over the ranks"""
         if not (distributed and world > 1):
             return bool(flag)
-        f = torch.tensor([1 if flag else 0], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(f, op=dist.ReduceOp.MIN)
-        return bool(int(f.item()))
+        return all_agree(flag, dist, device if args.backend == "nccl" else "cpu")
     wl = Workload(name, n, seed=1234 + rank, device=device, dev_index=dev_index, history=history,
                   sparse_tangent=args.sparse_tangent, grid=args.grid,
                   split_history=not args.no_split_history)

@@ -753,7 +753,7 @@ static int evaluate_wrapped(fcamd_model* m, int wrapper_constraint, double del_t
     a.counters = m->d_counters;
     a.tile_map = 0;
     a.nontemporal = 1;
-    a.masked_max = 0;  // the wrapped tile bodies have no row-masked path
+    a.masked_max = m->ctx->opt.masked_max >= 0 ? m->ctx->opt.masked_max : kMaskedRowMaxVonMises;  // eps_n rows of the fused VonMises3D wrapper
     a.flags = 0;
     constants_for(m, del_t);
     a.sc = m->sc;

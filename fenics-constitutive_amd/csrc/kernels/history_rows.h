@@ -89,6 +89,49 @@ struct PackedRows {
     }
 };
 
+// In-place plastic-strain rows of a tile whose plastic points are `rows` (the fused wrapper tiles; the plain in-place call of
+// tile_von_mises has the same logic inline): few rows -- the three wave-wide chunk instructions of the tile with the chunks of
+// untouched rows skipped (a 48-byte row is three 16-byte chunks); many rows -- the whole tile.  request() after the ballot,
+// gather() before the tile's first store, store() after the stress store.
+template <bool FULL, bool NT>
+struct MaskedRows {
+    Chunks<6> c;
+    bool masked = false;
+    bool row_live[3] = {true, true, true};
+
+    __device__ __forceinline__ void request(const double* rows_in, long long p0, int npts, int lane, unsigned long long rows, int masked_max) {
+        masked = FULL && (int)__popcll(rows) <= masked_max;
+        if (masked) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                row_live[k] = ((rows >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
+                d2 v;
+                v.x = 0.0;
+                v.y = 0.0;
+                if (row_live[k]) v = load16<NT>(rows_in + p0 * 6 + 2 * (k * kWave + lane));
+                c.v[k] = v;
+            }
+        } else {
+            tile_load<6, FULL, NT>(c, rows_in + p0 * 6, npts * 6, lane);
+        }
+    }
+    __device__ __forceinline__ void gather(double* region, int lane, double (&ep)[6]) { transpose_in<6>(c, region, lane, ep); }
+    __device__ __forceinline__ void store(double* rows_out, long long p0, int npts, int lane, double* region, const double (&ep)[6]) {
+        if (masked) {
+            lds_put_point<6>(region, lane, ep);
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int q = k * kWave + lane;
+                if (row_live[k]) store16<NT>(rows_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+            }
+            wave_sync();
+        } else {
+            transpose_out<6, FULL, NT>(ep, region, lane, rows_out + p0 * 6, npts * 6);
+        }
+    }
+};
+
 // History write policy of the laws with one [alpha, eps_p(6)] row per point (comfe-rs Mises and
 // Drucker-Prager; the row is always READ: alpha enters the yield function).  Which rows change:
 //   in place                      : the plastic points of this evaluate (ballot `mask`);

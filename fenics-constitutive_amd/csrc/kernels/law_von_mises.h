@@ -261,21 +261,23 @@ __device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const 
     const bool plastic = live && (tr.phitr > 0.0);
     const unsigned long long mask = __ballot(plastic);
 
-    Chunks<6> ce;
-    if (mask != 0ull) tile_load<6, FULL, NT>(ce, a.h0_in + p0 * 6, npts * 6, lane);
+    // eps_n of the plastic points, in place: requested right after the ballot (in flight with the Newton iteration), taken into
+    // the lanes before the tile's first store, row-masked when few points are plastic (MaskedRows)
+    MaskedRows<FULL, NT> er;
+    if (mask != 0ull) er.request(a.h0_in, p0, npts, lane, mask, a.masked_max);
     VMReturn rm;
     if (mask != 0ull) {
         if (plastic) vm_return(a.sc, tr, alpha_n, rm, st);
         st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
     }
+    double ep[6];
+    if (mask != 0ull) er.gather(region, lane, ep);
     vm_stress(a.sc, tr, rm, s);
     wrapped_store_stress<WRAP, FULL, NT>(a, region, p0, npts, lane, s);
     if (mask != 0ull) {
-        double ep[6];
-        transpose_in<6>(ce, region, lane, ep);
 #pragma unroll
         for (int i = 0; i < 6; ++i) ep[i] = ep[i] + rm.gamma * rm.N[i];
-        transpose_out<6, FULL, NT>(ep, region, lane, a.h0_out + p0 * 6, npts * 6);
+        er.store(a.h0_out, p0, npts, lane, region, ep);
         if (live) a.h1_out[p0 + lane] = alpha_n + a.sc.s[3] * rm.gamma;
     }
     if (a.tangent) {

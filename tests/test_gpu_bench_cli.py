@@ -59,18 +59,27 @@ def test_two_ranks_weak_scaling_with_strong_leg_and_gather():
     assert hm["sizes"]["4000000"]["registered"]["resident_sparse"]["Mpts_s"] > 0 and "per_call_us" not in hm
 
 
-def test_four_ranks_rehearsal():
-    """world = 4 on one GPU (the process guard of the box allows six GPU processes: pytest + four ranks): staggered peer
-    order, three peers per rank in the IPC gather, a chunk plan forced down to several chunks, four device contexts in the
-    host_path_multi leg."""
-    r, out = run_bench("--gpus", "4", "--backend", "gloo", "--points", "1000000", "--steps", "2", "--warmup", "1", "--configs", "none",
+def test_five_ranks_rehearsal():
+    """world = 5 on one GPU -- the most the box allows (its process guard: six GPU processes, pytest + five ranks; the
+    decisions of world 8 run on the CPU in tests/test_sharded_gloo.py): staggered peer order, four peers per rank in the
+    IPC gather, a chunk plan forced down to several chunks, five device contexts in the host_path_multi leg."""
+    r, out = run_bench("--gpus", "5", "--backend", "gloo", "--points", "1000000", "--steps", "2", "--warmup", "1", "--configs", "none",
                        "--no-cpu-baseline", "--placement", "first", "--gather-points", "300000")
     assert r.returncode == 0, r.stderr[-2000:]
-    assert out["n_gpus"] == 4 and len(out["per_rank_kernel_ms"]) == 4 and out["config"]["points_total"] == 4_000_000
-    assert out["strong_scaling"]["points_per_gpu"] == (1_000_000 // 4 // 64) * 64
+    assert out["n_gpus"] == 5 and len(out["per_rank_kernel_ms"]) == 5 and out["config"]["points_total"] == 5_000_000
+    assert out["strong_scaling"]["points_per_gpu"] == (1_000_000 // 5 // 64) * 64 and len(out["strong_scaling"]["per_rank_kernel_ms"]) == 5
     ag = out["allgather"]
     assert "error" not in ag and ag["direct_ms"] > 0 and ag["points_per_rank"] == (300_000 // 64) * 64, ag
-    assert out["host_path_multi"]["devices"] == [0, 0, 0, 0] and "error" not in out["host_path_multi"]
+    assert out["host_path_multi"]["devices"] == [0] * 5 and "error" not in out["host_path_multi"]
+
+
+def test_host_mode_eight_contexts():
+    """--mode host with the target's EIGHT device contexts (one process: no process-guard limit), all on GPU 0: the
+    single-assembler path of an 8-GPU node cut as it will be cut there"""
+    r, out = run_bench("--mode", "host", "--gpus", "8", "--host-devices", "0,0,0,0,0,0,0,0", "--points", "200000", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["mode"] == "host" and out["n_gpus"] == 8 and out["config"]["devices_used"] == 8
+    assert out["config"]["points_total"] == 1_600_000 and out["value"] > 0
 
 
 def test_two_ranks_strong_scaling():

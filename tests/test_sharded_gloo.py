@@ -61,8 +61,9 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,direct", [(2, False), (2, True), (3, True)])
-@pytest.mark.parametrize("n", [1000, 128, 65])
+@pytest.mark.parametrize("world,direct,n", [(2, False, 1000), (2, True, 1000), (3, True, 1000), (2, False, 128), (2, True, 65), (3, True, 128), (3, True, 65),
+                                            # the target shape, world 8 (BASELINE configs[4]): full shards, a ragged last one, empty trailing ranks
+                                            (8, True, 64 * 8 * 3), (8, False, 1000), (8, True, 129)])
 def test_sharded_equals_unsharded(n, world, direct, tmp_path):
     mp.spawn(worker, args=(world, free_port(), n, str(tmp_path), direct), nprocs=world, join=True)
     g, s, h = make_inputs(n)
@@ -141,7 +142,9 @@ def chunk_worker(rank, world, port, n, budget, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world,tiles_per_chunk", [(1000, 2, 2), (1000, 3, 1), (130, 2, 8), (64 * 7 + 1, 2, 3)])
+@pytest.mark.parametrize("n,world,tiles_per_chunk", [(1000, 2, 2), (1000, 3, 1), (130, 2, 8), (64 * 7 + 1, 2, 3),
+                                                     # config 5 scaled down: 8 ranks, shards of 9 tiles, the gathered tangent in THREE chunks
+                                                     (8 * 64 * 9, 8, 3), (8 * 64 * 9 - 100, 8, 3)])
 def test_chunked_gather_equals_the_global_array(n, world, tiles_per_chunk, tmp_path):
     """ChunkedGather: every point of every rank arrives exactly once, whatever the chunk length (ragged
     last rank, last chunk shorter than the others, slices that end inside a chunk)."""
@@ -152,3 +155,46 @@ def test_chunked_gather_equals_the_global_array(n, world, tiles_per_chunk, tmp_p
         assert np.array_equal(np.load(tmp_path / f"chunked{r}.npy"), ref), f"rank {r}"
         k, chunk = np.load(tmp_path / f"nchunks{r}.npy")
         assert chunk <= 64 * tiles_per_chunk and (k > 1 or n <= world * chunk)
+
+
+def test_config5_chunk_plan_scaled_down_is_the_full_size_plan():
+    """the world-8 case above runs the SAME plan shape as config 5 at full size: three equalised chunks per shard"""
+    from fenics_constitutive_amd.sharded import GatherChunks
+
+    full = GatherChunks.create(10**8, 8, 36, int(288e9 - 56.8e9 - 38.4e9 - 16e9))
+    small = GatherChunks.create(64 * 9, 8, 36, 8 * 36 * 8 * 64 * 3 * 2)
+    assert full.n_chunks == small.n_chunks == 3 and small.chunk == 64 * 3 and full.n_buffers == small.n_buffers == 2
+
+
+def agree_worker(rank, world, port, out_dir):
+    import importlib.util
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        # a leg with collectives is entered by all ranks or by none: one rank short of budget vetoes it for everybody
+        votes = [bench.all_agree(True, dist, "cpu"), bench.all_agree(rank != 5, dist, "cpu"), bench.all_agree(False, dist, "cpu")]
+        # max-over-ranks timing and the per-rank kernel times, as the timed region reduces them
+        t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tk = torch.zeros(world, dtype=torch.float64)
+        tk[rank] = 8.0 + rank
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        np.save(os.path.join(out_dir, f"agree{rank}.npy"), np.array([*votes, float(t.item()), *tk.tolist()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_collective_decisions_at_world_8(tmp_path):
+    """bench.py's N > 1 control decisions at the TARGET world size (the box's process guard allows no 8-rank GPU run: the
+    kernels of that shape are rehearsed with 5 ranks in tests/test_gpu_bench_cli.py, the decisions here)."""
+    world = 8
+    mp.spawn(agree_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        z = np.load(tmp_path / f"agree{r}.npy")
+        assert list(z[:3]) == [1.0, 0.0, 0.0], (r, z)
+        assert z[3] == pytest.approx(0.008) and list(z[4:]) == [8.0 + k for k in range(world)]
