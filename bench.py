@@ -656,6 +656,69 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
         out["extra"] = extra
     except Exception as e:  # the extra figures are informational only
         out["extra"] = {"error": str(e)}
+    try:
+        out["small_call_crossover"] = small_call_crossover()
+    except Exception as e:  # informational
+        out["small_call_crossover"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
+def small_call_crossover(sizes=(64, 256, 1024, 4096, 16384, 65536), reps=7):
+    """Per law: the number of points below which ONE ndarray ``evaluate`` call on the GPU (launch + PCIe round trips: a floor
+    of tens of microseconds) loses to the NumPy restatement of the reference's own code path on this box's host -- what a
+    dolfinx rank with a few thousand quadrature points per law pays (solver/_lawonsubmesh.py:86-94).  Medians of `reps`
+    calls per size; the crossover is interpolated between the two sizes where the order flips.  DeviceLaw.evaluate warns
+    once below `device.SMALL_CALL_POINTS` (INTEGRATION.md states the measured table)."""
+    import numpy as np
+
+    import fenics_constitutive_amd as fc
+    from fenics_constitutive_amd import device as fdev
+    from oracle import numpy_oracle as NO
+
+    FULL = fc.StressStrainConstraint.FULL
+    rng = np.random.default_rng(5)
+    cases = {"linear_elasticity": (fc.LinearElasticityModel(LE_P, FULL), LE_P, None, 1e-3),
+             "von_mises_3d": (fc.VonMises3D(VM_P), VM_P, {"eps_n": 6, "alpha": 1}, 3e-3),
+             "spring_maxwell": (fc.SpringMaxwellModel(SLS_P, FULL), SLS_P, {"strain_visco": 6, "strain": 6}, 1e-3),
+             "spring_kelvin": (fc.SpringKelvinModel(SLS_P, FULL), SLS_P, {"strain_visco": 6, "strain": 6}, 1e-3)}
+    out = {"sizes": list(sizes), "unit": "us per call (median)", "warn_below_points": dict(fdev.SMALL_CALL_POINTS)}
+    import warnings
+
+    for kind, (law, params, hd, scale) in cases.items():
+        gpu_us, np_us = [], []
+        for n in sizes:
+            g = rng.normal(scale=scale, size=9 * n)
+            s0 = rng.normal(size=6 * n)
+            h0 = None if hd is None else {k: np.abs(rng.normal(scale=1e-3, size=d * n)) for k, d in hd.items()}
+            t = np.zeros(36 * n)
+
+            def run(fn, is_law):
+                ts = []
+                for _ in range(reps + 2):
+                    s = s0.copy()
+                    h = None if h0 is None else {k: v.copy() for k, v in h0.items()}
+                    t0 = time.perf_counter()
+                    if is_law:
+                        fn.evaluate(0.0, 2.0, g, s, t, h)
+                    else:
+                        fn(params, 0.0, 2.0, g, s, t, h)
+                    ts.append(time.perf_counter() - t0)
+                return sorted(ts[2:])[reps // 2] * 1e6
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")  # the very warning this table calibrates
+                gpu_us.append(round(run(law, True), 1))
+            np_us.append(round(run(NO.MODELS[kind], False), 1))
+        cross = None
+        for k in range(len(sizes)):
+            if gpu_us[k] <= np_us[k]:
+                if k == 0:
+                    cross = sizes[0]
+                else:  # linear interpolation of the difference between the two sizes
+                    d0, d1 = gpu_us[k - 1] - np_us[k - 1], gpu_us[k] - np_us[k]
+                    cross = int(sizes[k - 1] + (sizes[k] - sizes[k - 1]) * d0 / (d0 - d1)) if d0 != d1 else sizes[k]
+                break
+        out[kind] = {"gpu_call_us": gpu_us, "numpy_port_us": np_us, "crossover_points": cross}
     return out
 
 

@@ -115,6 +115,32 @@ def unpack_rows(packed, ever, n=None):
     return rows
 
 
+#: Below this many points ONE ndarray ``evaluate`` call is bound by its fixed cost -- the launch and the PCIe round trips of a
+#: kernel that reads and writes host memory, 45-60 us on MI355X -- and a NumPy evaluation of the same law on the host is
+#: faster (measured per law by bench.py, ``cpu_baseline.small_call_crossover``; table in INTEGRATION.md).  A dolfinx rank
+#: often holds 1e3-1e5 quadrature points per law (solver/_lawonsubmesh.py:86-94): the first such call of a law warns, once.
+#: VonMises3D: the reference evaluates it point by point in Python (30-70 us per POINT), so the engine wins from a few points on;
+#: the figure is the crossover against a vectorised NumPy restatement.  ``FCAMD_SMALL_CALL_WARNING=0`` silences the warning.
+SMALL_CALL_POINTS = {"LinearElasticityModel": 2000, "LinearElasticity3D": 2000, "SpringMaxwellModel": 400, "SpringKelvinModel": 400,
+                     "VonMises3D": 200}
+_small_call_warned: set = set()
+
+
+def _warn_small_call(law, n: int) -> None:
+    import os
+    import warnings
+
+    name = type(law).__name__
+    limit = SMALL_CALL_POINTS.get(name)
+    if limit is None or n >= limit or n == 0 or name in _small_call_warned or os.environ.get("FCAMD_SMALL_CALL_WARNING") == "0":
+        return
+    _small_call_warned.add(name)
+    warnings.warn(f"{name}.evaluate on {n} points: below ~{limit} points one call is bound by its fixed cost on the GPU (launch + PCIe round "
+                  "trips, 45-60 us) and a NumPy evaluation of this law on the host is faster; batch several laws / cells into one "
+                  "call, keep the state resident (ResidentState), or stay on the CPU for this size (INTEGRATION.md, 'small calls').  "
+                  "Shown once per law; FCAMD_SMALL_CALL_WARNING=0 silences it.", RuntimeWarning, stacklevel=3)
+
+
 class DeviceLaw(IncrSmallStrainModel):
     """Base of all GPU-backed laws: owns the C model handle (created lazily, per device)
     and implements ``evaluate`` on top of the C ABI with the reference's validation."""
@@ -225,6 +251,7 @@ class DeviceLaw(IncrSmallStrainModel):
             if check:
                 self.device_stats(grad_del_u.device.index or 0)
         else:
+            _warn_small_call(self, n)
             self._evaluate_host(t, del_t, n, grad_del_u, stress, tangent, hist)
 
     def _evaluate_host(self, t, del_t, n, grad, stress, tangent, hist) -> None:

@@ -95,3 +95,58 @@ def test_hyperbolic_hydrostatic_states():
     assert law.last_stats.n_plastic == npl
     assert not np.isnan(t).any() and not np.isnan(s).any()
     assert rel_err(s, s_ref) <= 1e-9 and rel_err(t, t_ref) <= 1e-7 and rel_err(h["history"], h_ref["history"]) <= 1e-6
+
+
+def test_nonconvergence_set_equals_the_8x8_newton():
+    """VERDICT r3 / general.rs:181-190,236: the kernel iterates in invariant coordinates with a closed-form inverse, the
+    reference on the full 8x8 system with LU -- the same Newton iterates in exact arithmetic.  Far outside the regime the
+    other tests use (tensile prestress, strain increments up to 1e-1) the reference's iteration fails for ~15 % of the states
+    (`it > 25` -> panic).  Point by point: the kernel must fail on EXACTLY the states the 8x8 iteration fails on, converge
+    on exactly the others, with the same iteration counts -- the reduced iteration neither rescues nor loses a point."""
+    import warnings
+
+    law, p = make(True)
+    rng = np.random.default_rng(0)
+    n = 600
+    S, G = np.zeros((n, 6)), np.zeros((n, 9))
+    for i in range(n):
+        S[i, :3] = rng.uniform(-2000.0, 900.0)
+        S[i] += rng.normal(scale=rng.choice([1.0, 30.0, 300.0]), size=6)
+        G[i] = rng.normal(size=9) * 10 ** rng.uniform(-5.0, -1.0)
+
+    def oracle_one(g, s):
+        s, t, h = s.copy(), np.zeros(36), {"history": np.zeros(7)}
+        try:
+            npl, nit = O.comfe_drucker_prager(p, 0, 1, g, s, t, h, hyperbolic=True)
+            return (1 if npl else 0), nit, s
+        except O.DruckerPragerNotConverged:
+            return 2, 0, s
+
+    def kernel_one(g, s):
+        s, t, h = s.copy(), np.zeros(36), {"history": np.zeros(7)}
+        try:
+            law.evaluate(0.0, 1.0, g.copy(), s, t, h)
+            return (1 if law.last_stats.n_plastic else 0), int(law.last_stats.n_newton_iters), s
+        except RuntimeError as e:
+            assert "did not converge" in str(e)
+            return 2, 0, s
+
+    table = np.zeros((3, 3), dtype=int)  # rows: oracle (elastic, converged, not converged); columns: kernel
+    iters, worst = [0, 0], 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # overflow warnings of the diverging NumPy iterates; the small-call warning
+        for i in range(n):
+            o, k = oracle_one(G[i], S[i]), kernel_one(G[i], S[i])
+            table[o[0], k[0]] += 1
+            if o[0] == 1 and k[0] == 1:
+                iters[0] += o[1]
+                iters[1] += k[1]
+                worst = max(worst, np.abs(o[2] - k[2]).max() / max(1.0, np.abs(o[2]).max()))
+    assert table.sum() == n and np.count_nonzero(table - np.diag(np.diag(table))) == 0, table
+    assert table[2, 2] > 40 and table[1, 1] > 200 and table[0, 0] > 50, table  # every class is well populated
+    assert iters[0] == iters[1] and worst <= 1e-10, (iters, worst)
+    # the whole batch in ONE call: the count of non-converged points is the oracle's, the call raises like the reference
+    s, t, h = S.reshape(-1).copy(), np.zeros(36 * n), {"history": np.zeros(7 * n)}
+    with pytest.raises(RuntimeError, match="did not converge"):
+        law.evaluate(0.0, 1.0, G.reshape(-1).copy(), s, t, h)
+    assert law.last_stats.n_nonconverged == table[2, 2]

@@ -407,3 +407,31 @@ def test_reference_import_paths_resolve():
         mod = importlib.import_module("fenics_constitutive_amd.models" + sub)
         for name in names:
             assert getattr(mod, name) is getattr(fc, name), (sub, name)
+
+
+def test_small_ndarray_calls_warn_once(monkeypatch):
+    """Below the measured crossover (bench.py: cpu_baseline.small_call_crossover) one ndarray call costs more
+    than a NumPy evaluation of the law on the host: the first such call of a law warns, once; device tensors never do."""
+    import warnings
+
+    from fenics_constitutive_amd import device as fdev
+
+    monkeypatch.delenv("FCAMD_SMALL_CALL_WARNING", raising=False)
+    le = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, C.FULL)
+    fdev._small_call_warned.discard("LinearElasticityModel")
+    limit = fdev.SMALL_CALL_POINTS["LinearElasticityModel"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        fdev._warn_small_call(le, limit)      # at the limit: nothing
+        fdev._warn_small_call(le, 0)          # empty calls: nothing
+    with pytest.warns(RuntimeWarning, match="fixed cost"):
+        fdev._warn_small_call(le, limit - 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        fdev._warn_small_call(le, 10)         # once per law
+    fdev._small_call_warned.discard("LinearElasticityModel")
+    monkeypatch.setenv("FCAMD_SMALL_CALL_WARNING", "0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        fdev._warn_small_call(le, 10)         # silenced
+    assert set(fdev.SMALL_CALL_POINTS) >= {"LinearElasticityModel", "VonMises3D", "SpringMaxwellModel", "SpringKelvinModel"}
