@@ -18,7 +18,7 @@ ALGORITHMIC bytes per point -- the traffic the call's interface mandates -- stat
                                      _history.py:64-88 (f1)                     elastic 72 + 96 + 8 = 176 (its tangent row is not rewritten),
                                                                                 a plastic / formerly plastic one 568
 
-Used by bench.py: `python bench.py --frow NAME` runs one row alone (the child of the PMC passes); the default run
+Used by bench.py (benchlib/frows.py): `python bench.py --frow NAME` runs one row alone (the child of the PMC passes); the default run
 appends all of them to `configs`."""
 
 from __future__ import annotations

@@ -119,10 +119,11 @@ def unpack_rows(packed, ever, n=None):
 #: kernel that reads and writes host memory, 45-60 us on MI355X -- and a NumPy evaluation of the same law on the host is
 #: faster (measured per law by bench.py, ``cpu_baseline.small_call_crossover``; table in INTEGRATION.md).  A dolfinx rank
 #: often holds 1e3-1e5 quadrature points per law (solver/_lawonsubmesh.py:86-94): the first such call of a law warns, once.
-#: VonMises3D: the reference evaluates it point by point in Python (30-70 us per POINT), so the engine wins from a few points on;
-#: the figure is the crossover against a vectorised NumPy restatement.  ``FCAMD_SMALL_CALL_WARNING=0`` silences the warning.
-SMALL_CALL_POINTS = {"LinearElasticityModel": 2000, "LinearElasticity3D": 2000, "SpringMaxwellModel": 400, "SpringKelvinModel": 400,
-                     "VonMises3D": 200}
+#: Measured on an MI355X box (EPYC 9575F host, round 4): LinearElasticityModel 2980, SpringMaxwellModel 1969, SpringKelvinModel 708,
+#: VonMises3D < 64 points (against a vectorised NumPy restatement; the reference itself evaluates VonMises3D point by point in
+#: Python, 30-70 us per POINT -- there the engine wins from the first point on).  ``FCAMD_SMALL_CALL_WARNING=0`` silences the warning.
+SMALL_CALL_POINTS = {"LinearElasticityModel": 3000, "LinearElasticity3D": 3000, "SpringMaxwellModel": 2000, "SpringKelvinModel": 700,
+                     "VonMises3D": 64}
 _small_call_warned: set = set()
 
 
