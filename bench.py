@@ -158,7 +158,7 @@ def main_frow(args):
         sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(device)
-    out = bench_frows.run_frow(args.frow, args.n, device, launches=max(1, args.steps), warm=max(1, args.warmup), peak_gbs=HBM_PEAK_GBS)
+    out = bench_frows.run_frow(args.frow, args.n, device, launches=max(1, args.steps), warm=max(1, args.warmup), peak_gbs=HBM_PEAK_GBS, draws=1)
     print(json.dumps({"metric": METRIC, "frow": args.frow, **out}), flush=True)
     return 0
 

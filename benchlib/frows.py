@@ -253,24 +253,42 @@ SURVEY_ROW = {"indexed_runs": "f2", "indexed_permuted": "f2", "wrapped_plane_str
               "resident_sparse_tangent": "f1"}
 
 
-def run_frow(name, n, device, launches=6, warm=2, peak_gbs=8000.0):
-    """one row, measured: warm launches, the row's own counts, `launches` event-timed launches"""
-    row = FROWS[name](n, device)
+def run_frow(name, n, device, launches=6, warm=2, peak_gbs=8000.0, draws=3):
+    """one row, measured: warm launches, the row's own counts, `launches` event-timed launches -- on up to `draws` fresh sets
+    of allocations (the kernel time follows where the driver puts the written arrays, DESIGN.md 6: `frac` is the fastest
+    set, as the headline's is the fastest tangent candidate; `frac_first_allocation` what the first set gave)"""
+    import torch
+
+    rows, results = [], []
     try:
-        for _ in range(warm):
-            row.reset()
-            row.launch()
-        row.launch_log.append(["warmup", warm])
-        if hasattr(row, "count"):
-            row.count()
-        ms = row.timed(launches)
-        avg, alg = sum(ms) / len(ms), row.alg_bytes()
+        for k in range(max(1, draws)):
+            free_b = torch.cuda.mem_get_info(device)[0]
+            if k > 0 and free_b < 1.3 * rows[0].extra.get("_bytes", 0):
+                break  # the earlier sets stay alive (so that the allocator must find new memory): only while they fit
+            before = torch.cuda.memory_allocated(device)
+            row = FROWS[name](n, device)
+            rows.append(row)
+            for _ in range(warm):
+                row.reset()
+                row.launch()
+            row.launch_log.append(["warmup", warm])
+            if hasattr(row, "count"):
+                row.count()
+            ms = row.timed(launches)
+            row.extra["_bytes"] = max(row.extra.get("_bytes", 0), torch.cuda.memory_allocated(device) - before)
+            results.append((sum(ms) / len(ms), min(ms), row))
+        avg, best_min, row = min(results, key=lambda r: r[0])
+        alg = row.alg_bytes()
+        frac = lambda t: round(alg / (t * 1e-3) / 1e9 / peak_gbs, 4)  # noqa: E731
+        log = [x for r in rows for x in r.launch_log] if len(rows) > 1 else row.launch_log
         out = {"survey_row": SURVEY_ROW[name], "reference": row.reference, "workload": row.text, "points": row.n, "launches": launches,
-               "kernel_ms_avg": round(avg, 4), "kernel_ms_min": round(min(ms), 4), "Mpts_s": round(row.n / (avg * 1e-3) / 1e6, 1),
+               "kernel_ms_avg": round(avg, 4), "kernel_ms_min": round(best_min, 4), "Mpts_s": round(row.n / (avg * 1e-3) / 1e6, 1),
                "algorithmic_bytes_per_launch": int(alg), "bytes_per_point": round(alg / row.n, 1),
-               "achieved_GBs": round(alg / (avg * 1e-3) / 1e9, 1), "frac": round(alg / (avg * 1e-3) / 1e9 / peak_gbs, 4),
-               "traffic": None, "traffic_over_algorithmic": None, "launch_log": row.launch_log}
-        out.update(row.extra)
+               "achieved_GBs": round(alg / (avg * 1e-3) / 1e9, 1), "frac": frac(avg), "frac_first_allocation": frac(results[0][0]),
+               "allocation_draws_ms": [round(r[0], 4) for r in results],
+               "traffic": None, "traffic_over_algorithmic": None, "launch_log": log}
+        out.update({k: v for k, v in row.extra.items() if not k.startswith("_")})
         return out
     finally:
-        row.free()
+        for r in rows:
+            r.free()

@@ -365,7 +365,8 @@ int grid_for(fcamd_model* m, int64_t n) {
         grid = m->grid_auto;
     }
     const int64_t tiles = (n + 63) / 64;
-    const int64_t need = (tiles + 3) / 4;
+    // an explicit grid is capped at one tile per wave; the automatic one keeps two tiles per wave (fcamd_kernels.hip: default_grid)
+    const int64_t need = c->grid_override > 0 ? (tiles + 3) / 4 : (tiles + 7) / 8;
     if (need < grid) grid = (int)std::max<int64_t>(need, 1);
     return grid;
 }

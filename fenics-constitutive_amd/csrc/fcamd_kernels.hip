@@ -365,11 +365,13 @@ hipError_t launch_evaluate_wrapped(int law, int wrap, const EvalArgs& args, int 
 }
 
 int default_grid(int law, int num_cu) {
-    // Measured on MI355X (VonMises3D, 1e8 points, round-2 probe variance_probe2.py (git history)): the more workgroups
-    // the better, monotonically -- 512: 9.5-10.3 ms, 1024 (= resident set): 9.3-10.0, 4096:
-    // 9.0-9.6, 16384: 9.0-9.4 -- short queues of workgroups rebalance CUs and HBM channels.
+    // Measured on MI355X, 1e8 points, identical buffers in one process (round 4, tools/ab_knobs.py): the more workgroups the
+    // better up to 256-512 per CU -- VonMises3D mixed 16384: 7.87 ms, 65536: 7.755, 131072: 7.76 (LinearElasticity 7.05 ->
+    // 6.97) -- short queues of workgroups rebalance CUs and HBM channels; beyond (262144: 8.04, one tile per wave = 390625:
+    // 8.27 ms) the dispatch itself shows.  3e7 points: 16384: 2.40, 65536: 2.34 ms; 1e7: flat (0.83 ms).  grid_for() also keeps
+    // at least two tiles per wave.
     (void)law;
-    return 64 * num_cu;
+    return 512 * num_cu;
 }
 
 }  // namespace fcamd
