@@ -191,7 +191,7 @@ def agree_worker(rank, world, port, out_dir):
 
 def test_bench_collective_decisions_at_world_8(tmp_path):
     """bench.py's N > 1 control decisions at the TARGET world size (the box's process guard allows no 8-rank GPU run: the
-    kernels of that shape are rehearsed with 5 ranks in tests/test_gpu_bench_cli.py, the decisions here)."""
+    kernels of that shape are rehearsed with 4 ranks in tests/test_gpu_bench_cli.py, the decisions here)."""
     world = 8
     mp.spawn(agree_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
