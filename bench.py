@@ -86,13 +86,26 @@ class LineGuard:
             self.proc = None
 
     def final(self, line):
+        """the complete line: through the guard when there is one -- and then NEVER printed directly as well (the guard prints
+        the last line it received when the pipe closes, whatever happens to this process afterwards: two lines would break
+        the one-line contract); directly only when no guard exists or the send itself failed"""
         if self.proc is not None:
+            sent = False
             try:
                 self._send(line)
+                sent = True
                 self.proc.stdin.close()
-                self.proc.wait(timeout=30)
+            except (OSError, ValueError):
+                pass
+            if sent:
+                try:
+                    self.proc.wait(timeout=30)
+                except Exception:  # noqa: BLE001 -- a slow guard still prints the line on its own
+                    pass
                 return
-            except Exception:
+            try:  # the guard never received the final line: silence it (it would print a stale provisional one), print here
+                self.proc.kill()
+            except Exception:  # noqa: BLE001
                 pass
         print(line, flush=True)
 
@@ -380,6 +393,7 @@ def main():
                           "of its arrays), same timing bracket as `value`; compare with the N = 1 line's value"}
         for i in (0, 1):  # the sparse protocol's masks and trial rows back in step with whole-array launches
             wl.launch(i)
+        wl.launch_log.append(["strong_scaling_resync", 2])
 
     # next to the headline: the same step without the sparse protocol (every launch rewrites the whole trial
     # history, fcamd_evaluate_device_from) -- six extra launches after the timed region
