@@ -351,7 +351,7 @@ def test_kernel_hash_ignores_comments_but_not_code():
     base = _build.kernel_hash()
     assert _build.kernel_hash(tree(lambda t: t)) == base
     assert _build.kernel_hash(tree(lambda t: t.replace("namespace fcamd {", "namespace fcamd {  // a remark\n\n   /* and\n another */", 1))) == base
-    assert _build.kernel_hash(tree(lambda t: t.replace("return 64 * num_cu;", "return 32 * num_cu;", 1))) != base
+    assert _build.kernel_hash(tree(lambda t: t.replace("return 512 * num_cu;", "return 256 * num_cu;", 1))) != base
     assert "-pthread" not in _build.KERNEL_FLAGS and "-ffp-contract=off" in _build.KERNEL_FLAGS
 
 
