@@ -96,7 +96,7 @@ class IndexedRow(FRow):
         self.n_parent = 2 * n_sub
         self.law = fc.LinearElasticityModel(LE_P, fc.StressStrainConstraint.FULL)
         if permuted:  # cells of this material scattered all over the parent numbering: every lane its own 48-byte / 288-byte row
-            rows = t.randperm(self.n_parent, device=device)[:n_sub]
+            rows = t.randperm(self.n_parent, device=device, generator=self.gen)[:n_sub]
         else:  # cells numbered in runs (blocks of 4096 points, every other block is this material's): whole tiles are consecutive rows
             blk = t.arange(n_sub // 4096, device=device) * 2
             rows = (blk[:, None] * 4096 + t.arange(4096, device=device)[None, :]).reshape(-1)
