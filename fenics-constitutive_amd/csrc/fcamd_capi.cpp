@@ -398,7 +398,8 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.flags = split ? FCAMD_EVAL_SPLIT_HISTORY : 0;
     if (hmask) {
         if (tangent) a.flags |= flags & FCAMD_EVAL_SPARSE_TANGENT;  // needs an array that holds the previous tangent
-        if ((m->law == FCAMD_VON_MISES_3D || split) && emask_prev && emask && !rows) a.flags |= flags & FCAMD_EVAL_PACKED_HISTORY;
+        // (with parent_rows: VonMises3D only -- the indexed split-history kernels would need instantiations of their own)
+        if ((m->law == FCAMD_VON_MISES_3D || (split && !rows)) && emask_prev && emask) a.flags |= flags & FCAMD_EVAL_PACKED_HISTORY;
     }
     a.emask_in = emask_prev;
     a.emask_out = emask;
@@ -690,7 +691,8 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
                                                "comfe-rs plasticity laws");
         if (!x->history_mask || !x->packed_mask_prev || !x->packed_mask)
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs history_mask, packed_mask_prev and packed_mask");
-        if (x->parent_rows) return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_PACKED_HISTORY: not with parent_rows");
+        if (x->parent_rows && m->law != FCAMD_VON_MISES_3D)
+            return fail(FCAMD_ERR_UNSUPPORTED, "FCAMD_EVAL_PACKED_HISTORY with parent_rows: VonMises3D only");
         const int kd = split ? 1 : 0;
         if (x->history[kd] == x->history_prev[kd] || x->packed_mask == x->packed_mask_prev)
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs trial plastic-strain and mask arrays of their own");

@@ -263,6 +263,13 @@ constexpr bool kNT = true;
 template <int LAW>
 static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream) {
     if constexpr (LAW == LAW_VM3D) {
+        if (args.hmask && args.rows && (args.flags & kFlagPackedHistory)) {  // ... on the packed plastic-strain layout (local to the law)
+            if (args.n >= kWave)
+                hipLaunchKernelGGL((evaluate_kernel<LAW, true, true, 2>), dim3(grid), dim3(kBlock), 0, stream, args);
+            if (args.n % kWave != 0)
+                hipLaunchKernelGGL((evaluate_tail_kernel<LAW, true, 2>), dim3(1), dim3(kWave), 0, stream, args);
+            return hipGetLastError();
+        }
         if (args.hmask && args.rows) {  // sparse trial history on a submesh (history is local, stress/tangent indexed)
             if (args.n >= kWave)
                 hipLaunchKernelGGL((evaluate_kernel<LAW, true, true, 1>), dim3(grid), dim3(kBlock), 0, stream, args);

@@ -390,7 +390,7 @@ class DeviceLaw(IncrSmallStrainModel):
 
     def evaluate_indexed(self, t, del_t, grad_del_u, stress_prev_parent, stress_parent, tangent_parent,
                          parent_rows, history_prev, history, history_mask=None, sparse_tangent: bool = False,
-                         counters=None) -> None:
+                         counters=None, packed_masks=None) -> None:
         """Multi-material form: this law owns ``n = len(parent_rows)`` points whose stress/tangent
         rows live in PARENT arrays at ``parent_rows`` (int32 device tensor).  Reads the committed
         stress from ``stress_prev_parent`` rows, writes stress and tangent into the parent rows;
@@ -413,7 +413,7 @@ class DeviceLaw(IncrSmallStrainModel):
         m = self._handle(dev)
         m.ctx.set_stream(_current_stream_ptr(dev))
         tan_ptr = None if tangent_parent is None else _check_torch("tangent", tangent_parent).data_ptr()
-        if history_mask is None and counters is None:
+        if history_mask is None and counters is None and packed_masks is None:
             m.evaluate_device_indexed(
                 t, del_t, n, grad_del_u.data_ptr(), stress_prev_parent.data_ptr(), stress_parent.data_ptr(),
                 tan_ptr, parent_rows.data_ptr(), [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist])
@@ -421,12 +421,17 @@ class DeviceLaw(IncrSmallStrainModel):
         # sparse trial history on a submesh (fcamd_evaluate_device_ex): mask and history are local to the law
         if history_mask is not None:
             assert history_mask.dtype == torch.int64 and history_mask.is_cuda and history_mask.numel() >= (n + 63) // 64
+        flags = _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tan_ptr is not None and history_mask is not None) else 0
+        pm = None
+        if packed_masks is not None:  # the law's (local) plastic-strain arrays in the packed layout (VonMises3D; ``pack_rows``)
+            assert history_mask is not None, "packed history: with history_mask"
+            flags |= _capi.EVAL_PACKED_HISTORY
+            pm = (packed_masks[0].data_ptr(), packed_masks[1].data_ptr())
         m.evaluate_device_ex(
             t, del_t, n, grad_del_u.data_ptr(), stress_prev_parent.data_ptr(), stress_parent.data_ptr(), tan_ptr,
             [h.data_ptr() for h in hprev], [h.data_ptr() for h in hist], parent_rows.data_ptr(),
-            None if history_mask is None else history_mask.data_ptr(),
-            _capi.EVAL_SPARSE_TANGENT if (sparse_tangent and tan_ptr is not None and history_mask is not None) else 0,
-            counters_ptr=_counters_ptr(counters))
+            None if history_mask is None else history_mask.data_ptr(), flags,
+            counters_ptr=_counters_ptr(counters), packed_mask_ptrs=pm)
 
     def raise_for_stats(self, st) -> None:
         """The reference's errors for the counters of a finished launch: the Drucker-Prager tip

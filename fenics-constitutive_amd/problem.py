@@ -40,7 +40,7 @@ def rows_of_cells(cells: np.ndarray, points_per_cell: int) -> np.ndarray:
 
 
 class _LawState:
-    def __init__(self, law, rows, n, f, device, sparse_history):
+    def __init__(self, law, rows, n, f, device, sparse_history, packed_history=True):
         import torch
 
         self.law, self.n = law, n
@@ -59,6 +59,10 @@ class _LawState:
         if sparse_history and type(law).__name__ in ("VonMises3D", "MisesPlasticityLinearHardening3D",
                                                      "DruckerPrager3D", "DruckerPragerHyperbolic3D"):
             self.mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=device)
+        # packed plastic-strain history (see ResidentState; FCAMD_EVAL_PACKED_HISTORY): VonMises3D's eps_n -- both copies packed per
+        # tile, one EVER mask per copy; ``history_view`` hands the reference's layout out (a copy)
+        self.packed = bool(packed_history) and self.mask is not None and type(law).__name__ == "VonMises3D"
+        self.ever = [torch.zeros_like(self.mask), torch.zeros_like(self.mask)] if self.packed else None
         # sparse tangent (see ResidentState): the array that received this law's previous tangent --
         # "dev" (the state's device array) or the address of the host assembler's parent array
         self.tangent_target = None
@@ -71,6 +75,34 @@ class _LawState:
         self.stats_pending = False
         self.failed = None  # the error of THIS law's last evaluate (cleared only when this law is evaluated again)
 
+    def packed_masks(self, c):
+        """(EVER mask of the committed copy ``c``, of the trial copy) for the launches, or None"""
+        return (self.ever[c], self.ever[1 - c]) if self.packed else None
+
+    def history_view(self, copy):
+        """this law's history of one copy in the reference's layout (the packed plastic-strain array unpacked: a new tensor)"""
+        if self.hist is None:
+            return None
+        if not self.packed:
+            return self.hist[copy]
+        from .device import unpack_rows
+
+        h = self.hist[copy]
+        return {**h, "eps_n": unpack_rows(h["eps_n"], self.ever[copy], self.n)}
+
+    def store_history(self, c, h):
+        """committed copy ``c`` <- ``h`` (reference layout; NumPy or device), the trial copy set equal to it (sparse-history contract)"""
+        from .device import pack_rows
+
+        for k in self.hist[c]:
+            _store(self.hist[c][k], h[k])
+            if self.packed and k == "eps_n":
+                packed, ever = pack_rows(self.hist[c][k].clone())
+                self.hist[c][k].copy_(packed)
+                self.ever[c].copy_(ever)
+                self.ever[1 - c].copy_(ever)
+            self.hist[1 - c][k].copy_(self.hist[c][k])
+
 
 class ResidentProblemState:
     """``laws``: one ``DeviceLaw`` (covers all ``n_points``) or a list of ``(law, rows)`` with
@@ -82,7 +114,7 @@ class ResidentProblemState:
     AUTO_TUNE_MIN_BYTES = 256 << 20
 
     def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None, reuse_constant_tangent: bool = True,
-                 sparse_history: bool = True, sparse_tangent: bool = True, placement: str = "auto"):
+                 sparse_history: bool = True, sparse_tangent: bool = True, placement: str = "auto", packed_history: bool = True):
         import torch
 
         from . import _capi
@@ -106,7 +138,7 @@ class ResidentProblemState:
                 n_k = rows.size
                 assert rows.min(initial=0) >= 0 and rows.max(initial=-1) < self.n, "row out of range"
                 np.add.at(covered, rows, 1)
-            self._laws.append(_LawState(law, rows, n_k, f, self.device, sparse_history))
+            self._laws.append(_LawState(law, rows, n_k, f, self.device, sparse_history, packed_history))
         assert covered.max(initial=0) <= 1, "a quadrature point belongs to more than one law"
         self._stress = [torch.zeros(6 * self.n, **f), torch.zeros(6 * self.n, **f)]
         self._tangent = None  # parent tangent on the device: allocated on first use (device-assembler mode only)
@@ -151,11 +183,13 @@ class ResidentProblemState:
 
     @property
     def _history_0(self):
-        return [None if ls.hist is None else ls.hist[self._c] for ls in self._laws]
+        """committed history per law, reference layout (live tensors; VonMises3D's packed ``eps_n``: a copy)"""
+        return [ls.history_view(self._c) for ls in self._laws]
 
     @property
     def _history_1(self):
-        return [None if ls.hist is None else ls.hist[1 - self._c] for ls in self._laws]
+        """trial history per law (before the first evaluate of an increment the trial state IS the committed one)"""
+        return [ls.history_view(1 - self._c if (self._evaluated or not ls.packed) else self._c) for ls in self._laws]
 
     def set_state(self, stress=None, history=None) -> None:
         """Initial committed state: parent stress (6 n) and a list of per-law history dicts."""
@@ -167,10 +201,7 @@ class ResidentProblemState:
             for ls, h in zip(self._laws, history):
                 if ls.hist is None:
                     continue
-                for k in ls.hist[self._c]:
-                    v = h[k]
-                    _store(ls.hist[self._c][k], v)
-                    ls.hist[1 - self._c][k].copy_(ls.hist[self._c][k])  # trial == committed (sparse-history contract)
+                ls.store_history(self._c, h)  # trial == committed (sparse-history contract)
                 if ls.mask is not None:
                     ls.mask.zero_()
                 ls.tangent_target = None  # the mask no longer remembers which rows hold plastic tangents
@@ -212,10 +243,11 @@ class ResidentProblemState:
             ls.tangent_target = None
             if ls.rows is None:
                 ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent, hp, hc,
-                                     history_mask=ls.mask, sparse_tangent=st, counters=ls.counters)
+                                     history_mask=ls.mask, sparse_tangent=st, counters=ls.counters, packed_masks=ls.packed_masks(self._c))
             else:
                 ls.law.evaluate_indexed(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent,
-                                        ls.rows, hp, hc, history_mask=ls.mask, sparse_tangent=st, counters=ls.counters)
+                                        ls.rows, hp, hc, history_mask=ls.mask, sparse_tangent=st, counters=ls.counters,
+                                        packed_masks=ls.packed_masks(self._c))
             ls.tangent_key = key
             ls.tangent_target = "dev"
             ls.stats_pending = ls.counters is not None
@@ -279,10 +311,14 @@ class ResidentProblemState:
         ls.tangent_target = None
         ls.failed = None  # this law's record only: another law's failure of the same iteration stays on the books
         self._evaluated = True  # the trial state is touched even if the launch fails
+        pm = ls.packed_masks(self._c)
+        if pm is not None:
+            flags |= _capi.EVAL_PACKED_HISTORY
         m.evaluate_device_ex(self._time, self._del_t, ls.n, gptr, self.stress_0.data_ptr(), self.stress_1.data_ptr(), tptr,
                              hp, hc, None if ls.rows is None else ls.rows.data_ptr(),
                              None if ls.mask is None else ls.mask.data_ptr(), flags, stress2_ptr=sptr,
-                             counters_ptr=None if ls.counters is None else ls.counters.data_ptr())
+                             counters_ptr=None if ls.counters is None else ls.counters.data_ptr(),
+                             packed_mask_ptrs=None if pm is None else (pm[0].data_ptr(), pm[1].data_ptr()))
         ls.host_tangent_key = key
         ls.tangent_target = target
         ls.stats_pending = ls.counters is not None
@@ -307,13 +343,13 @@ class ResidentProblemState:
         ls.stats_pending = ls.counters is not None
         if ls.rows is None:
             ls.law.evaluate_from(self._time, self._del_t, ls.grad, self.stress_0, self.stress_1, tan, hp, hc,
-                                 history_mask=ls.mask, counters=ls.counters)
+                                 history_mask=ls.mask, counters=ls.counters, packed_masks=ls.packed_masks(self._c))
             assign(stress_parent, self.stress_1)
             if tan is not None:
                 assign(tangent_parent, tan)
         else:
             ls.law.evaluate_indexed(self._time, self._del_t, ls.grad, self.stress_0, self.stress_1, tan, ls.rows, hp, hc,
-                                    history_mask=ls.mask, counters=ls.counters)
+                                    history_mask=ls.mask, counters=ls.counters, packed_masks=ls.packed_masks(self._c))
             rows = ls.rows.long()
             rows_h = to_host(rows)
             stress_parent.reshape(-1, 6)[rows_h] = to_host(self.stress_1.view(-1, 6)[rows])

@@ -253,7 +253,7 @@ typedef struct fcamd_eval_args {
    arrays; FULL 3-D only. */
 #define FCAMD_EVAL_SPLIT_HISTORY 4
 /* Packed plastic-strain history (with history_mask; VonMises3D: history[0] = eps_n; the comfe-rs plasticity laws with
-   FCAMD_EVAL_SPLIT_HISTORY: history[1] = the eps_p rows; not with parent_rows).  The plastic-strain array only accumulates
+   FCAMD_EVAL_SPLIT_HISTORY: history[1] = the eps_p rows; with parent_rows: VonMises3D only -- the history is local to the law's n points either way).  The plastic-strain array only accumulates
    (models/mises_plasticity_isotropic_hardening.py:161, comfe-rs/src/mises_plasticity.rs:112, plasticity/general.rs:243)
    and is +0.0 wherever a point has never been plastic, so a device-resident state keeps BOTH its copies packed per
    64-point tile: the rows of the points whose row is not all +0.0 -- the tile's EVER mask, `packed_mask_prev[tile]` for the

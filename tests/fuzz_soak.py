@@ -18,7 +18,7 @@ kinds = ["von_mises_3d", "von_mises_3d+unpacked", "von_mises_3d+dense_rows", "co
          "drucker_prager_hyperbolic+unpacked", "linear_elasticity", "spring_maxwell"]
 bad = 0
 for seed in range(lo, hi + 1):
-    cases = [(RF.test_random_call_sequences, (k, seed)) for k in kinds] + [(PF.test_random_call_sequences, (seed,))]
+    cases = [(RF.test_random_call_sequences, (k, seed)) for k in kinds] + [(PF.test_random_call_sequences, (seed, True)), (PF.test_random_call_sequences, (seed, False))]
     cases += [(MF.test_random_call_sequences, (k, [0] * (2 + (seed + i) % 3), seed)) for i, k in enumerate(
         ["von_mises_3d", "comfe_mises_plasticity", "comfe_mises_plasticity+rows7", "drucker_prager", "drucker_prager_hyperbolic",
          "linear_elasticity", "spring_maxwell", "spring_kelvin"])]

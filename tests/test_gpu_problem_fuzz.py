@@ -19,8 +19,9 @@ def own(k):
     return np.frombuffer(mmap.mmap(-1, max(8 * k, 8)), dtype=np.float64, count=k)
 
 
+@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_random_call_sequences(seed):
+def test_random_call_sequences(seed, packed):
     n = 9000
     rng = np.random.default_rng(seed)
     perm = rng.permutation(n)
@@ -30,7 +31,10 @@ def test_random_call_sequences(seed):
     laws = [make_law(k, c[0]) for k, c in zip(kinds, cases)]
     stress0 = rng.normal(size=6 * n)
     hist0 = [c[3] for c in cases]
-    opt = ResidentProblemState(list(zip(laws, rows)), n, del_t=1.0)
+    # most points of the VonMises3D law have never been plastic: +0.0 plastic-strain rows (what the packed layout leaves out)
+    hist0[0]["eps_n"].reshape(-1, 6)[np.random.default_rng(50 + seed).random(rows[0].size) < 0.6] = 0.0
+    opt = ResidentProblemState(list(zip(laws, rows)), n, del_t=1.0, packed_history=packed)
+    assert opt._laws[0].packed == packed and not opt._laws[1].packed
     ref = ResidentProblemState(list(zip(laws, rows)), n, del_t=1.0, sparse_history=False, sparse_tangent=False,
                                reuse_constant_tangent=False)
     for st in (opt, ref):
