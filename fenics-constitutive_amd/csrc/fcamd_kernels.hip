@@ -186,6 +186,20 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_lowdim_kernel(const EvalAr
     }
 }
 
+#ifndef FCAMD_UX_TRIPS
+#define FCAMD_UX_TRIPS 4
+#endif
+// Uniaxial constraints: a plain element-wise stream over the whole 64-point tiles (kernels/law_lowdim.h: stream_uniaxial);
+// the ragged rest goes to evaluate_lowdim_tail_kernel<LAW, 1>.  NOT persistent: a workgroup takes kBlock * FCAMD_UX_TRIPS
+// consecutive pairs of points and ends, so the resident workgroups sweep the arrays as one front (measured on
+// 1e8 points, one process, identical buffers: a grid-stride loop over 16k workgroups 0.536 ms, over 64k 0.496 ms).
+template <int LAW, bool NT>
+__global__ void __launch_bounds__(kBlock, 8) evaluate_uniaxial_kernel(const EvalArgs a) {
+    const long long npairs = (a.n / kWave) * (kWave / 2);
+    const long long lo = (long long)blockIdx.x * (kBlock * FCAMD_UX_TRIPS), hi = lo + kBlock * FCAMD_UX_TRIPS;
+    stream_uniaxial<LAW, NT>(a, hi < npairs ? hi : npairs, lo + threadIdx.x, kBlock);
+}
+
 template <int LAW, int DIMS>
 __global__ void __launch_bounds__(kWave) evaluate_lowdim_tail_kernel(const EvalArgs a) {
     __shared__ __attribute__((aligned(16))) Tables T;
@@ -312,8 +326,13 @@ static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream)
 
 template <int LAW, int DIMS>
 static hipError_t launch_lowdim(const EvalArgs& args, int grid, hipStream_t stream) {
-    if (args.n >= kWave)
-        hipLaunchKernelGGL((evaluate_lowdim_kernel<LAW, DIMS, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+    if (args.n >= kWave) {
+        if constexpr (DIMS == 1) {  // one workgroup per kBlock * FCAMD_UX_TRIPS pairs: `grid` does not apply
+            const long long npairs = (args.n / kWave) * (kWave / 2), per = kBlock * FCAMD_UX_TRIPS;
+            hipLaunchKernelGGL((evaluate_uniaxial_kernel<LAW, true>), dim3((unsigned)((npairs + per - 1) / per)), dim3(kBlock), 0, stream, args);
+        } else
+            hipLaunchKernelGGL((evaluate_lowdim_kernel<LAW, DIMS, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+    }
     if (args.n % kWave != 0)
         hipLaunchKernelGGL((evaluate_lowdim_tail_kernel<LAW, DIMS>), dim3(1), dim3(kWave), 0, stream, args);
     return hipGetLastError();

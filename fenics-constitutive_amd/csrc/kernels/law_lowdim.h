@@ -71,6 +71,48 @@ __device__ __forceinline__ void tangent_const_n(const double* tab, double* dst, 
     }
 }
 
+// One point: stress and the two history fields advanced by the strain increment e.  A, B = the law's tables (LDS for the
+// tiled kernels, kernel arguments for the uniaxial stream).
+template <int LAW, int DIMS>
+__device__ __forceinline__ void lowdim_point(const Scalars& sc, const double* A, const double* B,
+                                             const double (&e)[LowDim<DIMS>::SD], double (&s)[LowDim<DIMS>::SD],
+                                             double (&ev)[LowDim<DIMS>::SD], double (&en)[LowDim<DIMS>::SD]) {
+    constexpr int SD = LowDim<DIMS>::SD;
+    double y[SD];
+    if constexpr (LAW == LAW_LE) {
+        row_times_matrix_fma_n<SD>(e, A, y);
+#pragma unroll
+        for (int i = 0; i < SD; ++i) s[i] = s[i] + y[i];
+    } else {
+        double dv[SD];
+        const double inv_factor = sc.s[1], cA = sc.s[2], cB = sc.s[3], c2mu = sc.s[4];
+        if constexpr (LAW == LAW_MAXWELL) {
+            double x[SD];
+#pragma unroll
+            for (int i = 0; i < SD; ++i) x[i] = cA * (en[i] + e[i]);
+            row_times_matrix_fma_n<SD>(x, A, y);
+#pragma unroll
+            for (int i = 0; i < SD; ++i) dv[i] = inv_factor * (y[i] - cB * ev[i]);
+            row_times_matrix_fma_n<SD>(e, B, y);
+        } else {
+            const double cC = sc.s[5], cD = sc.s[6];
+            double tr = e[0];  // np.sum(strain_increment[:, :gdim], axis=1), gdim = DIMS
+            if constexpr (DIMS == 2) tr = e[0] + e[1];
+            const double ctr = cD * tr;
+#pragma unroll
+            for (int i = 0; i < SD; ++i)
+                dv[i] = inv_factor * (((cA * s[i] - cB * ev[i]) + cC * e[i]) + ctr * sc.s[8 + i]);
+            row_times_matrix_fma_n<SD>(e, A, y);
+        }
+#pragma unroll
+        for (int i = 0; i < SD; ++i) {
+            s[i] = s[i] + (y[i] - c2mu * dv[i]);
+            ev[i] = ev[i] + dv[i];
+            en[i] = en[i] + e[i];
+        }
+    }
+}
+
 template <int LAW, int DIMS, bool FULL, bool NT>
 __device__ __forceinline__ void tile_lowdim(const EvalArgs& a, const Tables* T, double* region,
                                             long long p0, int npts, int lane) {
@@ -85,47 +127,70 @@ __device__ __forceinline__ void tile_lowdim(const EvalArgs& a, const Tables* T, 
         tile_load<SD, FULL, NT>(cn, a.h1_in + p0 * SD, npts * SD, lane);
     }
     if (a.tangent) tangent_const_n<SD, FULL, NT>(T->c, a.tangent + p0 * SD * SD, npts, lane);
-    double g[GD2], s[SD], e[SD], y[SD];
+    double g[GD2], s[SD], e[SD], ev[SD], en[SD];
     transpose_in<GD2>(cg, region, lane, g);
     transpose_in<SD>(cs, region, lane, s);
     strain_lowdim<DIMS>(g, a.sc.s[0], e);
-    if constexpr (LAW == LAW_LE) {
-        row_times_matrix_fma_n<SD>(e, T->a, y);
-#pragma unroll
-        for (int i = 0; i < SD; ++i) s[i] = s[i] + y[i];
-        transpose_out<SD, FULL, NT>(s, region, lane, a.stress_out + p0 * SD, npts * SD);
-    } else {
-        double ev[SD], en[SD], dv[SD];
+    if constexpr (HIST) {
         transpose_in<SD>(cv, region, lane, ev);
         transpose_in<SD>(cn, region, lane, en);
-        const double inv_factor = a.sc.s[1], cA = a.sc.s[2], cB = a.sc.s[3], c2mu = a.sc.s[4];
-        if constexpr (LAW == LAW_MAXWELL) {
-            double x[SD];
-#pragma unroll
-            for (int i = 0; i < SD; ++i) x[i] = cA * (en[i] + e[i]);
-            row_times_matrix_fma_n<SD>(x, T->a, y);
-#pragma unroll
-            for (int i = 0; i < SD; ++i) dv[i] = inv_factor * (y[i] - cB * ev[i]);
-            row_times_matrix_fma_n<SD>(e, T->b, y);
-        } else {
-            const double cC = a.sc.s[5], cD = a.sc.s[6];
-            double tr = e[0];  // np.sum(strain_increment[:, :gdim], axis=1), gdim = DIMS
-            if constexpr (DIMS == 2) tr = e[0] + e[1];
-            const double ctr = cD * tr;
-#pragma unroll
-            for (int i = 0; i < SD; ++i)
-                dv[i] = inv_factor * (((cA * s[i] - cB * ev[i]) + cC * e[i]) + ctr * a.sc.s[8 + i]);
-            row_times_matrix_fma_n<SD>(e, T->a, y);
-        }
-#pragma unroll
-        for (int i = 0; i < SD; ++i) {
-            s[i] = s[i] + (y[i] - c2mu * dv[i]);
-            ev[i] = ev[i] + dv[i];
-            en[i] = en[i] + e[i];
-        }
-        transpose_out<SD, FULL, NT>(s, region, lane, a.stress_out + p0 * SD, npts * SD);
+    }
+    lowdim_point<LAW, DIMS>(a.sc, T->a, T->b, e, s, ev, en);
+    transpose_out<SD, FULL, NT>(s, region, lane, a.stress_out + p0 * SD, npts * SD);
+    if constexpr (HIST) {
         transpose_out<SD, FULL, NT>(ev, region, lane, a.h0_out + p0 * SD, npts * SD);
         transpose_out<SD, FULL, NT>(en, region, lane, a.h1_out + p0 * SD, npts * SD);
+    }
+}
+
+// Uniaxial constraints are one double per point in every array: AoS = SoA, no transposition.  A lane takes PAIRS of
+// consecutive points (16-byte accesses), two pairs per trip (2 KiB per wave and array in flight); the arithmetic is
+// lowdim_point<LAW, 1>, the same instructions as the tiled form.
+template <int LAW, bool NT>
+__device__ __forceinline__ void pair_uniaxial(const EvalArgs& a, long long q, const d2 g, const d2 s0, const d2 v0, const d2 n0) {
+    double e[1], s[1], ev[1], en[1];
+    d2 so, vo, no;
+    e[0] = g.x; s[0] = s0.x; ev[0] = v0.x; en[0] = n0.x;
+    lowdim_point<LAW, 1>(a.sc, a.tb.a, a.tb.b, e, s, ev, en);
+    so.x = s[0]; vo.x = ev[0]; no.x = en[0];
+    e[0] = g.y; s[0] = s0.y; ev[0] = v0.y; en[0] = n0.y;
+    lowdim_point<LAW, 1>(a.sc, a.tb.a, a.tb.b, e, s, ev, en);
+    so.y = s[0]; vo.y = ev[0]; no.y = en[0];
+    store16<NT>(a.stress_out + 2 * q, so);
+    if constexpr (LAW != LAW_LE) {
+        store16<NT>(a.h0_out + 2 * q, vo);
+        store16<NT>(a.h1_out + 2 * q, no);
+    }
+    if (a.tangent) {
+        d2 t;
+        t.x = a.tb.c[0];
+        t.y = a.tb.c[0];
+        store16<NT>(a.tangent + 2 * q, t);
+    }
+}
+
+template <int LAW, bool NT>
+__device__ __forceinline__ void stream_uniaxial(const EvalArgs& a, long long npairs, long long first, long long stride) {
+    constexpr bool HIST = (LAW != LAW_LE);
+    const d2 z = {0.0, 0.0};
+    long long q = first;
+    for (; q + stride < npairs; q += 2 * stride) {
+        const long long r = q + stride;
+        const d2 g0 = load16<NT>(a.grad + 2 * q), g1 = load16<NT>(a.grad + 2 * r);
+        const d2 s0 = load16<NT>(a.stress_in + 2 * q), s1 = load16<NT>(a.stress_in + 2 * r);
+        d2 v0 = z, v1 = z, n0 = z, n1 = z;
+        if constexpr (HIST) {
+            v0 = load16<NT>(a.h0_in + 2 * q), v1 = load16<NT>(a.h0_in + 2 * r);
+            n0 = load16<NT>(a.h1_in + 2 * q), n1 = load16<NT>(a.h1_in + 2 * r);
+        }
+        pair_uniaxial<LAW, NT>(a, q, g0, s0, v0, n0);
+        pair_uniaxial<LAW, NT>(a, r, g1, s1, v1, n1);
+    }
+    if (q < npairs) {
+        const d2 g0 = load16<NT>(a.grad + 2 * q), s0 = load16<NT>(a.stress_in + 2 * q);
+        d2 v0 = z, n0 = z;
+        if constexpr (HIST) v0 = load16<NT>(a.h0_in + 2 * q), n0 = load16<NT>(a.h1_in + 2 * q);
+        pair_uniaxial<LAW, NT>(a, q, g0, s0, v0, n0);
     }
 }
 

@@ -3,7 +3,8 @@
     python tools/ab_lib.py libA.so libB.so [n ...]
 VonMises3D mixed workload, committed->trial evaluate.  AB_SPARSE=1: sparse trial-history protocol
 (fcamd_evaluate_device_ex with history_mask, VonMises3D only); AB_ZONED=1: plastic points in contiguous
-4096-point zones instead of a random mixture; AB_SCALE=1e-2 / 1e-4: uniform strain scale (all plastic / all elastic)."""
+4096-point zones instead of a random mixture; AB_SCALE=1e-2 / 1e-4: uniform strain scale (all plastic / all elastic);
+AB_CONSTRAINT=1..4 (le / maxwell): a low-dimensional constraint on the first entries of the same arrays."""
 import ctypes as C
 import sys
 
@@ -18,6 +19,7 @@ sizes = [int(float(x)) for x in sys.argv[1:] if not x.endswith('.so')] or [1_000
 LAW = os.environ.get("AB_LAW", "vm")  # vm | le | maxwell
 SPARSE = os.environ.get("AB_SPARSE", "0") == "1"
 ZONED = os.environ.get("AB_ZONED", "0") == "1"
+CONSTRAINT = int(os.environ.get("AB_CONSTRAINT", "5"))
 MODEL = {"vm": (2, [175000.0, 80769.0, 1200.0, 2500.0, 200.0], 2), "le": (1, [42.0, 0.3], 0), "maxwell": (3, [42.0, 10.0, 10.0, 0.2], 2)}[LAW]
 dev = torch.device("cuda", 0)
 torch.zeros(1, device=dev)
@@ -32,7 +34,7 @@ class Lib:
         assert self.l.fcamd_context_create(0, stream, C.byref(self.ctx)) == 0
         # torch's default stream has handle 0 = "own a private stream" for create(); bind it explicitly
         assert self.l.fcamd_context_set_stream(self.ctx, stream) == 0
-        assert self.l.fcamd_model_create(self.ctx, MODEL[0], 5, P, len(MODEL[1]), C.byref(self.m)) == 0
+        assert self.l.fcamd_model_create(self.ctx, MODEL[0], CONSTRAINT, P, len(MODEL[1]), C.byref(self.m)) == 0
         self.l.fcamd_evaluate_device_ex.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs)]
         self.mask = None
 
