@@ -5,8 +5,8 @@ Every row is one evaluate kernel launch per step on device-resident synthetic ar
 ALGORITHMIC bytes per point -- the traffic the call's interface mandates -- stated here and in DESIGN.md 3:
 
   row                                reference                                  bytes per point
-  indexed_runs / indexed_permuted    solver/maps.py:82-123 folded into the      LinearElasticity 456 + 4 (the int32 parent row)
-                                     kernel (f2), LinearElasticityModel
+  indexed_runs / indexed_scattered_  solver/maps.py:82-123 folded into the      LinearElasticity 456 + 4 (the int32 parent row)
+  cells / indexed_permuted           kernel (f2), LinearElasticityModel
   wrapped_plane_strain_von_mises     models/utils.py:332-412 around VonMises3D  grad 32 + stress 32 R + 32 W + tangent 128 W + cached
                                      (f3, fused wrapper kernel)                 3-D stress 48 R + 48 W + alpha 8 R = 328 elastic;
                                                                                 + eps_n 48 R + 48 W + alpha 8 W = 432 plastic
@@ -86,17 +86,22 @@ class IndexedRow(FRow):
 
     reference = "solver/maps.py:82-123, solver/_lawonsubmesh.py:58-95"
 
-    def __init__(self, n, device, permuted):
+    def __init__(self, n, device, order):
         import fenics_constitutive_amd as fc
 
         n_sub = max(64, (n // 2 // 8192) * 8192)
         super().__init__(n_sub, device)
         t = self.torch
-        self.name = "indexed_permuted" if permuted else "indexed_runs"
+        self.name = "indexed_" + order
         self.n_parent = 2 * n_sub
         self.law = fc.LinearElasticityModel(LE_P, fc.StressStrainConstraint.FULL)
-        if permuted:  # cells of this material scattered all over the parent numbering: every lane its own 48-byte / 288-byte row
+        if order == "permuted":  # a map no mesh produces: every lane its own 48-byte / 288-byte row anywhere in the parent arrays
             rows = t.randperm(self.n_parent, device=device, generator=self.gen)[:n_sub]
+        elif order == "scattered_cells":
+            # what build_subspace_map (maps.py:125-177) yields for a material whose cells are sprinkled over the mesh: ascending cells,
+            # the 4 quadrature points of a cell consecutive (V.dofmap.cell_dofs), every other cell at random belongs to the material
+            cells = t.randperm(self.n_parent // 4, device=device, generator=self.gen)[: n_sub // 4].sort().values
+            rows = (cells[:, None] * 4 + t.arange(4, device=device)[None, :]).reshape(-1)
         else:  # cells numbered in runs (blocks of 4096 points, every other block is this material's): whole tiles are consecutive rows
             blk = t.arange(n_sub // 4096, device=device) * 2
             rows = (blk[:, None] * 4096 + t.arange(4096, device=device)[None, :]).reshape(-1)
@@ -105,8 +110,10 @@ class IndexedRow(FRow):
         self.stress_prev = self.randn(6 * self.n_parent, 1.0)
         self.stress = t.empty_like(self.stress_prev)
         self.tangent = t.empty(36 * self.n_parent, **self.f)
+        how = {"permuted": "a random permutation of the parent rows", "runs": "runs of 4096 consecutive parent rows",
+               "scattered_cells": "ascending cells of 4 consecutive rows, half of the cells at random"}[order]
         self.text = (f"{self.name}: LinearElasticityModel on {n_sub} points whose stress / tangent rows live in PARENT arrays of {self.n_parent} rows "
-                     f"({'a random permutation of the parent rows' if permuted else 'runs of 4096 consecutive parent rows'}), committed -> trial")
+                     f"({how}), committed -> trial")
 
     def launch(self):
         self.law.evaluate_indexed(0.0, 1.0, self.grad, self.stress_prev, self.stress, self.tangent, self.rows, None, None)
@@ -239,8 +246,9 @@ class ResidentSparseTangentRow(FRow):
 
 
 FROWS = {
-    "indexed_runs": lambda n, d: IndexedRow(n, d, permuted=False),
-    "indexed_permuted": lambda n, d: IndexedRow(n, d, permuted=True),
+    "indexed_runs": lambda n, d: IndexedRow(n, d, "runs"),
+    "indexed_scattered_cells": lambda n, d: IndexedRow(n, d, "scattered_cells"),
+    "indexed_permuted": lambda n, d: IndexedRow(n, d, "permuted"),
     "wrapped_plane_strain_von_mises": WrappedRow,
     "lowdim_le_plane_strain": lambda n, d: LowDimRow(n, d, "le", "PLANE_STRAIN"),
     "lowdim_le_uniaxial_strain": lambda n, d: LowDimRow(n, d, "le", "UNIAXIAL_STRAIN"),
@@ -248,7 +256,7 @@ FROWS = {
     "lowdim_maxwell_uniaxial_stress": lambda n, d: LowDimRow(n, d, "maxwell", "UNIAXIAL_STRESS"),
     "resident_sparse_tangent": ResidentSparseTangentRow,
 }
-SURVEY_ROW = {"indexed_runs": "f2", "indexed_permuted": "f2", "wrapped_plane_strain_von_mises": "f3", "lowdim_le_plane_strain": "f3",
+SURVEY_ROW = {"indexed_runs": "f2", "indexed_scattered_cells": "f2", "indexed_permuted": "f2", "wrapped_plane_strain_von_mises": "f3", "lowdim_le_plane_strain": "f3",
               "lowdim_le_uniaxial_strain": "f3", "lowdim_maxwell_plane_strain": "f3", "lowdim_maxwell_uniaxial_stress": "f3",
               "resident_sparse_tangent": "f1"}
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
         hr.request(a, w, p0, npts, lane, touched, hist_in_place);
         hr.gather(region, lane, mask, d6);
     }
-    sr.put(sb, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts, rows_lds);
     if (split) {
         hr.store(a, p0, npts, lane, mask, hist_in_place, region, h[0], d6);
     } else {

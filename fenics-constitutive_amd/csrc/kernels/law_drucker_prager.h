@@ -279,7 +279,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
             hr.request(a, w, p0, npts, lane, touched, hist_in_place);
             hr.gather(region, lane, 0ull, d6);
         }
-        sr.put(sb, region, lane, t.sig1, p0, npts);
+        sr.put(sb, region, lane, t.sig1, p0, npts, rows_lds);
         if (split) {
             hr.store(a, p0, npts, lane, 0ull, hist_in_place, region, h[0], d6);
         } else {
@@ -311,7 +311,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
         hr.request(a, w, p0, npts, lane, touched, hist_in_place);
         hr.gather(region, lane, mask, d6);
     }
-    sr.put(sb, region, lane, t.sig1, p0, npts);
+    sr.put(sb, region, lane, t.sig1, p0, npts, rows_lds);
     if (split) {
         hr.store(a, p0, npts, lane, mask, hist_in_place, region, h[0], d6);
     } else {

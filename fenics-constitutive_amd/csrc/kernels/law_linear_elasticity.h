@@ -32,7 +32,7 @@ __device__ __forceinline__ void tile_linear_elasticity(const EvalArgs& a, const 
     row_times_matrix_fma(e, T->a, ds);
 #pragma unroll
     for (int i = 0; i < 6; ++i) s[i] = s[i] + ds[i];
-    sr.put(sb, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts, rows_lds);
 }
 
 // --- comfe-rs LinearElasticity3D: sigma += C . d_eps (column axpy, no FMA) ---------------
@@ -58,7 +58,7 @@ __device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const StressBas
         for (int j = 1; j < 6; ++j) acc = T->a[6 * i + j] * e[j] + acc;
         s[i] = s[i] + acc;
     }
-    sr.put(sb, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts, rows_lds);
 }
 
 // LinearElasticityModel behind the wrappers (what the reference's own tests wrap, test_elasticity.py:206,278)

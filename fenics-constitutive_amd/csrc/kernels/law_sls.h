@@ -59,7 +59,7 @@ __device__ __forceinline__ void tile_sls(const EvalArgs& a, const StressBases& s
         ev[i] = ev[i] + dv[i];
         en[i] = en[i] + e[i];
     }
-    sr.put(sb, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts, rows_lds);
     transpose_out<6, FULL, NT>(ev, region, lane, a.h0_out + p0 * 6, npts * 6);
     transpose_out<6, FULL, NT>(en, region, lane, a.h1_out + p0 * 6, npts * 6);
 }

@@ -195,7 +195,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     }
 
     vm_stress(a.sc, tr, rm, s);
-    sr.put(sb, region, lane, s, p0, npts);
+    sr.put(sb, region, lane, s, p0, npts, rows_lds);
 
     // history: eps_n += gamma N ; alpha += sqrt(2/3) gamma
     if constexpr (packed) {

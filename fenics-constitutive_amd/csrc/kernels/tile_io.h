@@ -203,52 +203,55 @@ struct StressBases {
     double* sout2 = nullptr;  // second copy of the stress rows (EvalArgs::stress_out2; contiguous tiles only)
 };
 
+// address of stress chunk q (= 16 bytes) of an indexed tile: chunk q belongs to point q / 3
+__device__ __forceinline__ long long stress_chunk_offset(int q, const int* rows_lds) {
+    const int p = q / 3;
+    return (long long)rows_lds[p] * 6 + 2 * (q - 3 * p);
+}
+
 template <bool IDX, bool FULL, bool NT>
 struct StressRows {
     Chunks<6> c;
-    long long row = 0;
 
     __device__ __forceinline__ void load(const EvalArgs& a, const StressBases& sb, long long p0, int npts, int lane,
                                          int* rows_lds) {
         if constexpr (IDX) {
-            const bool live = FULL || lane < npts;
-            row = live ? (long long)a.rows[p0 + lane] : 0ll;
-            rows_lds[lane] = (int)row;
+            // chunk-major like the contiguous tile: lane l moves chunks l, l + 64, l + 128 of the tile's VIRTUAL image, three
+            // neighbouring lanes one 48-byte row, the rows of a cell (consecutive parent rows, maps.py:159-161) one contiguous
+            // piece -- every parent line is requested by one instruction (round 4; before: every lane its own row, three
+            // instructions over the same lines: ascending cells of 4 rows 5.06 ms at 5e7 points)
+            rows_lds[lane] = (FULL || lane < npts) ? a.rows[p0 + lane] : 0;
+            wave_sync();
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
+                const int q = k * kWave + lane;
                 d2 z;
                 z.x = 0.0;
                 z.y = 0.0;
-                c.v[k] = live ? load16<NT>(sb.sin + row * 6 + 2 * k) : z;
+                c.v[k] = (FULL || q < 3 * npts) ? load16<NT>(sb.sin + stress_chunk_offset(q, rows_lds)) : z;
             }
         } else {
             tile_load<6, FULL, NT>(c, sb.sin + p0 * 6, npts * 6, lane);
         }
     }
-    __device__ __forceinline__ void get(double* region, int lane, double (&s)[6]) {
+    __device__ __forceinline__ void get(double* region, int lane, double (&s)[6]) { transpose_in<6>(c, region, lane, s); }
+    __device__ __forceinline__ void put(const StressBases& sb, double* region, int lane, const double (&s)[6],
+                                        long long p0, int npts, const int* rows_lds = nullptr) {
         if constexpr (IDX) {
+            lds_put_point<6>(region, lane, s);
+            wave_sync();
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                s[2 * k] = c.v[k].x;
-                s[2 * k + 1] = c.v[k].y;
-            }
-        } else {
-            transpose_in<6>(c, region, lane, s);
-        }
-    }
-    __device__ __forceinline__ void put(const StressBases& sb, double* region, int lane, const double (&s)[6],
-                                        long long p0, int npts) {
-        if constexpr (IDX) {
-            if (FULL || lane < npts) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    d2 v;
-                    v.x = s[2 * k];
-                    v.y = s[2 * k + 1];
-                    store16<NT>(sb.sout + row * 6 + 2 * k, v);
-                    if (sb.sout2 != nullptr) store16<NT>(sb.sout2 + row * 6 + 2 * k, v);
+                int q = k * kWave + lane;
+                asm volatile("" : "+v"(q));  // recomputed here, not kept alive since load(): registers
+                if (FULL || q < 3 * npts) {
+                    const d2 v = reinterpret_cast<const d2*>(region)[q];
+                    const long long o = stress_chunk_offset(q, rows_lds);
+                    store16<NT>(sb.sout + o, v);
+                    if (sb.sout2 != nullptr) store16<NT>(sb.sout2 + o, v);
                 }
             }
+            wave_sync();
         } else if (sb.sout2 == nullptr) {
             transpose_out<6, FULL, NT>(s, region, lane, sb.sout + p0 * 6, npts * 6);
         } else {  // resident state on the device + the host assembler's array: one LDS image, two streams
