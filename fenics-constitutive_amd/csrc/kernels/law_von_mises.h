@@ -278,7 +278,9 @@ __device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const 
 #pragma unroll
         for (int i = 0; i < 6; ++i) ep[i] = ep[i] + rm.gamma * rm.N[i];
         er.store(a.h0_out, p0, npts, lane, region, ep);
-        if (live) a.h1_out[p0 + lane] = alpha_n + a.sc.s[3] * rm.gamma;
+        // alpha, in place: the 32-byte sectors that hold a plastic point (the others keep their value; whole sectors so that no
+        // partial sector is written: -2 % on identical buffers at 6 % plastic points against the whole tile's 512 bytes)
+        if (live && ((mask >> (lane & ~3)) & 0xFull) != 0ull) a.h1_out[p0 + lane] = alpha_n + a.sc.s[3] * rm.gamma;
     }
     if (a.tangent) {
         double B, C;

@@ -13,13 +13,18 @@ torch = pytest.importorskip("torch")
 FULL_KINDS = ["linear_elasticity", "von_mises_3d", "spring_maxwell", "spring_kelvin", "comfe_linear_elasticity", "comfe_mises_plasticity"]
 
 
-@pytest.mark.parametrize("order", ["sorted", "random"])
+@pytest.mark.parametrize("order", ["sorted", "random", "cells"])
 @pytest.mark.parametrize("n_sub", [1, 63, 64, 65, 1000, 20_011])
 @pytest.mark.parametrize("kind", FULL_KINDS)
 def test_indexed_equals_gather_evaluate_scatter(kind, n_sub, order):
     rng = np.random.default_rng(n_sub + 3)
     n_parent = 2 * n_sub + 17
-    rows = rng.choice(n_parent, size=n_sub, replace=False)
+    if order == "cells":  # what build_subspace_map yields (maps.py:159-161): ascending cells, 4 consecutive rows each, last one ragged
+        n_parent = 8 * ((n_sub + 3) // 4) + 17
+        cells = np.sort(rng.choice(n_parent // 4, size=(n_sub + 3) // 4, replace=False))
+        rows = (cells[:, None] * 4 + np.arange(4)[None, :]).reshape(-1)[:n_sub]
+    else:
+        rows = rng.choice(n_parent, size=n_sub, replace=False)
     if order == "sorted":
         rows.sort()
     p, g, s_sub, h = random_case(kind, n_sub, seed=n_sub + 5)
