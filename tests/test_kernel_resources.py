@@ -21,7 +21,7 @@ def rows():
 def test_all_kernels_reported(rows):
     names = [r["name"] for r in rows]
     assert len(rows) >= 70, names
-    for must in ("evaluate_kernel<2, true, false, 2>", "evaluate_kernel<3, true, true, 0>", "stream_copy_kernel", "strain_kernel"):
+    for must in ("evaluate_kernel<2, true, false, 2>", "evaluate_kernel<3, true, true, 0>", "evaluate_uniaxial_kernel<1, true>", "stream_copy_kernel", "strain_kernel"):
         assert any(must in n for n in names), must
     for r in rows:
         for key in ("vgpr", "scratch", "occupancy", "vgpr_spill"):
