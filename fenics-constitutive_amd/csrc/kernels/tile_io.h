@@ -189,9 +189,9 @@ __device__ __forceinline__ void transpose_out(const double (&x)[NC], double* reg
 //   IDX = false: the law's own arrays, point p0 + lane at row p0 + lane (contiguous tile).
 //   IDX = true : rows of PARENT arrays, point p0 + lane at row a.rows[p0 + lane] -- the submesh
 //                gather/scatter of the reference (solver/maps.py:82-123, "parent_array[parent] =
-//                sub_array[sub]") folded into the kernel's addressing: every lane loads and stores
-//                its own 48-byte stress row, and the tangent writers look the row of each chunk's
-//                point up in a per-wave LDS table.
+//                sub_array[sub]") folded into the kernel's addressing: stress and tangent chunks keep
+//                their chunk-major lane assignment and look the row of their point up in a per-wave
+//                LDS table of the tile's 64 parent rows.
 // ---------------------------------------------------------------------------------------
 // Base pointers of the stress / tangent arrays as seen by one tile.  Normally the kernel arguments;
 // for a tile of the indexed kernel whose 64 parent rows are consecutive they are shifted by
@@ -236,7 +236,7 @@ struct StressRows {
     }
     __device__ __forceinline__ void get(double* region, int lane, double (&s)[6]) { transpose_in<6>(c, region, lane, s); }
     __device__ __forceinline__ void put(const StressBases& sb, double* region, int lane, const double (&s)[6],
-                                        long long p0, int npts, const int* rows_lds = nullptr) {
+                                        long long p0, int npts, const int* rows_lds) {
         if constexpr (IDX) {
             lds_put_point<6>(region, lane, s);
             wave_sync();
