@@ -22,10 +22,17 @@ namespace fcamd {
 // load(): requests the committed run (as early as the tile knows that it is touched, so that the request is in flight with the
 // law's arithmetic); gather(): the committed row of every lane's point, BEFORE the tile issues its first store; scatter():
 // rows_out run <- rows + d at the plastic points, records ever_trial.
+//
+// Rows inside the run (load_rows()): where the run is long and few of its rows are touched (every point has yielded once, a
+// scattered few yield now) moving the whole run costs more than the isolated rows of the plain layout (measured: 1.13 x).  If
+// the trial run has the committed run's layout (same EVER word: nothing grew since the last commit) and no new row appears,
+// the untouched rows of the trial run already hold the committed values -- the sparse protocol's invariant, row by row -- and
+// only the touched rows move, chunk-masked like MaskedRows but through the rank of a row in the run.
 template <bool FULL, bool NT>
 struct PackedRows {
     Chunks<6> c;
     unsigned long long ever_in = 0ull;
+    unsigned long long live = ~0ull;  // rows of the RUN (rank space) that move; all ones = the whole run
 
     // 16-byte chunks of a run of `rows` rows, rounded up to whole 128-byte lines (a slot is 24 lines; the ragged last tile,
     // whose slot ends with the array: the exact run; FCAMD_PACKED_LINE=0: always exact, the experiment knob)
@@ -50,6 +57,25 @@ struct PackedRows {
             v.x = 0.0;
             v.y = 0.0;
             if (q < nq) v = load16<NT>(rows_in + p0 * 6 + 2 * q);
+            c.v[k] = v;
+        }
+    }
+    // requests only the rows of the run that belong to the points in `touched` (a subset of ever_in); uses the wave's LDS region
+    __device__ __forceinline__ void load_rows(const double* rows_in, long long p0, int lane, unsigned long long touched, double* region) {
+        int* flag = reinterpret_cast<int*>(region);
+        const int rows = (int)__popcll(ever_in);
+        const int rank_in = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ever_in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ever_in, 0u));
+        if (((ever_in >> lane) & 1ull) != 0ull) flag[rank_in] = (int)((touched >> lane) & 1ull);
+        wave_sync();
+        live = __ballot(lane < rows && flag[lane] != 0);  // the rank-space image of `touched`
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int q = k * kWave + lane;
+            d2 v;
+            v.x = 0.0;
+            v.y = 0.0;
+            if (((live >> (q / 3)) & 1ull) != 0ull) v = load16<NT>(rows_in + p0 * 6 + 2 * q);
             c.v[k] = v;
         }
     }
@@ -82,10 +108,10 @@ struct PackedRows {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int q = k * kWave + lane;
-            if (q < nq_out) store16<NT>(rows_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+            if (q < nq_out && ((live >> (q / 3)) & 1ull) != 0ull) store16<NT>(rows_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
         }
         wave_sync();
-        if (lane == 0) a.emask_out[p0 >> 6] = ever_out;
+        if (lane == 0 && live == ~0ull) a.emask_out[p0 >> 6] = ever_out;  // rows inside the run: the trial word is ever_in already
     }
 };
 

@@ -96,6 +96,16 @@ __device__ __forceinline__ void vm_tangent_coefficients(const Scalars& sc, const
 // tables:  a = ka*xioi, b = xpp
 // HIST: 0 = the caller's arrays as they are (in place or out of place), 1 = sparse trial history (a.hmask),
 //       2 = sparse protocol on the packed plastic-strain layout (history_rows.h: PackedRows)
+// rows inside a packed run (PackedRows::load_rows) when at most 1 / kPackedRowsDiv of the run's rows are touched
+#ifndef FCAMD_PACKED_ROWS_DIV
+#define FCAMD_PACKED_ROWS_DIV 3
+#endif
+constexpr int kPackedRowsDiv = FCAMD_PACKED_ROWS_DIV;
+#ifndef FCAMD_PACKED_ROWS_MIN_RUN
+#define FCAMD_PACKED_ROWS_MIN_RUN 32
+#endif
+constexpr int kPackedRowsMinRun = FCAMD_PACKED_ROWS_MIN_RUN;  // ... of a run of at least this many rows
+
 template <bool IDX, int HIST, bool FULL, bool NT>
 __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                                int* rows_lds, long long p0, int npts, int lane,
@@ -107,7 +117,11 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     unsigned long long m_old = 0ull;
     PackedRows<FULL, NT> pk;
     if constexpr (sparse) m_old = a.hmask[p0 >> 6];
-    if constexpr (packed) pk.ever_in = a.emask_in[p0 >> 6];
+    unsigned long long ever_trial = 0ull;
+    if constexpr (packed) {
+        pk.ever_in = a.emask_in[p0 >> 6];
+        ever_trial = a.emask_out[p0 >> 6];
+    }
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
     tile_load<9, FULL, NT>(cg, a.grad + p0 * 9, npts * 9, lane);
@@ -117,7 +131,11 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     const bool hist_in_place = (a.h0_in == a.h0_out) && (a.h1_in == a.h1_out);
     // packed layout: a tile that was plastic at the previous evaluate is touched whatever happens now (new values or stale
     // rows) -- its committed run is requested right away, long before the ballot
-    const bool early = packed && m_old != 0ull;
+    // ... unless few rows of a long run were touched last time and the trial run has the committed layout: then few will be
+    // touched now, and they are requested alone after the ballot (PackedRows::load_rows)
+    const int run_rows = (int)__popcll(pk.ever_in);
+    const bool same_layout = FULL && ever_trial == pk.ever_in && run_rows >= kPackedRowsMinRun;  // (short runs: the whole run is 1-6 lines)
+    const bool early = packed && m_old != 0ull && !(same_layout && kPackedRowsDiv * (int)__popcll(m_old) <= run_rows);
     if constexpr (packed) {
         if (early) pk.load(a.h0_in, p0, lane);
     }
@@ -162,7 +180,12 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
         for (int k = 0; k < 3; ++k) row_live[k] = ((eps_mask >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
     }
     if constexpr (packed) {
-        if (!early && touch_eps) pk.load(a.h0_in, p0, lane);  // a tile that turns plastic now: the one late request
+        if (!early && touch_eps) {  // a tile that turns plastic now, or one with few touched rows in a long run: the late request
+            if (same_layout && (mask & ~pk.ever_in) == 0ull && kPackedRowsDiv * (int)__popcll(need_mask) <= run_rows)
+                pk.load_rows(a.h0_in, p0, lane, need_mask, region);
+            else
+                pk.load(a.h0_in, p0, lane);
+        }
     } else if (touch_eps) {
         if (masked) {
 #pragma unroll
