@@ -28,6 +28,15 @@ namespace fcamd {
 // the trial run has the committed run's layout (same EVER word: nothing grew since the last commit) and no new row appears,
 // the untouched rows of the trial run already hold the committed values -- the sparse protocol's invariant, row by row -- and
 // only the touched rows move, chunk-masked like MaskedRows but through the rank of a row in the run.
+// rows inside a packed run (load_rows) when the run has at least kPackedRowsMinRun rows and at most 1 / kPackedRowsDiv of them are touched
+#ifndef FCAMD_PACKED_ROWS_DIV
+#define FCAMD_PACKED_ROWS_DIV 3
+#endif
+#ifndef FCAMD_PACKED_ROWS_MIN_RUN
+#define FCAMD_PACKED_ROWS_MIN_RUN 32
+#endif
+constexpr int kPackedRowsDiv = FCAMD_PACKED_ROWS_DIV, kPackedRowsMinRun = FCAMD_PACKED_ROWS_MIN_RUN;
+
 template <bool FULL, bool NT>
 struct PackedRows {
     Chunks<6> c;
@@ -175,13 +184,16 @@ struct MaskedRows {
 // ballot.  The new ballot is recorded at the END of the tile (sparse_record): a store issued earlier would sit, in the wave's one
 // vmcnt, in front of the row loads that follow it.
 struct SparseWords {
-    unsigned long long m_old = 0ull, ever = 0ull;
+    unsigned long long m_old = 0ull, ever = 0ull, ever_trial = 0ull;
 };
 __device__ __forceinline__ SparseWords sparse_words(const EvalArgs& a, long long p0) {
     SparseWords w;
     if (a.hmask != nullptr) {
         w.m_old = a.hmask[p0 >> 6];
-        if ((a.flags & kFlagPackedHistory) != 0) w.ever = a.emask_in[p0 >> 6];
+        if ((a.flags & kFlagPackedHistory) != 0) {
+            w.ever = a.emask_in[p0 >> 6];
+            w.ever_trial = a.emask_out[p0 >> 6];  // the trial run's layout as the last evaluate of this tile left it
+        }
     }
     return w;
 }
@@ -193,6 +205,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
 __device__ __forceinline__ void sparse_words_uniform(SparseWords& w) {
     w.m_old = uniform64(w.m_old);
     w.ever = uniform64(w.ever);
+    w.ever_trial = uniform64(w.ever_trial);
 }
 // plastic | formerly plastic points of the tile under the sparse protocol
 __device__ __forceinline__ unsigned long long sparse_touched(const EvalArgs& a, const SparseWords& w, unsigned long long mask) {
@@ -241,13 +254,19 @@ struct SplitRows {
     bool row_live[3] = {true, true, true};
 
     __device__ __forceinline__ void request(const EvalArgs& a, const SparseWords& w, long long p0, int npts, int lane,
-                                            unsigned long long touched, bool hist_in_place) {
+                                            unsigned long long touched, bool hist_in_place, double* region) {
         rows = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
         if (rows == 0ull) return;
         packed = (a.flags & kFlagPackedHistory) != 0 && a.hmask != nullptr;  // committed run in, trial run out (PackedRows)
         if (packed) {
             pk.ever_in = w.ever;
-            pk.load(a.h1_in, p0, lane);
+            const int run_rows = (int)__popcll(w.ever);
+            // few touched rows of a long run, no new row, trial run in the committed layout: the rows alone (PackedRows::load_rows)
+            if (FULL && w.ever_trial == w.ever && run_rows >= kPackedRowsMinRun && (rows & ~w.ever) == 0ull &&
+                kPackedRowsDiv * (int)__popcll(rows) <= run_rows)
+                pk.load_rows(a.h1_in, p0, lane, rows, region);
+            else
+                pk.load(a.h1_in, p0, lane);
             return;
         }
         masked = FULL && rows != ~0ull && (int)__popcll(rows) <= a.masked_max;

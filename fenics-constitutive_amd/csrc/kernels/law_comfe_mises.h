@@ -113,7 +113,7 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
     SplitRows<FULL, NT> hr;
     double d6[6] = {h[1], h[2], h[3], h[4], h[5], h[6]};
     if (split) {
-        hr.request(a, w, p0, npts, lane, touched, hist_in_place);
+        hr.request(a, w, p0, npts, lane, touched, hist_in_place, region);
         hr.gather(region, lane, mask, d6);
     }
     sr.put(sb, region, lane, s, p0, npts, rows_lds);

@@ -276,7 +276,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
         // fully elastic tile: stress = sigma_tr, tangent = E, history untouched (sparse protocol: stale rows restored)
         double d6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (split) {
-            hr.request(a, w, p0, npts, lane, touched, hist_in_place);
+            hr.request(a, w, p0, npts, lane, touched, hist_in_place, region);
             hr.gather(region, lane, 0ull, d6);
         }
         sr.put(sb, region, lane, t.sig1, p0, npts, rows_lds);
@@ -308,7 +308,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
     // 168-VGPR cap of the indexed kernels) and taken into the lanes before the first store of the tile
     double d6[6] = {h[1], h[2], h[3], h[4], h[5], h[6]};
     if (split) {
-        hr.request(a, w, p0, npts, lane, touched, hist_in_place);
+        hr.request(a, w, p0, npts, lane, touched, hist_in_place, region);
         hr.gather(region, lane, mask, d6);
     }
     sr.put(sb, region, lane, t.sig1, p0, npts, rows_lds);

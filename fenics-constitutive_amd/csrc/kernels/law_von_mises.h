@@ -96,16 +96,6 @@ __device__ __forceinline__ void vm_tangent_coefficients(const Scalars& sc, const
 // tables:  a = ka*xioi, b = xpp
 // HIST: 0 = the caller's arrays as they are (in place or out of place), 1 = sparse trial history (a.hmask),
 //       2 = sparse protocol on the packed plastic-strain layout (history_rows.h: PackedRows)
-// rows inside a packed run (PackedRows::load_rows) when at most 1 / kPackedRowsDiv of the run's rows are touched
-#ifndef FCAMD_PACKED_ROWS_DIV
-#define FCAMD_PACKED_ROWS_DIV 3
-#endif
-constexpr int kPackedRowsDiv = FCAMD_PACKED_ROWS_DIV;
-#ifndef FCAMD_PACKED_ROWS_MIN_RUN
-#define FCAMD_PACKED_ROWS_MIN_RUN 32
-#endif
-constexpr int kPackedRowsMinRun = FCAMD_PACKED_ROWS_MIN_RUN;  // ... of a run of at least this many rows
-
 template <bool IDX, int HIST, bool FULL, bool NT>
 __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
                                                int* rows_lds, long long p0, int npts, int lane,

@@ -358,26 +358,32 @@ def test_vmm_placement_moves_the_state_and_keeps_results(numpy_grad):
     assert torch.equal(keep, ref)  # the view keeps the working set's memory alive
 
 
+@pytest.mark.parametrize("law_name", ["VonMises3D", "MisesPlasticityLinearHardening3D", "DruckerPragerHyperbolic3D"])
 @pytest.mark.parametrize("n", [64 * 40 + 5, 64 * 64])
-def test_packed_rows_inside_long_runs(n):
-    """Every point has yielded once (no +0.0 row: every tile's run is 64 rows long) and only a scattered few yield now: the packed
-    state moves the touched rows INSIDE the run (PackedRows::load_rows) while the trial run has the committed layout, the whole run
-    otherwise -- plastic sets of 1-2 points per tile, a burst of 40 %, an iterate without a strain increment, commits in between.  Bit for bit the
-    plain protocol, after every iterate."""
+def test_packed_rows_inside_long_runs(n, law_name):
+    """Every point has yielded once (hardly a +0.0 row: every tile's run is about 64 rows long) and only a scattered few yield now:
+    the packed state moves the touched rows INSIDE the run (PackedRows::load_rows) while the trial run has the committed layout, the
+    whole run otherwise -- plastic sets of 1-2 points per tile, a burst of 40 %, an iterate without a strain increment, commits in
+    between.  Bit for bit the plain protocol, after every iterate."""
     rng = np.random.default_rng(n + 1)
-    law = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
-    s0 = rng.normal(scale=30.0, size=6 * n)
-    eps = rng.normal(scale=1e-3, size=6 * n)
-    eps.reshape(-1, 6)[rng.random(n) < 0.03] = 0.0   # a few virgin rows: points that can still GROW a run
-    h0 = {"eps_n": eps, "alpha": rng.uniform(0, 0.02, size=n)}
+    law, s0, h0, _ = _sparse_case(law_name, n, rng)
+    key, w = ("eps_n", 6) if law_name == "VonMises3D" else ("history", 7)
+    rows = h0[key].reshape(-1, w)[:, w - 6:]
+    rows[:] = rng.normal(scale=1e-3, size=rows.shape)
+    rows[rng.random(n) < 0.03] = 0.0   # a few virgin rows: points that can still GROW a run
+    big = 5e-3 if law_name.startswith("Drucker") else 2e-2
     p = ResidentState(law, n, stress0=s0, history0=h0)
-    f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False, packed_history=False)
+    f = ResidentState(law, n, stress0=s0, history0=h0, sparse_history=False, sparse_tangent=False, packed_history=False,
+                      **({} if law_name == "VonMises3D" else {"split_history": False}))
     assert p._packed
     fractions = []
     for inc, plan in enumerate(([0.02, 0.03, 0.02], [0.02, 0.4, 0.03], [0.03, 0.0, 0.02], [0.01, 0.01, 0.01])):
         for it, frac in enumerate(plan):
-            scale = np.where(rng.random(n) < frac, 2e-2, 1e-5)  # the chosen points yield for certain, the others stay elastic
-            g = torch.from_numpy((rng.normal(size=(n, 9)) * scale[:, None]).reshape(-1)).cuda()
+            scale = np.where(rng.random(n) < frac, big, 1e-6)  # the chosen points yield, nearly all others stay elastic
+            gn = rng.normal(size=(n, 9)) * scale[:, None]
+            if law_name.startswith("Drucker"):
+                gn[:, [0, 4, 8]] -= (0.95 * gn[:, [0, 4, 8]].sum(axis=1) / 3.0)[:, None]  # mostly isochoric
+            g = torch.from_numpy(gn.reshape(-1)).cuda()
             p.evaluate(0.0, 1.0, g)
             f.evaluate(0.0, 1.0, g)
             fractions.append(int(f.check().n_plastic) / n)
@@ -389,7 +395,7 @@ def test_packed_rows_inside_long_runs(n):
         p.update(), f.update()
         for k in h0:
             assert torch.equal(p.history_committed[k], f.history_committed[k]), (inc, k)
-    assert 0.005 < fractions[0] < 0.05 and max(fractions) > 0.3 and min(fractions) < 0.03
+    assert max(fractions) > 0.3 and min(fractions) < 0.1, fractions
 
 
 @pytest.mark.parametrize("law_name", ["VonMises3D", "MisesPlasticityLinearHardening3D", "DruckerPrager3D", "DruckerPragerHyperbolic3D"])

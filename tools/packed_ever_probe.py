@@ -13,7 +13,7 @@ import bench  # noqa: E402
 from fenics_constitutive_amd.device import pack_rows  # noqa: E402
 
 n = int(float(os.environ.get("AB_POINTS", "1e8")))
-wl = bench.Workload(bench.HEADLINE, n, 1234, torch.device("cuda", 0), 0)
+wl = bench.Workload(os.environ.get("AB_WORKLOAD", bench.HEADLINE), n, 1234, torch.device("cuda", 0), 0)
 key = wl.rows_key
 base = [g.clone() for g in wl.grads]
 
@@ -48,7 +48,7 @@ for ever_all in (False, True):
         wl.ever_t = wl.ever_c.clone()
         wl.hist_t[key].copy_(wl.hist_c[key])
         wl.hmask.zero_()
-    for scale in (1.0, 0.35, 0.2):
+    for scale in [float(x) for x in os.environ.get("AB_SCALES", "1.0,0.35,0.2").split(",")]:
         for i in range(2):
             wl.grads[i].copy_(base[i] * scale)
         res = {False: [], True: []}
