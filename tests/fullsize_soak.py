@@ -28,6 +28,8 @@ LAWS = {
         {k: np.array([v]) for k, v in {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0}.items()}),
     "DruckerPragerHyperbolic3D": lambda: fc.DruckerPragerHyperbolic3D(
         {k: np.array([v]) for k, v in {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02, "d": 40.0}.items()}),
+    # every point has yielded once (no +0.0 row: runs of 64 rows) and few yield now: the rows-inside-the-run path of the packed layout
+    "VonMises3D, every point yielded once": lambda: fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}),
 }
 
 
@@ -48,14 +50,19 @@ def run(name):
         del tr, gv
     else:
         base.view(N, 9).mul_(torch.pow(10.0, torch.rand(N, generator=gen, **f) * 2 - 4)[:, None])
-    sp = ResidentState(law, N)                                           # the product default
-    fu = ResidentState(law, N, sparse_history=False, sparse_tangent=False, packed_history=False,
-                       **({"split_history": False} if name != "VonMises3D" else {}))
+    yielded = "yielded once" in name
+    h0 = None
+    if yielded:
+        h0 = {"eps_n": torch.randn(6 * N, generator=gen, **f) * 1e-4, "alpha": torch.rand(N, generator=gen, **f) * 0.01}
+    sp = ResidentState(law, N, history0=h0)                              # the product default
+    fu = ResidentState(law, N, history0=h0, sparse_history=False, sparse_tangent=False, packed_history=False,
+                       **({"split_history": False} if not name.startswith("VonMises3D") else {}))
+    del h0
     t0, fr, iterates = time.time(), [], 0
     for inc in range(INCREMENTS):
         for it in range(3):
             # iterate 0 overshoots, 1 falls back, 2 settles in between: the plastic set of the trial state shrinks and grows
-            scale = (0.6 + 0.1 * inc) * (1.5, 0.4, 1.0)[it]
+            scale = (0.6 + 0.1 * inc) * (1.5, 0.4, 1.0)[it] * (0.22 if yielded else 1.0)
             g = base * scale
             sp.evaluate(float(inc), 1.0, g)
             fu.evaluate(float(inc), 1.0, g)
