@@ -41,7 +41,8 @@ template <bool FULL, bool NT>
 struct PackedRows {
     Chunks<6> c;
     unsigned long long ever_in = 0ull;
-    unsigned long long live = ~0ull;  // rows of the RUN (rank space) that move; all ones = the whole run
+    bool partial = false;              // only the touched rows of the run move (load_rows)
+    bool row_live[3] = {true, true, true};  // ... chunk k of this lane lies in such a row
 
     // 16-byte chunks of a run of `rows` rows, rounded up to whole 128-byte lines (a slot is 24 lines; the ragged last tile,
     // whose slot ends with the array: the exact run; FCAMD_PACKED_LINE=0: always exact, the experiment knob)
@@ -71,20 +72,25 @@ struct PackedRows {
     }
     // requests only the rows of the run that belong to the points in `touched` (a subset of ever_in); uses the wave's LDS region
     __device__ __forceinline__ void load_rows(const double* rows_in, long long p0, int lane, unsigned long long touched, double* region) {
-        int* flag = reinterpret_cast<int*>(region);
-        const int rows = (int)__popcll(ever_in);
+        int* flag = reinterpret_cast<int*>(region);  // flag[r]: row r of the run belongs to a touched point
         const int rank_in = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ever_in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ever_in, 0u));
+        flag[lane] = 0;  // rows beyond the run (chunk q of lane l belongs to row q / 3 <= 63)
+        wave_sync();
         if (((ever_in >> lane) & 1ull) != 0ull) flag[rank_in] = (int)((touched >> lane) & 1ull);
         wave_sync();
-        live = __ballot(lane < rows && flag[lane] != 0);  // the rank-space image of `touched`
-        wave_sync();
+        partial = true;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int q = k * kWave + lane;
+            row_live[k] = flag[q / 3] != 0;
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
             d2 v;
             v.x = 0.0;
             v.y = 0.0;
-            if (((live >> (q / 3)) & 1ull) != 0ull) v = load16<NT>(rows_in + p0 * 6 + 2 * q);
+            if (row_live[k]) v = load16<NT>(rows_in + p0 * 6 + 2 * (k * kWave + lane));
             c.v[k] = v;
         }
     }
@@ -114,13 +120,21 @@ struct PackedRows {
         const int rank_out = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ever_out >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ever_out, 0u));
         if (((ever_out >> lane) & 1ull) != 0ull) lds_put_point<6>(region, rank_out, row);
         wave_sync();
+        if (!partial) {  // the whole run, and its EVER word
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int q = k * kWave + lane;
-            if (q < nq_out && ((live >> (q / 3)) & 1ull) != 0ull) store16<NT>(rows_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+            for (int k = 0; k < 3; ++k) {
+                const int q = k * kWave + lane;
+                if (q < nq_out) store16<NT>(rows_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+            }
+            if (lane == 0) a.emask_out[p0 >> 6] = ever_out;
+        } else {  // rows inside the run: the trial word is ever_in already
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int q = k * kWave + lane;
+                if (row_live[k]) store16<NT>(rows_out + p0 * 6 + 2 * q, reinterpret_cast<const d2*>(region)[q]);
+            }
         }
         wave_sync();
-        if (lane == 0 && live == ~0ull) a.emask_out[p0 >> 6] = ever_out;  // rows inside the run: the trial word is ever_in already
     }
 };
 
@@ -184,7 +198,8 @@ struct MaskedRows {
 // ballot.  The new ballot is recorded at the END of the tile (sparse_record): a store issued earlier would sit, in the wave's one
 // vmcnt, in front of the row loads that follow it.
 struct SparseWords {
-    unsigned long long m_old = 0ull, ever = 0ull, ever_trial = 0ull;
+    unsigned long long m_old = 0ull, ever = 0ull;
+    bool same_layout = false;  // packed: the trial run has the committed run's layout (same EVER word: nothing grew since the last commit)
 };
 __device__ __forceinline__ SparseWords sparse_words(const EvalArgs& a, long long p0) {
     SparseWords w;
@@ -192,7 +207,7 @@ __device__ __forceinline__ SparseWords sparse_words(const EvalArgs& a, long long
         w.m_old = a.hmask[p0 >> 6];
         if ((a.flags & kFlagPackedHistory) != 0) {
             w.ever = a.emask_in[p0 >> 6];
-            w.ever_trial = a.emask_out[p0 >> 6];  // the trial run's layout as the last evaluate of this tile left it
+            w.same_layout = a.emask_out[p0 >> 6] == w.ever;  // the trial word as the last evaluate of this tile left it
         }
     }
     return w;
@@ -205,7 +220,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
 __device__ __forceinline__ void sparse_words_uniform(SparseWords& w) {
     w.m_old = uniform64(w.m_old);
     w.ever = uniform64(w.ever);
-    w.ever_trial = uniform64(w.ever_trial);
+    w.same_layout = __builtin_amdgcn_readfirstlane((int)w.same_layout) != 0;
 }
 // plastic | formerly plastic points of the tile under the sparse protocol
 __device__ __forceinline__ unsigned long long sparse_touched(const EvalArgs& a, const SparseWords& w, unsigned long long mask) {
@@ -262,7 +277,7 @@ struct SplitRows {
             pk.ever_in = w.ever;
             const int run_rows = (int)__popcll(w.ever);
             // few touched rows of a long run, no new row, trial run in the committed layout: the rows alone (PackedRows::load_rows)
-            if (FULL && w.ever_trial == w.ever && run_rows >= kPackedRowsMinRun && (rows & ~w.ever) == 0ull &&
+            if (FULL && w.same_layout && run_rows >= kPackedRowsMinRun && (rows & ~w.ever) == 0ull &&
                 kPackedRowsDiv * (int)__popcll(rows) <= run_rows)
                 pk.load_rows(a.h1_in, p0, lane, rows, region);
             else

@@ -44,3 +44,19 @@ def test_headline_kernels_keep_four_waves(rows):
         for r in rows:
             if r["name"].startswith(f"void evaluate_kernel<{law}, true, false"):
                 assert r["occupancy"] >= 4 and r["vgpr"] <= 128, r
+
+
+def test_sgpr_spill_reloads_stay_bounded():
+    """An SGPR that does not fit lives in a VGPR lane and every use of it is a VALU instruction (v_readlane).  Round 4: three more
+    64-bit uniform words in the packed VonMises3D tile took that kernel's reloads from 57 to 365 and its executed VALU
+    instructions up 22 % -- nothing in the register table shows it.  Static reloads of the streaming kernels, bounded."""
+    import kernel_resources
+
+    traffic = kernel_resources.sgpr_spill_traffic()
+    head = [n for n in traffic if n.startswith("void evaluate_kernel<2, true, false")]
+    assert len(head) == 3, sorted(traffic)
+    for n in head:
+        assert traffic[n][1] <= 150, (n, traffic[n])
+    for n, (w, r) in traffic.items():
+        if "evaluate_kernel<" in n and "true, false" in n:
+            assert r <= 320, (n, w, r)

@@ -62,6 +62,39 @@ def kernel_resources(sources=None):
     return rows
 
 
+def sgpr_spill_traffic(source="fcamd_kernels.hip"):
+    """{kernel: (v_writelane_b32, v_readlane_b32)} from the device assembly: an SGPR that does not fit is parked in a VGPR lane, and every
+    use of it is a VALU instruction (v_readlane) -- round 4: three more 64-bit uniform words in the packed VonMises3D tile took
+    the reloads of that kernel from 57 to 365 and its executed VALU instructions up 22 %, invisible in the register table."""
+    import collections
+
+    from fenics_constitutive_amd import _build
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    flags = [f for f in _build.FLAGS if f not in ("-shared", "-fPIC", "-pthread")]
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        r = subprocess.run([hipcc, f"--offload-arch={_build.ARCH}", *flags, "--cuda-device-only", "-S", "-o", out, os.path.join(_build.CSRC, source)],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-2000:])
+        counts, cur = collections.defaultdict(lambda: [0, 0]), None
+        for line in open(out):
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                cur = m.group(1)
+            elif line.startswith(".Lfunc_end"):
+                cur = None
+            elif cur and line.startswith("\t"):
+                op = line.split()[0] if line.split() else ""
+                if op == "v_writelane_b32":
+                    counts[cur][0] += 1
+                elif op == "v_readlane_b32":
+                    counts[cur][1] += 1
+    names = list(counts)
+    return {n: tuple(counts[m]) for m, n in zip(names, demangle(names))}
+
+
 def main():
     rows = kernel_resources()
     md = "--md" in sys.argv
