@@ -543,6 +543,12 @@ FCAMD_API int fcamd_version(void);
 /* ================================================================================================================
  * Conveniences: `static inline` shorthands of the entries above (the names and arguments of ABI 0.3).  No symbols.
  * ================================================================================================================ */
+/* zero initialiser of a struct in both languages (C: {0}; C++: {} -- keeps -Wextra quiet in a C++ caller) */
+#ifdef __cplusplus
+#define FCAMD_ZERO_INIT {}
+#else
+#define FCAMD_ZERO_INIT {0}
+#endif
 #if defined(__GNUC__) || defined(__clang__)
 #define FCAMD_INLINE static inline __attribute__((unused))
 #else
@@ -606,7 +612,7 @@ FCAMD_INLINE int fcamd_evaluate_device_from(fcamd_model* model, double t, double
                                             const double* grad_del_u, const double* stress_prev,
                                             double* stress, double* tangent,
                                             const double* const* history_prev, double* const* history, int n_hist) {
-    fcamd_eval_args x = {0};
+    fcamd_eval_args x = FCAMD_ZERO_INIT;
     x.grad_del_u = grad_del_u, x.stress_prev = stress_prev, x.stress = stress, x.tangent = tangent;
     x.history_prev = history_prev, x.history = history, x.n_hist = n_hist;
     return fcamd_evaluate_device_ex(model, t, del_t, n, &x);
@@ -622,7 +628,7 @@ FCAMD_INLINE int fcamd_evaluate_device_from_sparse(fcamd_model* model, double t,
                                                    double* stress, double* tangent,
                                                    const double* const* history_prev, double* const* history,
                                                    int n_hist, uint64_t* history_mask) {
-    fcamd_eval_args x = {0};
+    fcamd_eval_args x = FCAMD_ZERO_INIT;
     if (n > 0 && !history_mask) return FCAMD_ERR_BAD_ARG;
     x.grad_del_u = grad_del_u, x.stress_prev = stress_prev, x.stress = stress, x.tangent = tangent;
     x.history_prev = history_prev, x.history = history, x.n_hist = n_hist, x.history_mask = history_mask;
@@ -633,7 +639,7 @@ FCAMD_INLINE int fcamd_evaluate_device_indexed(fcamd_model* model, double t, dou
                                                double* stress_parent, double* tangent_parent,
                                                const int32_t* parent_rows,
                                                const double* const* history_prev, double* const* history, int n_hist) {
-    fcamd_eval_args x = {0};
+    fcamd_eval_args x = FCAMD_ZERO_INIT;
     if (n > 0 && !parent_rows) return FCAMD_ERR_BAD_ARG;
     x.grad_del_u = grad_del_u, x.stress_prev = stress_prev_parent, x.stress = stress_parent, x.tangent = tangent_parent;
     x.history_prev = history_prev, x.history = history, x.n_hist = n_hist, x.parent_rows = parent_rows;
@@ -642,7 +648,7 @@ FCAMD_INLINE int fcamd_evaluate_device_indexed(fcamd_model* model, double t, dou
 FCAMD_INLINE int fcamd_evaluate_device_wrapped(fcamd_model* model, int wrapper_constraint, double t, double del_t,
                                                int64_t n, const double* grad_lo, double* stress_lo,
                                                double* tangent_lo, double* stress_3d, double* const* history, int n_hist) {
-    fcamd_eval_args x = {0};
+    fcamd_eval_args x = FCAMD_ZERO_INIT;
     x.grad_del_u = grad_lo, x.stress_prev = stress_lo, x.stress = stress_lo, x.tangent = tangent_lo;
     x.history_prev = (const double* const*)history, x.history = history, x.n_hist = n_hist;
     x.wrapper_constraint = wrapper_constraint ? wrapper_constraint : -1, x.stress_3d = stress_3d;
