@@ -348,3 +348,53 @@ def test_host_path_arrays_beyond_4GiB(contexts):
     step = 3_000_000  # compare the tangent in pieces: no second 5 GB host copy
     for lo in range(0, n, step):
         assert np.array_equal(tv[lo: lo + step], td.view(n, 36)[lo: lo + step].cpu().numpy()), lo
+
+
+@pytest.mark.parametrize("law_name", ["LinearElasticityModel", "VonMises3D"])
+def test_indexed_cell_map_5e7(law_name):
+    """Submesh-indexed evaluate at bench.py's size: 5e7 points of one material whose stress / tangent rows live in parent
+    arrays of 1e8 rows, under the map build_subspace_map yields (solver/maps.py:125-177: ascending cells, 4 consecutive rows each, every
+    other cell at random).  Size-independent property: the fused launch == gather of the committed rows, the plain evaluate, scatter
+    (the reference's map_to_sub / evaluate / map_to_parent), bit for bit -- and the rows of the other material keep their values."""
+    need_memory(150)
+    n_sub, n_parent = 50_000_000, 100_000_000
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    f = dict(dtype=torch.float64, device="cuda")
+    cells = torch.randperm(n_parent // 4, device="cuda", generator=gen)[: n_sub // 4].sort().values
+    rows = (cells[:, None] * 4 + torch.arange(4, device="cuda")[None, :]).reshape(-1)
+    del cells
+    rows32 = rows.to(torch.int32)
+    g = torch.randn(9 * n_sub, generator=gen, **f)
+    if law_name == "VonMises3D":
+        law = fc.VonMises3D(VM_P)
+        g.view(n_sub, 9).mul_(torch.pow(10.0, torch.rand(n_sub, generator=gen, **f) * 2 - 4)[:, None])
+        hp = {"eps_n": torch.randn(6 * n_sub, generator=gen, **f) * 1e-4, "alpha": torch.rand(n_sub, generator=gen, **f) * 0.02}
+        h_a = {k: torch.empty_like(v) for k, v in hp.items()}
+        h_b = {k: torch.empty_like(v) for k, v in hp.items()}
+    else:
+        law = fc.LinearElasticityModel(LE_P, FULL)
+        g.mul_(1e-3)
+        hp = h_a = h_b = None
+    sp = torch.randn(6 * n_parent, generator=gen, **f) * 30.0          # committed parent stress
+    sc = torch.randn(6 * n_parent, generator=gen, **f)                 # trial parent stress: the other material's rows must survive
+    sc0 = sc.clone()
+    tp = torch.full((36 * n_parent,), float("nan"), **f)               # parent tangent: untouched rows stay NaN
+    law.evaluate_indexed(0.0, 1.0, g, sp, sc, tp, rows32, hp, h_a)
+    # the reference sequence with the plain kernel
+    s_prev = sp.view(-1, 6)[rows].reshape(-1)
+    s_sub, t_sub = torch.empty_like(s_prev), torch.empty(36 * n_sub, **f)
+    law.evaluate_from(0.0, 1.0, g, s_prev, s_sub, t_sub, hp, h_b)
+    torch.cuda.synchronize()
+    assert torch.equal(sc.view(-1, 6)[rows], s_sub.view(-1, 6))
+    del s_prev, s_sub
+    got_t = tp.view(-1, 36)[rows]
+    assert torch.equal(got_t, t_sub.view(-1, 36))
+    del got_t, t_sub
+    if hp is not None:
+        for k in hp:
+            assert torch.equal(h_a[k], h_b[k]), k
+    other = torch.ones(n_parent, dtype=torch.bool, device="cuda")
+    other[rows] = False
+    assert int(other.sum()) == n_parent - n_sub
+    assert torch.equal(sc.view(-1, 6)[other], sc0.view(-1, 6)[other])
+    assert bool(torch.isnan(tp.view(-1, 36)[other][:, ::7]).all())     # (a sixth of the entries: the rows are written whole or not at all)
