@@ -398,3 +398,69 @@ def test_indexed_cell_map_5e7(law_name):
     assert int(other.sum()) == n_parent - n_sub
     assert torch.equal(sc.view(-1, 6)[other], sc0.view(-1, 6)[other])
     assert bool(torch.isnan(tp.view(-1, 36)[other][:, ::7]).all())     # (a sixth of the entries: the rows are written whole or not at all)
+
+
+@pytest.mark.parametrize("kind", ["plane_strain", "uniaxial_strain"])
+def test_fused_wrapper_1e8(kind):
+    """The fused 3D -> plane-strain / uniaxial-strain wrapper kernels around VonMises3D at 1e8 points: bit for bit the
+    generic sequence of the reference's wrapper classes (models/utils.py:243-273, 332-359: pad, 3-D evaluate, map back) run with the 3-D
+    kernel on device arrays, over two calls (the cached 3-D stress of the first enters the second)."""
+    need_memory(170)
+    W = fc.PlaneStrainFrom3D if kind == "plane_strain" else fc.UniaxialStrainFrom3D
+    a, b = W(fc.VonMises3D(VM_P)), W(fc.VonMises3D(VM_P))
+    b.fused = False
+    gd2, sd = a.geometric_dim**2, a.stress_strain_dim
+    gen = torch.Generator(device="cuda").manual_seed(29)
+    f = dict(dtype=torch.float64, device="cuda")
+    s0 = torch.randn(sd * N, generator=gen, **f) * 30.0
+    h0 = {"eps_n": torch.randn(6 * N, generator=gen, **f) * 1e-3, "alpha": torch.rand(N, generator=gen, **f) * 0.02}
+    sa, sb = s0.clone(), s0
+    ha, hb = {k: v.clone() for k, v in h0.items()}, h0
+    ta, tb = torch.zeros(sd * sd * N, **f), torch.zeros(sd * sd * N, **f)
+    plastic = []
+    for call in range(2):
+        g = torch.randn(gd2 * N, generator=gen, **f)
+        g.view(N, gd2).mul_(torch.pow(10.0, torch.rand(N, generator=gen, **f) * (2.0 + 0.2 * call) - 4.0)[:, None])
+        a.evaluate(0.0, 1.0, g, sa, ta, ha)
+        b.evaluate(0.0, 1.0, g, sb, tb, hb)
+        del g
+        torch.cuda.synchronize()
+        plastic.append(a.model.device_stats().n_plastic / N)
+        assert torch.equal(sa, sb) and torch.equal(ta, tb), (kind, call)
+        assert torch.equal(a.stress_3d, b.stress_3d), (kind, call)
+        for k in ha:
+            assert torch.equal(ha[k], hb[k]), (kind, call, k)
+    assert a.tangent_3d is None and b.tangent_3d is not None and min(plastic) > 0.01, plastic
+
+
+@pytest.mark.parametrize("law,cname", [("le", "UNIAXIAL_STRAIN"), ("maxwell", "UNIAXIAL_STRESS"), ("kelvin", "UNIAXIAL_STRAIN"),
+                                       ("le", "PLANE_STRAIN"), ("maxwell", "PLANE_STRESS")])
+def test_lowdim_1e8(law, cname):
+    """The native low-dimensional kernels (uniaxial: the element-wise stream kernel, plane: the tiled one) at 1e8
+    points plus a ragged rest: a strided sample, the first and the last points against the NumPy restatement of the reference
+    (linear_elasticity_model.py:26-45, spring_maxwell_model.py:40-88, spring_kelvin_model.py:43-88 under utils.py:52-87,153-186),
+    1e-10; no point left unwritten."""
+    from wrappers_util import CPARAMS
+
+    n = N + 37
+    gdim, sd = O.DIMS[cname]
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    f = dict(dtype=torch.float64, device="cuda")
+    g = torch.randn(gdim * gdim * n, generator=gen, **f) * 1e-3
+    s0 = torch.randn(sd * n, generator=gen, **f)
+    h0 = None if law == "le" else {"strain_visco": torch.randn(sd * n, generator=gen, **f) * 1e-4, "strain": torch.randn(sd * n, generator=gen, **f) * 1e-3}
+    s, t = s0.clone(), torch.full((sd * sd * n,), float("nan"), **f)
+    h = None if h0 is None else {k: v.clone() for k, v in h0.items()}
+    m = {"le": fc.LinearElasticityModel, "maxwell": fc.SpringMaxwellModel, "kelvin": fc.SpringKelvinModel}[law](CPARAMS[law], fc.StressStrainConstraint[cname])
+    m.evaluate(0.0, 0.7, g, s, t, h)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(t).any()) and not bool(torch.isnan(s).any())
+    idx = torch.unique(torch.cat([sample_points(N), torch.arange(n - 200, n, device="cuda"), torch.arange(0, 4200, device="cuda")]))
+    gs, ss = gather(g, idx, gdim * gdim), gather(s0, idx, sd)
+    hs = None if h0 is None else {k: gather(v, idx, sd) for k, v in h0.items()}
+    ts = np.zeros(sd * sd * idx.numel())
+    O.MODELS_C[law](CPARAMS[law], cname, 0.0, 0.7, gs, ss, ts, hs)
+    assert rel_err(gather(s, idx, sd), ss) <= 1e-10 and rel_err(gather(t, idx, sd * sd), ts) <= 1e-10
+    if hs is not None:
+        for k in hs:
+            assert rel_err(gather(h[k], idx, sd), hs[k]) <= 1e-10, k
