@@ -464,3 +464,63 @@ def test_lowdim_1e8(law, cname):
     if hs is not None:
         for k in hs:
             assert rel_err(gather(h[k], idx, sd), hs[k]) <= 1e-10, k
+
+
+@pytest.mark.parametrize("kind", ["comfe_linear_elasticity", "comfe_mises_plasticity", "drucker_prager", "drucker_prager_hyperbolic"])
+def test_comfe_laws_1e8(kind):
+    """The comfe-rs laws at 1e8 points on the plain device path: a strided sample plus the first and last points
+    against the NumPy restatement of the Rust text (linear_elasticity.rs:42-75, mises_plasticity.rs:58-126, plasticity/general.rs:105-266
+    with drucker_prager_classic.rs / _hyperbolic.rs) at the tolerances of the small tests; no non-convergence, no unwritten entry."""
+    need_memory(70)
+    rs = lambda p: {k: np.array([v]) for k, v in p.items()}  # noqa: E731
+    gen = torch.Generator(device="cuda").manual_seed(37)
+    f = dict(dtype=torch.float64, device="cuda")
+    g = torch.randn(9 * N, generator=gen, **f)
+    dp = kind.startswith("drucker")
+    if kind == "comfe_linear_elasticity":
+        p, law, tol = {"mu": 16.0, "kappa": 35.0}, None, 1e-10
+        law = fc.LinearElasticity3D(rs(p))
+        g.mul_(1e-3)
+        s0, h0 = torch.randn(6 * N, generator=gen, **f), None
+    else:
+        tol = 1e-6
+        g.view(N, 9).mul_(torch.pow(10.0, torch.rand(N, generator=gen, **f) * (1.7 if dp else 2.0) - 4.0)[:, None])
+        h = torch.randn(7 * N, generator=gen, **f) * 1e-4
+        h.view(N, 7)[:, 0] = torch.rand(N, generator=gen, **f) * (0.1 if dp else 0.02)
+        h0 = {"history": h}
+        s0 = torch.randn(6 * N, generator=gen, **f) * (50.0 if dp else 30.0)
+        if dp:  # dp_inputs of the small tests: mostly isochoric increments on a compressive prestress
+            gv = g.view(N, 9)
+            tr = (gv[:, 0] + gv[:, 4] + gv[:, 8]) * (0.95 / 3.0)
+            for c in (0, 4, 8):
+                gv[:, c] -= tr
+            s0.view(N, 6)[:, :3] -= 1000.0
+            del tr
+            p = {"mu": 80769.0, "kappa": 175000.0, "a": 100.0, "b": 0.05, "b_flow": 0.02}
+            if kind.endswith("hyperbolic"):
+                p = {"mu": p["mu"], "kappa": p["kappa"], "a": p["a"], "b": p["b"], "d": 40.0, "b_flow": p["b_flow"]}
+            law = (fc.DruckerPragerHyperbolic3D if kind.endswith("hyperbolic") else fc.DruckerPrager3D)(rs(p))
+        else:
+            p = {"mu": 80769.0, "kappa": 175000.0, "y_0": 1200.0, "h": 200.0}
+            law = fc.MisesPlasticityLinearHardening3D(rs(p))
+    s = s0.clone()
+    hh = None if h0 is None else {"history": h0["history"].clone()}
+    t = torch.full((36 * N,), float("nan"), **f)
+    law.evaluate(0.0, 1.0, g, s, t, hh)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(t).any()) and not bool(torch.isnan(s).any())
+    if h0 is not None:
+        st = law.device_stats()
+        assert st.n_nonconverged == 0 and 0.05 * N < st.n_plastic < 0.95 * N, (st.n_plastic, st.n_nonconverged)
+    idx = torch.unique(torch.cat([sample_points(N, 40_000), torch.arange(0, 2100, device="cuda")]))
+    gs, ss = gather(g, idx, 9), gather(s0, idx, 6)
+    hs = None if h0 is None else {"history": gather(h0["history"], idx, 7)}
+    ts = np.zeros(36 * idx.numel())
+    if dp:
+        O.comfe_drucker_prager(p, 0.0, 1.0, gs, ss, ts, hs, hyperbolic=kind.endswith("hyperbolic"))
+    else:
+        O.MODELS[kind](p, 0.0, 1.0, gs, ss, ts, hs)
+    assert rel_err(gather(s, idx, 6), ss) <= tol and rel_err(gather(t, idx, 36), ts) <= tol
+    if hs is not None:
+        assert rel_err(gather(hh["history"], idx, 7), hs["history"]) <= tol
+        assert rel_err(gather(s, idx, 6), ss) <= 1e-10 and rel_err(gather(hh["history"], idx, 7), hs["history"]) <= 1e-10  # regression bound
