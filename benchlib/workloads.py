@@ -148,7 +148,7 @@ class Workload:
         # reference's Newton loop only grad_del_u changes (solver/_solver.py:130-147), and with it the
         # plastic set at its margin -- so the sparse protocol sees new and stale points as it does in use.
         self.grads = [grad_array()]
-        self.grads.append(self.grads[0] if os.environ.get("BENCH_SINGLE_ITERATE") == "1" else self.grads[0] * 1.03)  # knob: A/B only
+        self.grads.append(self.grads[0] * 1.03)
         # trial-state arrays: every timed step reads the committed state and writes the trial state
         # (same traffic as in place, stationary workload)
         self.stress_t = torch.empty_like(self.stress_c)
