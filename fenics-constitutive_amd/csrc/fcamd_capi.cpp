@@ -286,7 +286,6 @@ void options_from_env(Options* o) {
     };
     o->tile_map = (int)geti("FCAMD_TILE_MAP", 0);
     o->masked_max = (int)geti("FCAMD_MASKED_MAX", -1);
-    o->nontemporal = geti("FCAMD_NT", 1) != 0;
     o->host_chunk = geti("FCAMD_HOST_CHUNK", 0);
     o->host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, geti("FCAMD_HOST_SLOTS", fcamd_context::kSlots)));
     o->zero_copy = geti("FCAMD_ZERO_COPY", 1) != 0;
@@ -407,7 +406,6 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.counters = counters ? counters : m->d_counters;  // caller-owned counters are always reset here
     const Options& o = m->ctx->opt;
     a.tile_map = o.tile_map;
-    a.nontemporal = o.nontemporal;
     a.masked_max = o.masked_max >= 0 ? o.masked_max  // split history: 48-byte eps_p rows, as VonMises3D's eps_n
                                      : ((m->law == FCAMD_VON_MISES_3D || split) ? kMaskedRowMaxVonMises : kMaskedRowMaxRows7);
     constants_for(m, del_t);
@@ -519,7 +517,6 @@ int fcamd_context_set_option(fcamd_context* c, const char* name, long long value
     Options& o = c->opt;
     if (k == "tile_map") o.tile_map = (int)value;
     else if (k == "masked_max") o.masked_max = (int)value;
-    else if (k == "nontemporal") o.nontemporal = value != 0;
     else if (k == "host_chunk") o.host_chunk = value;
     else if (k == "host_slots") o.host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, value));
     else if (k == "zero_copy") o.zero_copy = value != 0;
@@ -539,7 +536,6 @@ int fcamd_context_get_option(fcamd_context* c, const char* name, long long* valu
     const Options& o = c->opt;
     if (k == "tile_map") *value = o.tile_map;
     else if (k == "masked_max") *value = o.masked_max;
-    else if (k == "nontemporal") *value = o.nontemporal;
     else if (k == "host_chunk") *value = o.host_chunk;
     else if (k == "host_slots") *value = o.host_slots;
     else if (k == "zero_copy") *value = o.zero_copy;
@@ -755,7 +751,6 @@ static int evaluate_wrapped(fcamd_model* m, int wrapper_constraint, double del_t
     a.n = n;
     a.counters = m->d_counters;
     a.tile_map = 0;
-    a.nontemporal = 1;
     a.masked_max = m->ctx->opt.masked_max >= 0 ? m->ctx->opt.masked_max : kMaskedRowMaxVonMises;  // eps_n rows of the fused VonMises3D wrapper
     a.flags = 0;
     constants_for(m, del_t);

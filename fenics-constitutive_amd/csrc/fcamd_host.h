@@ -49,7 +49,6 @@ struct Dims {
 struct Options {
     int tile_map = 0;          // FCAMD_TILE_MAP      0: tiles round-robin over all waves; 1: one region per XCD
     int masked_max = -1;       // FCAMD_MASKED_MAX    row-masked history access up to this many touched rows; -1: per-law default
-    int nontemporal = 1;       // FCAMD_NT            non-temporal global accesses of the main kernel
     long long host_chunk = 0;  // FCAMD_HOST_CHUNK    points per chunk of the staged host entries; 0: automatic
     int host_slots = 4;        // FCAMD_HOST_SLOTS    chunk slots in flight (1..4)
     int zero_copy = 1;         // FCAMD_ZERO_COPY     0 keeps page-locked caller arrays on the staged path

@@ -53,7 +53,6 @@ struct EvalArgs {
     long long n;               // quadrature points
     unsigned long long* counters;  // [kCounterSlots][4]: nonconverged, plastic, newton iterations, reserved
     int tile_map;              // 0: tiles dealt round-robin to all waves; 1: one contiguous region per XCD
-    int nontemporal;           // main kernel of the plain (non-indexed, non-sparse) form: non-temporal global accesses (default) or plain ones
     int masked_max;            // row-masked history access for tiles with at most this many touched rows (else dense)
     int flags;                 // bit 0: sparse-tangent protocol (fcamd_kernels.hip: sparse_tangent_need); bit 2: split history; bit 3: packed plastic-strain history
     Scalars sc;

@@ -272,8 +272,6 @@ __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) 
 // ---------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------
-constexpr bool kNT = true;
-
 template <int LAW>
 static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream) {
     if constexpr (LAW == LAW_VM3D) {
@@ -314,10 +312,7 @@ static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream)
         return hipGetLastError();
     }
     if (args.n >= kWave) {
-        if (args.nontemporal)  // experiments: Options::nontemporal = 0 selects plain (temporal) accesses
-            hipLaunchKernelGGL((evaluate_kernel<LAW, true, false>), dim3(grid), dim3(kBlock), 0, stream, args);
-        else
-            hipLaunchKernelGGL((evaluate_kernel<LAW, false, false>), dim3(grid), dim3(kBlock), 0, stream, args);
+        hipLaunchKernelGGL((evaluate_kernel<LAW, true, false>), dim3(grid), dim3(kBlock), 0, stream, args);
     }
     if (args.n % kWave != 0)
         hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false>), dim3(1), dim3(kWave), 0, stream, args);

@@ -520,8 +520,8 @@ FCAMD_API int fcamd_device_free(fcamd_context* ctx, void* ptr);
 /* ---- tuning / introspection -------------------------------------------------- */
 /* Context options (name, value).  Launch / data-path knobs (experiments; the defaults are the measured optimum) and
    their FCAMD_* environment defaults, which are read ONCE, when the context is created:
-     "tile_map" (FCAMD_TILE_MAP, 0), "masked_max" (FCAMD_MASKED_MAX, -1 = per law), "nontemporal"
-     (FCAMD_NT, 1), "host_chunk" (FCAMD_HOST_CHUNK, 0 = automatic), "host_slots" (FCAMD_HOST_SLOTS, 4),
+     "tile_map" (FCAMD_TILE_MAP, 0), "masked_max" (FCAMD_MASKED_MAX, -1 = per law),
+     "host_chunk" (FCAMD_HOST_CHUNK, 0 = automatic), "host_slots" (FCAMD_HOST_SLOTS, 4),
      "bounce_max" (FCAMD_BOUNCE_MAX, 256 KiB: host calls up to this size go through the page-locked scratch),
      "zero_copy" (FCAMD_ZERO_COPY, 1), "zero_copy_grad" (FCAMD_ZERO_COPY_GRAD, 1);
    "grid": the launch grid (number of 256-thread workgroups; 0 = automatic);

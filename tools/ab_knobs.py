@@ -29,7 +29,7 @@ if os.environ.get("AB_FROW"):  # a SURVEY 8(f) row (benchlib/frows.py) instead o
 else:
     wl = bench.Workload(os.environ.get("AB_WORKLOAD", bench.HEADLINE), n, 1234, torch.device("cuda", 0), 0)
 ctx = wl.law._handle(0).ctx
-defaults = {"tile_map": 0, "grid": 0, "masked_max": -1, "nontemporal": 1}
+defaults = {"tile_map": 0, "grid": 0, "masked_max": -1}
 variants = [v.split("=") for v in sys.argv[1:]] or [["tile_map", "0"], ["tile_map", "1"]]
 res = {tuple(v): [] for v in variants}
 for rnd in range(5):

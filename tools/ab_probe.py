@@ -23,7 +23,7 @@ mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
 e1.copy_(e0), a1.copy_(a0)  # sparse contract: trial == committed
 # launch knobs are context options (fcamd_context_set_option); the FCAMD_* environment names select them here
 variants = [v.split("=") for v in sys.argv[1:]] or [["FCAMD_TILE_MAP", "0"], ["FCAMD_TILE_MAP", "1"]]
-OPTION = {"FCAMD_TILE_MAP": "tile_map", "FCAMD_NT": "nontemporal", "FCAMD_MASKED_MAX": "masked_max"}
+OPTION = {"FCAMD_TILE_MAP": "tile_map", "FCAMD_MASKED_MAX": "masked_max"}
 ctx = law._handle(0).ctx
 res = {tuple(v): [] for v in variants}
 for rnd in range(6):
