@@ -435,3 +435,17 @@ def test_small_ndarray_calls_warn_once(monkeypatch):
         warnings.simplefilter("error")
         fdev._warn_small_call(le, 10)         # silenced
     assert set(fdev.SMALL_CALL_POINTS) >= {"LinearElasticityModel", "VonMises3D", "SpringMaxwellModel", "SpringKelvinModel"}
+
+
+def test_scripts_compile():
+    """bench.py, benchlib/, tools/, examples/ and the soak scripts are not imported by the CPU suite: at least they must parse"""
+    import glob
+    import py_compile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    for d in ("benchlib", "tools", "examples", "oracle", "tests"):
+        files += glob.glob(os.path.join(root, d, "*.py"))
+    assert len(files) > 60
+    for f in files:
+        py_compile.compile(f, doraise=True)
