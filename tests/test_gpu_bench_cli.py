@@ -11,6 +11,8 @@ import socket
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -162,3 +164,22 @@ def test_one_rank_under_the_launcher_with_rccl():
     assert out["n_gpus"] == 1 and out["per_rank_kernel_ms"] and len(out["per_rank_kernel_ms"]) == 1
     assert "allgather" not in out and "strong_scaling" not in out and "host_path" not in out and "host_path_multi" not in out
     assert abs(out["value"] - 2_000_000 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) <= 0.01 * out["value"]
+
+
+def test_default_legs_at_small_size_carry_every_configuration_and_8f_row():
+    """The driver's command shape (N = 1, no --workload) at 2e6 points: the line carries the five other BASELINE configurations
+    and every SURVEY 8(f) row, each with a kernel time, a roofline fraction and a launch log whose phases end with the timed one."""
+    from benchlib import frows
+
+    r, out = run_bench("--points", "2000000", "--steps", "3", "--warmup", "1", "--config-steps", "5", "--no-cpu-baseline", "--no-host-path",
+                       "--placement-tries", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["n_gpus"] == 1 and out["value"] > 0 and 0 < out["roofline"]["frac"] < 1
+    cfg = out["configs"]
+    for name in ("linear_elasticity", "von_mises_plastic", "von_mises_elastic", "spring_maxwell", "spring_kelvin", *frows.FROWS):
+        assert name in cfg, (name, sorted(cfg))
+        c = cfg[name]
+        assert "error" not in c, (name, c)
+        assert c["kernel_ms_avg"] > 0 and 0 < c["frac"] < 1.2, (name, c)
+        assert c["launch_log"] and c["launch_log"][-1][0] == "timed", (name, c["launch_log"])
+    assert set(frows.SURVEY_ROW) == set(frows.FROWS)
