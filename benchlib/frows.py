@@ -97,6 +97,10 @@ class IndexedRow(FRow):
         self.name = "indexed_" + order
         self.n_parent = 2 * n_sub
         self.law = fc.LinearElasticityModel(LE_P, fc.StressStrainConstraint.FULL)
+        self.hist = None
+        if os.environ.get("FROW_INDEXED_LAW") == "maxwell":  # experiments (tools/ab_knobs.py): the indexed SpringMaxwell kernel, 648 + 4 B/pt
+            self.law = fc.SpringMaxwellModel(SLS_P, fc.StressStrainConstraint.FULL)
+            self.hist = [{k: t.zeros(6 * n_sub, **self.f) for k in ("strain_visco", "strain")} for _ in range(2)]
         if order == "permuted":  # a map no mesh produces: every lane its own 48-byte / 288-byte row anywhere in the parent arrays
             rows = t.randperm(self.n_parent, device=device, generator=self.gen)[:n_sub]
         elif order == "scattered_cells":
@@ -118,7 +122,8 @@ class IndexedRow(FRow):
                      f"({how}), committed -> trial")
 
     def launch(self):
-        self.law.evaluate_indexed(0.0, 1.0, self.grad, self.stress_prev, self.stress, self.tangent, self.rows, None, None)
+        self.law.evaluate_indexed(0.0, 1.0, self.grad, self.stress_prev, self.stress, self.tangent, self.rows,
+                                  None if self.hist is None else self.hist[0], None if self.hist is None else self.hist[1])
 
     def alg_bytes(self):
         return 460 * self.n

@@ -129,10 +129,11 @@ __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& 
 // Main kernel: all full 64-point tiles.  Persistent: wave w of the grid takes tiles
 // w, w + W, w + 2W, ...
 // SPARSE (VonMises3D): 0 plain, 1 sparse trial history, 2 sparse on the packed plastic-strain layout (tile_von_mises: HIST)
-// Waves per SIMD the register budget is cut for: 4 (128 VGPRs), 3 for the Drucker-Prager laws (their return mapping) and for
-// the indexed Maxwell kernel (four loaded arrays plus the per-chunk row look-ups of its tangent spilled 5 VGPRs at 128).
+// Waves per SIMD the register budget is cut for: 4 (128 VGPRs), 3 for the Drucker-Prager laws (their return mapping).  (The
+// indexed Maxwell kernel was cut for 3 as well while its per-lane stress rows spilled at 128; with the chunk-major rows it fits,
+// and 4 waves are worth 16 % to it: 6.24 -> 5.24 ms at 5e7 points on identical buffers.)
 template <int LAW, bool IDX>
-constexpr int kMinBlocks = (LAW >= LAW_COMFE_DP || (LAW == LAW_MAXWELL && IDX)) ? 3 : 4;
+constexpr int kMinBlocks = LAW >= LAW_COMFE_DP ? 3 : 4;
 
 template <int LAW, bool NT, bool IDX, int SPARSE = 0>
 __global__ void __launch_bounds__(kBlock, (kMinBlocks<LAW, IDX>)) evaluate_kernel(const EvalArgs a) {
