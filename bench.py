@@ -22,9 +22,14 @@ stress/tangent all-gather of the single-assembler mode (config 5) is timed separ
 shard -- stress in one piece, tangent in chunks that fit next to the working set -- and reported under
 "allgather", never inside `value`.
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `roofline.traffic` (HBM bytes per launch by the PMC counters) is
-measured at the end of an N = 1 run by two child passes of this file under `rocprofv3 --pmc` (--no-live-traffic: the stored
-figure of profiles/traffic.json instead).
+Rank 0 prints ONE compact JSON line (< 4 KB, numbers only: benchlib/line.py; see DESIGN.md "Measurement") and writes the full
+record -- workload sentences, launch logs, placement candidates, host-path tables, notes -- to the detail file the line names
+(--detail, default gpurun_out/bench_detail.json).  `roofline.traffic` (HBM bytes per launch by the PMC counters) is measured at the
+end of an N = 1 run by two child passes of this file under `rocprofv3 --pmc` (one pass per counter; every measured workload runs in
+the same child: --pmc-child) while the CPU baseline runs on the host (--no-live-traffic: the stored figure of profiles/traffic.json
+instead).  The default command is the lean one (about two minutes); --full adds the per-configuration CPU figures, the small-call
+crossover table, more allocation draws per row and PMC passes for every configuration.  `--plan` prints what a run with these
+arguments WOULD do -- per-leg memory and time estimates, no GPU work.
 """
 
 from __future__ import annotations
@@ -42,7 +47,8 @@ if ROOT not in sys.path:
 from benchlib.cpu import cpu_baseline, cpu_quick  # noqa: E402,F401
 from benchlib.gather import time_allgather  # noqa: E402
 from benchlib.hostpath import host_path_figures, main_host  # noqa: E402,F401
-from benchlib.traffic import library_hash, live_traffic, read_traffic, read_traffic_split, under_profiler  # noqa: E402,F401
+from benchlib.line import compact_line, dumps as dump_line, write_detail  # noqa: E402
+from benchlib.traffic import library_hash, live_traffic_batch, read_traffic, read_traffic_split, under_profiler  # noqa: E402,F401
 from benchlib.workloads import (BASELINE_CONFIG, EXTRA_CONFIGS, HBM_PEAK_GBS, HEADLINE, METRIC, WORKLOADS, Workload, placement_fracs,  # noqa: E402,F401
                                 traffic_key)
 
@@ -77,11 +83,14 @@ class LineGuard:
         self.proc.stdin.write(line + "\n")
         self.proc.stdin.flush()
 
-    def provisional(self, out, leg):
+    def provisional(self, out, leg, detail_path=None):
+        """the line as it stands (compact, like the final one), marked incomplete; the full record goes to the detail file"""
         if self.proc is None:
             return
+        rec = dict(out, incomplete=f"the process ended in the optional leg '{leg}'; everything in this line was measured before it")
+        written = write_detail(rec, detail_path) if detail_path else None
         try:
-            self._send(json.dumps(dict(out, incomplete=f"the process ended in the optional leg '{leg}'; everything in this line was measured before it")))
+            self._send(dump_line(compact_line(rec, written)))
         except (OSError, ValueError):
             self.proc = None
 
@@ -176,6 +185,66 @@ def main_frow(args):
     return 0
 
 
+def main_pmc_child(args):
+    """`--pmc-child A,B,...`: the child of one `rocprofv3 --pmc` pass (benchlib.traffic.live_traffic_batch).  Every named workload
+    (a WORKLOADS name, `+unpacked` / `+in_place` / `+full` for the reference-layout forms of the same step, or a SURVEY 8(f) row
+    of benchlib.frows) is built in turn, on the allocator's arrays as they come (the bytes of a launch do not depend on where its
+    arrays lie), warmed and launched 4 times; the ONE line printed is the ordered log [item, phase, evaluate launches] the parent
+    slices the counter CSV with."""
+    import torch
+
+    from benchlib import frows as bench_frows
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    os.environ["FROW_PLACEMENT"] = "torch"
+    history = "sparse" if args.sparse_history else args.history
+    log = []
+    for k, item in enumerate([x for x in args.pmc_child.split(",") if x]):
+        name, _, form = item.partition("+")
+        try:
+            if name in bench_frows.FROWS:
+                out = bench_frows.run_frow(name, args.n, device, launches=4, warm=2, peak_gbs=HBM_PEAK_GBS, draws=1)
+                log += [[item, ph, c] for ph, c in out["launch_log"]]
+            else:
+                wl = Workload(name, args.n, seed=1234 if name == (args.workload or HEADLINE) else 4321 + k, device=device,
+                              dev_index=device.index or 0, history=history, sparse_tangent=args.sparse_tangent,
+                              split_history=not args.no_split_history)
+                try:
+                    if form == "in_place":
+                        wl.timed_in_place(4, phase="timed")
+                    elif form in ("unpacked", "full"):
+                        kw = {"unpacked": True} if form == "unpacked" else {"full_history": True}
+                        wl.launch(0, sparse_tangent=False, **kw), wl.launch(1, sparse_tangent=False, **kw)
+                        wl.launch_log.append(["warmup", 2])
+                        wl.timed_events(4, phase="timed", sparse_tangent=False, **kw)
+                    else:
+                        wl.warmup(2)
+                        wl.timed_events(4)
+                    log += [[item, ph, c] for ph, c in wl.launch_log]
+                finally:
+                    wl.free()
+        except Exception as e:  # the parent drops this item and everything after it (the dispatch count is unknown from here on)
+            log.append([item, "error", f"{type(e).__name__}: {e}"[:200]])
+            break
+        torch.cuda.empty_cache()
+    print(json.dumps({"metric": METRIC, "pmc_child": True, "log": log}), flush=True)
+    return 0
+
+
+def plan(args):
+    """`--plan`: what a run with these arguments would do -- legs, memory per GPU, time estimates against the driver's limits --
+    from arithmetic alone (no torch, no GPU): lets the first real 8-GPU launch be a one-shot (tests/test_bench_plan.py holds the
+    totals to the limits).  Rates: this round's single-GPU measurements and MI355X_MICROARCH.md (xGMI 153 GB/s per link, 7 links,
+    PCIe 56 GB/s per GPU)."""
+    from benchlib.plan import bench_plan
+
+    print(json.dumps(bench_plan(args), separators=(",", ":")), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +255,13 @@ def main():
     ap.add_argument("--frow", default=None,
                     help="run ONE row of SURVEY 8(f) alone (benchlib.frows.FROWS: indexed evaluate, fused wrapper, low-dimensional kernels, "
                          "resident sparse-tangent iteration) and print its figures -- the child of the default run's PMC passes")
+    ap.add_argument("--pmc-child", default=None, help="(internal) the child of a rocprofv3 --pmc pass: comma-separated workloads / 8(f) rows, see main_pmc_child")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the full record behind the compact stdout line is written (the line carries the path)")
+    ap.add_argument("--full", action="store_true",
+                    help="everything round 4's default ran: per-configuration CPU figures, small-call crossover table, three allocation draws per 8(f) row, "
+                         "four placement candidates per configuration, PMC passes for the configurations too (about four minutes)")
+    ap.add_argument("--plan", action="store_true", help="print the legs, memory and time estimates of a run with these arguments; no GPU work")
     ap.add_argument("--no-frows", action="store_true", help="N = 1 default run: skip the SURVEY 8(f) rows after the BASELINE configurations")
     ap.add_argument("--configs", choices=["auto", "all", "none"], default="auto",
                     help="the other single-GPU BASELINE configurations after the headline: auto = when no --workload is given and N = 1")
@@ -244,7 +320,7 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="N = 1: do not measure roofline.traffic in this run (two child passes under rocprofv3 --pmc, about 40 s); the "
                          "stored figure of profiles/traffic.json is reported instead (labelled as stored)")
-    ap.add_argument("--wall-budget", type=float, default=420.0,
+    ap.add_argument("--wall-budget", type=float, default=300.0,
                     help="seconds of wall clock after which the optional legs (strong-scaling leg, gather variants, extra configurations, host_path) "
                          "are skipped so that the line is printed inside the driver's limit")
     args = ap.parse_args()
@@ -252,6 +328,10 @@ def main():
         args.n = 10_000_000 if args.mode == "host" else 100_000_000
     if args.mode == "host":
         sys.exit(main_host(args))
+    if args.plan:
+        sys.exit(plan(args))
+    if args.pmc_child is not None:
+        sys.exit(main_pmc_child(args))
     if args.frow is not None:
         sys.exit(main_frow(args))
 
@@ -395,6 +475,14 @@ def main():
             wl.launch(i)
         wl.launch_log.append(["strong_scaling_resync", 2])
 
+    legs_s = {"import_and_setup": round(t_start - t_prog, 1), "headline": round(time.perf_counter() - t_start, 1)}  # wall seconds per leg (detail file)
+    t_leg = time.perf_counter()
+
+    def leg_done(name_):
+        nonlocal t_leg
+        legs_s[name_] = round(time.perf_counter() - t_leg, 1)
+        t_leg = time.perf_counter()
+
     # next to the headline: the same step without the sparse protocol (every launch rewrites the whole trial
     # history, fcamd_evaluate_device_from) -- six extra launches after the timed region
     full_ms = None
@@ -409,6 +497,17 @@ def main():
         wl.launch_log.append(["sparse_unpacked_history_warm", 2])
         ms = wl.timed_events(6, phase="sparse_unpacked_history", unpacked=True, sparse_tangent=False)
         unpacked_ms = sum(ms) / len(ms)
+
+    # ... and the reference's own call: law.evaluate(...) IN PLACE on the interface's arrays (what a drop-in torch caller launches;
+    # the committed state is copied into the call's arrays before every launch, outside the event bracket)
+    in_place_ms = None
+    if wl.plasticity and not wl.split and world == 1:
+        try:
+            ms = wl.timed_in_place(5)
+            in_place_ms = sum(ms) / len(ms)
+        except Exception as e:  # informational (e.g. no room for the second copy of the state)
+            stage(f"in-place leg skipped: {type(e).__name__}: {e}")
+    leg_done("reference_layout_legs")
 
     # "achievable" next to "peak" (SURVEY 8d): a plain device copy over half of the tangent array
     # (read + write counted)
@@ -458,9 +557,13 @@ def main():
     cpu_args = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # sample of the headline arrays, taken before they are released for the other configurations
-        cpu_args = (wl.kind, wl.params, wl.grads[0][: 9 * 2_000_000].clone(), wl.stress_c[: 12_000_000].clone(),
-                    None if wl.hist_c is None else {k: v[: {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}[k] * 2_000_000].clone()
-                                                    for k, v in wl.reference_history().items()}, wl.del_t)
+        from benchlib.cpu import host_sample
+
+        cpu_args = host_sample(wl.kind, wl.params, wl.grads[0][: 9 * 2_000_000], wl.stress_c[: 12_000_000],
+                               None if wl.hist_c is None else {k: v[: {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}[k] * 2_000_000]
+                                                               for k, v in wl.reference_history().items()}, wl.del_t)
+    wl.drop_plain_twin()
+    ever_fraction = wl.ever_fraction()
     headline = {"placement": wl.placement, "vmm_info": wl.vmm_info, "launch_log": list(wl.launch_log), "config_text": wl.config_text(), "kind": wl.kind,
                 "b_el": wl.b_el, "b_pl": wl.b_pl, "alg": wl.alg_bytes(n_pl), "alg0": wl.alg_bytes(wl.n_pl_ab[0]),
                 "fracs": placement_fracs(wl, wl.alg_bytes(wl.n_pl_ab[0])), "sparse": wl.sparse, "plasticity": wl.plasticity,
@@ -498,6 +601,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": headline["config_text"],
+                       "workload_short": f"{name}: {headline['kind']} FULL-3D, {n} pts/GPU device-resident, committed->trial evaluate"
+                                         + (", packed sparse history" if headline["packed"] else (", sparse history" if headline["sparse"] else "")),
+                       "ever_fraction": ever_fraction,
                        "baseline_config": BASELINE_CONFIG.get(name),
                        "points_per_gpu": n, "points_total": args.n if (args.scaling == "strong" and world > 1) else n * world,
                        "plastic_fraction": round(n_pl / n, 4),
@@ -536,6 +642,11 @@ def main():
                                               "frac": round(alg_bytes / (unpacked_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                               "note": "same step, same sparse protocol, plastic-strain arrays in the reference's layout "
                                                       "(--history sparse; isolated 48-byte rows instead of one run per tile)"}
+        if in_place_ms is not None:
+            out["in_place"] = {"kernel_ms_avg": round(in_place_ms, 4),
+                               "frac": round(alg_bytes / (in_place_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "same step as the reference's own call: law.evaluate(...) in place on the interface's arrays (reference layout, "
+                                       "no protocol words) -- what a drop-in torch caller launches"}
         out["placement"] = dict(headline["vmm_info"] or {"mode": "hipmalloc_tuned" if headline["placement"] else "first"})
         if headline["placement"] is not None:
             out["placement"].update({"hipmalloc_tangent_" + k: v for k, v in headline["placement"].items()})
@@ -548,12 +659,13 @@ def main():
         out["library"] = {"srchash": library_hash(), "kernel_hash": library_hash(kernels_only=True)}
 
     def emit():
-        out["wall_s"] = round(time.perf_counter() - t_start, 1)
-        guard.final(json.dumps(out))
+        out["wall_s"] = round(time.perf_counter() - t_prog, 1)
+        out["legs_s"] = legs_s
+        guard.final(dump_line(compact_line(out, write_detail(out, args.detail))))
 
     def checkpoint(leg):  # the line as it stands, in case the process does not survive `leg`
         if rank == 0:
-            guard.provisional(dict(out, wall_s=round(time.perf_counter() - t_start, 1)), leg)
+            guard.provisional(dict(out, wall_s=round(time.perf_counter() - t_prog, 1), legs_s=legs_s), leg, args.detail)
             if os.environ.get("BENCH_DIE_IN") == leg.split(":")[0]:  # knob: fault injection (tests/test_gpu_bench_cli.py)
                 os.kill(os.getpid(), 9)
 
@@ -594,6 +706,8 @@ def main():
             out["allgather"] = gather
     wl.free()
 
+    if distributed and world > 1:
+        leg_done("multi_gpu_legs")
     # every other single-GPU configuration of BASELINE.json, same method, >= 5 event-timed launches each
     do_configs = args.configs == "all" or (args.configs == "auto" and args.workload is None and world == 1)
     if do_configs and rank == 0:
@@ -605,11 +719,12 @@ def main():
                 configs[cname] = {"skipped": "wall budget"}
                 continue
             try:
+                # lean default: four hipMalloc candidates of the tangent, no VMM set; --full: four + the VMM set
                 # (under rocprofv3 released VMM memory stays alive: five more working sets would not fit -- hipMalloc candidates only)
+                lean_placement = "tune" if (args.placement == "auto" and (under_profiler() or not args.full)) else args.placement
                 configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
-                                            min(tries, 4), history=history,
-                                            placement="tune" if (args.placement == "auto" and under_profiler()) else args.placement,
-                                            cpu=not args.no_cpu_baseline)
+                                            min(tries, 4), history=history, placement=lean_placement,
+                                            cpu=args.full and not args.no_cpu_baseline)
             except Exception as e:  # one configuration failing must not lose the line
                 configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
@@ -620,6 +735,7 @@ def main():
                 configs[cname]["streaming_model"] = {"ms": round(model_ms, 3),
                                                      "kernel_over_model": round(configs[cname]["kernel_ms_avg"] / model_ms, 3)}
         out["configs"] = configs
+        leg_done("configs")
 
     # the "next" rows of SURVEY 8(f) on the roofline: indexed evaluate (f2), fused wrapper and low-dimensional kernels (f3), the
     # resident state's sparse-tangent Newton iteration (f1) -- same method as the configurations, appended to `configs`
@@ -633,11 +749,13 @@ def main():
                 out["configs"][fname] = {"skipped": "wall budget"}
                 continue
             try:
-                out["configs"][fname] = bench_frows.run_frow(fname, n, device, launches=max(5, args.config_steps), peak_gbs=HBM_PEAK_GBS)
+                out["configs"][fname] = bench_frows.run_frow(fname, n, device, launches=max(5, args.config_steps), peak_gbs=HBM_PEAK_GBS,
+                                                             draws=3 if args.full else 2)
                 frow_names.append(fname)
             except Exception as e:  # one row failing must not lose the line
                 out["configs"][fname] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
+        leg_done("frows")
 
     # N > 1: the single-process form of the host path on THIS node's GPUs (fcamd_multi) -- rank 0 alone drives all
     # of them over their own PCIe links while the other ranks wait on the CPU (a key in the process group's store, not a
@@ -690,37 +808,64 @@ def main():
             checkpoint("host_path")
             try:
                 torch.cuda.empty_cache()
-                out["host_path"] = host_path_figures(devices=None, sizes=(1_000_000, min(n, 10_000_000)) if n > 1_000_000 else (n,))
+                big = min(n, 10_000_000 if args.full else 4_000_000)
+                out["host_path"] = host_path_figures(devices=None, sizes=(1_000_000, big) if n > 1_000_000 else (n,))
             except Exception as e:  # informational: must not lose the line
                 out["host_path"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            leg_done("host_path")
+        # the CPU baseline runs on the host (one thread, inside a C call that releases the GIL) WHILE the PMC child passes keep the GPU busy
+        cpu_thread = None
+        if world == 1:
+            checkpoint("cpu_baseline")
+            if cpu_args is not None:
+                import threading
+
+                def run_cpu():
+                    try:
+                        out["cpu_baseline"] = cpu_baseline(*cpu_args, extras="full" if args.full else "lean")
+                    except Exception as e:  # noqa: BLE001 -- reported, never fatal
+                        out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+                cpu_thread = threading.Thread(target=run_cpu, daemon=True)
+                cpu_thread.start()
+            else:
+                out["cpu_baseline"] = None
         if world == 1 and not args.no_live_traffic and budget_left() > 100:
             # roofline.traffic measured in THIS run (the kernels' memory is free by now); the stored figure stays next to it
             checkpoint("live_traffic")
             extra = (["--no-split-history"] if args.no_split_history else []) \
                 + (["--sparse-tangent"] if args.sparse_tangent else [])
             torch.cuda.empty_cache()
-            lt = live_traffic(name, n, history, extra, min(120.0, budget_left() - 45.0))
+            # ONE child per counter runs every measured item: the headline, its reference-layout forms, the 8(f) rows (--full: the
+            # configurations too)
+            items = [name] + ([name + "+unpacked"] if headline["packed"] else []) + ([name + "+in_place"] if in_place_ms is not None else [])
+            measured = [c for c, v in (out.get("configs") or {}).items() if isinstance(v, dict) and "kernel_ms_avg" in v]
+            items += [c for c in measured if c in frow_names or args.full]
+            lt_all = live_traffic_batch(items, n, history, extra, min(150.0, budget_left() - 30.0), headline=name) or {}
+            lt = lt_all.get(name)
             if lt is not None:
                 rf = out["roofline"]
                 rf["traffic_stored"] = rf["traffic"]
                 rf["traffic"] = lt["hbm_bytes_per_launch"]
                 rf["traffic_read_write"] = [lt["read_bytes"], lt["write_bytes"]]
                 rf["traffic_GBs"] = round(lt["hbm_bytes_per_launch"] / (kernel_avg_ms * 1e-3) / 1e9, 1)
-                rf["traffic_source"] = ("measured in this run: two child passes of this workload under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                rf["traffic_source"] = ("measured in this run: two child passes under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                                         "(4 timed launches each; KiB x 1024, FETCH_SIZE x 2 on gfx950); traffic_stored = profiles/traffic.json")
-                # ... and the other configurations of the line, the same way, while the budget lasts
-                for cname, c in (out.get("configs") or {}).items():
-                    if "kernel_ms_avg" not in c or budget_left() < 110:
-                        continue
-                    checkpoint(f"live_traffic: {cname}")
-                    lc = live_traffic(cname, n, history, extra, min(60.0, budget_left() - 60.0), frow=cname in frow_names)
-                    if lc is not None:
-                        c["traffic_stored"], c["traffic"] = c.get("traffic"), lc["hbm_bytes_per_launch"]
-                        c["traffic_source"] = "measured in this run (rocprofv3 --pmc child passes, as roofline.traffic)"
-                        c["traffic_over_algorithmic"] = round(lc["hbm_bytes_per_launch"] / c["algorithmic_bytes_per_launch"], 4)
-        if world == 1:
-            checkpoint("cpu_baseline")
-            out["cpu_baseline"] = cpu_baseline(*cpu_args) if cpu_args is not None else None
+            for form, key in (("+unpacked", "sparse_unpacked_history"), ("+in_place", "in_place")):
+                lf = lt_all.get(name + form)
+                if lf is not None and key in out:
+                    out[key]["traffic"] = lf["hbm_bytes_per_launch"]
+                    out[key]["traffic_over_algorithmic"] = round(lf["hbm_bytes_per_launch"] / out["roofline"]["algorithmic_bytes_per_launch"], 4)
+            for cname, c in (out.get("configs") or {}).items():
+                lc = lt_all.get(cname)
+                if lc is not None and isinstance(c, dict) and c.get("algorithmic_bytes_per_launch"):
+                    c["traffic_stored"], c["traffic"] = c.get("traffic"), lc["hbm_bytes_per_launch"]
+                    c["traffic_source"] = "measured in this run (rocprofv3 --pmc child passes, as roofline.traffic)"
+                    c["traffic_over_algorithmic"] = round(lc["hbm_bytes_per_launch"] / c["algorithmic_bytes_per_launch"], 4)
+            leg_done("live_traffic")
+        if cpu_thread is not None:
+            cpu_thread.join()
+            leg_done("cpu_baseline_after_traffic")
         emit()
     if distributed:
         dist.barrier()

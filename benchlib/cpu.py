@@ -48,19 +48,28 @@ def cpu_quick(wl, budget_s=1.0, ns=1_000_000):
     return out
 
 
-def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
+def host_sample(kind, params, grad, stress, hist, del_t):
+    """the sample of the headline arrays as NumPy arrays (device -> host copies, on the calling thread)"""
+    from fenics_constitutive_amd.hostio import to_host
+
+    return (kind, params, to_host(grad), to_host(stress), None if hist is None else {k: to_host(v) for k, v in hist.items()}, del_t)
+
+
+def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0, extras="full"):
     """Time the C oracle ("port": serial per-point loop, 1 thread -- what the reference does per
-    MPI rank) on a bounded sample of the same workload."""
+    MPI rank) on a bounded sample of the same workload (NumPy arrays: host_sample()).  extras: "full" adds the small-call
+    crossover table (GPU calls: not while a PMC pass is running) and longer side figures, "lean" (the default command)
+    keeps the side figures short."""
     import numpy as np
 
-    from fenics_constitutive_amd.hostio import to_host
     from oracle import c_oracle as CO
 
-    ns = min(grad.numel() // 9, 2_000_000)
-    g = to_host(grad[: 9 * ns])
-    s0 = to_host(stress[: 6 * ns])
+    ns = min(grad.size // 9, 2_000_000)
+    g = grad[: 9 * ns]
+    s0 = stress[: 6 * ns]
     dims = {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}
-    h0 = None if hist is None else {k: to_host(v[: dims[k] * ns]) for k, v in hist.items()}
+    h0 = None if hist is None else {k: v[: dims[k] * ns] for k, v in hist.items()}
+    side_s = 1.5 if extras == "full" else 0.8
     tan = np.zeros(36 * ns)
     fn = CO.MODELS[kind]
 
@@ -106,7 +115,7 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
             hr.reshape(-1, 7)[:, 0] = h0["alpha"]
             rs_p = {"mu": params["p_mu"], "kappa": params["p_ka"], "y_0": params["p_y0"], "h": 200.0}
             tt, rr = 0.0, 0
-            while tt < 1.5 and rr < 100:
+            while tt < side_s and rr < 100:
                 s, hh = s0.copy(), {"history": hr.copy()}
                 t0 = time.perf_counter()
                 CO.MODELS["comfe_mises_plasticity"](rs_p, 0.0, del_t, g, s, tan, hh)
@@ -131,7 +140,7 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
         CO.set_num_threads(nthr)
         one_pass()
         tt, rr = 0.0, 0
-        while tt < 1.5 and rr < 200:
+        while tt < side_s and rr < 200:
             tt += one_pass()
             rr += 1
         CO.set_num_threads(1)
@@ -140,10 +149,11 @@ def cpu_baseline(kind, params, grad, stress, hist, del_t, budget_s=8.0):
         out["extra"] = extra
     except Exception as e:  # the extra figures are informational only
         out["extra"] = {"error": str(e)}
-    try:
-        out["small_call_crossover"] = small_call_crossover()
-    except Exception as e:  # informational
-        out["small_call_crossover"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    if extras == "full":
+        try:
+            out["small_call_crossover"] = small_call_crossover()
+        except Exception as e:  # informational
+            out["small_call_crossover"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out
 
 

@@ -202,5 +202,10 @@ def main_host(args):
     if out["roofline"]["peak"]:
         out["roofline"]["frac"] = round(out["roofline"]["achieved"] / out["roofline"]["peak"], 4)
     out["wall_s"] = round(time.perf_counter() - t_start, 1)
-    print(json.dumps(out), flush=True)
+    from benchlib.line import compact_line, dumps, write_detail
+
+    line = compact_line(out, write_detail(out, args.detail))  # the full record (host_path tables, notes) is the detail file
+    line["mode"] = "host"
+    line["config"].update({"devices_used": used, "devices": len(devices)})
+    print(dumps(line), flush=True)
     return 0

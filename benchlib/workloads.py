@@ -377,6 +377,40 @@ class Workload:
         self.launch_log.append([phase, steps])
         return [a.elapsed_time(b) for a, b in ev]
 
+    def timed_in_place(self, steps, phase="in_place"):
+        """The reference's own call, `law.evaluate(t, del_t, grad, stress, tangent, history)` IN PLACE on arrays in the interface's
+        layout (models/interfaces.py:82-101) -- what a drop-in caller with device tensors launches.  The committed state is copied
+        into the call's arrays before every launch, outside the event bracket (the call overwrites them); one warm launch, then
+        `steps` event-timed ones.  Returns the kernel times in ms."""
+        torch = self.torch
+        ref = self.reference_history()
+        s = torch.empty_like(self.stress_c)
+        h = None if ref is None else {k: torch.empty_like(v) for k, v in ref.items()}
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps + 1)]
+        for i, (a, b) in enumerate(ev):
+            s.copy_(self.stress_c)
+            for k in (h or {}):
+                h[k].copy_(ref[k])
+            a.record()
+            self.law.evaluate(0.0, self.del_t, self.grads[i & 1], s, self.tangent, h)
+            b.record()
+        torch.cuda.synchronize()
+        self.launch_log.append(["in_place_warm", 1])
+        self.launch_log.append([phase, steps])
+        return [a.elapsed_time(b) for a, b in ev[1:]]
+
+    def ever_fraction(self):
+        """share of the points whose plastic-strain row is in the committed EVER set (packed layout): what the packed runs hold
+        before the timed steps -- the warm increment's plastic set, not an empty one"""
+        if not self.packed or self.ever_c is None:
+            return None
+        t = self.torch
+        shifts = t.arange(64, device=self.device, dtype=t.int64)
+        total = 0
+        for part in self.ever_c.split(1 << 18):  # bounded temporaries
+            total += int(((part[:, None] >> shifts[None, :]) & 1).sum())
+        return round(total / self.n, 4)
+
     def config_text(self):
         return (f"{self.name}: {self.kind} FULL-3D, {self.n} quadrature points per GPU, device-resident AoS, "
                 f"committed->trial evaluate of two alternating Newton iterates"

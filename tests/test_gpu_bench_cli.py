@@ -26,15 +26,44 @@ def free_port():
         return s.getsockname()[1]
 
 
+LAST_LINE = {}  # the compact stdout line of the last run_bench call (the tests below read the full record, the detail file)
+
+
+def check_line(stdout, detail_path):
+    """ONE JSON line on stdout, whatever happened; compact (the driver keeps an 8 KB tail: round 4's 22 KB line came back
+    unparsed); it names the detail file, whose record agrees with it.  Returns (line, full record)."""
+    from benchlib.line import MAX_LINE_BYTES
+
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) <= 1 and all(ln.startswith("{") for ln in lines), stdout[-3000:]
+    if not lines:
+        return None, None
+    assert len(lines[0]) < MAX_LINE_BYTES, len(lines[0])
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert key in line, key
+    assert isinstance(line["config"]["workload"], str) and line["roofline"]["bound"] in ("hbm", "pcie")
+    assert line.get("detail") == detail_path, line.get("detail")
+    with open(detail_path) as f:
+        detail = json.load(f)
+    assert detail["value"] == line["value"] and detail["ms_per_step"] == line["ms_per_step"]
+    return line, detail
+
+
 def run_bench(*args, timeout=420, env=None, live_traffic=False):
+    import tempfile
+
     e = dict(os.environ, MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     e.update(env or {})
     if not live_traffic and "--mode" not in args:
         args = (*args, "--no-live-traffic")  # (two more child processes under rocprofv3 --pmc: one test below runs them)
-    r = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) <= 1, r.stdout[-3000:]  # ONE JSON line, whatever happened
-    return r, (json.loads(lines[-1]) if lines else None)
+    with tempfile.TemporaryDirectory(prefix="fcamd_bench_") as d:
+        detail_path = os.path.join(d, "detail.json")
+        r = subprocess.run([sys.executable, BENCH, *args, "--detail", detail_path], capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+        line, detail = check_line(r.stdout, detail_path)
+    LAST_LINE.clear()
+    LAST_LINE.update(line or {})
+    return r, detail
 
 
 def test_two_ranks_weak_scaling_with_strong_leg_and_gather():
@@ -144,6 +173,12 @@ def test_default_line_carries_the_host_path_block():
         assert "measured in this run" in rf["traffic_source"], rf.get("traffic_source")
         assert rf["algorithmic_bytes_per_launch"] * 0.99 <= rf["traffic"] <= rf["algorithmic_bytes_per_launch"] * 1.25, rf
         assert sum(rf["traffic_read_write"]) == rf["traffic"]
+        assert LAST_LINE["roofline"]["traffic_source"] == "live_pmc" and LAST_LINE["roofline"]["traffic"] == rf["traffic"]
+        # the reference-layout forms of the same step were measured by the same child passes
+        for key in ("sparse_unpacked_history", "in_place"):
+            assert 0.99 <= out[key]["traffic_over_algorithmic"] <= 1.3, out[key]
+    for key in ("frac_reference_layout", "frac_in_place", "frac_full_history"):
+        assert 0 < LAST_LINE["roofline"][key] < 1, key
     hp = out["host_path"]
     assert "error" not in hp, hp
     assert set(hp["sizes"]) == {"1000000", "2000000"}
@@ -151,18 +186,20 @@ def test_default_line_carries_the_host_path_block():
     assert out["roofline"]["traffic"] is None or "traffic_source" in out["roofline"]
 
 
-def test_one_rank_under_the_launcher_with_rccl():
+def test_one_rank_under_the_launcher_with_rccl(tmp_path):
     """The driver's launch shape (python -m torch.distributed.run ... bench.py --gpus N) with N = 1: the process group is
     RCCL, the barriers / all-reduces of the timed region and of the per-rank kernel times run on the device."""
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), BENCH, "--gpus", "1", "--steps", "3", "--warmup", "1", "--points", "2000000",
-           "--configs", "none", "--no-cpu-baseline", "--no-host-path", "--placement-tries", "2"]
+           "--configs", "none", "--no-cpu-baseline", "--no-host-path", "--placement-tries", "2", "--no-live-traffic", "--detail", os.path.join(tmp_path, "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["per_rank_kernel_ms"] and len(out["per_rank_kernel_ms"]) == 1
-    assert "allgather" not in out and "strong_scaling" not in out and "host_path" not in out and "host_path_multi" not in out
+    assert "allgather" not in out and "strong_scaling" not in out and "host_path_Mpts_s" not in out and "host_path_multi_Mpts_s" not in out
     assert abs(out["value"] - 2_000_000 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) <= 0.01 * out["value"]
 
 
@@ -183,3 +220,9 @@ def test_default_legs_at_small_size_carry_every_configuration_and_8f_row():
         assert c["kernel_ms_avg"] > 0 and 0 < c["frac"] < 1.2, (name, c)
         assert c["launch_log"] and c["launch_log"][-1][0] == "timed", (name, c["launch_log"])
     assert set(frows.SURVEY_ROW) == set(frows.FROWS)
+    # the compact line: one short list per configuration, columns named once
+    from benchlib.line import CONFIG_COLUMNS
+
+    assert LAST_LINE["configs_columns"] == CONFIG_COLUMNS and set(LAST_LINE["configs"]) == set(cfg)
+    for name, row in LAST_LINE["configs"].items():
+        assert row[0] == cfg[name]["frac"] and row[2] == cfg[name]["kernel_ms_avg"], (name, row)
