@@ -153,7 +153,7 @@ struct MaskedRows {
         if (masked) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                row_live[k] = ((rows >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
+                row_live[k] = rows_granule_live(rows, k * kWave + lane);
                 d2 v;
                 v.x = 0.0;
                 v.y = 0.0;
@@ -288,7 +288,7 @@ struct SplitRows {
         if (masked) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                row_live[k] = ((rows >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
+                row_live[k] = rows_granule_live(rows, k * kWave + lane);
                 d2 v;
                 v.x = 0.0;
                 v.y = 0.0;
@@ -313,7 +313,7 @@ struct SplitRows {
             return;  // only stale rows: they leave as the chunks they came as
         const bool plastic = ((mask >> lane) & 1ull) != 0ull;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = (plastic || !packed) ? ep[i] + d[i] : ep[i];
+        for (int i = 0; i < 6; ++i) d[i] = plastic ? ep[i] + d[i] : ep[i];  // the others keep their bits (whole granules move: a neighbour's chunks leave as they came)
     }
     __device__ __forceinline__ void store(const EvalArgs& a, long long p0, int npts, int lane, unsigned long long mask,
                                           bool hist_in_place, double* region, double scalar, const double (&d)[6]) {

@@ -129,7 +129,6 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     if constexpr (packed) {
         if (early) pk.load(a.h0_in, p0, lane);
     }
-
     double g[9], s[6], e[6];
     transpose_in<9>(cg, region, lane, g);
     sr.get(region, lane, s);
@@ -167,7 +166,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     bool row_live[3] = {true, true, true};  // per chunk of this lane: its row is touched
     if (masked) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) row_live[k] = ((eps_mask >> ((k * kWave + lane) / 3)) & 1ull) != 0ull;
+        for (int k = 0; k < 3; ++k) row_live[k] = rows_granule_live(eps_mask, k * kWave + lane);
     }
     if constexpr (packed) {
         if (!early && touch_eps) {  // a tile that turns plastic now, or one with few touched rows in a long run: the late request
@@ -220,7 +219,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
     } else if (touch_eps) {
         if (mask != 0ull) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ep[i] = ep[i] + rm.gamma * rm.N[i];
+            for (int i = 0; i < 6; ++i) ep[i] = plastic ? ep[i] + rm.gamma * rm.N[i] : ep[i];  // the others keep their bits
             if (masked) {
                 lds_put_point<6>(region, lane, ep);
                 wave_sync();
@@ -289,7 +288,7 @@ __device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const 
     wrapped_store_stress<WRAP, FULL, NT>(a, region, p0, npts, lane, s);
     if (mask != 0ull) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) ep[i] = ep[i] + rm.gamma * rm.N[i];
+        for (int i = 0; i < 6; ++i) ep[i] = plastic ? ep[i] + rm.gamma * rm.N[i] : ep[i];  // the others keep their bits
         er.store(a.h0_out, p0, npts, lane, region, ep);
         // alpha, in place: the 32-byte sectors that hold a plastic point (the others keep their value; whole sectors so that no
         // partial sector is written: -2 % on identical buffers at 6 % plastic points against the whole tile's 512 bytes)

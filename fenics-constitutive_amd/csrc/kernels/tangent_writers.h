@@ -39,7 +39,8 @@ __device__ __forceinline__ void tangent_const_masked(const double* tab, double* 
         const int q = k * kWave + lane;
         const int p = q / 18;
         d2 v = reinterpret_cast<const d2*>(tab)[q - 18 * p];
-        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q, p);
+        if ((FULL || q < nchunks) && wanted) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
     }
 }
 
@@ -105,7 +106,8 @@ __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta
             v.x = (a.x + bc.x * b.x) + bc.y * (ni * nj.x);
             v.y = (a.y + bc.x * b.y) + bc.y * (ni * nj.y);
         }
-        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q, p);
+        if ((FULL || q < nchunks) && wanted) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         // bound the register pressure: let the scheduler interleave at most 3 chunks
         if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }

@@ -34,8 +34,8 @@ def check_line(stdout, detail_path):
     unparsed); it names the detail file, whose record agrees with it.  Returns (line, full record)."""
     from benchlib.line import MAX_LINE_BYTES
 
-    lines = [ln for ln in stdout.splitlines() if ln.strip()]
-    assert len(lines) <= 1 and all(ln.startswith("{") for ln in lines), stdout[-3000:]
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]  # (the gloo rehearsal backend prints "[Gloo] Rank ..." lines of its own)
+    assert len(lines) <= 1, stdout[-3000:]
     if not lines:
         return None, None
     assert len(lines[0]) < MAX_LINE_BYTES, len(lines[0])

@@ -18,6 +18,7 @@ libs = [a for a in sys.argv[1:] if a.endswith('.so')]
 sizes = [int(float(x)) for x in sys.argv[1:] if not x.endswith('.so')] or [1_000_000, 10_000_000, 100_000_000]
 LAW = os.environ.get("AB_LAW", "vm")  # vm | le | maxwell
 SPARSE = os.environ.get("AB_SPARSE", "0") == "1"
+FLAGS = int(os.environ.get("AB_FLAGS", "0"))  # fcamd_eval_args.flags of the sparse protocol's launches (1 = sparse tangent)
 ZONED = os.environ.get("AB_ZONED", "0") == "1"
 CONSTRAINT = int(os.environ.get("AB_CONSTRAINT", "5"))
 MODEL = {"vm": (2, [175000.0, 80769.0, 1200.0, 2500.0, 200.0], 2), "le": (1, [42.0, 0.3], 0), "maxwell": (3, [42.0, 10.0, 10.0, 0.2], 2)}[LAW]
@@ -37,6 +38,7 @@ class Lib:
         assert self.l.fcamd_model_create(self.ctx, MODEL[0], CONSTRAINT, P, len(MODEL[1]), C.byref(self.m)) == 0
         self.l.fcamd_evaluate_device_ex.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs)]
         self.mask = None
+        self.warm = False
 
     def run(self, n, g, s0, s1, t, h0, h1):
         a0 = (C.c_void_p * 2)(h0[0].data_ptr(), h0[1].data_ptr())
@@ -46,7 +48,10 @@ class Lib:
                 # protocol: trial == committed wherever the mask is clear
                 h1[0].copy_(h0[0]), h1[1].copy_(h0[1])
                 self.mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
-            x = EvalArgs(g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, MODEL[2], None, self.mask.data_ptr(), 0,
+                self.warm = False
+            flags = FLAGS if self.warm else 0  # the first launch of a size writes the whole tangent (the sparse-tangent protocol's premise)
+            self.warm = True
+            x = EvalArgs(g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, MODEL[2], None, self.mask.data_ptr(), flags,
                          None, None, None, None, 0, None)
             rc = self.l.fcamd_evaluate_device_ex(self.m, 0.0, 1.0, n, C.byref(x))
             assert rc == 0, rc
