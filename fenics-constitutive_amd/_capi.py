@@ -41,7 +41,7 @@ HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT, HOST_TEMP_LOCK, HOST_BOUNCE = 1, 2, 4, 8
 SYMBOLS = [
     "fcamd_context_create", "fcamd_context_destroy", "fcamd_context_set_stream", "fcamd_context_synchronize",
     "fcamd_model_create", "fcamd_model_destroy", "fcamd_model_get_info",
-    "fcamd_evaluate_host", "fcamd_evaluate_device_ex", "fcamd_evaluate_resident",
+    "fcamd_evaluate_host", "fcamd_evaluate_device_ex", "fcamd_evaluate_batch", "fcamd_evaluate_resident",
     "fcamd_strain_from_grad_u_device", "fcamd_convert_device", "fcamd_map_rows_device", "fcamd_model_last_stats",
     "fcamd_register_host_buffer", "fcamd_unregister_host_buffer", "fcamd_host_device_pointer", "fcamd_copy",
     "fcamd_shard_bounds", "fcamd_gather_chunk_plan", "fcamd_ipc_export", "fcamd_ipc_open", "fcamd_ipc_close",
@@ -155,6 +155,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         lib.fcamd_context_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
         lib.fcamd_evaluate_host.argtypes = [vp, C.c_double, C.c_double, C.c_int64, vp, vp, vp, C.POINTER(vp), C.c_int, C.POINTER(Stats)]
         lib.fcamd_evaluate_device_ex.argtypes = [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs)]
+        lib.fcamd_evaluate_batch.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(EvalArgs), C.c_double, C.c_double]
         lib.fcamd_evaluate_resident.argtypes = [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs), vp, vp, C.POINTER(Stats)]
         lib.fcamd_strain_from_grad_u_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int]
         lib.fcamd_convert_device.argtypes = [vp, C.c_int, C.c_int64, vp, vp]
@@ -415,6 +416,63 @@ def default_device() -> int:
 _tls = threading.local()
 
 
+class PreparedBatch:
+    """the argument arrays of one ``fcamd_evaluate_batch``, kept so that the same call (same arrays, same ``t`` / ``del_t``) can be
+    issued again without rebuilding them: ``launch()``"""
+
+    def __init__(self, calls, t, del_t):
+        k = len(calls)
+        self.count, self.t, self.del_t = k, C.c_double(t), C.c_double(del_t)
+        self.ctx = calls[0][0].ctx
+        self._lib = calls[0][0]._lib
+        self._keep = calls  # the models (handles) and the per-call pointer arrays the structs point into
+        self.models = (C.c_void_p * k)(*[m.handle for m, _, _, _ in calls])
+        self.ns = (C.c_int64 * k)(*[n for _, n, _, _ in calls])
+        self.args = (EvalArgs * k)(*[x for _, _, x, _ in calls])
+
+    def launch(self):
+        check(self._lib.fcamd_evaluate_batch(self.count, self.models, self.ns, self.args, self.t, self.del_t))
+
+
+class batched_launches:
+    """``with batched_launches():`` -- the device calls made inside the block (``Model.evaluate_device_ex``, i.e. every
+    ``DeviceLaw.evaluate_from`` / ``evaluate_indexed`` on device tensors) are recorded and leave together as ONE
+    ``fcamd_evaluate_batch`` when the block ends: the laws of one ``form()`` (solver/_solver.py:143-144) in one trip through the
+    binding, the small ones concurrently on the context's side streams.  A call with another context, ``t`` or ``del_t`` than
+    the recorded ones flushes what has been recorded first.  Not re-entrant; per thread."""
+
+    def __init__(self):
+        self.calls = []  # (model, n, args, keep-alive)
+        self.key = None
+        self.prepared = []  # what left: one PreparedBatch per flush (a caller whose arrays do not move may launch it again)
+
+    def __enter__(self):
+        assert getattr(_tls, "batch", None) is None, "batched_launches is not re-entrant"
+        _tls.batch = self
+        return self
+
+    def add(self, model, t, del_t, n, x, keep):
+        key = (id(model.ctx), t, del_t)
+        if self.key is not None and key != self.key:
+            self.flush()
+        self.key = key
+        self.calls.append((model, n, x, keep))
+
+    def flush(self):
+        calls, key, self.calls, self.key = self.calls, self.key, [], None
+        if not calls:
+            return
+        prepared = PreparedBatch(calls, key[1], key[2])
+        self.prepared.append(prepared)
+        prepared.launch()
+
+    def __exit__(self, exc_type, exc, tb):
+        _tls.batch = None
+        if exc_type is None:
+            self.flush()
+        return False
+
+
 def get_context(device: int = 0) -> Context:
     ctxs = _tls.__dict__.setdefault("contexts", {})
     ctx = ctxs.get(int(device))
@@ -605,13 +663,19 @@ class Model:
     def evaluate_device_ex(self, t, del_t, n, grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr, hist_prev_ptrs,
                            hist_ptrs, rows_ptr=None, mask_ptr=None, flags: int = 0, stress2_ptr=None,
                            counters_ptr=None, packed_mask_ptrs=None, wrapper_constraint: int = 0, stress3d_ptr=None) -> None:
-        """``fcamd_evaluate_device_ex``: THE device entry, every form of the call in one argument struct"""
+        """``fcamd_evaluate_device_ex``: THE device entry, every form of the call in one argument struct.  Inside a
+        ``batched_launches()`` block the call is recorded and leaves with the block's other calls as ONE
+        ``fcamd_evaluate_batch``."""
         arr, nh = self._ptr_array(hist_ptrs)
         parr, _ = self._ptr_array(hist_prev_ptrs)
         pm_prev, pm = packed_mask_ptrs or (None, None)
         x = EvalArgs(grad_ptr, stress_prev_ptr, stress_ptr, tangent_ptr or None, parr, arr, nh, rows_ptr or None,
                      mask_ptr or None, int(flags), stress2_ptr or None, counters_ptr or None, pm_prev or None, pm or None,
                      int(wrapper_constraint), stress3d_ptr or None)
+        batch = getattr(_tls, "batch", None)
+        if batch is not None and not wrapper_constraint:
+            batch.add(self, float(t), float(del_t), int(n), x, (arr, parr))
+            return
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
 
     def evaluate_device_wrapped(self, wrapper_constraint, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, stress3d_ptr,

@@ -284,8 +284,8 @@ void options_from_env(Options* o) {
         const char* e = getenv(name);
         return (e && *e) ? atoll(e) : dflt;
     };
-    o->tile_map = (int)geti("FCAMD_TILE_MAP", 0);
     o->masked_max = (int)geti("FCAMD_MASKED_MAX", -1);
+    o->batch_graph = (int)geti("FCAMD_BATCH_GRAPH", 1);
     o->host_chunk = geti("FCAMD_HOST_CHUNK", 0);
     o->host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, geti("FCAMD_HOST_SLOTS", fcamd_context::kSlots)));
     o->zero_copy = geti("FCAMD_ZERO_COPY", 1) != 0;
@@ -405,7 +405,6 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.n = n;
     a.counters = counters ? counters : m->d_counters;  // caller-owned counters are always reset here
     const Options& o = m->ctx->opt;
-    a.tile_map = o.tile_map;
     a.masked_max = o.masked_max >= 0 ? o.masked_max  // split history: 48-byte eps_p rows, as VonMises3D's eps_n
                                      : ((m->law == FCAMD_VON_MISES_3D || split) ? kMaskedRowMaxVonMises : kMaskedRowMaxRows7);
     constants_for(m, del_t);
@@ -515,8 +514,8 @@ int fcamd_context_set_option(fcamd_context* c, const char* name, long long value
     std::lock_guard<std::recursive_mutex> lock(c->host_mu);
     const std::string k(name);
     Options& o = c->opt;
-    if (k == "tile_map") o.tile_map = (int)value;
-    else if (k == "masked_max") o.masked_max = (int)value;
+    if (k == "masked_max") o.masked_max = (int)value;
+    else if (k == "batch_graph") o.batch_graph = (int)value;
     else if (k == "host_chunk") o.host_chunk = value;
     else if (k == "host_slots") o.host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, value));
     else if (k == "zero_copy") o.zero_copy = value != 0;
@@ -534,8 +533,8 @@ int fcamd_context_get_option(fcamd_context* c, const char* name, long long* valu
     if (!c || !name || !value) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     const std::string k(name);
     const Options& o = c->opt;
-    if (k == "tile_map") *value = o.tile_map;
-    else if (k == "masked_max") *value = o.masked_max;
+    if (k == "masked_max") *value = o.masked_max;
+    else if (k == "batch_graph") *value = o.batch_graph;
     else if (k == "host_chunk") *value = o.host_chunk;
     else if (k == "host_slots") *value = o.host_slots;
     else if (k == "zero_copy") *value = o.zero_copy;
@@ -563,6 +562,13 @@ int fcamd_context_destroy(fcamd_context* c) {
     for (hipEvent_t e : c->peer_events)
         if (e) (void)hipEventDestroy(e);
     for (auto& kv : c->ipc_open) (void)hipIpcCloseMemHandle(kv.second.base);
+    for (int i = 0; i < fcamd_context::kBatchStreams; ++i) {
+        if (c->batch_stream[i]) (void)hipStreamDestroy(c->batch_stream[i]);
+        if (c->batch_join[i]) (void)hipEventDestroy(c->batch_join[i]);
+    }
+    if (c->batch_fork) (void)hipEventDestroy(c->batch_fork);
+    if (c->batch_origin) (void)hipStreamDestroy(c->batch_origin);
+    for (auto& g : c->batch_graphs) (void)hipGraphExecDestroy(g.exec);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FCAMD_OK;
@@ -658,16 +664,8 @@ int fcamd_model_get_info(const fcamd_model* m, fcamd_model_info* info) {
     return FCAMD_OK;
 }
 
-int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, const fcamd_eval_args* x) {
-    (void)t;
-    if (!x) return fail(FCAMD_ERR_BAD_ARG, "args is NULL");
-    if (x->wrapper_constraint != 0) {  // the fused 3D -> 1D/2D wrapper form
-        if (x->parent_rows || x->history_mask || x->stress2 || x->counters || x->flags != 0)
-            return fail(FCAMD_ERR_UNSUPPORTED, "the fused wrapper form takes no parent_rows / history_mask / stress2 / counters / flags");
-        if (x->stress_prev != x->stress || (x->n_hist > 0 && x->history_prev != const_cast<const double* const*>(x->history)))
-            return fail(FCAMD_ERR_BAD_ARG, "the fused wrapper form is in place: stress_prev == stress, history_prev == history");
-        return evaluate_wrapped(m, x->wrapper_constraint, del_t, n, x->grad_del_u, x->stress, x->tangent, x->stress_3d, x->history, x->n_hist);
-    }
+// the checks of one device call (every form but the fused wrapper one); nothing is launched
+static int check_device_ex(fcamd_model* m, double del_t, int64_t n, const fcamd_eval_args* x) {
     int st = validate_call(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress,
                            reinterpret_cast<const void* const*>(x->history_prev),
                            reinterpret_cast<const void* const*>(x->history), x->n_hist, x->flags);
@@ -693,7 +691,7 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
         if (x->history[kd] == x->history_prev[kd] || x->packed_mask == x->packed_mask_prev)
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_PACKED_HISTORY needs trial plastic-strain and mask arrays of their own");
     }
-    if (!aligned16(x->grad_del_u) || !aligned16(x->stress) || !aligned16(x->stress_prev) || !aligned16(x->tangent))
+    if (!aligned16(x->grad_del_u) || !aligned16(x->stress) || !aligned16(x->stress_prev) || !aligned16(x->tangent) || !aligned16(x->stress2))
         return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
     for (int k = 0; k < x->n_hist; ++k)
         if (!aligned16(x->history[k]) || !aligned16(x->history_prev[k]))
@@ -703,17 +701,160 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
         if ((x->history[0] == x->history_prev[0]) != (x->history[1] == x->history_prev[1]))
             return fail(FCAMD_ERR_BAD_ARG, "FCAMD_EVAL_SPLIT_HISTORY: both history arrays in place or both out of place");
     }
+    return FCAMD_OK;
+}
+
+static int enqueue_ex(fcamd_model* m, double del_t, int64_t n, const fcamd_eval_args* x, hipStream_t stream, bool reset_counters) {
+    return enqueue(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history,
+                   stream, reset_counters, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask), x->flags,
+                   x->stress2, reinterpret_cast<unsigned long long*>(x->counters),
+                   (x->flags & FCAMD_EVAL_PACKED_HISTORY) ? reinterpret_cast<const unsigned long long*>(x->packed_mask_prev) : nullptr,
+                   (x->flags & FCAMD_EVAL_PACKED_HISTORY) ? reinterpret_cast<unsigned long long*>(x->packed_mask) : nullptr);
+}
+
+int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, const fcamd_eval_args* x) {
+    (void)t;
+    if (!x) return fail(FCAMD_ERR_BAD_ARG, "args is NULL");
+    if (x->wrapper_constraint != 0) {  // the fused 3D -> 1D/2D wrapper form
+        if (x->parent_rows || x->history_mask || x->stress2 || x->counters || x->flags != 0)
+            return fail(FCAMD_ERR_UNSUPPORTED, "the fused wrapper form takes no parent_rows / history_mask / stress2 / counters / flags");
+        if (x->stress_prev != x->stress || (x->n_hist > 0 && x->history_prev != const_cast<const double* const*>(x->history)))
+            return fail(FCAMD_ERR_BAD_ARG, "the fused wrapper form is in place: stress_prev == stress, history_prev == history");
+        return evaluate_wrapped(m, x->wrapper_constraint, del_t, n, x->grad_del_u, x->stress, x->tangent, x->stress_3d, x->history, x->n_hist);
+    }
+    int st = check_device_ex(m, del_t, n, x);
+    if (st != FCAMD_OK) return st;
     fcamd_context* c = m->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    if (!aligned16(x->stress2)) return fail(FCAMD_ERR_ALIGN, "device arrays must be 16-byte aligned");
     if ((st = timing_begin(m)) != FCAMD_OK) return st;
-    st = enqueue(m, del_t, n, x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history,
-                 c->stream, !m->timed, x->parent_rows, reinterpret_cast<unsigned long long*>(x->history_mask), x->flags,
-                 x->stress2, reinterpret_cast<unsigned long long*>(x->counters),
-                 (x->flags & FCAMD_EVAL_PACKED_HISTORY) ? reinterpret_cast<const unsigned long long*>(x->packed_mask_prev) : nullptr,
-                 (x->flags & FCAMD_EVAL_PACKED_HISTORY) ? reinterpret_cast<unsigned long long*>(x->packed_mask) : nullptr);
+    st = enqueue_ex(m, del_t, n, x, c->stream, !m->timed);
     if (st != FCAMD_OK) return st;
     return timing_end(m);
+}
+
+// fork the context's side streams from `origin`, enqueue every call (small laws on side streams, the others on `origin`), join
+static int batch_enqueue(fcamd_context* c, hipStream_t origin, int count, fcamd_model* const* models, const int64_t* n,
+                         const fcamd_eval_args* args, double del_t, int64_t small, int n_small, bool may_fork = true) {
+    static const bool env_fork = !(getenv("FCAMD_BATCH_FORK") && atoi(getenv("FCAMD_BATCH_FORK")) == 0);  // TEMPORARY experiment knob
+    const bool fork = env_fork && may_fork && n_small > 1;
+    int used = 0;
+    if (fork) {
+        used = n_small < fcamd_context::kBatchStreams ? n_small : fcamd_context::kBatchStreams;
+        HIP_TRY(hipEventRecord(c->batch_fork, origin));
+        for (int s = 0; s < used; ++s) HIP_TRY(hipStreamWaitEvent(c->batch_stream[s], c->batch_fork, 0));
+    }
+    int status = FCAMD_OK, next = 0;
+    for (int k = 0; k < count && status == FCAMD_OK; ++k) {
+        hipStream_t s = origin;
+        if (fork && n[k] > 0 && n[k] < small) s = c->batch_stream[next++ % used];
+        status = enqueue_ex(models[k], del_t, n[k], &args[k], s, true);
+    }
+    if (fork) {  // joined whatever happened: `origin` never runs ahead of work that was enqueued for it
+        for (int s = 0; s < used; ++s) {
+            HIP_TRY(hipEventRecord(c->batch_join[s], c->batch_stream[s]));
+            HIP_TRY(hipStreamWaitEvent(origin, c->batch_join[s], 0));
+        }
+    }
+    return status;
+}
+
+// replay a captured batch "on" the context's stream.  The legacy default stream (handle 0: torch's current stream unless the
+// caller set one) cannot take a graph launch on this runtime (hipGraphLaunch(exec, 0) dereferences it: rocgdb backtrace in
+// profiles/notes/r05_graph_launch_null_stream.md): the graph then runs on the capture-origin stream, ordered behind and in front
+// of the default stream by two events.
+static int batch_replay(fcamd_context* c, hipGraphExec_t exec) {
+    if (c->stream != nullptr) {
+        HIP_TRY(hipGraphLaunch(exec, c->stream));
+        return FCAMD_OK;
+    }
+    HIP_TRY(hipEventRecord(c->batch_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->batch_origin, c->batch_fork, 0));
+    HIP_TRY(hipGraphLaunch(exec, c->batch_origin));
+    HIP_TRY(hipEventRecord(c->batch_join[0], c->batch_origin));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->batch_join[0], 0));
+    return FCAMD_OK;
+}
+
+// The laws of one form() in one call (the reference calls them back to back: solver/_solver.py:143-144, one
+// LawOnSubMesh.evaluate per material).  Every call is checked first -- nothing is launched if one of them is refused --, then
+// all kernels are enqueued from here: one trip through the binding instead of `count`, and laws that cannot fill the device on
+// their own run CONCURRENTLY on the context's side streams (forked from and joined back by events; the laws of one form()
+// write disjoint rows of the shared arrays, which is the caller's contract here as it is the reference's).  A batch of small
+// laws only is launch-bound: it is captured once into a hipGraph (parallel branches, one per side stream) and REPLAYED for as
+// long as the very same call comes back -- between the Newton iterations of an increment nothing but the gradients' values
+// changes -- so that the iteration costs one graph launch.  Results are bit for bit those of the same calls made one by one.
+int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n, const fcamd_eval_args* args, double t, double del_t) {
+    (void)t;
+    if (count < 0 || (count > 0 && (!models || !n || !args))) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
+    if (count == 0) return FCAMD_OK;
+    fcamd_context* c = models[0] ? models[0]->ctx : nullptr;
+    for (int k = 0; k < count; ++k) {
+        if (!models[k]) return fail(FCAMD_ERR_BAD_ARG, "models[%d] is NULL", k);
+        if (models[k]->ctx != c) return fail(FCAMD_ERR_BAD_ARG, "fcamd_evaluate_batch: models[%d] belongs to another context", k);
+        if (args[k].wrapper_constraint != 0) return fail(FCAMD_ERR_UNSUPPORTED, "fcamd_evaluate_batch: the fused wrapper form is not batched (models[%d])", k);
+        const int st = check_device_ex(models[k], del_t, n[k], &args[k]);
+        if (st != FCAMD_OK) return st;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    // laws below this size do not fill the device (512 workgroups per CU at two tiles per wave: fcamd_kernels.hip): side streams
+    const int64_t small = (int64_t)c->num_cu * 64 * 64;
+    int n_small = 0;
+    for (int k = 0; k < count; ++k) n_small += (n[k] > 0 && n[k] < small) ? 1 : 0;
+    if (n_small > 1 && !c->batch_fork) {
+        HIP_TRY(hipEventCreateWithFlags(&c->batch_fork, hipEventDisableTiming));
+        for (int s = 0; s < fcamd_context::kBatchStreams; ++s) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->batch_stream[s], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->batch_join[s], hipEventDisableTiming));
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&c->batch_origin, hipStreamNonBlocking));
+    }
+    const bool graphable = c->opt.batch_graph != 0 && n_small > 1 && n_small == count;
+    if (!graphable) return batch_enqueue(c, c->stream, count, models, n, args, del_t, small, n_small);
+
+    // the call, byte for byte: handles, sizes, every argument struct and the history pointer arrays they point to, del_t
+    std::string key;
+    key.append(reinterpret_cast<const char*>(models), sizeof(models[0]) * count);
+    key.append(reinterpret_cast<const char*>(n), sizeof(n[0]) * count);
+    key.append(reinterpret_cast<const char*>(&del_t), sizeof(del_t));
+    for (int k = 0; k < count; ++k) {
+        fcamd_eval_args x = args[k];
+        const int nh = x.n_hist;
+        if (nh > 0) {
+            key.append(reinterpret_cast<const char*>(x.history_prev), sizeof(void*) * nh);
+            key.append(reinterpret_cast<const char*>(x.history), sizeof(void*) * nh);
+        }
+        x.history_prev = nullptr;  // (the arrays' ADDRESSES are not part of the call)
+        x.history = nullptr;
+        key.append(reinterpret_cast<const char*>(&x), sizeof(x));
+    }
+    for (size_t i = 0; i < c->batch_graphs.size(); ++i) {
+        if (c->batch_graphs[i].key == key) {
+            hipGraphExec_t exec = c->batch_graphs[i].exec;
+            if (i + 1 != c->batch_graphs.size()) std::rotate(c->batch_graphs.begin() + i, c->batch_graphs.begin() + i + 1, c->batch_graphs.end());  // most recent last
+            return batch_replay(c, exec);
+        }
+    }
+    // first time: capture on a stream of our own (the context's stream may be the legacy default stream, which cannot capture)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int status = FCAMD_OK;
+    if (hipStreamBeginCapture(c->batch_origin, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        status = batch_enqueue(c, c->batch_origin, count, models, n, args, del_t, small, n_small, c->opt.batch_graph == 1);
+        const hipError_t e = hipStreamEndCapture(c->batch_origin, &graph);
+        if (status == FCAMD_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            if (c->batch_graphs.size() >= fcamd_context::kBatchGraphs) {
+                (void)hipGraphExecDestroy(c->batch_graphs.front().exec);
+                c->batch_graphs.erase(c->batch_graphs.begin());
+            }
+            c->batch_graphs.push_back({std::move(key), exec});
+            return batch_replay(c, exec);
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+    (void)hipGetLastError();
+    c->opt.batch_graph = 0;  // this runtime does not capture the launches: plain launches from here on
+    return batch_enqueue(c, c->stream, count, models, n, args, del_t, small, n_small);
 }
 
 }  // extern "C"
@@ -750,7 +891,6 @@ static int evaluate_wrapped(fcamd_model* m, int wrapper_constraint, double del_t
     a.cache3d = stress_3d;
     a.n = n;
     a.counters = m->d_counters;
-    a.tile_map = 0;
     a.masked_max = m->ctx->opt.masked_max >= 0 ? m->ctx->opt.masked_max : kMaskedRowMaxVonMises;  // eps_n rows of the fused VonMises3D wrapper
     a.flags = 0;
     constants_for(m, del_t);

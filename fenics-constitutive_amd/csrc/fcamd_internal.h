@@ -52,7 +52,6 @@ struct EvalArgs {
     double* cache3d;           // fused 3D->1D/2D wrappers only: the wrapper's cached 3-D stress [6n], in place
     long long n;               // quadrature points
     unsigned long long* counters;  // [kCounterSlots][4]: nonconverged, plastic, newton iterations, reserved
-    int tile_map;              // 0: tiles dealt round-robin to all waves; 1: one contiguous region per XCD
     int masked_max;            // row-masked history access for tiles with at most this many touched rows (else dense)
     int flags;                 // bit 0: sparse-tangent protocol (fcamd_kernels.hip: sparse_tangent_need); bit 2: split history; bit 3: packed plastic-strain history
     Scalars sc;

@@ -151,21 +151,9 @@ __global__ void __launch_bounds__(kBlock, (kMinBlocks<LAW, IDX>)) evaluate_kerne
     const int r0 = lane % 18;
     const long long nfull = a.n / kWave;
     WaveStats st;
-    if (a.tile_map == 0) {
-        const long long wstride = (long long)gridDim.x * kWavesPerBlock;
-        for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
-            run_full_tile<LAW, IDX, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, lane, r0, st);
-    } else {
-        // XCD-aware variant (experiment): workgroups b and b+8 share an XCD (round-robin dispatch);
-        // give every XCD one contiguous eighth of the tiles.  There is no data reuse to keep in an
-        // L2, so this only changes DRAM/TLB locality.
-        const int xcd = blockIdx.x & 7;
-        const long long per = (nfull + 7) / 8;
-        const long long lo = xcd * per, hi = (lo + per < nfull) ? lo + per : nfull;
-        const long long wstride = (long long)((gridDim.x + 7 - xcd) / 8) * kWavesPerBlock;
-        for (long long tile = lo + (long long)(blockIdx.x >> 3) * kWavesPerBlock + wave; tile < hi; tile += wstride)
-            run_full_tile<LAW, IDX, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, lane, r0, st);
-    }
+    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
+    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
+        run_full_tile<LAW, IDX, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, lane, r0, st);
     flush_stats<LAW>(a, st, lane);
 }
 
@@ -187,17 +175,15 @@ __global__ void __launch_bounds__(kBlock, 4) evaluate_lowdim_kernel(const EvalAr
     }
 }
 
-#ifndef FCAMD_UX_TRIPS
-#define FCAMD_UX_TRIPS 4
-#endif
+constexpr int kUxTrips = 4;  // pairs of points per thread of the uniaxial stream kernel
 // Uniaxial constraints: a plain element-wise stream over the whole 64-point tiles (kernels/law_lowdim.h: stream_uniaxial);
-// the ragged rest goes to evaluate_lowdim_tail_kernel<LAW, 1>.  NOT persistent: a workgroup takes kBlock * FCAMD_UX_TRIPS
+// the ragged rest goes to evaluate_lowdim_tail_kernel<LAW, 1>.  NOT persistent: a workgroup takes kBlock * kUxTrips
 // consecutive pairs of points and ends, so the resident workgroups sweep the arrays as one front (measured on
 // 1e8 points, one process, identical buffers: a grid-stride loop over 16k workgroups 0.536 ms, over 64k 0.496 ms).
 template <int LAW, bool NT>
 __global__ void __launch_bounds__(kBlock, 8) evaluate_uniaxial_kernel(const EvalArgs a) {
     const long long npairs = (a.n / kWave) * (kWave / 2);
-    const long long lo = (long long)blockIdx.x * (kBlock * FCAMD_UX_TRIPS), hi = lo + kBlock * FCAMD_UX_TRIPS;
+    const long long lo = (long long)blockIdx.x * (kBlock * kUxTrips), hi = lo + kBlock * kUxTrips;
     stream_uniaxial<LAW, NT>(a, hi < npairs ? hi : npairs, lo + threadIdx.x, kBlock);
 }
 
@@ -323,8 +309,8 @@ static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream)
 template <int LAW, int DIMS>
 static hipError_t launch_lowdim(const EvalArgs& args, int grid, hipStream_t stream) {
     if (args.n >= kWave) {
-        if constexpr (DIMS == 1) {  // one workgroup per kBlock * FCAMD_UX_TRIPS pairs: `grid` does not apply
-            const long long npairs = (args.n / kWave) * (kWave / 2), per = kBlock * FCAMD_UX_TRIPS;
+        if constexpr (DIMS == 1) {  // one workgroup per kBlock * kUxTrips pairs: `grid` does not apply
+            const long long npairs = (args.n / kWave) * (kWave / 2), per = kBlock * kUxTrips;
             hipLaunchKernelGGL((evaluate_uniaxial_kernel<LAW, true>), dim3((unsigned)((npairs + per - 1) / per)), dim3(kBlock), 0, stream, args);
         } else
             hipLaunchKernelGGL((evaluate_lowdim_kernel<LAW, DIMS, true>), dim3(grid), dim3(kBlock), 0, stream, args);

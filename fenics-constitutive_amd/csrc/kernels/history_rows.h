@@ -29,13 +29,7 @@ namespace fcamd {
 // the untouched rows of the trial run already hold the committed values -- the sparse protocol's invariant, row by row -- and
 // only the touched rows move, chunk-masked like MaskedRows but through the rank of a row in the run.
 // rows inside a packed run (load_rows) when the run has at least kPackedRowsMinRun rows and at most 1 / kPackedRowsDiv of them are touched
-#ifndef FCAMD_PACKED_ROWS_DIV
-#define FCAMD_PACKED_ROWS_DIV 3
-#endif
-#ifndef FCAMD_PACKED_ROWS_MIN_RUN
-#define FCAMD_PACKED_ROWS_MIN_RUN 32
-#endif
-constexpr int kPackedRowsDiv = FCAMD_PACKED_ROWS_DIV, kPackedRowsMinRun = FCAMD_PACKED_ROWS_MIN_RUN;
+constexpr int kPackedRowsDiv = 3, kPackedRowsMinRun = 32;
 
 template <bool FULL, bool NT>
 struct PackedRows {
@@ -45,17 +39,8 @@ struct PackedRows {
     bool row_live[3] = {true, true, true};  // ... chunk k of this lane lies in such a row
 
     // 16-byte chunks of a run of `rows` rows, rounded up to whole 128-byte lines (a slot is 24 lines; the ragged last tile,
-    // whose slot ends with the array: the exact run; FCAMD_PACKED_LINE=0: always exact, the experiment knob)
-#ifndef FCAMD_PACKED_LINE
-#define FCAMD_PACKED_LINE 1
-#endif
-    static __device__ __forceinline__ int run_chunks(int rows) {
-#if FCAMD_PACKED_LINE
-        return FULL ? ((3 * rows + 7) & ~7) : 3 * rows;  // <= 192
-#else
-        return 3 * rows;
-#endif
-    }
+    // whose slot ends with the array: the exact run)
+    static __device__ __forceinline__ int run_chunks(int rows) { return FULL ? ((3 * rows + 7) & ~7) : 3 * rows; }  // <= 192
 
     // requests the committed run (ever_in must be set: the tile's EVER word, a.emask_in[tile])
     __device__ __forceinline__ void load(const double* rows_in, long long p0, int lane) {

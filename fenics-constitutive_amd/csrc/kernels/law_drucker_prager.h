@@ -87,7 +87,7 @@ __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11ta
         // i.e. the host-computed 2 mu P_dev + 3 kappa P_vol bit for bit, not kappa 1x1 + 2 mu P_dev
         const d2 el = *reinterpret_cast<const d2*>(etab + 6 * i + j);
         if (c2.y == 0.0) v = el;
-        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q, p);
+        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q);
         if ((FULL || q < nchunks) && wanted) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }

@@ -39,7 +39,7 @@ __device__ __forceinline__ void tangent_const_masked(const double* tab, double* 
         const int q = k * kWave + lane;
         const int p = q / 18;
         d2 v = reinterpret_cast<const d2*>(tab)[q - 18 * p];
-        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q, p);
+        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q);
         if ((FULL || q < nchunks) && wanted) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
     }
 }
@@ -67,10 +67,7 @@ __device__ __forceinline__ unsigned long long sparse_tangent_need(const EvalArgs
 
 // The tangent chunks of a tile are computed and stored in groups: the scheduler may interleave the LDS
 // reads, the arithmetic and the stores of one group, not across groups (bounds the register pressure).
-#ifndef FCAMD_TANGENT_GROUP
-#define FCAMD_TANGENT_GROUP 3
-#endif
-constexpr int kTangentGroup = FCAMD_TANGENT_GROUP;
+constexpr int kTangentGroup = 3;
 
 // Point-dependent tangent of the two Mises laws.  Lane p has published
 //   tp[10p + 0] = B, tp[10p + 1] = C, tp[10p + 2 .. 7] = N   (stride 10: conflict-free b128)
@@ -106,7 +103,7 @@ __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta
             v.x = (a.x + bc.x * b.x) + bc.y * (ni * nj.x);
             v.y = (a.y + bc.x * b.y) + bc.y * (ni * nj.y);
         }
-        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q, p);
+        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q);
         if ((FULL || q < nchunks) && wanted) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         // bound the register pressure: let the scheduler interleave at most 3 chunks
         if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);

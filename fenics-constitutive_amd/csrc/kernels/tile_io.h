@@ -41,25 +41,11 @@ __device__ __forceinline__ void store16(double* p, d2 v) {
         *reinterpret_cast<d2*>(p) = v;
 }
 
-// Store policy of the tangent stream (288 of the 456-648 bytes per point), a build-time experiment knob
-// (tools/ab_lib.py A/Bs two builds in one process): 0 = non-temporal (ships: +13 % over plain stores in round 1; `sc1` /
-// `sc0 sc1` write-through stores, which drop the line from the L2 at once, measured no better in round 2).
-#ifndef FCAMD_TANGENT_STORE
-#define FCAMD_TANGENT_STORE 0
-#endif
+// The tangent stream (288 of the 456-648 bytes per point) leaves non-temporal like every other stream (+13 % over plain stores
+// in round 1; `sc1` / `sc0 sc1` write-through stores measured no better in round 2).
 template <bool NT>
 __device__ __forceinline__ void store_tangent16(double* p, d2 v) {
-#if FCAMD_TANGENT_STORE == 1
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#elif FCAMD_TANGENT_STORE == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-#elif FCAMD_TANGENT_STORE == 3
-    *reinterpret_cast<d2*>(p) = v;
-#elif FCAMD_TANGENT_STORE == 4
-    asm volatile("global_store_dwordx4 %0, %1, off nt sc1" ::"v"(p), "v"(v) : "memory");
-#else
     store16<NT>(p, v);
-#endif
 }
 
 // A 64-point tile of an AoS array with NC doubles per point is 32*NC contiguous 16-byte
@@ -272,24 +258,17 @@ struct StressRows {
 // sparse protocol on the reference layout 16 / 32 / 64 / 128-byte units: 9.36 / 9.27 / 9.06 / 9.09 ms; sparse tangent
 // 288-byte rows / 64 / 128: 4.67 / 4.51 / 4.60 ms.  The price is bytes: +48 B per isolated plastic-strain row on average,
 // +32 B per isolated tangent row.
-#ifndef FCAMD_EPS_GRANULE
-#define FCAMD_EPS_GRANULE 4
-#endif
-#ifndef FCAMD_TAN_GRANULE
-#define FCAMD_TAN_GRANULE 4
-#endif
+constexpr int kRowGranule = 4;  // chunks of 16 bytes
 // chunk q of a tile image with 3 chunks per row is moved: its granule holds a piece of a row in `rows`
 __device__ __forceinline__ bool rows_granule_live(unsigned long long rows, int q) {
-    constexpr int G = FCAMD_EPS_GRANULE;
-    if constexpr (G == 1) return ((rows >> (q / 3)) & 1ull) != 0ull;
+    constexpr int G = kRowGranule;
     const int g0 = q & ~(G - 1);
     const int lo = g0 / 3, hi = (g0 + G - 1) / 3;  // <= 63: q <= 191
     return ((rows >> lo) & ((2ull << (hi - lo)) - 1ull)) != 0ull;
 }
 // the same for the tangent image (18 chunks per row)
-__device__ __forceinline__ bool tangent_granule_live(unsigned long long rows, int q, int p) {
-    constexpr int G = FCAMD_TAN_GRANULE;
-    if constexpr (G == 1) return ((rows >> p) & 1ull) != 0ull;
+__device__ __forceinline__ bool tangent_granule_live(unsigned long long rows, int q) {
+    constexpr int G = kRowGranule;
     const int g0 = q & ~(G - 1);
     const int lo = g0 / 18, hi = (g0 + G - 1) / 18;  // a granule of <= 18 chunks meets at most two rows
     return (((rows >> lo) | (rows >> hi)) & 1ull) != 0ull;

@@ -16,6 +16,8 @@ Names follow the reference's backward-compatibility properties (``stress_0``, ``
 
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 
 from .device import DeviceLaw, _is_torch
@@ -114,7 +116,8 @@ class ResidentProblemState:
     AUTO_TUNE_MIN_BYTES = 256 << 20
 
     def __init__(self, laws, n_points: int, del_t: float = 1.0, device=None, reuse_constant_tangent: bool = True,
-                 sparse_history: bool = True, sparse_tangent: bool = True, placement: str = "auto", packed_history: bool = True):
+                 sparse_history: bool = True, sparse_tangent: bool = True, placement: str = "auto", packed_history: bool = True,
+                 batch_launches: bool = True):
         import torch
 
         from . import _capi
@@ -147,6 +150,9 @@ class ResidentProblemState:
         self._evaluated = False
         self.reuse_constant_tangent = reuse_constant_tangent
         self.sparse_tangent = sparse_tangent
+        #: the laws of one ``evaluate`` leave as ONE ``fcamd_evaluate_batch`` (False: one ``fcamd_evaluate_device_ex`` per law)
+        self.batch_launches = batch_launches
+        self._batch_cache = {}  # committed copy -> (signature of every pointer of the call, _capi.PreparedBatch)
         # the error of a law's last evaluate, if it raised, lives with the law (_LawState.failed): nothing to commit
         # placement of the arrays the launches stream (see ResidentState): "auto" / "vmm" move the parent
         # stress pair, the parent tangent and every law's history pair into one interleaved VMM working set on
@@ -224,16 +230,20 @@ class ResidentProblemState:
                 self._place(grads)
         for ls in self._laws:
             ls.failed = None
+        from . import _capi
+
+        staged = []
         for ls, g in zip(self._laws, grads):
             if not _is_torch(g):
                 if ls.grad is None:
                     ls.grad = torch.empty(9 * ls.n, **self._f)
                 upload(ls.grad, np.ascontiguousarray(g, dtype=np.float64))  # synchronous: the caller may free or rewrite g on return
                 g = ls.grad
-            hp = None if ls.hist is None else ls.hist[self._c]
-            hc = None if ls.hist is None else ls.hist[1 - self._c]
-            tangent = self.tangent
-            key = None
+            staged.append(g)
+        # what every law's launch takes this time (the constant-tangent and sparse-tangent shortcuts are state of the law)
+        plan = []
+        for ls, g in zip(self._laws, staged):
+            tangent, key = self.tangent, None
             if ls.const_tangent and self.reuse_constant_tangent:
                 key = self._del_t if type(ls.law).__name__.startswith("Spring") else 0.0
                 if ls.tangent_key == key:
@@ -241,6 +251,40 @@ class ResidentProblemState:
                 ls.tangent_key = None  # valid again only once the launch below has been enqueued
             st = self.sparse_tangent and ls.mask is not None and ls.tangent_target == "dev"
             ls.tangent_target = None
+            plan.append((g, tangent, st, key))
+        # The laws of this form() leave as ONE fcamd_evaluate_batch (they write disjoint rows of the shared stress / tangent arrays):
+        # one trip through the binding, the small laws concurrently.  Between the Newton iterations of an increment nothing but the
+        # gradients' VALUES changes, so the argument arrays of the call are kept and issued again while every pointer is the same.
+        if self.batch_launches and len(self._laws) > 1:
+            import torch
+
+            from .device import _current_stream_ptr
+
+            dev = self.device.index or 0
+            sig = (self._c, self._time, self._del_t, self.stress_0.data_ptr(), self.stress_1.data_ptr(),
+                   tuple((g.data_ptr(), g.numel(), 0 if tan is None else tan.data_ptr(), st,
+                          0 if ls.hist is None else next(iter(ls.hist[0].values())).data_ptr(),
+                          0 if ls.hist is None else next(iter(ls.hist[1].values())).data_ptr()) for ls, (g, tan, st, _) in zip(self._laws, plan)))
+            cached = self._batch_cache.get(self._c)
+            if cached is not None and cached[0] == sig:
+                cached[1].ctx.set_stream(_current_stream_ptr(dev))
+                cached[1].launch()
+            else:
+                with _capi.batched_launches() as b:
+                    self._enqueue_laws(plan)
+                self._batch_cache[self._c] = (sig, b.prepared[0]) if len(b.prepared) == 1 else None
+        else:
+            self._enqueue_laws(plan)
+        for ls, (_, _, _, key) in zip(self._laws, plan):
+            ls.tangent_key = key
+            ls.tangent_target = "dev"
+            ls.stats_pending = ls.counters is not None
+        self._evaluated = True
+
+    def _enqueue_laws(self, plan) -> None:
+        for ls, (g, tangent, st, _) in zip(self._laws, plan):
+            hp = None if ls.hist is None else ls.hist[self._c]
+            hc = None if ls.hist is None else ls.hist[1 - self._c]
             if ls.rows is None:
                 ls.law.evaluate_from(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent, hp, hc,
                                      history_mask=ls.mask, sparse_tangent=st, counters=ls.counters, packed_masks=ls.packed_masks(self._c))
@@ -248,10 +292,6 @@ class ResidentProblemState:
                 ls.law.evaluate_indexed(self._time, self._del_t, g, self.stress_0, self.stress_1, tangent,
                                         ls.rows, hp, hc, history_mask=ls.mask, sparse_tangent=st, counters=ls.counters,
                                         packed_masks=ls.packed_masks(self._c))
-            ls.tangent_key = key
-            ls.tangent_target = "dev"
-            ls.stats_pending = ls.counters is not None
-        self._evaluated = True
 
     # the host assembler's Newton-iteration call, law by law (LawOnSubMesh.evaluate, solver/_lawonsubmesh.py:72-95)
     def evaluate_law_into(self, k: int, grad_del_u: np.ndarray, stress_parent: np.ndarray,

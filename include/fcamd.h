@@ -267,6 +267,17 @@ typedef struct fcamd_eval_args {
 FCAMD_API int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_t, int64_t n,
                                        const fcamd_eval_args* args);
 
+/* The laws of ONE form() in one call.  The reference calls its laws back to back, one LawOnSubMesh.evaluate per material
+   (solver/_solver.py:143-144); here `count` device calls -- models[k] over n[k] points with args[k], each exactly as
+   fcamd_evaluate_device_ex takes it (any form but the fused wrapper one), all of one context, one t / del_t -- are checked
+   first (if one is refused nothing is launched and its status is returned), then enqueued from this one call: one trip
+   through the binding instead of `count`, and the laws that cannot fill the device on their own (fewer than 4096 points per
+   compute unit) run concurrently on side streams of the context, forked from and joined back into the context's stream
+   by events -- to the caller it is one asynchronous operation on that stream.  Precondition (the reference's, too): the laws
+   write disjoint rows of the arrays they share.  Results are bit for bit those of the same calls made one by one. */
+FCAMD_API int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n, const fcamd_eval_args* args,
+                                   double t, double del_t);
+
 /* Resident-state evaluate for a host assembler (replaces the per-iteration copies of
    solver/_lawonsubmesh.py:58-61,84-95 and solver/_history.py:64-79): the committed and trial
    copies of stress and history are DEVICE arrays of n points (committed is read, trial is written), while what must
@@ -520,7 +531,7 @@ FCAMD_API int fcamd_device_free(fcamd_context* ctx, void* ptr);
 /* ---- tuning / introspection -------------------------------------------------- */
 /* Context options (name, value).  Launch / data-path knobs (experiments; the defaults are the measured optimum) and
    their FCAMD_* environment defaults, which are read ONCE, when the context is created:
-     "tile_map" (FCAMD_TILE_MAP, 0), "masked_max" (FCAMD_MASKED_MAX, -1 = per law),
+     "masked_max" (FCAMD_MASKED_MAX, -1 = per law),
      "host_chunk" (FCAMD_HOST_CHUNK, 0 = automatic), "host_slots" (FCAMD_HOST_SLOTS, 4),
      "bounce_max" (FCAMD_BOUNCE_MAX, 256 KiB: host calls up to this size go through the page-locked scratch),
      "zero_copy" (FCAMD_ZERO_COPY, 1), "zero_copy_grad" (FCAMD_ZERO_COPY_GRAD, 1);

@@ -81,7 +81,7 @@ def test_timing_applies_to_every_device_entry_and_to_the_host_entries():
 def test_context_options_replace_the_environment_knobs():
     law = fc.VonMises3D(VM_P)
     ctx = law._handle(0).ctx
-    assert ctx.get_option("tile_map") == 0 and ctx.get_option("masked_max") == -1
+    assert ctx.get_option("masked_max") == -1
     with pytest.raises(ValueError, match="unknown option"):
         ctx.set_option("no_such_knob", 1)
     n = 64 * 300 + 5
@@ -89,14 +89,14 @@ def test_context_options_replace_the_environment_knobs():
     law.evaluate_from(0, 1.0, g, s0, s1, t, h0, h1)
     ref = (s1.clone(), t.clone(), h1["eps_n"].clone())
     try:
-        for name, value in (("tile_map", 1), ("masked_max", 0), ("masked_max", 64)):
+        for name, value in (("masked_max", 0), ("masked_max", 64)):
             ctx.set_option(name, value)
             assert ctx.get_option(name) == value
             s1.zero_(), t.zero_(), h1["eps_n"].zero_()
             law.evaluate_from(0, 1.0, g, s0, s1, t, h0, h1)
             assert torch.equal(s1, ref[0]) and torch.equal(t, ref[1]) and torch.equal(h1["eps_n"], ref[2]), (name, value)
     finally:
-        ctx.set_option("tile_map", 0), ctx.set_option("masked_max", -1)
+        ctx.set_option("masked_max", -1)
     ctx.trim()  # staging buffers released; the next pageable host call allocates them again
     gh = g.cpu().numpy()
     sh, th = np.zeros(6 * n), np.empty(36 * n)

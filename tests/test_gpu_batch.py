@@ -1,0 +1,103 @@
+"""fcamd_evaluate_batch: the laws of one form() in one call (the reference calls them back to back, solver/_solver.py:143-144).
+Bit for bit the same state as one fcamd_evaluate_device_ex per law; a refused call launches nothing."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+from test_gpu_parity import make_law, random_case
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from fenics_constitutive_amd import _capi  # noqa: E402
+from fenics_constitutive_amd.problem import ResidentProblemState, rows_of_cells  # noqa: E402
+
+KINDS = ["linear_elasticity", "von_mises_3d", "spring_maxwell", "spring_kelvin", "comfe_mises_plasticity", "linear_elasticity",
+         "von_mises_3d", "comfe_linear_elasticity"]
+
+
+def build(n_cells, q, n_laws, seed, batch, big_first=False):
+    rng = np.random.default_rng(seed)
+    if big_first:  # one law that fills the device (context stream) next to small ones (side streams)
+        owner = np.where(rng.random(n_cells) < 0.85, 0, rng.integers(1, n_laws, size=n_cells))
+    else:
+        owner = rng.integers(0, n_laws, size=n_cells)
+    rows = [rows_of_cells(np.flatnonzero(owner == k), q) for k in range(n_laws)]
+    kinds = KINDS[:n_laws]
+    cases = [random_case(kind, r.size, seed=seed + 7 * i) for i, (kind, r) in enumerate(zip(kinds, rows))]
+    laws = [make_law(kind, c[0]) for kind, c in zip(kinds, cases)]
+    n = q * n_cells
+    st = ResidentProblemState(list(zip(laws, rows)), n, del_t=0.7, batch_launches=batch, placement="torch")
+    stress_0 = np.zeros(6 * n)
+    for r, c in zip(rows, cases):
+        stress_0.reshape(-1, 6)[r] = c[2].reshape(-1, 6)
+    st.set_state(stress_0, [None if c[3] is None else {k: v.copy() for k, v in c[3].items()} for c in cases])
+    return st, rows, rng
+
+
+@pytest.mark.parametrize("n_laws,n_cells,big_first", [(2, 700, False), (8, 3001, False), (8, 20000, False), (4, 400000, True)])
+def test_batched_form_equals_law_by_law(n_laws, n_cells, big_first):
+    q = 4
+    a, rows, rng = build(n_cells, q, n_laws, 5, True, big_first)
+    b, _, _ = build(n_cells, q, n_laws, 5, False, big_first)
+    assert a.batch_launches and not b.batch_launches
+    for inc in range(2):
+        for it in range(3):
+            hi = -2.0 if (inc + it) % 2 == 0 else -3.0
+            grads = [torch.from_numpy(rng.normal(size=9 * r.size) * np.repeat(10 ** rng.uniform(-4, hi, size=r.size), 9)).cuda() for r in rows]
+            a.evaluate(grads), b.evaluate(grads)
+            a.check(), b.check()
+            assert torch.equal(a.stress_1, b.stress_1) and torch.equal(a.tangent, b.tangent)
+            for ha, hb in zip(a._history_1, b._history_1):
+                for k in (ha or {}):
+                    assert torch.equal(ha[k], hb[k]), k
+        a.update(), b.update()
+        assert torch.equal(a.stress_0, b.stress_0)
+
+
+def test_batch_entry_raw_checks_everything_before_it_launches_anything():
+    lib = _capi.load()
+    n = 64 * 50 + 7
+    kinds = ["linear_elasticity", "spring_maxwell", "von_mises_3d"]
+    cases = [random_case(k, n, seed=2 + i) for i, k in enumerate(kinds)]
+    laws = [make_law(k, c[0]) for k, c in zip(kinds, cases)]
+    f = dict(dtype=torch.float64, device="cuda")
+    models = [law._handle(0) for law in laws]
+    stream = torch.cuda.current_stream().cuda_stream
+    models[0].ctx.set_stream(stream)
+    assert all(m.ctx is models[0].ctx for m in models)
+    keep, args, ref = [], [], []
+    for law, m, c in zip(laws, models, cases):
+        g = torch.from_numpy(c[1]).cuda()
+        s0, s1, t = torch.from_numpy(c[2]).cuda(), torch.zeros(6 * n, **f), torch.zeros(36 * n, **f)
+        h0 = [] if c[3] is None else [torch.from_numpy(c[3][name]).cuda() for name, _ in m.history_fields]
+        h1 = [torch.zeros_like(h) for h in h0]
+        a0, a1 = (C.c_void_p * max(1, len(h0)))(*[h.data_ptr() for h in h0]), (C.c_void_p * max(1, len(h1)))(*[h.data_ptr() for h in h1])
+        args.append(_capi.EvalArgs(g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, len(h0), None, None, 0, None, None, None, None, 0, None))
+        keep.append((g, s0, s1, t, h0, h1, a0, a1))
+        # the same call on its own, into arrays of its own
+        s1r, tr, h1r = torch.zeros(6 * n, **f), torch.zeros(36 * n, **f), [torch.zeros_like(h) for h in h0]
+        m.evaluate_device_ex(0.0, 0.7, n, g.data_ptr(), s0.data_ptr(), s1r.data_ptr(), tr.data_ptr(), [h.data_ptr() for h in h0], [h.data_ptr() for h in h1r])
+        ref.append((s1r, tr, h1r))
+    mh = (C.c_void_p * 3)(*[m.handle for m in models])
+    ns = (C.c_int64 * 3)(n, n, n)
+    xs = (_capi.EvalArgs * 3)(*args)
+    # the third call is refused (del_t <= 0 is checked per call; here: a NULL stress): nothing may have been written
+    bad = (_capi.EvalArgs * 3)(*args)
+    bad[2].stress = None
+    rc = lib.fcamd_evaluate_batch(3, mh, ns, bad, 0.0, 0.7)
+    assert rc != _capi.OK
+    torch.cuda.synchronize()
+    assert all(float(k[2].abs().max()) == 0.0 and float(k[3].abs().max()) == 0.0 for k in keep)
+    with pytest.raises(AssertionError):  # the reference's exception type for del_t <= 0, through the same status mapping
+        _capi.check(lib.fcamd_evaluate_batch(3, mh, ns, xs, 0.0, 0.0))
+    _capi.check(lib.fcamd_evaluate_batch(3, mh, ns, xs, 0.0, 0.7))
+    _capi.check(lib.fcamd_evaluate_batch(0, None, None, None, 0.0, 0.7))  # an empty form()
+    torch.cuda.synchronize()
+    for k, (s1r, tr, h1r) in zip(keep, ref):
+        assert torch.equal(k[2], s1r) and torch.equal(k[3], tr)
+        for h, hr in zip(k[5], h1r):
+            assert torch.equal(h, hr)
+    st = laws[2].device_stats(0)
+    assert st.n_plastic > 0  # the batch resets and fills the law's own counters like the single call
