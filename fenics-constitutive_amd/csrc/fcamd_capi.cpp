@@ -285,7 +285,7 @@ void options_from_env(Options* o) {
         return (e && *e) ? atoll(e) : dflt;
     };
     o->masked_max = (int)geti("FCAMD_MASKED_MAX", -1);
-    o->batch_graph = (int)geti("FCAMD_BATCH_GRAPH", 1);
+    o->batch_kernel = geti("FCAMD_BATCH_KERNEL", 1) != 0;
     o->host_chunk = geti("FCAMD_HOST_CHUNK", 0);
     o->host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, geti("FCAMD_HOST_SLOTS", fcamd_context::kSlots)));
     o->zero_copy = geti("FCAMD_ZERO_COPY", 1) != 0;
@@ -374,12 +374,11 @@ int grid_for(fcamd_model* m, int64_t n) {
 }  // namespace
 
 namespace fcamd {
-int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
-            double* stress, double* tangent, const double* const* hprev, double* const* hcur,
-            hipStream_t stream, bool reset_counters, const int* rows,
-            unsigned long long* hmask, int flags, double* stress2,
-            unsigned long long* counters, const unsigned long long* emask_prev, unsigned long long* emask) {
-    EvalArgs a;
+// the kernel arguments of one launch (device pointers already validated)
+static void fill_args(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
+                      double* stress, double* tangent, const double* const* hprev, double* const* hcur, const int* rows,
+                      unsigned long long* hmask, int flags, double* stress2,
+                      unsigned long long* counters, const unsigned long long* emask_prev, unsigned long long* emask, EvalArgs& a) {
     a.grad = grad;
     a.stress_in = stress_prev;
     a.stress_out = stress;
@@ -403,13 +402,22 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
     a.emask_in = emask_prev;
     a.emask_out = emask;
     a.n = n;
-    a.counters = counters ? counters : m->d_counters;  // caller-owned counters are always reset here
+    a.counters = counters ? counters : m->d_counters;  // caller-owned counters are always reset by the launch
     const Options& o = m->ctx->opt;
     a.masked_max = o.masked_max >= 0 ? o.masked_max  // split history: 48-byte eps_p rows, as VonMises3D's eps_n
                                      : ((m->law == FCAMD_VON_MISES_3D || split) ? kMaskedRowMaxVonMises : kMaskedRowMaxRows7);
     constants_for(m, del_t);
     a.sc = m->sc;
     a.tb = m->tb;
+}
+
+int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
+            double* stress, double* tangent, const double* const* hprev, double* const* hcur,
+            hipStream_t stream, bool reset_counters, const int* rows,
+            unsigned long long* hmask, int flags, double* stress2,
+            unsigned long long* counters, const unsigned long long* emask_prev, unsigned long long* emask) {
+    EvalArgs a;
+    fill_args(m, del_t, n, grad, stress_prev, stress, tangent, hprev, hcur, rows, hmask, flags, stress2, counters, emask_prev, emask, a);
     // only the plasticity laws count anything: skip the extra launch for the others
     if ((reset_counters || counters) && law_counts(m->law)) HIP_TRY(hipMemsetAsync(a.counters, 0, kCounterBytes, stream));
     if (n == 0) return FCAMD_OK;
@@ -515,7 +523,7 @@ int fcamd_context_set_option(fcamd_context* c, const char* name, long long value
     const std::string k(name);
     Options& o = c->opt;
     if (k == "masked_max") o.masked_max = (int)value;
-    else if (k == "batch_graph") o.batch_graph = (int)value;
+    else if (k == "batch_kernel") o.batch_kernel = value != 0;
     else if (k == "host_chunk") o.host_chunk = value;
     else if (k == "host_slots") o.host_slots = (int)std::min<long long>(fcamd_context::kSlots, std::max<long long>(1, value));
     else if (k == "zero_copy") o.zero_copy = value != 0;
@@ -534,7 +542,7 @@ int fcamd_context_get_option(fcamd_context* c, const char* name, long long* valu
     const std::string k(name);
     const Options& o = c->opt;
     if (k == "masked_max") *value = o.masked_max;
-    else if (k == "batch_graph") *value = o.batch_graph;
+    else if (k == "batch_kernel") *value = o.batch_kernel ? 1 : 0;
     else if (k == "host_chunk") *value = o.host_chunk;
     else if (k == "host_slots") *value = o.host_slots;
     else if (k == "zero_copy") *value = o.zero_copy;
@@ -562,13 +570,10 @@ int fcamd_context_destroy(fcamd_context* c) {
     for (hipEvent_t e : c->peer_events)
         if (e) (void)hipEventDestroy(e);
     for (auto& kv : c->ipc_open) (void)hipIpcCloseMemHandle(kv.second.base);
-    for (int i = 0; i < fcamd_context::kBatchStreams; ++i) {
-        if (c->batch_stream[i]) (void)hipStreamDestroy(c->batch_stream[i]);
-        if (c->batch_join[i]) (void)hipEventDestroy(c->batch_join[i]);
+    for (auto& sl : c->batch_slots) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
     }
-    if (c->batch_fork) (void)hipEventDestroy(c->batch_fork);
-    if (c->batch_origin) (void)hipStreamDestroy(c->batch_origin);
-    for (auto& g : c->batch_graphs) (void)hipGraphExecDestroy(g.exec);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FCAMD_OK;
@@ -732,57 +737,14 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
     return timing_end(m);
 }
 
-// fork the context's side streams from `origin`, enqueue every call (small laws on side streams, the others on `origin`), join
-static int batch_enqueue(fcamd_context* c, hipStream_t origin, int count, fcamd_model* const* models, const int64_t* n,
-                         const fcamd_eval_args* args, double del_t, int64_t small, int n_small, bool may_fork = true) {
-    static const bool env_fork = !(getenv("FCAMD_BATCH_FORK") && atoi(getenv("FCAMD_BATCH_FORK")) == 0);  // TEMPORARY experiment knob
-    const bool fork = env_fork && may_fork && n_small > 1;
-    int used = 0;
-    if (fork) {
-        used = n_small < fcamd_context::kBatchStreams ? n_small : fcamd_context::kBatchStreams;
-        HIP_TRY(hipEventRecord(c->batch_fork, origin));
-        for (int s = 0; s < used; ++s) HIP_TRY(hipStreamWaitEvent(c->batch_stream[s], c->batch_fork, 0));
-    }
-    int status = FCAMD_OK, next = 0;
-    for (int k = 0; k < count && status == FCAMD_OK; ++k) {
-        hipStream_t s = origin;
-        if (fork && n[k] > 0 && n[k] < small) s = c->batch_stream[next++ % used];
-        status = enqueue_ex(models[k], del_t, n[k], &args[k], s, true);
-    }
-    if (fork) {  // joined whatever happened: `origin` never runs ahead of work that was enqueued for it
-        for (int s = 0; s < used; ++s) {
-            HIP_TRY(hipEventRecord(c->batch_join[s], c->batch_stream[s]));
-            HIP_TRY(hipStreamWaitEvent(origin, c->batch_join[s], 0));
-        }
-    }
-    return status;
-}
-
-// replay a captured batch "on" the context's stream.  The legacy default stream (handle 0: torch's current stream unless the
-// caller set one) cannot take a graph launch on this runtime (hipGraphLaunch(exec, 0) dereferences it: rocgdb backtrace in
-// profiles/notes/r05_graph_launch_null_stream.md): the graph then runs on the capture-origin stream, ordered behind and in front
-// of the default stream by two events.
-static int batch_replay(fcamd_context* c, hipGraphExec_t exec) {
-    if (c->stream != nullptr) {
-        HIP_TRY(hipGraphLaunch(exec, c->stream));
-        return FCAMD_OK;
-    }
-    HIP_TRY(hipEventRecord(c->batch_fork, c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->batch_origin, c->batch_fork, 0));
-    HIP_TRY(hipGraphLaunch(exec, c->batch_origin));
-    HIP_TRY(hipEventRecord(c->batch_join[0], c->batch_origin));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->batch_join[0], 0));
-    return FCAMD_OK;
-}
-
 // The laws of one form() in one call (the reference calls them back to back: solver/_solver.py:143-144, one
-// LawOnSubMesh.evaluate per material).  Every call is checked first -- nothing is launched if one of them is refused --, then
-// all kernels are enqueued from here: one trip through the binding instead of `count`, and laws that cannot fill the device on
-// their own run CONCURRENTLY on the context's side streams (forked from and joined back by events; the laws of one form()
-// write disjoint rows of the shared arrays, which is the caller's contract here as it is the reference's).  A batch of small
-// laws only is launch-bound: it is captured once into a hipGraph (parallel branches, one per side stream) and REPLAYED for as
-// long as the very same call comes back -- between the Newton iterations of an increment nothing but the gradients' values
-// changes -- so that the iteration costs one graph launch.  Results are bit for bit those of the same calls made one by one.
+// LawOnSubMesh.evaluate per material).  Every call is checked first -- nothing is launched if one of them is refused.  Laws
+// that fill the device on their own keep their own launches (the kernels cut for their register budget); the others -- as
+// separate launches three dispatches each: counters, main kernel, ragged tile, ~30 us of stream time per law at 1e4 points --
+// leave as ONE launch of the batch kernel (fcamd_kernels.hip: evaluate_batch_kernel), which reads each law's arguments from a
+// table in device memory.  The table is uploaded only when it CHANGES: between the Newton iterations of an increment nothing but
+// the gradients' values does, so an iteration costs two dispatches (counters, batch kernel) whatever the number of laws.
+// Results are bit for bit those of the same calls made one by one (same tile code, same arguments).
 int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n, const fcamd_eval_args* args, double t, double del_t) {
     (void)t;
     if (count < 0 || (count > 0 && (!models || !n || !args))) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
@@ -796,65 +758,68 @@ int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n
         if (st != FCAMD_OK) return st;
     }
     HIP_TRY(hipSetDevice(c->device));
-    // laws below this size do not fill the device (512 workgroups per CU at two tiles per wave: fcamd_kernels.hip): side streams
+    // laws below this size do not fill the device (512 workgroups per CU at two tiles per wave: fcamd_kernels.hip)
     const int64_t small = (int64_t)c->num_cu * 64 * 64;
+    auto batched = [&](int k) { return c->opt.batch_kernel && n[k] > 0 && n[k] < small && models[k]->constraint == FCAMD_FULL; };
     int n_small = 0;
-    for (int k = 0; k < count; ++k) n_small += (n[k] > 0 && n[k] < small) ? 1 : 0;
-    if (n_small > 1 && !c->batch_fork) {
-        HIP_TRY(hipEventCreateWithFlags(&c->batch_fork, hipEventDisableTiming));
-        for (int s = 0; s < fcamd_context::kBatchStreams; ++s) {
-            HIP_TRY(hipStreamCreateWithFlags(&c->batch_stream[s], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&c->batch_join[s], hipEventDisableTiming));
-        }
-        HIP_TRY(hipStreamCreateWithFlags(&c->batch_origin, hipStreamNonBlocking));
-    }
-    const bool graphable = c->opt.batch_graph != 0 && n_small > 1 && n_small == count;
-    if (!graphable) return batch_enqueue(c, c->stream, count, models, n, args, del_t, small, n_small);
-
-    // the call, byte for byte: handles, sizes, every argument struct and the history pointer arrays they point to, del_t
-    std::string key;
-    key.append(reinterpret_cast<const char*>(models), sizeof(models[0]) * count);
-    key.append(reinterpret_cast<const char*>(n), sizeof(n[0]) * count);
-    key.append(reinterpret_cast<const char*>(&del_t), sizeof(del_t));
+    for (int k = 0; k < count; ++k) n_small += batched(k) ? 1 : 0;
+    if (n_small < 2) n_small = 0;  // nothing to merge
+    // the others first, each with its own launch
     for (int k = 0; k < count; ++k) {
-        fcamd_eval_args x = args[k];
-        const int nh = x.n_hist;
-        if (nh > 0) {
-            key.append(reinterpret_cast<const char*>(x.history_prev), sizeof(void*) * nh);
-            key.append(reinterpret_cast<const char*>(x.history), sizeof(void*) * nh);
-        }
-        x.history_prev = nullptr;  // (the arrays' ADDRESSES are not part of the call)
-        x.history = nullptr;
-        key.append(reinterpret_cast<const char*>(&x), sizeof(x));
+        if (n_small && batched(k)) continue;
+        const int st = enqueue_ex(models[k], del_t, n[k], &args[k], c->stream, true);
+        if (st != FCAMD_OK) return st;
     }
-    for (size_t i = 0; i < c->batch_graphs.size(); ++i) {
-        if (c->batch_graphs[i].key == key) {
-            hipGraphExec_t exec = c->batch_graphs[i].exec;
-            if (i + 1 != c->batch_graphs.size()) std::rotate(c->batch_graphs.begin() + i, c->batch_graphs.begin() + i + 1, c->batch_graphs.end());  // most recent last
-            return batch_replay(c, exec);
+    for (int k0 = 0; n_small && k0 < count;) {  // tables of at most kBatchMax entries
+        std::vector<fcamd::BatchEntry>& tab = c->batch_build;
+        tab.clear();
+        int blocks = 0;
+        bool any_counts = false;
+        int k = k0;
+        for (; k < count && (int)tab.size() < fcamd_context::kBatchMax; ++k) {
+            if (!batched(k)) continue;
+            fcamd_model* m = models[k];
+            const fcamd_eval_args* x = &args[k];
+            fcamd::BatchEntry e;
+            memset(&e, 0, sizeof(e));  // (padding bytes too: the table is compared byte for byte)
+            const bool packed = (x->flags & FCAMD_EVAL_PACKED_HISTORY) != 0;
+            fcamd::fill_args(m, del_t, n[k], x->grad_del_u, x->stress_prev, x->stress, x->tangent, x->history_prev, x->history, x->parent_rows,
+                             reinterpret_cast<unsigned long long*>(x->history_mask), x->flags, x->stress2,
+                             reinterpret_cast<unsigned long long*>(x->counters),
+                             packed ? reinterpret_cast<const unsigned long long*>(x->packed_mask_prev) : nullptr,
+                             packed ? reinterpret_cast<unsigned long long*>(x->packed_mask) : nullptr, e.args);
+            e.variant = fcamd::batch_variant_of(m->law, e.args);
+            e.first_block = blocks;
+            e.main_blocks = n[k] >= 64 ? grid_for(m, n[k]) : 0;
+            e.has_tail = (n[k] % 64) != 0 ? 1 : 0;
+            e.counts = law_counts(m->law) ? 1 : 0;
+            any_counts = any_counts || e.counts;
+            blocks += e.main_blocks + e.has_tail;
+            tab.push_back(e);
         }
-    }
-    // first time: capture on a stream of our own (the context's stream may be the legacy default stream, which cannot capture)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    int status = FCAMD_OK;
-    if (hipStreamBeginCapture(c->batch_origin, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        status = batch_enqueue(c, c->batch_origin, count, models, n, args, del_t, small, n_small, c->opt.batch_graph == 1);
-        const hipError_t e = hipStreamEndCapture(c->batch_origin, &graph);
-        if (status == FCAMD_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-            (void)hipGraphDestroy(graph);
-            if (c->batch_graphs.size() >= fcamd_context::kBatchGraphs) {
-                (void)hipGraphExecDestroy(c->batch_graphs.front().exec);
-                c->batch_graphs.erase(c->batch_graphs.begin());
+        k0 = k;
+        if (tab.empty()) break;
+        const size_t bytes = tab.size() * sizeof(fcamd::BatchEntry);
+        // a slot that holds this very table already (the Newton iterations of an increment): nothing to upload
+        fcamd_context::BatchSlot* slot = nullptr;
+        for (auto& sl : c->batch_slots)
+            if (sl.host && sl.bytes == bytes && memcmp(sl.host, tab.data(), bytes) == 0) slot = &sl;
+        if (!slot) {
+            slot = &c->batch_slots[c->batch_next++ % fcamd_context::kBatchSlots];
+            if (!slot->host) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&slot->host), fcamd_context::kBatchMax * sizeof(fcamd::BatchEntry), hipHostMallocDefault));
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot->dev), fcamd_context::kBatchMax * sizeof(fcamd::BatchEntry)));
+            } else if (slot->bytes) {
+                HIP_TRY(hipDeviceSynchronize());  // a launch that still reads the slot's old table may be in flight (rare: all slots in use and a new table)
             }
-            c->batch_graphs.push_back({std::move(key), exec});
-            return batch_replay(c, exec);
+            memcpy(slot->host, tab.data(), bytes);
+            slot->bytes = bytes;
+            HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, c->stream));
         }
-        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        HIP_TRY(fcamd::launch_evaluate_batch(slot->dev, (int)tab.size(), blocks, any_counts, c->stream));
     }
-    (void)hipGetLastError();
-    c->opt.batch_graph = 0;  // this runtime does not capture the launches: plain launches from here on
-    return batch_enqueue(c, c->stream, count, models, n, args, del_t, small, n_small);
+    return FCAMD_OK;
 }
 
 }  // extern "C"

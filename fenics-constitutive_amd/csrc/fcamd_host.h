@@ -47,7 +47,7 @@ struct Dims {
 // ONCE when the context is created (never on the launch path); fcamd_context_set_option changes them
 // afterwards (experiments: tools/ab_*.py).
 struct Options {
-    int batch_graph = 1;       // FCAMD_BATCH_GRAPH   fcamd_evaluate_batch, launch-bound batches: 0 plain launches, 1 hipGraph with parallel branches, 2 hipGraph, one chain
+    bool batch_kernel = true;  // FCAMD_BATCH_KERNEL  fcamd_evaluate_batch: the small laws of a call leave as one launch of the batch kernel (0: one launch per law)
     int masked_max = -1;       // FCAMD_MASKED_MAX    row-masked history access up to this many touched rows; -1: per-law default
     long long host_chunk = 0;  // FCAMD_HOST_CHUNK    points per chunk of the staged host entries; 0: automatic
     int host_slots = 4;        // FCAMD_HOST_SLOTS    chunk slots in flight (1..4)
@@ -100,19 +100,18 @@ struct fcamd_context {
         int refs;
     };
     std::map<std::string, IpcMapping> ipc_open;
-    // fcamd_evaluate_batch: side streams for the small laws of one form(), forked from / joined into `stream` (created on first use)
-    static constexpr int kBatchStreams = 8;
-    hipStream_t batch_stream[kBatchStreams] = {};
-    hipEvent_t batch_join[kBatchStreams] = {};
-    hipEvent_t batch_fork = nullptr;
-    // ... and the hipGraphs of launch-bound batches (small laws only), replayed while the very same call comes back
-    hipStream_t batch_origin = nullptr;  // capture origin (the context's stream may be the legacy default stream)
-    struct BatchGraph {
-        std::string key;  // the call, byte for byte
-        hipGraphExec_t exec;
+    // fcamd_evaluate_batch: tables of the batch kernel (page-locked host copy + device copy each; a table is uploaded only when it
+    // differs from what its slot holds)
+    static constexpr int kBatchMax = 32;   // entries per launch of the batch kernel
+    static constexpr int kBatchSlots = 4;  // two copies of a state (committed / trial) x two tables in flight
+    struct BatchSlot {
+        fcamd::BatchEntry* host = nullptr;
+        fcamd::BatchEntry* dev = nullptr;
+        size_t bytes = 0;
     };
-    static constexpr size_t kBatchGraphs = 8;
-    std::vector<BatchGraph> batch_graphs;  // least recently used first
+    BatchSlot batch_slots[kBatchSlots];
+    unsigned batch_next = 0;
+    std::vector<fcamd::BatchEntry> batch_build;
 };
 
 struct fcamd_model {

@@ -58,6 +58,32 @@ struct EvalArgs {
     Tables tb;
 };
 
+// One law of a batch (fcamd_evaluate_batch; table in device memory, read by evaluate_batch_kernel)
+struct BatchEntry {
+    EvalArgs args;     // exactly what the law's own kernel would get
+    int variant;       // batch_variant_of(law, args)
+    int first_block;   // the workgroups [first_block, first_block + main_blocks + has_tail) of the launch are this law's
+    int main_blocks;   // ... of which the first main_blocks run the full tiles (0: fewer than 64 points)
+    int has_tail;      // one more workgroup for the ragged last tile (n % 64 points)
+    int counts;        // the law counts (plastic points, Newton iterations, ...): args.counters is zeroed before the launch
+    int pad[3];
+};
+int batch_variant_of(int law, const EvalArgs& args);
+hipError_t launch_evaluate_batch(const BatchEntry* table, int count, int total_blocks, bool any_counts, hipStream_t stream);
+
+#ifdef __HIPCC__
+// How the device code sees its arguments: a reference into CONSTANT address space (4) -- uniform, invariant loads that the
+// compiler keeps in scalar registers and re-loads instead of spilling.  A kernel's by-value EvalArgs parameter IS such memory
+// (offset 0 of its kernarg segment: kernel_args()); the batch kernel (fcamd_evaluate_batch: the laws of one form() in one
+// launch) reads its EvalArgs from a table in device memory through the same type, so every tile function serves both.
+#define FCAMD_CONSTANT __attribute__((address_space(4)))
+typedef const EvalArgs FCAMD_CONSTANT& ArgsRef;
+typedef const Scalars FCAMD_CONSTANT& ScalarsRef;
+__device__ __forceinline__ ArgsRef kernel_args() {
+    return *(const EvalArgs FCAMD_CONSTANT*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+#endif
+
 // Launch the evaluate kernel of `law` on `stream` with `grid` workgroups of 256 threads.
 // dims = geometric dimension of the constraint (3: FULL; 2: plane strain/stress; 1: uniaxial)
 hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hipStream_t stream);

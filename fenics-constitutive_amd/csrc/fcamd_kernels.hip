@@ -49,7 +49,7 @@ namespace fcamd {
 // the kernel
 // ---------------------------------------------------------------------------------------
 template <int LAW, bool IDX, bool FULL, bool NT, int SPARSE = 0>
-__device__ __forceinline__ void run_tile(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
+__device__ __forceinline__ void run_tile(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                          int* rows_lds, long long p0, int npts, int lane, int r0,
                                          WaveStats& st) {
     // Everything derived from the lane id (chunk -> point/row/column maps, LDS and global
@@ -81,7 +81,7 @@ __device__ __forceinline__ void run_tile(const EvalArgs& a, const StressBases& s
 // consecutive (cells of a material are mostly numbered in runs) the coalesced tile body runs on
 // shifted base pointers; only tiles with scattered rows pay the per-lane row accesses.
 template <int LAW, bool IDX, bool NT, int SPARSE>
-__device__ __forceinline__ void run_full_tile(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void run_full_tile(ArgsRef a, const Tables* T, double* region,
                                               int* rows_lds, long long p0, int lane, int r0, WaveStats& st) {
     const StressBases sb{a.stress_in, a.stress_out, a.tangent, a.stress_out2};
     if constexpr (IDX) {
@@ -99,8 +99,8 @@ __device__ __forceinline__ void run_full_tile(const EvalArgs& a, const Tables* T
     run_tile<LAW, IDX, true, NT, SPARSE>(a, sb, T, region, rows_lds, p0, kWave, lane, r0, st);
 }
 
-__device__ __forceinline__ void stage_tables(const EvalArgs& a, Tables* T) {
-    const double* src = reinterpret_cast<const double*>(&a.tb);
+__device__ __forceinline__ void stage_tables(ArgsRef a, Tables* T) {
+    const double FCAMD_CONSTANT* src = (const double FCAMD_CONSTANT*)&a.tb;
     double* dst = reinterpret_cast<double*>(T);
     for (int i = threadIdx.x; i < 108; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
@@ -110,14 +110,14 @@ __device__ __forceinline__ void stage_tables(const EvalArgs& a, Tables* T) {
 // with tens of thousands of waves, atomics on ONE address serialise at ~10 ns each (measured:
 // +0.8 ms at 65k waves); spread over 64 addresses they vanish.  The host sums the slots.
 template <int LAW>
-__device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& st, int lane) {
+__device__ __forceinline__ void flush_stats(ArgsRef a, const WaveStats& st, int lane, int block = (int)blockIdx.x) {
     if constexpr (LAW == LAW_VM3D || LAW == LAW_COMFE_MISES || LAW == LAW_COMFE_DP || LAW == LAW_COMFE_DP_HYPER) {
         const unsigned long long nc = wave_sum(st.nonconv);
         const unsigned long long np = wave_sum(st.plastic);
         const unsigned long long ni = wave_sum(st.iters);
         const unsigned long long nd = wave_sum(st.domain);
         if (lane == 0) {
-            unsigned long long* c = a.counters + 4 * (blockIdx.x & (kCounterSlots - 1));
+            unsigned long long* c = a.counters + 4 * (block & (kCounterSlots - 1));
             if (nc) atomicAdd(c + 0, nc);
             if (np) atomicAdd(c + 1, np);
             if (ni) atomicAdd(c + 2, ni);
@@ -135,13 +135,10 @@ __device__ __forceinline__ void flush_stats(const EvalArgs& a, const WaveStats& 
 template <int LAW, bool IDX>
 constexpr int kMinBlocks = LAW >= LAW_COMFE_DP ? 3 : 4;
 
-template <int LAW, bool NT, bool IDX, int SPARSE = 0>
-__global__ void __launch_bounds__(kBlock, (kMinBlocks<LAW, IDX>)) evaluate_kernel(const EvalArgs a) {
-    __shared__ __attribute__((aligned(16))) Tables T;
-    __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
-    __shared__ int rows_all[IDX ? kWavesPerBlock : 1][kWave];
-    stage_tables(a, &T);
-
+// the work of workgroup `block` of `nblocks` (tables staged): shared by the law's own kernel and the batch kernel
+template <int LAW, bool NT, bool IDX, int SPARSE>
+__device__ __forceinline__ void evaluate_blocks(ArgsRef a, const Tables* T, double (*scratch)[kRegionDoubles], int (*rows_all)[kWave],
+                                                int block, int nblocks) {
     const int lane = threadIdx.x & (kWave - 1);
     // wave index as a scalar: tile index, p0 and every array's tile base pointer then live in SGPRs and
     // the per-lane part of an address is a small 32-bit offset (saddr addressing)
@@ -151,15 +148,36 @@ __global__ void __launch_bounds__(kBlock, (kMinBlocks<LAW, IDX>)) evaluate_kerne
     const int r0 = lane % 18;
     const long long nfull = a.n / kWave;
     WaveStats st;
-    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
-    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride)
-        run_full_tile<LAW, IDX, NT, SPARSE>(a, &T, region, rows_lds, tile * kWave, lane, r0, st);
-    flush_stats<LAW>(a, st, lane);
+    const long long wstride = (long long)nblocks * kWavesPerBlock;
+    for (long long tile = (long long)block * kWavesPerBlock + wave; tile < nfull; tile += wstride)
+        run_full_tile<LAW, IDX, NT, SPARSE>(a, T, region, rows_lds, tile * kWave, lane, r0, st);
+    flush_stats<LAW>(a, st, lane, block);
+}
+
+// the last, ragged tile (n % 64 points): one wavefront, guarded 8-byte accesses
+template <int LAW, bool IDX, int SPARSE>
+__device__ __forceinline__ void evaluate_tail_tile(ArgsRef a, const Tables* T, double* region, int* rows_lds, int lane) {
+    const long long p0 = (a.n / kWave) * kWave;
+    WaveStats st;
+    const StressBases sb{a.stress_in, a.stress_out, a.tangent, a.stress_out2};
+    run_tile<LAW, IDX, false, false, SPARSE>(a, sb, T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
+    flush_stats<LAW>(a, st, lane, 0);
+}
+
+template <int LAW, bool NT, bool IDX, int SPARSE = 0>
+__global__ void __launch_bounds__(kBlock, (kMinBlocks<LAW, IDX>)) evaluate_kernel(const EvalArgs) {
+    ArgsRef a = kernel_args();
+    __shared__ __attribute__((aligned(16))) Tables T;
+    __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
+    __shared__ int rows_all[IDX ? kWavesPerBlock : 1][kWave];
+    stage_tables(a, &T);
+    evaluate_blocks<LAW, NT, IDX, SPARSE>(a, &T, scratch, rows_all, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Low-dimensional constraints: same persistent structure, DIMS = 1 or 2.
 template <int LAW, int DIMS, bool NT>
-__global__ void __launch_bounds__(kBlock, 4) evaluate_lowdim_kernel(const EvalArgs a) {
+__global__ void __launch_bounds__(kBlock, 4) evaluate_lowdim_kernel(const EvalArgs) {
+    ArgsRef a = kernel_args();
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     stage_tables(a, &T);
@@ -181,14 +199,16 @@ constexpr int kUxTrips = 4;  // pairs of points per thread of the uniaxial strea
 // consecutive pairs of points and ends, so the resident workgroups sweep the arrays as one front (measured on
 // 1e8 points, one process, identical buffers: a grid-stride loop over 16k workgroups 0.536 ms, over 64k 0.496 ms).
 template <int LAW, bool NT>
-__global__ void __launch_bounds__(kBlock, 8) evaluate_uniaxial_kernel(const EvalArgs a) {
+__global__ void __launch_bounds__(kBlock, 8) evaluate_uniaxial_kernel(const EvalArgs) {
+    ArgsRef a = kernel_args();
     const long long npairs = (a.n / kWave) * (kWave / 2);
     const long long lo = (long long)blockIdx.x * (kBlock * kUxTrips), hi = lo + kBlock * kUxTrips;
     stream_uniaxial<LAW, NT>(a, hi < npairs ? hi : npairs, lo + threadIdx.x, kBlock);
 }
 
 template <int LAW, int DIMS>
-__global__ void __launch_bounds__(kWave) evaluate_lowdim_tail_kernel(const EvalArgs a) {
+__global__ void __launch_bounds__(kWave) evaluate_lowdim_tail_kernel(const EvalArgs) {
+    ArgsRef a = kernel_args();
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
     stage_tables(a, &T);
@@ -198,7 +218,7 @@ __global__ void __launch_bounds__(kWave) evaluate_lowdim_tail_kernel(const EvalA
 
 // Fused wrapper kernels (VonMises3D under UniaxialStrainFrom3D / PlaneStrainFrom3D).
 template <int LAW, int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void run_wrapped_tile(const EvalArgs& a, const Tables* T, double* region, long long p0,
+__device__ __forceinline__ void run_wrapped_tile(ArgsRef a, const Tables* T, double* region, long long p0,
                                                  int npts, int lane, WaveStats& st) {
     if constexpr (LAW == LAW_VM3D)
         tile_von_mises_wrapped<WRAP, FULL, NT>(a, T, region, p0, npts, lane, st);
@@ -213,7 +233,8 @@ __device__ __forceinline__ void run_wrapped_tile(const EvalArgs& a, const Tables
 }
 
 template <int LAW, int WRAP, bool NT>
-__global__ void __launch_bounds__(kBlock, (LAW >= LAW_COMFE_DP ? 3 : 4)) evaluate_wrapped_kernel(const EvalArgs a) {
+__global__ void __launch_bounds__(kBlock, (LAW >= LAW_COMFE_DP ? 3 : 4)) evaluate_wrapped_kernel(const EvalArgs) {
+    ArgsRef a = kernel_args();
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     stage_tables(a, &T);
@@ -231,7 +252,8 @@ __global__ void __launch_bounds__(kBlock, (LAW >= LAW_COMFE_DP ? 3 : 4)) evaluat
 }
 
 template <int LAW, int WRAP>
-__global__ void __launch_bounds__(kWave) evaluate_wrapped_tail_kernel(const EvalArgs a) {
+__global__ void __launch_bounds__(kWave) evaluate_wrapped_tail_kernel(const EvalArgs) {
+    ArgsRef a = kernel_args();
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
     stage_tables(a, &T);
@@ -243,17 +265,75 @@ __global__ void __launch_bounds__(kWave) evaluate_wrapped_tail_kernel(const Eval
 
 // Tail kernel: the last, ragged tile (n % 64 points), one wavefront, guarded 8-byte accesses.
 template <int LAW, bool IDX, int SPARSE = 0>
-__global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs a) {
+__global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs) {
+    ArgsRef a = kernel_args();
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double region[kRegionDoubles];
     __shared__ int rows_lds[kWave];
     stage_tables(a, &T);
-    const int lane = threadIdx.x;
-    const long long p0 = (a.n / kWave) * kWave;
-    WaveStats st;
-    const StressBases sb{a.stress_in, a.stress_out, a.tangent, a.stress_out2};
-    run_tile<LAW, IDX, false, false, SPARSE>(a, sb, &T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
-    flush_stats<LAW>(a, st, lane);
+    evaluate_tail_tile<LAW, IDX, SPARSE>(a, &T, region, rows_lds, (int)threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------
+// The batch kernel (fcamd_evaluate_batch): the laws of ONE form() in one launch.  The reference calls its laws back to back
+// (solver/_solver.py:143-144); as separate launches every small law costs the stream three dispatches (counters, main kernel,
+// ragged tile: ~30 us together at 1e4 points, measured), which is what a multi-material Newton iteration of a small mesh then
+// consists of.  Here a table in device memory holds one entry per law -- its EvalArgs exactly as its own kernel would get them,
+// the kernel variant, and the workgroups it owns -- and workgroup b finds its entry, stages that law's tables and runs the very
+// same tile code (evaluate_blocks / evaluate_tail_tile); the arguments are read through the constant address space like kernel
+// arguments (ArgsRef).  Bit for bit the results of the separate launches.
+// ---------------------------------------------------------------------------------------
+constexpr int batch_variant(int law, bool idx, int sparse) { return law * 8 + (idx ? 4 : 0) + sparse; }
+
+template <int LAW, bool IDX, int SPARSE>
+__device__ __forceinline__ void batch_run(ArgsRef a, const Tables* T, double (*scratch)[kRegionDoubles], int (*rows_all)[kWave],
+                                          int local, int main_blocks) {
+    if (local < main_blocks)
+        evaluate_blocks<LAW, true, IDX, SPARSE>(a, T, scratch, rows_all, local, main_blocks);
+    else if (threadIdx.x < kWave)
+        evaluate_tail_tile<LAW, IDX, SPARSE>(a, T, scratch[0], rows_all[0], (int)threadIdx.x);
+}
+
+__global__ void __launch_bounds__(kBlock, 3) evaluate_batch_kernel(const BatchEntry* table, int count) {
+    __shared__ __attribute__((aligned(16))) Tables T;
+    __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
+    __shared__ int rows_all[kWavesPerBlock][kWave];
+    const BatchEntry FCAMD_CONSTANT* tab = (const BatchEntry FCAMD_CONSTANT*)table;
+    int k = 0;  // the entry this workgroup belongs to (uniform: scalar loads and compares)
+    for (int j = 1; j < count; ++j)
+        if ((int)blockIdx.x >= tab[j].first_block) k = j;
+    ArgsRef a = tab[k].args;
+    const int local = (int)blockIdx.x - tab[k].first_block, mb = tab[k].main_blocks;
+    stage_tables(a, &T);
+#define FCAMD_BATCH_CASE(LAW, IDX, SPARSE)                                           \
+    case batch_variant(LAW, IDX, SPARSE):                                            \
+        batch_run<LAW, IDX, SPARSE>(a, &T, scratch, rows_all, local, mb);            \
+        break;
+#define FCAMD_BATCH_LAW(LAW) FCAMD_BATCH_CASE(LAW, false, 0) FCAMD_BATCH_CASE(LAW, true, 0)
+    switch (tab[k].variant) {
+        FCAMD_BATCH_LAW(LAW_LE)
+        FCAMD_BATCH_LAW(LAW_VM3D)
+        FCAMD_BATCH_CASE(LAW_VM3D, false, 1)
+        FCAMD_BATCH_CASE(LAW_VM3D, true, 1)
+        FCAMD_BATCH_CASE(LAW_VM3D, false, 2)
+        FCAMD_BATCH_CASE(LAW_VM3D, true, 2)
+        FCAMD_BATCH_LAW(LAW_MAXWELL)
+        FCAMD_BATCH_LAW(LAW_KELVIN)
+        FCAMD_BATCH_LAW(LAW_COMFE_LE)
+        FCAMD_BATCH_LAW(LAW_COMFE_MISES)
+        FCAMD_BATCH_LAW(LAW_COMFE_DP)
+        FCAMD_BATCH_LAW(LAW_COMFE_DP_HYPER)
+        default: break;
+    }
+#undef FCAMD_BATCH_LAW
+#undef FCAMD_BATCH_CASE
+}
+
+// the counters of every counting law of the table back to zero: one workgroup per entry (kCounterSlots x 4 = 256 words)
+__global__ void __launch_bounds__(kBlock) batch_zero_counters_kernel(const BatchEntry* table) {
+    const BatchEntry FCAMD_CONSTANT* tab = (const BatchEntry FCAMD_CONSTANT*)table;
+    unsigned long long* c = tab[blockIdx.x].args.counters;
+    if (tab[blockIdx.x].counts && c != nullptr) c[threadIdx.x] = 0ull;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -317,6 +397,21 @@ static hipError_t launch_lowdim(const EvalArgs& args, int grid, hipStream_t stre
     }
     if (args.n % kWave != 0)
         hipLaunchKernelGGL((evaluate_lowdim_tail_kernel<LAW, DIMS>), dim3(1), dim3(kWave), 0, stream, args);
+    return hipGetLastError();
+}
+
+// the kernel variant launch_law<LAW> picks for these arguments, as the batch kernel's code
+int batch_variant_of(int law, const EvalArgs& args) {
+    int sparse = 0;
+    if (law == LAW_VM3D && args.hmask) sparse = (args.flags & kFlagPackedHistory) ? 2 : 1;
+    return batch_variant(law, args.rows != nullptr, sparse);
+}
+
+hipError_t launch_evaluate_batch(const BatchEntry* table, int count, int total_blocks, bool any_counts, hipStream_t stream) {
+    static_assert(kCounterSlots * 4 == kBlock, "batch_zero_counters_kernel: one thread per counter word");
+    if (count <= 0 || total_blocks <= 0) return hipSuccess;
+    if (any_counts) hipLaunchKernelGGL(batch_zero_counters_kernel, dim3(count), dim3(kBlock), 0, stream, table);
+    hipLaunchKernelGGL(evaluate_batch_kernel, dim3(total_blocks), dim3(kBlock), 0, stream, table, count);
     return hipGetLastError();
 }
 

@@ -97,7 +97,7 @@ struct PackedRows {
     }
     // trial run <- `row` (the final row of this lane's point: committed row + increment where it is plastic now, the committed
     // row's bits elsewhere, as the plain protocol leaves them); records ever_trial = ever_in | mask
-    __device__ __forceinline__ void scatter(const EvalArgs& a, double* rows_out, long long p0, int lane, unsigned long long mask,
+    __device__ __forceinline__ void scatter(ArgsRef a, double* rows_out, long long p0, int lane, unsigned long long mask,
                                             double* region, const double (&row)[6]) {
         const unsigned long long ever_out = ever_in | mask;
         // the run that is written ends on a 128-byte line (the rest of the slot is undefined by contract): no partial line leaves
@@ -186,7 +186,7 @@ struct SparseWords {
     unsigned long long m_old = 0ull, ever = 0ull;
     bool same_layout = false;  // packed: the trial run has the committed run's layout (same EVER word: nothing grew since the last commit)
 };
-__device__ __forceinline__ SparseWords sparse_words(const EvalArgs& a, long long p0) {
+__device__ __forceinline__ SparseWords sparse_words(ArgsRef a, long long p0) {
     SparseWords w;
     if (a.hmask != nullptr) {
         w.m_old = a.hmask[p0 >> 6];
@@ -208,16 +208,16 @@ __device__ __forceinline__ void sparse_words_uniform(SparseWords& w) {
     w.same_layout = __builtin_amdgcn_readfirstlane((int)w.same_layout) != 0;
 }
 // plastic | formerly plastic points of the tile under the sparse protocol
-__device__ __forceinline__ unsigned long long sparse_touched(const EvalArgs& a, const SparseWords& w, unsigned long long mask) {
+__device__ __forceinline__ unsigned long long sparse_touched(ArgsRef a, const SparseWords& w, unsigned long long mask) {
     return a.hmask == nullptr ? mask : (mask | w.m_old);
 }
-__device__ __forceinline__ void sparse_record(const EvalArgs& a, const SparseWords& w, long long p0, unsigned long long mask, int lane) {
+__device__ __forceinline__ void sparse_record(ArgsRef a, const SparseWords& w, long long p0, unsigned long long mask, int lane) {
     if (a.hmask != nullptr && lane == 0 && mask != w.m_old) a.hmask[p0 >> 6] = mask;
 }
 
 // `touched`: sparse_touched() of the tile
 template <bool FULL, bool NT>
-__device__ __forceinline__ void history7_store(const EvalArgs& a, long long p0, int npts, int lane,
+__device__ __forceinline__ void history7_store(ArgsRef a, long long p0, int npts, int lane,
                                                unsigned long long touched, bool hist_in_place, double* region,
                                                const double (&h)[7]) {
     const unsigned long long need = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
@@ -253,7 +253,7 @@ struct SplitRows {
     bool packed = false, masked = false;
     bool row_live[3] = {true, true, true};
 
-    __device__ __forceinline__ void request(const EvalArgs& a, const SparseWords& w, long long p0, int npts, int lane,
+    __device__ __forceinline__ void request(ArgsRef a, const SparseWords& w, long long p0, int npts, int lane,
                                             unsigned long long touched, bool hist_in_place, double* region) {
         rows = (a.hmask != nullptr || hist_in_place) ? touched : ~0ull;
         if (rows == 0ull) return;
@@ -300,7 +300,7 @@ struct SplitRows {
 #pragma unroll
         for (int i = 0; i < 6; ++i) d[i] = plastic ? ep[i] + d[i] : ep[i];  // the others keep their bits (whole granules move: a neighbour's chunks leave as they came)
     }
-    __device__ __forceinline__ void store(const EvalArgs& a, long long p0, int npts, int lane, unsigned long long mask,
+    __device__ __forceinline__ void store(ArgsRef a, long long p0, int npts, int lane, unsigned long long mask,
                                           bool hist_in_place, double* region, double scalar, const double (&d)[6]) {
         const bool live = FULL || lane < npts;
         if (rows == 0ull) return;

@@ -11,7 +11,7 @@ namespace fcamd {
 // comfe-rs MisesPlasticity3D (mises_plasticity.rs:58-126): the whole update of one point.  In: e, s (sigma_n),
 // h = [alpha, eps_p(6)].  Out: s (total stress), h (updated if plastic), tangent parameters B, sc2 and the
 // (non-unit) flow direction nv.  Returns whether the point is plastic.
-__device__ __forceinline__ bool cm_point(const Scalars& sc, bool live, const double (&e)[6], double (&s)[6], double (&h)[7],
+__device__ __forceinline__ bool cm_point(ScalarsRef sc, bool live, const double (&e)[6], double (&s)[6], double (&h)[7],
                                          double& B, double& sc2, double (&nv)[6]) {
     const double kappa = sc.s[2], y_0 = sc.s[3], hh = sc.s[4], two_mu = sc.s[5], den = sc.s[6], s32 = sc.s[7],
                  three_mu = sc.s[8], hfac = sc.s[9];
@@ -72,7 +72,7 @@ __device__ __forceinline__ bool cm_point(const Scalars& sc, bool live, const dou
 //          s[5]=2*mu, s[6]=3*mu+h, s[7]=sqrt(3/2), s[8]=3*mu, s[9]=1/(1+h/(3 mu))
 // tables:  a = kappa*sym_id(x)sym_id, b = P_dev.   history field 0: [alpha, eps_p(6)] per point.
 template <bool IDX, bool FULL, bool NT>
-__device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
+__device__ __forceinline__ void tile_comfe_mises(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                                  int* rows_lds, long long p0, int npts, int lane,
                                                  WaveStats& st) {
     const SparseWords w = sparse_words(a, p0);  // first: they arrive with the gradient
@@ -134,7 +134,7 @@ __device__ __forceinline__ void tile_comfe_mises(const EvalArgs& a, const Stress
 }
 
 template <int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void tile_comfe_mises_wrapped(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void tile_comfe_mises_wrapped(ArgsRef a, const Tables* T, double* region,
                                                          long long p0, int npts, int lane, WaveStats& st) {
     const bool live = FULL || lane < npts;
     Chunks<7> ch;

@@ -101,7 +101,7 @@ struct DPTrial {
 };
 
 template <bool HYPER>
-__device__ __forceinline__ void dp_trial(const Scalars& sc, const double (&e)[6], const double (&sig0)[6], DPTrial& t) {
+__device__ __forceinline__ void dp_trial(ScalarsRef sc, const double (&e)[6], const double (&sig0)[6], DPTrial& t) {
     const double kappa = sc.s[2], a_ = sc.s[3], b = sc.s[4], dsq = sc.s[6], two_mu = sc.s[7];
     {
         const double tr = (e[0] + e[1]) + e[2], vol = tr / 3.0;
@@ -129,7 +129,7 @@ struct DPTangent {
 // return mapping of one plastic point: Newton in invariant coordinates, converged stress in t.sig1,
 // history h = [alpha, plastic_strain(6)] updated, tangent coefficients in tg
 template <bool HYPER>
-__device__ __forceinline__ void dp_return(const Scalars& sc, const double (&e)[6], const double (&sig0)[6], DPTrial& t,
+__device__ __forceinline__ void dp_return(ScalarsRef sc, const double (&e)[6], const double (&sig0)[6], DPTrial& t,
                                           double (&h)[7], DPTangent& tg, WaveStats& st) {
     const double kappa = sc.s[2], a_ = sc.s[3], b = sc.s[4], bflow = sc.s[5], dsq = sc.s[6], two_mu = sc.s[7],
                  s23 = sc.s[8], inv4mu = sc.s[9], inv9k = sc.s[10];
@@ -235,7 +235,7 @@ __device__ __forceinline__ void dp_publish(double* region, int lane, const DPTan
 }
 
 template <bool HYPER, bool IDX, bool FULL, bool NT>
-__device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBases& sb, const Tables* T,
+__device__ __forceinline__ void tile_comfe_dp(ArgsRef a, const StressBases& sb, const Tables* T,
                                               double* region, int* rows_lds, long long p0, int npts, int lane,
                                               int r0, WaveStats& st) {
     SparseWords w = sparse_words(a, p0);  // first: they arrive with the gradient
@@ -331,7 +331,7 @@ __device__ __forceinline__ void tile_comfe_dp(const EvalArgs& a, const StressBas
 
 // fused 3D -> 1D/2D wrapper around the Drucker-Prager laws (see the Mises versions above)
 template <bool HYPER, int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void tile_comfe_dp_wrapped(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void tile_comfe_dp_wrapped(ArgsRef a, const Tables* T, double* region,
                                                       long long p0, int npts, int lane, WaveStats& st) {
     const bool live = FULL || lane < npts;
     Chunks<7> ch;

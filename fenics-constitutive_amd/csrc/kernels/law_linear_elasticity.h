@@ -13,7 +13,7 @@ namespace fcamd {
 
 // --- LinearElasticityModel: sigma += d_eps @ D ; tangent = tile(D) ----------------------
 template <bool IDX, bool FULL, bool NT>
-__device__ __forceinline__ void tile_linear_elasticity(const EvalArgs& a, const StressBases& sb, const Tables* T,
+__device__ __forceinline__ void tile_linear_elasticity(ArgsRef a, const StressBases& sb, const Tables* T,
                                                        double* region, int* rows_lds, long long p0,
                                                        int npts, int lane, int r0) {
     Chunks<9> cg;
@@ -37,7 +37,7 @@ __device__ __forceinline__ void tile_linear_elasticity(const EvalArgs& a, const 
 
 // --- comfe-rs LinearElasticity3D: sigma += C . d_eps (column axpy, no FMA) ---------------
 template <bool IDX, bool FULL, bool NT>
-__device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
+__device__ __forceinline__ void tile_comfe_le(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                               int* rows_lds, long long p0, int npts, int lane, int r0) {
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void tile_comfe_le(const EvalArgs& a, const StressBas
 
 // LinearElasticityModel behind the wrappers (what the reference's own tests wrap, test_elasticity.py:206,278)
 template <int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void tile_linear_elasticity_wrapped(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void tile_linear_elasticity_wrapped(ArgsRef a, const Tables* T, double* region,
                                                                long long p0, int npts, int lane) {
     if (a.tangent) wrapped_tangent_const<WRAP, FULL, NT>(a, T->c, p0, npts, lane);
     double g[9], s[6], e[6], ds[6];

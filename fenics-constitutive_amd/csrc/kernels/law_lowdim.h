@@ -34,8 +34,8 @@ __device__ __forceinline__ void strain_lowdim(const double (&g)[LowDim<DIMS>::GD
     }
 }
 
-template <int SD>
-__device__ __forceinline__ void row_times_matrix_fma_n(const double (&x)[SD], const double* M,
+template <int SD, class TAB>
+__device__ __forceinline__ void row_times_matrix_fma_n(const double (&x)[SD], TAB M,  // M: a table in LDS or among the kernel arguments
                                                        double (&y)[SD]) {
 #pragma unroll
     for (int i = 0; i < SD; ++i) {
@@ -73,8 +73,8 @@ __device__ __forceinline__ void tangent_const_n(const double* tab, double* dst, 
 
 // One point: stress and the two history fields advanced by the strain increment e.  A, B = the law's tables (LDS for the
 // tiled kernels, kernel arguments for the uniaxial stream).
-template <int LAW, int DIMS>
-__device__ __forceinline__ void lowdim_point(const Scalars& sc, const double* A, const double* B,
+template <int LAW, int DIMS, class TAB>
+__device__ __forceinline__ void lowdim_point(ScalarsRef sc, TAB A, TAB B,
                                              const double (&e)[LowDim<DIMS>::SD], double (&s)[LowDim<DIMS>::SD],
                                              double (&ev)[LowDim<DIMS>::SD], double (&en)[LowDim<DIMS>::SD]) {
     constexpr int SD = LowDim<DIMS>::SD;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void lowdim_point(const Scalars& sc, const double* A,
 }
 
 template <int LAW, int DIMS, bool FULL, bool NT>
-__device__ __forceinline__ void tile_lowdim(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void tile_lowdim(ArgsRef a, const Tables* T, double* region,
                                             long long p0, int npts, int lane) {
     constexpr int GD2 = LowDim<DIMS>::GD2, SD = LowDim<DIMS>::SD;
     constexpr bool HIST = (LAW != LAW_LE);
@@ -147,7 +147,7 @@ __device__ __forceinline__ void tile_lowdim(const EvalArgs& a, const Tables* T, 
 // consecutive points (16-byte accesses), two pairs per trip (2 KiB per wave and array in flight); the arithmetic is
 // lowdim_point<LAW, 1>, the same instructions as the tiled form.
 template <int LAW, bool NT>
-__device__ __forceinline__ void pair_uniaxial(const EvalArgs& a, long long q, const d2 g, const d2 s0, const d2 v0, const d2 n0) {
+__device__ __forceinline__ void pair_uniaxial(ArgsRef a, long long q, const d2 g, const d2 s0, const d2 v0, const d2 n0) {
     double e[1], s[1], ev[1], en[1];
     d2 so, vo, no;
     e[0] = g.x; s[0] = s0.x; ev[0] = v0.x; en[0] = n0.x;
@@ -170,7 +170,7 @@ __device__ __forceinline__ void pair_uniaxial(const EvalArgs& a, long long q, co
 }
 
 template <int LAW, bool NT>
-__device__ __forceinline__ void stream_uniaxial(const EvalArgs& a, long long npairs, long long first, long long stride) {
+__device__ __forceinline__ void stream_uniaxial(ArgsRef a, long long npairs, long long first, long long stride) {
     constexpr bool HIST = (LAW != LAW_LE);
     const d2 z = {0.0, 0.0};
     long long q = first;

@@ -11,7 +11,7 @@ namespace fcamd {
 //          Maxwell: s[4]=2*mu1 ; Kelvin: s[4]=2*mu0, s[5]=mu0/(tau*mu1), s[6]=lam0/(tau*2*mu1)
 // tables:  Maxwell a=D1, b=D0+D1, c=tangent ; Kelvin a=D0, c=tangent
 template <bool KELVIN, bool IDX, bool FULL, bool NT>
-__device__ __forceinline__ void tile_sls(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
+__device__ __forceinline__ void tile_sls(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                          int* rows_lds, long long p0, int npts, int lane, int r0) {
     Chunks<9> cg;
     StressRows<IDX, FULL, NT> sr;

@@ -20,7 +20,7 @@ struct VMTrial {
     double tr_eps, sigtrn, phitr;
 };
 
-__device__ __forceinline__ void vm_trial(const Scalars& sc, const double (&e)[6], const double (&s)[6], double alpha_n,
+__device__ __forceinline__ void vm_trial(ScalarsRef sc, const double (&e)[6], const double (&s)[6], double alpha_n,
                                          VMTrial& t) {
     const double two_mu = sc.s[2], s23 = sc.s[3], y0 = sc.s[4], dy = sc.s[5], mw = sc.s[6];
     t.tr_eps = (e[0] + e[1]) + e[2];
@@ -47,7 +47,7 @@ struct VMReturn {
     double N[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 };
 
-__device__ __forceinline__ void vm_return(const Scalars& sc, const VMTrial& t, double alpha_n, VMReturn& r, WaveStats& st) {
+__device__ __forceinline__ void vm_return(ScalarsRef sc, const VMTrial& t, double alpha_n, VMReturn& r, WaveStats& st) {
     const double two_mu = sc.s[2], s23 = sc.s[3], y0 = sc.s[4], dy = sc.s[5], mw = sc.s[6], m2mu = sc.s[7], c23dyw = sc.s[8];
     double g0 = 1.0, g1 = 0.0, xr = 1.0, xg;
     int it = 0;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void vm_return(const Scalars& sc, const VMTrial& t, d
 }
 
 // stress (:165-167): sigma += (ka tr_eps) I2 + del_sigtr - (2 mu gamma) N;  tangent coefficients (:170-175)
-__device__ __forceinline__ void vm_stress(const Scalars& sc, const VMTrial& t, const VMReturn& r, double (&s)[6]) {
+__device__ __forceinline__ void vm_stress(ScalarsRef sc, const VMTrial& t, const VMReturn& r, double (&s)[6]) {
     const double kt = sc.s[1] * t.tr_eps, tmg = sc.s[2] * r.gamma;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -84,7 +84,7 @@ __device__ __forceinline__ void vm_stress(const Scalars& sc, const VMTrial& t, c
         s[i] = s[i] + ((vol + t.dsig[i]) - tmg * r.N[i]);
     }
 }
-__device__ __forceinline__ void vm_tangent_coefficients(const Scalars& sc, const VMReturn& r, double& B, double& C) {
+__device__ __forceinline__ void vm_tangent_coefficients(ScalarsRef sc, const VMReturn& r, double& B, double& C) {
     const double two_mu = sc.s[2], four_mu2 = sc.s[9];
     B = two_mu * (1.0 - two_mu * r.xc2);
     C = four_mu2 * (r.xc2 - r.xc1);
@@ -97,7 +97,7 @@ __device__ __forceinline__ void vm_tangent_coefficients(const Scalars& sc, const
 // HIST: 0 = the caller's arrays as they are (in place or out of place), 1 = sparse trial history (a.hmask),
 //       2 = sparse protocol on the packed plastic-strain layout (history_rows.h: PackedRows)
 template <bool IDX, int HIST, bool FULL, bool NT>
-__device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBases& sb, const Tables* T, double* region,
+__device__ __forceinline__ void tile_von_mises(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                                int* rows_lds, long long p0, int npts, int lane,
                                                WaveStats& st) {
     constexpr bool sparse = HIST != 0;
@@ -260,7 +260,7 @@ __device__ __forceinline__ void tile_von_mises(const EvalArgs& a, const StressBa
 }
 
 template <int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void tile_von_mises_wrapped(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void tile_von_mises_wrapped(ArgsRef a, const Tables* T, double* region,
                                                        long long p0, int npts, int lane, WaveStats& st) {
     const bool live = FULL || lane < npts;
     double g[9], s[6], e[6];

@@ -61,7 +61,7 @@ constexpr int kFlagSplitHistory = 4;
 // the rows of the ever-plastic points as one contiguous run; EvalArgs::emask_in / emask_out are the tiles' EVER masks.
 constexpr int kFlagPackedHistory = 8;
 template <bool FULL>
-__device__ __forceinline__ unsigned long long sparse_tangent_need(const EvalArgs& a, unsigned long long need) {
+__device__ __forceinline__ unsigned long long sparse_tangent_need(ArgsRef a, unsigned long long need) {
     return (FULL && (a.flags & kFlagSparseTangent) != 0 && a.hmask != nullptr) ? need : ~0ull;
 }
 

@@ -199,7 +199,7 @@ template <bool IDX, bool FULL, bool NT>
 struct StressRows {
     Chunks<6> c;
 
-    __device__ __forceinline__ void load(const EvalArgs& a, const StressBases& sb, long long p0, int npts, int lane,
+    __device__ __forceinline__ void load(ArgsRef a, const StressBases& sb, long long p0, int npts, int lane,
                                          int* rows_lds) {
         if constexpr (IDX) {
             // chunk-major like the contiguous tile: lane l moves chunks l, l + 64, l + 128 of the tile's VIRTUAL image, three

@@ -21,7 +21,7 @@ namespace fcamd {
 
 // inputs of a wrapped tile: padded gradient g[9] and the 3-D stress row s[6] (cache + mapped components)
 template <int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void wrapped_load(const EvalArgs& a, double* region, long long p0, int npts, int lane,
+__device__ __forceinline__ void wrapped_load(ArgsRef a, double* region, long long p0, int npts, int lane,
                                              double (&g)[9], double (&s)[6]) {
     constexpr int LD = WRAP == 1 ? 1 : 4;  // doubles per point of the low-dimensional gradient and stress
     const bool live = FULL || lane < npts;
@@ -49,7 +49,7 @@ __device__ __forceinline__ void wrapped_load(const EvalArgs& a, double* region, 
 
 // the full 3-D row goes back to the wrapper's cache, the mapped components to the caller
 template <int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void wrapped_store_stress(const EvalArgs& a, double* region, long long p0, int npts,
+__device__ __forceinline__ void wrapped_store_stress(ArgsRef a, double* region, long long p0, int npts,
                                                      int lane, const double (&s)[6]) {
     transpose_out<6, FULL, NT>(s, region, lane, a.cache3d + p0 * 6, npts * 6);
     if constexpr (WRAP == 1) {
@@ -64,7 +64,7 @@ __device__ __forceinline__ void wrapped_store_stress(const EvalArgs& a, double* 
 
 // mapped block of the Mises tangents, entries formed exactly as tangent_mises does
 template <bool COMFE, int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void wrapped_tangent_mises(const EvalArgs& a, const Tables* T, double* region,
+__device__ __forceinline__ void wrapped_tangent_mises(ArgsRef a, const Tables* T, double* region,
                                                       long long p0, int npts, int lane, double B, double C,
                                                       const double (&N)[6]) {
     if constexpr (WRAP == 1) {
@@ -107,7 +107,7 @@ __device__ __forceinline__ void wrapped_tangent_mises(const EvalArgs& a, const T
 
 // mapped block of a point-independent tangent table (LE): [0][0] or the block [0:4, 0:4]
 template <int WRAP, bool FULL, bool NT>
-__device__ __forceinline__ void wrapped_tangent_const(const EvalArgs& a, const double* tab, long long p0, int npts,
+__device__ __forceinline__ void wrapped_tangent_const(ArgsRef a, const double* tab, long long p0, int npts,
                                                       int lane) {
     if constexpr (WRAP == 1) {
         if (FULL || lane < npts) a.tangent[p0 + lane] = tab[0];

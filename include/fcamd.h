@@ -270,11 +270,13 @@ FCAMD_API int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_
 /* The laws of ONE form() in one call.  The reference calls its laws back to back, one LawOnSubMesh.evaluate per material
    (solver/_solver.py:143-144); here `count` device calls -- models[k] over n[k] points with args[k], each exactly as
    fcamd_evaluate_device_ex takes it (any form but the fused wrapper one), all of one context, one t / del_t -- are checked
-   first (if one is refused nothing is launched and its status is returned), then enqueued from this one call: one trip
-   through the binding instead of `count`, and the laws that cannot fill the device on their own (fewer than 4096 points per
-   compute unit) run concurrently on side streams of the context, forked from and joined back into the context's stream
-   by events -- to the caller it is one asynchronous operation on that stream.  Precondition (the reference's, too): the laws
-   write disjoint rows of the arrays they share.  Results are bit for bit those of the same calls made one by one. */
+   first (if one is refused nothing is launched and its status is returned), then enqueued on the context's stream from this
+   one call.  Laws that fill the device on their own (4096 points per compute unit and more) keep their own launches; the
+   others -- as separate launches three dispatches each: counters, main kernel, ragged tile -- leave as ONE launch of a batch
+   kernel that reads every law's arguments from a table in device memory.  The table is uploaded only when it changes, so the
+   Newton iterations of an increment (same arrays, new gradient values) cost two dispatches whatever the number of laws.
+   Precondition (the reference's, too): the laws write disjoint rows of the arrays they share.  Results are bit for bit those
+   of the same calls made one by one.  Context option "batch_kernel" (FCAMD_BATCH_KERNEL, 1): 0 = one launch per law. */
 FCAMD_API int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n, const fcamd_eval_args* args,
                                    double t, double del_t);
 
@@ -531,7 +533,7 @@ FCAMD_API int fcamd_device_free(fcamd_context* ctx, void* ptr);
 /* ---- tuning / introspection -------------------------------------------------- */
 /* Context options (name, value).  Launch / data-path knobs (experiments; the defaults are the measured optimum) and
    their FCAMD_* environment defaults, which are read ONCE, when the context is created:
-     "masked_max" (FCAMD_MASKED_MAX, -1 = per law),
+     "masked_max" (FCAMD_MASKED_MAX, -1 = per law), "batch_kernel" (FCAMD_BATCH_KERNEL, 1: fcamd_evaluate_batch),
      "host_chunk" (FCAMD_HOST_CHUNK, 0 = automatic), "host_slots" (FCAMD_HOST_SLOTS, 4),
      "bounce_max" (FCAMD_BOUNCE_MAX, 256 KiB: host calls up to this size go through the page-locked scratch),
      "zero_copy" (FCAMD_ZERO_COPY, 1), "zero_copy_grad" (FCAMD_ZERO_COPY_GRAD, 1);
