@@ -202,8 +202,12 @@ def main_pmc_child(args):
     os.environ["FROW_PLACEMENT"] = "torch"
     history = "sparse" if args.sparse_history else args.history
     log = []
+    t_child = time.perf_counter()
     for k, item in enumerate([x for x in args.pmc_child.split(",") if x]):
         name, _, form = item.partition("+")
+        if args.pmc_budget > 0 and time.perf_counter() - t_child > args.pmc_budget:
+            log.append([item, "error", "time budget of this pass"])  # the parent keeps what came before
+            break
         try:
             if name in bench_frows.FROWS:
                 out = bench_frows.run_frow(name, args.n, device, launches=4, warm=2, peak_gbs=HBM_PEAK_GBS, draws=1)
@@ -256,6 +260,7 @@ def main():
                     help="run ONE row of SURVEY 8(f) alone (benchlib.frows.FROWS: indexed evaluate, fused wrapper, low-dimensional kernels, "
                          "resident sparse-tangent iteration) and print its figures -- the child of the default run's PMC passes")
     ap.add_argument("--pmc-child", default=None, help="(internal) the child of a rocprofv3 --pmc pass: comma-separated workloads / 8(f) rows, see main_pmc_child")
+    ap.add_argument("--pmc-budget", type=float, default=0.0, help="(internal) --pmc-child: seconds after which no further item is started")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
                     help="where the full record behind the compact stdout line is written (the line carries the path)")
     ap.add_argument("--full", action="store_true",
@@ -501,10 +506,15 @@ def main():
     # ... and the reference's own call: law.evaluate(...) IN PLACE on the interface's arrays (what a drop-in torch caller launches;
     # the committed state is copied into the call's arrays before every launch, outside the event bracket)
     in_place_ms = None
+
+    class wl_in_place_draws:  # (the workload is freed before the line is assembled)
+        v = None
+
     if wl.plasticity and not wl.split and world == 1:
         try:
-            ms = wl.timed_in_place(5)
+            ms = wl.timed_in_place(5, sets=2)
             in_place_ms = sum(ms) / len(ms)
+            wl_in_place_draws.v = list(wl.in_place_draws_ms)
         except Exception as e:  # informational (e.g. no room for the second copy of the state)
             stage(f"in-place leg skipped: {type(e).__name__}: {e}")
     leg_done("reference_layout_legs")
@@ -645,6 +655,7 @@ def main():
         if in_place_ms is not None:
             out["in_place"] = {"kernel_ms_avg": round(in_place_ms, 4),
                                "frac": round(alg_bytes / (in_place_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "allocation_draws_ms": getattr(wl_in_place_draws, "v", None),
                                "note": "same step as the reference's own call: law.evaluate(...) in place on the interface's arrays (reference layout, "
                                        "no protocol words) -- what a drop-in torch caller launches"}
         out["placement"] = dict(headline["vmm_info"] or {"mode": "hipmalloc_tuned" if headline["placement"] else "first"})
@@ -719,11 +730,11 @@ def main():
                 configs[cname] = {"skipped": "wall budget"}
                 continue
             try:
-                # lean default: four hipMalloc candidates of the tangent, no VMM set; --full: four + the VMM set
+                # lean default: three hipMalloc candidates of the tangent, no VMM set; --full: four + the VMM set
                 # (under rocprofv3 released VMM memory stays alive: five more working sets would not fit -- hipMalloc candidates only)
                 lean_placement = "tune" if (args.placement == "auto" and (under_profiler() or not args.full)) else args.placement
                 configs[cname] = run_config(cname, n, 4321 + k, device, dev_index, max(5, args.config_steps), 2,
-                                            min(tries, 4), history=history, placement=lean_placement,
+                                            min(tries, 4 if args.full else 3), history=history, placement=lean_placement,
                                             cpu=args.full and not args.no_cpu_baseline)
             except Exception as e:  # one configuration failing must not lose the line
                 configs[cname] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -836,12 +847,15 @@ def main():
             extra = (["--no-split-history"] if args.no_split_history else []) \
                 + (["--sparse-tangent"] if args.sparse_tangent else [])
             torch.cuda.empty_cache()
-            # ONE child per counter runs every measured item: the headline, its reference-layout forms, the 8(f) rows (--full: the
-            # configurations too)
+            # ONE child per counter runs every measured item: the headline, its reference-layout forms, the configurations, the 8(f) rows
             items = [name] + ([name + "+unpacked"] if headline["packed"] else []) + ([name + "+in_place"] if in_place_ms is not None else [])
             measured = [c for c, v in (out.get("configs") or {}).items() if isinstance(v, dict) and "kernel_ms_avg" in v]
-            items += [c for c in measured if c in frow_names or args.full]
-            lt_all = live_traffic_batch(items, n, history, extra, min(150.0, budget_left() - 30.0), headline=name) or {}
+            items += [c for c in measured if c in frow_names] + [c for c in measured if c not in frow_names]
+            # the default command stays under two minutes: what is left of 108 s goes to the two passes (each stops starting new
+            # items when its half is used up: headline first, then its forms, the 8(f) rows, the configurations)
+            target = 240.0 if args.full else 108.0
+            pass_s = max(12.0, (target - (time.perf_counter() - t_prog)) / 2.0 - 3.0)
+            lt_all = live_traffic_batch(items, n, history, extra, min(150.0, budget_left() - 30.0), headline=name, pass_budget_s=pass_s) or {}
             lt = lt_all.get(name)
             if lt is not None:
                 rf = out["roofline"]

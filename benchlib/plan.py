@@ -65,7 +65,7 @@ def bench_plan(args):
                          f"shard {shard_gb:.1f} GB/GPU, stress gathered whole ({stress_all_gb:.1f} GB), tangent in ~{chunks} chunks through two buffers "
                          f"({buf_gb:.0f} GB); link-rate bounds: direct {direct_s:.2f} s, ring {ring_s:.2f} s; watchdog --gather-timeout {args.gather_timeout:.0f} s"))
     if world == 1 and args.workload is None and args.configs != "none":
-        cfg_tries = 4
+        cfg_tries = 4 if args.full else 3
         legs.append(_leg("configs", 5 * (ALLOC_S_PER_GB * (state_gb + (cfg_tries - 1) * tan_gb) + 3.0 + (4 * cfg_tries + 12) * step_s * 1.2), state_gb + (cfg_tries - 1) * tan_gb,
                          f"five other BASELINE configurations, {cfg_tries} tangent candidates each"))
         if not args.no_frows:
@@ -82,7 +82,8 @@ def bench_plan(args):
             legs.append(_leg("host_path", 2.0 + big * 568 / 2.0e9 + 18 * big * 400 / (PCIE_GBS * 1e9), 1.0, f"ndarray entries over PCIe at 1e6 and {big} points"))
     if world == 1:
         if not args.no_live_traffic:
-            items = 3 + (0 if (args.no_frows or args.workload is not None or args.configs == "none") else 9) + (5 if args.full else 0)
+            extra_rows = args.workload is None and args.configs != "none"
+            items = 3 + (5 if extra_rows else 0) + (9 if (extra_rows and not args.no_frows) else 0)
             legs.append(_leg("live_traffic", 2 * (IMPORT_S + 4.0 + items * (ALLOC_S_PER_GB * 0.8 * state_gb + 1.5)), state_gb,
                              f"two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE), {items} items each; the CPU baseline runs on the host meanwhile"))
         if not args.no_cpu_baseline:

@@ -115,7 +115,7 @@ def slice_timed(log, vals):
     return out
 
 
-def live_traffic_batch(items, n, history, extra, budget_s, headline=None):
+def live_traffic_batch(items, n, history, extra, budget_s, headline=None, pass_budget_s=0.0):
     """HBM bytes per timed launch of every item (workloads, their reference-layout forms `name+unpacked` / `name+in_place`, SURVEY
     8(f) rows), measured NOW as MI355X_MICROARCH.md ("HBM", rocprofv3) prescribes: two child runs of this file (`--pmc-child`: all
     items in ONE process, 4 timed launches each, the allocator's arrays as they come -- the traffic of a launch does not depend on
@@ -129,7 +129,8 @@ def live_traffic_batch(items, n, history, extra, budget_s, headline=None):
     if shutil.which("rocprofv3") is None or under_profiler() or not items:
         return None
     t_end = time.perf_counter() + budget_s
-    child_args = ["--pmc-child", ",".join(items), "--points", str(n), "--history", history] + (["--workload", headline] if headline else []) + list(extra)
+    child_args = ["--pmc-child", ",".join(items), "--points", str(n), "--history", history, "--pmc-budget", f"{pass_budget_s:.1f}"] \
+        + (["--workload", headline] if headline else []) + list(extra)
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         left = t_end - time.perf_counter()

@@ -18,6 +18,7 @@ libs = [a for a in sys.argv[1:] if a.endswith('.so')]
 sizes = [int(float(x)) for x in sys.argv[1:] if not x.endswith('.so')] or [1_000_000, 10_000_000, 100_000_000]
 LAW = os.environ.get("AB_LAW", "vm")  # vm | le | maxwell
 SPARSE = os.environ.get("AB_SPARSE", "0") == "1"
+INPLACE = os.environ.get("AB_INPLACE", "0") == "1"  # stress_prev == stress, history_prev == history (state restored before every launch)
 FLAGS = int(os.environ.get("AB_FLAGS", "0"))  # fcamd_eval_args.flags of the sparse protocol's launches (1 = sparse tangent)
 ZONED = os.environ.get("AB_ZONED", "0") == "1"
 CONSTRAINT = int(os.environ.get("AB_CONSTRAINT", "5"))
@@ -40,7 +41,7 @@ class Lib:
         self.mask = None
         self.warm = False
 
-    def run(self, n, g, s0, s1, t, h0, h1):
+    def run(self, n, g, s0, s1, t, h0, h1, ev=None):
         a0 = (C.c_void_p * 2)(h0[0].data_ptr(), h0[1].data_ptr())
         a1 = (C.c_void_p * 2)(h1[0].data_ptr(), h1[1].data_ptr())
         if SPARSE:
@@ -56,7 +57,13 @@ class Lib:
             rc = self.l.fcamd_evaluate_device_ex(self.m, 0.0, 1.0, n, C.byref(x))
             assert rc == 0, rc
             return
-        x = EvalArgs(g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, MODEL[2], None, None, 0, None, None, None, None, 0, None)
+        if INPLACE:  # the reference's own call: in place on the interface's arrays (the committed state is copied in first, outside the caller's events)
+            s1.copy_(s0), h1[0].copy_(h0[0]), h1[1].copy_(h0[1])
+            if ev is not None:
+                ev[0].record()
+            x = EvalArgs(g.data_ptr(), s1.data_ptr(), s1.data_ptr(), t.data_ptr(), a1, a1, MODEL[2], None, None, 0, None, None, None, None, 0, None)
+        else:
+            x = EvalArgs(g.data_ptr(), s0.data_ptr(), s1.data_ptr(), t.data_ptr(), a0, a1, MODEL[2], None, None, 0, None, None, None, None, 0, None)
         rc = self.l.fcamd_evaluate_device_ex(self.m, 0.0, 1.0, n, C.byref(x))
         assert rc == 0, rc
 
@@ -107,8 +114,9 @@ for n in sizes:
                 lib.run(n, g, s0, s1, t, h0, h1)
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
             for a, b in ev:
-                a.record()
-                lib.run(n, g, s0, s1, t, h0, h1)
+                if not INPLACE:
+                    a.record()
+                lib.run(n, g, s0, s1, t, h0, h1, ev=(a, b))
                 b.record()
             torch.cuda.synchronize()
             res[i].append(sum(a.elapsed_time(b) for a, b in ev) / reps)
