@@ -22,7 +22,8 @@ INPLACE = os.environ.get("AB_INPLACE", "0") == "1"  # stress_prev == stress, his
 FLAGS = int(os.environ.get("AB_FLAGS", "0"))  # fcamd_eval_args.flags of the sparse protocol's launches (1 = sparse tangent)
 ZONED = os.environ.get("AB_ZONED", "0") == "1"
 CONSTRAINT = int(os.environ.get("AB_CONSTRAINT", "5"))
-MODEL = {"vm": (2, [175000.0, 80769.0, 1200.0, 2500.0, 200.0], 2), "le": (1, [42.0, 0.3], 0), "maxwell": (3, [42.0, 10.0, 10.0, 0.2], 2)}[LAW]
+MODEL = {"vm": (2, [175000.0, 80769.0, 1200.0, 2500.0, 200.0], 2), "le": (1, [42.0, 0.3], 0), "maxwell": (3, [42.0, 10.0, 10.0, 0.2], 2),
+         "dp": (7, [80769.0, 175000.0, 100.0, 0.05, 0.02], 1)}[LAW]  # dp: Drucker-Prager (classic), bench.py's drucker_prager_mixed inputs
 dev = torch.device("cuda", 0)
 torch.zeros(1, device=dev)
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -42,12 +43,12 @@ class Lib:
         self.warm = False
 
     def run(self, n, g, s0, s1, t, h0, h1, ev=None):
-        a0 = (C.c_void_p * 2)(h0[0].data_ptr(), h0[1].data_ptr())
-        a1 = (C.c_void_p * 2)(h1[0].data_ptr(), h1[1].data_ptr())
+        a0 = (C.c_void_p * 2)(h0[0].data_ptr(), h0[-1].data_ptr())
+        a1 = (C.c_void_p * 2)(h1[0].data_ptr(), h1[-1].data_ptr())
         if SPARSE:
             if self.mask is None or self.mask.numel() != (n + 63) // 64:
                 # protocol: trial == committed wherever the mask is clear
-                h1[0].copy_(h0[0]), h1[1].copy_(h0[1])
+                h1[0].copy_(h0[0]), h1[-1].copy_(h0[-1])
                 self.mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
                 self.warm = False
             flags = FLAGS if self.warm else 0  # the first launch of a size writes the whole tangent (the sparse-tangent protocol's premise)
@@ -58,7 +59,7 @@ class Lib:
             assert rc == 0, rc
             return
         if INPLACE:  # the reference's own call: in place on the interface's arrays (the committed state is copied in first, outside the caller's events)
-            s1.copy_(s0), h1[0].copy_(h0[0]), h1[1].copy_(h0[1])
+            s1.copy_(s0), h1[0].copy_(h0[0]), h1[-1].copy_(h0[-1])
             if ev is not None:
                 ev[0].record()
             x = EvalArgs(g.data_ptr(), s1.data_ptr(), s1.data_ptr(), t.data_ptr(), a1, a1, MODEL[2], None, None, 0, None, None, None, None, 0, None)
@@ -81,7 +82,17 @@ for n in sizes:
     else:
         g.view(n, 9).mul_(torch.pow(10.0, torch.rand(n, generator=gen, **f) * 2 - 4)[:, None])
     s0, s1 = torch.zeros(6 * n, **f), torch.empty(6 * n, **f)
-    if LAW == "maxwell":
+    if LAW == "dp":  # mostly isochoric increments, scale log-uniform in [1e-4, 5e-3], compressive prestress (benchlib/workloads.py)
+        g = torch.randn(9 * n, generator=gen, **f)
+        gv = g.view(n, 9)
+        gv.mul_(torch.pow(10.0, torch.rand(n, generator=gen, **f) * 1.7 - 4.0)[:, None])
+        tr = (gv[:, 0] + gv[:, 4] + gv[:, 8]) * (0.95 / 3.0)
+        for c_ in (0, 4, 8):
+            gv[:, c_] -= tr
+        s0.view(n, 6)[:, :3] = -1000.0
+        h0 = [torch.zeros(7 * n, **f)]
+        h1 = [torch.empty(7 * n, **f)]
+    elif LAW == "maxwell":
         h0 = [torch.zeros(6 * n, **f), torch.zeros(6 * n, **f)]
         h1 = [torch.empty(6 * n, **f), torch.empty(6 * n, **f)]
     else:

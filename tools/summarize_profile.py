@@ -30,10 +30,20 @@ def rows(pattern):
 
 
 def bench_line(name):
-    p = os.path.join(src, name)
-    if os.path.exists(p):
+    """the full record of a profiled bench.py run: its --detail file (round 5: the stdout line is compact and carries no launch logs)"""
+    for cand in (name, name.replace(".log", "_detail.json")):
+        p = os.path.join(src, cand)
+        if not os.path.exists(p):
+            continue
+        try:
+            with open(p) as f:
+                d = json.load(f)
+            if isinstance(d, dict) and "launch_log" in d:
+                return d
+        except ValueError:
+            pass
         for line in open(p):
-            if line.startswith("{") and '"metric"' in line:
+            if line.startswith("{") and '"metric"' in line and '"launch_log"' in line:
                 return json.loads(line)
     return {}
 
@@ -70,7 +80,8 @@ with open(out, "w") as f:
     f.write(f"# rocprofv3 summary, round {rnd}, workload `{workload}`\n\n")
     if is_default:
         f.write("Command (tools/profile_default.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py` "
-                "-- the driver's bench command, no flags: the headline workload and the five other single-GPU configurations.\n\n")
+                "-- the driver's bench command (+ `--detail`, which only names where the full record is written): the headline workload, the five other "
+                "single-GPU configurations and the SURVEY 8(f) rows.\n\n")
     else:
         wl = next((workload[: -len(sfx)] for sfx in ("_full", "_unpacked", "_rows7") if workload.endswith(sfx)), workload)
         f.write("Command (tools/profile_gpu.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py "
@@ -133,7 +144,7 @@ with open(out, "w") as f:
     if os.path.exists(notes):
         f.write("\n" + open(notes).read())
     if bench:
-        slim = {k: v for k, v in bench.items() if k not in ("configs", "launch_log")}
+        slim = {k: v for k, v in bench.items() if k not in ("configs", "launch_log", "host_path", "cpu_baseline")}
         if bench.get("configs"):
             slim["configs"] = {k: {kk: vv for kk, vv in c.items() if kk not in ("launch_log", "workload")} for k, c in bench["configs"].items()}
         f.write("\n## bench line of the profiled run (launch logs omitted)\n\n```json\n" + json.dumps(slim) + "\n```\n")
