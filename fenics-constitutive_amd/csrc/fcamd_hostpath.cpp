@@ -226,9 +226,12 @@ int fcamd_register_host_buffer(fcamd_context* c, void* ptr, size_t bytes) {
     if (overlaps_call_scoped_lock(base, bytes))
         return fail(FCAMD_ERR_BAD_ARG, "a host call in progress on another thread holds a page lock on this range: register it when no evaluate runs on it");
     if (c->registered.count(base)) {
-        // Same address again: either a repeated call or a NEW buffer that landed where a freed,
-        // still-registered one was.  Leave the old lock (the last holder unlocks it) and pin again: a stale
-        // registration would DMA through old pages.
+        // Same address again: either a repeated call or a NEW buffer that landed where a freed, still-registered one was.
+        // This context gives its reference up.  If it was the LAST holder the pages are unlocked here and locked afresh
+        // below -- a stale registration would DMA through the old pages.  If other contexts of the process still hold the
+        // lock, in_process_registry() below finds the range and this context re-enters the SAME lock: re-pinning is
+        // impossible while a range is shared, so a buffer that was freed and allocated again at this address must be
+        // unregistered by every context that had registered it before it is registered again (include/fcamd.h).
         if (c->registered[base].lock_base) release_registered(c->registered[base].lock_base);
         c->registered.erase(base);
     }

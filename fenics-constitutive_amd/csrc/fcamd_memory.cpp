@@ -176,13 +176,21 @@ int fcamd_device_free(fcamd_context* c, void* ptr) {
     if (!c) return fail(FCAMD_ERR_BAD_ARG, "context is NULL");
     if (!ptr) return FCAMD_OK;
     VmmArray a;
+    bool plain = false;
     {
         std::lock_guard<std::mutex> lock(g_vmm_mu);
-        if (g_plain.erase(ptr)) {  // an FCAMD_ALLOC_IPC block
-            HIP_TRY(hipSetDevice(c->device));
-            HIP_TRY(hipFree(ptr));  // waits for the device
-            return FCAMD_OK;
-        }
+        plain = g_plain.count(ptr) != 0;
+    }
+    if (plain) {  // an FCAMD_ALLOC_IPC block.  hipFree waits for the device: not under the process-wide lock, and the block stays
+                  // tracked until the runtime has really released it (a failed free can be tried again)
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipFree(ptr));
+        std::lock_guard<std::mutex> lock(g_vmm_mu);
+        g_plain.erase(ptr);
+        return FCAMD_OK;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_vmm_mu);
         auto it = g_vmm.find(ptr);
         if (it == g_vmm.end()) return fail(FCAMD_ERR_BAD_ARG, "pointer was not returned by fcamd_device_alloc_set");
         a = std::move(it->second);

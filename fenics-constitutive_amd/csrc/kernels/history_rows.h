@@ -65,9 +65,9 @@ struct PackedRows {
         wave_sync();
         partial = true;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int q = k * kWave + lane;
-            row_live[k] = flag[q / 3] != 0;
+        for (int k = 0; k < 3; ++k) {  // whole 64-byte granules, as in the plain layout (rows_granule_live): a granule of 4 chunks meets two rows
+            const int r = ((k * kWave + lane) & ~(kRowGranule - 1)) / 3;
+            row_live[k] = (flag[r] | flag[r + 1 < kWave ? r + 1 : r]) != 0;
         }
         wave_sync();
 #pragma unroll

@@ -433,6 +433,32 @@ class DeviceLaw(IncrSmallStrainModel):
             None if history_mask is None else history_mask.data_ptr(), flags,
             counters_ptr=_counters_ptr(counters), packed_mask_ptrs=pm)
 
+    def empty_tangent(self, grad_del_u, stress, history, del_t: float = 1.0, tries: int = 6):
+        """A tangent array for ``evaluate(t, del_t, grad_del_u, stress, tangent, history)`` on device tensors, PLACED: on MI355X
+        the kernel time follows where the driver puts the written arrays (above all the tangent) -- identical data in different
+        hipMalloc allocations run 0.65-0.82 of the roofline, reproducibly per allocation.  Up to ``tries``
+        candidate allocations are timed with this law's real launch on the caller's arrays (committed -> scratch trial arrays:
+        ``stress`` and ``history`` are NOT modified) and the fastest is returned with what was measured:
+        ``(tangent, {"candidate_ms": [...], "chosen": k})``.  What ``ResidentState(placement="auto")`` does for its own arrays,
+        for a caller who keeps the reference's in-place protocol on tensors of their own; costs 4 launches per candidate, once."""
+        import torch
+
+        from .placement import fastest_allocation
+
+        _check_torch("grad_del_u", grad_del_u), _check_torch("stress", stress)
+        sd = self.stress_strain_dim
+        n = _size(stress) // sd
+        scratch_s = torch.empty_like(stress)
+        scratch_h = None if history is None else {k: torch.empty_like(v) for k, v in history.items()}
+
+        def probe(tan):
+            self.evaluate_from(0.0, del_t, grad_del_u, stress, scratch_s, tan, history, scratch_h)
+
+        tangent, info = fastest_allocation(sd * sd * n, probe, tries=tries, device=stress.device)
+        del scratch_s, scratch_h
+        torch.cuda.empty_cache()
+        return tangent, info
+
     def raise_for_stats(self, st) -> None:
         """The reference's errors for the counters of a finished launch: the Drucker-Prager tip
         (drucker_prager_classic.rs:82) and Newton non-convergence (general.rs:186 resp.

@@ -174,7 +174,7 @@ def use_resident_problem_state(problem, sync_history: bool = True, pin: bool = T
                 if devices is not None:  # every device's slice straight into the problem's history_0 arrays
                     state.download_history(_k, {key: fn.x.array for key, fn in self.history.history_0.items()})
                 else:
-                    committed = state._history_0[_k]
+                    committed = state.history_of(_k, committed=True)
                     for key, fn in self.history.history_0.items():
                         assign(fn.x.array, committed[key])
                 for key, fn in self.history.history_0.items():

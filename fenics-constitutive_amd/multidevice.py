@@ -337,7 +337,7 @@ class MultiDeviceProblemState:
             lo, hi = self._bounds[d][k]
             if hi == lo:
                 continue
-            src = (s._history_0 if committed else s._history_1)[k]
+            src = s.history_of(k, committed=committed)
             for key, arr in history.items():
                 download(arr[dims[key] * lo: dims[key] * hi], src[key])
 

@@ -187,15 +187,24 @@ class ResidentProblemState:
         """Trial stress (``IncrementalStress.current``)."""
         return self._stress[1 - self._c]
 
+    def history_of(self, k: int, committed: bool = True):
+        """History of law ``k`` alone in the reference's layout -- committed, or trial (before the first evaluate of an increment
+        the trial state IS the committed one).  Live tensors, except VonMises3D's packed ``eps_n``, which is unpacked into a new
+        tensor: ask for the law you need (``_history_0`` / ``_history_1`` unpack EVERY packed law on each access)."""
+        ls = self._laws[k]
+        if committed:
+            return ls.history_view(self._c)
+        return ls.history_view(1 - self._c if (self._evaluated or not ls.packed) else self._c)
+
     @property
     def _history_0(self):
-        """committed history per law, reference layout (live tensors; VonMises3D's packed ``eps_n``: a copy)"""
-        return [ls.history_view(self._c) for ls in self._laws]
+        """committed history per law, reference layout (live tensors; VonMises3D's packed ``eps_n``: a copy) -- ``history_of(k)`` for one law"""
+        return [self.history_of(k, True) for k in range(len(self._laws))]
 
     @property
     def _history_1(self):
-        """trial history per law (before the first evaluate of an increment the trial state IS the committed one)"""
-        return [ls.history_view(1 - self._c if (self._evaluated or not ls.packed) else self._c) for ls in self._laws]
+        """trial history per law -- ``history_of(k, committed=False)`` for one law"""
+        return [self.history_of(k, False) for k in range(len(self._laws))]
 
     def set_state(self, stress=None, history=None) -> None:
         """Initial committed state: parent stress (6 n) and a list of per-law history dicts."""

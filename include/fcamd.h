@@ -351,7 +351,9 @@ FCAMD_API int fcamd_model_last_stats(fcamd_model* model, fcamd_stats* stats);
    only: arrays that are not registered are page-locked for the duration of each call.  A range that ANOTHER context of
    the process has registered already (several GPUs or threads, one array) is entered into this context's registry with
    its own device's view of it; the page lock is shared and reference-counted -- it is released when the LAST of the
-   contexts unregisters the range (or is destroyed), in any order.  Threads: a range
+   contexts unregisters the range (or is destroyed), in any order; while a range is shared it cannot be pinned AGAIN
+   (registering the same address once more re-enters the existing lock), so EVERY context must unregister a buffer before
+   it is freed.  Threads: a range
    on which a host entry of another thread is running right now (it holds a call-scoped page lock) is refused with
    FCAMD_ERR_BAD_ARG -- register between calls; unregistering a range while another thread's call uses it is the
    caller's error, like freeing it. */
@@ -555,6 +557,11 @@ FCAMD_API int fcamd_version(void);
 
 /* ================================================================================================================
  * Conveniences: `static inline` shorthands of the entries above (the names and arguments of ABI 0.3).  No symbols.
+ * SOURCE compatibility only, not behaviour: a shorthand that finds its own argument wrong returns FCAMD_ERR_BAD_ARG without
+ * setting fcamd_last_error() (the text then still describes an earlier call); fcamd_model_last_kernel_ms goes through
+ * fcamd_model_last_stats, i.e. it downloads the counters and synchronises the context's stream (0.3 read two events).
+ * A binary built against the 0.3 header must not be run against this library: fcamd_stats grew by `kernel_ms` and every
+ * entry that takes a fcamd_stats* writes the whole struct -- check fcamd_version() (ABI 0.4 = 4) before the first call.
  * ================================================================================================================ */
 /* zero initialiser of a struct in both languages (C: {0}; C++: {} -- keeps -Wextra quiet in a C++ caller) */
 #ifdef __cplusplus

@@ -76,3 +76,22 @@ def test_problem_state_placement_modes_keep_results(mode, monkeypatch):
         b.update()
     assert b.placement["mode"] in ("vmm_interleaved", "hipmalloc_tuned")
     assert (b._vmm is not None) == (b.placement["mode"] == "vmm_interleaved")
+
+
+def test_empty_tangent_places_without_touching_the_callers_state():
+    """DeviceLaw.empty_tangent: the candidate search for a caller who keeps the reference's in-place protocol on tensors of their own"""
+    p, g, s, h = random_case("von_mises_3d", 64 * 500 + 9, seed=4)
+    law = make_law("von_mises_3d", p)
+    gd, sd = torch.from_numpy(g).cuda(), torch.from_numpy(s).cuda()
+    hd = {k: torch.from_numpy(v).cuda() for k, v in h.items()}
+    s0, h0 = sd.clone(), {k: v.clone() for k, v in hd.items()}
+    tangent, info = law.empty_tangent(gd, sd, hd, tries=3)
+    assert tangent.numel() == 36 * (s.size // 6) and tangent.is_cuda and tangent.dtype == torch.float64
+    assert len(info["candidate_ms"]) == 3 and 0 <= info["chosen"] < 3 and all(ms > 0 for ms in info["candidate_ms"])
+    assert torch.equal(sd, s0) and all(torch.equal(hd[k], h0[k]) for k in hd)  # the probes wrote scratch arrays only
+    # ... and the in-place call on the placed array gives what it gives on any other
+    ref_t = torch.empty_like(tangent)
+    s1, h1 = sd.clone(), {k: v.clone() for k, v in hd.items()}
+    law.evaluate(0.0, 1.0, gd, s1, ref_t, h1)
+    law.evaluate(0.0, 1.0, gd, sd, tangent, hd)
+    assert torch.equal(tangent, ref_t) and torch.equal(sd, s1)
