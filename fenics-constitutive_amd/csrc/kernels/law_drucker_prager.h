@@ -57,11 +57,61 @@ __device__ __forceinline__ DPInv dp_state(double I1, double rho, double n2, doub
     return m;
 }
 
-// T[i][j..j+1] for chunk q of the tile from the published parameters
+// T[i][j..j+1] for chunk r (entries [i][j], [i][j + 1], j = 2 jj) of point p from the published parameters
+__device__ __forceinline__ d2 tangent_dp_chunk(const double* tp, const double* t11tab, const double* pdtab, const double* etab,
+                                               int p, int r, int i, int jj) {
+    const double* t = tp + kDpStride * p;
+    const d2 c0 = reinterpret_cast<const d2*>(t)[0];  // t11, tP
+    const d2 c1 = reinterpret_cast<const d2*>(t)[1];  // tss, t1s
+    const d2 c2 = reinterpret_cast<const d2*>(t)[2];  // ts1, plastic flag
+    const double ts1 = c2.x;
+    const double si = t[6 + i];
+    const d2 sj = *reinterpret_cast<const d2*>(t + 6 + 2 * jj);
+    const d2 o = *reinterpret_cast<const d2*>(t11tab + 2 * r);  // (1 x 1)[i][j]: 6 i + j = 2 r
+    const d2 pd = *reinterpret_cast<const d2*>(pdtab + 2 * r);
+    const double oi = i < 3 ? 1.0 : 0.0;
+    d2 v;
+    v.x = (c0.x * o.x + c0.y * pd.x) + ((c1.x * si) * sj.x + (c1.y * oi) * sj.x + (ts1 * si) * (jj < 2 ? 1.0 : 0.0));   // j < 3
+    v.y = (c0.x * o.y + c0.y * pd.y) + ((c1.x * si) * sj.y + (c1.y * oi) * sj.y + (ts1 * si) * (jj < 1 ? 1.0 : 0.0));   // j + 1 < 3
+    // elastic points of a mixed tile: the reference returns elastic_tangent() itself (general.rs:131-135),
+    // i.e. the host-computed 2 mu P_dev + 3 kappa P_vol bit for bit, not kappa 1x1 + 2 mu P_dev
+    const d2 el = *reinterpret_cast<const d2*>(etab + 2 * r);
+    if (c2.y == 0.0) v = el;
+    return v;
+}
+
+template <bool NT, bool MASKED, int K>
+__device__ __forceinline__ void tangent_dp_pass(const double* tp, const double* t11tab, const double* pdtab, const double* etab,
+                                                double* tile, int lane, ChunkLane& cl, unsigned long long tneed) {
+    // the maps of pass k and k + 9 coincide up to a constant ((10 k) % 18 has period 9): left alone the compiler keeps them alive
+    // across nine passes, and this kernel sits at its 168-VGPR cap (scratch: 9.0 -> 9.8 ms).  Fresh values per group of passes.
+    if constexpr (K % kTangentGroup == 0) asm volatile("" : "+v"(cl.pl), "+v"(cl.r0));
+    const ChunkMap m = chunk_map<K>(cl);
+    bool wanted = true;
+    if constexpr (MASKED) wanted = quad_any(((tneed >> m.p) & 1ull) != 0ull);
+    if (wanted) store_tangent16<NT>(tile + 2 * (K * kWave + lane), tangent_dp_chunk(tp, t11tab, pdtab, etab, m.p, m.r, m.i, m.jj));
+    if constexpr (K % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool NT, bool MASKED, int... K>
+__device__ __forceinline__ void tangent_dp_passes(const double* tp, const double* t11tab, const double* pdtab, const double* etab,
+                                                  double* tile, int lane, unsigned long long tneed, std::integer_sequence<int, K...>) {
+    ChunkLane cl = chunk_lane(lane);
+    (tangent_dp_pass<NT, MASKED, K>(tp, t11tab, pdtab, etab, tile, lane, cl, tneed), ...);
+}
+
 template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11tab, const double* pdtab,
                                            const double* etab, double* tangent, long long p0,
                                            const int* rows_lds, int npts, int lane, unsigned long long tneed) {
+    if constexpr (FULL && !IDX) {  // the contiguous tile: incremental chunk maps (tangent_writers.h: chunk_map), need test only when sparse
+        double* tile = tangent + p0 * 36;
+        if (tneed == ~0ull)
+            tangent_dp_passes<NT, false>(tp, t11tab, pdtab, etab, tile, lane, tneed, std::make_integer_sequence<int, 18>{});
+        else
+            tangent_dp_passes<NT, true>(tp, t11tab, pdtab, etab, tile, lane, tneed, std::make_integer_sequence<int, 18>{});
+        return;
+    }
     const int nchunks = npts * 18;
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
@@ -69,26 +119,8 @@ __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11ta
         const int p = q / 18;
         const int r = q - 18 * p;
         const int i = r / 3;
-        const int j = 2 * (r - 3 * i);
-        const double* t = tp + kDpStride * p;
-        const d2 c0 = reinterpret_cast<const d2*>(t)[0];  // t11, tP
-        const d2 c1 = reinterpret_cast<const d2*>(t)[1];  // tss, t1s
-        const d2 c2 = reinterpret_cast<const d2*>(t)[2];  // ts1, plastic flag
-        const double ts1 = c2.x;
-        const double si = t[6 + i];
-        const d2 sj = *reinterpret_cast<const d2*>(t + 6 + j);
-        const d2 o = *reinterpret_cast<const d2*>(t11tab + 6 * i + j);  // (1 x 1)[i][j]
-        const d2 pd = *reinterpret_cast<const d2*>(pdtab + 6 * i + j);
-        const double oi = i < 3 ? 1.0 : 0.0;
-        d2 v;
-        v.x = (c0.x * o.x + c0.y * pd.x) + ((c1.x * si) * sj.x + (c1.y * oi) * sj.x + (ts1 * si) * (j < 3 ? 1.0 : 0.0));
-        v.y = (c0.x * o.y + c0.y * pd.y) + ((c1.x * si) * sj.y + (c1.y * oi) * sj.y + (ts1 * si) * (j + 1 < 3 ? 1.0 : 0.0));
-        // elastic points of a mixed tile: the reference returns elastic_tangent() itself (general.rs:131-135),
-        // i.e. the host-computed 2 mu P_dev + 3 kappa P_vol bit for bit, not kappa 1x1 + 2 mu P_dev
-        const d2 el = *reinterpret_cast<const d2*>(etab + 6 * i + j);
-        if (c2.y == 0.0) v = el;
-        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q);
-        if ((FULL || q < nchunks) && wanted) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        const d2 v = tangent_dp_chunk(tp, t11tab, pdtab, etab, p, r, i, r - 3 * i);
+        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -2,6 +2,8 @@
 // per 16-byte chunk from 8 doubles per point; the protocol flags of EvalArgs::flags.
 // Part of the device code of libfcamd (translation unit: ../fcamd_kernels.hip, which holds the kernels and launchers).
 #pragma once
+#include <utility>
+
 #include "tile_io.h"
 
 namespace fcamd {
@@ -9,6 +11,16 @@ namespace fcamd {
 // ---------------------------------------------------------------------------------------
 // tangent writers
 // ---------------------------------------------------------------------------------------
+
+// Sparse-tangent protocol: is chunk q of this lane written?  Whole 64-byte granules move (tile_io.h: kRowGranule = 4 chunks), and
+// the four chunks of a granule are the chunks of four neighbouring lanes of the SAME pass (q = 64 k + lane): a lane's chunk is
+// written if the row of any chunk of its quad is needed -- an OR over the quad (two DPP operations) of each lane's own row bit.
+__device__ __forceinline__ bool quad_any(bool mine) {
+    int v = mine ? 1 : 0;
+    v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);  // quad_perm [2, 3, 0, 1]
+    return v != 0;
+}
 
 // Constant tangent (LE, SLS, comfe LE): every point gets the same 36 doubles = 18 chunks,
 // read from the LDS table `tab` (np.tile(D.flatten(), n) in the reference).
@@ -39,7 +51,8 @@ __device__ __forceinline__ void tangent_const_masked(const double* tab, double* 
         const int q = k * kWave + lane;
         const int p = q / 18;
         d2 v = reinterpret_cast<const d2*>(tab)[q - 18 * p];
-        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q);
+        bool wanted = ((tneed >> p) & 1ull) != 0ull;
+        if constexpr (FULL && !IDX) wanted = quad_any(wanted);  // whole 64-byte granules (quad_any below)
         if ((FULL || q < nchunks) && wanted) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
     }
 }
@@ -69,6 +82,37 @@ __device__ __forceinline__ unsigned long long sparse_tangent_need(ArgsRef a, uns
 // reads, the arithmetic and the stores of one group, not across groups (bounds the register pressure).
 constexpr int kTangentGroup = 3;
 
+// Which point and which entries chunk q = 64 k + lane of a tile's tangent image holds (18 chunks of 16 bytes per point:
+// point p = q / 18, chunk r = q % 18 of its row-major 6 x 6 matrix, i.e. entries [i][j], [i][j + 1] with i = r / 3, j = 2 (r % 3)).
+// The evaluate kernels are VALU co-limited wherever they move few bytes per tile (sparse tangent: VALUBusy 88 %; Drucker-Prager:
+// 79 %; profiles/r05_row_counters.md), and these integer maps used to be half of the tangent writer's instructions (a division
+// by 18 and one by 3 per pass).  With lane = 18 pl + r0 split ONCE per tile, pass k needs a compare and three adds:
+//     64 k = 18 (3 k + (10 k) / 18) + (10 k) % 18   ->   r = r0 + (10 k) % 18 (- 18 on carry),  p = pl + 3 k + (10 k) / 18 + carry
+// and the table offset of the chunk is 6 i + j = 2 r.
+struct ChunkLane {
+    int pl, r0;
+};
+__device__ __forceinline__ ChunkLane chunk_lane(int lane) {
+    ChunkLane c;
+    c.pl = (lane * 57) >> 10;  // lane / 18 for lane < 64
+    c.r0 = lane - 18 * c.pl;
+    return c;
+}
+struct ChunkMap {
+    int p, r, i, jj;  // point of the tile, chunk of its matrix, matrix row, column pair (j = 2 jj)
+};
+template <int K>
+__device__ __forceinline__ ChunkMap chunk_map(const ChunkLane& c) {
+    constexpr int m = (10 * K) % 18, base = 3 * K + (10 * K) / 18;
+    const int carry = (c.r0 + m >= 18) ? 1 : 0;
+    ChunkMap x;
+    x.p = c.pl + base + carry;
+    x.r = c.r0 + m - 18 * carry;
+    x.i = (x.r * 11) >> 5;  // r / 3 for r < 18
+    x.jj = x.r - 3 * x.i;
+    return x;
+}
+
 // Point-dependent tangent of the two Mises laws.  Lane p has published
 //   tp[10p + 0] = B, tp[10p + 1] = C, tp[10p + 2 .. 7] = N   (stride 10: conflict-free b128)
 // and the tile's tangent is   T[p][i][j] = (ta[i][j] + B * tb[i][j]) + third(i, j)  with
@@ -77,10 +121,55 @@ constexpr int kTangentGroup = 3;
 //                                               mises_plasticity.rs:118-123)
 // `tneed`: the points of the tile whose tangent rows are written (all ones unless the caller runs the
 // sparse-tangent protocol, see sparse_tangent_need()).
+template <bool COMFE>
+__device__ __forceinline__ d2 tangent_mises_chunk(const double* tp, const double* ta, const double* tb, int p, int r, int i, int jj) {
+    const double* t = tp + 10 * p;
+    const d2 bc = reinterpret_cast<const d2*>(t)[0];
+    const double ni = t[2 + i];
+    const d2 nj = *reinterpret_cast<const d2*>(t + 2 + 2 * jj);
+    const d2 a = *reinterpret_cast<const d2*>(ta + 2 * r);  // 6 i + j = 2 r
+    const d2 b = *reinterpret_cast<const d2*>(tb + 2 * r);
+    d2 v;
+    if constexpr (COMFE) {
+        v.x = (a.x + bc.x * b.x) + (bc.y * nj.x) * ni;
+        v.y = (a.y + bc.x * b.y) + (bc.y * nj.y) * ni;
+    } else {
+        v.x = (a.x + bc.x * b.x) + bc.y * (ni * nj.x);
+        v.y = (a.y + bc.x * b.y) + bc.y * (ni * nj.y);
+    }
+    return v;
+}
+
+template <bool COMFE, bool NT, bool MASKED, int K>
+__device__ __forceinline__ void tangent_mises_pass(const double* tp, const double* ta, const double* tb, double* tile, int lane,
+                                                   const ChunkLane& cl, unsigned long long tneed) {
+    const ChunkMap m = chunk_map<K>(cl);
+    bool wanted = true;
+    if constexpr (MASKED) wanted = quad_any(((tneed >> m.p) & 1ull) != 0ull);
+    if (wanted) store_tangent16<NT>(tile + 2 * (K * kWave + lane), tangent_mises_chunk<COMFE>(tp, ta, tb, m.p, m.r, m.i, m.jj));
+    // bound the register pressure: let the scheduler interleave at most 3 chunks
+    if constexpr (K % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool COMFE, bool NT, bool MASKED, int... K>
+__device__ __forceinline__ void tangent_mises_passes(const double* tp, const double* ta, const double* tb, double* tile, int lane,
+                                                     unsigned long long tneed, std::integer_sequence<int, K...>) {
+    const ChunkLane cl = chunk_lane(lane);
+    (tangent_mises_pass<COMFE, NT, MASKED, K>(tp, ta, tb, tile, lane, cl, tneed), ...);
+}
+
 template <bool COMFE, bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta, const double* tb,
                                               double* tangent, long long p0, const int* rows_lds,
                                               int npts, int lane, unsigned long long tneed) {
+    if constexpr (FULL && !IDX) {  // the contiguous tile: incremental chunk maps; the need test only under the sparse-tangent protocol
+        double* tile = tangent + p0 * 36;
+        if (tneed == ~0ull)
+            tangent_mises_passes<COMFE, NT, false>(tp, ta, tb, tile, lane, tneed, std::make_integer_sequence<int, 18>{});
+        else
+            tangent_mises_passes<COMFE, NT, true>(tp, ta, tb, tile, lane, tneed, std::make_integer_sequence<int, 18>{});
+        return;
+    }
     const int nchunks = npts * 18;
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
@@ -88,23 +177,8 @@ __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta
         const int p = q / 18;
         const int r = q - 18 * p;
         const int i = r / 3;
-        const int j = 2 * (r - 3 * i);
-        const double* t = tp + 10 * p;
-        const d2 bc = reinterpret_cast<const d2*>(t)[0];
-        const double ni = t[2 + i];
-        const d2 nj = *reinterpret_cast<const d2*>(t + 2 + j);
-        const d2 a = *reinterpret_cast<const d2*>(ta + 6 * i + j);
-        const d2 b = *reinterpret_cast<const d2*>(tb + 6 * i + j);
-        d2 v;
-        if constexpr (COMFE) {
-            v.x = (a.x + bc.x * b.x) + (bc.y * nj.x) * ni;
-            v.y = (a.y + bc.x * b.y) + (bc.y * nj.y) * ni;
-        } else {
-            v.x = (a.x + bc.x * b.x) + bc.y * (ni * nj.x);
-            v.y = (a.y + bc.x * b.y) + bc.y * (ni * nj.y);
-        }
-        const bool wanted = (IDX || !FULL) ? ((tneed >> p) & 1ull) != 0ull : tangent_granule_live(tneed, q);
-        if ((FULL || q < nchunks) && wanted) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
+        const d2 v = tangent_mises_chunk<COMFE>(tp, ta, tb, p, r, i, r - 3 * i);
+        if ((FULL || q < nchunks) && ((tneed >> p) & 1ull)) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
         // bound the register pressure: let the scheduler interleave at most 3 chunks
         if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }

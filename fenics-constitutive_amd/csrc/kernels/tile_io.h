@@ -257,7 +257,8 @@ struct StressRows {
 // previous evaluate).  Measured in one process on identical buffers, 1e8 points, 22 % plastic (tools/ab_lib.py, round 5):
 // sparse protocol on the reference layout 16 / 32 / 64 / 128-byte units: 9.36 / 9.27 / 9.06 / 9.09 ms; sparse tangent
 // 288-byte rows / 64 / 128: 4.67 / 4.51 / 4.60 ms.  The price is bytes: +48 B per isolated plastic-strain row on average,
-// +32 B per isolated tangent row.
+// +32 B per isolated tangent row.  (The tangent writers test "any chunk of my granule in a needed row" as an OR over the quad of
+// lanes that holds the granule: tangent_writers.h, quad_any.)
 constexpr int kRowGranule = 4;  // chunks of 16 bytes
 // chunk q of a tile image with 3 chunks per row is moved: its granule holds a piece of a row in `rows`
 __device__ __forceinline__ bool rows_granule_live(unsigned long long rows, int q) {
@@ -266,14 +267,6 @@ __device__ __forceinline__ bool rows_granule_live(unsigned long long rows, int q
     const int lo = g0 / 3, hi = (g0 + G - 1) / 3;  // <= 63: q <= 191
     return ((rows >> lo) & ((2ull << (hi - lo)) - 1ull)) != 0ull;
 }
-// the same for the tangent image (18 chunks per row)
-__device__ __forceinline__ bool tangent_granule_live(unsigned long long rows, int q) {
-    constexpr int G = kRowGranule;
-    const int g0 = q & ~(G - 1);
-    const int lo = g0 / 18, hi = (g0 + G - 1) / 18;  // a granule of <= 18 chunks meets at most two rows
-    return (((rows >> lo) | (rows >> hi)) & 1ull) != 0ull;
-}
-
 // destination of tangent chunk q (= 16 bytes) of the tile
 template <bool IDX>
 __device__ __forceinline__ double* tangent_chunk(double* tangent, long long p0, int q, const int* rows_lds) {
