@@ -89,7 +89,8 @@ __device__ __forceinline__ void tangent_dp_pass(const double* tp, const double* 
     const ChunkMap m = chunk_map<K>(cl);
     bool wanted = true;
     if constexpr (MASKED) wanted = quad_any(((tneed >> m.p) & 1ull) != 0ull);
-    if (wanted) store_tangent16<NT>(tile + 2 * (K * kWave + lane), tangent_dp_chunk(tp, t11tab, pdtab, etab, m.p, m.r, m.i, m.jj));
+    char* dst = reinterpret_cast<char*>(tile) + K * (kWave * 16) + (unsigned)lane * 16u;  // scalar base of the pass + the lane's byte offset
+    if (wanted) store_tangent16<NT>(reinterpret_cast<double*>(dst), tangent_dp_chunk(tp, t11tab, pdtab, etab, m.p, m.r, m.i, m.jj));
     if constexpr (K % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
 }
 

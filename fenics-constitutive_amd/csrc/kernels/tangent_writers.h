@@ -94,8 +94,8 @@ struct ChunkLane {
 };
 __device__ __forceinline__ ChunkLane chunk_lane(int lane) {
     ChunkLane c;
-    c.pl = (lane * 57) >> 10;  // lane / 18 for lane < 64
-    c.r0 = lane - 18 * c.pl;
+    c.pl = (int)(__umul24((unsigned)lane, 57u) >> 10);  // lane / 18 for lane < 64
+    c.r0 = lane - __mul24(18, c.pl);
     return c;
 }
 struct ChunkMap {
@@ -108,8 +108,8 @@ __device__ __forceinline__ ChunkMap chunk_map(const ChunkLane& c) {
     ChunkMap x;
     x.p = c.pl + base + carry;
     x.r = c.r0 + m - 18 * carry;
-    x.i = (x.r * 11) >> 5;  // r / 3 for r < 18
-    x.jj = x.r - 3 * x.i;
+    x.i = (int)(__umul24((unsigned)x.r, 11u) >> 5);  // r / 3 for r < 18 (24-bit multiply: full rate; the 32-bit one is a quarter)
+    x.jj = x.r - __mul24(3, x.i);
     return x;
 }
 
@@ -146,7 +146,9 @@ __device__ __forceinline__ void tangent_mises_pass(const double* tp, const doubl
     const ChunkMap m = chunk_map<K>(cl);
     bool wanted = true;
     if constexpr (MASKED) wanted = quad_any(((tneed >> m.p) & 1ull) != 0ull);
-    if (wanted) store_tangent16<NT>(tile + 2 * (K * kWave + lane), tangent_mises_chunk<COMFE>(tp, ta, tb, m.p, m.r, m.i, m.jj));
+    // destination: the pass's base (scalar) + this lane's byte offset (32 bits, the same in every pass)
+    char* dst = reinterpret_cast<char*>(tile) + K * (kWave * 16) + (unsigned)lane * 16u;
+    if (wanted) store_tangent16<NT>(reinterpret_cast<double*>(dst), tangent_mises_chunk<COMFE>(tp, ta, tb, m.p, m.r, m.i, m.jj));
     // bound the register pressure: let the scheduler interleave at most 3 chunks
     if constexpr (K % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
 }
