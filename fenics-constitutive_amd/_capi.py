@@ -434,6 +434,29 @@ class PreparedBatch:
         check(self._lib.fcamd_evaluate_batch(self.count, self.models, self.ns, self.args, self.t, self.del_t))
 
 
+class LaunchCache:
+    """Replays the ``PreparedBatch`` of a group of device calls for as long as the group's signature -- every pointer, ``del_t`` -- is
+    the one it was built for (the Newton iterations of an increment: same arrays, new gradient values); otherwise the calls are
+    made through ``enqueue()`` inside a ``batched_launches()`` block and kept.  ``t`` is not part of a signature: no law of the
+    reference uses it and the C entries ignore it."""
+
+    def __init__(self):
+        self._kept = {}
+
+    def run(self, slot, signature, enqueue, stream_ptr):
+        kept = self._kept.get(slot)
+        if kept is not None and kept[0] == signature:
+            kept[1].ctx.set_stream(stream_ptr)
+            kept[1].launch()
+            return
+        with batched_launches() as b:
+            enqueue()
+        self._kept[slot] = (signature, b.prepared[0]) if len(b.prepared) == 1 else None
+
+    def clear(self):
+        self._kept.clear()
+
+
 class batched_launches:
     """``with batched_launches():`` -- the device calls made inside the block (``Model.evaluate_device_ex``, i.e. every
     ``DeviceLaw.evaluate_from`` / ``evaluate_indexed`` on device tensors) are recorded and leave together as ONE

@@ -763,7 +763,6 @@ int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n
     auto batched = [&](int k) { return c->opt.batch_kernel && n[k] > 0 && n[k] < small && models[k]->constraint == FCAMD_FULL; };
     int n_small = 0;
     for (int k = 0; k < count; ++k) n_small += batched(k) ? 1 : 0;
-    if (n_small < 2) n_small = 0;  // nothing to merge
     // the others first, each with its own launch
     for (int k = 0; k < count; ++k) {
         if (n_small && batched(k)) continue;

@@ -16,7 +16,6 @@ Names follow the reference's backward-compatibility properties (``stress_0``, ``
 
 from __future__ import annotations
 
-import contextlib
 
 import numpy as np
 
@@ -152,7 +151,7 @@ class ResidentProblemState:
         self.sparse_tangent = sparse_tangent
         #: the laws of one ``evaluate`` leave as ONE ``fcamd_evaluate_batch`` (False: one ``fcamd_evaluate_device_ex`` per law)
         self.batch_launches = batch_launches
-        self._batch_cache = {}  # committed copy -> (signature of every pointer of the call, _capi.PreparedBatch)
+        self._launch_cache = _capi.LaunchCache()  # committed copy -> the kept argument arrays of the call (_capi.PreparedBatch)
         # the error of a law's last evaluate, if it raised, lives with the law (_LawState.failed): nothing to commit
         # placement of the arrays the launches stream (see ResidentState): "auto" / "vmm" move the parent
         # stress pair, the parent tangent and every law's history pair into one interleaved VMM working set on
@@ -264,24 +263,15 @@ class ResidentProblemState:
         # The laws of this form() leave as ONE fcamd_evaluate_batch (they write disjoint rows of the shared stress / tangent arrays):
         # one trip through the binding, the small laws concurrently.  Between the Newton iterations of an increment nothing but the
         # gradients' VALUES changes, so the argument arrays of the call are kept and issued again while every pointer is the same.
-        if self.batch_launches and len(self._laws) > 1:
-            import torch
-
+        if self.batch_launches:
             from .device import _current_stream_ptr
 
-            dev = self.device.index or 0
-            sig = (self._c, self._time, self._del_t, self.stress_0.data_ptr(), self.stress_1.data_ptr(),
+            sig = (self._del_t, self.stress_0.data_ptr(), self.stress_1.data_ptr(),
                    tuple((g.data_ptr(), g.numel(), 0 if tan is None else tan.data_ptr(), st,
                           0 if ls.hist is None else next(iter(ls.hist[0].values())).data_ptr(),
-                          0 if ls.hist is None else next(iter(ls.hist[1].values())).data_ptr()) for ls, (g, tan, st, _) in zip(self._laws, plan)))
-            cached = self._batch_cache.get(self._c)
-            if cached is not None and cached[0] == sig:
-                cached[1].ctx.set_stream(_current_stream_ptr(dev))
-                cached[1].launch()
-            else:
-                with _capi.batched_launches() as b:
-                    self._enqueue_laws(plan)
-                self._batch_cache[self._c] = (sig, b.prepared[0]) if len(b.prepared) == 1 else None
+                          0 if ls.hist is None else next(iter(ls.hist[1].values())).data_ptr(),
+                          0 if ls.mask is None else ls.mask.data_ptr()) for ls, (g, tan, st, _) in zip(self._laws, plan)))
+            self._launch_cache.run(self._c, sig, lambda: self._enqueue_laws(plan), _current_stream_ptr(self.device.index or 0))
         else:
             self._enqueue_laws(plan)
         for ls, (_, _, _, key) in zip(self._laws, plan):

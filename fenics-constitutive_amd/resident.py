@@ -26,7 +26,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .device import DeviceLaw, _is_torch
+from .device import DeviceLaw, _current_stream_ptr, _is_torch
 from .hostio import assign, to_device, upload
 
 __all__ = ["ResidentState"]
@@ -84,6 +84,7 @@ class ResidentState:
             hd = dict(SPLIT_HISTORY_FIELDS)
         self._hist = None if hd is None else [{k: torch.zeros(d * n, **f) for k, d in hd.items()} for _ in range(2)]
         self._c = 0  # index of the committed copy
+        self._launch_cache = _capi.LaunchCache()  # committed copy -> the kept argument arrays of evaluate()'s call
         if stress0 is not None:
             self._stress[0].copy_(self._as_dev(stress0))
         if history0 is not None and self._hist is not None:
@@ -293,7 +294,12 @@ class ResidentState:
         sparse = self._sparse_tangent and self._tangent_target == "dev"
         self._tangent_target = None
         self._failed = None
-        self._launch(t, del_t, g, tangent, sparse)
+        # the Newton iterations of an increment issue the very same call (same arrays, new gradient VALUES): its argument arrays are
+        # kept and replayed; a small state leaves through the batch kernel (counters + ONE launch instead of counters, main kernel,
+        # ragged tile: 52 -> 38 us per iteration at 1e4 points)
+        sig = (float(del_t), g.data_ptr(), 0 if tangent is None else tangent.data_ptr(), sparse, self.stress_committed.data_ptr(),
+               self.stress.data_ptr(), self.generation)
+        self._launch_cache.run(self._c, sig, lambda: self._launch(t, del_t, g, tangent, sparse), _current_stream_ptr(self.device.index or 0))
         self._tangent_key = key
         self._tangent_target = "dev"
         self._evaluated = True

@@ -19,7 +19,7 @@ from fenics_constitutive_amd.problem import ResidentProblemState, rows_of_cells 
 VM_P = {"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}
 os.environ.setdefault("FCAMD_SMALL_CALL_WARNING", "0")
 out = {}
-for n_laws in (2, 8):
+for n_laws in [int(x) for x in os.environ.get('BATCH_BENCH_LAWS', '2,8').split(',')]:
     out[str(n_laws)] = {}
     for per_law in (10_000, 100_000, 1_000_000):
         q = 4
