@@ -133,6 +133,24 @@ def test_c_program_drives_several_device_contexts(tmp_path, lib):
     assert "3 device contexts (3 used" in r.stdout and "bit for bit" in r.stdout
 
 
+def test_c_program_batches_the_laws_of_one_form(tmp_path, lib):
+    """examples/c_caller_batch.c: a plain-C host (no HIP runtime of its own: device memory and copies through the C ABI) evaluates
+    two materials on interleaved cells of one mesh as ONE fcamd_evaluate_batch, twice (the second call replays the kept table)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(LIB)
+    exe = tmp_path / "c_caller_batch"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_caller_batch.c"),
+                    "-o", str(exe), "-L", libdir, "-lfcamd", "-lm", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "2 laws, 3004 + 3000 points in one call" in r.stdout and "0 plastic points" in r.stdout
+
+
 def test_host_mapping_and_flag_errors(lib):
     """fcamd_host_device_pointer / FCAMD_EVAL_SPARSE_TANGENT argument checks, raw."""
     import mmap
