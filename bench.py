@@ -853,8 +853,9 @@ def main():
             items += [c for c in measured if c in frow_names] + [c for c in measured if c not in frow_names]
             # the default command stays under two minutes: what is left of 108 s goes to the two passes (each stops starting new
             # items when its half is used up: headline first, then its forms, the 8(f) rows, the configurations)
-            target = 240.0 if args.full else 108.0
-            pass_s = max(12.0, (target - (time.perf_counter() - t_prog)) / 2.0 - 3.0)
+            # (counted from the end of the imports: a cold image pages torch in for a minute or two, which is nobody's to spend)
+            target = 240.0 if args.full else 104.0
+            pass_s = max(12.0, (target - (time.perf_counter() - t_start)) / 2.0 - 3.0)
             lt_all = live_traffic_batch(items, n, history, extra, min(150.0, budget_left() - 30.0), headline=name, pass_budget_s=pass_s) or {}
             lt = lt_all.get(name)
             if lt is not None:
