@@ -360,7 +360,12 @@ int grid_for(fcamd_model* m, int64_t n) {
     fcamd_context* c = m->ctx;
     int grid = c->grid_override;
     if (grid <= 0) {
-        if (m->grid_auto <= 0) m->grid_auto = default_grid(m->law, c->num_cu);
+        if (m->grid_auto <= 0) {
+            m->grid_auto = default_grid(m->law, c->num_cu);
+            // Drucker-Prager (3 waves per SIMD, the longest tile): a quarter of that -- 9.08 / 9.11 / 9.25 / 9.18 / 9.37 ms at 32768 /
+            // 65536 / 131072 / 262144 / 390625 workgroups (round 5, tools/ab_lib.py path.so@GRID, 1e8 points, identical buffers)
+            if (m->law == FCAMD_COMFE_DRUCKER_PRAGER || m->law == FCAMD_COMFE_DRUCKER_PRAGER_HYPERBOLIC) m->grid_auto /= 4;
+        }
         grid = m->grid_auto;
     }
     const int64_t tiles = (n + 63) / 64;

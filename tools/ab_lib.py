@@ -14,8 +14,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fenics_constitutive_amd._capi import EvalArgs  # noqa: E402  (the struct only; the libraries are loaded by path below)
-libs = [a for a in sys.argv[1:] if a.endswith('.so')]
-sizes = [int(float(x)) for x in sys.argv[1:] if not x.endswith('.so')] or [1_000_000, 10_000_000, 100_000_000]
+libs = [a for a in sys.argv[1:] if '.so' in a]  # path.so or path.so@GRID (context option "grid": workgroups of the launch)
+sizes = [int(float(x)) for x in sys.argv[1:] if '.so' not in x] or [1_000_000, 10_000_000, 100_000_000]
 LAW = os.environ.get("AB_LAW", "vm")  # vm | le | maxwell
 SPARSE = os.environ.get("AB_SPARSE", "0") == "1"
 INPLACE = os.environ.get("AB_INPLACE", "0") == "1"  # stress_prev == stress, history_prev == history (state restored before every launch)
@@ -32,11 +32,15 @@ P = (C.c_double * len(MODEL[1]))(*MODEL[1])
 
 class Lib:
     def __init__(self, path):
+        path, _, grid = path.partition("@")
         self.l = C.CDLL(path)
         self.ctx, self.m = C.c_void_p(), C.c_void_p()
         assert self.l.fcamd_context_create(0, stream, C.byref(self.ctx)) == 0
         # torch's default stream has handle 0 = "own a private stream" for create(); bind it explicitly
         assert self.l.fcamd_context_set_stream(self.ctx, stream) == 0
+        if grid:
+            self.l.fcamd_context_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+            assert self.l.fcamd_context_set_option(self.ctx, b"grid", int(grid)) == 0
         assert self.l.fcamd_model_create(self.ctx, MODEL[0], CONSTRAINT, P, len(MODEL[1]), C.byref(self.m)) == 0
         self.l.fcamd_evaluate_device_ex.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.POINTER(EvalArgs)]
         self.mask = None
