@@ -14,7 +14,7 @@ ALGORITHMIC bytes per point -- the traffic the call's interface mandates -- stat
   lowdim_le_uniaxial_strain                                                     8 + 16 + 8 = 32
   lowdim_maxwell_plane_strain        spring_maxwell_model.py:40-88, 2-D         224 + 2 x (32 R + 32 W) = 352
   lowdim_maxwell_uniaxial_stress                                                32 + 2 x (8 R + 8 W) = 64
-  resident_sparse_tangent            solver/_lawonsubmesh.py:72-95 +            ResidentState.evaluate, VonMises3D mixed: a point that stays
+  resident_sparse_tangent            solver/_lawonsubmesh.py:72-95 +            ResidentState.evaluate, VonMises3D mixed (_zoned: plastic zones): a point that stays
                                      _history.py:64-88 (f1)                     elastic 72 + 96 + 8 = 176 (its tangent row is not rewritten),
                                                                                 a plastic / formerly plastic one 568
 
@@ -55,6 +55,15 @@ class FRow:
         t = self.torch
         g = t.randn(width * self.n, generator=self.gen, **self.f)
         g.view(self.n, width).mul_(t.pow(10.0, t.rand(self.n, generator=self.gen, **self.f) * 2.0 - 4.0)[:, None])
+        return g
+
+    def zoned_gradient(self, width, zone=4096, share=0.22):
+        """contiguous zones of `zone` points, `share` of them at strain scale 1e-2 (plastic), the others at 1e-4: what a plastic zone of
+        a mesh-ordered point array looks like (the workloads `*_zoned` of benchlib/workloads.py)"""
+        t = self.torch
+        g = t.randn(width * self.n, generator=self.gen, **self.f)
+        pl = t.rand((self.n + zone - 1) // zone, generator=self.gen, **self.f) < share
+        g.view(self.n, width).mul_(t.where(pl, 1e-2, 1e-4).to(t.float64).repeat_interleave(zone)[: self.n][:, None])
         return g
 
     def reset(self):
@@ -209,23 +218,26 @@ class ResidentSparseTangentRow(FRow):
     max_draws = 1
     reference = "solver/_lawonsubmesh.py:72-95, solver/_history.py:64-88 (the Newton-iteration protocol, state resident)"
 
-    def __init__(self, n, device):
+    def __init__(self, n, device, zoned=False):
         import fenics_constitutive_amd as fc
         from fenics_constitutive_amd.resident import ResidentState
 
         super().__init__(n, device)
         t = self.torch
+        if zoned:
+            self.name = "resident_sparse_tangent_zoned"
+        draw = (lambda w: self.zoned_gradient(w)) if zoned else (lambda w: self.mixed_gradient(w))
         self.law = fc.VonMises3D(VM_P)
         h0 = {"eps_n": t.zeros(6 * n, **self.f), "alpha": t.rand(n, generator=self.gen, **self.f) * 0.02}
         # the product default: the state's own placement step (hipMalloc candidates of the tangent + one VMM set, timed on the real launch)
         # runs inside the first evaluate -- one set of allocations is enough then (max_draws)
         self.state = ResidentState(self.law, n, device=device, history0=h0, placement=os.environ.get("FROW_PLACEMENT", "auto"))
         del h0
-        warm = self.mixed_gradient(9)
+        warm = draw(9)
         self.state.evaluate(0.0, 1.0, warm)  # a committed state "from a previous step"
         self.state.update()
         del warm
-        g0 = self.mixed_gradient(9)
+        g0 = draw(9)
         self.grads = [g0, g0 * 1.03]  # two Newton iterates of one increment, evaluated alternately
         self.i = 0
         # launches of that first evaluate: its own + the placement step's (4 per hipMalloc candidate of the tangent and 1 evaluate on the
@@ -234,7 +246,7 @@ class ResidentSparseTangentRow(FRow):
         cands = len(pl.get("candidate_ms", []))
         self.launch_log.append(["warm_increment_and_placement", 1 + (4 * cands + 1 if cands else 0) + (4 if "vmm_ms" in pl else 0)])
         self.extra["placement_mode"] = pl.get("mode", "torch")
-        self.text = (f"{self.name}: ResidentState.evaluate, VonMises3D, {n} points, two alternating Newton iterates; packed plastic-strain history, "
+        self.text = (f"{self.name}: ResidentState.evaluate, VonMises3D, {n} points{' in plastic zones of 4096 points (22 % of the zones)' if zoned else ''}, two alternating Newton iterates; packed plastic-strain history, "
                      "sparse trial history, sparse tangent, the state's own placement step (product default of a device assembler)")
         self.n_touched = 0
 
@@ -270,10 +282,11 @@ FROWS = {
     "lowdim_maxwell_plane_strain": lambda n, d: LowDimRow(n, d, "maxwell", "PLANE_STRAIN"),
     "lowdim_maxwell_uniaxial_stress": lambda n, d: LowDimRow(n, d, "maxwell", "UNIAXIAL_STRESS"),
     "resident_sparse_tangent": ResidentSparseTangentRow,
+    "resident_sparse_tangent_zoned": lambda n, d: ResidentSparseTangentRow(n, d, zoned=True),
 }
 SURVEY_ROW = {"indexed_runs": "f2", "indexed_scattered_cells": "f2", "indexed_permuted": "f2", "wrapped_plane_strain_von_mises": "f3", "lowdim_le_plane_strain": "f3",
               "lowdim_le_uniaxial_strain": "f3", "lowdim_maxwell_plane_strain": "f3", "lowdim_maxwell_uniaxial_stress": "f3",
-              "resident_sparse_tangent": "f1"}
+              "resident_sparse_tangent": "f1", "resident_sparse_tangent_zoned": "f1"}
 
 
 def run_frow(name, n, device, launches=6, warm=2, peak_gbs=8000.0, draws=3):

@@ -70,7 +70,7 @@ def bench_plan(args):
                          f"five other BASELINE configurations, {cfg_tries} tangent candidates each"))
         if not args.no_frows:
             draws = 3 if args.full else 2
-            legs.append(_leg("frows", 9 * draws * (ALLOC_S_PER_GB * 0.7 * state_gb + 1.2), draws * 0.8 * state_gb, f"nine SURVEY 8(f) rows, up to {draws} sets of allocations each"))
+            legs.append(_leg("frows", 10 * draws * (ALLOC_S_PER_GB * 0.7 * state_gb + 1.2), draws * 0.8 * state_gb, f"ten SURVEY 8(f) rows, up to {draws} sets of allocations each"))
     if not args.no_host_path:
         if world > 1:
             per_dev = min(n, 2_500_000)
@@ -83,7 +83,7 @@ def bench_plan(args):
     if world == 1:
         if not args.no_live_traffic:
             extra_rows = args.workload is None and args.configs != "none"
-            items = 3 + (5 if extra_rows else 0) + (9 if (extra_rows and not args.no_frows) else 0)
+            items = 3 + (5 if extra_rows else 0) + (10 if (extra_rows and not args.no_frows) else 0)
             legs.append(_leg("live_traffic", 2 * (IMPORT_S + 4.0 + items * (ALLOC_S_PER_GB * 0.8 * state_gb + 1.5)), state_gb,
                              f"two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE), {items} items each; the CPU baseline runs on the host meanwhile"))
         if not args.no_cpu_baseline:
