@@ -751,7 +751,6 @@ int fcamd_evaluate_device_ex(fcamd_model* m, double t, double del_t, int64_t n, 
 // the gradients' values does, so an iteration costs two dispatches (counters, batch kernel) whatever the number of laws.
 // Results are bit for bit those of the same calls made one by one (same tile code, same arguments).
 int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n, const fcamd_eval_args* args, double t, double del_t) {
-    (void)t;
     if (count < 0 || (count > 0 && (!models || !n || !args))) return fail(FCAMD_ERR_BAD_ARG, "NULL argument");
     if (count == 0) return FCAMD_OK;
     fcamd_context* c = models[0] ? models[0]->ctx : nullptr;
@@ -761,6 +760,13 @@ int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n
         if (args[k].wrapper_constraint != 0) return fail(FCAMD_ERR_UNSUPPORTED, "fcamd_evaluate_batch: the fused wrapper form is not batched (models[%d])", k);
         const int st = check_device_ex(models[k], del_t, n[k], &args[k]);
         if (st != FCAMD_OK) return st;
+    }
+    if (c->timing) {  // context option "timing": every law bracketed by its own events, as fcamd_model_last_stats reports them
+        for (int k = 0; k < count; ++k) {
+            const int st = fcamd_evaluate_device_ex(models[k], t, del_t, n[k], &args[k]);
+            if (st != FCAMD_OK) return st;
+        }
+        return FCAMD_OK;
     }
     HIP_TRY(hipSetDevice(c->device));
     // laws below this size do not fill the device (512 workgroups per CU at two tiles per wave: fcamd_kernels.hip)

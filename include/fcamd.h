@@ -276,7 +276,8 @@ FCAMD_API int fcamd_evaluate_device_ex(fcamd_model* model, double t, double del_
    kernel that reads every law's arguments from a table in device memory.  The table is uploaded only when it changes, so the
    Newton iterations of an increment (same arrays, new gradient values) cost two dispatches whatever the number of laws.
    Precondition (the reference's, too): the laws write disjoint rows of the arrays they share.  Results are bit for bit those
-   of the same calls made one by one.  Context option "batch_kernel" (FCAMD_BATCH_KERNEL, 1): 0 = one launch per law. */
+   of the same calls made one by one.  Context option "batch_kernel" (FCAMD_BATCH_KERNEL, 1): 0 = one launch per law; with the
+   context option "timing" on, the laws are launched (and timed) one by one. */
 FCAMD_API int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n, const fcamd_eval_args* args,
                                    double t, double del_t);
 

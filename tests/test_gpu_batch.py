@@ -101,3 +101,21 @@ def test_batch_entry_raw_checks_everything_before_it_launches_anything():
             assert torch.equal(h, hr)
     st = laws[2].device_stats(0)
     assert st.n_plastic > 0  # the batch resets and fills the law's own counters like the single call
+
+
+def test_timed_context_launches_the_laws_one_by_one():
+    """context option "timing": fcamd_model_last_stats must keep reporting each law's own kernel time"""
+    a, rows, rng = build(600, 4, 2, 9, True)
+    ctx = a._laws[0].law._handle(0).ctx
+    grads = [torch.from_numpy(rng.normal(size=9 * r.size) * 1e-3).cuda() for r in rows]
+    ctx.set_timing(True)
+    try:
+        a.evaluate(grads)
+        a.check()
+        for ls in a._laws:
+            assert ls.law._handle(0).last_kernel_ms() > 0.0
+    finally:
+        ctx.set_timing(False)
+    b, _, _ = build(600, 4, 2, 9, False)
+    b.evaluate(grads)
+    assert torch.equal(a.stress_1, b.stress_1) and torch.equal(a.tangent, b.tangent)
