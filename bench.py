@@ -846,8 +846,12 @@ def main():
                     except Exception as e:  # noqa: BLE001 -- reported, never fatal
                         out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-                cpu_thread = threading.Thread(target=run_cpu, daemon=True)
-                cpu_thread.start()
+                if args.full:  # its crossover table makes GPU calls of its own: not next to a PMC pass
+                    run_cpu()
+                    leg_done("cpu_baseline")
+                else:
+                    cpu_thread = threading.Thread(target=run_cpu, daemon=True)
+                    cpu_thread.start()
             else:
                 out["cpu_baseline"] = None
         if world == 1 and not args.no_live_traffic and budget_left() > 100:
