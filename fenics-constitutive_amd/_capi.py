@@ -444,6 +444,9 @@ class LaunchCache:
         self._kept = {}
 
     def run(self, slot, signature, enqueue, stream_ptr):
+        if getattr(_tls, "batch", None) is not None:  # inside a caller's own batched_launches(): the calls join that batch
+            enqueue()
+            return
         kept = self._kept.get(slot)
         if kept is not None and kept[0] == signature:
             kept[1].ctx.set_stream(stream_ptr)
