@@ -465,7 +465,9 @@ class batched_launches:
     ``DeviceLaw.evaluate_from`` / ``evaluate_indexed`` on device tensors) are recorded and leave together as ONE
     ``fcamd_evaluate_batch`` when the block ends: the laws of one ``form()`` (solver/_solver.py:143-144) in one trip through the
     binding, the small ones concurrently on the context's side streams.  A call with another context, ``t`` or ``del_t`` than
-    the recorded ones flushes what has been recorded first.  Not re-entrant; per thread."""
+    the recorded ones flushes what has been recorded first.  The launches happen when the block ENDS: every array passed to a
+    recorded call must stay alive and unchanged until then (a temporary tensor freed inside the block may be handed out again
+    before the kernel reads it).  Not re-entrant; per thread."""
 
     def __init__(self):
         self.calls = []  # (model, n, args, keep-alive)

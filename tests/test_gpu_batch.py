@@ -119,3 +119,33 @@ def test_timed_context_launches_the_laws_one_by_one():
     b, _, _ = build(600, 4, 2, 9, False)
     b.evaluate(grads)
     assert torch.equal(a.stress_1, b.stress_1) and torch.equal(a.tangent, b.tangent)
+
+
+def test_resident_states_join_a_callers_batch():
+    """two ResidentStates (two single-law problems) evaluated inside the caller's own batched_launches(): one fcamd_evaluate_batch
+    for both, same trial states as evaluated one after the other"""
+    from fenics_constitutive_amd.resident import ResidentState
+
+    def states():
+        out = []
+        for i, kind in enumerate(("von_mises_3d", "spring_maxwell")):
+            p, g, s, h = random_case(kind, 64 * 90 + 11, seed=21 + i)
+            st = ResidentState(make_law(kind, p), s.size // 6, stress0=s, history0=h, placement="torch")
+            out.append((st, torch.from_numpy(g).cuda()))
+        return out
+
+    a, b = states(), states()
+    for it in range(3):
+        grads = [g * (1.0 + 0.1 * it) for _, g in a]  # recorded calls launch when the block ends: their arrays stay alive until then
+        with _capi.batched_launches() as batch:
+            for (st, _), g in zip(a, grads):
+                st.evaluate(0.0, 0.7, g)
+        assert len(batch.prepared) == 1 and batch.prepared[0].count == 2
+        for (st, _), g in zip(b, grads):
+            st.evaluate(0.0, 0.7, g)
+        for (sa, _), (sb, _) in zip(a, b):
+            sa.check(), sb.check()
+            assert torch.equal(sa.stress, sb.stress) and torch.equal(sa.tangent, sb.tangent)
+    for (sa, _), (sb, _) in zip(a, b):
+        sa.update(), sb.update()
+        assert torch.equal(sa.stress_committed, sb.stress_committed)
