@@ -289,7 +289,7 @@ SURVEY_ROW = {"indexed_runs": "f2", "indexed_scattered_cells": "f2", "indexed_pe
               "resident_sparse_tangent": "f1", "resident_sparse_tangent_zoned": "f1"}
 
 
-def run_frow(name, n, device, launches=6, warm=2, peak_gbs=8000.0, draws=3):
+def run_frow(name, n, device, launches=6, warm=2, peak_gbs=8000.0, draws=3, redraw=True):
     """one row, measured: warm launches, the row's own counts, `launches` event-timed launches -- on up to `draws` fresh sets
     of allocations (the kernel time follows where the driver puts the written arrays, DESIGN.md 6: `frac` is the fastest
     set, as the headline's is the fastest tangent candidate; `frac_first_allocation` what the first set gave)"""
@@ -297,8 +297,16 @@ def run_frow(name, n, device, launches=6, warm=2, peak_gbs=8000.0, draws=3):
 
     rows, results = [], []
     try:
-        for k in range(max(1, draws)):
-            if rows and k >= getattr(rows[0], "max_draws", draws):
+        k = -1
+        while True:
+            k += 1
+            if k >= max(1, draws):
+                # every set of allocations a slow one (recognisable from the byte rate alone)?  One more, once -- not for
+                # the row whose rate is low by construction
+                slow = max(r[2].alg_bytes() / (r[0] * 1e-3) / 1e9 / peak_gbs for r in results) < 0.77
+                if not (slow and redraw and k == draws and draws > 1 and name != "indexed_permuted"):
+                    break
+            if rows and k >= getattr(rows[0], "max_draws", draws + 1):
                 break  # a row that places its own arrays
             free_b = torch.cuda.mem_get_info(device)[0]
             if k > 0 and free_b < 1.3 * rows[0].extra.get("_bytes", 0):
