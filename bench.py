@@ -514,16 +514,12 @@ def main():
 
     # ... and the reference's own call: law.evaluate(...) IN PLACE on the interface's arrays (what a drop-in torch caller launches;
     # the committed state is copied into the call's arrays before every launch, outside the event bracket)
-    in_place_ms = None
-
-    class wl_in_place_draws:  # (the workload is freed before the line is assembled)
-        v = None
-
+    in_place_ms = in_place_draws = None
     if wl.plasticity and not wl.split and world == 1:
         try:
             ms = wl.timed_in_place(5, sets=2)
             in_place_ms = sum(ms) / len(ms)
-            wl_in_place_draws.v = list(wl.in_place_draws_ms)
+            in_place_draws = list(wl.in_place_draws_ms)  # (the workload is freed before the line is assembled)
         except Exception as e:  # informational (e.g. no room for the second copy of the state)
             stage(f"in-place leg skipped: {type(e).__name__}: {e}")
     leg_done("reference_layout_legs")
@@ -664,7 +660,7 @@ def main():
         if in_place_ms is not None:
             out["in_place"] = {"kernel_ms_avg": round(in_place_ms, 4),
                                "frac": round(alg_bytes / (in_place_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "allocation_draws_ms": getattr(wl_in_place_draws, "v", None),
+                               "allocation_draws_ms": in_place_draws,
                                "note": "same step as the reference's own call: law.evaluate(...) in place on the interface's arrays (reference layout, "
                                        "no protocol words) -- what a drop-in torch caller launches"}
         out["placement"] = dict(headline["vmm_info"] or {"mode": "hipmalloc_tuned" if headline["placement"] else "first"})
