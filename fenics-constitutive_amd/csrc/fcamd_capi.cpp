@@ -811,9 +811,13 @@ int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n
         if (tab.empty()) break;
         const size_t bytes = tab.size() * sizeof(fcamd::BatchEntry);
         // a slot that holds this very table already (the Newton iterations of an increment): nothing to upload
+        static_assert(sizeof(fcamd::BatchEntry) % 8 == 0, "the table is hashed word by word");
+        uint64_t hash = 0x9E3779B97F4A7C15ull ^ bytes;
+        const uint64_t* words = reinterpret_cast<const uint64_t*>(tab.data());
+        for (size_t i = 0; i < bytes / 8; ++i) hash = (hash ^ words[i]) * 0x100000001B3ull;
         fcamd_context::BatchSlot* slot = nullptr;
         for (auto& sl : c->batch_slots)
-            if (sl.host && sl.bytes == bytes && memcmp(sl.host, tab.data(), bytes) == 0) slot = &sl;
+            if (sl.host && sl.bytes == bytes && sl.hash == hash && memcmp(sl.host, tab.data(), bytes) == 0) slot = &sl;
         if (!slot) {
             slot = &c->batch_slots[c->batch_next++ % fcamd_context::kBatchSlots];
             if (!slot->host) {
@@ -824,6 +828,7 @@ int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n
             }
             memcpy(slot->host, tab.data(), bytes);
             slot->bytes = bytes;
+            slot->hash = hash;
             HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, c->stream));
         }
         (void)hipGetLastError();

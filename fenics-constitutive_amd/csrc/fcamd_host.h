@@ -103,11 +103,12 @@ struct fcamd_context {
     // fcamd_evaluate_batch: tables of the batch kernel (page-locked host copy + device copy each; a table is uploaded only when it
     // differs from what its slot holds)
     static constexpr int kBatchMax = 32;   // entries per launch of the batch kernel
-    static constexpr int kBatchSlots = 4;  // two copies of a state (committed / trial) x two tables in flight
+    static constexpr int kBatchSlots = 16;  // tables kept: two per state (committed / trial copy) for up to eight states of a thread
     struct BatchSlot {
         fcamd::BatchEntry* host = nullptr;
         fcamd::BatchEntry* dev = nullptr;
         size_t bytes = 0;
+        uint64_t hash = 0;
     };
     BatchSlot batch_slots[kBatchSlots];
     unsigned batch_next = 0;

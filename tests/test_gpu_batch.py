@@ -149,3 +149,34 @@ def test_resident_states_join_a_callers_batch():
     for (sa, _), (sb, _) in zip(a, b):
         sa.update(), sb.update()
         assert torch.equal(sa.stress_committed, sb.stress_committed)
+
+
+def test_many_states_on_one_thread_keep_their_tables():
+    """twelve resident states evaluated in turn, again and again (one context: more distinct batch tables than a handful of slots):
+    every state keeps computing what a state with the batch kernel off computes"""
+    from fenics_constitutive_amd.resident import ResidentState
+
+    p, g, s, h = random_case("von_mises_3d", 64 * 40 + 5, seed=33)
+    law = make_law("von_mises_3d", p)
+    ctx = law._handle(0).ctx
+    sts = [ResidentState(law, s.size // 6, stress0=s, history0=h, placement="torch") for _ in range(12)]
+    ref = ResidentState(law, s.size // 6, stress0=s, history0=h, placement="torch")
+    gd = torch.from_numpy(g).cuda()
+    for it in range(4):
+        gi = gd * (1.0 + 0.05 * it)
+        for st in sts:
+            st.evaluate(0.0, 1.0, gi)
+        ctx.set_option("batch_kernel", 0)
+        try:
+            ref._launch_cache.clear()
+            ref.evaluate(0.0, 1.0, gi)
+        finally:
+            ctx.set_option("batch_kernel", 1)
+        ref.check()
+        for st in sts:
+            st.check()
+            assert torch.equal(st.stress, ref.stress) and torch.equal(st.tangent, ref.tangent)
+        if it == 1:
+            ref.update()
+            for st in sts:
+                st.update()
