@@ -102,3 +102,24 @@ def test_plan_of_the_default_command_is_under_two_minutes_plus_margin():
     for n in ("2", "4"):
         q = run_plan("--gpus", n)
         assert q["fits_memory"] and q["fits_driver_limit"]
+
+
+def test_round5_line_is_what_compact_line_makes_of_its_detail_file():
+    """profiles/r05_default_bench_line.json (what the driver's command printed) == compact_line(profiles/r05_default_bench_detail.json)"""
+    with open(os.path.join(ROOT, "profiles", "r05_default_bench_detail.json")) as f:
+        detail = json.load(f)
+    with open(os.path.join(ROOT, "profiles", "r05_default_bench_line.json")) as f:
+        text = f.read().strip()
+    line = json.loads(text)
+    assert len(text) < MAX_LINE_BYTES and "\n" not in text
+    assert json.loads(dumps(compact_line(detail, line["detail"]))) == line
+    rf = line["roofline"]
+    assert rf["traffic_source"] == "live_pmc" and 1.0 <= rf["traffic_over_algorithmic"] <= 1.03
+    assert 0.7 < rf["frac"] < 0.85 and rf["frac_in_place"] < rf["frac"] and rf["frac_reference_layout"] < rf["frac"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
+    assert line["wall_s"] < 120.0  # VERDICT r4: the default command back under two minutes
+    from benchlib import frows
+    from benchlib.workloads import EXTRA_CONFIGS
+
+    assert list(line["configs"]) == EXTRA_CONFIGS + list(frows.FROWS)
+    assert all(isinstance(v, list) and len(v) == len(CONFIG_COLUMNS) for v in line["configs"].values())
