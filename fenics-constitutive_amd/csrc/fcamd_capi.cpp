@@ -379,6 +379,18 @@ int grid_for(fcamd_model* m, int64_t n) {
 }  // namespace
 
 namespace fcamd {
+constexpr int kFlagExactTangentRows = 16;  // kernels/tangent_writers.h (library-internal bit of EvalArgs::flags)
+
+// does the device address `p` lie in host memory this context has mapped (registered caller ranges, the page-locked scratch)?
+static bool host_mapped(fcamd_context* c, const void* p) {
+    const char* q = static_cast<const char*>(p);
+    if (c->bounce_dev && q >= c->bounce_dev && q < c->bounce_dev + c->bounce_bytes) return true;
+    std::lock_guard<std::recursive_mutex> lock(c->host_mu);
+    for (const auto& kv : c->registered)
+        if (kv.second.dev && q >= kv.second.dev && q < kv.second.dev + kv.second.bytes) return true;
+    return false;
+}
+
 // the kernel arguments of one launch (device pointers already validated)
 static void fill_args(fcamd_model* m, double del_t, int64_t n, const double* grad, const double* stress_prev,
                       double* stress, double* tangent, const double* const* hprev, double* const* hcur, const int* rows,
@@ -401,6 +413,8 @@ static void fill_args(fcamd_model* m, double del_t, int64_t n, const double* gra
     a.flags = split ? FCAMD_EVAL_SPLIT_HISTORY : 0;
     if (hmask) {
         if (tangent) a.flags |= flags & FCAMD_EVAL_SPARSE_TANGENT;  // needs an array that holds the previous tangent
+        // the tangent is page-locked host memory written over PCIe (a registered range or the bounce scratch): bare rows, no granules
+        if ((a.flags & FCAMD_EVAL_SPARSE_TANGENT) && host_mapped(m->ctx, tangent)) a.flags |= kFlagExactTangentRows;
         // (with parent_rows: VonMises3D only -- the indexed split-history kernels would need instantiations of their own)
         if ((m->law == FCAMD_VON_MISES_3D || (split && !rows)) && emask_prev && emask) a.flags |= flags & FCAMD_EVAL_PACKED_HISTORY;
     }

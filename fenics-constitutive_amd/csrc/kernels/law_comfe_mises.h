@@ -128,7 +128,7 @@ __device__ __forceinline__ void tile_comfe_mises(ArgsRef a, const StressBases& s
     if (sb.tan && tneed != 0ull) {
         publish_tangent_params(region, lane, B, sc2, nv);
         wave_sync();
-        tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed);
+        tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
         wave_sync();
     }
 }

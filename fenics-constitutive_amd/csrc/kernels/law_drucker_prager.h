@@ -82,13 +82,13 @@ __device__ __forceinline__ d2 tangent_dp_chunk(const double* tp, const double* t
 
 template <bool NT, bool MASKED, int K>
 __device__ __forceinline__ void tangent_dp_pass(const double* tp, const double* t11tab, const double* pdtab, const double* etab,
-                                                double* tile, int lane, ChunkLane& cl, unsigned long long tneed) {
+                                                double* tile, int lane, ChunkLane& cl, unsigned long long tneed, bool exact_rows) {
     // the maps of pass k and k + 9 coincide up to a constant ((10 k) % 18 has period 9): left alone the compiler keeps them alive
     // across nine passes, and this kernel sits at its 168-VGPR cap (scratch: 9.0 -> 9.8 ms).  Fresh values per group of passes.
     if constexpr (K % kTangentGroup == 0) asm volatile("" : "+v"(cl.pl), "+v"(cl.r0));
     const ChunkMap m = chunk_map<K>(cl);
     bool wanted = true;
-    if constexpr (MASKED) wanted = quad_any(((tneed >> m.p) & 1ull) != 0ull);
+    if constexpr (MASKED) wanted = tangent_chunk_wanted(tneed, m.p, exact_rows);
     char* dst = reinterpret_cast<char*>(tile) + K * (kWave * 16) + (unsigned)lane * 16u;  // scalar base of the pass + the lane's byte offset
     if (wanted) store_tangent16<NT>(reinterpret_cast<double*>(dst), tangent_dp_chunk(tp, t11tab, pdtab, etab, m.p, m.r, m.i, m.jj));
     if constexpr (K % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
@@ -96,21 +96,21 @@ __device__ __forceinline__ void tangent_dp_pass(const double* tp, const double* 
 
 template <bool NT, bool MASKED, int... K>
 __device__ __forceinline__ void tangent_dp_passes(const double* tp, const double* t11tab, const double* pdtab, const double* etab,
-                                                  double* tile, int lane, unsigned long long tneed, std::integer_sequence<int, K...>) {
+                                                  double* tile, int lane, unsigned long long tneed, bool exact_rows, std::integer_sequence<int, K...>) {
     ChunkLane cl = chunk_lane(lane);
-    (tangent_dp_pass<NT, MASKED, K>(tp, t11tab, pdtab, etab, tile, lane, cl, tneed), ...);
+    (tangent_dp_pass<NT, MASKED, K>(tp, t11tab, pdtab, etab, tile, lane, cl, tneed, exact_rows), ...);
 }
 
 template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tangent_dp(const double* tp, const double* t11tab, const double* pdtab,
                                            const double* etab, double* tangent, long long p0,
-                                           const int* rows_lds, int npts, int lane, unsigned long long tneed) {
+                                           const int* rows_lds, int npts, int lane, unsigned long long tneed, bool exact_rows = false) {
     if constexpr (FULL && !IDX) {  // the contiguous tile: incremental chunk maps (tangent_writers.h: chunk_map), need test only when sparse
         double* tile = tangent + p0 * 36;
         if (tneed == ~0ull)
-            tangent_dp_passes<NT, false>(tp, t11tab, pdtab, etab, tile, lane, tneed, std::make_integer_sequence<int, 18>{});
+            tangent_dp_passes<NT, false>(tp, t11tab, pdtab, etab, tile, lane, tneed, false, std::make_integer_sequence<int, 18>{});
         else
-            tangent_dp_passes<NT, true>(tp, t11tab, pdtab, etab, tile, lane, tneed, std::make_integer_sequence<int, 18>{});
+            tangent_dp_passes<NT, true>(tp, t11tab, pdtab, etab, tile, lane, tneed, exact_rows, std::make_integer_sequence<int, 18>{});
         return;
     }
     const int nchunks = npts * 18;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void tile_comfe_dp(ArgsRef a, const StressBases& sb, 
             if (tneed == ~0ull)
                 tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
             else
-                tangent_const_masked<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, tneed);
+                tangent_const_masked<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
         }
         st.domain += (live && t.tip) ? 1ull : 0ull;
         return;
@@ -357,7 +357,7 @@ __device__ __forceinline__ void tile_comfe_dp(ArgsRef a, const StressBases& sb, 
     if (sb.tan && tneed != 0ull) {
         dp_publish(region, lane, tg, t.s_tr, plastic);
         wave_sync();
-        tangent_dp<IDX, FULL, NT>(region, T->a, T->b, T->c, sb.tan, p0, rows_lds, npts, lane, tneed);
+        tangent_dp<IDX, FULL, NT>(region, T->a, T->b, T->c, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
         wave_sync();
     }
 }

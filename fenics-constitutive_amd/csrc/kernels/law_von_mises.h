@@ -254,7 +254,7 @@ __device__ __forceinline__ void tile_von_mises(ArgsRef a, const StressBases& sb,
         vm_tangent_coefficients(a.sc, rm, B, C);
         publish_tangent_params(region, lane, B, C, rm.N);
         wave_sync();
-        tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed);
+        tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
         wave_sync();
     }
 }

@@ -22,6 +22,13 @@ __device__ __forceinline__ bool quad_any(bool mine) {
     return v != 0;
 }
 
+// chunk of point p under the sparse-tangent protocol: its row is needed, or (unless the rows go out bare) a row of its granule is
+__device__ __forceinline__ bool tangent_chunk_wanted(unsigned long long tneed, int p, bool exact_rows) {
+    const bool mine = ((tneed >> p) & 1ull) != 0ull;
+    const bool quad = quad_any(mine);  // (all lanes take part)
+    return exact_rows ? mine : quad;
+}
+
 // Constant tangent (LE, SLS, comfe LE): every point gets the same 36 doubles = 18 chunks,
 // read from the LDS table `tab` (np.tile(D.flatten(), n) in the reference).
 template <bool IDX, bool FULL, bool NT>
@@ -44,7 +51,7 @@ __device__ __forceinline__ void tangent_const(const double* tab, double* tangent
 template <bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tangent_const_masked(const double* tab, double* tangent, long long p0,
                                                      const int* rows_lds, int npts, int lane,
-                                                     unsigned long long tneed) {
+                                                     unsigned long long tneed, bool exact_rows = false) {
     const int nchunks = npts * 18;
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
@@ -52,7 +59,7 @@ __device__ __forceinline__ void tangent_const_masked(const double* tab, double* 
         const int p = q / 18;
         d2 v = reinterpret_cast<const d2*>(tab)[q - 18 * p];
         bool wanted = ((tneed >> p) & 1ull) != 0ull;
-        if constexpr (FULL && !IDX) wanted = quad_any(wanted);  // whole 64-byte granules (quad_any below)
+        if constexpr (FULL && !IDX) wanted = tangent_chunk_wanted(tneed, p, exact_rows);  // whole 64-byte granules unless the rows go out bare
         if ((FULL || q < nchunks) && wanted) store_tangent16<NT>(tangent_chunk<IDX>(tangent, p0, q, rows_lds), v);
     }
 }
@@ -73,6 +80,10 @@ constexpr int kFlagSplitHistory = 4;
 // Packed plastic-strain history (kernels/history_rows.h: PackedRows): committed and trial plastic-strain arrays hold, per tile,
 // the rows of the ever-plastic points as one contiguous run; EvalArgs::emask_in / emask_out are the tiles' EVER masks.
 constexpr int kFlagPackedHistory = 8;
+// (library-internal, set by fill_args when the tangent array is page-locked HOST memory the kernel writes over PCIe:) the sparse tangent
+// moves the needed rows alone, not whole 64-byte granules -- over the link every byte counts and there is no partial-unit penalty
+// to avoid (host assembler, resident state + sparse tangent, 1e7 points: 503 Mpts/s with bare rows, 488 with granules)
+constexpr int kFlagExactTangentRows = 16;
 template <bool FULL>
 __device__ __forceinline__ unsigned long long sparse_tangent_need(ArgsRef a, unsigned long long need) {
     return (FULL && (a.flags & kFlagSparseTangent) != 0 && a.hmask != nullptr) ? need : ~0ull;
@@ -142,10 +153,10 @@ __device__ __forceinline__ d2 tangent_mises_chunk(const double* tp, const double
 
 template <bool COMFE, bool NT, bool MASKED, int K>
 __device__ __forceinline__ void tangent_mises_pass(const double* tp, const double* ta, const double* tb, double* tile, int lane,
-                                                   const ChunkLane& cl, unsigned long long tneed) {
+                                                   const ChunkLane& cl, unsigned long long tneed, bool exact_rows) {
     const ChunkMap m = chunk_map<K>(cl);
     bool wanted = true;
-    if constexpr (MASKED) wanted = quad_any(((tneed >> m.p) & 1ull) != 0ull);
+    if constexpr (MASKED) wanted = tangent_chunk_wanted(tneed, m.p, exact_rows);
     // destination: the pass's base (scalar) + this lane's byte offset (32 bits, the same in every pass)
     char* dst = reinterpret_cast<char*>(tile) + K * (kWave * 16) + (unsigned)lane * 16u;
     if (wanted) store_tangent16<NT>(reinterpret_cast<double*>(dst), tangent_mises_chunk<COMFE>(tp, ta, tb, m.p, m.r, m.i, m.jj));
@@ -155,21 +166,21 @@ __device__ __forceinline__ void tangent_mises_pass(const double* tp, const doubl
 
 template <bool COMFE, bool NT, bool MASKED, int... K>
 __device__ __forceinline__ void tangent_mises_passes(const double* tp, const double* ta, const double* tb, double* tile, int lane,
-                                                     unsigned long long tneed, std::integer_sequence<int, K...>) {
+                                                     unsigned long long tneed, bool exact_rows, std::integer_sequence<int, K...>) {
     const ChunkLane cl = chunk_lane(lane);
-    (tangent_mises_pass<COMFE, NT, MASKED, K>(tp, ta, tb, tile, lane, cl, tneed), ...);
+    (tangent_mises_pass<COMFE, NT, MASKED, K>(tp, ta, tb, tile, lane, cl, tneed, exact_rows), ...);
 }
 
 template <bool COMFE, bool IDX, bool FULL, bool NT>
 __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta, const double* tb,
                                               double* tangent, long long p0, const int* rows_lds,
-                                              int npts, int lane, unsigned long long tneed) {
+                                              int npts, int lane, unsigned long long tneed, bool exact_rows = false) {
     if constexpr (FULL && !IDX) {  // the contiguous tile: incremental chunk maps; the need test only under the sparse-tangent protocol
         double* tile = tangent + p0 * 36;
         if (tneed == ~0ull)
-            tangent_mises_passes<COMFE, NT, false>(tp, ta, tb, tile, lane, tneed, std::make_integer_sequence<int, 18>{});
+            tangent_mises_passes<COMFE, NT, false>(tp, ta, tb, tile, lane, tneed, false, std::make_integer_sequence<int, 18>{});
         else
-            tangent_mises_passes<COMFE, NT, true>(tp, ta, tb, tile, lane, tneed, std::make_integer_sequence<int, 18>{});
+            tangent_mises_passes<COMFE, NT, true>(tp, ta, tb, tile, lane, tneed, exact_rows, std::make_integer_sequence<int, 18>{});
         return;
     }
     const int nchunks = npts * 18;
