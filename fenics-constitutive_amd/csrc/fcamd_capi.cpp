@@ -592,6 +592,7 @@ int fcamd_context_destroy(fcamd_context* c) {
     for (auto& sl : c->batch_slots) {
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
     }
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -844,6 +845,12 @@ int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n
             slot->bytes = bytes;
             slot->hash = hash;
             HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, c->stream));
+            if (!slot->uploaded) HIP_TRY(hipEventCreateWithFlags(&slot->uploaded, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(slot->uploaded, c->stream));
+            slot->stream = c->stream;
+        } else if (slot->stream != c->stream) {
+            // the context has been bound to another stream since the table went up: the launch waits for the upload
+            HIP_TRY(hipStreamWaitEvent(c->stream, slot->uploaded, 0));
         }
         (void)hipGetLastError();
         HIP_TRY(fcamd::launch_evaluate_batch(slot->dev, (int)tab.size(), blocks, any_counts, c->stream));

@@ -109,6 +109,8 @@ struct fcamd_context {
         fcamd::BatchEntry* dev = nullptr;
         size_t bytes = 0;
         uint64_t hash = 0;
+        hipEvent_t uploaded = nullptr;  // recorded behind the table's upload, on ...
+        hipStream_t stream = nullptr;   // ... this stream (a launch from another stream waits for the event)
     };
     BatchSlot batch_slots[kBatchSlots];
     unsigned batch_next = 0;

@@ -180,3 +180,21 @@ def test_many_states_on_one_thread_keep_their_tables():
             ref.update()
             for st in sts:
                 st.update()
+
+
+def test_batch_table_uploaded_on_one_stream_launched_from_another():
+    """the first evaluate uploads the batch table on stream A; the next iteration, the same call, comes from stream B: it waits for the upload"""
+    a, rows, rng = build(900, 4, 3, 17, True)
+    b, _, _ = build(900, 4, 3, 17, False)
+    grads = [torch.from_numpy(rng.normal(size=9 * r.size) * np.repeat(10 ** rng.uniform(-4, -2, size=r.size), 9)).cuda() for r in rows]
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sa):
+        a.evaluate(grads)
+    with torch.cuda.stream(sb):
+        sb.wait_stream(sa)
+        a.evaluate(grads)
+        a.check()
+    b.evaluate(grads), b.evaluate(grads)
+    b.check()
+    assert torch.equal(a.stress_1, b.stress_1) and torch.equal(a.tangent, b.tangent)
