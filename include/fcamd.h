@@ -23,7 +23,8 @@
  *
  * Version 0.4 (round 4): the boundary is THREE evaluate entries -- fcamd_evaluate_host (the ndarray call),
  * fcamd_evaluate_device_ex (device arrays, every option in one argument struct), fcamd_evaluate_resident (host
- * assembler on a device-resident state) -- 45 exported symbols in all (0.3: 69).  The narrower forms of 0.3
+ * assembler on a device-resident state) --, plus (round 5) fcamd_evaluate_batch, the laws of one form() in one call: 46 exported
+ * symbols in all (0.3: 69).  The narrower forms of 0.3
  * (fcamd_evaluate_device, _from, _from_sparse, _indexed, _wrapped, the single-value getters and setters) are
  * `static inline` shorthands at the end of this header: same names, same arguments, no symbols.
  */
