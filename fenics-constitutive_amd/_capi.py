@@ -447,6 +447,7 @@ class LaunchCache:
         if getattr(_tls, "batch", None) is not None:  # inside a caller's own batched_launches(): the calls join that batch
             enqueue()
             return
+        signature = (threading.get_ident(), signature)  # (model handles and contexts belong to the thread that made the calls)
         kept = self._kept.get(slot)
         if kept is not None and kept[0] == signature:
             kept[1].ctx.set_stream(stream_ptr)
