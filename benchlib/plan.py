@@ -88,6 +88,15 @@ def bench_plan(args):
                              f"two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE), {items} items each; the CPU baseline runs on the host meanwhile"))
         if not args.no_cpu_baseline:
             legs.append(_leg("cpu_baseline", 0.0 if not args.no_live_traffic else 14.0, 0.0, "C port, 1 thread, 2e6 points x 8 s + side figures (overlapped with the PMC passes)"))
+    # what bench.py checks before it enters an optional leg: seconds that must be left of --wall-budget (all ranks agree by all-reduce)
+    needs = {"strong_scaling_leg": 60, "allgather": 90, "configs": 45, "frows": 60, "host_path_multi": 75, "host_path": 40, "live_traffic": 100}
+    spent = 0.0
+    for x in legs:
+        x["starts_at_s"] = round(spent, 1)
+        if x["leg"] in needs:
+            x["skipped_if_budget_left_below_s"] = needs[x["leg"]]
+            x["runs"] = bool(args.wall_budget - spent > needs[x["leg"]])
+        spent += x["est_s"]
     total = sum(x["est_s"] for x in legs)
     peak = max(x["peak_GB_per_gpu"] for x in legs)
     return {"plan": True, "n_gpus": world, "points_per_gpu": n, "points_total": total_pts, "est_total_s": round(total, 1),

@@ -88,6 +88,8 @@ def test_plan_of_the_eight_gpu_launch_fits_the_limits():
     for name in ("setup", "placement", "timed_steps", "strong_scaling_leg", "allgather", "host_path_multi"):
         assert name in legs and legs[name]["est_s"] >= 0, name
     assert legs["allgather"]["est_s"] < 240.0  # --gather-timeout
+    # every optional leg starts with more of --wall-budget left than it asks for: none is skipped by the plan's own arithmetic
+    assert all(x["runs"] for x in p["legs"] if "runs" in x), [(x["leg"], x["starts_at_s"]) for x in p["legs"]]
     assert "configs" not in legs and "live_traffic" not in legs  # N = 1 legs
     # the estimated value scales with N (weak scaling, no data-path collective)
     p1 = run_plan("--gpus", "1")
