@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfcamd.so")
-SOURCES = ["fcamd_kernels.hip", "fcamd_aux_kernels.hip", "fcamd_capi.cpp", "fcamd_hostpath.cpp", "fcamd_multigpu.cpp", "fcamd_memory.cpp", "fcamd_multi.cpp"]
+SOURCES = ["fcamd_kernels.hip", "fcamd_aux_kernels.hip", "fcamd_capi.cpp", "fcamd_hostpath.cpp", "fcamd_hosttangent.cpp", "fcamd_multigpu.cpp", "fcamd_memory.cpp", "fcamd_multi.cpp"]
 # the device code lives in per-law headers that fcamd_kernels.hip includes
 KERNEL_HEADERS = [os.path.join("kernels", h) for h in (
     "tile_io.h", "tangent_writers.h", "wrapped_io.h", "history_rows.h", "law_linear_elasticity.h", "law_sls.h",

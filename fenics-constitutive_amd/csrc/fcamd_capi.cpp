@@ -291,6 +291,9 @@ void options_from_env(Options* o) {
     o->zero_copy = geti("FCAMD_ZERO_COPY", 1) != 0;
     o->zero_copy_grad = geti("FCAMD_ZERO_COPY_GRAD", 1) != 0;
     o->bounce_max = std::max<long long>(0, geti("FCAMD_BOUNCE_MAX", 256 << 10));
+    o->host_tangent_threads = (int)geti("FCAMD_HOST_TANGENT_THREADS", -1);
+    o->host_tangent_min_points = std::max<long long>(0, geti("FCAMD_HOST_TANGENT_MIN", 1 << 16));
+    o->host_tangent_chunk = std::max<long long>(0, geti("FCAMD_HOST_TANGENT_CHUNK", 0));
 }
 
 // the law's host constants, recomputed only when del_t changes (SLS) -- not once per launch
@@ -418,6 +421,8 @@ static void fill_args(fcamd_model* m, double del_t, int64_t n, const double* gra
         // (with parent_rows: VonMises3D only -- the indexed split-history kernels would need instantiations of their own)
         if ((m->law == FCAMD_VON_MISES_3D || (split && !rows)) && emask_prev && emask) a.flags |= flags & FCAMD_EVAL_PACKED_HISTORY;
     }
+    // (library-internal, host entries only:) `tangent` is the ring of 8 doubles per point, the host rebuilds the rows
+    if (tangent && (flags & kFlagTangentParamsHost)) a.flags = (a.flags & ~FCAMD_EVAL_SPARSE_TANGENT) | kFlagTangentParamsHost;
     a.emask_in = emask_prev;
     a.emask_out = emask;
     a.n = n;
@@ -450,6 +455,8 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
 }  // namespace fcamd
 
 namespace fcamd {
+void constants_for_call(fcamd_model* m, double del_t) { constants_for(m, del_t); }
+
 void sum_counters(const fcamd_model* m, fcamd_stats* out) {
     out->n_nonconverged = out->n_plastic = out->n_newton_iters = out->n_domain = 0;
     out->kernel_ms = -1.0;  // fcamd_model_last_stats fills it
@@ -533,6 +540,7 @@ static int context_trim(fcamd_context* c) {
     for (int i = 0; i < fcamd_context::kSlots; ++i)
         if (c->hstream[i]) HIP_TRY(hipStreamSynchronize(c->hstream[i]));
     free_host_staging(c);
+    fcamd::host_tangent_release(c);
     return FCAMD_OK;
 }
 
@@ -548,6 +556,9 @@ int fcamd_context_set_option(fcamd_context* c, const char* name, long long value
     else if (k == "zero_copy") o.zero_copy = value != 0;
     else if (k == "zero_copy_grad") o.zero_copy_grad = value != 0;
     else if (k == "bounce_max") o.bounce_max = std::max<long long>(0, value);
+    else if (k == "host_tangent_threads") o.host_tangent_threads = (int)std::max<long long>(-1, std::min<long long>(value, 256));
+    else if (k == "host_tangent_min_points") o.host_tangent_min_points = std::max<long long>(0, value);
+    else if (k == "host_tangent_chunk") o.host_tangent_chunk = std::max<long long>(0, (value / 64) * 64);
     else if (k == "grid") c->grid_override = value > 0 ? (int)value : 0;
     else if (k == "timing") c->timing = value != 0;
     else if (k == "trim") return context_trim(c);
@@ -567,6 +578,11 @@ int fcamd_context_get_option(fcamd_context* c, const char* name, long long* valu
     else if (k == "zero_copy") *value = o.zero_copy;
     else if (k == "zero_copy_grad") *value = o.zero_copy_grad;
     else if (k == "bounce_max") *value = o.bounce_max;
+    else if (k == "host_tangent_threads") *value = fcamd::host_tangent_threads(c);  // resolved (-1 -> the automatic count)
+    else if (k == "host_tangent_min_points") *value = o.host_tangent_min_points;
+    else if (k == "host_tangent_chunk") *value = o.host_tangent_chunk;
+    else if (k == "last_host_tangent_cpu_us") *value = c->last_host_tangent_cpu_us;
+    else if (k == "last_host_tangent_threads") *value = c->last_host_tangent_threads;
     else if (k == "grid") *value = c->grid_override;
     else if (k == "timing") *value = c->timing ? 1 : 0;
     else if (k == "last_host_mode") *value = c->last_host_mode;
@@ -582,6 +598,7 @@ int fcamd_context_destroy(fcamd_context* c) {
         release_registered_ranges(c);  // the page locks it shares: the last context to leave unlocks the pages
     }
     free_host_staging(c);
+    fcamd::host_tangent_release(c);
     for (int i = 0; i < fcamd_context::kSlots; ++i)
         if (c->hstream[i]) (void)hipStreamDestroy(c->hstream[i]);
     for (hipStream_t s : c->peer_streams)

@@ -55,7 +55,23 @@ struct Options {
     int zero_copy_grad = 1;    // FCAMD_ZERO_COPY_GRAD 0: fcamd_evaluate_resident uploads the gradient by DMA even if page-locked
     long long bounce_max = 256 << 10;  // FCAMD_BOUNCE_MAX  host calls that move at most this many bytes of pageable caller memory go
                                      // through the context's own page-locked scratch (CPU copies); larger ones page-lock the arrays
+    // the tangent of the host entries rebuilt on the CPU (fcamd_hosttangent.cpp)
+    int host_tangent_threads = -1;            // FCAMD_HOST_TANGENT_THREADS  threads of the expansion; 0: the kernel writes the tangent over PCIe; -1: automatic
+    long long host_tangent_min_points = 1 << 16;  // FCAMD_HOST_TANGENT_MIN  calls with fewer points keep the kernel's own tangent stores
+    long long host_tangent_chunk = 0;         // FCAMD_HOST_TANGENT_CHUNK  points per chunk of the parameter ring (Mises laws); 0: automatic
 };
+
+// One expansion job of the host tangent (fcamd_hosttangent.cpp): what to write into which array
+struct HostTangentJob {
+    enum Kind { CONST = 0, MISES = 1, MISES_COMFE = 2 } kind;
+    int td;                 // doubles per tangent row: stress_strain_dim squared
+    const double* table_a;  // Mises: the tables the kernel's tangent writer reads (Tables::a, ::b) ...
+    const double* table_b;
+    const double* table_c;  // ... constant tangent: the law's tangent table (Tables::c)
+    double* tangent;        // the caller's array (CPU-written only)
+    double elastic_row[36]; // Mises: the tangent of an elastic point, formed by the expansion from an elastic point's parameters
+};
+class ExpandPool;
 
 }  // namespace fcamd
 
@@ -115,6 +131,15 @@ struct fcamd_context {
     BatchSlot batch_slots[kBatchSlots];
     unsigned batch_next = 0;
     std::vector<fcamd::BatchEntry> batch_build;
+    // host tangent (fcamd_hosttangent.cpp): the pool of expansion threads, the page-locked ring of parameter chunks (8 doubles per
+    // point) with one event per slot, and what the last host call spent on the expansion
+    fcamd::ExpandPool* pool = nullptr;
+    char* tparams = nullptr;
+    char* tparams_dev = nullptr;
+    size_t tparams_bytes = 0;
+    hipEvent_t tp_event[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    long long last_host_tangent_cpu_us = 0;  // summed busy time of the expansion threads in the last host call (0: kernel-written tangent)
+    int last_host_tangent_threads = 0;
 };
 
 struct fcamd_model {
@@ -165,6 +190,9 @@ int enqueue(fcamd_model* m, double del_t, int64_t n, const double* grad, const d
             unsigned long long* counters = nullptr, const unsigned long long* emask_prev = nullptr,
             unsigned long long* emask = nullptr);
 
+// m->sc / m->tb brought up to date for `del_t` (what every launch does; the host tangent reads the tables before its launch)
+void constants_for_call(fcamd_model* m, double del_t);
+
 // download and sum the model's counters (synchronises `stream`); the two halves for callers that have a
 // synchronisation of their own coming: enqueue the 2 KB download behind the launches, sum after the wait
 int read_stats(fcamd_model* m, hipStream_t stream, fcamd_stats* out);
@@ -184,6 +212,24 @@ void temp_lock_release(char* base);
 int adopt_registered_range(fcamd_context* c, void* ptr, size_t bytes);
 // drop c's own registrations from the process-wide registry of registered ranges (context destruction)
 void release_registered_ranges(fcamd_context* c);
+
+// ---- host tangent (fcamd_hosttangent.cpp) ----
+constexpr int kFlagTangentParamsHost = 32;  // kernels/tangent_writers.h: kFlagTangentParams (library-internal bit of EvalArgs::flags)
+int host_tangent_kind(const fcamd_model* m);          // 0: the law keeps the kernel's tangent stores; else 1 + HostTangentJob::Kind
+int host_tangent_threads(const fcamd_context* c);     // resolved thread count (0: off)
+bool host_tangent_applies(const fcamd_model* m, int64_t n, int flags);  // would a host entry of n points rebuild the tangent on the CPU?
+ExpandPool* host_tangent_pool(fcamd_context* c);      // the context's pool, created / resized on demand (nullptr: off)
+void host_tangent_release(fcamd_context* c);          // pool, ring and events (context destruction, option "trim")
+HostTangentJob host_tangent_job(const fcamd_model* m, double* tangent);
+int host_tangent_ring(fcamd_context* c, int64_t chunk, int slots);
+void pool_begin(ExpandPool* p, const HostTangentJob& job);
+int pool_post(ExpandPool* p, int64_t p0, int64_t np, const double* src, const unsigned long long* mask);  // -> ticket
+// doubles of one ring slot for chunks of `chunk` points (a multiple of 64): 8 per point + one ballot word per tile
+inline size_t host_tangent_slot_doubles(int64_t chunk) { return (size_t)chunk * 8 + (((size_t)chunk / 64 + 1) & ~(size_t)1); }  // (slots stay 16-byte aligned)
+void pool_wait(ExpandPool* p, int ticket);
+void pool_finish(ExpandPool* p);
+double pool_busy_seconds(ExpandPool* p);
+int pool_threads(ExpandPool* p);
 
 // fcamd_aux_kernels.hip: dst = src over n16 16-byte chunks (non-temporal accesses, grid-stride)
 hipError_t launch_stream_copy(void* dst, const void* src, size_t n16, int grid, hipStream_t stream);

@@ -507,6 +507,102 @@ int64_t bounce_chunk(const fcamd_context* c, int64_t n, size_t bytes_per_point) 
 
 }  // namespace
 
+
+namespace {
+
+// ---- host tangent (fcamd_hosttangent.cpp) ------------------------------------------------------------------------------------
+// Is the tangent of this call rebuilt on the CPU?  Returns the pool (nullptr: the kernel writes the tangent itself).
+ExpandPool* host_tangent_for(fcamd_model* m, int64_t n, const double* tangent) {
+    fcamd_context* c = m->ctx;
+    c->last_host_tangent_cpu_us = 0;
+    c->last_host_tangent_threads = 0;
+    if (!tangent || !host_tangent_applies(m, n, 0)) return nullptr;
+    return host_tangent_pool(c);
+}
+
+void host_tangent_done(fcamd_context* c, ExpandPool* pool) {
+    pool_finish(pool);  // nothing of this call writes the caller's tangent array after the entry has returned
+    c->last_host_tangent_cpu_us = (long long)(pool_busy_seconds(pool) * 1e6);
+    c->last_host_tangent_threads = pool_threads(pool);
+    c->last_host_mode |= FCAMD_HOST_TANGENT_CPU;
+}
+
+// Constant tangent: ONE launch without a tangent array while the pool fills the caller's array from the law's table.
+template <class Launch>
+int run_const_tangent(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangent, fcamd_stats* stats, Launch&& launch) {
+    fcamd_context* c = m->ctx;
+    pool_begin(pool, host_tangent_job(m, tangent));  // (the tables of m were brought up to date for this del_t by the caller)
+    pool_post(pool, 0, n, nullptr, nullptr);
+    int st = launch(0, n, nullptr);
+    if (st == FCAMD_OK) st = finish_single_stream(m, stats);
+    else st = drain_and_return(c, st);
+    host_tangent_done(c, pool);
+    return st;
+}
+
+// Mises laws: the kernel stores 8 doubles per point into a ring of page-locked chunks (kFlagTangentParams); the pool expands chunk k
+// while the GPU works on the chunks behind it.  `launch(p0, np, params)` enqueues the kernel of one chunk on hstream[0].  All HIP
+// calls stay on the calling thread: it posts a chunk to the pool when the chunk's event has completed and reuses a slot when the
+// pool has expanded what the slot held.
+template <class Launch>
+int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangent, fcamd_stats* stats, Launch&& launch) {
+    fcamd_context* c = m->ctx;
+    constexpr int nslots = fcamd_context::kSlots;
+    // chunks: at least ~8 per call so that the expansion overlaps the kernel, at most 1 Mi points (64 MiB of parameters per slot)
+    int64_t chunk = c->opt.host_tangent_chunk > 0 ? c->opt.host_tangent_chunk : std::max<int64_t>(1 << 15, std::min<int64_t>(1 << 20, (n / 8 + 63) / 64 * 64));
+    chunk = std::max<int64_t>(64, chunk / 64 * 64);
+    chunk = std::min<int64_t>(chunk, (n + 63) / 64 * 64);
+    int st = host_tangent_ring(c, chunk, nslots);
+    if (st != FCAMD_OK) return st;
+    pool_begin(pool, host_tangent_job(m, tangent));
+    hipStream_t s = c->hstream[0];
+    const int64_t nchunks = (n + chunk - 1) / chunk;
+    std::vector<int> ticket((size_t)nchunks, -1);
+    int64_t posted = 0;  // chunks [0, posted) have completed on the GPU and are with the pool
+    const size_t slot_doubles = host_tangent_slot_doubles(chunk);
+    auto slot_host = [&](int64_t k) { return reinterpret_cast<const double*>(c->tparams) + (size_t)(k % nslots) * slot_doubles; };
+    auto slot_dev = [&](int64_t k) { return reinterpret_cast<double*>(c->tparams_dev) + (size_t)(k % nslots) * slot_doubles; };
+    auto post = [&](int64_t k) {
+        const int64_t np = std::min<int64_t>(chunk, n - k * chunk);
+        // the ballots of a launch of np points lie behind its 8 * roundup(np, 64) parameter doubles (tangent_writers.h: store_tangent_params)
+        const unsigned long long* words = reinterpret_cast<const unsigned long long*>(slot_host(k) + 8 * ((np + 63) / 64 * 64));
+        ticket[(size_t)k] = pool_post(pool, k * chunk, np, slot_host(k), words);
+    };
+    hipError_t err = hipSuccess;
+    for (int64_t k = 0; k < nchunks && st == FCAMD_OK && err == hipSuccess; ++k) {
+        // whatever has completed goes to the pool first
+        while (posted < k && hipEventQuery(c->tp_event[posted % nslots]) == hipSuccess) post(posted++);
+        (void)hipGetLastError();  // (hipErrorNotReady of the query)
+        if (k >= nslots) {  // the slot's previous chunk: completed, posted, expanded
+            while (posted <= k - nslots && err == hipSuccess) {
+                err = hipEventSynchronize(c->tp_event[posted % nslots]);
+                if (err == hipSuccess) post(posted++);
+            }
+            if (err != hipSuccess) break;
+            pool_wait(pool, ticket[(size_t)(k - nslots)]);
+        }
+        st = launch(k * chunk, std::min<int64_t>(chunk, n - k * chunk), slot_dev(k));
+        if (st == FCAMD_OK) err = hipEventRecord(c->tp_event[k % nslots], s);
+    }
+    if (st == FCAMD_OK && err == hipSuccess) {
+        if (has_sparse_history(m->law)) st = enqueue_counters_download(m, s);
+        while (posted < nchunks && err == hipSuccess) {
+            err = hipEventSynchronize(c->tp_event[posted % nslots]);
+            if (err == hipSuccess) post(posted++);
+        }
+    }
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        st = fail(FCAMD_ERR_HIP, "host tangent pipeline: %s", hipGetErrorString(err));
+    }
+    if (st != FCAMD_OK) st = drain_and_return(c, st);
+    else st = finish_chunks(m, stats, /*downloaded=*/true);
+    host_tangent_done(c, pool);
+    return st;
+}
+
+}  // namespace
+
 extern "C" {
 
 // Host (ndarray) entry.  The kernel runs directly on the caller's arrays (zero copy): on ranges registered with
@@ -540,9 +636,12 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     for (int k = 0; k < NH; ++k) hist_doubles += (size_t)m->info.hist[k].dim;
     const size_t bytes_per_point = (GD2 + SD + (tangent ? TD : 0) + hist_doubles) * sizeof(double);
 
+    // the tangent rebuilt on the CPU (fcamd_hosttangent.cpp): the caller's tangent array is then neither locked nor mapped
+    ExpandPool* pool = host_tangent_for(m, n, tangent);
+
     // every array inside the caller's registered ranges: nothing to lock, whatever the size
     bool all_registered = mapped(c, grad, N * GD2 * sizeof(double)) && mapped(c, stress, N * SD * sizeof(double)) &&
-                          (!tangent || mapped(c, tangent, N * TD * sizeof(double)));
+                          (pool || !tangent || mapped(c, tangent, N * TD * sizeof(double)));
     for (int k = 0; k < NH && all_registered; ++k)
         all_registered = mapped(c, hist[k], N * (size_t)m->info.hist[k].dim * sizeof(double)) != nullptr;
 
@@ -550,12 +649,18 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
     char *z_grad = nullptr, *z_stress = nullptr, *z_tan = nullptr, *z_hist[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
     bool locked = false;
     if (all_registered || N * bytes_per_point > (size_t)c->opt.bounce_max) {
-        locked = arrays.lock(grad, N * GD2 * sizeof(double), &z_grad) && arrays.lock(stress, N * SD * sizeof(double), &z_stress) &&
-                 arrays.lock(tangent, tangent ? N * TD * sizeof(double) : 0, &z_tan);
+        locked = arrays.lock(grad, N * GD2 * sizeof(double), &z_grad) && arrays.lock(stress, N * SD * sizeof(double), &z_stress);
         for (int k = 0; k < NH && locked; ++k)
             locked = arrays.lock(hist[k], N * (size_t)m->info.hist[k].dim * sizeof(double), &z_hist[k]);
+        if (locked && pool) {  // the zero-copy launch needs the other arrays on the 16-byte grid; else: today's paths, tangent and all
+            bool ok = aligned16(z_grad) && aligned16(z_stress);
+            for (int k = 0; k < NH; ++k) ok = ok && aligned16(z_hist[k]);
+            if (!ok) pool = nullptr;
+        }
+        if (locked && !pool) locked = arrays.lock(tangent, tangent ? N * TD * sizeof(double) : 0, &z_tan);
         if (!locked) arrays.release();
     }
+    if (!locked) pool = nullptr;
 
     if (!locked) {
         // bounce: CPU copies through the context's page-locked scratch, one launch per chunk
@@ -610,6 +715,17 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
         if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         double* zh[FCAMD_MAX_HISTORY] = {reinterpret_cast<double*>(z_hist[0]), reinterpret_cast<double*>(z_hist[1])};
         double* zs = reinterpret_cast<double*>(z_stress);
+        if (pool) {  // the kernel works on the other arrays in place; the tangent rows are the CPU's (fcamd_hosttangent.cpp)
+            constants_for_call(m, del_t);
+            auto launch = [&](int64_t p0, int64_t np, double* params) {
+                double* h[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+                for (int k = 0; k < NH; ++k) h[k] = zh[k] + (size_t)m->info.hist[k].dim * p0;
+                return enqueue(m, del_t, np, reinterpret_cast<const double*>(z_grad) + GD2 * p0, zs + SD * p0, zs + SD * p0, params, h, h, s,
+                               false, nullptr, nullptr, params ? kFlagTangentParamsHost : 0);
+            };
+            if (host_tangent_kind(m) == 1 + HostTangentJob::CONST) return run_const_tangent(m, pool, n, tangent, stats, launch);
+            return run_param_chunks(m, pool, n, tangent, stats, launch);
+        }
         st = enqueue(m, del_t, n, reinterpret_cast<const double*>(z_grad), zs, zs, reinterpret_cast<double*>(z_tan), zh, zh, s, false);
         if (st != FCAMD_OK) return drain_and_return(c, st);
         return finish_single_stream(m, stats);
@@ -717,9 +833,13 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     }
     const size_t N = (size_t)n;
     const size_t bytes_per_point = (GD2 + (stress_host ? SD : 0) + (tangent_host ? TD : 0)) * sizeof(double);
+    // the tangent rebuilt on the CPU (fcamd_hosttangent.cpp) -- not under the sparse-tangent protocol, whose untouched rows stay as
+    // they are in the caller's array, and for the 3-D laws' one-launch pass only
+    ExpandPool* pool = host_tangent_for(m, n, tangent_host);
+    if ((flags & FCAMD_EVAL_SPARSE_TANGENT) || m->dims.gdim != 3) pool = nullptr;
     const bool all_registered = mapped(c, grad, N * GD2 * sizeof(double)) &&
                                 (!stress_host || mapped(c, stress_host, N * SD * sizeof(double))) &&
-                                (!tangent_host || mapped(c, tangent_host, N * TD * sizeof(double)));
+                                (pool || !tangent_host || mapped(c, tangent_host, N * TD * sizeof(double)));
     // the host arrays of the pass: ranges the caller registered as they are, pageable ones page-locked for the
     // duration of the call, small passes through the context's page-locked scratch (CallerArrays)
     CallerArrays arrays(c);
@@ -727,10 +847,12 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     bool locked = false;
     if (all_registered || N * bytes_per_point > (size_t)c->opt.bounce_max) {
         locked = arrays.lock(grad, N * GD2 * sizeof(double), &l_grad) &&
-                 arrays.lock(stress_host, stress_host ? N * SD * sizeof(double) : 0, &l_stress) &&
-                 arrays.lock(tangent_host, tangent_host ? N * TD * sizeof(double) : 0, &l_tan);
+                 arrays.lock(stress_host, stress_host ? N * SD * sizeof(double) : 0, &l_stress);
+        if (locked && pool && !(c->opt.zero_copy_grad && aligned16(l_grad) && aligned16(l_stress))) pool = nullptr;  // no one-launch pass
+        if (locked && !pool) locked = arrays.lock(tangent_host, tangent_host ? N * TD * sizeof(double) : 0, &l_tan);
         if (!locked) arrays.release();
     }
+    if (!locked) pool = nullptr;
     if (!locked) {
         c->last_host_mode = FCAMD_HOST_BOUNCE;
         const int64_t chunk = bounce_chunk(c, n, bytes_per_point);
@@ -779,9 +901,26 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
     // store can feed two destinations): ONE launch reads the gradient from and writes stress and tangent
     // to the host arrays while it updates the device-resident state -- no chunks, no copies.
     double* z_stress = (zc && stress_host && m->dims.gdim == 3 && aligned16(l_stress)) ? reinterpret_cast<double*>(l_stress) : nullptr;
-    if (z_grad && (z_tan || !tangent_host) && (z_stress || !stress_host) && m->dims.gdim == 3) {
+    if (z_grad && (z_tan || !tangent_host || pool) && (z_stress || !stress_host) && m->dims.gdim == 3) {
         hipStream_t s = c->hstream[0];
         if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
+        if (pool) {  // state on the device, gradient and stress over the link in place, the tangent rows from the CPU
+            constants_for_call(m, del_t);
+            auto launch = [&](int64_t p0, int64_t np, double* params) {
+                const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+                double* hc[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
+                for (int k = 0; k < NH; ++k) {
+                    hp[k] = hist_prev[k] + hdim[k] * p0;
+                    hc[k] = hist[k] + hdim[k] * p0;
+                }
+                return enqueue(m, del_t, np, z_grad + GD2 * p0, stress_prev + SD * p0, stress + SD * p0, params, hp, hc, s, false, nullptr,
+                               history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
+                               flags | (params ? kFlagTangentParamsHost : 0), z_stress ? z_stress + SD * p0 : nullptr, nullptr,
+                               emask_prev ? emask_prev + p0 / 64 : nullptr, emask ? emask + p0 / 64 : nullptr);
+            };
+            if (host_tangent_kind(m) == 1 + HostTangentJob::CONST) return run_const_tangent(m, pool, n, tangent_host, stats, launch);
+            return run_param_chunks(m, pool, n, tangent_host, stats, launch);
+        }
         st = enqueue(m, del_t, n, z_grad, stress_prev, stress, z_tan, hist_prev, hist, s, false, nullptr,
                      reinterpret_cast<unsigned long long*>(history_mask), flags, z_stress, nullptr, emask_prev, emask);
         if (st != FCAMD_OK) return drain_and_return(c, st);

@@ -48,7 +48,9 @@ namespace fcamd {
 // ---------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------
-template <int LAW, bool IDX, bool FULL, bool NT, int SPARSE = 0>
+// PM: the tangent leaves as 8 parameters per point (kFlagTangentParams: the host rebuilds the rows, fcamd_hosttangent.cpp) -- 0 never,
+// 1 always (the kernels instantiated for it), 2 decided by the flag at run time (the ragged last tile)
+template <int LAW, bool IDX, bool FULL, bool NT, int SPARSE = 0, int PM = 0>
 __device__ __forceinline__ void run_tile(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                          int* rows_lds, long long p0, int npts, int lane, int r0,
                                          WaveStats& st) {
@@ -68,19 +70,19 @@ __device__ __forceinline__ void run_tile(ArgsRef a, const StressBases& sb, const
     else if constexpr (LAW == LAW_KELVIN)
         tile_sls<true, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_VM3D)
-        tile_von_mises<IDX, SPARSE, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, st);
+        tile_von_mises<IDX, SPARSE, FULL, NT, PM>(a, sb, T, region, rows_lds, p0, npts, lane, st);
     else if constexpr (LAW == LAW_COMFE_DP)
         tile_comfe_dp<false, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0, st);
     else if constexpr (LAW == LAW_COMFE_DP_HYPER)
         tile_comfe_dp<true, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0, st);
     else
-        tile_comfe_mises<IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, st);
+        tile_comfe_mises<IDX, FULL, NT, PM>(a, sb, T, region, rows_lds, p0, npts, lane, st);
 }
 
 // One full tile of the main kernel.  Indexed kernel: when the 64 parent rows of the tile are
 // consecutive (cells of a material are mostly numbered in runs) the coalesced tile body runs on
 // shifted base pointers; only tiles with scattered rows pay the per-lane row accesses.
-template <int LAW, bool IDX, bool NT, int SPARSE>
+template <int LAW, bool IDX, bool NT, int SPARSE, bool PARAMS = false>
 __device__ __forceinline__ void run_full_tile(ArgsRef a, const Tables* T, double* region,
                                               int* rows_lds, long long p0, int lane, int r0, WaveStats& st) {
     const StressBases sb{a.stress_in, a.stress_out, a.tangent, a.stress_out2};
@@ -96,7 +98,7 @@ __device__ __forceinline__ void run_full_tile(ArgsRef a, const Tables* T, double
             return;
         }
     }
-    run_tile<LAW, IDX, true, NT, SPARSE>(a, sb, T, region, rows_lds, p0, kWave, lane, r0, st);
+    run_tile<LAW, IDX, true, NT, SPARSE, PARAMS ? 1 : 0>(a, sb, T, region, rows_lds, p0, kWave, lane, r0, st);
 }
 
 __device__ __forceinline__ void stage_tables(ArgsRef a, Tables* T) {
@@ -136,7 +138,7 @@ template <int LAW, bool IDX>
 constexpr int kMinBlocks = LAW >= LAW_COMFE_DP ? 3 : 4;
 
 // the work of workgroup `block` of `nblocks` (tables staged): shared by the law's own kernel and the batch kernel
-template <int LAW, bool NT, bool IDX, int SPARSE>
+template <int LAW, bool NT, bool IDX, int SPARSE, bool PARAMS = false>
 __device__ __forceinline__ void evaluate_blocks(ArgsRef a, const Tables* T, double (*scratch)[kRegionDoubles], int (*rows_all)[kWave],
                                                 int block, int nblocks) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -150,7 +152,7 @@ __device__ __forceinline__ void evaluate_blocks(ArgsRef a, const Tables* T, doub
     WaveStats st;
     const long long wstride = (long long)nblocks * kWavesPerBlock;
     for (long long tile = (long long)block * kWavesPerBlock + wave; tile < nfull; tile += wstride)
-        run_full_tile<LAW, IDX, NT, SPARSE>(a, T, region, rows_lds, tile * kWave, lane, r0, st);
+        run_full_tile<LAW, IDX, NT, SPARSE, PARAMS>(a, T, region, rows_lds, tile * kWave, lane, r0, st);
     flush_stats<LAW>(a, st, lane, block);
 }
 
@@ -160,18 +162,18 @@ __device__ __forceinline__ void evaluate_tail_tile(ArgsRef a, const Tables* T, d
     const long long p0 = (a.n / kWave) * kWave;
     WaveStats st;
     const StressBases sb{a.stress_in, a.stress_out, a.tangent, a.stress_out2};
-    run_tile<LAW, IDX, false, false, SPARSE>(a, sb, T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
+    run_tile<LAW, IDX, false, false, SPARSE, 2>(a, sb, T, region, rows_lds, p0, (int)(a.n - p0), lane, lane % 18, st);
     flush_stats<LAW>(a, st, lane, 0);
 }
 
-template <int LAW, bool NT, bool IDX, int SPARSE = 0>
+template <int LAW, bool NT, bool IDX, int SPARSE = 0, bool PARAMS = false>
 __global__ void __launch_bounds__(kBlock, (kMinBlocks<LAW, IDX>)) evaluate_kernel(const EvalArgs) {
     ArgsRef a = kernel_args();
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     __shared__ int rows_all[IDX ? kWavesPerBlock : 1][kWave];
     stage_tables(a, &T);
-    evaluate_blocks<LAW, NT, IDX, SPARSE>(a, &T, scratch, rows_all, (int)blockIdx.x, (int)gridDim.x);
+    evaluate_blocks<LAW, NT, IDX, SPARSE, PARAMS>(a, &T, scratch, rows_all, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Low-dimensional constraints: same persistent structure, DIMS = 1 or 2.
@@ -339,8 +341,27 @@ __global__ void __launch_bounds__(kBlock) batch_zero_counters_kernel(const Batch
 // ---------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------
+// the variants whose full tiles store the tangent's 8 parameters per point (kFlagTangentParams; contiguous rows only)
+template <int LAW, int SPARSE>
+static hipError_t launch_params(const EvalArgs& args, int grid, hipStream_t stream) {
+    if (args.n >= kWave)
+        hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, SPARSE, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+    if (args.n % kWave != 0)
+        hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false, SPARSE>), dim3(1), dim3(kWave), 0, stream, args);
+    return hipGetLastError();
+}
+
 template <int LAW>
 static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream) {
+    if constexpr (LAW == LAW_VM3D || LAW == LAW_COMFE_MISES) {
+        if ((args.flags & kFlagTangentParams) != 0) {
+            if (args.rows) return hipErrorInvalidValue;
+            if constexpr (LAW == LAW_VM3D) {
+                if (args.hmask) return (args.flags & kFlagPackedHistory) ? launch_params<LAW, 2>(args, grid, stream) : launch_params<LAW, 1>(args, grid, stream);
+            }
+            return launch_params<LAW, 0>(args, grid, stream);
+        }
+    }
     if constexpr (LAW == LAW_VM3D) {
         if (args.hmask && args.rows && (args.flags & kFlagPackedHistory)) {  // ... on the packed plastic-strain layout (local to the law)
             if (args.n >= kWave)

@@ -281,7 +281,8 @@ int fcamd_multi_evaluate_host(fcamd_multi* mg, double t, double del_t, int64_t n
             };
             want(grad, N * GD2 * sizeof(double));
             want(stress, N * SD * sizeof(double));
-            want(tangent, N * TD * sizeof(double));
+            // (a tangent the CPU rebuilds is neither locked nor mapped: fcamd_hosttangent.cpp)
+            if (!host_tangent_applies(mg->w[0]->model, (int64_t)(N / (size_t)used), 0)) want(tangent, N * TD * sizeof(double));
             for (int k = 0; k < NH; ++k) want(hist[k], N * (size_t)mg->info.hist[k].dim * sizeof(double));
         }
     }
@@ -621,7 +622,7 @@ int fcamd_multi_state_evaluate(fcamd_multi_state* st, double t, double del_t, co
             };
             want(grad, N * GD2 * sizeof(double));
             want(stress_host, N * SD * sizeof(double));
-            want(tangent_host, N * TD * sizeof(double));
+            if (!host_tangent_applies(mg->w[0]->model, (int64_t)(N / (size_t)world), flags)) want(tangent_host, N * TD * sizeof(double));
         }
     }
     const int c = st->committed;

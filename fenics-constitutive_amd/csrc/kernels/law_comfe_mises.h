@@ -71,7 +71,7 @@ __device__ __forceinline__ bool cm_point(ScalarsRef sc, bool live, const double 
 // scalars: s[0]=strain factor (FRAC_1_SQRT_2), s[1]=mu, s[2]=kappa, s[3]=y_0, s[4]=h,
 //          s[5]=2*mu, s[6]=3*mu+h, s[7]=sqrt(3/2), s[8]=3*mu, s[9]=1/(1+h/(3 mu))
 // tables:  a = kappa*sym_id(x)sym_id, b = P_dev.   history field 0: [alpha, eps_p(6)] per point.
-template <bool IDX, bool FULL, bool NT>
+template <bool IDX, bool FULL, bool NT, int PM = 0>
 __device__ __forceinline__ void tile_comfe_mises(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                                  int* rows_lds, long long p0, int npts, int lane,
                                                  WaveStats& st) {
@@ -128,7 +128,10 @@ __device__ __forceinline__ void tile_comfe_mises(ArgsRef a, const StressBases& s
     if (sb.tan && tneed != 0ull) {
         publish_tangent_params(region, lane, B, sc2, nv);
         wave_sync();
-        tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
+        if (tangent_params_mode<PM>(a))  // the host rebuilds the rows (fcamd_hosttangent.cpp)
+            store_tangent_params<FULL, NT>(a, region, sb.tan, p0, npts, lane, mask);
+        else
+            tangent_mises<true, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
         wave_sync();
     }
 }

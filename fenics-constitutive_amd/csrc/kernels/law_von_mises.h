@@ -96,7 +96,8 @@ __device__ __forceinline__ void vm_tangent_coefficients(ScalarsRef sc, const VMR
 // tables:  a = ka*xioi, b = xpp
 // HIST: 0 = the caller's arrays as they are (in place or out of place), 1 = sparse trial history (a.hmask),
 //       2 = sparse protocol on the packed plastic-strain layout (history_rows.h: PackedRows)
-template <bool IDX, int HIST, bool FULL, bool NT>
+// PM: the tangent leaves as its 8 parameters per point (0 never, 1 always, 2 by kFlagTangentParams at run time; fcamd_kernels.hip: run_tile)
+template <bool IDX, int HIST, bool FULL, bool NT, int PM = 0>
 __device__ __forceinline__ void tile_von_mises(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                                int* rows_lds, long long p0, int npts, int lane,
                                                WaveStats& st) {
@@ -254,7 +255,10 @@ __device__ __forceinline__ void tile_von_mises(ArgsRef a, const StressBases& sb,
         vm_tangent_coefficients(a.sc, rm, B, C);
         publish_tangent_params(region, lane, B, C, rm.N);
         wave_sync();
-        tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
+        if (tangent_params_mode<PM>(a))  // the host rebuilds the rows (fcamd_hosttangent.cpp)
+            store_tangent_params<FULL, NT>(a, region, sb.tan, p0, npts, lane, mask);
+        else
+            tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
         wave_sync();
     }
 }

@@ -84,6 +84,12 @@ constexpr int kFlagPackedHistory = 8;
 // moves the needed rows alone, not whole 64-byte granules -- over the link every byte counts and there is no partial-unit penalty
 // to avoid (host assembler, resident state + sparse tangent, 1e7 points: 503 Mpts/s with bare rows, 488 with granules)
 constexpr int kFlagExactTangentRows = 16;
+// (library-internal, set by the host entries that rebuild the tangent on the CPU, fcamd_hosttangent.cpp:) EvalArgs::tangent is an array
+// of 8 doubles per point followed by one 64-bit word per tile, and the Mises laws store what they publish -- B, C, N[6] -- for the
+// PLASTIC points of the tile and the tile's plastic ballot, instead of the 36 entries built from it: 64 bytes per plastic point and 8
+// per tile cross PCIe instead of 288 per point; the host expands them with tangent_mises_chunk's own expression and gives every
+// elastic point the row that expression yields for an elastic point's parameters (one constant per law).
+constexpr int kFlagTangentParams = 32;
 template <bool FULL>
 __device__ __forceinline__ unsigned long long sparse_tangent_need(ArgsRef a, unsigned long long need) {
     return (FULL && (a.flags & kFlagSparseTangent) != 0 && a.hmask != nullptr) ? need : ~0ull;
@@ -195,6 +201,28 @@ __device__ __forceinline__ void tangent_mises(const double* tp, const double* ta
         // bound the register pressure: let the scheduler interleave at most 3 chunks
         if (k % kTangentGroup == kTangentGroup - 1) __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <int PM>
+__device__ __forceinline__ bool tangent_params_mode(ArgsRef a) {
+    if constexpr (PM == 0) return false;
+    if constexpr (PM == 1) return true;
+    return (a.flags & kFlagTangentParams) != 0;
+}
+
+// kFlagTangentParams: the published parameters (LDS, stride 10) of the tile's plastic points leave as 8 doubles = one aligned 64-byte
+// unit per point (four neighbouring lanes), and the plastic ballot as the tile's word behind the parameters of the launch's n points
+template <bool FULL, bool NT>
+__device__ __forceinline__ void store_tangent_params(ArgsRef a, const double* tp, double* params, long long p0, int npts, int lane,
+                                                     unsigned long long plastic) {
+    double* tile = params + p0 * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = k * kWave + lane;
+        const d2 v = *reinterpret_cast<const d2*>(tp + 10 * (q >> 2) + 2 * (q & 3));
+        if ((FULL || q < 4 * npts) && ((plastic >> (q >> 2)) & 1ull) != 0ull) store16<NT>(tile + 2 * q, v);
+    }
+    if (lane == 0) reinterpret_cast<unsigned long long*>(params + 8 * ((a.n + 63) & ~63ll))[p0 >> 6] = plastic;
 }
 
 __device__ __forceinline__ void publish_tangent_params(double* region, int lane, double B, double C,

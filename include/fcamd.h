@@ -367,6 +367,7 @@ FCAMD_API int fcamd_unregister_host_buffer(fcamd_context* ctx, void* ptr);
 #define FCAMD_HOST_ZERO_COPY_OUT 2 /* results written by the kernel into the caller's host arrays */
 #define FCAMD_HOST_TEMP_LOCK 4     /* pageable caller arrays were page-locked for the duration of the call */
 #define FCAMD_HOST_BOUNCE 8        /* pageable caller arrays were moved by the CPU through the context's page-locked scratch */
+#define FCAMD_HOST_TANGENT_CPU 16  /* the tangent rows were written by the CPU ("host_tangent_threads", below), not sent over the link */
 /* Address at which fcamd_evaluate_device_ex can read / write the host range
    [host_ptr, host_ptr + bytes): it must lie inside one range registered with
    fcamd_register_host_buffer and be 16-byte aligned (FCAMD_ERR_BAD_ARG otherwise).  With it a device
@@ -541,6 +542,18 @@ FCAMD_API int fcamd_device_free(fcamd_context* ctx, void* ptr);
      "host_chunk" (FCAMD_HOST_CHUNK, 0 = automatic), "host_slots" (FCAMD_HOST_SLOTS, 4),
      "bounce_max" (FCAMD_BOUNCE_MAX, 256 KiB: host calls up to this size go through the page-locked scratch),
      "zero_copy" (FCAMD_ZERO_COPY, 1), "zero_copy_grad" (FCAMD_ZERO_COPY_GRAD, 1);
+   "host_tangent_threads" (FCAMD_HOST_TANGENT_THREADS, -1): the host entries do not send the tangent -- 288 of the 336-392 bytes per
+       point that come down the link -- when the host can rebuild it, as the reference does (np.tile(D.flatten(), n),
+       linear_elasticity_model.py:45; C = ka xioi + B xpp + C N (x) N, mises_plasticity_isotropic_hardening.py:170-175): for the laws
+       with a constant tangent the kernel writes none and this many threads fill the caller's array from the law's table; for
+       VonMises3D and the comfe-rs Mises law the kernel sends the 8 doubles per point its own tangent writer starts from and the
+       threads expand them chunk by chunk behind the kernel, with the kernel's expression in the kernel's operation order: the
+       array holds bit for bit what the kernel would have written.  0: the kernel writes the tangent over PCIe (ABI 0.4's path);
+       -1: automatic = the CPUs the process may run on less one, at most 16; reading the option returns the resolved count.
+       "host_tangent_min_points" (FCAMD_HOST_TANGENT_MIN, 65536): smaller calls keep the kernel's tangent stores;
+       "host_tangent_chunk" (FCAMD_HOST_TANGENT_CHUNK, 0 = automatic): points per chunk of the parameter ring;
+       "last_host_tangent_cpu_us" / "last_host_tangent_threads" (get only): summed busy time and number of the expansion threads in
+       the context's last host entry (0: the kernel wrote the tangent).  The Drucker-Prager laws keep the kernel's stores.
    "grid": the launch grid (number of 256-thread workgroups; 0 = automatic);
    "timing": 1 = every fcamd_evaluate_device_ex is bracketed by HIP events on the context's stream and every host entry
        by a wall clock; fcamd_model_last_stats reports the time (fcamd_stats.kernel_ms) -- the counterpart of the
