@@ -19,8 +19,13 @@ def host_path_figures(devices=None, sizes=(1_000_000, 10_000_000), latency_sizes
                       seed=99):
     """PCIe-inclusive figures of the HOST entries -- the call the reference times with Timer("constitutive-law-evaluation")
     (solver/_lawonsubmesh.py:86-94: evaluate on views of Function.x.array) -- VonMises3D, mixed elastic / plastic NumPy arrays:
-      evaluate            the reference contract: law.evaluate(ndarrays) in place (fcamd_evaluate_host), 176 B/pt up, <= 392 down;
-      resident            ResidentState.evaluate_into (fcamd_evaluate_resident): state on the device, 72 B/pt up, 336 down;
+      evaluate            the reference contract: law.evaluate(ndarrays) in place (fcamd_evaluate_host).  The tangent rows are rebuilt on
+                          the host by `tangent_threads` threads (context option "host_tangent_threads", csrc/fcamd_hosttangent.cpp):
+                          128 B/pt + 48 per plastic point up, 56 + 120 per plastic point down instead of <= 392;
+      evaluate_pcie_tangent  the same call with "host_tangent_threads" = 0 (the kernel writes the tangent over the link: rounds 2-5);
+      evaluate_le         LinearElasticityModel.evaluate(ndarrays) in place: 120 B/pt up, 48 down, the tangent filled by the threads;
+      resident            ResidentState.evaluate_into (fcamd_evaluate_resident): state on the device, 72 B/pt up, 48 + 64 per plastic
+                          point down, the tangent rows from the host threads (336 down with "host_tangent_threads" = 0);
       resident_sparse     the same with the sparse tangent (the product default): only the tangent rows of plastic / formerly
                           plastic points cross PCIe from the second call on;
     each with pageable arrays (page-locked by the library for the duration of the call) and with arrays registered once.
@@ -36,6 +41,8 @@ def host_path_figures(devices=None, sizes=(1_000_000, 10_000_000), latency_sizes
     n_max = max(sizes)
     rng = np.random.default_rng(seed)
     law = fc.VonMises3D(VM_P)
+    law_le = fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, fc.StressStrainConstraint.FULL)
+    registered_now = [False]
     if multi:
         law.use_devices(devices)
     g = rng.standard_normal(9 * n_max)
@@ -45,7 +52,11 @@ def host_path_figures(devices=None, sizes=(1_000_000, 10_000_000), latency_sizes
     s, t = np.zeros(6 * n_max), np.zeros(36 * n_max)
     e, a = np.zeros(6 * n_max), a0.copy()
     out = {"law": "VonMises3D, grad scale log-uniform in [1e-4, 1e-2], alpha ~ U(0, 0.02)", "devices": devices or [_capi.default_device()],
-           "bytes_per_point": {"evaluate_up": 176, "evaluate_down_max": 392, "resident_up": 72, "resident_down": 336}, "sizes": {}}
+           "bytes_per_point": {"evaluate_up": "128 + 48 per plastic point", "evaluate_down": "56 + 120 per plastic point (+ 8 per 64 points)",
+                               "evaluate_down_pcie_tangent_max": 392, "resident_up": 72, "resident_down": "48 + 64 per plastic point",
+                               "resident_down_pcie_tangent": 336}, "sizes": {}}
+    if not multi:
+        out["host_tangent_threads"] = law._handle(_capi.default_device()).ctx.get_option("host_tangent_threads")
 
     def make_state(n):
         if multi:
@@ -78,9 +89,24 @@ def host_path_figures(devices=None, sizes=(1_000_000, 10_000_000), latency_sizes
             al[:] = a0[:n]
 
         row = {}
-        legs = (("evaluate", lambda: law.evaluate(0.0, 1.0, gs, ss, ts, {"eps_n": es, "alpha": al}), reset, 568),
+        ctx = None if multi else law._handle(_capi.default_device()).ctx
+
+        def kernel_tangent():
+            ctx.set_option("host_tangent_threads", 0)
+            try:
+                law.evaluate(0.0, 1.0, gs, ss, ts, {"eps_n": es, "alpha": al})
+            finally:
+                ctx.set_option("host_tangent_threads", -1)
+
+        def reset_le():
+            ss[:] = 0.0
+
+        legs = [("evaluate", lambda: law.evaluate(0.0, 1.0, gs, ss, ts, {"eps_n": es, "alpha": al}), reset, 568),
                 ("resident", lambda: full.evaluate_into(0.0, 1.0, gs, ss, ts), None, 408),
-                ("resident_sparse", lambda: sparse.evaluate_into(0.0, 1.0, gs, ss, ts), None, 408))
+                ("resident_sparse", lambda: sparse.evaluate_into(0.0, 1.0, gs, ss, ts), None, 408)]
+        if ctx is not None and not lat and registered_now[0]:
+            legs += [("evaluate_pcie_tangent", kernel_tangent, reset, 568),
+                     ("evaluate_le", lambda: law_le.evaluate(0.0, 1.0, gs, ss, ts, None), reset_le, 456)]
         for name, fn, rs_, bpp in legs:
             fn()  # warm: first touch, first page lock, (sparse) the full tangent
             dt = best_of(fn, k, rs_)
@@ -88,6 +114,9 @@ def host_path_figures(devices=None, sizes=(1_000_000, 10_000_000), latency_sizes
                 row[name + "_us"] = round(dt * 1e6, 1)
             else:
                 row[name] = {"ms": round(dt * 1e3, 3), "Mpts_s": round(n / dt / 1e6, 1), "interface_GBs": round(n * bpp / dt / 1e9, 2)}
+                if ctx is not None:  # who wrote the tangent rows of the leg's last call, and what it cost the host
+                    row[name]["tangent_threads"] = ctx.get_option("last_host_tangent_threads")
+                    row[name]["tangent_cpu_ms"] = round(ctx.get_option("last_host_tangent_cpu_us") / 1e3, 2)
         if not lat:
             row["plastic_fraction"] = round(law.last_stats.n_plastic / n, 4)
         for st in (full, sparse):
@@ -105,6 +134,7 @@ def host_path_figures(devices=None, sizes=(1_000_000, 10_000_000), latency_sizes
                     pin_target = law._handle(_capi.default_device()).ctx
                 for x in (g, s, t, e, a):
                     pin_target.register_host_buffer(x)
+            registered_now[0] = registered
             key = "registered" if registered else "pageable"
             for n in sizes:
                 if time.perf_counter() - t_begin > budget_s and n != min(sizes):
@@ -128,8 +158,13 @@ def host_path_figures(devices=None, sizes=(1_000_000, 10_000_000), latency_sizes
                                   "note": "fcamd_copy_to_device / _to_host of 36 doubles x %d points between the registered tangent array and one device" % m}
         big = out["sizes"].get(str(n_max), {}).get("registered")
         if isinstance(big, dict):
-            down = n_max * 392 / (big["evaluate"]["ms"] * 1e-3) / 1e9
-            out["evaluate_d2h_over_pinned_copy"] = round(down / (out["pinned_copy_GBs"]["d2h"] * (len(devices) if multi else 1)), 3)
+            ndev = len(devices) if multi else 1
+            ref = big.get("evaluate_pcie_tangent") or (big["evaluate"] if big["evaluate"].get("tangent_threads", 0) == 0 else None)
+            if ref:  # the kernel's tangent over the link: the downlink is the bound
+                out["evaluate_d2h_over_pinned_copy"] = round(n_max * 392 / (ref["ms"] * 1e-3) / 1e9 / (out["pinned_copy_GBs"]["d2h"] * ndev), 3)
+            if big["evaluate"].get("tangent_threads", 0) > 0:  # the tangent from the host threads: the uplink is (what the kernel reads over it)
+                up = n_max * (128 + 48 * big.get("plastic_fraction", 0.0)) / (big["evaluate"]["ms"] * 1e-3) / 1e9
+                out["evaluate_h2d_over_pinned_copy"] = round(up / (out["pinned_copy_GBs"]["h2d"] * ndev), 3)
     finally:
         if pin_target is not None:
             for x in (g, s, t, e, a):

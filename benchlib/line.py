@@ -30,8 +30,11 @@ def _host_rates(hp):
         sizes = hp["sizes"]
         big = sizes[max(sizes, key=int)]
         rows = big.get("registered") or big.get("pageable")
-        out = {leg: rows[leg]["Mpts_s"] for leg in ("evaluate", "resident", "resident_sparse") if leg in rows}
+        out = {leg: rows[leg]["Mpts_s"] for leg in ("evaluate", "evaluate_pcie_tangent", "evaluate_le", "resident", "resident_sparse") if leg in rows}
         out["points"] = int(max(sizes, key=int))
+        if "tangent_threads" in rows.get("evaluate", {}):  # the tangent rows of `evaluate` come from this many host threads, at this summed CPU time
+            out["tangent_threads"] = rows["evaluate"]["tangent_threads"]
+            out["tangent_cpu_ms"] = rows["evaluate"]["tangent_cpu_ms"]
         return out
     except Exception:
         return {"error": _short(hp.get("error", "no figures"), 80)} if isinstance(hp, dict) else None

@@ -294,6 +294,7 @@ void options_from_env(Options* o) {
     o->host_tangent_threads = (int)geti("FCAMD_HOST_TANGENT_THREADS", -1);
     o->host_tangent_min_points = std::max<long long>(0, geti("FCAMD_HOST_TANGENT_MIN", 1 << 16));
     o->host_tangent_chunk = std::max<long long>(0, geti("FCAMD_HOST_TANGENT_CHUNK", 0));
+    o->host_tangent_streams = (int)std::max<long long>(1, std::min<long long>(fcamd_context::kSlots, geti("FCAMD_HOST_TANGENT_STREAMS", 1)));
 }
 
 // the law's host constants, recomputed only when del_t changes (SLS) -- not once per launch
@@ -559,6 +560,7 @@ int fcamd_context_set_option(fcamd_context* c, const char* name, long long value
     else if (k == "host_tangent_threads") o.host_tangent_threads = (int)std::max<long long>(-1, std::min<long long>(value, 256));
     else if (k == "host_tangent_min_points") o.host_tangent_min_points = std::max<long long>(0, value);
     else if (k == "host_tangent_chunk") o.host_tangent_chunk = std::max<long long>(0, (value / 64) * 64);
+    else if (k == "host_tangent_streams") o.host_tangent_streams = (int)std::max<long long>(1, std::min<long long>(fcamd_context::kSlots, value));
     else if (k == "grid") c->grid_override = value > 0 ? (int)value : 0;
     else if (k == "timing") c->timing = value != 0;
     else if (k == "trim") return context_trim(c);
@@ -581,6 +583,7 @@ int fcamd_context_get_option(fcamd_context* c, const char* name, long long* valu
     else if (k == "host_tangent_threads") *value = fcamd::host_tangent_threads(c);  // resolved (-1 -> the automatic count)
     else if (k == "host_tangent_min_points") *value = o.host_tangent_min_points;
     else if (k == "host_tangent_chunk") *value = o.host_tangent_chunk;
+    else if (k == "host_tangent_streams") *value = o.host_tangent_streams;
     else if (k == "last_host_tangent_cpu_us") *value = c->last_host_tangent_cpu_us;
     else if (k == "last_host_tangent_threads") *value = c->last_host_tangent_threads;
     else if (k == "grid") *value = c->grid_override;

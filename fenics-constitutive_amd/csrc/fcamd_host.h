@@ -59,6 +59,7 @@ struct Options {
     int host_tangent_threads = -1;            // FCAMD_HOST_TANGENT_THREADS  threads of the expansion; 0: the kernel writes the tangent over PCIe; -1: automatic
     long long host_tangent_min_points = 1 << 16;  // FCAMD_HOST_TANGENT_MIN  calls with fewer points keep the kernel's own tangent stores
     long long host_tangent_chunk = 0;         // FCAMD_HOST_TANGENT_CHUNK  points per chunk of the parameter ring (Mises laws); 0: automatic
+    int host_tangent_streams = 1;             // FCAMD_HOST_TANGENT_STREAMS  streams the chunks of the parameter ring alternate between (1..4)
 };
 
 // One expansion job of the host tangent (fcamd_hosttangent.cpp): what to write into which array

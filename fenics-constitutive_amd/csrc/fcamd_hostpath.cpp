@@ -533,7 +533,7 @@ int run_const_tangent(fcamd_model* m, ExpandPool* pool, int64_t n, double* tange
     fcamd_context* c = m->ctx;
     pool_begin(pool, host_tangent_job(m, tangent));  // (the tables of m were brought up to date for this del_t by the caller)
     pool_post(pool, 0, n, nullptr, nullptr);
-    int st = launch(0, n, nullptr);
+    int st = launch(0, n, nullptr, c->hstream[0]);
     if (st == FCAMD_OK) st = finish_single_stream(m, stats);
     else st = drain_and_return(c, st);
     host_tangent_done(c, pool);
@@ -555,7 +555,12 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
     int st = host_tangent_ring(c, chunk, nslots);
     if (st != FCAMD_OK) return st;
     pool_begin(pool, host_tangent_job(m, tangent));
-    hipStream_t s = c->hstream[0];
+    // the chunks alternate between streams: the next chunk's first waves start while the previous chunk's last ones drain (over the
+    // link a chunk boundary on ONE stream is a bubble of a few hundred microseconds; the chunks are independent, the counters atomic)
+    const int nstreams = std::max(1, std::min(c->opt.host_tangent_streams, fcamd_context::kSlots));
+    for (int i = 1; i < nstreams; ++i)
+        if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
+    if (nstreams > 1) HIP_TRY(hipStreamSynchronize(c->hstream[0]));  // the counters' reset (queued by the caller) before any chunk counts
     const int64_t nchunks = (n + chunk - 1) / chunk;
     std::vector<int> ticket((size_t)nchunks, -1);
     int64_t posted = 0;  // chunks [0, posted) have completed on the GPU and are with the pool
@@ -581,15 +586,16 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
             if (err != hipSuccess) break;
             pool_wait(pool, ticket[(size_t)(k - nslots)]);
         }
-        st = launch(k * chunk, std::min<int64_t>(chunk, n - k * chunk), slot_dev(k));
+        hipStream_t s = c->hstream[k % nstreams];
+        st = launch(k * chunk, std::min<int64_t>(chunk, n - k * chunk), slot_dev(k), s);
         if (st == FCAMD_OK) err = hipEventRecord(c->tp_event[k % nslots], s);
     }
     if (st == FCAMD_OK && err == hipSuccess) {
-        if (has_sparse_history(m->law)) st = enqueue_counters_download(m, s);
         while (posted < nchunks && err == hipSuccess) {
             err = hipEventSynchronize(c->tp_event[posted % nslots]);
             if (err == hipSuccess) post(posted++);
         }
+        if (err == hipSuccess && has_sparse_history(m->law)) st = enqueue_counters_download(m, c->hstream[0]);  // every chunk has completed
     }
     if (err != hipSuccess) {
         (void)hipGetLastError();
@@ -717,10 +723,10 @@ int fcamd_evaluate_host(fcamd_model* m, double t, double del_t, int64_t n, const
         double* zs = reinterpret_cast<double*>(z_stress);
         if (pool) {  // the kernel works on the other arrays in place; the tangent rows are the CPU's (fcamd_hosttangent.cpp)
             constants_for_call(m, del_t);
-            auto launch = [&](int64_t p0, int64_t np, double* params) {
+            auto launch = [&](int64_t p0, int64_t np, double* params, hipStream_t on) {
                 double* h[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
                 for (int k = 0; k < NH; ++k) h[k] = zh[k] + (size_t)m->info.hist[k].dim * p0;
-                return enqueue(m, del_t, np, reinterpret_cast<const double*>(z_grad) + GD2 * p0, zs + SD * p0, zs + SD * p0, params, h, h, s,
+                return enqueue(m, del_t, np, reinterpret_cast<const double*>(z_grad) + GD2 * p0, zs + SD * p0, zs + SD * p0, params, h, h, on,
                                false, nullptr, nullptr, params ? kFlagTangentParamsHost : 0);
             };
             if (host_tangent_kind(m) == 1 + HostTangentJob::CONST) return run_const_tangent(m, pool, n, tangent, stats, launch);
@@ -906,14 +912,14 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         if (pool) {  // state on the device, gradient and stress over the link in place, the tangent rows from the CPU
             constants_for_call(m, del_t);
-            auto launch = [&](int64_t p0, int64_t np, double* params) {
+            auto launch = [&](int64_t p0, int64_t np, double* params, hipStream_t on) {
                 const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
                 double* hc[FCAMD_MAX_HISTORY] = {nullptr, nullptr};
                 for (int k = 0; k < NH; ++k) {
                     hp[k] = hist_prev[k] + hdim[k] * p0;
                     hc[k] = hist[k] + hdim[k] * p0;
                 }
-                return enqueue(m, del_t, np, z_grad + GD2 * p0, stress_prev + SD * p0, stress + SD * p0, params, hp, hc, s, false, nullptr,
+                return enqueue(m, del_t, np, z_grad + GD2 * p0, stress_prev + SD * p0, stress + SD * p0, params, hp, hc, on, false, nullptr,
                                history_mask ? reinterpret_cast<unsigned long long*>(history_mask) + p0 / 64 : nullptr,
                                flags | (params ? kFlagTangentParamsHost : 0), z_stress ? z_stress + SD * p0 : nullptr, nullptr,
                                emask_prev ? emask_prev + p0 / 64 : nullptr, emask ? emask + p0 / 64 : nullptr);

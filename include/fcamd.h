@@ -546,12 +546,14 @@ FCAMD_API int fcamd_device_free(fcamd_context* ctx, void* ptr);
        point that come down the link -- when the host can rebuild it, as the reference does (np.tile(D.flatten(), n),
        linear_elasticity_model.py:45; C = ka xioi + B xpp + C N (x) N, mises_plasticity_isotropic_hardening.py:170-175): for the laws
        with a constant tangent the kernel writes none and this many threads fill the caller's array from the law's table; for
-       VonMises3D and the comfe-rs Mises law the kernel sends the 8 doubles per point its own tangent writer starts from and the
-       threads expand them chunk by chunk behind the kernel, with the kernel's expression in the kernel's operation order: the
+       VonMises3D and the comfe-rs Mises law the kernel sends, for the plastic points, the 8 doubles per point its own tangent writer
+       starts from, and every tile's plastic ballot; the threads expand them chunk by chunk behind the kernel, with the kernel's expression in the kernel's operation order: the
        array holds bit for bit what the kernel would have written.  0: the kernel writes the tangent over PCIe (ABI 0.4's path);
        -1: automatic = the CPUs the process may run on less one, at most 16; reading the option returns the resolved count.
        "host_tangent_min_points" (FCAMD_HOST_TANGENT_MIN, 65536): smaller calls keep the kernel's tangent stores;
-       "host_tangent_chunk" (FCAMD_HOST_TANGENT_CHUNK, 0 = automatic): points per chunk of the parameter ring;
+       "host_tangent_chunk" (FCAMD_HOST_TANGENT_CHUNK, 0 = automatic: n / 8, 32 Ki .. 1 Mi points): points per chunk of the parameter ring;
+       "host_tangent_streams" (FCAMD_HOST_TANGENT_STREAMS, 1): streams the chunk launches alternate between (2 helps chunks of
+       256 Ki points and less, 1 is best at the automatic size);
        "last_host_tangent_cpu_us" / "last_host_tangent_threads" (get only): summed busy time and number of the expansion threads in
        the context's last host entry (0: the kernel wrote the tangent).  The Drucker-Prager laws keep the kernel's stores.
    "grid": the launch grid (number of 256-thread workgroups; 0 = automatic);

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--threads", default="0,4,8,16")
     ap.add_argument("--chunks", default="0")
+    ap.add_argument("--streams", default="2", help="host_tangent_streams values to sweep")
+    ap.add_argument("--skip-pageable", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--laws", default="von_mises,linear_elasticity,maxwell")
     ap.add_argument("--out", default=None)
@@ -75,16 +77,17 @@ def main():
                 for k, v in h.items():
                     v[:] = a0 if k == "alpha" else 0.0
 
-        for registered in (False, True):
+        for registered in ((True,) if args.skip_pageable else (False, True)):
             arrays = [g, s, t] + ([] if h is None else list(h.values()))
             if registered:
                 for x in arrays:
                     ctx.register_host_buffer(x)
             try:
-                for th in [int(x) for x in args.threads.split(",")]:
-                    for chunk in [int(x) for x in args.chunks.split(",")]:
-                        if th == 0 and chunk != int(args.chunks.split(",")[0]):
+                for th, chunk, numa in [(int(a), int(b), int(c)) for a in args.threads.split(",") for b in args.chunks.split(",") for c in args.streams.split(",")]:
+                    if True:
+                        if th == 0 and (chunk != int(args.chunks.split(",")[0]) or numa != int(args.streams.split(",")[0])):
                             continue
+                        ctx.set_option("host_tangent_streams", numa)
                         ctx.set_option("host_tangent_threads", th)
                         ctx.set_option("host_tangent_chunk", chunk)
                         reset()
@@ -94,7 +97,7 @@ def main():
                             t_ref = t.copy()
                         same = bool(np.array_equal(t.view(np.uint64), t_ref.view(np.uint64)))
                         dt = best(lambda: law.evaluate(0.0, 1.0, g, s, t, h), reset)
-                        row = {"law": name, "entry": "evaluate", "registered": registered, "threads": th, "chunk": chunk, "ms": round(dt * 1e3, 2),
+                        row = {"law": name, "entry": "evaluate", "registered": registered, "threads": th, "chunk": chunk, "streams": numa, "ms": round(dt * 1e3, 2),
                                "Mpts_s": round(n / dt / 1e6, 1), "identical": same, "cpu_ms": round(ctx.get_option("last_host_tangent_cpu_us") / 1e3, 1),
                                "mode": ctx.last_host_mode()}
                         out["rows"].append(row)
