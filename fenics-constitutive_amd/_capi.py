@@ -461,12 +461,21 @@ class LaunchCache:
         self._kept.clear()
 
 
+def _flush_recorded() -> None:
+    """an evaluate that is NOT recorded (the fused wrapper form, the host and resident entries) is about to run inside a
+    ``batched_launches()`` block: the calls recorded so far leave first, so that the block keeps the order the caller wrote"""
+    batch = getattr(_tls, "batch", None)
+    if batch is not None:
+        batch.flush()
+
+
 class batched_launches:
     """``with batched_launches():`` -- the device calls made inside the block (``Model.evaluate_device_ex``, i.e. every
     ``DeviceLaw.evaluate_from`` / ``evaluate_indexed`` on device tensors) are recorded and leave together as ONE
     ``fcamd_evaluate_batch`` when the block ends: the laws of one ``form()`` (solver/_solver.py:143-144) in one trip through the
-    binding, the small ones concurrently on the context's side streams.  A call with another context, ``t`` or ``del_t`` than
-    the recorded ones flushes what has been recorded first.  The launches happen when the block ENDS: every array passed to a
+    binding, the small ones as ONE launch of the batch kernel (``fcamd_evaluate_batch``).  A call with another context, ``t`` or
+    ``del_t`` than the recorded ones flushes what has been recorded first, and so does every evaluate that is not recorded (the
+    fused wrapper form, the host and resident entries): the block keeps the order in which the calls were written.  The launches happen when the block ENDS: every array passed to a
     recorded call must stay alive and unchanged until then (a temporary tensor freed inside the block may be handed out again
     before the kernel reads it).  Not re-entrant; per thread."""
 
@@ -676,6 +685,7 @@ class Model:
     def evaluate_host(self, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, hist_ptrs) -> Stats:
         arr, nh = self._ptr_array(hist_ptrs)
         st = Stats()
+        _flush_recorded()
         status = self._lib.fcamd_evaluate_host(self.handle, float(t), float(del_t), int(n),
                                                C.c_void_p(grad_ptr), C.c_void_p(stress_ptr),
                                                C.c_void_p(tangent_ptr or 0), arr, nh, C.byref(st))
@@ -705,6 +715,7 @@ class Model:
         if batch is not None and not wrapper_constraint:
             batch.add(self, float(t), float(del_t), int(n), x, (arr, parr))
             return
+        _flush_recorded()  # (the fused wrapper form is not batched: what was recorded before it runs before it)
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
 
     def evaluate_device_wrapped(self, wrapper_constraint, t, del_t, n, grad_ptr, stress_ptr, tangent_ptr, stress3d_ptr,
@@ -715,6 +726,7 @@ class Model:
         arr, nh = self._ptr_array(hist_ptrs)
         x = EvalArgs(grad_ptr, stress_ptr, stress_ptr, tangent_ptr or None, arr, arr, nh, None, None, 0, None, None, None, None,
                      int(wrapper_constraint) or -1, stress3d_ptr or None)
+        _flush_recorded()
         check(self._lib.fcamd_evaluate_device_ex(self.handle, float(t), float(del_t), int(n), C.byref(x)))
 
     def evaluate_resident(self, t, del_t, n, grad_host_ptr, stress_prev_ptr, stress_ptr, hist_prev_ptrs, hist_ptrs,
@@ -725,6 +737,7 @@ class Model:
         x = EvalArgs(grad_host_ptr, stress_prev_ptr, stress_ptr, None, parr, arr, nh, None, mask_ptr or None, int(flags), None, None,
                      pm_prev or None, pm or None, 0, None)
         st = Stats()
+        _flush_recorded()
         status = self._lib.fcamd_evaluate_resident(self.handle, float(t), float(del_t), int(n), C.byref(x),
                                                    C.c_void_p(stress_host_ptr or 0), C.c_void_p(tangent_host_ptr or 0), C.byref(st))
         check(status)

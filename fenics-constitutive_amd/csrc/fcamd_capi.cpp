@@ -815,14 +815,18 @@ int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n
         const int st = enqueue_ex(models[k], del_t, n[k], &args[k], c->stream, true);
         if (st != FCAMD_OK) return st;
     }
-    for (int k0 = 0; n_small && k0 < count;) {  // tables of at most kBatchMax entries
+    // tables of at most kBatchMax entries, the Drucker-Prager laws in tables of their own (their batch kernel is cut for 3 waves per
+    // SIMD, the others' for 4: fcamd_kernels.hip)
+    for (int pass = 0; pass < 2; ++pass)
+    for (int k0 = 0; n_small && k0 < count;) {
+        const bool dp = pass == 1;
         std::vector<fcamd::BatchEntry>& tab = c->batch_build;
         tab.clear();
         int blocks = 0;
         bool any_counts = false;
         int k = k0;
         for (; k < count && (int)tab.size() < fcamd_context::kBatchMax; ++k) {
-            if (!batched(k)) continue;
+            if (!batched(k) || fcamd::batch_law_is_dp(models[k]->law) != dp) continue;
             fcamd_model* m = models[k];
             const fcamd_eval_args* x = &args[k];
             fcamd::BatchEntry e;
@@ -861,19 +865,20 @@ int fcamd_evaluate_batch(int count, fcamd_model* const* models, const int64_t* n
             } else if (slot->bytes) {
                 HIP_TRY(hipDeviceSynchronize());  // a launch that still reads the slot's old table may be in flight (rare: all slots in use and a new table)
             }
+            slot->bytes = 0;  // the slot advertises the new table only once its upload is queued (a failure below must not leave a match)
             memcpy(slot->host, tab.data(), bytes);
-            slot->bytes = bytes;
-            slot->hash = hash;
             HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, c->stream));
             if (!slot->uploaded) HIP_TRY(hipEventCreateWithFlags(&slot->uploaded, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(slot->uploaded, c->stream));
             slot->stream = c->stream;
+            slot->bytes = bytes;
+            slot->hash = hash;
         } else if (slot->stream != c->stream) {
             // the context has been bound to another stream since the table went up: the launch waits for the upload
             HIP_TRY(hipStreamWaitEvent(c->stream, slot->uploaded, 0));
         }
         (void)hipGetLastError();
-        HIP_TRY(fcamd::launch_evaluate_batch(slot->dev, (int)tab.size(), blocks, any_counts, c->stream));
+        HIP_TRY(fcamd::launch_evaluate_batch(slot->dev, (int)tab.size(), blocks, any_counts, dp, c->stream));
     }
     return FCAMD_OK;
 }

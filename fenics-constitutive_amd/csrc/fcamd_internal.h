@@ -69,7 +69,9 @@ struct BatchEntry {
     int pad[3];
 };
 int batch_variant_of(int law, const EvalArgs& args);
-hipError_t launch_evaluate_batch(const BatchEntry* table, int count, int total_blocks, bool any_counts, hipStream_t stream);
+// one table holds either Drucker-Prager laws (dp: the kernel cut for 3 waves per SIMD) or the others (4 waves): batch_law_is_dp
+bool batch_law_is_dp(int law);
+hipError_t launch_evaluate_batch(const BatchEntry* table, int count, int total_blocks, bool any_counts, bool dp, hipStream_t stream);
 
 #ifdef __HIPCC__
 // How the device code sees its arguments: a reference into CONSTANT address space (4) -- uniform, invariant loads that the

@@ -140,11 +140,11 @@ constexpr int kMinBlocks = LAW >= LAW_COMFE_DP ? 3 : 4;
 // the work of workgroup `block` of `nblocks` (tables staged): shared by the law's own kernel and the batch kernel
 template <int LAW, bool NT, bool IDX, int SPARSE, bool PARAMS = false>
 __device__ __forceinline__ void evaluate_blocks(ArgsRef a, const Tables* T, double (*scratch)[kRegionDoubles], int (*rows_all)[kWave],
-                                                int block, int nblocks) {
-    const int lane = threadIdx.x & (kWave - 1);
+                                                int block, int nblocks, int tid = (int)threadIdx.x) {
+    const int lane = tid & (kWave - 1);
     // wave index as a scalar: tile index, p0 and every array's tile base pointer then live in SGPRs and
     // the per-lane part of an address is a small 32-bit offset (saddr addressing)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     double* region = scratch[wave];
     int* rows_lds = rows_all[IDX ? wave : 0];
     const int r0 = lane % 18;
@@ -287,16 +287,25 @@ __global__ void __launch_bounds__(kWave) evaluate_tail_kernel(const EvalArgs) {
 // ---------------------------------------------------------------------------------------
 constexpr int batch_variant(int law, bool idx, int sparse) { return law * 8 + (idx ? 4 : 0) + sparse; }
 
+// `wave`: the wave's index in its workgroup, a scalar.  The thread id is put together again from it and the lane's position in the
+// wave (v_mbcnt) inside every variant: threadIdx.x itself would have to stay in a VGPR from the kernel's entry to the start of every
+// variant, and the variants cut for exactly 128 VGPRs made the compiler spill it (8 bytes of scratch per lane, one store and one load
+// per workgroup -- harmless, but "no kernel uses scratch" is a rule tests/test_kernel_resources.py enforces without exceptions).
 template <int LAW, bool IDX, int SPARSE>
 __device__ __forceinline__ void batch_run(ArgsRef a, const Tables* T, double (*scratch)[kRegionDoubles], int (*rows_all)[kWave],
-                                          int local, int main_blocks) {
+                                          int local, int main_blocks, int wave) {
+    const int tid = wave * kWave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (local < main_blocks)
-        evaluate_blocks<LAW, true, IDX, SPARSE>(a, T, scratch, rows_all, local, main_blocks);
-    else if (threadIdx.x < kWave)
-        evaluate_tail_tile<LAW, IDX, SPARSE>(a, T, scratch[0], rows_all[0], (int)threadIdx.x);
+        evaluate_blocks<LAW, true, IDX, SPARSE>(a, T, scratch, rows_all, local, main_blocks, tid);
+    else if (wave == 0)
+        evaluate_tail_tile<LAW, IDX, SPARSE>(a, T, scratch[0], rows_all[0], tid);
 }
 
-__global__ void __launch_bounds__(kBlock, 3) evaluate_batch_kernel(const BatchEntry* table, int count) {
+// Two kernels, each with the register budget of the laws it runs (round 6): the Drucker-Prager variants (168 VGPRs, 3 waves per SIMD)
+// in one, every other law in the other at the 4 waves per SIMD of its own kernel -- as ONE switch the LE / VonMises3D / SLS entries ran
+// at Drucker-Prager's occupancy and the kernel carried 608 SGPR spills (profiles/r05_kernel_resources.md).
+template <bool DP>
+__global__ void __launch_bounds__(kBlock, DP ? 3 : 4) evaluate_batch_kernel(const BatchEntry* table, int count) {
     __shared__ __attribute__((aligned(16))) Tables T;
     __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
     __shared__ int rows_all[kWavesPerBlock][kWave];
@@ -307,25 +316,32 @@ __global__ void __launch_bounds__(kBlock, 3) evaluate_batch_kernel(const BatchEn
     ArgsRef a = tab[k].args;
     const int local = (int)blockIdx.x - tab[k].first_block, mb = tab[k].main_blocks;
     stage_tables(a, &T);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
 #define FCAMD_BATCH_CASE(LAW, IDX, SPARSE)                                           \
     case batch_variant(LAW, IDX, SPARSE):                                            \
-        batch_run<LAW, IDX, SPARSE>(a, &T, scratch, rows_all, local, mb);            \
+        batch_run<LAW, IDX, SPARSE>(a, &T, scratch, rows_all, local, mb, wave);      \
         break;
 #define FCAMD_BATCH_LAW(LAW) FCAMD_BATCH_CASE(LAW, false, 0) FCAMD_BATCH_CASE(LAW, true, 0)
-    switch (tab[k].variant) {
-        FCAMD_BATCH_LAW(LAW_LE)
-        FCAMD_BATCH_LAW(LAW_VM3D)
-        FCAMD_BATCH_CASE(LAW_VM3D, false, 1)
-        FCAMD_BATCH_CASE(LAW_VM3D, true, 1)
-        FCAMD_BATCH_CASE(LAW_VM3D, false, 2)
-        FCAMD_BATCH_CASE(LAW_VM3D, true, 2)
-        FCAMD_BATCH_LAW(LAW_MAXWELL)
-        FCAMD_BATCH_LAW(LAW_KELVIN)
-        FCAMD_BATCH_LAW(LAW_COMFE_LE)
-        FCAMD_BATCH_LAW(LAW_COMFE_MISES)
-        FCAMD_BATCH_LAW(LAW_COMFE_DP)
-        FCAMD_BATCH_LAW(LAW_COMFE_DP_HYPER)
-        default: break;
+    if constexpr (DP) {
+        switch (tab[k].variant) {
+            FCAMD_BATCH_LAW(LAW_COMFE_DP)
+            FCAMD_BATCH_LAW(LAW_COMFE_DP_HYPER)
+            default: break;
+        }
+    } else {
+        switch (tab[k].variant) {
+            FCAMD_BATCH_LAW(LAW_LE)
+            FCAMD_BATCH_LAW(LAW_VM3D)
+            FCAMD_BATCH_CASE(LAW_VM3D, false, 1)
+            FCAMD_BATCH_CASE(LAW_VM3D, true, 1)
+            FCAMD_BATCH_CASE(LAW_VM3D, false, 2)
+            FCAMD_BATCH_CASE(LAW_VM3D, true, 2)
+            FCAMD_BATCH_LAW(LAW_MAXWELL)
+            FCAMD_BATCH_LAW(LAW_KELVIN)
+            FCAMD_BATCH_LAW(LAW_COMFE_LE)
+            FCAMD_BATCH_LAW(LAW_COMFE_MISES)
+            default: break;
+        }
     }
 #undef FCAMD_BATCH_LAW
 #undef FCAMD_BATCH_CASE
@@ -428,11 +444,16 @@ int batch_variant_of(int law, const EvalArgs& args) {
     return batch_variant(law, args.rows != nullptr, sparse);
 }
 
-hipError_t launch_evaluate_batch(const BatchEntry* table, int count, int total_blocks, bool any_counts, hipStream_t stream) {
+bool batch_law_is_dp(int law) { return law == LAW_COMFE_DP || law == LAW_COMFE_DP_HYPER; }
+
+hipError_t launch_evaluate_batch(const BatchEntry* table, int count, int total_blocks, bool any_counts, bool dp, hipStream_t stream) {
     static_assert(kCounterSlots * 4 == kBlock, "batch_zero_counters_kernel: one thread per counter word");
     if (count <= 0 || total_blocks <= 0) return hipSuccess;
     if (any_counts) hipLaunchKernelGGL(batch_zero_counters_kernel, dim3(count), dim3(kBlock), 0, stream, table);
-    hipLaunchKernelGGL(evaluate_batch_kernel, dim3(total_blocks), dim3(kBlock), 0, stream, table, count);
+    if (dp)
+        hipLaunchKernelGGL(evaluate_batch_kernel<true>, dim3(total_blocks), dim3(kBlock), 0, stream, table, count);
+    else
+        hipLaunchKernelGGL(evaluate_batch_kernel<false>, dim3(total_blocks), dim3(kBlock), 0, stream, table, count);
     return hipGetLastError();
 }
 

@@ -178,15 +178,20 @@ int fcamd_device_free(fcamd_context* c, void* ptr) {
     VmmArray a;
     bool plain = false;
     {
+        // The block leaves the table BEFORE the runtime gets it back: once hipFree has returned, another thread's hipMalloc may be
+        // handed the same address, and an erase after the free would untrack that new, live block.
         std::lock_guard<std::mutex> lock(g_vmm_mu);
-        plain = g_plain.count(ptr) != 0;
+        plain = g_plain.erase(ptr) != 0;
     }
-    if (plain) {  // an FCAMD_ALLOC_IPC block.  hipFree waits for the device: not under the process-wide lock, and the block stays
-                  // tracked until the runtime has really released it (a failed free can be tried again)
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipFree(ptr));
-        std::lock_guard<std::mutex> lock(g_vmm_mu);
-        g_plain.erase(ptr);
+    if (plain) {  // an FCAMD_ALLOC_IPC block.  hipFree waits for the device: not under the process-wide lock
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipFree(ptr);
+        if (e != hipSuccess) {  // still allocated: tracked again, so that the free can be tried again
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lock(g_vmm_mu);
+            g_plain.insert(ptr);
+            return fail(FCAMD_ERR_HIP, "hipFree of an FCAMD_ALLOC_IPC block failed: %s", hipGetErrorString(e));
+        }
         return FCAMD_OK;
     }
     {

@@ -21,7 +21,7 @@ os.environ.setdefault("FCAMD_SMALL_CALL_WARNING", "0")
 out = {}
 for n_laws in [int(x) for x in os.environ.get('BATCH_BENCH_LAWS', '2,8').split(',')]:
     out[str(n_laws)] = {}
-    for per_law in (10_000, 100_000, 1_000_000):
+    for per_law in [int(x) for x in os.environ.get('BATCH_BENCH_SIZES', '10000,100000,1000000').split(',')]:
         q = 4
         n_cells = n_laws * per_law // q
         rng = np.random.default_rng(1)
