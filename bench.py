@@ -574,8 +574,9 @@ def main():
         # sample of the headline arrays, taken before they are released for the other configurations
         from benchlib.cpu import host_sample
 
-        cpu_args = host_sample(wl.kind, wl.params, wl.grads[0][: 9 * 2_000_000], wl.stress_c[: 12_000_000],
-                               None if wl.hist_c is None else {k: v[: {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}[k] * 2_000_000]
+        ncpu = min(n, 10_000_000)  # n = 1e7
+        cpu_args = host_sample(wl.kind, wl.params, wl.grads[0][: 9 * ncpu], wl.stress_c[: 6 * ncpu],
+                               None if wl.hist_c is None else {k: v[: {"eps_n": 6, "alpha": 1, "strain_visco": 6, "strain": 6, "history": 7}[k] * ncpu]
                                                                for k, v in wl.reference_history().items()}, wl.del_t)
     wl.drop_plain_twin()
     ever_fraction = wl.ever_fraction()
@@ -829,25 +830,18 @@ def main():
             except Exception as e:  # informational: must not lose the line
                 out["host_path"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             leg_done("host_path")
-        # the CPU baseline runs on the host (one thread, inside a C call that releases the GIL) WHILE the PMC child passes keep the GPU busy
+        # The CPU baseline has the host to itself: it runs BEFORE the PMC child passes start (round 5 ran it on a thread beside them --
+        # two rocprofv3 children starting Python and parsing CSVs on the same cores can only slow the figure the GPU is compared with,
+        # and the all-cores leg, 256 threads under a cgroup quota of 16 CPUs, came out at the one-thread rate: ADVICE r5)
         cpu_thread = None
         if world == 1:
             checkpoint("cpu_baseline")
             if cpu_args is not None:
-                import threading
-
-                def run_cpu():
-                    try:
-                        out["cpu_baseline"] = cpu_baseline(*cpu_args, extras="full" if args.full else "lean")
-                    except Exception as e:  # noqa: BLE001 -- reported, never fatal
-                        out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-
-                if args.full:  # its crossover table makes GPU calls of its own: not next to a PMC pass
-                    run_cpu()
-                    leg_done("cpu_baseline")
-                else:
-                    cpu_thread = threading.Thread(target=run_cpu, daemon=True)
-                    cpu_thread.start()
+                try:
+                    out["cpu_baseline"] = cpu_baseline(*cpu_args, extras="full" if args.full else "lean")
+                except Exception as e:  # noqa: BLE001 -- reported, never fatal
+                    out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                leg_done("cpu_baseline")
             else:
                 out["cpu_baseline"] = None
         if world == 1 and not args.no_live_traffic and budget_left() > 100:
@@ -863,7 +857,7 @@ def main():
             # the default command stays under two minutes: what is left of 108 s goes to the two passes (each stops starting new
             # items when its half is used up: headline first, then its forms, the 8(f) rows, the configurations)
             # (counted from the end of the imports: a cold image pages torch in for a minute or two, which is nobody's to spend)
-            target = 240.0 if args.full else 104.0
+            target = 240.0 if args.full else 118.0  # (the CPU baseline, ~14 s, now runs before the passes instead of beside them)
             pass_s = max(12.0, (target - (time.perf_counter() - t_start)) / 2.0 - 3.0)
             lt_all = live_traffic_batch(items, n, history, extra, min(150.0, budget_left() - 30.0), headline=name, pass_budget_s=pass_s) or {}
             lt = lt_all.get(name)

@@ -76,7 +76,8 @@ def compact_line(d, detail_path=None):
                                 "sample": _short(cb.get("sample", ""), 150)}
         ex = cb.get("extra") or {}
         for k_out, k_in in (("numpy_port", "numpy_port_Mpts_s"), ("comfe_rs_c_port", "comfe_rs_mises_c_port_1_thread_Mpts_s"),
-                            ("all_cores", "c_port_all_cores_Mpts_s"), ("all_cores_threads", "c_port_all_cores_threads")):
+                            ("all_cores", "c_port_all_cores_Mpts_s"), ("all_cores_threads", "c_port_all_cores_threads"),
+                            ("all_cores_per_thread", "c_port_all_cores_per_thread_Mpts_s")):
             if ex.get(k_in) is not None:
                 line["cpu_baseline"][k_out] = ex[k_in]
     elif "cpu_baseline" in d:

@@ -45,13 +45,6 @@ int main(void) {
     CHECK(fcamd_evaluate_host(law, 0.0, 1.0, N, grad, stress, tangent, NULL, 0, &stats));
     float ms = -1.0f;
     CHECK(fcamd_model_last_kernel_ms(law, &ms));
-    /* contiguous 64-aligned slices of the point axis for 8 ranks (multi-GPU: every rank evaluates its own slice) */
-    int64_t lo = 0, hi = 0, covered = 0;
-    for (int r = 0; r < 8; ++r) {
-        CHECK(fcamd_shard_bounds(N, 8, r, &lo, &hi, NULL));
-        covered += hi - lo;
-    }
-    if (covered != N) return 4;
 
     double worst = 0.0;
     for (int i = 0; i < N; ++i) {

@@ -1,4 +1,4 @@
-/* A plain-C host that drives SEVERAL GPUs from one process through the C ABI (include/fcamd.h, "one process, several
+/* A plain-C host that drives SEVERAL GPUs from one process through the C ABI (include/fcamd_multi.h, "one process, several
  * GPUs"): the single assembler of BASELINE.json's north_star.  VonMises3D on N points in this process's own arrays;
  * every device context evaluates its slice in place (fcamd_multi_evaluate_host) -- compared bit for bit with the
  * single-device entry -- and then a two-increment Newton-style loop on the device-resident state (fcamd_multi_state_*).
@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "fcamd.h"
+#include "fcamd_multi.h"
 
 #define CHECK(call)                                                                 \
     do {                                                                            \

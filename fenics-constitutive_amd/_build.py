@@ -20,7 +20,7 @@ SOURCES = ["fcamd_kernels.hip", "fcamd_aux_kernels.hip", "fcamd_capi.cpp", "fcam
 KERNEL_HEADERS = [os.path.join("kernels", h) for h in (
     "tile_io.h", "tangent_writers.h", "wrapped_io.h", "history_rows.h", "law_linear_elasticity.h", "law_sls.h",
     "law_von_mises.h", "law_comfe_mises.h", "law_drucker_prager.h", "law_lowdim.h")]
-HEADERS = ["fcamd_internal.h", "fcamd_host.h", os.path.join("..", "..", "include", "fcamd.h"), *KERNEL_HEADERS]
+HEADERS = ["fcamd_internal.h", "fcamd_host.h", os.path.join("..", "..", "include", "fcamd.h"), os.path.join("..", "..", "include", "fcamd_multi.h"), *KERNEL_HEADERS]
 ARCH = "gfx950"
 # -ffp-contract=off: arithmetic order is part of the parity contract (see fcamd_kernels.hip)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

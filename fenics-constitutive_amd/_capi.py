@@ -32,12 +32,13 @@ EVAL_PACKED_HISTORY = 8
 
 # context option "last_host_mode": FCAMD_HOST_* flags (include/fcamd.h)
 HOST_ZERO_COPY_IN, HOST_ZERO_COPY_OUT, HOST_TEMP_LOCK, HOST_BOUNCE = 1, 2, 4, 8
+HOST_TANGENT_CPU = 16  # the tangent rows were written by host threads (context option "host_tangent_threads"), not sent over the link
 
 # conversion kinds (include/fcamd.h)
 (GRAD_1D_TO_3D, STRESS_1D_TO_3D, STRESS_3D_TO_1D, TANGENT_3D_TO_1D,
  GRAD_2D_TO_3D, STRESS_2D_TO_3D, STRESS_3D_TO_2D, TANGENT_3D_TO_2D) = range(1, 9)
 
-#: every symbol include/fcamd.h exports (FCAMD_API; checked by tests/test_host_logic.py::test_library_exports_every_declared_symbol)
+#: every symbol include/fcamd.h (26: the measured core) and include/fcamd_multi.h (20: the multi-GPU forms) export (FCAMD_API; checked by tests/test_host_logic.py::test_library_exports_every_declared_symbol)
 SYMBOLS = [
     "fcamd_context_create", "fcamd_context_destroy", "fcamd_context_set_stream", "fcamd_context_synchronize",
     "fcamd_model_create", "fcamd_model_destroy", "fcamd_model_get_info",

@@ -3,6 +3,7 @@
 // Not installed; the public boundary is include/fcamd.h.
 #pragma once
 #include "../../include/fcamd.h"
+#include "../../include/fcamd_multi.h"
 
 #include <cstdint>
 #include <map>

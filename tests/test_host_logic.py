@@ -79,10 +79,19 @@ def test_strain_from_grad_u_needs_the_gpu_for_every_constraint():
 def test_library_exports_every_declared_symbol():
     import subprocess
 
-    hdr = open(os.path.join(ROOT, "include", "fcamd.h")).read()
-    declared = sorted(set(re.findall(r"^FCAMD_API [a-z_ *]*?\b(fcamd_[a-z_0-9]+)\s*\(", hdr, re.M)))
+    core = open(os.path.join(ROOT, "include", "fcamd.h")).read()
+    multi = open(os.path.join(ROOT, "include", "fcamd_multi.h")).read()
+    pat = r"^FCAMD_API [a-z_ *]*?\b(fcamd_[a-z_0-9]+)\s*\("
+    core_syms, multi_syms = set(re.findall(pat, core, re.M)), set(re.findall(pat, multi, re.M))
+    # the measured core (one evaluate per data path -- bindings/src/lib.rs:76-129 has one per model -- + the batch of one form()) and
+    # the multi-GPU forms (fcamd_multi.h: never run on a multi-GPU node) are kept apart
+    assert len(core_syms) <= 26 and len(multi_syms) <= 20 and not (core_syms & multi_syms)
+    assert all(s.startswith(("fcamd_multi_", "fcamd_ipc_", "fcamd_allgather_", "fcamd_shard_", "fcamd_gather_")) for s in multi_syms)
+    assert not any(s.startswith(("fcamd_multi_", "fcamd_ipc_", "fcamd_allgather_")) for s in core_syms)
+    assert "UNMEASURED ON MULTI-GPU HARDWARE" in multi
+    hdr = core + multi
+    declared = sorted(core_syms | multi_syms)
     assert declared == sorted(_capi.SYMBOLS)
-    assert len(declared) <= 46  # the boundary stays small: one evaluate per data path (bindings/src/lib.rs:76-129 has one per model) + the batch of one form()
     lib = ctypes.CDLL(_capi.library_path()) if os.path.exists(_capi.library_path()) else _capi.load()
     for name in declared:
         assert hasattr(lib, name), name
@@ -257,11 +266,11 @@ def test_header_constants_match_the_ctypes_module():
 
     from fenics_constitutive_amd import _capi
 
-    hdr = open(os.path.join(ROOT, "include", "fcamd.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "fcamd.h")).read() + open(os.path.join(ROOT, "include", "fcamd_multi.h")).read()
     defines = {k: int(v, 0) for k, v in re.findall(r"#define (FCAMD_[A-Z_0-9]+) (\d+|0x[0-9a-fA-F]+)\b", hdr)}
     pairs = {"FCAMD_EVAL_SPARSE_TANGENT": _capi.EVAL_SPARSE_TANGENT,
              "FCAMD_HOST_ZERO_COPY_IN": _capi.HOST_ZERO_COPY_IN, "FCAMD_HOST_ZERO_COPY_OUT": _capi.HOST_ZERO_COPY_OUT,
-             "FCAMD_HOST_TEMP_LOCK": _capi.HOST_TEMP_LOCK, "FCAMD_HOST_BOUNCE": _capi.HOST_BOUNCE,
+             "FCAMD_HOST_TEMP_LOCK": _capi.HOST_TEMP_LOCK, "FCAMD_HOST_BOUNCE": _capi.HOST_BOUNCE, "FCAMD_HOST_TANGENT_CPU": _capi.HOST_TANGENT_CPU,
              "FCAMD_COUNTER_SLOTS": _capi.COUNTER_SLOTS,
              "FCAMD_MAX_HISTORY": _capi.MAX_HISTORY, "FCAMD_IPC_HANDLE_BYTES": _capi.IPC_HANDLE_BYTES,
              "FCAMD_GATHER_PULL": _capi.GATHER_PULL, "FCAMD_ALLOC_SEQUENTIAL": _capi.ALLOC_SEQUENTIAL,
