@@ -15,7 +15,59 @@ import ctypes as C
 from . import _capi
 from .device import _check_torch, _current_stream_ptr
 
-__all__ = ["DeviceIdentityMap", "DeviceSubSpaceMap"]
+__all__ = ["DeviceIdentityMap", "DeviceSubSpaceMap", "row_order", "ascending_order", "warn_if_rows_not_ascending"]
+
+_warned_rows = False
+
+
+def row_order(parent_rows) -> dict:
+    """How the fused indexed kernel (``DeviceLaw.evaluate_indexed``: stress / tangent rows addressed through ``parent_rows``) will see
+    a map: ``ascending`` -- the rows never go down; ``consecutive_tiles`` -- the share of 64-point tiles whose rows are one run
+    (they take the coalesced tile body on shifted base pointers, csrc/fcamd_kernels.hip: run_full_tile)."""
+    import numpy as np
+
+    r = np.asarray(parent_rows).astype(np.int64, copy=False).ravel()
+    if r.size < 2:
+        return {"ascending": True, "consecutive_tiles": 1.0}
+    d = np.diff(r)
+    full = (r.size // 64) * 64
+    run = 1.0
+    if full:
+        inside = np.ones(full, dtype=bool)
+        inside[63::64] = False  # the step from one tile to the next does not count
+        steps = np.concatenate([d, [1]])[:full]
+        run = float(np.mean(np.all(((steps == 1) | ~inside).reshape(-1, 64), axis=1)))
+    return {"ascending": bool(np.all(d >= 0)), "consecutive_tiles": run}
+
+
+def ascending_order(parent_rows):
+    """Permutation that visits a law's points in ascending parent-row order (stable).  Apply it ONCE, where the law's local arrays
+    are laid out -- ``parent_rows[order]`` as the map, the gradient producer writing row ``k`` for point ``order[k]``, the history
+    arrays permuted the same way -- and the indexed kernel meets cells as runs of consecutive rows."""
+    import numpy as np
+
+    return np.argsort(np.asarray(parent_rows), kind="stable")
+
+
+def warn_if_rows_not_ascending(parent_rows, who: str) -> None:
+    """The reference builds its submesh maps from the cells of a material in ascending order (solver/maps.py:127-178): rows rise,
+    cells are runs.  A map whose rows go up and down makes every 336-byte stress + tangent row of a tile a scattered write:
+    measured at 5e7 of 1e8 parent rows (profiles/r05_default_bench_rocprof.md, row `indexed_permuted`) 0.33-0.41 of the HBM roofline at 1.29 x
+    the algorithmic bytes, against 0.76-0.82 for ascending maps.  Said once per process."""
+    global _warned_rows
+    if _warned_rows:
+        return
+    o = row_order(parent_rows)
+    if not o["ascending"]:
+        import warnings
+
+        _warned_rows = True
+        warnings.warn(
+            f"{who}: the parent rows of this law are not ascending ({100.0 * o['consecutive_tiles']:.0f} % of its 64-point tiles are runs of "
+            "consecutive rows).  The fused indexed kernel then scatters every 336-byte stress + tangent row: about 0.35 of the HBM "
+            "roofline at 1.3 x the bytes instead of 0.76-0.82 (measured, MI355X).  Lay the law's points out in ascending parent-row "
+            "order once (fenics_constitutive_amd.maps.ascending_order), as the reference's submesh maps are (solver/maps.py:127-178).",
+            RuntimeWarning, stacklevel=3)
 
 
 def _rows(ctx, n_rows, row_size, src, src_idx, dst, dst_idx):
@@ -33,6 +85,8 @@ class DeviceSubSpaceMap:
         import torch
 
         dev = torch.device("cuda", _capi.default_device()) if device is None else torch.device(device)
+        if not hasattr(parent, "is_cuda") or not parent.is_cuda:  # (host index arrays: looked at once, at construction, as maps.py builds them once)
+            warn_if_rows_not_ascending(parent, "DeviceSubSpaceMap")
         self.parent = torch.as_tensor(parent, dtype=torch.int32).to(dev).contiguous()
         self.sub = torch.as_tensor(sub, dtype=torch.int32).to(dev).contiguous()
         assert self.parent.numel() == self.sub.numel(), "index arrays must have equal length"

@@ -138,6 +138,9 @@ class ResidentProblemState:
             else:
                 rows = np.asarray(rows)
                 n_k = rows.size
+                from .maps import warn_if_rows_not_ascending
+
+                warn_if_rows_not_ascending(rows, "ResidentProblemState")
                 assert rows.min(initial=0) >= 0 and rows.max(initial=-1) < self.n, "row out of range"
                 np.add.at(covered, rows, 1)
             self._laws.append(_LawState(law, rows, n_k, f, self.device, sparse_history, packed_history))

@@ -458,3 +458,30 @@ def test_scripts_compile():
     assert len(files) > 60
     for f in files:
         py_compile.compile(f, doraise=True)
+
+
+def test_row_order_diagnostics_and_the_one_time_warning():
+    """maps.row_order / ascending_order / warn_if_rows_not_ascending: what the fused indexed kernel meets for a submesh map (the
+    reference builds ascending maps, solver/maps.py:127-178; a map that goes up and down costs 0.35 instead of 0.8 of the roofline)."""
+    import warnings
+
+    from fenics_constitutive_amd import maps
+
+    rng = np.random.default_rng(0)
+    assert maps.row_order(np.arange(1000)) == {"ascending": True, "consecutive_tiles": 1.0}
+    cells = np.sort(rng.choice(500, 250, replace=False))
+    rows = (cells[:, None] * 4 + np.arange(4)).ravel()  # ascending cells of 4 points: ascending, but no tile is one run
+    o = maps.row_order(rows)
+    assert o["ascending"] and o["consecutive_tiles"] < 0.2
+    perm = rng.permutation(1000)
+    assert not maps.row_order(perm)["ascending"]
+    order = maps.ascending_order(perm)
+    assert maps.row_order(perm[order]) == {"ascending": True, "consecutive_tiles": 1.0}
+    maps._warned_rows = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        maps.warn_if_rows_not_ascending(rows, "test")  # ascending: silent
+        maps.warn_if_rows_not_ascending(perm, "test")
+        maps.warn_if_rows_not_ascending(perm, "test")  # once per process
+    assert len(w) == 1 and "not ascending" in str(w[0].message) and "ascending_order" in str(w[0].message)
+    maps._warned_rows = False
