@@ -189,7 +189,8 @@ def main_frow(args):
         sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(device)
-    out = bench_frows.run_frow(args.frow, args.n, device, launches=max(1, args.steps), warm=max(1, args.warmup), peak_gbs=HBM_PEAK_GBS, draws=1)
+    out = bench_frows.run_frow(args.frow, args.n, device, launches=max(1, args.steps), warm=max(1, args.warmup), peak_gbs=HBM_PEAK_GBS, draws=1,
+                               floor_launches=4)
     print(json.dumps({"metric": METRIC, "frow": args.frow, **out}), flush=True)
     return 0
 
@@ -767,7 +768,7 @@ def main():
                 continue
             try:
                 out["configs"][fname] = bench_frows.run_frow(fname, n, device, launches=max(5, args.config_steps), peak_gbs=HBM_PEAK_GBS,
-                                                             draws=3 if args.full else 2)
+                                                             draws=3 if args.full else 2, floor_launches=4)
                 frow_names.append(fname)
             except Exception as e:  # one row failing must not lose the line
                 out["configs"][fname] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -271,6 +271,37 @@ class ResidentSparseTangentRow(FRow):
     def alg_bytes(self):
         return 176 * (self.n - self.n_touched) + 568 * self.n_touched
 
+    def mem_floor(self, launches):
+        """The row's SYNTHETIC TWIN, measured ("measure, don't compute, the bound"): the very launches of the
+        timed phase issued as evaluate_twin_kernel (context option "twin_masks", csrc/fcamd_kernels.hip) -- the same loads and stores
+        at the same addresses on the same buffers, every tile's plastic ballot read from a recording of the real step instead of
+        computed, no constitutive arithmetic.  What the memory system alone takes for this request stream.  The state's trial arrays
+        hold meaningless values afterwards: the last thing a row does."""
+        t = self.torch
+        ctx = self.law._handle(self.device.index or 0).ctx
+        recorded = [None, None]
+        for _ in range(2):  # the ballots of the two alternating iterates, as the real kernel leaves them in the state's mask
+            p = self.i & 1
+            self.launch()
+            t.cuda.synchronize()
+            recorded[p] = self.state._mask.clone()
+        self.launch_log.append(["mem_floor_record", 2])
+        ev = [(t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)) for _ in range(launches + 2)]
+        try:
+            for a, b in ev:
+                ctx.set_option("twin_masks", recorded[self.i & 1].data_ptr())
+                a.record()
+                self.launch()
+                b.record()
+            t.cuda.synchronize()
+        finally:
+            ctx.set_option("twin_masks", 0)
+        self.launch_log.append(["mem_floor_twin", launches + 2])
+        same = bool(t.equal(self.state._mask, recorded[(self.i - 1) & 1]))  # the twin left the ballots the real step leaves
+        ms = [a.elapsed_time(b) for a, b in ev][2:]
+        self.extra["mem_floor_ms"] = round(sum(ms) / len(ms), 4)
+        self.extra["mem_floor_ballots_reproduced"] = same
+
 
 FROWS = {
     "indexed_runs": lambda n, d: IndexedRow(n, d, "runs"),
@@ -289,7 +320,7 @@ SURVEY_ROW = {"indexed_runs": "f2", "indexed_scattered_cells": "f2", "indexed_pe
               "resident_sparse_tangent": "f1", "resident_sparse_tangent_zoned": "f1"}
 
 
-def run_frow(name, n, device, launches=6, warm=2, peak_gbs=8000.0, draws=3, redraw=True):
+def run_frow(name, n, device, launches=6, warm=2, peak_gbs=8000.0, draws=3, redraw=True, floor_launches=0):
     """one row, measured: warm launches, the row's own counts, `launches` event-timed launches -- on up to `draws` fresh sets
     of allocations (the kernel time follows where the driver puts the written arrays, DESIGN.md 6: `frac` is the fastest
     set, as the headline's is the fastest tangent candidate; `frac_first_allocation` what the first set gave)"""
@@ -324,6 +355,9 @@ def run_frow(name, n, device, launches=6, warm=2, peak_gbs=8000.0, draws=3, redr
             row.extra["_bytes"] = max(row.extra.get("_bytes", 0), torch.cuda.memory_allocated(device) - before)
             results.append((sum(ms) / len(ms), min(ms), row))
         avg, best_min, row = min(results, key=lambda r: r[0])
+        if floor_launches and hasattr(row, "mem_floor"):
+            row.mem_floor(floor_launches)  # (after the timed launches: the twin leaves the trial state meaningless)
+            row.extra["kernel_over_mem_floor"] = round(avg / row.extra["mem_floor_ms"], 4)
         alg = row.alg_bytes()
         frac = lambda t: round(alg / (t * 1e-3) / 1e9 / peak_gbs, 4)  # noqa: E731
         log = [x for r in rows for x in r.launch_log] if len(rows) > 1 else row.launch_log

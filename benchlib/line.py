@@ -91,6 +91,8 @@ def compact_line(d, detail_path=None):
                 line["configs"][name] = _short((c or {}).get("error") or (c or {}).get("skipped") or "no figures", 60) if isinstance(c, dict) else None
                 continue
             line["configs"][name] = [c.get("frac"), c.get("traffic_over_algorithmic"), c.get("kernel_ms_avg"), c.get("frac_first_allocation", c.get("frac"))]
+            if c.get("mem_floor_ms") is not None:  # the row's synthetic twin (same request stream, no arithmetic), measured
+                line.setdefault("mem_floor_ms", {})[name] = [c["mem_floor_ms"], c.get("kernel_over_mem_floor")]
     if isinstance(d.get("host_path"), dict):
         line["host_path_Mpts_s"] = _host_rates(d["host_path"])
     if d.get("per_rank_kernel_ms") is not None:

@@ -422,6 +422,11 @@ static void fill_args(fcamd_model* m, double del_t, int64_t n, const double* gra
         // (with parent_rows: VonMises3D only -- the indexed split-history kernels would need instantiations of their own)
         if ((m->law == FCAMD_VON_MISES_3D || (split && !rows)) && emask_prev && emask) a.flags |= flags & FCAMD_EVAL_PACKED_HISTORY;
     }
+    // (measurement device, context option "twin_masks":) the synthetic twin of the packed sparse-protocol VonMises3D launch
+    if (m->ctx->twin_masks && m->law == FCAMD_VON_MISES_3D && !rows && (a.flags & FCAMD_EVAL_PACKED_HISTORY)) {
+        a.flags |= 64;  // kernels/tangent_writers.h: kFlagTwin
+        a.cache3d = reinterpret_cast<double*>(m->ctx->twin_masks);
+    }
     // (library-internal, host entries only:) `tangent` is the ring of 8 doubles per point, the host rebuilds the rows
     if (tangent && (flags & kFlagTangentParamsHost)) a.flags = (a.flags & ~FCAMD_EVAL_SPARSE_TANGENT) | kFlagTangentParamsHost;
     a.emask_in = emask_prev;
@@ -561,6 +566,7 @@ int fcamd_context_set_option(fcamd_context* c, const char* name, long long value
     else if (k == "host_tangent_min_points") o.host_tangent_min_points = std::max<long long>(0, value);
     else if (k == "host_tangent_chunk") o.host_tangent_chunk = std::max<long long>(0, (value / 64) * 64);
     else if (k == "host_tangent_streams") o.host_tangent_streams = (int)std::max<long long>(1, std::min<long long>(fcamd_context::kSlots, value));
+    else if (k == "twin_masks") c->twin_masks = (unsigned long long)value;  // device address of one recorded ballot word per tile; 0: off
     else if (k == "grid") c->grid_override = value > 0 ? (int)value : 0;
     else if (k == "timing") c->timing = value != 0;
     else if (k == "trim") return context_trim(c);

@@ -104,6 +104,7 @@ struct fcamd_context {
     // releases the GIL); the unregistration then waits for that call instead of racing it.
     std::recursive_mutex host_mu;
     int last_host_mode = 0;  // FCAMD_HOST_* flags of the last host-entry call
+    unsigned long long twin_masks = 0;  // option "twin_masks": VonMises3D launches of the packed sparse protocol run as their synthetic twin (fcamd_kernels.hip)
     // page-locked scratch of the bounce path (hipHostMalloc: pages of its own, locked for its whole life)
     char* bounce = nullptr;
     char* bounce_dev = nullptr;  // the address the GPU sees it at

@@ -50,7 +50,7 @@ namespace fcamd {
 // ---------------------------------------------------------------------------------------
 // PM: the tangent leaves as 8 parameters per point (kFlagTangentParams: the host rebuilds the rows, fcamd_hosttangent.cpp) -- 0 never,
 // 1 always (the kernels instantiated for it), 2 decided by the flag at run time (the ragged last tile)
-template <int LAW, bool IDX, bool FULL, bool NT, int SPARSE = 0, int PM = 0>
+template <int LAW, bool IDX, bool FULL, bool NT, int SPARSE = 0, int PM = 0, bool TWIN = false>
 __device__ __forceinline__ void run_tile(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                          int* rows_lds, long long p0, int npts, int lane, int r0,
                                          WaveStats& st) {
@@ -70,7 +70,7 @@ __device__ __forceinline__ void run_tile(ArgsRef a, const StressBases& sb, const
     else if constexpr (LAW == LAW_KELVIN)
         tile_sls<true, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0);
     else if constexpr (LAW == LAW_VM3D)
-        tile_von_mises<IDX, SPARSE, FULL, NT, PM>(a, sb, T, region, rows_lds, p0, npts, lane, st);
+        tile_von_mises<IDX, SPARSE, FULL, NT, PM, TWIN>(a, sb, T, region, rows_lds, p0, npts, lane, st);
     else if constexpr (LAW == LAW_COMFE_DP)
         tile_comfe_dp<false, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0, st);
     else if constexpr (LAW == LAW_COMFE_DP_HYPER)
@@ -174,6 +174,27 @@ __global__ void __launch_bounds__(kBlock, (kMinBlocks<LAW, IDX>)) evaluate_kerne
     __shared__ int rows_all[IDX ? kWavesPerBlock : 1][kWave];
     stage_tables(a, &T);
     evaluate_blocks<LAW, NT, IDX, SPARSE, PARAMS>(a, &T, scratch, rows_all, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The synthetic twin of evaluate_kernel<LAW_VM3D, true, false, 2> (kernels/tangent_writers.h: kFlagTwin): the full tiles' request stream
+// with the ballots read from a.cache3d and no constitutive arithmetic.  A measurement device (context option "twin_masks"), never a result.
+__global__ void __launch_bounds__(kBlock, 4) evaluate_twin_kernel(const EvalArgs) {
+    ArgsRef a = kernel_args();
+    __shared__ __attribute__((aligned(16))) Tables T;
+    __shared__ __attribute__((aligned(16))) double scratch[kWavesPerBlock][kRegionDoubles];
+    stage_tables(a, &T);
+    int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const long long nfull = a.n / kWave;
+    const long long wstride = (long long)gridDim.x * kWavesPerBlock;
+    WaveStats st;
+    const StressBases sb{a.stress_in, a.stress_out, a.tangent, a.stress_out2};
+    for (long long tile = (long long)blockIdx.x * kWavesPerBlock + wave; tile < nfull; tile += wstride) {
+        asm volatile("" : "+v"(lane));
+        lane &= kWave - 1;
+        run_tile<LAW_VM3D, false, true, true, 2, 0, true>(a, sb, &T, scratch[wave], nullptr, tile * kWave, kWave, lane, lane % 18, st);
+    }
+    flush_stats<LAW_VM3D>(a, st, lane);
 }
 
 // Low-dimensional constraints: same persistent structure, DIMS = 1 or 2.
@@ -379,6 +400,11 @@ static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream)
         }
     }
     if constexpr (LAW == LAW_VM3D) {
+        if ((args.flags & kFlagTwin) != 0) {  // the synthetic twin: full tiles of the packed sparse protocol only
+            if (!args.hmask || args.rows || !(args.flags & kFlagPackedHistory) || !args.cache3d) return hipErrorInvalidValue;
+            if (args.n >= kWave) hipLaunchKernelGGL(evaluate_twin_kernel, dim3(grid), dim3(kBlock), 0, stream, args);
+            return hipGetLastError();
+        }
         if (args.hmask && args.rows && (args.flags & kFlagPackedHistory)) {  // ... on the packed plastic-strain layout (local to the law)
             if (args.n >= kWave)
                 hipLaunchKernelGGL((evaluate_kernel<LAW, true, true, 2>), dim3(grid), dim3(kBlock), 0, stream, args);

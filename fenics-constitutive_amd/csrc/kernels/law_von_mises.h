@@ -97,7 +97,8 @@ __device__ __forceinline__ void vm_tangent_coefficients(ScalarsRef sc, const VMR
 // HIST: 0 = the caller's arrays as they are (in place or out of place), 1 = sparse trial history (a.hmask),
 //       2 = sparse protocol on the packed plastic-strain layout (history_rows.h: PackedRows)
 // PM: the tangent leaves as its 8 parameters per point (0 never, 1 always, 2 by kFlagTangentParams at run time; fcamd_kernels.hip: run_tile)
-template <bool IDX, int HIST, bool FULL, bool NT, int PM = 0>
+// TWIN: the synthetic twin (tangent_writers.h: kFlagTwin) -- ballots from a.cache3d, no constitutive arithmetic
+template <bool IDX, int HIST, bool FULL, bool NT, int PM = 0, bool TWIN = false>
 __device__ __forceinline__ void tile_von_mises(ArgsRef a, const StressBases& sb, const Tables* T, double* region,
                                                int* rows_lds, long long p0, int npts, int lane,
                                                WaveStats& st) {
@@ -136,8 +137,17 @@ __device__ __forceinline__ void tile_von_mises(ArgsRef a, const StressBases& sb,
     mandel_strain(g, a.sc.s[0], e);
 
     VMTrial tr;
-    vm_trial(a.sc, e, s, alpha_n, tr);
-    const bool plastic = live && (tr.phitr > 0.0);
+    bool plastic;
+    if constexpr (TWIN) {
+        const unsigned long long recorded = reinterpret_cast<const unsigned long long*>(a.cache3d)[p0 >> 6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tr.dsig[i] = e[i], tr.sigtr[i] = s[i];
+        tr.tr_eps = e[0], tr.sigtrn = 1.0, tr.phitr = 0.0;
+        plastic = live && ((recorded >> lane) & 1ull) != 0ull;
+    } else {
+        vm_trial(a.sc, e, s, alpha_n, tr);
+        plastic = live && (tr.phitr > 0.0);
+    }
     const unsigned long long mask = __ballot(plastic);
 
     // plastic-strain history: needed only by tiles with a plastic point (in place), or always
@@ -192,7 +202,15 @@ __device__ __forceinline__ void tile_von_mises(ArgsRef a, const StressBases& sb,
 
     VMReturn rm;
     if (mask != 0ull) {
-        if (plastic) vm_return(a.sc, tr, alpha_n, rm, st);
+        if constexpr (TWIN) {
+            if (plastic) {
+                rm.gamma = e[1];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) rm.N[i] = s[i];
+            }
+        } else {
+            if (plastic) vm_return(a.sc, tr, alpha_n, rm, st);
+        }
         st.plastic += (lane == 0) ? (unsigned long long)__popcll(mask) : 0ull;
     }
 
@@ -255,7 +273,10 @@ __device__ __forceinline__ void tile_von_mises(ArgsRef a, const StressBases& sb,
         vm_tangent_coefficients(a.sc, rm, B, C);
         publish_tangent_params(region, lane, B, C, rm.N);
         wave_sync();
-        if (tangent_params_mode<PM>(a))  // the host rebuilds the rows (fcamd_hosttangent.cpp)
+        if constexpr (TWIN && FULL && !IDX) {
+            if (tneed == ~0ull) tangent_const<false, true, NT>(T->a, sb.tan, p0, rows_lds, npts, lane, lane % 18);
+            else tangent_twin_passes<NT>(region, sb.tan + p0 * 36, lane, tneed, (a.flags & kFlagExactTangentRows) != 0, std::make_integer_sequence<int, 18>{});
+        } else if (tangent_params_mode<PM>(a))  // the host rebuilds the rows (fcamd_hosttangent.cpp)
             store_tangent_params<FULL, NT>(a, region, sb.tan, p0, npts, lane, mask);
         else
             tangent_mises<false, IDX, FULL, NT>(region, T->a, T->b, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);

@@ -90,6 +90,11 @@ constexpr int kFlagExactTangentRows = 16;
 // per tile cross PCIe instead of 288 per point; the host expands them with tangent_mises_chunk's own expression and gives every
 // elastic point the row that expression yields for an elastic point's parameters (one constant per law).
 constexpr int kFlagTangentParams = 32;
+// (library-internal, context option "twin_masks":) the launch is the SYNTHETIC TWIN of the packed sparse-protocol VonMises3D kernel: the
+// same loads and stores at the same addresses -- the plastic ballot of every tile is read from EvalArgs::cache3d (one word per tile,
+// recorded from a real evaluate of the same step) instead of computed -- and no constitutive arithmetic: what the memory system alone
+// takes for the step's request stream (bench.py: mem_floor_ms of the row resident_sparse_tangent).  The values it writes mean nothing.
+constexpr int kFlagTwin = 64;
 template <bool FULL>
 __device__ __forceinline__ unsigned long long sparse_tangent_need(ArgsRef a, unsigned long long need) {
     return (FULL && (a.flags & kFlagSparseTangent) != 0 && a.hmask != nullptr) ? need : ~0ull;
@@ -175,6 +180,23 @@ __device__ __forceinline__ void tangent_mises_passes(const double* tp, const dou
                                                      unsigned long long tneed, bool exact_rows, std::integer_sequence<int, K...>) {
     const ChunkLane cl = chunk_lane(lane);
     (tangent_mises_pass<COMFE, NT, MASKED, K>(tp, ta, tb, tile, lane, cl, tneed, exact_rows), ...);
+}
+
+// The request stream of the masked passes without their arithmetic (the synthetic twin of the sparse-tangent iteration, law_von_mises.h:
+// TWIN): the same chunks leave, each holding the two doubles at the head of its point's published parameters.
+template <bool NT, int K>
+__device__ __forceinline__ void tangent_twin_pass(const double* tp, double* tile, int lane, const ChunkLane& cl, unsigned long long tneed,
+                                                  bool exact_rows) {
+    const ChunkMap m = chunk_map<K>(cl);
+    const bool wanted = tangent_chunk_wanted(tneed, m.p, exact_rows);
+    char* dst = reinterpret_cast<char*>(tile) + K * (kWave * 16) + (unsigned)lane * 16u;
+    if (wanted) store_tangent16<NT>(reinterpret_cast<double*>(dst), *reinterpret_cast<const d2*>(tp + 10 * m.p));
+}
+template <bool NT, int... K>
+__device__ __forceinline__ void tangent_twin_passes(const double* tp, double* tile, int lane, unsigned long long tneed, bool exact_rows,
+                                                    std::integer_sequence<int, K...>) {
+    const ChunkLane cl = chunk_lane(lane);
+    (tangent_twin_pass<NT, K>(tp, tile, lane, cl, tneed, exact_rows), ...);
 }
 
 template <bool COMFE, bool IDX, bool FULL, bool NT>

@@ -576,3 +576,45 @@ def test_row_masked_access_leaves_identical_bits(kind, split):
         assert len(results[fill]) == len(results[0])
         for a, b in zip(results[fill], results[0]):
             assert torch.equal(a.view(torch.int64), b.view(torch.int64)), fill
+
+
+def test_synthetic_twin_reproduces_the_request_stream_bookkeeping():
+    """Context option "twin_masks" (csrc/fcamd_kernels.hip: evaluate_twin_kernel): the measurement device behind the bench row's
+    mem_floor_ms.  The twin of a packed sparse-protocol VonMises3D launch reads every tile's plastic ballot from a recording and must
+    leave the protocol words exactly as the real launch does: the same sparse-history mask, the same EVER masks of the trial copy."""
+    import fenics_constitutive_amd as fc
+    from fenics_constitutive_amd import _capi
+    from fenics_constitutive_amd.resident import ResidentState
+
+    n = 64 * 40_000  # above the batch kernel's size: the launch is the law's own kernel (the twin exists for that one)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    f = dict(dtype=torch.float64, device="cuda")
+
+    def grad():
+        g = torch.randn(9 * n, generator=gen, **f)
+        g.view(n, 9).mul_(torch.pow(10.0, torch.rand(n, generator=gen, **f) * 2.0 - 4.0)[:, None])
+        return g
+
+    law = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
+    st = ResidentState(law, n, history0={"eps_n": torch.zeros(6 * n, **f), "alpha": torch.rand(n, generator=gen, **f) * 0.02}, placement="torch")
+    st.evaluate(0.0, 1.0, grad())
+    st.update()
+    ga, gb = grad(), grad()
+    st.evaluate(0.0, 1.0, ga)
+    st.evaluate(0.0, 1.0, gb)
+    torch.cuda.synchronize()
+    mask_b, ever_b = st._mask.clone(), st._ever[1 - st._c].clone()
+    st.evaluate(0.0, 1.0, ga)
+    torch.cuda.synchronize()
+    assert not torch.equal(st._mask, mask_b)
+    ctx = law._handle(_capi.default_device()).ctx
+    ctx.set_option("twin_masks", mask_b.data_ptr())
+    try:
+        st.evaluate(0.0, 1.0, gb)  # the twin of iterate B after iterate A
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("twin_masks", 0)
+    assert torch.equal(st._mask, mask_b) and torch.equal(st._ever[1 - st._c], ever_b)
+    st.evaluate(0.0, 1.0, gb)  # real launches again (what the twin wrote into the trial arrays is overwritten where the protocol touches)
+    torch.cuda.synchronize()
+    assert torch.equal(st._mask, mask_b)
