@@ -523,6 +523,13 @@ def main():
             in_place_draws = list(wl.in_place_draws_ms)  # (the workload is freed before the line is assembled)
         except Exception as e:  # informational (e.g. no room for the second copy of the state)
             stage(f"in-place leg skipped: {type(e).__name__}: {e}")
+    # ... and what the memory system alone takes for the headline's request stream: the kernel's synthetic twin
+    mem_floor_ms = None
+    if world == 1:
+        try:
+            mem_floor_ms = wl.mem_floor(4)
+        except Exception as e:  # informational
+            stage(f"mem-floor leg skipped: {type(e).__name__}: {e}")
     leg_done("reference_layout_legs")
 
     # "achievable" next to "peak" (SURVEY 8d): a plain device copy over half of the tangent array
@@ -665,6 +672,12 @@ def main():
                                "allocation_draws_ms": in_place_draws,
                                "note": "same step as the reference's own call: law.evaluate(...) in place on the interface's arrays (reference layout, "
                                        "no protocol words) -- what a drop-in torch caller launches"}
+        if mem_floor_ms is not None:
+            out["roofline"]["mem_floor_ms"] = round(mem_floor_ms, 4)
+            out["roofline"]["kernel_over_mem_floor"] = round(kernel_avg_ms / mem_floor_ms, 4)
+            out["roofline"]["mem_floor_note"] = ("the dominant kernel's synthetic twin (evaluate_twin_kernel: the same loads and stores at the same addresses on "
+                                                 "the same buffers, the tiles' plastic ballots read from a recording of the real step, no constitutive "
+                                                 "arithmetic), 4 event-timed launches after the timed region: what the memory system alone takes")
         out["placement"] = dict(headline["vmm_info"] or {"mode": "hipmalloc_tuned" if headline["placement"] else "first"})
         if headline["placement"] is not None:
             out["placement"].update({"hipmalloc_tangent_" + k: v for k, v in headline["placement"].items()})

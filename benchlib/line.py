@@ -61,7 +61,7 @@ def compact_line(d, detail_path=None):
         "algorithmic_bytes_per_launch": alg,
         "kernel_ms_avg": rf.get("kernel_ms_avg"),
     }
-    for k in ("frac_first_allocation", "frac_worst_candidate", "frac_vmm_set", "stream_copy_GBs"):
+    for k in ("frac_first_allocation", "frac_worst_candidate", "frac_vmm_set", "stream_copy_GBs", "mem_floor_ms", "kernel_over_mem_floor"):
         if rf.get(k) is not None:
             line["roofline"][k] = rf[k]
     # the same step in the reference's forms: the sparse protocol on the reference's array layout, the plain in-place call of a

@@ -377,6 +377,39 @@ class Workload:
         self.launch_log.append([phase, steps])
         return [a.elapsed_time(b) for a, b in ev]
 
+    def mem_floor(self, launches=4):
+        """The headline kernel's SYNTHETIC TWIN, measured (the packed sparse-protocol VonMises3D launch only): the launches of the timed
+        region issued as evaluate_twin_kernel (context option "twin_masks", csrc/fcamd_kernels.hip) -- the same loads and stores at
+        the same addresses on the same buffers, every tile's plastic ballot read from a recording of the real step, no constitutive
+        arithmetic: what the memory system alone takes for the step's request stream.  Returns the average ms, or None."""
+        if not (self.packed and self.sparse and self.kind == "von_mises_3d" and self.hmask is not None):
+            return None
+        torch = self.torch
+        ctx = self.law._handle(self.device.index or 0).ctx
+        recorded = []
+        for i in (0, 1):  # the ballots of the two alternating iterates, as the real kernel leaves them in the mask array
+            self.launch(i)
+            torch.cuda.synchronize()
+            recorded.append(self.hmask.clone())
+        self.launch_log.append(["mem_floor_record", 2])
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches + 2)]
+        try:
+            for i, (a, b) in enumerate(ev):
+                ctx.set_option("twin_masks", recorded[i & 1].data_ptr())
+                a.record()
+                self.launch(i)
+                b.record()
+            torch.cuda.synchronize()
+        finally:
+            ctx.set_option("twin_masks", 0)
+        self.launch_log.append(["mem_floor_twin", launches + 2])
+        if not torch.equal(self.hmask, recorded[(launches + 1) & 1]):
+            return None  # the twin did not reproduce the step's ballots: no figure
+        ms = [a.elapsed_time(b) for a, b in ev][2:]
+        self.launch(0), self.launch(1)  # real launches again: the trial state is meaningful where the protocol touches it
+        self.launch_log.append(["mem_floor_resync", 2])
+        return sum(ms) / len(ms)
+
     def timed_in_place(self, steps, phase="in_place", sets=1):
         """The reference's own call, `law.evaluate(t, del_t, grad, stress, tangent, history)` IN PLACE on arrays in the interface's
         layout (models/interfaces.py:82-101) -- what a drop-in caller with device tensors launches.  The committed state is copied
