@@ -871,7 +871,7 @@ def main():
             # the default command stays under two minutes: what is left of 108 s goes to the two passes (each stops starting new
             # items when its half is used up: headline first, then its forms, the 8(f) rows, the configurations)
             # (counted from the end of the imports: a cold image pages torch in for a minute or two, which is nobody's to spend)
-            target = 240.0 if args.full else 118.0  # (the CPU baseline, ~14 s, now runs before the passes instead of beside them)
+            target = 240.0 if args.full else 150.0  # (the CPU baseline, ~14 s, now runs before the passes instead of beside them)
             pass_s = max(12.0, (target - (time.perf_counter() - t_start)) / 2.0 - 3.0)
             lt_all = live_traffic_batch(items, n, history, extra, min(150.0, budget_left() - 30.0), headline=name, pass_budget_s=pass_s) or {}
             lt = lt_all.get(name)

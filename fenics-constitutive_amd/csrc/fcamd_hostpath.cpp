@@ -548,10 +548,27 @@ template <class Launch>
 int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangent, fcamd_stats* stats, Launch&& launch) {
     fcamd_context* c = m->ctx;
     constexpr int nslots = fcamd_context::kSlots;
-    // chunks: at least ~8 per call so that the expansion overlaps the kernel, at most 1 Mi points (64 MiB of parameters per slot)
-    int64_t chunk = c->opt.host_tangent_chunk > 0 ? c->opt.host_tangent_chunk : std::max<int64_t>(1 << 15, std::min<int64_t>(1 << 20, (n / 8 + 63) / 64 * 64));
+    // Chunks.  The GPU is the slower side of the pipeline (VonMises3D at 1e7 points: 33 ms on the link against 16 x 17 ms of expansion),
+    // so a call takes the kernels' time plus the expansion of the LAST chunk.  Large chunks keep the launches efficient (every chunk
+    // boundary is a bubble of ~60 us on the link: 256 Ki-point chunks 267, 1 Mi-point chunks 300 Mpts/s) -- a quarter of the call, at most
+    // 1 Mi points (64 MiB of parameters per slot) -- and the last of them is cut in halves down to 64 Ki points, which the threads
+    // expand in 0.2 ms.
+    int64_t chunk = c->opt.host_tangent_chunk > 0 ? c->opt.host_tangent_chunk : std::max<int64_t>(1 << 15, std::min<int64_t>(1 << 20, (n / 4 + 63) / 64 * 64));
     chunk = std::max<int64_t>(64, chunk / 64 * 64);
     chunk = std::min<int64_t>(chunk, (n + 63) / 64 * 64);
+    std::vector<int64_t> start;  // chunk k = points [start[k], start[k + 1])
+    {
+        const int64_t taper_min = c->opt.host_tangent_chunk > 0 ? chunk : (1 << 16);
+        int64_t p = 0;
+        while (p < n) {
+            start.push_back(p);
+            const int64_t left = n - p;
+            int64_t take = chunk;
+            if (left <= chunk) take = left > 2 * taper_min ? (left / 2 + 63) / 64 * 64 : left;  // the tail: halves down to taper_min
+            p += std::min(take, left);
+        }
+        start.push_back(n);
+    }
     int st = host_tangent_ring(c, chunk, nslots);
     if (st != FCAMD_OK) return st;
     pool_begin(pool, host_tangent_job(m, tangent));
@@ -561,17 +578,18 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
     for (int i = 1; i < nstreams; ++i)
         if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
     if (nstreams > 1) HIP_TRY(hipStreamSynchronize(c->hstream[0]));  // the counters' reset (queued by the caller) before any chunk counts
-    const int64_t nchunks = (n + chunk - 1) / chunk;
+    const int64_t nchunks = (int64_t)start.size() - 1;
     std::vector<int> ticket((size_t)nchunks, -1);
     int64_t posted = 0;  // chunks [0, posted) have completed on the GPU and are with the pool
     const size_t slot_doubles = host_tangent_slot_doubles(chunk);
     auto slot_host = [&](int64_t k) { return reinterpret_cast<const double*>(c->tparams) + (size_t)(k % nslots) * slot_doubles; };
     auto slot_dev = [&](int64_t k) { return reinterpret_cast<double*>(c->tparams_dev) + (size_t)(k % nslots) * slot_doubles; };
+    auto points = [&](int64_t k) { return start[(size_t)k + 1] - start[(size_t)k]; };
     auto post = [&](int64_t k) {
-        const int64_t np = std::min<int64_t>(chunk, n - k * chunk);
+        const int64_t np = points(k);
         // the ballots of a launch of np points lie behind its 8 * roundup(np, 64) parameter doubles (tangent_writers.h: store_tangent_params)
         const unsigned long long* words = reinterpret_cast<const unsigned long long*>(slot_host(k) + 8 * ((np + 63) / 64 * 64));
-        ticket[(size_t)k] = pool_post(pool, k * chunk, np, slot_host(k), words);
+        ticket[(size_t)k] = pool_post(pool, start[(size_t)k], np, slot_host(k), words);
     };
     hipError_t err = hipSuccess;
     for (int64_t k = 0; k < nchunks && st == FCAMD_OK && err == hipSuccess; ++k) {
@@ -587,7 +605,7 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
             pool_wait(pool, ticket[(size_t)(k - nslots)]);
         }
         hipStream_t s = c->hstream[k % nstreams];
-        st = launch(k * chunk, std::min<int64_t>(chunk, n - k * chunk), slot_dev(k), s);
+        st = launch(start[(size_t)k], points(k), slot_dev(k), s);
         if (st == FCAMD_OK) err = hipEventRecord(c->tp_event[k % nslots], s);
     }
     if (st == FCAMD_OK && err == hipSuccess) {

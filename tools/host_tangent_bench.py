@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--threads", default="0,4,8,16")
     ap.add_argument("--chunks", default="0")
-    ap.add_argument("--streams", default="2", help="host_tangent_streams values to sweep")
+    ap.add_argument("--streams", default="1", help="host_tangent_streams values to sweep")
     ap.add_argument("--skip-pageable", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--laws", default="von_mises,linear_elasticity,maxwell")
