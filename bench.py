@@ -524,10 +524,12 @@ def main():
         except Exception as e:  # informational (e.g. no room for the second copy of the state)
             stage(f"in-place leg skipped: {type(e).__name__}: {e}")
     # ... and what the memory system alone takes for the headline's request stream: the kernel's synthetic twin
-    mem_floor_ms = None
+    mem_floor_ms = in_place_lines = None
     if world == 1:
         try:
             mem_floor_ms = wl.mem_floor(4)
+            if in_place_ms is not None:
+                in_place_lines = wl.in_place_line_bytes()
         except Exception as e:  # informational
             stage(f"mem-floor leg skipped: {type(e).__name__}: {e}")
     leg_done("reference_layout_legs")
@@ -670,6 +672,7 @@ def main():
             out["in_place"] = {"kernel_ms_avg": round(in_place_ms, 4),
                                "frac": round(alg_bytes / (in_place_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "allocation_draws_ms": in_place_draws,
+                               "line_bytes": in_place_lines,
                                "note": "same step as the reference's own call: law.evaluate(...) in place on the interface's arrays (reference layout, "
                                        "no protocol words) -- what a drop-in torch caller launches"}
         if mem_floor_ms is not None:
@@ -888,6 +891,11 @@ def main():
                 if lf is not None and key in out:
                     out[key]["traffic"] = lf["hbm_bytes_per_launch"]
                     out[key]["traffic_over_algorithmic"] = round(lf["hbm_bytes_per_launch"] / out["roofline"]["algorithmic_bytes_per_launch"], 4)
+                    lb = out[key].get("line_bytes")
+                    if lb:  # measured bytes over what the call must move at line / granule granularity (1.0: every line fetched is needed)
+                        out[key]["traffic_read_write"] = [lf["read_bytes"], lf["write_bytes"]]
+                        out[key]["read_over_needed_lines"] = round(lf["read_bytes"] / lb["read_bytes"], 4)
+                        out[key]["write_over_needed_granules"] = round(lf["write_bytes"] / lb["write_bytes"], 4)
             for cname, c in (out.get("configs") or {}).items():
                 lc = lt_all.get(cname)
                 if lc is not None and isinstance(c, dict) and c.get("algorithmic_bytes_per_launch"):

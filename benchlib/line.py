@@ -70,6 +70,8 @@ def compact_line(d, detail_path=None):
         leg = d.get(src_key)
         if isinstance(leg, dict) and leg.get("frac") is not None:
             line["roofline"][key] = leg["frac"]
+            if leg.get("read_over_needed_lines") is not None:  # in place: measured bytes over the lines / granules the call must move
+                line["roofline"][key + "_bytes_over_needed"] = [leg["read_over_needed_lines"], leg.get("write_over_needed_granules")]
     cb = d.get("cpu_baseline")
     if isinstance(cb, dict):
         line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),

@@ -392,6 +392,7 @@ class Workload:
             torch.cuda.synchronize()
             recorded.append(self.hmask.clone())
         self.launch_log.append(["mem_floor_record", 2])
+        self.recorded_ballots = recorded  # (in_place_line_bytes: the same step's plastic sets)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches + 2)]
         try:
             for i, (a, b) in enumerate(ev):
@@ -409,6 +410,35 @@ class Workload:
         self.launch(0), self.launch(1)  # real launches again: the trial state is meaningful where the protocol touches it
         self.launch_log.append(["mem_floor_resync", 2])
         return sum(ms) / len(ms)
+
+    def in_place_line_bytes(self):
+        """What the reference's in-place call MUST move at the memory system's granularity, from the step's recorded plastic sets
+        (mem_floor): the dense streams as they are, the 48-byte plastic-strain rows of the plastic points as the distinct 128-byte lines
+        their 64-byte granules lie in (reads; every read request of the L2 is one line) and as distinct 64-byte granules (writes), alpha
+        read whole and written per touched tile.  Average of the two alternating iterates.  (if the measured bytes of
+        the in-place call equal these, every line it fetches is needed -- the 3 % to the packed layout are the layout's.)"""
+        rec = getattr(self, "recorded_ballots", None)
+        if rec is None or self.kind != "von_mises_3d":
+            return None
+        t = self.torch
+        shifts = t.arange(64, device=self.device, dtype=t.int64)
+        reads = writes = 0.0
+        for mask in rec:
+            lines = granules = tiles = 0
+            for lo in range(0, mask.numel(), 1 << 16):  # bounded temporaries
+                part = mask[lo: lo + (1 << 16)]
+                bits = ((part[:, None] >> shifts[None, :]) & 1).bool()
+                tiles += int(bits.any(dim=1).sum())
+                pts = bits.nonzero()
+                p = (pts[:, 0] + lo) * 64 + pts[:, 1]  # plastic points of this part (ascending)
+                g = t.cat([(48 * p) // 64, (48 * p + 47) // 64])  # the granules a row lies in (one or two)
+                g = t.unique(g)
+                granules += int(g.numel())
+                lines += int(t.unique(g // 2).numel())
+            n = self.n
+            reads += n * (72 + 48 + 8) + 128.0 * lines
+            writes += n * (48 + 288) + 64.0 * granules + 512.0 * tiles
+        return {"read_bytes": reads / len(rec), "write_bytes": writes / len(rec)}
 
     def timed_in_place(self, steps, phase="in_place", sets=1):
         """The reference's own call, `law.evaluate(t, del_t, grad, stress, tangent, history)` IN PLACE on arrays in the interface's

@@ -205,7 +205,8 @@ def test_one_rank_under_the_launcher_with_rccl(tmp_path):
 
 def test_default_legs_at_small_size_carry_every_configuration_and_8f_row():
     """The driver's command shape (N = 1, no --workload) at 2e6 points: the line carries the five other BASELINE configurations
-    and every SURVEY 8(f) row, each with a kernel time, a roofline fraction and a launch log whose phases end with the timed one."""
+    and every SURVEY 8(f) row, each with a kernel time, a roofline fraction and a launch log whose phases end with the timed one (and, for the rows that have one,
+    the measurement of their synthetic twin: mem_floor_ms)."""
     from benchlib import frows
 
     r, out = run_bench("--points", "2000000", "--steps", "3", "--warmup", "1", "--config-steps", "5", "--no-cpu-baseline", "--no-host-path",
@@ -218,7 +219,8 @@ def test_default_legs_at_small_size_carry_every_configuration_and_8f_row():
         c = cfg[name]
         assert "error" not in c, (name, c)
         assert c["kernel_ms_avg"] > 0 and 0 < c["frac"] < 1.2, (name, c)
-        assert c["launch_log"] and c["launch_log"][-1][0] == "timed", (name, c["launch_log"])
+        phases = [ph for ph, _ in c["launch_log"]]  # ... end with the timed phase (rows with a synthetic twin: then its measurement)
+        assert "timed" in phases and all(ph.startswith("mem_floor_") for ph in phases[phases.index("timed") + 1:]), (name, c["launch_log"])
     assert set(frows.SURVEY_ROW) == set(frows.FROWS)
     # the compact line: one short list per configuration, columns named once
     from benchlib.line import CONFIG_COLUMNS
