@@ -929,6 +929,7 @@ int fcamd_evaluate_resident(fcamd_model* m, double t, double del_t, int64_t n, c
         hipStream_t s = c->hstream[0];
         if (has_sparse_history(m->law)) HIP_TRY(hipMemsetAsync(m->d_counters, 0, kCounterBytes, s));
         if (pool) {  // state on the device, gradient and stress over the link in place, the tangent rows from the CPU
+            if (z_stress) c->last_host_mode |= FCAMD_HOST_ZERO_COPY_OUT;  // (the stress is the kernel's own store into the caller's array)
             constants_for_call(m, del_t);
             auto launch = [&](int64_t p0, int64_t np, double* params, hipStream_t on) {
                 const double* hp[FCAMD_MAX_HISTORY] = {nullptr, nullptr};

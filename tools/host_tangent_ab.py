@@ -24,11 +24,12 @@ for x in (g, s, t, e, a):
     ctx.register_host_buffer(x)
 times = [[] for _ in cfgs]
 cpu = [[] for _ in cfgs]
-for rnd in range(8):
+for rnd in range(int(os.environ.get("AB_ROUNDS", "8"))):
     for k, c in enumerate(cfgs):
         ctx.set_option("host_tangent_threads", int(c.get("threads", -1)))
         ctx.set_option("host_tangent_chunk", int(c.get("chunk", 0)))
         ctx.set_option("host_tangent_streams", int(c.get("streams", 1)))
+        ctx.set_option("host_tangent_min_points", int(c.get("min", 65536)))
         s[:] = 0.0
         e[:] = 0.0
         a[:] = a0
