@@ -220,6 +220,7 @@ void release_registered_ranges(fcamd_context* c);
 constexpr int kFlagTangentParamsHost = 32;  // kernels/tangent_writers.h: kFlagTangentParams (library-internal bit of EvalArgs::flags)
 int host_tangent_kind(const fcamd_model* m);          // 0: the law keeps the kernel's tangent stores; else 1 + HostTangentJob::Kind
 int host_tangent_threads(const fcamd_context* c);     // resolved thread count (0: off)
+int host_tangent_threads_shared(int n_contexts);      // the automatic count of ONE of n contexts that work at the same time (fcamd_multi)
 bool host_tangent_applies(const fcamd_model* m, int64_t n, int flags);  // would a host entry of n points rebuild the tangent on the CPU?
 ExpandPool* host_tangent_pool(fcamd_context* c);      // the context's pool, created / resized on demand (nullptr: off)
 void host_tangent_release(fcamd_context* c);          // pool, ring and events (context destruction, option "trim")

@@ -249,20 +249,28 @@ static int cgroup_cpu_quota() {
 // process may run on less one for the calling thread, within the cgroup's CPU quota (more threads than that are throttled: 32 threads
 // under a quota of 16 CPUs took 1.3 - 12 x the CPU time of 16), at most 16 (a GPU's share of the cores of an 8-GPU host; VonMises3D at
 // 1e7 points: 4 / 8 / 16 threads 244 / 288 / 300 Mpts/s)
-int host_tangent_threads(const fcamd_context* c) {
-    const int opt = c->opt.host_tangent_threads;
-    if (opt >= 0) return std::min(opt, 256);
-    static const int automatic = [] {
+// the CPUs this process may keep busy: its affinity mask less the calling thread, within the cgroup's quota
+static int usable_cpus() {
+    static const int usable = [] {
         cpu_set_t set;
         int cpus = (int)std::thread::hardware_concurrency();
         if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
-        int n = std::min(16, cpus - 1);
+        int n = cpus - 1;
         const int quota = cgroup_cpu_quota();
         if (quota > 0) n = std::min(n, quota);
         return std::max(1, n);
     }();
-    return automatic;
+    return usable;
 }
+
+int host_tangent_threads(const fcamd_context* c) {
+    const int opt = c->opt.host_tangent_threads;
+    if (opt >= 0) return std::min(opt, 256);
+    return std::min(16, usable_cpus());
+}
+
+// one process driving n devices (fcamd_multi): every device's context expands its own slice at the same time
+int host_tangent_threads_shared(int n_contexts) { return std::max(1, std::min(16, usable_cpus() / std::max(1, n_contexts))); }
 
 bool host_tangent_applies(const fcamd_model* m, int64_t n, int flags) {
     const fcamd_context* c = m->ctx;

@@ -198,6 +198,8 @@ int fcamd_multi_create(const int* devices, int n_devices, int model_id, int cons
         Worker* w = mg->w[k].get();
         int s = fcamd_context_create(w->device, nullptr, &w->ctx);
         if (s != FCAMD_OK) return s;
+        // the expansion threads of the host tangent (fcamd_hosttangent.cpp): the devices of one process share the process's CPUs
+        if (w->ctx->opt.host_tangent_threads < 0) w->ctx->opt.host_tangent_threads = host_tangent_threads_shared(n_devices);
         return fcamd_model_create(w->ctx, model_id, constraint, p.data(), (int)p.size(), &w->model);
     });
     if (st != FCAMD_OK) {

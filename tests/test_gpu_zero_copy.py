@@ -337,7 +337,7 @@ def test_sparse_tangent_into_page_locked_host_array(law_name):
 
 
 @pytest.mark.parametrize("kind", ["von_mises_3d", "spring_maxwell"])
-def test_resident_scratch_path_in_chunks(kind):
+def test_resident_scratch_path_in_chunks(kind, request):
     """fcamd_evaluate_resident with host arrays that cannot be page-locked (the tangent array lies half inside a
     registered range) and do not fit one pass through the scratch: several chunks, the sparse-history mask words and the
     state rows of every chunk at the right offsets -- same numbers as the one-launch pass on pageable arrays."""
@@ -349,6 +349,10 @@ def test_resident_scratch_path_in_chunks(kind):
     ctx = law._handle(_capi.default_device()).ctx
     sa, ta = np.zeros(6 * n), own(np.full(36 * n, np.nan))
     sb, tb = np.zeros(6 * n), np.full(36 * n, np.nan)
+    # (the kernel writes the tangent here -- "host_tangent_threads" = 0: with the rows written by host threads a tangent array that
+    # cannot be page-locked is no obstacle at all, tests/test_gpu_host_tangent.py)
+    ctx.set_option("host_tangent_threads", 0)
+    request.addfinalizer(lambda: ctx.set_option("host_tangent_threads", -1))
     with Pinned(law, [ta[: 18 * n]]):
         for it, scale in enumerate((1.0, 0.3, 1.5)):
             gi = g * scale
