@@ -85,7 +85,7 @@ def bench_plan(args):
             extra_rows = args.workload is None and args.configs != "none"
             items = 3 + (5 if extra_rows else 0) + (10 if (extra_rows and not args.no_frows) else 0)
             legs.append(_leg("live_traffic", 2 * (IMPORT_S + 4.0 + items * (ALLOC_S_PER_GB * 0.8 * state_gb + 1.5)), state_gb,
-                             f"two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE), {items} items each; the CPU baseline runs on the host meanwhile"))
+                             f"two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE), {items} items each; the CPU baseline (~20 s, alone on the host) runs before them"))
         if not args.no_cpu_baseline:
             legs.append(_leg("cpu_baseline", 0.0 if not args.no_live_traffic else 14.0, 0.0, "C port, 1 thread, 2e6 points x 8 s + side figures (overlapped with the PMC passes)"))
     # what bench.py checks before it enters an optional leg: seconds that must be left of --wall-budget (all ranks agree by all-reduce)

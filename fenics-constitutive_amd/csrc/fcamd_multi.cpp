@@ -358,6 +358,7 @@ int fcamd_multi_get_option(const fcamd_multi* mg, const char* name, long long* v
     else if (std::strcmp(name, "last_host_mode") == 0) *value = mg->last_mode;
     else if (std::strcmp(name, "last_n_used") == 0) *value = mg->last_used;
     else if (std::strcmp(name, "min_points") == 0) *value = mg->min_points;
+    else if (!mg->w.empty()) return fcamd_context_get_option(mg->w[0]->ctx, name, value);  // a context option: what the first device's context holds
     else return fail(FCAMD_ERR_BAD_ARG, "unknown option '%s'", name);
     return FCAMD_OK;
 }

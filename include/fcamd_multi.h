@@ -115,7 +115,9 @@ FCAMD_API int fcamd_multi_evaluate_host(fcamd_multi* mg, double t, double del_t,
 FCAMD_API int fcamd_multi_register_host_buffer(fcamd_multi* mg, void* ptr, size_t bytes);
 /* Options.  set: an option of every context of the handle (fcamd_context_set_option), or the handle's own "min_points"
    (default FCAMD_MULTI_MIN_POINTS: a call over n points uses at most n / min_points devices).  get (read-only):
-   "n_devices"; "last_host_mode" (FCAMD_HOST_* flags of the last call, OR-ed over the devices used), "last_n_used". */
+   "n_devices"; "last_host_mode" (FCAMD_HOST_* flags of the last call, OR-ed over the devices used), "last_n_used"; any other name: the
+   option as the FIRST device's context holds it (fcamd_context_get_option).  A handle's contexts share the host's CPUs: their automatic
+   "host_tangent_threads" (fcamd.h) is the process's usable CPUs divided by the number of devices, at most 16 each. */
 FCAMD_API int fcamd_multi_set_option(fcamd_multi* mg, const char* name, long long value);
 FCAMD_API int fcamd_multi_get_option(const fcamd_multi* mg, const char* name, long long* value);
 

@@ -194,3 +194,63 @@ def test_ten_million_points(ctx, kind):
     assert_identical(kernel, cpu, f"{kind}/1e7")
     assert ctx.get_option("last_host_tangent_threads") == threads
     assert ctx.get_option("last_host_tangent_cpu_us") > 0
+
+
+def test_two_threads_two_contexts_expand_at_the_same_time():
+    """Every thread has a context of its own (thread-local), hence a pool and a parameter ring of its own: two threads inside their
+    host entries at the same time -- the same gradient array read by both -- give what each gives alone."""
+    import threading
+
+    n = 150_001
+    p, g, s, h = random_case("von_mises_3d", n, seed=77)
+    ref = {}
+
+    def run(tag, rounds):
+        ctx = _capi.get_context(_capi.default_device())  # this thread's
+        ctx.set_option("host_tangent_min_points", 0)
+        ctx.set_option("host_tangent_threads", 3)
+        ctx.set_option("host_tangent_chunk", 8192)
+        law = make_law("von_mises_3d", p)
+        out = None
+        for _ in range(rounds):
+            s1, t1 = s.copy(), np.full(36 * n, np.nan)
+            h1 = {k: v.copy() for k, v in h.items()}
+            law.evaluate(0.0, 1.0, g, s1, t1, h1)
+            assert ctx.last_host_mode() & HOST_TANGENT_CPU
+            if out is not None:
+                assert np.array_equal(bits(out[1]), bits(t1))
+            out = (s1, t1, h1)
+        ref[tag] = out
+
+    run("serial", 1)
+    threads = [threading.Thread(target=run, args=(f"t{k}", 6)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+        assert not th.is_alive(), "a host entry with the tangent rebuilt on the host hangs under concurrency"
+    for k in range(2):
+        got = ref[f"t{k}"]
+        assert np.array_equal(bits(got[0]), bits(ref["serial"][0])) and np.array_equal(bits(got[1]), bits(ref["serial"][1]))
+        for name in h:
+            assert np.array_equal(bits(got[2][name]), bits(ref["serial"][2][name]))
+
+
+def test_one_process_several_contexts_share_the_cpus():
+    """law.use_devices([...]) (fcamd_multi: one process, several device contexts, here on one GPU): every context expands the tangent of
+    its own slice with its share of the host's threads; the result is the single-context result bit for bit."""
+    n = 400_003
+    p, g, s, h = random_case("von_mises_3d", n, seed=12)
+    single = make_law("von_mises_3d", p)
+    s1, t1, h1 = s.copy(), np.full(36 * n, np.nan), {k: v.copy() for k, v in h.items()}
+    single.evaluate(0.0, 1.0, g, s1, t1, h1)
+    assert _capi.get_context(_capi.default_device()).last_host_mode() & HOST_TANGENT_CPU
+    multi = make_law("von_mises_3d", p).use_devices([0, 0, 0])
+    s2, t2, h2 = s.copy(), np.full(36 * n, np.nan), {k: v.copy() for k, v in h.items()}
+    multi.evaluate(0.0, 1.0, g, s2, t2, h2)
+    mode, used = multi._multi().last_host_mode()
+    assert used == 3 and (mode & HOST_TANGENT_CPU), (mode, used)
+    assert 1 <= multi._multi().get_option("host_tangent_threads") <= 16
+    assert np.array_equal(bits(t1), bits(t2)) and np.array_equal(bits(s1), bits(s2))
+    for k in h:
+        assert np.array_equal(bits(h1[k]), bits(h2[k]))
