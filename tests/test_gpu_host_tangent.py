@@ -196,7 +196,7 @@ def test_ten_million_points(ctx, kind):
     assert ctx.get_option("last_host_tangent_cpu_us") > 0
 
 
-def test_two_threads_two_contexts_expand_at_the_same_time():
+def test_two_threads_two_contexts_expand_at_the_same_time(ctx):  # (ctx: the main thread's options are restored afterwards)
     """Every thread has a context of its own (thread-local), hence a pool and a parameter ring of its own: two threads inside their
     host entries at the same time -- the same gradient array read by both -- give what each gives alone."""
     import threading
