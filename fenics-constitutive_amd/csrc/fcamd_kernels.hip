@@ -134,6 +134,12 @@ __device__ __forceinline__ void flush_stats(ArgsRef a, const WaveStats& st, int 
 // Waves per SIMD the register budget is cut for: 4 (128 VGPRs), 3 for the Drucker-Prager laws (their return mapping).  (The
 // indexed Maxwell kernel was cut for 3 as well while its per-lane stress rows spilled at 128; with the chunk-major rows it fits,
 // and 4 waves are worth 16 % to it: 6.24 -> 5.24 ms at 5e7 points on identical buffers.)
+// Build knob of the occupancy experiment (tools/build_variant.py three_waves -DFCAMD_EXTRA_LDS=12288): dynamic LDS that the kernels never
+// touch, so that only 3 workgroups (12 waves) fit a CU's 160 KiB instead of 4 -- the register budget alone does not lower the occupancy
+// of a kernel that needs fewer registers than it allows.
+#ifndef FCAMD_EXTRA_LDS
+#define FCAMD_EXTRA_LDS 0
+#endif
 template <int LAW, bool IDX>
 constexpr int kMinBlocks = LAW >= LAW_COMFE_DP ? 3 : 4;
 
@@ -382,7 +388,7 @@ __global__ void __launch_bounds__(kBlock) batch_zero_counters_kernel(const Batch
 template <int LAW, int SPARSE>
 static hipError_t launch_params(const EvalArgs& args, int grid, hipStream_t stream) {
     if (args.n >= kWave)
-        hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, SPARSE, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+        hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, SPARSE, true>), dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
     if (args.n % kWave != 0)
         hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false, SPARSE>), dim3(1), dim3(kWave), 0, stream, args);
     return hipGetLastError();
@@ -402,33 +408,33 @@ static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream)
     if constexpr (LAW == LAW_VM3D) {
         if ((args.flags & kFlagTwin) != 0) {  // the synthetic twin: full tiles of the packed sparse protocol only
             if (!args.hmask || args.rows || !(args.flags & kFlagPackedHistory) || !args.cache3d) return hipErrorInvalidValue;
-            if (args.n >= kWave) hipLaunchKernelGGL(evaluate_twin_kernel, dim3(grid), dim3(kBlock), 0, stream, args);
+            if (args.n >= kWave) hipLaunchKernelGGL(evaluate_twin_kernel, dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
             return hipGetLastError();
         }
         if (args.hmask && args.rows && (args.flags & kFlagPackedHistory)) {  // ... on the packed plastic-strain layout (local to the law)
             if (args.n >= kWave)
-                hipLaunchKernelGGL((evaluate_kernel<LAW, true, true, 2>), dim3(grid), dim3(kBlock), 0, stream, args);
+                hipLaunchKernelGGL((evaluate_kernel<LAW, true, true, 2>), dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
             if (args.n % kWave != 0)
                 hipLaunchKernelGGL((evaluate_tail_kernel<LAW, true, 2>), dim3(1), dim3(kWave), 0, stream, args);
             return hipGetLastError();
         }
         if (args.hmask && args.rows) {  // sparse trial history on a submesh (history is local, stress/tangent indexed)
             if (args.n >= kWave)
-                hipLaunchKernelGGL((evaluate_kernel<LAW, true, true, 1>), dim3(grid), dim3(kBlock), 0, stream, args);
+                hipLaunchKernelGGL((evaluate_kernel<LAW, true, true, 1>), dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
             if (args.n % kWave != 0)
                 hipLaunchKernelGGL((evaluate_tail_kernel<LAW, true, 1>), dim3(1), dim3(kWave), 0, stream, args);
             return hipGetLastError();
         }
         if (args.hmask && (args.flags & kFlagPackedHistory)) {  // sparse protocol on the packed plastic-strain layout
             if (args.n >= kWave)
-                hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, 2>), dim3(grid), dim3(kBlock), 0, stream, args);
+                hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, 2>), dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
             if (args.n % kWave != 0)
                 hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false, 2>), dim3(1), dim3(kWave), 0, stream, args);
             return hipGetLastError();
         }
         if (args.hmask) {  // sparse trial history
             if (args.n >= kWave)
-                hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, 1>), dim3(grid), dim3(kBlock), 0, stream, args);
+                hipLaunchKernelGGL((evaluate_kernel<LAW, true, false, 1>), dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
             if (args.n % kWave != 0)
                 hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false, 1>), dim3(1), dim3(kWave), 0, stream, args);
             return hipGetLastError();
@@ -436,13 +442,13 @@ static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream)
     }
     if (args.rows) {  // stress / tangent rows addressed through a parent-row index
         if (args.n >= kWave)
-            hipLaunchKernelGGL((evaluate_kernel<LAW, true, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+            hipLaunchKernelGGL((evaluate_kernel<LAW, true, true>), dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
         if (args.n % kWave != 0)
             hipLaunchKernelGGL((evaluate_tail_kernel<LAW, true>), dim3(1), dim3(kWave), 0, stream, args);
         return hipGetLastError();
     }
     if (args.n >= kWave) {
-        hipLaunchKernelGGL((evaluate_kernel<LAW, true, false>), dim3(grid), dim3(kBlock), 0, stream, args);
+        hipLaunchKernelGGL((evaluate_kernel<LAW, true, false>), dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
     }
     if (args.n % kWave != 0)
         hipLaunchKernelGGL((evaluate_tail_kernel<LAW, false>), dim3(1), dim3(kWave), 0, stream, args);
@@ -456,7 +462,7 @@ static hipError_t launch_lowdim(const EvalArgs& args, int grid, hipStream_t stre
             const long long npairs = (args.n / kWave) * (kWave / 2), per = kBlock * kUxTrips;
             hipLaunchKernelGGL((evaluate_uniaxial_kernel<LAW, true>), dim3((unsigned)((npairs + per - 1) / per)), dim3(kBlock), 0, stream, args);
         } else
-            hipLaunchKernelGGL((evaluate_lowdim_kernel<LAW, DIMS, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+            hipLaunchKernelGGL((evaluate_lowdim_kernel<LAW, DIMS, true>), dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
     }
     if (args.n % kWave != 0)
         hipLaunchKernelGGL((evaluate_lowdim_tail_kernel<LAW, DIMS>), dim3(1), dim3(kWave), 0, stream, args);
@@ -511,7 +517,7 @@ hipError_t launch_evaluate(int law, int dims, const EvalArgs& args, int grid, hi
 template <int LAW, int WRAP>
 static hipError_t launch_wrapped(const EvalArgs& args, int grid, hipStream_t stream) {
     if (args.n >= kWave)
-        hipLaunchKernelGGL((evaluate_wrapped_kernel<LAW, WRAP, true>), dim3(grid), dim3(kBlock), 0, stream, args);
+        hipLaunchKernelGGL((evaluate_wrapped_kernel<LAW, WRAP, true>), dim3(grid), dim3(kBlock), FCAMD_EXTRA_LDS, stream, args);
     if (args.n % kWave != 0)
         hipLaunchKernelGGL((evaluate_wrapped_tail_kernel<LAW, WRAP>), dim3(1), dim3(kWave), 0, stream, args);
     return hipGetLastError();
