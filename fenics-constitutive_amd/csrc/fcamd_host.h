@@ -65,7 +65,8 @@ struct Options {
 
 // One expansion job of the host tangent (fcamd_hosttangent.cpp): what to write into which array
 struct HostTangentJob {
-    enum Kind { CONST = 0, MISES = 1, MISES_COMFE = 2 } kind;
+    enum Kind { CONST = 0, MISES = 1, MISES_COMFE = 2, DRUCKER_PRAGER = 3 } kind;
+    int prm;                // doubles per plastic point the kernel sends: 8 (Mises laws: B, C, N[6]) or 12 (Drucker-Prager: 5 coefficients, flag, rho s_tr[6])
     int td;                 // doubles per tangent row: stress_strain_dim squared
     const double* table_a;  // Mises: the tables the kernel's tangent writer reads (Tables::a, ::b) ...
     const double* table_b;
@@ -225,11 +226,11 @@ bool host_tangent_applies(const fcamd_model* m, int64_t n, int flags);  // would
 ExpandPool* host_tangent_pool(fcamd_context* c);      // the context's pool, created / resized on demand (nullptr: off)
 void host_tangent_release(fcamd_context* c);          // pool, ring and events (context destruction, option "trim")
 HostTangentJob host_tangent_job(const fcamd_model* m, double* tangent);
-int host_tangent_ring(fcamd_context* c, int64_t chunk, int slots);
+int host_tangent_ring(fcamd_context* c, int64_t chunk, int slots, int prm);
 void pool_begin(ExpandPool* p, const HostTangentJob& job);
 int pool_post(ExpandPool* p, int64_t p0, int64_t np, const double* src, const unsigned long long* mask);  // -> ticket
 // doubles of one ring slot for chunks of `chunk` points (a multiple of 64): 8 per point + one ballot word per tile
-inline size_t host_tangent_slot_doubles(int64_t chunk) { return (size_t)chunk * 8 + (((size_t)chunk / 64 + 1) & ~(size_t)1); }  // (slots stay 16-byte aligned)
+inline size_t host_tangent_slot_doubles(int64_t chunk, int prm) { return (size_t)chunk * (size_t)prm + (((size_t)chunk / 64 + 1) & ~(size_t)1); }  // (slots stay 16-byte aligned)
 void pool_wait(ExpandPool* p, int ticket);
 void pool_finish(ExpandPool* p);
 double pool_busy_seconds(ExpandPool* p);

@@ -569,9 +569,11 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
         }
         start.push_back(n);
     }
-    int st = host_tangent_ring(c, chunk, nslots);
+    const HostTangentJob job = host_tangent_job(m, tangent);
+    const int prm = job.prm;
+    int st = host_tangent_ring(c, chunk, nslots, prm);
     if (st != FCAMD_OK) return st;
-    pool_begin(pool, host_tangent_job(m, tangent));
+    pool_begin(pool, job);
     // the chunks alternate between streams: the next chunk's first waves start while the previous chunk's last ones drain (over the
     // link a chunk boundary on ONE stream is a bubble of a few hundred microseconds; the chunks are independent, the counters atomic)
     const int nstreams = std::max(1, std::min(c->opt.host_tangent_streams, fcamd_context::kSlots));
@@ -581,14 +583,14 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
     const int64_t nchunks = (int64_t)start.size() - 1;
     std::vector<int> ticket((size_t)nchunks, -1);
     int64_t posted = 0;  // chunks [0, posted) have completed on the GPU and are with the pool
-    const size_t slot_doubles = host_tangent_slot_doubles(chunk);
+    const size_t slot_doubles = host_tangent_slot_doubles(chunk, prm);
     auto slot_host = [&](int64_t k) { return reinterpret_cast<const double*>(c->tparams) + (size_t)(k % nslots) * slot_doubles; };
     auto slot_dev = [&](int64_t k) { return reinterpret_cast<double*>(c->tparams_dev) + (size_t)(k % nslots) * slot_doubles; };
     auto points = [&](int64_t k) { return start[(size_t)k + 1] - start[(size_t)k]; };
     auto post = [&](int64_t k) {
         const int64_t np = points(k);
-        // the ballots of a launch of np points lie behind its 8 * roundup(np, 64) parameter doubles (tangent_writers.h: store_tangent_params)
-        const unsigned long long* words = reinterpret_cast<const unsigned long long*>(slot_host(k) + 8 * ((np + 63) / 64 * 64));
+        // the ballots of a launch of np points lie behind its prm * roundup(np, 64) parameter doubles (tangent_writers.h: store_tangent_params)
+        const unsigned long long* words = reinterpret_cast<const unsigned long long*>(slot_host(k) + (size_t)prm * (size_t)((np + 63) / 64 * 64));
         ticket[(size_t)k] = pool_post(pool, start[(size_t)k], np, slot_host(k), words);
     };
     hipError_t err = hipSuccess;

@@ -88,6 +88,39 @@ void expand_mises(const double* prm, const unsigned long long* mask, const doubl
     }
 }
 
+// Drucker-Prager: rows [p0, p1) from 12 doubles per plastic point (kernels/law_drucker_prager.h: tangent_dp_chunk -- the expressions below
+// are that function's); elastic points get the law's E table itself, as the kernel gives them (general.rs:131-135)
+template <bool NT>
+void expand_dp(const double* prm, const unsigned long long* mask, const double* t11tab, const double* pdtab, const double* etab,
+               double* tangent, int64_t p0, int64_t p1) {
+    for (int64_t t0 = p0; t0 < p1; t0 += 64) {
+        const unsigned long long word = mask[(t0 - p0) >> 6];
+        const int cnt = (int)std::min<int64_t>(64, p1 - t0);
+        for (int l = 0; l < cnt; ++l) {
+            double* row = tangent + 36 * (t0 + l);
+            const double* t = prm + 12 * (t0 + l - p0);
+            const bool plastic = ((word >> l) & 1ull) != 0ull && t[5] != 0.0;  // (the record's own flag: 1.0 for every point the kernel sends)
+            for (int i = 0; i < 6; ++i) {
+                const double oi = i < 3 ? 1.0 : 0.0;
+                for (int jj = 0; jj < 3; ++jj) {
+                    const int e = 6 * i + 2 * jj;
+                    v2 v;
+                    if (plastic) {
+                        const double c0x = t[0], c0y = t[1], c1x = t[2], c1y = t[3], ts1 = t[4];
+                        const double si = t[6 + i], sjx = t[6 + 2 * jj], sjy = t[7 + 2 * jj];
+                        v.x = (c0x * t11tab[e] + c0y * pdtab[e]) + ((c1x * si) * sjx + (c1y * oi) * sjx + (ts1 * si) * (jj < 2 ? 1.0 : 0.0));
+                        v.y = (c0x * t11tab[e + 1] + c0y * pdtab[e + 1]) + ((c1x * si) * sjy + (c1y * oi) * sjy + (ts1 * si) * (jj < 1 ? 1.0 : 0.0));
+                    } else {
+                        v.x = etab[e];
+                        v.y = etab[e + 1];
+                    }
+                    put2<NT>(row + e, v);
+                }
+            }
+        }
+    }
+}
+
 // tangent[td * p + k] = table[k] for p0 <= p < p1 (np.tile(D.flatten(), n)); td = 36, 16 or 1
 template <bool NT>
 void fill_const(const double* table, int td, double* tangent, int64_t p0, int64_t p1) {
@@ -144,7 +177,7 @@ class ExpandPool {
         for (int k = 0; k < parts; ++k) {
             // cut on whole tiles: one mask word per 64 points (and 64 rows are 288 whole 64-byte lines)
             const int64_t a = (np * k / parts) & ~(int64_t)63, b = (k + 1 == parts) ? np : ((np * (k + 1) / parts) & ~(int64_t)63);
-            tasks_.push_back({ticket, p0 + a, p0 + b, src ? src + 8 * a : nullptr, mask ? mask + (a >> 6) : nullptr});
+            tasks_.push_back({ticket, p0 + a, p0 + b, src ? src + (size_t)job_.prm * a : nullptr, mask ? mask + (a >> 6) : nullptr});
         }
         cv_work_.notify_all();
         return ticket;
@@ -187,6 +220,10 @@ class ExpandPool {
                 nt ? expand_mises<true, true>(t.src, t.mask, j.table_a, j.table_b, j.elastic_row, j.tangent, t.p0, t.p1)
                    : expand_mises<true, false>(t.src, t.mask, j.table_a, j.table_b, j.elastic_row, j.tangent, t.p0, t.p1);
                 break;
+            case HostTangentJob::DRUCKER_PRAGER:
+                nt ? expand_dp<true>(t.src, t.mask, j.table_a, j.table_b, j.table_c, j.tangent, t.p0, t.p1)
+                   : expand_dp<false>(t.src, t.mask, j.table_a, j.table_b, j.table_c, j.tangent, t.p0, t.p1);
+                break;
         }
         __builtin_ia32_sfence();  // the non-temporal stores are globally visible before the task counts as done
     }
@@ -219,7 +256,7 @@ class ExpandPool {
     long long busy_ns_ = 0;
 };
 
-// which laws the host can rebuild the tangent of (0: none -- the Drucker-Prager laws publish 11 doubles and keep the device path)
+// which laws the host can rebuild the tangent of (every law of the library; 0: none)
 int host_tangent_kind(const fcamd_model* m) {
     switch (m->law) {
         case FCAMD_LINEAR_ELASTICITY:
@@ -228,6 +265,8 @@ int host_tangent_kind(const fcamd_model* m) {
         case FCAMD_COMFE_LINEAR_ELASTICITY: return 1 + HostTangentJob::CONST;
         case FCAMD_VON_MISES_3D: return 1 + HostTangentJob::MISES;
         case FCAMD_COMFE_MISES_PLASTICITY: return 1 + HostTangentJob::MISES_COMFE;
+        case FCAMD_COMFE_DRUCKER_PRAGER:
+        case FCAMD_COMFE_DRUCKER_PRAGER_HYPERBOLIC: return 1 + HostTangentJob::DRUCKER_PRAGER;
         default: return 0;
     }
 }
@@ -313,11 +352,12 @@ HostTangentJob host_tangent_job(const fcamd_model* m, double* tangent) {
     HostTangentJob j{};
     j.kind = (HostTangentJob::Kind)(host_tangent_kind(m) - 1);
     j.td = m->dims.sd * m->dims.sd;
+    j.prm = j.kind == HostTangentJob::DRUCKER_PRAGER ? 12 : 8;
     j.table_a = m->tb.a;
     j.table_b = m->tb.b;
     j.table_c = m->tb.c;
     j.tangent = tangent;
-    if (j.kind != HostTangentJob::CONST) {
+    if (j.kind == HostTangentJob::MISES || j.kind == HostTangentJob::MISES_COMFE) {
         // what an elastic point publishes (law_von_mises.h: VMReturn's zeros through vm_tangent_coefficients; law_comfe_mises.h: cm_point)
         // expanded by the very function that expands the plastic points' parameters
         double prm[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -334,9 +374,9 @@ HostTangentJob host_tangent_job(const fcamd_model* m, double* tangent) {
     return j;
 }
 
-// the ring of page-locked parameter chunks: `slots` x (`chunk` points x 8 doubles + chunk / 64 ballot words), and one event per slot
-int host_tangent_ring(fcamd_context* c, int64_t chunk, int slots) {
-    const size_t bytes = (size_t)slots * host_tangent_slot_doubles(chunk) * sizeof(double);
+// the ring of page-locked parameter chunks: `slots` x (`chunk` points x `prm` doubles + chunk / 64 ballot words), and one event per slot
+int host_tangent_ring(fcamd_context* c, int64_t chunk, int slots, int prm) {
+    const size_t bytes = (size_t)slots * host_tangent_slot_doubles(chunk, prm) * sizeof(double);
     if (bytes > c->tparams_bytes) {
         if (c->tparams) HIP_TRY(hipHostFree(c->tparams));
         c->tparams = c->tparams_dev = nullptr;

@@ -72,9 +72,9 @@ __device__ __forceinline__ void run_tile(ArgsRef a, const StressBases& sb, const
     else if constexpr (LAW == LAW_VM3D)
         tile_von_mises<IDX, SPARSE, FULL, NT, PM, TWIN>(a, sb, T, region, rows_lds, p0, npts, lane, st);
     else if constexpr (LAW == LAW_COMFE_DP)
-        tile_comfe_dp<false, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0, st);
+        tile_comfe_dp<false, IDX, FULL, NT, PM>(a, sb, T, region, rows_lds, p0, npts, lane, r0, st);
     else if constexpr (LAW == LAW_COMFE_DP_HYPER)
-        tile_comfe_dp<true, IDX, FULL, NT>(a, sb, T, region, rows_lds, p0, npts, lane, r0, st);
+        tile_comfe_dp<true, IDX, FULL, NT, PM>(a, sb, T, region, rows_lds, p0, npts, lane, r0, st);
     else
         tile_comfe_mises<IDX, FULL, NT, PM>(a, sb, T, region, rows_lds, p0, npts, lane, st);
 }
@@ -396,7 +396,7 @@ static hipError_t launch_params(const EvalArgs& args, int grid, hipStream_t stre
 
 template <int LAW>
 static hipError_t launch_law(const EvalArgs& args, int grid, hipStream_t stream) {
-    if constexpr (LAW == LAW_VM3D || LAW == LAW_COMFE_MISES) {
+    if constexpr (LAW == LAW_VM3D || LAW == LAW_COMFE_MISES || LAW == LAW_COMFE_DP || LAW == LAW_COMFE_DP_HYPER) {
         if ((args.flags & kFlagTangentParams) != 0) {
             if (args.rows) return hipErrorInvalidValue;
             if constexpr (LAW == LAW_VM3D) {

@@ -267,7 +267,28 @@ __device__ __forceinline__ void dp_publish(double* region, int lane, const DPTan
     }
 }
 
-template <bool HYPER, bool IDX, bool FULL, bool NT>
+// kFlagTangentParams (host tangent, fcamd_hosttangent.cpp) for the Drucker-Prager laws: the plastic points of a tile leave as the first 12
+// doubles of their published record -- t11, tP, tss, t1s, ts1, the plastic flag, rho s_tr[6]: 96 bytes per point -- and the tile's
+// plastic ballot as one word behind the launch's 12 * roundup(n, 64) parameter doubles; elastic points get E on the host.
+constexpr int kDpParamDoubles = 12;
+template <bool FULL, bool NT>
+__device__ __forceinline__ void store_dp_params(ArgsRef a, const double* tp, double* params, long long p0, int npts, int lane,
+                                                unsigned long long plastic, bool published) {
+    double* tile = params + p0 * kDpParamDoubles;
+    if (published) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int q = k * kWave + lane;  // chunk q of the tile's parameter image: point q / 6, 16-byte part q % 6
+            const int pt = (int)(__umul24((unsigned)q, 10923u) >> 16);  // q / 6 for q < 384
+            const d2 v = *reinterpret_cast<const d2*>(tp + kDpStride * pt + 2 * (q - 6 * pt));
+            if ((FULL || q < 6 * npts) && ((plastic >> pt) & 1ull) != 0ull) store16<NT>(tile + 2 * q, v);
+        }
+    }
+    if (lane == 0) reinterpret_cast<unsigned long long*>(params + kDpParamDoubles * ((a.n + 63) & ~63ll))[p0 >> 6] = plastic;
+}
+
+// PM: the tangent leaves as parameters (0 never, 1 always, 2 by kFlagTangentParams at run time; fcamd_kernels.hip: run_tile)
+template <bool HYPER, bool IDX, bool FULL, bool NT, int PM = 0>
 __device__ __forceinline__ void tile_comfe_dp(ArgsRef a, const StressBases& sb, const Tables* T,
                                               double* region, int* rows_lds, long long p0, int npts, int lane,
                                               int r0, WaveStats& st) {
@@ -322,6 +343,11 @@ __device__ __forceinline__ void tile_comfe_dp(ArgsRef a, const StressBases& sb, 
         sparse_record(a, w, p0, 0ull, lane);
         const unsigned long long tneed = sparse_tangent_need<FULL>(a, touched);
         if (sb.tan && tneed != 0ull) {
+            if (tangent_params_mode<PM>(a)) {  // fully elastic tile: the ballot word alone (the host writes E into every row)
+                store_dp_params<FULL, NT>(a, region, sb.tan, p0, npts, lane, 0ull, false);
+                st.domain += (live && t.tip) ? 1ull : 0ull;
+                return;
+            }
             if constexpr (IDX) wave_sync();
             if (tneed == ~0ull)
                 tangent_const<IDX, FULL, NT>(T->c, sb.tan, p0, rows_lds, npts, lane, r0);
@@ -357,7 +383,10 @@ __device__ __forceinline__ void tile_comfe_dp(ArgsRef a, const StressBases& sb, 
     if (sb.tan && tneed != 0ull) {
         dp_publish(region, lane, tg, t.s_tr, plastic);
         wave_sync();
-        tangent_dp<IDX, FULL, NT>(region, T->a, T->b, T->c, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
+        if (tangent_params_mode<PM>(a))
+            store_dp_params<FULL, NT>(a, region, sb.tan, p0, npts, lane, mask, true);
+        else
+            tangent_dp<IDX, FULL, NT>(region, T->a, T->b, T->c, sb.tan, p0, rows_lds, npts, lane, tneed, (a.flags & kFlagExactTangentRows) != 0);
         wave_sync();
     }
 }

@@ -440,7 +440,8 @@ FCAMD_API int fcamd_device_free(fcamd_context* ctx, void* ptr);
        "host_tangent_streams" (FCAMD_HOST_TANGENT_STREAMS, 1): streams the chunk launches alternate between (2 helps chunks of
        256 Ki points and less, 1 is best at the automatic size);
        "last_host_tangent_cpu_us" / "last_host_tangent_threads" (get only): summed busy time and number of the expansion threads in
-       the context's last host entry (0: the kernel wrote the tangent).  The Drucker-Prager laws keep the kernel's stores.
+       the context's last host entry (0: the kernel wrote the tangent).  The Drucker-Prager laws send 12 doubles per plastic point (the five
+       coefficients of their isotropic tangent form, the plastic flag, rho s_tr) and the ballots; elastic points get elastic_tangent() itself.
    "grid": the launch grid (number of 256-thread workgroups; 0 = automatic);
    "timing": 1 = every fcamd_evaluate_device_ex is bracketed by HIP events on the context's stream and every host entry
        by a wall clock; fcamd_model_last_stats reports the time (fcamd_stats.kernel_ms) -- the counterpart of the

@@ -254,3 +254,42 @@ def test_one_process_several_contexts_share_the_cpus():
     assert np.array_equal(bits(t1), bits(t2)) and np.array_equal(bits(s1), bits(s2))
     for k in h:
         assert np.array_equal(bits(h1[k]), bits(h2[k]))
+
+
+@pytest.mark.parametrize("n", [70_001, 300_000])
+@pytest.mark.parametrize("hyper", [False, True])
+def test_drucker_prager_laws(ctx, hyper, n):
+    """The Drucker-Prager laws (comfe-rs general return mapping): the kernel sends 12 doubles per plastic point -- the five coefficients of
+    the isotropic tangent form, the flag, rho s_tr -- and the tile's ballot; elastic points get elastic_tangent() itself."""
+    from test_gpu_drucker_prager import make
+    from test_oracle_golden import dp_inputs
+
+    ctx.set_option("host_tangent_min_points", 0)
+    ctx.set_option("bounce_max", 0)
+    ctx.set_option("host_tangent_chunk", 8192 if n < 100_000 else 0)
+    law, _ = make(hyper)
+    g, s0, h0 = dp_inputs(n, n + 3)
+    kernel, cpu = both_ways(ctx, law, 1.0, g, s0, h0)
+    assert_identical(kernel, cpu, f"drucker_prager hyper={hyper} n={n}")
+    assert 0 < cpu[4].n_plastic < n
+
+
+def test_drucker_prager_resident_entry(ctx):
+    from fenics_constitutive_amd.resident import ResidentState
+    from test_gpu_drucker_prager import make
+    from test_oracle_golden import dp_inputs
+
+    ctx.set_option("host_tangent_min_points", 0)
+    ctx.set_option("bounce_max", 0)
+    n = 90_005
+    g, s0, h0 = dp_inputs(n, 11)
+    outs = []
+    for th in (0, 3):
+        ctx.set_option("host_tangent_threads", th)
+        law, _ = make(True)
+        st = ResidentState(law, n, stress0=s0, history0=h0, sparse_tangent=False, placement="torch")
+        so, to = np.full(6 * n, np.nan), np.full(36 * n, np.nan)
+        st.evaluate_into(0.0, 1.0, g, so, to)
+        outs.append((so, to, ctx.last_host_mode()))
+    assert not (outs[0][2] & HOST_TANGENT_CPU) and (outs[1][2] & HOST_TANGENT_CPU)
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0])) and np.array_equal(bits(outs[0][1]), bits(outs[1][1]))
