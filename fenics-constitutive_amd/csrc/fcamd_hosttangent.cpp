@@ -170,7 +170,8 @@ class ExpandPool {
     // points [p0, p0 + np) are ready (p0 a multiple of 64): `src` = their 8 doubles per point, `mask` = their tiles' plastic ballots
     // (Mises kinds; unused for the constant fill).  Returns the ticket of the chunk for wait().
     int post(int64_t p0, int64_t np, const double* src, const unsigned long long* mask) {
-        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(threads(), np / kMinPart));
+        // four tasks per thread and chunk: a thread that another tenant of the host slows down delays a sixty-fourth of a chunk, not a sixteenth
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)threads(), np / kMinPart));
         std::lock_guard<std::mutex> g(mu_);
         const int ticket = (int)left_.size();
         left_.push_back(parts);
@@ -302,14 +303,23 @@ static int usable_cpus() {
     return usable;
 }
 
+// Fewer threads than this cannot keep up with the link: one thread expands 32-41 Mpts/s of VonMises3D rows (70-140 of constant rows),
+// the kernel's own tangent stores over PCIe give the whole call 135 Mpts/s -- with four threads the two are even.  A process that may
+// use fewer CPUs (an MPI rank bound to one or two cores) keeps the kernel's stores unless the option asks for threads explicitly.
+constexpr int kMinAutoThreads = 6;
+
 int host_tangent_threads(const fcamd_context* c) {
     const int opt = c->opt.host_tangent_threads;
     if (opt >= 0) return std::min(opt, 256);
-    return std::min(16, usable_cpus());
+    const int n = std::min(16, usable_cpus());
+    return n >= kMinAutoThreads ? n : 0;
 }
 
 // one process driving n devices (fcamd_multi): every device's context expands its own slice at the same time
-int host_tangent_threads_shared(int n_contexts) { return std::max(1, std::min(16, usable_cpus() / std::max(1, n_contexts))); }
+int host_tangent_threads_shared(int n_contexts) {
+    const int n = std::min(16, usable_cpus() / std::max(1, n_contexts));
+    return n >= kMinAutoThreads ? n : 0;
+}
 
 bool host_tangent_applies(const fcamd_model* m, int64_t n, int flags) {
     const fcamd_context* c = m->ctx;

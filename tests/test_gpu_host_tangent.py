@@ -187,8 +187,7 @@ def test_ten_million_points(ctx, kind):
     expansion's CPU time is reported"""
     n = 10_000_000
     p, g, s, h = random_case(kind, n, seed=21)
-    threads = ctx.get_option("host_tangent_threads")
-    assert threads >= 1
+    threads = ctx.get_option("host_tangent_threads") or 4  # (0 = a box that grants this process fewer than 7 CPUs: the automatic choice is "off")
     law = make_law(kind, p)
     kernel, cpu = both_ways(ctx, law, 1.0, g, s, h, threads=threads)
     assert_identical(kernel, cpu, f"{kind}/1e7")
@@ -236,21 +235,24 @@ def test_two_threads_two_contexts_expand_at_the_same_time(ctx):  # (ctx: the mai
             assert np.array_equal(bits(got[2][name]), bits(ref["serial"][2][name]))
 
 
-def test_one_process_several_contexts_share_the_cpus():
+def test_one_process_several_contexts_share_the_cpus(ctx):
     """law.use_devices([...]) (fcamd_multi: one process, several device contexts, here on one GPU): every context expands the tangent of
     its own slice with its share of the host's threads; the result is the single-context result bit for bit."""
     n = 400_003
     p, g, s, h = random_case("von_mises_3d", n, seed=12)
     single = make_law("von_mises_3d", p)
     s1, t1, h1 = s.copy(), np.full(36 * n, np.nan), {k: v.copy() for k, v in h.items()}
+    ctx.set_option("host_tangent_threads", 3)
     single.evaluate(0.0, 1.0, g, s1, t1, h1)
-    assert _capi.get_context(_capi.default_device()).last_host_mode() & HOST_TANGENT_CPU
+    assert ctx.last_host_mode() & HOST_TANGENT_CPU
     multi = make_law("von_mises_3d", p).use_devices([0, 0, 0])
+    auto = multi._multi().get_option("host_tangent_threads")  # the usable CPUs shared by three contexts: 0 (too few to keep up) or 6 .. 16 each
+    assert auto == 0 or 6 <= auto <= 16, auto
+    multi._multi().set_option("host_tangent_threads", 3)
     s2, t2, h2 = s.copy(), np.full(36 * n, np.nan), {k: v.copy() for k, v in h.items()}
     multi.evaluate(0.0, 1.0, g, s2, t2, h2)
     mode, used = multi._multi().last_host_mode()
     assert used == 3 and (mode & HOST_TANGENT_CPU), (mode, used)
-    assert 1 <= multi._multi().get_option("host_tangent_threads") <= 16
     assert np.array_equal(bits(t1), bits(t2)) and np.array_equal(bits(s1), bits(s2))
     for k in h:
         assert np.array_equal(bits(h1[k]), bits(h2[k]))
