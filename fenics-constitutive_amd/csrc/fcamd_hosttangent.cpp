@@ -285,11 +285,10 @@ static int cgroup_cpu_quota() {
     return quota > 0 ? (int)((quota + period - 1) / period) : 0;
 }
 
-// threads of the expansion for this context: option "host_tangent_threads" (FCAMD_HOST_TANGENT_THREADS); -1 = automatic: the CPUs this
-// process may run on less one for the calling thread, within the cgroup's CPU quota (more threads than that are throttled: 32 threads
-// under a quota of 16 CPUs took 1.3 - 12 x the CPU time of 16), at most 16 (a GPU's share of the cores of an 8-GPU host; VonMises3D at
-// 1e7 points: 4 / 8 / 16 threads 244 / 288 / 300 Mpts/s)
-// the CPUs this process may keep busy: its affinity mask less the calling thread, within the cgroup's quota
+// Threads of the expansion for a context: option "host_tangent_threads" (FCAMD_HOST_TANGENT_THREADS); -1 = automatic: the CPUs this
+// process may keep busy -- its affinity mask less the calling thread, within the cgroup's CPU quota (more threads than that are throttled:
+// 32 threads under a quota of 16 CPUs took 1.3 - 12 x the CPU time of 16) --, at most 16 (a GPU's share of the cores of an 8-GPU host;
+// VonMises3D at 1e7 points: 4 / 8 / 16 threads 244 / 288 / 300 Mpts/s).
 static int usable_cpus() {
     static const int usable = [] {
         cpu_set_t set;
