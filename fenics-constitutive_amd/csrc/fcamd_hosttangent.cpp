@@ -170,8 +170,13 @@ class ExpandPool {
     // points [p0, p0 + np) are ready (p0 a multiple of 64): `src` = their 8 doubles per point, `mask` = their tiles' plastic ballots
     // (Mises kinds; unused for the constant fill).  Returns the ticket of the chunk for wait().
     int post(int64_t p0, int64_t np, const double* src, const unsigned long long* mask) {
-        // four tasks per thread and chunk: a thread that another tenant of the host slows down delays a sixty-fourth of a chunk, not a sixteenth
-        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)threads(), np / kMinPart));
+        // up to four tasks per thread and chunk (a thread that another tenant of the host slows down delays a sixty-fourth of a chunk,
+        // not a sixteenth), none smaller than kMinPart points: a small call wakes few threads -- waking a sleeping thread costs 50-300 us
+        // on this host, sixteen of them for 64 Ki points cost more than the rows they write (LE, 65 536 points: 0.65 ms with 16 threads
+        // woken, 0.48 ms with 4, 0.52 ms with the kernel's own tangent stores)
+        // (the chunks of the parameter pipeline are small by design and follow each other within a millisecond: every thread takes part)
+        const int64_t min_part = job_.kind == HostTangentJob::CONST ? kMinPart : kMinPartPipeline;
+        const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)threads(), np / min_part));
         std::lock_guard<std::mutex> g(mu_);
         const int ticket = (int)left_.size();
         left_.push_back(parts);
@@ -180,7 +185,9 @@ class ExpandPool {
             const int64_t a = (np * k / parts) & ~(int64_t)63, b = (k + 1 == parts) ? np : ((np * (k + 1) / parts) & ~(int64_t)63);
             tasks_.push_back({ticket, p0 + a, p0 + b, src ? src + (size_t)job_.prm * a : nullptr, mask ? mask + (a >> 6) : nullptr});
         }
-        cv_work_.notify_all();
+        if (parts >= threads()) cv_work_.notify_all();
+        else
+            for (int k = 0; k < parts; ++k) cv_work_.notify_one();
         return ticket;
     }
     void wait(int ticket) {
@@ -201,7 +208,8 @@ class ExpandPool {
     }
 
   private:
-    static constexpr int64_t kMinPart = 2048;  // points per task at least (0.6 MB of rows)
+    static constexpr int64_t kMinPart = 16384;         // points per task at least (4.7 MB of rows): the one-shot fill of a constant tangent
+    static constexpr int64_t kMinPartPipeline = 2048;  // ... of a chunk of the parameter pipeline (VonMises3D, 131 072 points: 200 Mpts/s; with 16 384: 110)
     struct Task {
         int ticket;
         int64_t p0, p1;
@@ -322,7 +330,11 @@ int host_tangent_threads_shared(int n_contexts) {
 
 bool host_tangent_applies(const fcamd_model* m, int64_t n, int flags) {
     const fcamd_context* c = m->ctx;
-    if (!c->opt.zero_copy || n < c->opt.host_tangent_min_points || n < 64 || host_tangent_kind(m) == 0) return false;
+    const int kind = host_tangent_kind(m);
+    // the one-shot fill of a constant tangent pays off from half the size at which the parameter pipeline does (measured, 16 threads:
+    // LE 2.1 x at 32 768 points; VonMises3D even at 32 768, 1.4 x at 65 536)
+    const long long min_points = kind == 1 + HostTangentJob::CONST ? c->opt.host_tangent_min_points / 2 : c->opt.host_tangent_min_points;
+    if (!c->opt.zero_copy || n < min_points || n < 64 || kind == 0) return false;
     if ((flags & FCAMD_EVAL_SPARSE_TANGENT) || (flags != 0 && m->dims.gdim != 3)) return false;
     return host_tangent_threads(c) > 0;
 }

@@ -15,7 +15,8 @@ n = int(float(sys.argv[1]))
 cfgs = [dict(kv.split("=") for kv in a.split(",")) for a in sys.argv[2:]]
 rng = np.random.default_rng(3)
 ctx = _capi.get_context(_capi.default_device())
-law = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0})
+LAW = os.environ.get("AB_LAW", "vm")  # vm | le
+law = fc.VonMises3D({"p_ka": 175000.0, "p_mu": 80769.0, "p_y0": 1200.0, "p_y00": 2500.0, "p_w": 200.0}) if LAW == "vm" else fc.LinearElasticityModel({"E": 42.0, "nu": 0.3}, fc.StressStrainConstraint.FULL)
 g = rng.standard_normal(9 * n)
 g *= np.repeat(10.0 ** (rng.random(n) * 2.0 - 4.0), 9)
 a0 = rng.random(n) * 0.02
@@ -34,7 +35,7 @@ for rnd in range(int(os.environ.get("AB_ROUNDS", "8"))):
         e[:] = 0.0
         a[:] = a0
         t0 = time.perf_counter()
-        law.evaluate(0.0, 1.0, g, s, t, {"eps_n": e, "alpha": a})
+        law.evaluate(0.0, 1.0, g, s, t, {"eps_n": e, "alpha": a} if LAW == "vm" else None)
         dt = time.perf_counter() - t0
         if rnd >= 2:
             times[k].append(dt)
