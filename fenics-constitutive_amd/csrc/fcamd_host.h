@@ -141,7 +141,8 @@ struct fcamd_context {
     char* tparams = nullptr;
     char* tparams_dev = nullptr;
     size_t tparams_bytes = 0;
-    hipEvent_t tp_event[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kTangentSlots = 16;  // chunks of the parameter ring the GPU may run ahead of the expansion
+    hipEvent_t tp_event[kTangentSlots] = {};
     long long last_host_tangent_cpu_us = 0;  // summed busy time of the expansion threads in the last host call (0: kernel-written tangent)
     int last_host_tangent_threads = 0;
 };

@@ -547,13 +547,14 @@ int run_const_tangent(fcamd_model* m, ExpandPool* pool, int64_t n, double* tange
 template <class Launch>
 int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangent, fcamd_stats* stats, Launch&& launch) {
     fcamd_context* c = m->ctx;
-    constexpr int nslots = fcamd_context::kSlots;
     // Chunks.  The GPU is the slower side of the pipeline (VonMises3D at 1e7 points: 33 ms on the link against 16 x 17 ms of expansion),
-    // so a call takes the kernels' time plus the expansion of the LAST chunk.  Large chunks keep the launches efficient (every chunk
-    // boundary is a bubble of ~60 us on the link: 256 Ki-point chunks 267, 1 Mi-point chunks 300 Mpts/s) -- a quarter of the call, at most
-    // 1 Mi points (64 MiB of parameters per slot) -- and the last of them is cut in halves down to 64 Ki points, which the threads
-    // expand in 0.2 ms.
-    int64_t chunk = c->opt.host_tangent_chunk > 0 ? c->opt.host_tangent_chunk : std::max<int64_t>(1 << 15, std::min<int64_t>(1 << 20, (n / 4 + 63) / 64 * 64));
+    // so a call takes the kernels' time plus the expansion of the LAST chunk (2.3 ns per point of it) plus what the chunk boundaries cost:
+    // a kernel's last waves drain over the link before the next kernel of the stream may start -- ~150 us per boundary at 1e7 points
+    // (38 chunks of 256 Ki points 37.7 ms, 10 of 1 Mi 33.4 ms, same run-ahead), nothing measurable at 1e6 (chunks of 64 Ki / 128 Ki /
+    // 256 Ki points: 4.02 / 4.17 / 4.28 ms: there the tail decides).  So: a twelfth of the call, 64 Ki .. 1 Mi points, the last chunk cut
+    // in halves down to 64 Ki points; and as many ring slots as 256 MiB of page-locked memory hold (4 .. 16): the GPU runs that far
+    // ahead of the expansion when a thread of the pool is held up by another tenant of the host.
+    int64_t chunk = c->opt.host_tangent_chunk > 0 ? c->opt.host_tangent_chunk : std::max<int64_t>(1 << 16, std::min<int64_t>(1 << 20, (n / 12 + 63) / 64 * 64));
     chunk = std::max<int64_t>(64, chunk / 64 * 64);
     chunk = std::min<int64_t>(chunk, (n + 63) / 64 * 64);
     std::vector<int64_t> start;  // chunk k = points [start[k], start[k + 1])
@@ -571,12 +572,13 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
     }
     const HostTangentJob job = host_tangent_job(m, tangent);
     const int prm = job.prm;
+    const int nslots = (int)std::max<int64_t>(4, std::min<int64_t>(fcamd_context::kTangentSlots, ((int64_t)256 << 20) / (chunk * prm * 8)));
     int st = host_tangent_ring(c, chunk, nslots, prm);
     if (st != FCAMD_OK) return st;
     pool_begin(pool, job);
     // the chunks alternate between streams: the next chunk's first waves start while the previous chunk's last ones drain (over the
     // link a chunk boundary on ONE stream is a bubble of a few hundred microseconds; the chunks are independent, the counters atomic)
-    const int nstreams = std::max(1, std::min(c->opt.host_tangent_streams, fcamd_context::kSlots));
+    const int nstreams = std::max(1, std::min(c->opt.host_tangent_streams, fcamd_context::kSlots));  // (hstream[] has kSlots entries)
     for (int i = 1; i < nstreams; ++i)
         if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
     if (nstreams > 1) HIP_TRY(hipStreamSynchronize(c->hstream[0]));  // the counters' reset (queued by the caller) before any chunk counts

@@ -353,7 +353,7 @@ ExpandPool* host_tangent_pool(fcamd_context* c) {
 void host_tangent_release(fcamd_context* c) {
     delete c->pool;
     c->pool = nullptr;
-    for (int i = 0; i < fcamd_context::kSlots; ++i) {
+    for (int i = 0; i < fcamd_context::kTangentSlots; ++i) {
         if (c->tp_event[i]) (void)hipEventDestroy(c->tp_event[i]);
         c->tp_event[i] = nullptr;
     }

@@ -437,8 +437,8 @@ FCAMD_API int fcamd_device_free(fcamd_context* ctx, void* ptr);
        (a rank bound to one or two cores cannot expand as fast as the link delivers); reading the option returns the resolved count.
        "host_tangent_min_points" (FCAMD_HOST_TANGENT_MIN, 65536): smaller calls keep the kernel's tangent stores (laws with a constant
        tangent: half of it, 32768 -- their one-shot fill pays off earlier than the parameter pipeline);
-       "host_tangent_chunk" (FCAMD_HOST_TANGENT_CHUNK, 0 = automatic: n / 4, 32 Ki .. 1 Mi points, the last chunk cut in halves down to
-       64 Ki points): points per chunk of the parameter ring (a value: uniform chunks of that size);
+       "host_tangent_chunk" (FCAMD_HOST_TANGENT_CHUNK, 0 = automatic: n / 12, 64 Ki .. 1 Mi points, the last chunk cut in halves down to
+       64 Ki points): points per chunk of the parameter ring (4 .. 16 slots, at most 256 MiB page-locked; a value: uniform chunks of that size);
        "host_tangent_streams" (FCAMD_HOST_TANGENT_STREAMS, 1): streams the chunk launches alternate between (2 helps chunks of
        256 Ki points and less, 1 is best at the automatic size);
        "last_host_tangent_cpu_us" / "last_host_tangent_threads" (get only): summed busy time and number of the expansion threads in
