@@ -540,10 +540,10 @@ int run_const_tangent(fcamd_model* m, ExpandPool* pool, int64_t n, double* tange
     return st;
 }
 
-// Mises laws: the kernel stores 8 doubles per point into a ring of page-locked chunks (kFlagTangentParams); the pool expands chunk k
-// while the GPU works on the chunks behind it.  `launch(p0, np, params)` enqueues the kernel of one chunk on hstream[0].  All HIP
-// calls stay on the calling thread: it posts a chunk to the pool when the chunk's event has completed and reuses a slot when the
-// pool has expanded what the slot held.
+// Plasticity laws: the kernel stores the tangent parameters of the plastic points (8 doubles, Drucker-Prager: 12) and every tile's
+// ballot into a ring of page-locked chunks (kFlagTangentParams); the pool expands chunk k while the GPU works on the chunks behind it.
+// `launch(p0, np, params, stream)` enqueues the kernel of one chunk.  All HIP calls stay on the calling thread: it posts a chunk to
+// the pool when the chunk's event has completed and reuses a slot when the pool has expanded what the slot held.
 template <class Launch>
 int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangent, fcamd_stats* stats, Launch&& launch) {
     fcamd_context* c = m->ctx;
@@ -576,8 +576,9 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
     int st = host_tangent_ring(c, chunk, nslots, prm);
     if (st != FCAMD_OK) return st;
     pool_begin(pool, job);
-    // the chunks alternate between streams: the next chunk's first waves start while the previous chunk's last ones drain (over the
-    // link a chunk boundary on ONE stream is a bubble of a few hundred microseconds; the chunks are independent, the counters atomic)
+    // option "host_tangent_streams" > 1: the chunks alternate between streams (they are independent, the counters atomic).  Measured: it
+    // helps chunks of 256 Ki points and less and loses at the automatic sizes -- two kernels share the link, each chunk completes later
+    // and the call ends with two expansions instead of one -- so the default is ONE stream.
     const int nstreams = std::max(1, std::min(c->opt.host_tangent_streams, fcamd_context::kSlots));  // (hstream[] has kSlots entries)
     for (int i = 1; i < nstreams; ++i)
         if (!c->hstream[i]) HIP_TRY(hipStreamCreateWithFlags(&c->hstream[i], hipStreamNonBlocking));
