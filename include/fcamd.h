@@ -450,7 +450,13 @@ FCAMD_API int fcamd_device_free(fcamd_context* ctx, void* ptr);
        reference's Timer("constitutive-law-evaluation") around evaluate (solver/_lawonsubmesh.py:86); default 0;
    "peer_access" (set only): value = a HIP device ordinal whose memory the context's device may access directly from
        now on (one process driving several GPUs: fcamd_allgather_direct);
-   "trim" (set only): release the staging buffers the pageable host path keeps between calls (up to ~1.1 GB);
+   "trim" (set only): release the staging buffers the pageable host path keeps between calls (up to ~1.1 GB), the expansion threads and
+       the parameter ring of the host tangent;
+   "twin_masks" (set only; a MEASUREMENT DEVICE, never a result): value = device address of one 64-bit word per 64-point tile, the plastic
+       ballots recorded from a real evaluate (the history_mask array after it); while it is non-zero, the context's VonMises3D launches of
+       the packed sparse protocol (FCAMD_EVAL_PACKED_HISTORY, n >= 64 points per CU x 64, no parent_rows) run as their SYNTHETIC TWIN --
+       the same loads and stores at the same addresses with the ballots read from the recording and no constitutive arithmetic: what the
+       memory system alone takes for the step (bench.py: roofline.mem_floor_ms).  The values such a launch writes mean nothing; 0 = off;
    "last_host_mode" (get only): FCAMD_HOST_* flags of the context's last host entry. */
 FCAMD_API int fcamd_context_set_option(fcamd_context* ctx, const char* name, long long value);
 FCAMD_API int fcamd_context_get_option(fcamd_context* ctx, const char* name, long long* value);
