@@ -295,3 +295,32 @@ def test_drucker_prager_resident_entry(ctx):
         outs.append((so, to, ctx.last_host_mode()))
     assert not (outs[0][2] & HOST_TANGENT_CPU) and (outs[1][2] & HOST_TANGENT_CPU)
     assert np.array_equal(bits(outs[0][0]), bits(outs[1][0])) and np.array_equal(bits(outs[0][1]), bits(outs[1][1]))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_sizes_chunks_threads(ctx, seed):
+    """random law, size (ragged tails, fewer chunks than ring slots, more chunks than slots), chunk size (0 = automatic with its tapered
+    tail), thread count and stream count: always bit for bit the kernel's tangent"""
+    from test_gpu_drucker_prager import make
+    from test_oracle_golden import dp_inputs
+
+    rng = np.random.default_rng(1000 + seed)
+    ctx.set_option("host_tangent_min_points", 0)
+    ctx.set_option("bounce_max", 0)
+    kind = ["linear_elasticity", "von_mises_3d", "spring_maxwell", "spring_kelvin", "comfe_linear_elasticity", "comfe_mises_plasticity",
+            "dp_classic", "dp_hyperbolic"][int(rng.integers(0, 8))]
+    n = int(rng.choice([64, 65, 127, 4096, 4097, int(rng.integers(64, 20_000)), int(rng.integers(20_000, 400_000))]))
+    chunk = int(rng.choice([0, 64, 128, 1024, 4096 + 64 * int(rng.integers(0, 64)), 65536, 131072]))
+    ctx.set_option("host_tangent_chunk", chunk)
+    ctx.set_option("host_tangent_streams", int(rng.integers(1, 4)))
+    try:
+        if kind.startswith("dp_"):
+            law, _ = make(kind == "dp_hyperbolic")
+            g, s, h = dp_inputs(n, seed)
+        else:
+            p, g, s, h = random_case(kind, n, seed=seed)
+            law = make_law(kind, p)
+        kernel, cpu = both_ways(ctx, law, 1.5, g, s, h, threads=int(rng.integers(1, 6)))
+        assert_identical(kernel, cpu, f"fuzz {seed}: {kind} n={n} chunk={chunk}")
+    finally:
+        ctx.set_option("host_tangent_streams", 1)
