@@ -597,6 +597,7 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
         ticket[(size_t)k] = pool_post(pool, start[(size_t)k], np, slot_host(k), words);
     };
     hipError_t err = hipSuccess;
+    bool counters_queued = false;
     for (int64_t k = 0; k < nchunks && st == FCAMD_OK && err == hipSuccess; ++k) {
         // whatever has completed goes to the pool first
         while (posted < k && hipEventQuery(c->tp_event[posted % nslots]) == hipSuccess) post(posted++);
@@ -612,13 +613,18 @@ int run_param_chunks(fcamd_model* m, ExpandPool* pool, int64_t n, double* tangen
         hipStream_t s = c->hstream[k % nstreams];
         st = launch(start[(size_t)k], points(k), slot_dev(k), s);
         if (st == FCAMD_OK) err = hipEventRecord(c->tp_event[k % nslots], s);
+        // one stream: the counters ride behind the last chunk (no extra round trip after the last event)
+        if (st == FCAMD_OK && err == hipSuccess && k + 1 == nchunks && nstreams == 1 && has_sparse_history(m->law)) {
+            st = enqueue_counters_download(m, s);
+            counters_queued = true;
+        }
     }
     if (st == FCAMD_OK && err == hipSuccess) {
         while (posted < nchunks && err == hipSuccess) {
             err = hipEventSynchronize(c->tp_event[posted % nslots]);
             if (err == hipSuccess) post(posted++);
         }
-        if (err == hipSuccess && has_sparse_history(m->law)) st = enqueue_counters_download(m, c->hstream[0]);  // every chunk has completed
+        if (err == hipSuccess && !counters_queued && has_sparse_history(m->law)) st = enqueue_counters_download(m, c->hstream[0]);  // every chunk has completed
     }
     if (err != hipSuccess) {
         (void)hipGetLastError();

@@ -414,6 +414,8 @@ int host_tangent_ring(fcamd_context* c, int64_t chunk, int slots, int prm) {
         c->tparams_bytes = bytes;
     }
     for (int i = 0; i < slots; ++i)
+        // (blocking sync: the calling thread sleeps in hipEventSynchronize instead of spinning next to the expansion threads; events that
+        // spin were measured: no difference at 1.3e5, 1e6, 1e7 points)
         if (!c->tp_event[i]) HIP_TRY(hipEventCreateWithFlags(&c->tp_event[i], hipEventDisableTiming | hipEventBlockingSync));
     return FCAMD_OK;
 }
