@@ -324,3 +324,22 @@ def test_fuzz_sizes_chunks_threads(ctx, seed):
         assert_identical(kernel, cpu, f"fuzz {seed}: {kind} n={n} chunk={chunk}")
     finally:
         ctx.set_option("host_tangent_streams", 1)
+
+
+def test_nonconvergence_is_reported_and_leaves_no_work_behind(ctx):
+    """A Newton iteration that does not converge (reference: RuntimeError inside evaluate, mises_plasticity_isotropic_hardening.py:141-143)
+    on the pipelined path: the error surfaces after the last chunk, the pool is idle again, and the next call works."""
+    from test_oracle_c import NONCONVERGING, nonconverging_inputs
+
+    ctx.set_option("host_tangent_min_points", 0)
+    ctx.set_option("host_tangent_threads", 3)
+    ctx.set_option("host_tangent_chunk", 8192)
+    n = 70_017
+    bad = fc.VonMises3D(NONCONVERGING)
+    g, s, t, h = nonconverging_inputs(n)
+    with pytest.raises(RuntimeError, match="did not converge"):
+        bad.evaluate(0, 1.0, g, s, t, h)
+    assert ctx.last_host_mode() & HOST_TANGENT_CPU
+    p, g, s, h = random_case("von_mises_3d", n, seed=2)
+    kernel, cpu = both_ways(ctx, make_law("von_mises_3d", p), 1.0, g, s, h)
+    assert_identical(kernel, cpu, "after a failed call")
