@@ -343,3 +343,39 @@ def test_nonconvergence_is_reported_and_leaves_no_work_behind(ctx):
     p, g, s, h = random_case("von_mises_3d", n, seed=2)
     kernel, cpu = both_ways(ctx, make_law("von_mises_3d", p), 1.0, g, s, h)
     assert_identical(kernel, cpu, "after a failed call")
+
+
+@pytest.mark.parametrize("kind", ["von_mises_3d", "comfe_mises_plasticity", "linear_elasticity"])
+def test_non_finite_points(ctx, kind):
+    """NaN / Inf / huge inputs at a few points (tests/test_gpu_special_values.py's poison): the other points' rows are bit for bit the
+    kernel's, the poisoned points' rows are non-finite where the kernel's are (the bit pattern of a NaN is the arithmetic unit's: the
+    host's SSE unit and the GPU propagate payloads differently) and bit-identical where finite."""
+    from test_gpu_special_values import POISON
+
+    ctx.set_option("host_tangent_min_points", 0)
+    ctx.set_option("bounce_max", 0)
+    ctx.set_option("host_tangent_chunk", 4096)
+    n = 30_011
+    p, g, s, h = random_case(kind, n, seed=19)
+    bad = np.array([3, 64, 130, 4191, 8200, 20_301, n - 1])
+    for pt, v in zip(bad, POISON):
+        g.reshape(-1, 9)[pt, pt % 9] = v
+    s.reshape(-1, 6)[bad[0], 2] = float("nan")
+    outs = []
+    for th in (0, 3):
+        ctx.set_option("host_tangent_threads", th)
+        s1, t1 = s.copy(), np.full(36 * n, -1.0)
+        h1 = None if h is None else {k: v.copy() for k, v in h.items()}
+        try:
+            make_law(kind, p).evaluate(0.0, 0.7, g, s1, t1, h1)
+        except RuntimeError:  # non-convergence at a poisoned point is allowed to raise -- after the whole call has been written
+            pass
+        outs.append((s1, t1, ctx.last_host_mode()))
+    (s0, t0, m0), (s1, t1, m1) = outs
+    assert not (m0 & HOST_TANGENT_CPU) and (m1 & HOST_TANGENT_CPU)
+    ok = np.setdiff1d(np.arange(n), bad)
+    assert np.array_equal(bits(t0.reshape(-1, 36)[ok]), bits(t1.reshape(-1, 36)[ok])), "clean points differ"
+    assert np.array_equal(np.isnan(t0), np.isnan(t1)) and np.array_equal(np.isinf(t0), np.isinf(t1))
+    fin = np.isfinite(t0)
+    assert np.array_equal(bits(t0[fin]), bits(t1[fin]))
+    assert np.array_equal(bits(s0.reshape(-1, 6)[ok]), bits(s1.reshape(-1, 6)[ok]))
